@@ -1,0 +1,164 @@
+"""Deterministic synthetic inputs and weights for the M3P pre-training hot path.
+
+Shapes / dtypes / normalisation follow the reference's data contract:
+  * ``x``        (T, B) int64 token ids, BOS=0 first, EOS=2 last valid, PAD=1 after
+                 (reference collate ``batch_sentences_v2``, M3P/src/xtrainer.py:855-880)
+  * ``x_img``    (R, B, 2048) fp32 region features, L2-normalised per region
+                 (M3P/src/data/dataset_pretrain.py:326,379)
+  * ``image_loc``(R, B, 5) fp32 box geometry, L2-normalised (dataset_pretrain.py:294-301)
+  * MLM labels   (T, B) int64, -1 = not predicted (xtrainer.py:2226-2232)
+
+Everything is drawn from ``numpy.random.RandomState`` streams, which are frozen
+across NumPy versions, so fixtures generated in one container reproduce in another.
+Used by the golden-vector generator, the tests and ``bench.py``.
+"""
+from collections import OrderedDict
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+N_MAX_POSITIONS = 514  # M3P/src/model/transformer.py:16
+
+BOS, PAD, EOS = 0, 1, 2
+
+
+def model_params(emb_dim, n_heads, n_layers, n_words, dropout=0.0, attention_dropout=0.0,
+                 refine_layers=0, **extra):
+    """The flat ``params`` Namespace fields the TransformerModel ctor reads
+    (M3P/src/model/transformer.py:627-679, 725-729; PredLayer :88-102)."""
+    p = SimpleNamespace(
+        n_langs=1, n_words=n_words, eos_index=EOS, pad_index=PAD, mask_index=n_words - 1,
+        id2lang={0: 'en'}, lang2id={'en': 0},
+        emb_dim=emb_dim, n_heads=n_heads, n_layers=n_layers, n_dec_layers=-1,
+        dropout=dropout, attention_dropout=attention_dropout,
+        sinusoidal_embeddings=False, refine_layers=refine_layers,
+        attention_setting='v1', use_externel_att=False, gelu_activation=True,
+        asm=False, share_inout_emb=True,
+    )
+    for k, v in extra.items():
+        setattr(p, k, v)
+    return p
+
+
+CONFIGS = {
+    # BASELINE.json configs[0]: the reference's CPU-runnable case
+    'cfg1': dict(emb_dim=128, n_heads=4, n_layers=2, n_words=1000, T=64, R=10, B=8, n_pred=9),
+    # BASELINE.json configs[1]: M3P-base on one MI355X
+    'cfg2': dict(emb_dim=768, n_heads=12, n_layers=12, n_words=250002, T=128, R=36, B=256, n_pred=19),
+    # configs[3]: M3P-large
+    'cfg4': dict(emb_dim=1024, n_heads=16, n_layers=24, n_words=250002, T=256, R=100, B=64, n_pred=38),
+    # configs[4]: ITM fine-tune shape
+    'cfg5': dict(emb_dim=768, n_heads=12, n_layers=12, n_words=250002, T=80, R=36, B=96, n_pred=0),
+}
+
+
+def hot_param_shapes(p):
+    """(name, shape) of every parameter the pre-training step touches, in the
+    reference's state-dict naming.  ``pred_layer.proj.weight`` is tied to
+    ``embeddings.weight`` (transformer.py:728-729) and therefore not listed twice."""
+    d, V, L = p.emb_dim, p.n_words, p.n_layers
+    out = OrderedDict()
+    out['position_embeddings.weight'] = (N_MAX_POSITIONS, d)
+    out['embeddings.weight'] = (V, d)
+    out['layer_norm_emb.weight'] = (d,)
+    out['layer_norm_emb.bias'] = (d,)
+    out['image_embeddings.image_embeddings.weight'] = (d, 2048)
+    out['image_embeddings.image_embeddings.bias'] = (d,)
+    out['image_embeddings.image_location_embeddings.weight'] = (d, 5)
+    out['image_embeddings.image_location_embeddings.bias'] = (d,)
+    out['image_embeddings.LayerNorm.weight'] = (d,)
+    out['image_embeddings.LayerNorm.bias'] = (d,)
+    for i in range(L):
+        for lin in ('q_lin', 'k_lin', 'v_lin', 'out_lin'):
+            out['attentions.%d.%s.weight' % (i, lin)] = (d, d)
+            out['attentions.%d.%s.bias' % (i, lin)] = (d,)
+        out['layer_norm1.%d.weight' % i] = (d,)
+        out['layer_norm1.%d.bias' % i] = (d,)
+        out['ffns.%d.lin1.weight' % i] = (4 * d, d)
+        out['ffns.%d.lin1.bias' % i] = (4 * d,)
+        out['ffns.%d.lin2.weight' % i] = (d, 4 * d)
+        out['ffns.%d.lin2.bias' % i] = (d,)
+        out['layer_norm2.%d.weight' % i] = (d,)
+        out['layer_norm2.%d.bias' % i] = (d,)
+    out['pooled_layer.dense.weight'] = (d, d)
+    out['pooled_layer.dense.bias'] = (d,)
+    out['seq_relationship.weight'] = (1, d)
+    out['seq_relationship.bias'] = (1,)
+    out['pred_layer.proj.bias'] = (V,)
+    return out
+
+
+def golden_weight(name, shape, rs, scale=0.02):
+    """One tensor of the golden weight stream: N(0,1)*scale, LayerNorm gains 1+that
+    (SURVEY §8c 'Golden inputs')."""
+    w = rs.standard_normal(shape).astype(np.float32) * np.float32(scale)
+    is_ln = ('layer_norm' in name or 'LayerNorm' in name)
+    if is_ln and name.endswith('weight'):
+        w = w + np.float32(1.0)
+    return w
+
+
+def golden_state_dict(names_shapes, seed=1234, scale=0.02, pad_index=PAD):
+    """Deterministic weights for every (name, shape) in *sorted key order*; the
+    embedding pad row is zeroed like the reference's init (transformer.py:21-26)."""
+    rs = np.random.RandomState(seed)
+    sd = OrderedDict()
+    for name in sorted(names_shapes):
+        w = golden_weight(name, tuple(names_shapes[name]), rs, scale)
+        if name == 'embeddings.weight' and pad_index is not None:
+            w[pad_index] = 0
+        sd[name] = torch.from_numpy(w)
+    return sd
+
+
+def make_batch(T, R, B, n_words, n_pred, seed=5678, ragged=True, sample_n=2):
+    """Synthetic pre-training batch.
+
+    Returns a dict of CPU tensors:
+      x (T,B) int64 [already masked with <mask>=V-1 at the predicted positions],
+      lengths (B,), x_labels (T,B) int64 (-1 = not predicted, else original id),
+      pred_mask (T,B) bool, y (n_pred*B,) int64 in (s,b) row order,
+      x_img (R,B,2048) fp32, image_loc (R,B,5) fp32, lengths_img (B,),
+      pos_labels (B/sample_n,) int64, itm_targets (B,) fp32 one-hot flattened.
+    """
+    rs = np.random.RandomState(seed)
+    mask_index = n_words - 1
+    if ragged:
+        lengths = rs.randint(T // 2, T + 1, size=B).astype(np.int64)
+        lengths[0] = T  # one full-length row so slen == T
+    else:
+        lengths = np.full(B, T, dtype=np.int64)
+    x = np.full((T, B), PAD, dtype=np.int64)
+    labels = np.full((T, B), -1, dtype=np.int64)
+    for b in range(B):
+        n = int(lengths[b])
+        x[0, b] = BOS
+        x[1:n - 1, b] = rs.randint(4, n_words - 1, size=n - 2)  # ids in [4, V-2]
+        x[n - 1, b] = EOS
+        if n_pred > 0:
+            k = min(n_pred, n - 2)
+            pos = 1 + rs.permutation(n - 2)[:k]  # uniform in [1, len-2]
+            labels[pos, b] = x[pos, b]
+            x[pos, b] = mask_index
+    pred_mask = labels != -1
+    y = labels[pred_mask]  # boolean gather on (T,B) -> (s,b) row order (transformer.py:1208)
+
+    feat = rs.standard_normal((R, B, 2048)).astype(np.float32)
+    feat /= np.linalg.norm(feat, axis=-1, keepdims=True)
+    loc = rs.uniform(0.0, 1.0, size=(R, B, 5)).astype(np.float32)
+    loc /= np.linalg.norm(loc, axis=-1, keepdims=True)
+    lengths_img = np.full(B, R, dtype=np.int64)
+
+    n_groups = max(B // sample_n, 1)
+    pos_labels = (np.arange(n_groups) % sample_n).astype(np.int64)
+    itm = np.eye(sample_n, dtype=np.float32)[pos_labels].reshape(-1)[:B]
+
+    return dict(
+        x=torch.from_numpy(x), lengths=torch.from_numpy(lengths),
+        x_labels=torch.from_numpy(labels), pred_mask=torch.from_numpy(pred_mask),
+        y=torch.from_numpy(y),
+        x_img=torch.from_numpy(feat), image_loc=torch.from_numpy(loc),
+        lengths_img=torch.from_numpy(lengths_img),
+        pos_labels=torch.from_numpy(pos_labels), itm_targets=torch.from_numpy(itm),
+    )

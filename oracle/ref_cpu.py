@@ -1,0 +1,296 @@
+"""ORACLE — test infrastructure only.  NOT part of the product path.
+
+A plain PyTorch (CPU, fp32 or fp64) restatement of the algorithm on M3P's
+pre-training hot path, written from the reference's behaviour; every function cites the
+reference file:line it follows (paths relative to /root/reference).  It is the checker
+for the HIP path: only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
+``cpu_baseline`` leg may import it.  Nothing under ``m3p_amd/`` imports it.
+
+Pinning: ``tests/test_oracle_golden.py`` checks every function here against golden
+vectors produced by importing the reference itself in the development container
+(``oracle/gen_goldens.py`` -> ``tests/golden/*.npz``).  The reference ships no tests or
+known-answer vectors of its own, so those generated vectors are the pin.
+
+Functional style: parameters come in as a ``dict`` keyed by the reference's state-dict
+names, so the same dict can be loaded into the reference model, this oracle and the
+HIP model.  Dropout is expressed through optional *keep masks* (already scaled or
+not, see ``_drop``) so a test can feed the exact masks the HIP kernels generate.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+LN_EPS = 1e-12  # nn.LayerNorm(dim, eps=1e-12): M3P/src/model/transformer.py:244,660,694,709
+
+
+# ----------------------------------------------------------------------------
+# elementary pieces
+# ----------------------------------------------------------------------------
+
+def gelu_erf(x):
+    """M3P/src/model/transformer.py:48-56 — exact (erf) GELU."""
+    return 0.5 * x * (1.0 + torch.erf(x / math.sqrt(2.0)))
+
+
+def layer_norm(x, w, b, eps=LN_EPS):
+    """nn.LayerNorm over the last dim, biased variance (transformer.py:694,709)."""
+    mu = x.mean(-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(-1, keepdim=True)
+    return (x - mu) / torch.sqrt(var + eps) * w + b
+
+
+def _drop(x, keep, p):
+    """F.dropout with an explicit keep mask: y = x * keep / (1 - p).
+    ``keep`` None or p == 0 -> identity (eval mode / parity runs)."""
+    if keep is None or p == 0:
+        return x
+    return x * keep.to(x.dtype) / (1.0 - p)
+
+
+def get_masks(slen, lengths):
+    """transformer.py:59-78, non-causal branch: mask[b, s] = s < lengths[b];
+    the attention mask is the same (bs, slen) tensor."""
+    assert int(lengths.max()) <= slen
+    alen = torch.arange(slen, dtype=torch.long)
+    mask = alen[None, :] < lengths[:, None]
+    return mask, mask
+
+
+def multi_head_attention(x, mask, wq, bq, wk, bk, wv, bv, wo, bo, n_heads,
+                         p_attn=0.0, keep_attn=None, return_ctx=False):
+    """transformer.py:149-210, self-attention branch (kv=None, cache=None).
+
+    x (bs, S, d); mask (bs, S) bool, True = valid key.  q is scaled by 1/sqrt(d_h)
+    *after* the bias (:197); padded keys get -inf (:199-200); softmax in fp32 (:202);
+    dropout on the probabilities (:203); context = P @ v (:204); out_lin (:208)."""
+    bs, S, d = x.shape
+    dh = d // n_heads
+
+    def shape(t):
+        return t.view(bs, S, n_heads, dh).transpose(1, 2)
+
+    q = shape(F.linear(x, wq, bq)) / math.sqrt(dh)
+    k = shape(F.linear(x, wk, bk))
+    v = shape(F.linear(x, wv, bv))
+    scores = torch.matmul(q, k.transpose(2, 3))
+    scores = scores.masked_fill(~mask[:, None, None, :], float('-inf'))
+    w = torch.softmax(scores.float(), dim=-1).to(scores.dtype)
+    w = _drop(w, keep_attn, p_attn)
+    ctx = torch.matmul(w, v).transpose(1, 2).contiguous().view(bs, S, d)
+    out = F.linear(ctx, wo, bo)
+    if return_ctx:
+        return out, ctx
+    return out
+
+
+def transformer_ffn(x, w1, b1, w2, b2, p=0.0, keep=None):
+    """transformer.py:222-227: lin2(gelu(lin1(x))) then dropout."""
+    return _drop(F.linear(gelu_erf(F.linear(x, w1, b1)), w2, b2), keep, p)
+
+
+def image_embeddings(sd, x_img, loc, p=0.0, keep=None, prefix='image_embeddings.'):
+    """BertImageEmbeddings.forward, transformer.py:247-269 with input_dist=None (the
+    only way jointfwd calls it, :901): LN(W_img x + b + W_loc loc + b) then dropout."""
+    e = F.linear(x_img, sd[prefix + 'image_embeddings.weight'], sd[prefix + 'image_embeddings.bias'])
+    e = e + F.linear(loc, sd[prefix + 'image_location_embeddings.weight'],
+                     sd[prefix + 'image_location_embeddings.bias'])
+    e = layer_norm(e, sd[prefix + 'LayerNorm.weight'], sd[prefix + 'LayerNorm.bias'])
+    return _drop(e, keep, p)
+
+
+# ----------------------------------------------------------------------------
+# the encoder: TransformerModel.jointfwd
+# ----------------------------------------------------------------------------
+
+def jointfwd(sd, n_layers, n_heads, x, lengths, x_img, lengths_img, image_loc,
+             dropout=0.0, attention_dropout=0.0, keeps=None, text_embed=None):
+    """TransformerModel.jointfwd, transformer.py:878-968 (refine_image=False).
+
+    x (T, B) int64; x_img (R, B, 2048); image_loc (R, B, 5) -> (S=R+T, B, d).
+    Order of operations reproduced exactly:
+      img = image_embeddings(...)                                     (:901)
+      tok = Emb[x] (pad row is zero by construction)                  (:913)
+      h = cat([img, tok], dim=1); h += Pos[0..S-1]                    (:929-936)
+      h *= mask (valid prefix of length len_img+len_txt, :917-919)    (:940)
+      h = LN_emb(h); dropout                                          (:942-943)
+      per layer: h = LN1(h + drop(attn(h))); h = LN2(h + ffn(h)); h *= mask   (:947-958)
+    ``keeps``: optional dict of keep masks {'img','emb', ('attn_p', i), ('attn_out', i), ('ffn', i)}.
+    """
+    keeps = keeps or {}
+    T, B = x.shape
+    xt = x.t()
+    img = image_embeddings(sd, x_img.transpose(0, 1), image_loc.transpose(0, 1),
+                           p=dropout, keep=keeps.get('img'))
+    R = img.shape[1]
+    tok = text_embed if text_embed is not None else F.embedding(xt, sd['embeddings.weight'])
+    S = R + T
+    mask, attn_mask = get_masks(S, lengths_img + lengths)
+    h = torch.cat([img, tok], dim=1)
+    h = h + sd['position_embeddings.weight'][:S][None]
+    h = h * mask[..., None].to(h.dtype)
+    h = layer_norm(h, sd['layer_norm_emb.weight'], sd['layer_norm_emb.bias'])
+    h = _drop(h, keeps.get('emb'), dropout)
+    for i in range(n_layers):
+        a = 'attentions.%d.' % i
+        attn = multi_head_attention(
+            h, attn_mask,
+            sd[a + 'q_lin.weight'], sd[a + 'q_lin.bias'], sd[a + 'k_lin.weight'], sd[a + 'k_lin.bias'],
+            sd[a + 'v_lin.weight'], sd[a + 'v_lin.bias'], sd[a + 'out_lin.weight'], sd[a + 'out_lin.bias'],
+            n_heads, p_attn=attention_dropout, keep_attn=keeps.get(('attn_p', i)))
+        attn = _drop(attn, keeps.get(('attn_out', i)), dropout)
+        h = layer_norm(h + attn, sd['layer_norm1.%d.weight' % i], sd['layer_norm1.%d.bias' % i])
+        f = 'ffns.%d.' % i
+        h = h + transformer_ffn(h, sd[f + 'lin1.weight'], sd[f + 'lin1.bias'],
+                                sd[f + 'lin2.weight'], sd[f + 'lin2.bias'],
+                                p=dropout, keep=keeps.get(('ffn', i)))
+        h = layer_norm(h, sd['layer_norm2.%d.weight' % i], sd['layer_norm2.%d.bias' % i])
+        h = h * mask[..., None].to(h.dtype)
+    return h.transpose(0, 1)
+
+
+# ----------------------------------------------------------------------------
+# heads: TransformerModel.predict
+# ----------------------------------------------------------------------------
+
+def predict_mlm(sd, tensor, pred_mask, y, pad_index=1):
+    """predict (default branch) + PredLayer.forward: transformer.py:1208-1212, 104-117.
+    tensor (T, B, d) sequence-major text part; pred_mask (T, B) bool; boolean gather
+    gives rows in (s, b) order; scores = rows @ Emb^T + b_V (tied weight, :728-729);
+    loss = mean cross-entropy.  Returns (scores, loss)."""
+    assert int((y == pad_index).sum()) == 0
+    d = tensor.shape[-1]
+    rows = tensor[pred_mask.unsqueeze(-1).expand_as(tensor)].view(-1, d)
+    scores = F.linear(rows, sd['embeddings.weight'], sd['pred_layer.proj.bias'])
+    loss = F.cross_entropy(scores.float(), y, reduction='mean')
+    return scores, loss
+
+
+def predict_relation(sd, tensor):
+    """predict(is_relation=True): transformer.py:1194-1197 + BertPooler :546-558.
+    tensor (B, S, d) batch-major; pools position 0 (image region 0) -> (B, 1)."""
+    pooled = torch.tanh(F.linear(tensor[:, 0], sd['pooled_layer.dense.weight'], sd['pooled_layer.dense.bias']))
+    return F.linear(pooled, sd['seq_relationship.weight'], sd['seq_relationship.bias'])
+
+
+def itm_loss(relation_scores, pos_labels, sample_n, multi_w, bin_w):
+    """XTrainer.pretrain_under_step ITM loss, M3P/src/xtrainer.py:2357-2372:
+    CE over groups of sample_n scores + BCE-with-logits against the one-hot of the
+    positive index, weighted by multi_cls_loss_weight / bin_cls_loss_weight."""
+    onehot = torch.eye(sample_n, dtype=torch.float32)[pos_labels].reshape(-1)
+    ce = F.cross_entropy(relation_scores.view(-1, sample_n).float(), pos_labels)
+    bce = F.binary_cross_entropy_with_logits(relation_scores.view(-1).float(), onehot)
+    return multi_w * ce + bin_w * bce
+
+
+def pretrain_losses(sd, n_layers, n_heads, batch, R, sample_n=2, multi_w=0.0, bin_w=1.0,
+                    with_itm=True, dropout=0.0, attention_dropout=0.0, keeps=None):
+    """The loss half of XTrainer.pretrain_under_step (xtrainer.py:2281-2375) for the
+    MLM (+ITM) objective: jointfwd -> text slice out[R:] -> MLM CE; whole sequence,
+    batch-major -> relation scores -> ITM loss; total = mlm + rel (lambdas = 1)."""
+    out = jointfwd(sd, n_layers, n_heads, batch['x'], batch['lengths'], batch['x_img'],
+                   batch['lengths_img'], batch['image_loc'], dropout, attention_dropout, keeps)
+    res = {'out': out}
+    total = 0
+    if batch['pred_mask'].any():
+        _, mlm = predict_mlm(sd, out[R:], batch['pred_mask'], batch['y'])
+        res['mlm'] = mlm
+        total = total + mlm
+    if with_itm:
+        rel = predict_relation(sd, out.transpose(0, 1))
+        itm = itm_loss(rel, batch['pos_labels'], sample_n, multi_w, bin_w)
+        res['rel_scores'] = rel
+        res['itm'] = itm
+        total = total + itm
+    res['total'] = total
+    return res
+
+
+# ----------------------------------------------------------------------------
+# optimizer: Adam / AdamInverseSqrtWithWarmup / clip
+# ----------------------------------------------------------------------------
+
+def inverse_sqrt_lr(num_updates, lr=1e-4, warmup_updates=4000, warmup_init_lr=1e-7, exp_factor=0.5):
+    """AdamInverseSqrtWithWarmup.get_lr_for_step, M3P/src/optim.py:129-133."""
+    if num_updates < warmup_updates:
+        return warmup_init_lr + num_updates * (lr - warmup_init_lr) / warmup_updates
+    return lr * warmup_updates ** exp_factor * num_updates ** -exp_factor
+
+
+def clip_grad_norm(grads, max_norm):
+    """torch.nn.utils.clip_grad_norm_ as called at xtrainer.py:225: global L2 norm
+    over all grads, coef = max_norm / (norm + 1e-6) clamped to 1."""
+    total = torch.sqrt(sum((g.double() ** 2).sum() for g in grads)).float()
+    coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+    return [g * coef for g in grads], total
+
+
+def adam_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.98, eps=1e-8, weight_decay=0.0):
+    """Adam.step, M3P/src/optim.py:45-86 (no amsgrad; eps added to sqrt(v) *before*
+    bias correction is folded into the step size; decoupled decay p -= wd*lr*p):
+        m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2
+        p -= lr * sqrt(1-b2^t)/(1-b1^t) * m / (sqrt(v) + eps)
+    ``step`` is the 1-based update count.  Returns new (p, m, v)."""
+    m = m * beta1 + (1 - beta1) * g
+    v = v * beta2 + (1 - beta2) * g * g
+    denom = v.sqrt() + eps
+    step_size = lr * math.sqrt(1 - beta2 ** step) / (1 - beta1 ** step)
+    if weight_decay != 0:
+        p = p - weight_decay * lr * p
+    p = p - step_size * m / denom
+    return p, m, v
+
+
+class AdamInvSqrt:
+    """Stateful wrapper restating AdamInverseSqrtWithWarmup (optim.py:89-139): the
+    optimizer is *constructed* with lr = warmup_init_lr (:103-109), each step uses the
+    current lr and then sets lr for the next one (:135-139)."""
+
+    def __init__(self, params, lr=1e-4, beta1=0.9, beta2=0.98, eps=1e-8, weight_decay=0.0,
+                 warmup_updates=4000, warmup_init_lr=1e-7):
+        self.p = [t.clone() for t in params]
+        self.m = [torch.zeros_like(t) for t in params]
+        self.v = [torch.zeros_like(t) for t in params]
+        self.cfg = dict(lr=lr, warmup_updates=warmup_updates, warmup_init_lr=warmup_init_lr)
+        self.b1, self.b2, self.eps, self.wd = beta1, beta2, eps, weight_decay
+        self.num_updates = 0
+        self.lr = warmup_init_lr
+        self.steps = [0] * len(params)
+
+    def step(self, grads):
+        for i, g in enumerate(grads):
+            if g is None:  # optim.py:55-56: params without grad are skipped (no step count)
+                continue
+            self.steps[i] += 1
+            self.p[i], self.m[i], self.v[i] = adam_step(
+                self.p[i], g, self.m[i], self.v[i], self.steps[i], self.lr,
+                self.b1, self.b2, self.eps, self.wd)
+        self.num_updates += 1
+        self.lr = inverse_sqrt_lr(self.num_updates, **self.cfg)
+
+
+def train_step(sd, names, opt, n_layers, n_heads, batch, R, clip=5.0, **loss_kw):
+    """One full reference training step (Trainer.optimize amp==-1 path,
+    xtrainer.py:218-228): zero_grad -> backward -> clip_grad_norm_ -> step.
+    ``sd`` is rebuilt from ``opt.p`` each call.  Returns (losses dict, grads, grad_norm)."""
+    leaves = {n: t.detach().clone().requires_grad_(True) for n, t in zip(names, opt.p)}
+    res = pretrain_losses(leaves, n_layers, n_heads, batch, R, **loss_kw)
+    grads = torch.autograd.grad(res['total'], [leaves[n] for n in names], allow_unused=True)
+    live = [g for g in grads if g is not None]
+    clipped, norm = clip_grad_norm(live, clip) if clip > 0 else (live, None)
+    it = iter(clipped)
+    grads_c = [None if g is None else next(it) for g in grads]
+    opt.step(grads_c)
+    return res, grads, norm
+
+
+# ----------------------------------------------------------------------------
+# retrieval metric (M3P/src/evaluation/xevaluator.py:1621-1657)
+# ----------------------------------------------------------------------------
+
+def recall_at_k(score_matrix, gt_index, ks=(1, 5, 10)):
+    """Recall@K of a (n_query, n_candidates) score matrix: a query counts as a hit at K
+    if its ground-truth candidate is among the K highest scores."""
+    order = torch.argsort(score_matrix, dim=1, descending=True)
+    rank = (order == gt_index[:, None]).float().argmax(dim=1)
+    return {k: float((rank < k).float().mean()) for k in ks}

@@ -1,0 +1,164 @@
+"""Pin the oracle (oracle/ref_cpu.py) to golden vectors recorded from the reference
+itself (oracle/gen_goldens.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from m3p_amd import synth
+from oracle import ref_cpu as O
+
+
+def _load(golden_dir, name):
+    return dict(np.load(os.path.join(golden_dir, name)))
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def rel_l2(a, b):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+@pytest.fixture(scope='module')
+def units(golden_dir):
+    return _load(golden_dir, 'units.npz')
+
+
+@pytest.fixture(scope='module')
+def cfg1(golden_dir):
+    return _load(golden_dir, 'cfg1_model.npz')
+
+
+def test_gelu(units):
+    assert rel_l2(O.gelu_erf(_t(units['gelu_x'])), units['gelu_y']) < 1e-7
+
+
+def test_get_masks(units):
+    mask, am = O.get_masks(9, _t(units['masks_len']))
+    assert np.array_equal(mask.numpy(), units['masks_mask'])
+    assert am is mask
+
+
+def test_mha(units):
+    sd = {k[len('mha_sd/'):]: _t(v) for k, v in units.items() if k.startswith('mha_sd/')}
+    y = O.multi_head_attention(_t(units['mha_x']), _t(units['mha_mask']),
+                               sd['q_lin.weight'], sd['q_lin.bias'], sd['k_lin.weight'], sd['k_lin.bias'],
+                               sd['v_lin.weight'], sd['v_lin.bias'], sd['out_lin.weight'], sd['out_lin.bias'], 2)
+    assert rel_l2(y, units['mha_y']) < 1e-6
+
+
+def test_ffn(units):
+    sd = {k[len('ffn_sd/'):]: _t(v) for k, v in units.items() if k.startswith('ffn_sd/')}
+    y = O.transformer_ffn(_t(units['mha_x']), sd['lin1.weight'], sd['lin1.bias'], sd['lin2.weight'], sd['lin2.bias'])
+    assert rel_l2(y, units['ffn_y']) < 1e-6
+
+
+def test_image_embeddings(units):
+    sd = {'image_embeddings.' + k[len('ie_sd/'):]: _t(v) for k, v in units.items() if k.startswith('ie_sd/')}
+    y = O.image_embeddings(sd, _t(units['ie_feats']), _t(units['ie_loc']))
+    assert rel_l2(y, units['ie_y']) < 1e-6
+
+
+def test_adam_plain(units):
+    p = _t(units['adam_p0']).clone()
+    m = torch.zeros_like(p)
+    v = torch.zeros_like(p)
+    for i in range(3):
+        p, m, v = O.adam_step(p, _t(units['adam_grads'][i]), m, v, i + 1, 1e-2, 0.9, 0.98, 1e-8, 0.01)
+        assert rel_l2(p, units['adam_p%d' % (i + 1)]) < 1e-6
+
+
+def test_inverse_sqrt_lr(cfg1):
+    lrs = [O.inverse_sqrt_lr(n) for n in range(4)]
+    assert np.allclose(lrs, cfg1['lrs'], rtol=1e-12, atol=0)
+    # after warm-up: lr * sqrt(4000) / sqrt(n)   (optim.py:133)
+    assert abs(O.inverse_sqrt_lr(16000) - 1e-4 * 0.5) < 1e-12
+
+
+def _cfg1_setup():
+    cfg = synth.CONFIGS['cfg1']
+    P = synth.model_params(cfg['emb_dim'], cfg['n_heads'], cfg['n_layers'], cfg['n_words'])
+    shapes = synth.hot_param_shapes(P)
+    sd = synth.golden_state_dict(shapes)
+    batch = synth.make_batch(cfg['T'], cfg['R'], cfg['B'], cfg['n_words'], cfg['n_pred'])
+    return cfg, P, sd, batch
+
+
+def test_cfg1_forward_and_losses(cfg1):
+    cfg, P, sd, batch = _cfg1_setup()
+    res = O.pretrain_losses(sd, cfg['n_layers'], cfg['n_heads'], batch, cfg['R'])
+    assert res['out'].shape == (cfg['R'] + cfg['T'], cfg['B'], cfg['emb_dim'])
+    assert rel_l2(res['out'], cfg1['out']) < 1e-5
+    assert abs(float(res['mlm']) - float(cfg1['mlm_loss'])) < 1e-5
+    assert abs(float(res['itm']) - float(cfg1['itm_bce'])) < 1e-6
+    assert rel_l2(res['rel_scores'], cfg1['rel_scores']) < 1e-5
+    scores, _ = O.predict_mlm(sd, res['out'][cfg['R']:], batch['pred_mask'], batch['y'])
+    assert rel_l2(scores[:8], cfg1['mlm_scores_rows8']) < 1e-5
+    ce = O.itm_loss(res['rel_scores'], batch['pos_labels'], 2, 1.0, 0.0)
+    assert abs(float(ce) - float(cfg1['itm_ce'])) < 1e-6
+
+
+def test_cfg1_gradients_and_adam(cfg1):
+    cfg, P, sd, batch = _cfg1_setup()
+    names = list(sd.keys())
+    opt = O.AdamInvSqrt([sd[n] for n in names])
+    for step in range(3):
+        res, grads, norm = O.train_step(sd, names, opt, cfg['n_layers'], cfg['n_heads'], batch, cfg['R'], clip=5.0)
+        assert abs(float(res['total'].detach()) - float(cfg1['total_loss_step%d' % step])) < 2e-5
+        assert abs(float(norm) - float(cfg1['gradnorm_total_step%d' % step])) < 1e-4 * float(norm)
+        if step == 0:
+            g = dict(zip(names, grads))
+            qb = float(cfg1['gradnorm/attentions.0.q_lin.bias'])
+            for n in names:
+                ref = float(cfg1['gradnorm/' + n])
+                if '.k_lin.bias' in n:  # true gradient is 0: rounding noise only
+                    assert float(g[n].norm()) < 1e-3 * qb
+                    continue
+                assert abs(float(g[n].norm()) - ref) < 1e-4 * ref + 1e-9, n
+            for k in cfg1:
+                if k.startswith('grad/') and not k.endswith('[rows]'):
+                    n = k[len('grad/'):]
+                    if '.k_lin.bias' in n:
+                        continue
+                    assert rel_l2(g[n], cfg1[k]) < 1e-4, n
+            rows = _t(cfg1['grad_emb_rows_idx'])
+            assert rel_l2(g['embeddings.weight'][rows], cfg1['grad/embeddings.weight[rows]']) < 1e-4
+        if step in (0, 2):
+            cur = dict(zip(names, opt.p))
+            for n in names:
+                ref = float(cfg1['param_norm_after%d/%s' % (step + 1, n)])
+                assert abs(float(cur[n].norm()) - ref) < 1e-6 * ref + 1e-9, n
+            for k in cfg1:
+                if k.startswith('param_after%d/' % (step + 1)):
+                    n = k.split('/', 1)[1]
+                    assert rel_l2(cur[n], cfg1[k]) < 1e-6, n
+        assert abs(opt.lr - float(cfg1['lrs'][step + 1])) < 1e-15
+
+
+def test_trainer_step_goldens(golden_dir):
+    """The oracle's train_step reproduces what XTrainer.pretrain_under_step logged."""
+    tg = _load(golden_dir, 'cfg1_trainer.npz')
+    cfg, P, sd, batch = _cfg1_setup()
+    names = list(sd.keys())
+    opt = O.AdamInvSqrt([sd[n] for n in names])
+    for step in range(2):
+        res, grads, norm = O.train_step(sd, names, opt, cfg['n_layers'], cfg['n_heads'], batch, cfg['R'], clip=5.0)
+        assert abs(float(res['mlm']) - float(tg['cmlm_step%d' % step])) < 2e-5
+        assert abs(float(res['itm']) - float(tg['t2i_step%d' % step])) < 2e-6
+        assert abs(opt.lr - float(tg['lr_after%d' % step])) < 1e-15
+        cur = dict(zip(names, opt.p))
+        for n in names:
+            ref = float(tg['param_norm_after%d/%s' % (step + 1, n)])
+            assert abs(float(cur[n].norm()) - ref) < 1e-6 * ref + 1e-9, n
+    assert int(tg['processed_s']) == 2 * cfg['B']
+    assert int(tg['processed_w']) == 2 * int(batch['lengths'].sum())
+
+
+def test_recall_at_k():
+    s = torch.tensor([[0.1, 0.9, 0.3], [0.8, 0.1, 0.2], [0.2, 0.3, 0.1]])
+    r = O.recall_at_k(s, torch.tensor([1, 2, 0]), ks=(1, 2))
+    assert abs(r[1] - 1 / 3) < 1e-6 and abs(r[2] - 1.0) < 1e-6
