@@ -1,0 +1,119 @@
+/*
+ * m3p_hip.h — C ABI of libm3p_hip.so: the MI355X (gfx950) kernels behind M3P's
+ * pre-training hot path (TransformerModel.jointfwd / predict, Adam, clip).
+ *
+ * The reference (microsoft/M3P) has no native code: every entry point below replaces
+ * a chain of ATen ops launched from Python at the cited reference file:line
+ * (paths relative to the reference checkout).  INTEGRATION.md shows the ctypes binding
+ * a reference maintainer would add.
+ *
+ * Conventions (all entry points):
+ *   - extern "C", plain pointers + sizes, no torch / C++ types in any signature;
+ *   - every pointer is DEVICE memory owned by the caller (no ownership transfer, the
+ *     library never allocates); activations are bf16 unless noted, parameters and
+ *     parameter gradients are fp32 ("master" precision), statistics fp32;
+ *   - `stream` is a hipStream_t passed as void*; kernels are enqueued asynchronously;
+ *   - return value: 0 = enqueued OK; <0 = M3P_E* (bad shape / alignment, nothing was
+ *     launched); >0 = a hipError_t.  Nothing throws across the ABI;
+ *   - no global mutable state, re-entrant (the autograd engine calls from its own thread).
+ */
+#ifndef M3P_HIP_H
+#define M3P_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define M3P_API __attribute__((visibility("default")))
+
+#define M3P_OK 0
+#define M3P_EINVAL (-1)
+#define M3P_ENOTIMPL (-2)
+
+/* library / build identification: returns a static string "m3p_hip <ver> gfx950" */
+M3P_API const char* m3p_version(void);
+
+/* ------------------------------------------------------------------------------------
+ * Dense contractions on MFMA (v_mfma_f32_16x16x32_bf16), fp32 accumulate.
+ * ---------------------------------------------------------------------------------- */
+
+/* epilogue selectors for m3p_gemm_nt_bf16 */
+enum {
+  M3P_EPI_NONE = 0,          /* C = alpha*acc                                            */
+  M3P_EPI_BIAS = 1,          /* C = alpha*acc + bias[n]; cols n < scale_cols are *= scale */
+  M3P_EPI_BIAS_GELU = 2,     /* u = acc + bias -> out2 (bf16); C = gelu_erf(u)           */
+  M3P_EPI_BIAS_DROP_RES = 3, /* C = dropout(acc + bias) + aux                            */
+  M3P_EPI_RES = 4,           /* C = alpha*acc + aux                                      */
+  M3P_EPI_DGELU = 5          /* C = acc * gelu_erf'(aux); colsum[n] += sum_m C (optional) */
+};
+
+typedef struct M3PEpilogue {
+  const float* bias;  /* [N] fp32 or NULL                                             */
+  const void* aux;    /* bf16 [M, ld_aux]: residual (DROP_RES, RES) / pre-activation (DGELU) */
+  void* out2;         /* bf16 [M, ld_out2]: pre-activation output (BIAS_GELU)          */
+  float* colsum;      /* fp32 [N] accumulated with atomics, or NULL (DGELU)            */
+  int32_t ld_aux;
+  int32_t ld_out2;
+  int32_t scale_cols; /* BIAS: number of leading output columns multiplied by `scale`   */
+  float scale;
+  float alpha;        /* accumulator multiplier (NONE, BIAS, RES); 0 is treated as 1    */
+  uint32_t seed;      /* dropout stream key (DROP_RES)                                 */
+  uint32_t thresh24;  /* drop iff (hash >> 8) < thresh24; 0 = no dropout               */
+  float inv_keep;     /* 1 / (1 - p)                                                   */
+} M3PEpilogue;
+
+/* C[M,N] (bf16, row pitch ldc) = epilogue( A[M,K] (bf16, pitch lda) x W[N,K]^T (bf16, pitch ldw) ).
+ * The nn.Linear shape: replaces F.linear at transformer.py:178-181 (q/k/v_lin as one
+ * N=3d GEMM), :208 (out_lin), :223/:225 (FFN lin1/lin2, with :56 gelu and :226 dropout
+ * and the residual adds of :951-957 folded into the epilogue), :257 (region
+ * projection), :111 (tied vocabulary projection) and, with transposed weight copies,
+ * every data-gradient GEMM of their backward.
+ * Requires K % 64 == 0, lda/ldw % 8 == 0, ldc % 4 == 0, 16-byte aligned bases. */
+M3P_API int m3p_gemm_nt_bf16(const void* A, int lda, const void* W, int ldw, void* C, int ldc,
+                             int M, int N, int K, int epilogue, const M3PEpilogue* ep, void* stream);
+
+/* Weight gradient: dW[N,K] (fp32, pitch lddw) += alpha * sum_m dY[m,n] * X[m,k]
+ * (dY bf16 [M,N] pitch lddy, X bf16 [M,K] pitch ldx).  Accumulates with fp32 atomics
+ * (split over M to fill 256 CUs), so dW must hold the running gradient (zero after
+ * zero_grad).  Replaces autograd's addmm-backward for every nn.Linear weight above.
+ * Requires N % 16 == 0 ... see source; lddy/ldx % 8 == 0. */
+M3P_API int m3p_gemm_wgrad_bf16(const void* dY, int lddy, const void* X, int ldx, float* dW, int lddw,
+                                int M, int N, int K, float alpha, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * LayerNorm (eps = 1e-12 in the reference: transformer.py:244,660,694,709)
+ * ---------------------------------------------------------------------------------- */
+
+/* y[r,:] = LN(x[r,:]) * gamma + beta, then * rowmask[r] if rowmask != NULL
+ * (the `tensor *= mask` of transformer.py:958).  x,y bf16 [rows,d]; gamma,beta fp32;
+ * mean,rstd fp32 [rows] saved for backward.  d % 4 == 0, d <= 2048. */
+M3P_API int m3p_layernorm_fwd(const void* x, const float* gamma, const float* beta, const uint8_t* rowmask,
+                              void* y, float* mean, float* rstd, int rows, int d, float eps, void* stream);
+
+/* Backward of the above.  dy = dy_a (+ dy_b if not NULL), multiplied by rowmask[r] if given.
+ *   dx        : bf16 [rows,d] gradient wrt the LayerNorm input (always written)
+ *   dx_drop   : if not NULL, also dx * keep/(1-p) with the dropout stream (seed,thresh24)
+ *               indexed by r*d+c — i.e. the gradient pushed through the dropout that
+ *               produced the residual branch (transformer.py:951 / :226)
+ *   dgamma,dbeta : fp32 [d], accumulated with atomics
+ *   dbias_drop: if not NULL fp32 [d] += column sums of dx_drop (the bias gradient of the
+ *               Linear feeding that dropout: out_lin.bias / lin2.bias). */
+M3P_API int m3p_layernorm_bwd(const void* dy_a, const void* dy_b, const void* x, const float* gamma,
+                              const float* mean, const float* rstd, const uint8_t* rowmask,
+                              void* dx, void* dx_drop, float* dgamma, float* dbeta, float* dbias_drop,
+                              int rows, int d, uint32_t seed, uint32_t thresh24, float inv_keep, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Hardware-semantics probes (used by tests/test_hw_probes.py only): each fills `out`
+ * with what the instruction delivered so the test can compare with the documented map.
+ * ---------------------------------------------------------------------------------- */
+M3P_API int m3p_probe_mfma_16x16x32(const void* a_rowmajor_16x32, const void* b_colmajor_32x16,
+                                    float* d_16x16, int* d_rowcol, void* stream);
+M3P_API int m3p_probe_tr16(const void* tile_bf16_64x16, void* out_64x4, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* M3P_HIP_H */

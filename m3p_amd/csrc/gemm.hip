@@ -1,0 +1,399 @@
+// MFMA GEMMs for the M3P hot path on gfx950 (MI355X).
+//
+//   gemm_nt   : C[M,N] = epi(A[M,K] x W[N,K]^T)    both operands K-contiguous (nn.Linear)
+//   gemm_wgrad: dW[N,K] += dY[M,N]^T x X[M,K]      both operands contraction-strided,
+//               fragments come out of LDS through ds_read_b64_tr_b16 (hardware transpose)
+//
+// Common structure: 128x128 output tile, 4 waves (2x2), each wave 64x64 = 4x4 tiles of
+// v_mfma_f32_16x16x32_bf16; contraction step 64 per LDS stage, two stages, HBM -> LDS by
+// global_load_lds_dwordx4 (no VGPR round trip), one barrier per stage.  The LDS image of a
+// K-contiguous tile is [rows][64] bf16 (128 B rows); because an LDS-DMA writes lane-linear,
+// the bank swizzle (16-B chunk ^= row & 7) is applied to the per-lane SOURCE address and
+// again on the ds_read_b128 (cdna guide rule 21), which makes the fragment reads
+// conflict-free.  Block ids are remapped so each XCD (private L2) walks a contiguous run
+// of tiles that share their A row-panel.
+#include "common.hpp"
+#include "../../include/m3p_hip.h"
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+namespace {
+
+constexpr int BK = 64;            // contraction elements per LDS stage
+constexpr int ROWB = BK * 2;      // bytes per LDS row of a K-contiguous tile (128)
+
+// ---------------------------------------------------------------------------------
+// NT kernel
+// ---------------------------------------------------------------------------------
+template <int EPI>
+__device__ __forceinline__ void epilogue_store(const M3PEpilogue& ep, bf16* __restrict__ C, int ldc,
+                                               int M, int N, int m, int n, f32x4 acc, f32x4& csum) {
+  if (m >= M || n >= N) return;
+  const bool full = (n + 3 < N);
+  float v[4] = {acc[0], acc[1], acc[2], acc[3]};
+  const float alpha = (ep.alpha == 0.f) ? 1.f : ep.alpha;
+  if (EPI == M3P_EPI_NONE || EPI == M3P_EPI_BIAS || EPI == M3P_EPI_RES) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] *= alpha;
+  }
+  if (EPI == M3P_EPI_BIAS || EPI == M3P_EPI_BIAS_GELU || EPI == M3P_EPI_BIAS_DROP_RES) {
+    if (ep.bias) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (n + r < N) v[r] += ep.bias[n + r];
+    }
+  }
+  if (EPI == M3P_EPI_BIAS) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (n + r < ep.scale_cols) v[r] *= ep.scale;
+  }
+  if (EPI == M3P_EPI_BIAS_GELU) {
+    bf16* U = reinterpret_cast<bf16*>(ep.out2) + (size_t)m * ep.ld_out2 + n;
+    bf16 ur[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { ur[r] = (bf16)v[r]; v[r] = gelu_erf_f((float)ur[r]); }
+    if (full) *reinterpret_cast<bf16x4*>(U) = bf16x4{ur[0], ur[1], ur[2], ur[3]};
+    else
+      for (int r = 0; r < 4; ++r) if (n + r < N) U[r] = ur[r];
+  }
+  if (EPI == M3P_EPI_BIAS_DROP_RES) {
+    if (ep.thresh24) {
+      const uint32_t base = (uint32_t)m * (uint32_t)N + (uint32_t)n;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = m3p_keep(base + r, ep.seed, ep.thresh24) ? v[r] * ep.inv_keep : 0.f;
+    }
+  }
+  if (EPI == M3P_EPI_BIAS_DROP_RES || EPI == M3P_EPI_RES || EPI == M3P_EPI_DGELU) {
+    const bf16* X = reinterpret_cast<const bf16*>(ep.aux) + (size_t)m * ep.ld_aux + n;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    if (full) { bf16x4 t = *reinterpret_cast<const bf16x4*>(X); a[0] = (float)t[0]; a[1] = (float)t[1]; a[2] = (float)t[2]; a[3] = (float)t[3]; }
+    else
+      for (int r = 0; r < 4; ++r) if (n + r < N) a[r] = (float)X[r];
+    if (EPI == M3P_EPI_DGELU) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_grad_f(a[r]);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] += a[r];
+    }
+  }
+  bf16 o[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) o[r] = (bf16)v[r];
+  bf16* Cp = C + (size_t)m * ldc + n;
+  if (full) *reinterpret_cast<bf16x4*>(Cp) = bf16x4{o[0], o[1], o[2], o[3]};
+  else
+    for (int r = 0; r < 4; ++r) if (n + r < N) Cp[r] = o[r];
+  if (EPI == M3P_EPI_DGELU) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) csum[r] += (n + r < N) ? (float)o[r] : 0.f;
+  }
+}
+
+template <int BM, int BN, int EPI>
+__global__ __launch_bounds__(64 * (BM / 64) * (BN / 64))
+void gemm_nt_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ W, int ldw,
+                    bf16* __restrict__ C, int ldc, int M, int N, int K, M3PEpilogue ep,
+                    int tiles_m, int tiles_n) {
+  constexpr int WAVES_M = BM / 64, WAVES_N = BN / 64, NWAVES = WAVES_M * WAVES_N;
+  constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int id = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int tm = id / tiles_n, tn = id - tm * tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // ---- staging: one wave instruction = 8 rows x 128 B, lane -> (row l>>3, LDS chunk l&7),
+  //      global chunk = LDS chunk ^ (row & 7)
+  const int sr = lane >> 3, sc = (lane & 7) ^ sr;
+  const bf16* a_src[BM / 8 / NWAVES];
+  const bf16* w_src[BN / 8 / NWAVES];
+#pragma unroll
+  for (int i = 0; i < BM / 8 / NWAVES; ++i) {
+    int row = (wid + i * NWAVES) * 8 + sr;
+    int gm = min(m0 + row, M - 1);
+    a_src[i] = A + (size_t)gm * lda + sc * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < BN / 8 / NWAVES; ++i) {
+    int row = (wid + i * NWAVES) * 8 + sr;
+    int gn = min(n0 + row, N - 1);
+    w_src[i] = W + (size_t)gn * ldw + sc * 8;
+  }
+  auto stage = [&](int kt, int s) {
+    char* sa = smem + s * STAGE;
+    char* sb = sa + A_BYTES;
+    const int k0 = kt * BK;
+#pragma unroll
+    for (int i = 0; i < BM / 8 / NWAVES; ++i)
+      __builtin_amdgcn_global_load_lds(GLB_PTR(a_src[i] + k0), LDS_PTR(sa + (wid + i * NWAVES) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < BN / 8 / NWAVES; ++i)
+      __builtin_amdgcn_global_load_lds(GLB_PTR(w_src[i] + k0), LDS_PTR(sb + (wid + i * NWAVES) * 1024), 16, 0, 0);
+  };
+
+  // ---- fragment addressing
+  const int wm = wid / WAVES_N, wn = wid - wm * WAVES_N;
+  const int fr = lane & 15, fg = lane >> 4;
+  int a_off[2], b_off[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int ch = ((fg + 4 * ks) ^ (fr & 7)) * 16;
+    a_off[ks] = (wm * 64 + fr) * ROWB + ch;
+    b_off[ks] = A_BYTES + (wn * 64 + fr) * ROWB + ch;
+  }
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = K / BK;
+  stage(0, 0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) stage(kt + 1, cur ^ 1);
+    const char* sbase = smem + cur * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[4], wf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sbase + a_off[ks] + i * 16 * ROWB);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(sbase + b_off[ks] + j * 16 * ROWB);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          // first operand = W rows (n), second = A rows (m): D[n][m] -> lane holds
+          // m = l&15 and four consecutive n = 4*(l>>4)+r  (8-byte bf16 stores along N)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue
+  f32x4 csum[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) csum[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wm * 64 + i * 16 + fr;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + fg * 4;
+      epilogue_store<EPI>(ep, C, ldc, M, N, m, n, acc[i][j], csum[j]);
+    }
+  }
+  if (EPI == M3P_EPI_DGELU && ep.colsum) {
+    // reduce over the 16 lanes that share fg (different rows), then one atomic per column
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float s = csum[j][r];
+        s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64);
+        s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
+        const int n = n0 + wn * 64 + j * 16 + fg * 4 + r;
+        if (fr == 0 && n < N) unsafeAtomicAdd(ep.colsum + n, s);
+      }
+    }
+  }
+}
+
+template <int EPI>
+int launch_nt(const bf16* A, int lda, const bf16* W, int ldw, bf16* C, int ldc, int M, int N, int K,
+              const M3PEpilogue& ep, hipStream_t st) {
+  constexpr int BM = 128, BN = 128;
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+  const size_t lds = 2 * (BM + BN) * ROWB;
+  auto kern = gemm_nt_kernel<BM, BN, EPI>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(tiles_m * tiles_n), dim3(256), lds, st, A, lda, W, ldw, C, ldc, M, N, K, ep,
+                     tiles_m, tiles_n);
+  M3P_CHECK_LAUNCH();
+  return M3P_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// weight-gradient kernel: dW[i,j] += alpha * sum_m dY[m,i] X[m,j]
+// LDS tiles are [64 m][128 cols] bf16 (256-B rows, as in HBM); MFMA operands need 8
+// consecutive m per lane for one column -> two ds_read_b64_tr_b16 per fragment.
+// ---------------------------------------------------------------------------------
+constexpr int WG_T = 128;           // output tile edge
+constexpr int WG_ROWB = WG_T * 2;   // 256 B per LDS row
+constexpr int WG_TILE_BYTES = BK * WG_ROWB;  // 16 KB
+
+__device__ __forceinline__ bf16x4 lds_tr16(const char* p) {
+  s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+  return __builtin_bit_cast(bf16x4, v);
+}
+
+__global__ __launch_bounds__(256)
+void gemm_wgrad_kernel(const bf16* __restrict__ dY, int lddy, const bf16* __restrict__ X, int ldx,
+                       float* __restrict__ dW, int lddw, int M, int N, int K, float alpha,
+                       int tiles_i, int tiles_j, int m_chunk) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntile = tiles_i * tiles_j;
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = id / ntile, tile = id - split * ntile;
+  const int ti = tile / tiles_j, tj = tile - ti * tiles_j;
+  const int i0 = ti * WG_T, j0 = tj * WG_T;
+  const int m_begin = split * m_chunk;
+  const int m_end = min(M, m_begin + m_chunk);
+  if (m_begin >= m_end) return;
+
+  // staging: one wave instruction = 4 rows x 256 B; lane -> (row l>>4, chunk l&15)
+  const int sr = lane >> 4, sc = lane & 15;
+  // clamp the 8-column chunk so a ragged N / K never reads past the row pitch
+  const int n_chunks = (N + 7) / 8, k_chunks = (K + 7) / 8;
+  const int ycol = min(i0 / 8 + sc, n_chunks - 1) * 8;
+  const int xcol = min(j0 / 8 + sc, k_chunks - 1) * 8;
+
+  auto stage = [&](int mt, int s) {
+    char* sy = smem + s * 2 * WG_TILE_BYTES;
+    char* sx = sy + WG_TILE_BYTES;
+    const int mbase = m_begin + mt * BK;
+    const bool fullt = (mbase + BK <= m_end);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rb = wid + i * 4;            // group of 4 rows
+      const int m = mbase + rb * 4 + sr;
+      if (fullt) {
+        __builtin_amdgcn_global_load_lds(GLB_PTR(dY + (size_t)m * lddy + ycol), LDS_PTR(sy + rb * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(GLB_PTR(X + (size_t)m * ldx + xcol), LDS_PTR(sx + rb * 1024), 16, 0, 0);
+      } else {
+        // ragged last tile: rows >= m_end contribute zeros
+        uint4 vy = make_uint4(0, 0, 0, 0), vx = make_uint4(0, 0, 0, 0);
+        if (m < m_end) {
+          vy = *reinterpret_cast<const uint4*>(dY + (size_t)m * lddy + ycol);
+          vx = *reinterpret_cast<const uint4*>(X + (size_t)m * ldx + xcol);
+        }
+        *reinterpret_cast<uint4*>(sy + rb * 1024 + lane * 16) = vy;
+        *reinterpret_cast<uint4*>(sx + rb * 1024 + lane * 16) = vx;
+      }
+    }
+  };
+
+  const int wi = wid >> 1, wj = wid & 1;
+  const int ft = lane & 15, fg = lane >> 4;
+  // tr16 address of lane (t,g) for k-step ks, half jj, sub-tile c:
+  //   row = ks*32 + g*8 + jj*4 + (t>>2);  col = wave_base + c*16 + (t&3)*4
+  const int y_off = (fg * 8 + (ft >> 2)) * WG_ROWB + (wi * 64 + (ft & 3) * 4) * 2;
+  const int x_off = WG_TILE_BYTES + (fg * 8 + (ft >> 2)) * WG_ROWB + (wj * 64 + (ft & 3) * 4) * 2;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nmt = (m_end - m_begin + BK - 1) / BK;
+  stage(0, 0);
+  __syncthreads();
+  for (int mt = 0; mt < nmt; ++mt) {
+    const int cur = mt & 1;
+    if (mt + 1 < nmt) stage(mt + 1, cur ^ 1);
+    const char* sbase = smem + cur * 2 * WG_TILE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 yf[4], xf[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const char* py = sbase + y_off + ks * 32 * WG_ROWB + c * 32;
+        const char* px = sbase + x_off + ks * 32 * WG_ROWB + c * 32;
+        bf16x4 y0 = lds_tr16(py), y1 = lds_tr16(py + 4 * WG_ROWB);
+        bf16x4 x0 = lds_tr16(px), x1 = lds_tr16(px + 4 * WG_ROWB);
+        yf[c] = bf16x8{y0[0], y0[1], y0[2], y0[3], y1[0], y1[1], y1[2], y1[3]};
+        xf[c] = bf16x8{x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[a], xf[b], acc[a][b], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // D[i][j]: lane holds j = l&15, i = 4*(l>>4)+r
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int j = j0 + wj * 64 + b * 16 + ft;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = i0 + wi * 64 + a * 16 + fg * 4 + r;
+        if (i < N && j < K) unsafeAtomicAdd(dW + (size_t)i * lddw + j, alpha * acc[a][b][r]);
+      }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int m3p_gemm_nt_bf16(const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K,
+                     int epilogue, const M3PEpilogue* ep_in, void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || (K % BK) != 0 || (lda % 8) != 0 || (ldw % 8) != 0 || (ldc % 4) != 0)
+    return M3P_EINVAL;
+  if (((uintptr_t)A & 15) || ((uintptr_t)W & 15) || ((uintptr_t)C & 7)) return M3P_EINVAL;
+  M3PEpilogue ep = {};
+  if (ep_in) ep = *ep_in;
+  if ((epilogue == M3P_EPI_BIAS_DROP_RES || epilogue == M3P_EPI_RES || epilogue == M3P_EPI_DGELU) &&
+      (!ep.aux || (ep.ld_aux % 4) != 0))
+    return M3P_EINVAL;
+  if (epilogue == M3P_EPI_BIAS_GELU && (!ep.out2 || (ep.ld_out2 % 4) != 0)) return M3P_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const bf16* a = (const bf16*)A; const bf16* w = (const bf16*)W; bf16* c = (bf16*)C;
+  switch (epilogue) {
+    case M3P_EPI_NONE: return launch_nt<M3P_EPI_NONE>(a, lda, w, ldw, c, ldc, M, N, K, ep, st);
+    case M3P_EPI_BIAS: return launch_nt<M3P_EPI_BIAS>(a, lda, w, ldw, c, ldc, M, N, K, ep, st);
+    case M3P_EPI_BIAS_GELU: return launch_nt<M3P_EPI_BIAS_GELU>(a, lda, w, ldw, c, ldc, M, N, K, ep, st);
+    case M3P_EPI_BIAS_DROP_RES: return launch_nt<M3P_EPI_BIAS_DROP_RES>(a, lda, w, ldw, c, ldc, M, N, K, ep, st);
+    case M3P_EPI_RES: return launch_nt<M3P_EPI_RES>(a, lda, w, ldw, c, ldc, M, N, K, ep, st);
+    case M3P_EPI_DGELU: return launch_nt<M3P_EPI_DGELU>(a, lda, w, ldw, c, ldc, M, N, K, ep, st);
+    default: return M3P_EINVAL;
+  }
+}
+
+int m3p_gemm_wgrad_bf16(const void* dY, int lddy, const void* X, int ldx, float* dW, int lddw, int M, int N, int K,
+                        float alpha, void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || (lddy % 8) != 0 || (ldx % 8) != 0) return M3P_EINVAL;
+  if (lddy < ((N + 7) / 8) * 8 || ldx < ((K + 7) / 8) * 8) return M3P_EINVAL;
+  if (((uintptr_t)dY & 15) || ((uintptr_t)X & 15)) return M3P_EINVAL;
+  const int tiles_i = (N + WG_T - 1) / WG_T, tiles_j = (K + WG_T - 1) / WG_T;
+  const int ntile = tiles_i * tiles_j;
+  // split the contraction so that ~2 blocks per CU are in flight; chunk is a multiple of 64
+  int split = (512 + ntile - 1) / ntile;
+  const int max_split = (M + BK - 1) / BK;
+  if (split > max_split) split = max_split;
+  if (split < 1) split = 1;
+  int m_chunk = ((M + split - 1) / split + BK - 1) / BK * BK;
+  split = (M + m_chunk - 1) / m_chunk;
+  const size_t lds = 4 * WG_TILE_BYTES;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gemm_wgrad_kernel, dim3(ntile * split), dim3(256), lds, (hipStream_t)stream,
+                     (const bf16*)dY, lddy, (const bf16*)X, ldx, dW, lddw, M, N, K, alpha, tiles_i, tiles_j, m_chunk);
+  M3P_CHECK_LAUNCH();
+  return M3P_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,82 @@
+"""ctypes binding of libm3p_hip.so (C ABI declared in include/m3p_hip.h).
+
+The HIP library is the product: there is NO fallback.  If the shared object is missing
+or a kernel reports an error, the call raises — a silent eager/PyTorch path would void
+every parity and performance claim made for this package.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libm3p_hip.so')
+
+EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_DROP_RES, EPI_RES, EPI_DGELU = range(6)
+
+
+class M3PError(RuntimeError):
+    pass
+
+
+class Epilogue(C.Structure):
+    """struct M3PEpilogue (include/m3p_hip.h)."""
+    _fields_ = [
+        ('bias', C.c_void_p), ('aux', C.c_void_p), ('out2', C.c_void_p), ('colsum', C.c_void_p),
+        ('ld_aux', C.c_int32), ('ld_out2', C.c_int32), ('scale_cols', C.c_int32), ('scale', C.c_float),
+        ('alpha', C.c_float), ('seed', C.c_uint32), ('thresh24', C.c_uint32), ('inv_keep', C.c_float),
+    ]
+
+
+_p, _i, _f, _u32 = C.c_void_p, C.c_int, C.c_float, C.c_uint32
+
+# name -> (restype, argtypes); mirrors include/m3p_hip.h one to one
+SIGNATURES = {
+    'm3p_version': (C.c_char_p, []),
+    'm3p_gemm_nt_bf16': (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, C.POINTER(Epilogue), _p]),
+    'm3p_gemm_wgrad_bf16': (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _f, _p]),
+    'm3p_layernorm_fwd': (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p]),
+    'm3p_layernorm_bwd': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _u32, _u32, _f, _p]),
+    'm3p_probe_mfma_16x16x32': (_i, [_p, _p, _p, _p, _p]),
+    'm3p_probe_tr16': (_i, [_p, _p, _p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the library once; raises M3PError if it has not been built
+    (``python -c 'import __graft_entry__ as g; g.build()'`` or ``make -C m3p_amd/csrc``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise M3PError('libm3p_hip.so not found at %s — build it first (make -C m3p_amd/csrc); '
+                       'there is no fallback path' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so is stale
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code, what):
+    if code != 0:
+        kind = {-1: 'M3P_EINVAL (bad shape/alignment)', -2: 'M3P_ENOTIMPL'}.get(code, 'hipError_t %d' % code)
+        raise M3PError('%s failed: %s' % (what, kind))
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def thresh24(p):
+    """Dropout probability -> 24-bit drop threshold used by every kernel (csrc/common.hpp)."""
+    return int(round(float(p) * (1 << 24)))

@@ -1,0 +1,137 @@
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from tests.util import randn_bf16, randn_f32, rel_l2, max_abs
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(128, 128, 64), (592, 384, 128), (300, 1000, 128), (41, 130, 192), (1024, 768, 768), (256, 3072, 768),
+          (520, 768, 3072)]
+
+
+def _tol(K):
+    return 4e-3
+
+
+@pytest.mark.parametrize('M,N,K', SHAPES)
+def test_gemm_nt_none_and_bias(M, N, K):
+    from m3p_amd import ops, lib as L
+    a, ac = randn_bf16((M, K), 1)
+    w, wc = randn_bf16((N, K), 2, 0.05)
+    bias, bc = randn_f32((N,), 3)
+    ldc = (N + 3) // 4 * 4
+    out = torch.full((M, ldc), 7.0, dtype=torch.bfloat16, device='cuda')
+    c = ops.gemm_nt(a, w, L.EPI_NONE, out=out, n=N)
+    ref = ac @ wc.t()
+    assert rel_l2(c[:, :N].float(), ref) < _tol(K)
+    if ldc > N:
+        assert bool((c[:, N:] == 7.0).all()), 'wrote outside the N range'
+    c = ops.gemm_nt(a, w, L.EPI_BIAS, bias=bias, scale_cols=N // 3, scale=0.125, out=out, n=N)
+    ref = ac @ wc.t() + bc
+    ref[:, :N // 3] *= 0.125
+    assert rel_l2(c[:, :N].float(), ref) < _tol(K)
+
+
+def test_gemm_nt_transpose_detecting():
+    """A = I-like, asymmetric W: catches a swapped result map."""
+    from m3p_amd import ops, lib as L
+    M = N = K = 128
+    a = torch.eye(M, dtype=torch.bfloat16, device='cuda')
+    w = (torch.arange(N * K, dtype=torch.float32).view(N, K) % 37 - 18).to(torch.bfloat16).cuda()
+    c = ops.gemm_nt(a, w, L.EPI_NONE)
+    assert torch.equal(c.float().cpu(), w.float().cpu().t())
+
+
+def test_gemm_nt_bias_gelu():
+    from m3p_amd import ops, lib as L
+    from oracle import ref_cpu as O
+    M, N, K = 300, 512, 128
+    a, ac = randn_bf16((M, K), 1)
+    w, wc = randn_bf16((N, K), 2, 0.1)
+    bias, bc = randn_f32((N,), 3)
+    u = torch.empty((M, N), dtype=torch.bfloat16, device='cuda')
+    h = ops.gemm_nt(a, w, L.EPI_BIAS_GELU, bias=bias, out2=u)
+    uref = ac @ wc.t() + bc
+    assert rel_l2(u.float(), uref) < 4e-3
+    assert rel_l2(h.float(), O.gelu_erf(u.float().cpu())) < 4e-3   # gelu of the stored pre-activation
+    assert rel_l2(h.float(), O.gelu_erf(uref)) < 8e-3
+
+
+@pytest.mark.parametrize('p', [0.0, 0.1])
+def test_gemm_nt_bias_dropout_residual(p):
+    from m3p_amd import ops, rng, lib as L
+    M, N, K, seed = 333, 768, 256, 777
+    a, ac = randn_bf16((M, K), 1)
+    w, wc = randn_bf16((N, K), 2, 0.1)
+    bias, bc = randn_f32((N,), 3)
+    r, rc = randn_bf16((M, N), 4)
+    c = ops.gemm_nt(a, w, L.EPI_BIAS_DROP_RES, bias=bias, aux=r, seed=seed, p_drop=p)
+    y = ac @ wc.t() + bc
+    if p > 0:
+        keep = torch.from_numpy(rng.keep_mask(M * N, seed, p, (M, N)))
+        y = y * keep / (1 - p)
+    assert rel_l2(c.float(), y + rc) < 4e-3
+
+
+def test_gemm_nt_res_and_dgelu():
+    from m3p_amd import ops, lib as L
+    M, N, K = 260, 512, 128
+    a, ac = randn_bf16((M, K), 1)
+    w, wc = randn_bf16((N, K), 2, 0.1)
+    r, rc = randn_bf16((M, N), 4)
+    c = ops.gemm_nt(a, w, L.EPI_RES, aux=r, alpha=0.5)
+    assert rel_l2(c.float(), 0.5 * (ac @ wc.t()) + rc) < 4e-3
+    cs = torch.zeros(N, device='cuda')
+    c = ops.gemm_nt(a, w, L.EPI_DGELU, aux=r, colsum=cs)
+    x = rc.double().requires_grad_(True)
+    g = 0.5 * x * (1 + torch.erf(x / math.sqrt(2)))
+    g.sum().backward()
+    ref = (ac @ wc.t()).double() * x.grad
+    assert rel_l2(c.float(), ref) < 4e-3
+    assert rel_l2(cs, c.float().sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize('M,N,K', [(64, 128, 128), (592, 384, 128), (1000, 100, 72), (4100, 768, 768), (131, 40, 264),
+                                   (8200, 3072, 768)])
+def test_gemm_wgrad(M, N, K):
+    from m3p_amd import ops
+    dy, dyc = randn_bf16((M, (N + 7) // 8 * 8), 1)
+    x, xc = randn_bf16((M, (K + 7) // 8 * 8), 2)
+    dw = torch.ones((N, K), dtype=torch.float32, device='cuda')
+    ops.gemm_wgrad(dy, x, dw, alpha=0.5, n=N, k=K)
+    ref = 1.0 + 0.5 * (dyc[:, :N].double().t() @ xc[:, :K].double())
+    assert rel_l2(dw, ref) < 1e-5
+
+
+def test_gemm_perf_smoke():
+    """Not a benchmark: prints achieved TF for the cfg2 shapes so the GPU log shows them."""
+    from m3p_amd import ops, lib as L
+    M = 41984
+    for (N, K) in [(2304, 768), (768, 768), (3072, 768), (768, 3072)]:
+        a, _ = randn_bf16((M, K), 1)
+        w, _ = randn_bf16((N, K), 2, 0.05)
+        out = torch.empty((M, N), dtype=torch.bfloat16, device='cuda')
+        for _ in range(3):
+            ops.gemm_nt(a, w, L.EPI_NONE, out=out)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            ops.gemm_nt(a, w, L.EPI_NONE, out=out)
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        print('gemm_nt M=%d N=%d K=%d: %.3f ms  %.1f TF' % (M, N, K, ms, 2.0 * M * N * K / ms / 1e9))
+        dw = torch.zeros((N, K), dtype=torch.float32, device='cuda')
+        dy = out
+        for _ in range(2):
+            ops.gemm_wgrad(dy, a, dw)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(10):
+            ops.gemm_wgrad(dy, a, dw)
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        print('gemm_wgrad M=%d N=%d K=%d: %.3f ms  %.1f TF' % (M, N, K, ms, 2.0 * M * N * K / ms / 1e9))

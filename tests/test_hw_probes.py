@@ -1,0 +1,39 @@
+"""Pin the gfx950 instruction semantics the kernels are built on (MFMA operand/result
+lane maps, ds_read_b64_tr_b16 gather).  If one of these fails, every GEMM/attention
+result is suspect — read this first."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_mfma_16x16x32_lane_maps():
+    from m3p_amd import lib as L
+    lib = L.load()
+    rs = np.random.RandomState(0)
+    a = torch.from_numpy(rs.randint(-4, 5, size=(16, 32)).astype(np.float32))
+    w = torch.from_numpy(rs.randint(-4, 5, size=(16, 32)).astype(np.float32))  # asymmetric on purpose
+    ad, wd = a.to(torch.bfloat16).cuda(), w.to(torch.bfloat16).cuda()
+    d = torch.zeros(16, 16, dtype=torch.float32, device='cuda')
+    rc = torch.zeros(256, 2, dtype=torch.int32, device='cuda')
+    L.check(lib.m3p_probe_mfma_16x16x32(ad.data_ptr(), wd.data_ptr(), d.data_ptr(), rc.data_ptr(), L.stream()), 'probe')
+    torch.cuda.synchronize()
+    ref = a @ w.t()
+    assert torch.equal(d.cpu(), ref), 'MFMA lane map differs from the documented one:\n%s\n%s' % (d.cpu(), ref)
+
+
+def test_ds_read_tr16_gather():
+    from m3p_amd import lib as L
+    lib = L.load()
+    tile = torch.arange(64 * 16, dtype=torch.int16).view(64, 16)
+    out = torch.zeros(64, 4, dtype=torch.int16, device='cuda')
+    L.check(lib.m3p_probe_tr16(tile.cuda().data_ptr(), out.data_ptr(), L.stream()), 'probe')
+    torch.cuda.synchronize()
+    exp = torch.zeros(64, 4, dtype=torch.int16)
+    for l in range(64):
+        g, t = l >> 4, l & 15
+        # the probe points group g at rows 4g..4g+3 (16 rows apart would be other groups)
+        for j in range(4):
+            exp[l, j] = tile[4 * g + j, t]
+    assert torch.equal(out.cpu(), exp), 'tr16 gather differs:\n%s' % out.cpu()
