@@ -106,6 +106,28 @@ M3P_API int m3p_layernorm_bwd(const void* dy_a, const void* dy_b, const void* x,
                               int rows, int d, uint32_t seed, uint32_t thresh24, float inv_keep, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * Fused multi-head self-attention (transformer.py:149-210, self-attention branch)
+ * ---------------------------------------------------------------------------------- */
+
+/* qkv bf16 [B*S, 3*H*dh] token-major (q | k | v column blocks, q already scaled by
+ * 1/sqrt(dh) — M3P_EPI_BIAS scale_cols); keylen int32 [B]: keys >= keylen[b] are masked
+ * to -inf (get_masks, transformer.py:59-78, non-causal).  Softmax in fp32, dropout on the
+ * probabilities with stream (seed, thresh24) indexed ((b*H+h)*S+q)*S+key, context = P v.
+ * ctx bf16 [B*S, H*dh] token-major; lse fp32 [B,H,S] = log-sum-exp saved for backward.
+ * dh in {32, 64}, S <= 512. */
+M3P_API int m3p_attn_fwd(const void* qkv, const int32_t* keylen, void* ctx, float* lse, int B, int S, int H,
+                         int dh, uint32_t seed, uint32_t thresh24, float inv_keep, void* stream);
+
+/* Backward: given dctx (bf16 [B*S, H*dh]) writes dqkv (bf16 [B*S, 3*H*dh]; the q block is
+ * multiplied by qscale = 1/sqrt(dh) so it is the gradient of the *unscaled* projection)
+ * and, if dbias_qkv != NULL, accumulates (atomics) the column sums of dqkv into the fp32
+ * [3*H*dh] bias gradient of the fused q/k/v projection.  Scores are recomputed from
+ * qkv + lse (nothing S x S is ever stored).  S <= 384. */
+M3P_API int m3p_attn_bwd(const void* qkv, const int32_t* keylen, const void* ctx, const void* dctx,
+                         const float* lse, void* dqkv, float* dbias_qkv, int B, int S, int H, int dh,
+                         float qscale, uint32_t seed, uint32_t thresh24, float inv_keep, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Hardware-semantics probes (used by tests/test_hw_probes.py only): each fills `out`
  * with what the instruction delivered so the test can compare with the documented map.
  * ---------------------------------------------------------------------------------- */

@@ -1,0 +1,514 @@
+// Fused multi-head self-attention (forward + backward) for the M3P encoder on gfx950.
+//
+// Reference semantics (M3P/src/model/transformer.py:149-210, self-attention branch):
+//   q = (x Wq + bq) / sqrt(dh)   <- the scale is already folded into the QKV GEMM epilogue
+//   P = softmax_fp32(q k^T, keys >= len[b] masked to -inf);  P = dropout(P);  ctx = P v
+// One workgroup per (batch, head).  The sequence is short (S = regions + tokens = 164 for
+// M3P-base, <= 512), so a whole head's K and V live in LDS (row-major, 16-B chunk XOR
+// swizzle applied on the LDS-DMA source address) and the S x S score matrix never
+// leaves registers:
+//   * S^T = K Q^T on v_mfma_f32_16x16x32_bf16 ("swapped" product): a lane then owns one
+//     query column and 4 keys per 16-key tile, so the softmax row reduction is in-lane
+//     plus two wave64 xor-shuffles (lanes l, l^16, l^32, l^48 share a query);
+//   * the fp32 probabilities are normalised, dropped (counter-based hash RNG, re-generated
+//     in backward), packed to bf16 and fed straight back as the MFMA B operand of
+//     O^T = V^T P^T — the MFMA k-slot order is permuted identically for P (registers) and
+//     V (ds_read_b64_tr_b16 transpose reads), so no cross-lane traffic is needed;
+//   * output is token-major [M, d] (head-interleaved) so out_lin consumes it directly.
+#include "common.hpp"
+
+namespace {
+
+template <int DH> struct AttnCfg {
+  static constexpr int ROWB = DH * 2;        // bytes per K/V row in LDS
+  static constexpr int CH = DH / 8;          // 16-B chunks per row
+  static constexpr int RPI = 1024 / ROWB;    // rows per LDS-DMA wave instruction
+  static constexpr int KK = DH / 32;         // MFMA k-steps across the head dim
+  static constexpr int NT = DH / 16;         // 16-wide tiles across the head dim
+  // chunk swizzle (only needed, and only bijective within a row, for 128-B rows)
+  static __device__ __forceinline__ int swz(int chunk, int row) { return DH == 64 ? (chunk ^ (row & 7)) : chunk; }
+};
+
+__device__ __forceinline__ bf16x4 lds_tr16(const char* p) {
+  s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+  return __builtin_bit_cast(bf16x4, v);
+}
+__device__ __forceinline__ bf16x8 cat8(bf16x4 a, bf16x4 b) {
+  return bf16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+
+// Stage `nrows` rows (clamped to the last valid row `S-1`) of a [S, DH] head slice whose rows
+// are `ld` elements apart into LDS as [nrows][DH] with the chunk swizzle.
+template <int DH>
+__device__ __forceinline__ void stage_rows(const bf16* __restrict__ g, size_t ld, int S, int nrows, char* lds,
+                                           int wid, int lane) {
+  using Cf = AttnCfg<DH>;
+  const int rin = lane / Cf::CH, c = lane % Cf::CH;
+  const int ninstr = (nrows + Cf::RPI - 1) / Cf::RPI;
+  for (int i = wid; i < ninstr; i += 4) {
+    const int row = i * Cf::RPI + rin;
+    const int gr = min(row, S - 1);
+    const int gc = Cf::swz(c, row);
+    __builtin_amdgcn_global_load_lds(GLB_PTR(g + (size_t)gr * ld + gc * 8), LDS_PTR(lds + i * 1024), 16, 0, 0);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------
+template <int DH, int KT>
+__global__ __launch_bounds__(256)
+void attn_fwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keylen, bf16* __restrict__ ctx,
+                     float* __restrict__ lse, int S, int H, int dmodel, uint32_t seed, uint32_t thresh24,
+                     float inv_keep) {
+  using Cf = AttnCfg<DH>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  const int nt = (S + 15) >> 4;    // 16-key tiles == 16-query blocks
+  const int nk = (S + 31) >> 5;    // 32-key MFMA steps of P V
+  const size_t ld = 3 * (size_t)dmodel;
+  const bf16* Qg = qkv + (size_t)b * S * ld + h * DH;
+  const bf16* Kg = Qg + dmodel;
+  const bf16* Vg = Qg + 2 * dmodel;
+  char* sK = smem;
+  char* sV = smem + nt * 16 * Cf::ROWB;
+  stage_rows<DH>(Kg, ld, S, nt * 16, sK, wid, lane);
+  stage_rows<DH>(Vg, ld, S, nk * 32, sV, wid, lane);
+  const int klen = keylen[b];
+  __syncthreads();
+
+  const int fq = lane & 15, fg = lane >> 4;
+  // K fragment: row 16t + fq, chunk (4kk + fg) swizzled with row & 7 == fq & 7
+  int k_off[Cf::KK];
+#pragma unroll
+  for (int kk = 0; kk < Cf::KK; ++kk) k_off[kk] = fq * Cf::ROWB + Cf::swz(4 * kk + fg, fq) * 16;
+  // V tr16 read: row R = 32kk + 16jj + 4fg + (fq >> 2), 8-byte piece (fq & 3) of d-tile n
+  const int vrow = 4 * fg + (fq >> 2);
+  int v_off[Cf::NT];
+#pragma unroll
+  for (int n = 0; n < Cf::NT; ++n)
+    v_off[n] = vrow * Cf::ROWB + Cf::swz(2 * n + ((fq & 3) >> 1), vrow) * 16 + 8 * (fq & 1);
+
+  for (int qb = wid; qb < nt; qb += 4) {
+    const int q = qb * 16 + fq;
+    const int qc = min(q, S - 1);
+    bf16x8 qf[Cf::KK];
+#pragma unroll
+    for (int kk = 0; kk < Cf::KK; ++kk)
+      qf[kk] = *reinterpret_cast<const bf16x8*>(Qg + (size_t)qc * ld + 32 * kk + 8 * fg);
+
+    f32x4 s[2 * KT];
+#pragma unroll
+    for (int t = 0; t < 2 * KT; ++t) {
+      s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (t < nt) {
+#pragma unroll
+        for (int kk = 0; kk < Cf::KK; ++kk) {
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + t * 16 * Cf::ROWB + k_off[kk]);
+          s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], s[t], 0, 0, 0);
+        }
+      }
+    }
+    // ---- softmax over keys (key = 16t + 4fg + r) for query column fq
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 2 * KT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = 16 * t + 4 * fg + r;
+        const float v = (key < klen) ? s[t][r] : -INFINITY;
+        s[t][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2 * KT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = __expf(s[t][r] - mx);
+        s[t][r] = p;
+        sum += p;
+      }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    const uint32_t rbase = (uint32_t)((b * H + h) * S + qc) * (uint32_t)S;
+    bf16x8 pf[KT];
+#pragma unroll
+    for (int kk = 0; kk < KT; ++kk) {
+      float p[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int t = 2 * kk + (j >> 2), r = j & 3;
+        float v = s[t][r] * inv;
+        if (thresh24) {
+          const int key = 16 * t + 4 * fg + r;
+          v = m3p_keep(rbase + (uint32_t)key, seed, thresh24) ? v * inv_keep : 0.f;
+        }
+        p[j] = v;
+      }
+      pf[kk] = bf16x8{(bf16)p[0], (bf16)p[1], (bf16)p[2], (bf16)p[3], (bf16)p[4], (bf16)p[5], (bf16)p[6], (bf16)p[7]};
+    }
+    // ---- O^T[d][q] = sum_key V[key][d] P[q][key]
+    f32x4 o[Cf::NT];
+#pragma unroll
+    for (int n = 0; n < Cf::NT; ++n) o[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < KT; ++kk) {
+      if (kk < nk) {
+#pragma unroll
+        for (int n = 0; n < Cf::NT; ++n) {
+          const char* pv = sV + kk * 32 * Cf::ROWB + v_off[n];
+          const bf16x8 vf = cat8(lds_tr16(pv), lds_tr16(pv + 16 * Cf::ROWB));
+          o[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[kk], o[n], 0, 0, 0);
+        }
+      }
+    }
+    if (q < S) {
+      bf16* op = ctx + (size_t)(b * S + q) * dmodel + h * DH + 4 * fg;
+#pragma unroll
+      for (int n = 0; n < Cf::NT; ++n)
+        *reinterpret_cast<bf16x4*>(op + 16 * n) = bf16x4{(bf16)o[n][0], (bf16)o[n][1], (bf16)o[n][2], (bf16)o[n][3]};
+      if (fg == 0) lse[(size_t)(b * H + h) * S + q] = mx + __logf(sum);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// backward
+//   D[q]  = sum_d dO[q][d] O[q][d]
+//   P     = exp(S - lse);  Pd = dropout(P)
+//   dV    = Pd^T dO ;  dPd = dO V^T ;  dS = P * (drop'(dPd) - D)
+//   dQ    = dS K (then * 1/sqrt(dh): q was stored pre-scaled) ;  dK = dS^T Q
+// Phase A (a wave owns 16-key blocks, Q and dO in LDS): S = Q K^T in the un-swapped
+//   orientation (lane = key column, 4 queries per tile) so P and dS feed the q-contraction
+//   MFMAs of dV^T / dK^T directly from registers.
+// Phase B (a wave owns 16-query blocks, K and V in LDS): the swapped orientation again
+//   (lane = query column) so dS^T feeds dQ^T = K^T dS^T from registers.
+// The scores are recomputed in both phases: MFMA time is cheap here, LDS transposes are not.
+// ---------------------------------------------------------------------------------------
+template <int DH, int KT>
+__global__ __launch_bounds__(256)
+void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keylen, const bf16* __restrict__ ctx,
+                     const bf16* __restrict__ dctx, const float* __restrict__ lse, bf16* __restrict__ dqkv,
+                     float* __restrict__ dbias_qkv, int S, int H, int dmodel, float qscale, uint32_t seed,
+                     uint32_t thresh24, float inv_keep) {
+  using Cf = AttnCfg<DH>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  const int nt = (S + 15) >> 4;
+  const int nk = (S + 31) >> 5;
+  const size_t ld = 3 * (size_t)dmodel;
+  const bf16* Qg = qkv + (size_t)b * S * ld + h * DH;
+  const bf16* Kg = Qg + dmodel;
+  const bf16* Vg = Qg + 2 * dmodel;
+  const bf16* Og = ctx + (size_t)b * S * dmodel + h * DH;
+  const bf16* dOg = dctx + (size_t)b * S * dmodel + h * DH;
+  bf16* dQg = dqkv + (size_t)b * S * ld + h * DH;
+  bf16* dKg = dQg + dmodel;
+  bf16* dVg = dQg + 2 * dmodel;
+  const float* lse_bh = lse + (size_t)(b * H + h) * S;
+  const int klen = keylen[b];
+
+  // LDS: two [nk*32][DH] bf16 tiles + lse[nk*32] + D[nk*32] (fp32)
+  const int tile_bytes = nk * 32 * Cf::ROWB;
+  char* s0 = smem;                    // phase A: Q   | phase B: K
+  char* s1 = smem + tile_bytes;       // phase A: dO  | phase B: V
+  float* sL = reinterpret_cast<float*>(smem + 2 * tile_bytes);
+  float* sD = sL + nk * 32;
+
+  const int fq = lane & 15, fg = lane >> 4;
+  int r_off[Cf::KK];   // row-major fragment (row 16t + fq, chunk 4kk + fg)
+#pragma unroll
+  for (int kk = 0; kk < Cf::KK; ++kk) r_off[kk] = fq * Cf::ROWB + Cf::swz(4 * kk + fg, fq) * 16;
+  const int trow = 4 * fg + (fq >> 2);
+  int t_off[Cf::NT];   // tr16 read (row R = 32kk + 16jj + trow, d-tile n)
+#pragma unroll
+  for (int n = 0; n < Cf::NT; ++n)
+    t_off[n] = trow * Cf::ROWB + Cf::swz(2 * n + ((fq & 3) >> 1), trow) * 16 + 8 * (fq & 1);
+
+  // ---- prologue: D[q] = rowsum(dO * O), lse -> LDS (padded rows: D = 0, lse = +inf so P = 0)
+  for (int q = tid; q < nk * 32; q += 256) {
+    float dsum = 0.f, l = INFINITY;
+    if (q < S) {
+      const bf16* op = Og + (size_t)q * dmodel;
+      const bf16* dp = dOg + (size_t)q * dmodel;
+#pragma unroll
+      for (int c = 0; c < DH / 8; ++c) {
+        const bf16x8 ov = *reinterpret_cast<const bf16x8*>(op + 8 * c);
+        const bf16x8 dv = *reinterpret_cast<const bf16x8*>(dp + 8 * c);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dsum += (float)ov[e] * (float)dv[e];
+      }
+      l = lse_bh[q];
+    }
+    sD[q] = dsum;
+    sL[q] = l;
+  }
+  // ================= phase A: dV, dK (wave owns key blocks) =================
+  stage_rows<DH>(Qg, ld, S, nk * 32, s0, wid, lane);
+  stage_rows<DH>(dOg, (size_t)dmodel, S, nk * 32, s1, wid, lane);
+  __syncthreads();
+
+  float bsum_k[Cf::NT][4], bsum_v[Cf::NT][4];   // bias-gradient partial sums (columns 16n+4fg+r)
+#pragma unroll
+  for (int n = 0; n < Cf::NT; ++n)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bsum_k[n][r] = bsum_v[n][r] = 0.f;
+
+  for (int kb = wid; kb < nt; kb += 4) {
+    const int key = kb * 16 + fq;            // this lane's key column
+    const int keyc = min(key, S - 1);
+    const bool kvalid = key < klen;
+    bf16x8 kf[Cf::KK], vf[Cf::KK];
+#pragma unroll
+    for (int kk = 0; kk < Cf::KK; ++kk) {
+      kf[kk] = *reinterpret_cast<const bf16x8*>(Kg + (size_t)keyc * ld + 32 * kk + 8 * fg);
+      vf[kk] = *reinterpret_cast<const bf16x8*>(Vg + (size_t)keyc * ld + 32 * kk + 8 * fg);
+    }
+    // P / dS for all queries against this key block: tile t covers queries 16t..16t+15,
+    // lane holds query 16t + 4fg + r for key column fq
+    f32x4 pd[2 * KT], ds[2 * KT];
+#pragma unroll
+    for (int t = 0; t < 2 * KT; ++t) {
+      pd[t] = ds[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (t < nt) {
+        f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < Cf::KK; ++kk) {
+          const bf16x8 qf = *reinterpret_cast<const bf16x8*>(s0 + t * 16 * Cf::ROWB + r_off[kk]);
+          const bf16x8 df = *reinterpret_cast<const bf16x8*>(s1 + t * 16 * Cf::ROWB + r_off[kk]);
+          sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf[kk], sc, 0, 0, 0);   // S[q][key]
+          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, vf[kk], dp, 0, 0, 0);   // dPd[q][key]
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int q = 16 * t + 4 * fg + r;
+          const float p = kvalid ? __expf(sc[r] - sL[q]) : 0.f;     // padded q: lse=+inf -> 0
+          float pdrop = p, dpr = dp[r];
+          if (thresh24) {
+            const uint32_t idx = (uint32_t)((b * H + h) * S + min(q, S - 1)) * (uint32_t)S + (uint32_t)keyc;
+            const bool keep = m3p_keep(idx, seed, thresh24);
+            pdrop = keep ? p * inv_keep : 0.f;
+            dpr = keep ? dpr * inv_keep : 0.f;
+          }
+          pd[t][r] = pdrop;
+          ds[t][r] = p * (dpr - sD[q]);
+        }
+      }
+    }
+    // dV^T[d][key] = sum_q dO[q][d] Pd[q][key] ; dK^T[d][key] = sum_q Q[q][d] dS[q][key]
+    f32x4 dv[Cf::NT], dk[Cf::NT];
+#pragma unroll
+    for (int n = 0; n < Cf::NT; ++n) dv[n] = dk[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < KT; ++kk) {
+      if (kk < nk) {
+        const f32x4 a = pd[2 * kk], c = pd[2 * kk + 1], e = ds[2 * kk], f = ds[2 * kk + 1];
+        const bf16x8 pfrag = bf16x8{(bf16)a[0], (bf16)a[1], (bf16)a[2], (bf16)a[3], (bf16)c[0], (bf16)c[1], (bf16)c[2], (bf16)c[3]};
+        const bf16x8 sfrag = bf16x8{(bf16)e[0], (bf16)e[1], (bf16)e[2], (bf16)e[3], (bf16)f[0], (bf16)f[1], (bf16)f[2], (bf16)f[3]};
+#pragma unroll
+        for (int n = 0; n < Cf::NT; ++n) {
+          const char* pq = s0 + kk * 32 * Cf::ROWB + t_off[n];
+          const char* pdo = s1 + kk * 32 * Cf::ROWB + t_off[n];
+          const bf16x8 qT = cat8(lds_tr16(pq), lds_tr16(pq + 16 * Cf::ROWB));
+          const bf16x8 dT = cat8(lds_tr16(pdo), lds_tr16(pdo + 16 * Cf::ROWB));
+          dv[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dT, pfrag, dv[n], 0, 0, 0);
+          dk[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qT, sfrag, dk[n], 0, 0, 0);
+        }
+      }
+    }
+    if (key < S) {
+      bf16* pk = dKg + (size_t)key * ld + 4 * fg;
+      bf16* pv = dVg + (size_t)key * ld + 4 * fg;
+#pragma unroll
+      for (int n = 0; n < Cf::NT; ++n) {
+        const bf16x4 kb4 = bf16x4{(bf16)dk[n][0], (bf16)dk[n][1], (bf16)dk[n][2], (bf16)dk[n][3]};
+        const bf16x4 vb4 = bf16x4{(bf16)dv[n][0], (bf16)dv[n][1], (bf16)dv[n][2], (bf16)dv[n][3]};
+        *reinterpret_cast<bf16x4*>(pk + 16 * n) = kb4;
+        *reinterpret_cast<bf16x4*>(pv + 16 * n) = vb4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { bsum_k[n][r] += (float)kb4[r]; bsum_v[n][r] += (float)vb4[r]; }
+      }
+    }
+  }
+  __syncthreads();   // everyone done with Q / dO tiles
+
+  // ================= phase B: dQ (wave owns query blocks) =================
+  stage_rows<DH>(Kg, ld, S, nk * 32, s0, wid, lane);
+  stage_rows<DH>(Vg, ld, S, nk * 32, s1, wid, lane);
+  __syncthreads();
+
+  float bsum_q[Cf::NT][4];
+#pragma unroll
+  for (int n = 0; n < Cf::NT; ++n)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bsum_q[n][r] = 0.f;
+
+  for (int qb = wid; qb < nt; qb += 4) {
+    const int q = qb * 16 + fq;
+    const int qc = min(q, S - 1);
+    bf16x8 qf[Cf::KK], df[Cf::KK];
+#pragma unroll
+    for (int kk = 0; kk < Cf::KK; ++kk) {
+      qf[kk] = *reinterpret_cast<const bf16x8*>(Qg + (size_t)qc * ld + 32 * kk + 8 * fg);
+      df[kk] = *reinterpret_cast<const bf16x8*>(dOg + (size_t)qc * dmodel + 32 * kk + 8 * fg);
+    }
+    const float lq = sL[q], dq_ = sD[q];
+    const uint32_t rbase = (uint32_t)((b * H + h) * S + qc) * (uint32_t)S;
+    f32x4 ds[2 * KT];
+#pragma unroll
+    for (int t = 0; t < 2 * KT; ++t) {
+      ds[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (t < nt) {
+        f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < Cf::KK; ++kk) {
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(s0 + t * 16 * Cf::ROWB + r_off[kk]);
+          const bf16x8 vf = *reinterpret_cast<const bf16x8*>(s1 + t * 16 * Cf::ROWB + r_off[kk]);
+          sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], sc, 0, 0, 0);   // S^T[key][q]
+          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, df[kk], dp, 0, 0, 0);   // dPd^T[key][q]
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = 16 * t + 4 * fg + r;
+          const float p = (key < klen) ? __expf(sc[r] - lq) : 0.f;
+          float dpr = dp[r];
+          if (thresh24) dpr = m3p_keep(rbase + (uint32_t)min(key, S - 1), seed, thresh24) ? dpr * inv_keep : 0.f;
+          ds[t][r] = p * (dpr - dq_);
+        }
+      }
+    }
+    // dQ^T[d][q] = sum_key K[key][d] dS[q][key]
+    f32x4 dq[Cf::NT];
+#pragma unroll
+    for (int n = 0; n < Cf::NT; ++n) dq[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < KT; ++kk) {
+      if (kk < nk) {
+        const f32x4 e = ds[2 * kk], f = ds[2 * kk + 1];
+        const bf16x8 sfrag = bf16x8{(bf16)e[0], (bf16)e[1], (bf16)e[2], (bf16)e[3], (bf16)f[0], (bf16)f[1], (bf16)f[2], (bf16)f[3]};
+#pragma unroll
+        for (int n = 0; n < Cf::NT; ++n) {
+          const char* pk = s0 + kk * 32 * Cf::ROWB + t_off[n];
+          const bf16x8 kT = cat8(lds_tr16(pk), lds_tr16(pk + 16 * Cf::ROWB));
+          dq[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kT, sfrag, dq[n], 0, 0, 0);
+        }
+      }
+    }
+    if (q < S) {
+      bf16* pq = dQg + (size_t)q * ld + 4 * fg;
+#pragma unroll
+      for (int n = 0; n < Cf::NT; ++n) {
+        const bf16x4 qb4 = bf16x4{(bf16)(dq[n][0] * qscale), (bf16)(dq[n][1] * qscale), (bf16)(dq[n][2] * qscale),
+                                  (bf16)(dq[n][3] * qscale)};
+        *reinterpret_cast<bf16x4*>(pq + 16 * n) = qb4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bsum_q[n][r] += (float)qb4[r];
+      }
+    }
+  }
+
+  // ---- bias gradients: column sums of the bf16 dQ/dK/dV this block wrote
+  if (dbias_qkv) {
+#pragma unroll
+    for (int n = 0; n < Cf::NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float a = bsum_q[n][r], c = bsum_k[n][r], e = bsum_v[n][r];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+          a += __shfl_xor(a, o, 64); c += __shfl_xor(c, o, 64); e += __shfl_xor(e, o, 64);
+        }
+        if (fq == 0) {
+          const int col = h * DH + 16 * n + 4 * fg + r;
+          atomicAdd(dbias_qkv + col, a);
+          atomicAdd(dbias_qkv + dmodel + col, c);
+          atomicAdd(dbias_qkv + 2 * dmodel + col, e);
+        }
+      }
+  }
+}
+
+template <int DH>
+int launch_fwd(const bf16* qkv, const int* keylen, bf16* ctx, float* lse, int B, int S, int H, int dmodel,
+               uint32_t seed, uint32_t thresh24, float inv_keep, hipStream_t st) {
+  const int nt = (S + 15) / 16, nk = (S + 31) / 32;
+  const size_t lds = (size_t)(nt * 16 + nk * 32) * DH * 2;
+#define M3P_ATTN_FWD(KT)                                                                                        \
+  do {                                                                                                          \
+    auto kern = attn_fwd_kernel<DH, KT>;                                                                        \
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    if (e != hipSuccess) return (int)e;                                                                         \
+    hipLaunchKernelGGL(kern, dim3(B* H), dim3(256), lds, st, qkv, keylen, ctx, lse, S, H, dmodel, seed,         \
+                       thresh24, inv_keep);                                                                     \
+  } while (0)
+  if (nk <= 6) M3P_ATTN_FWD(6);
+  else if (nk <= 12) M3P_ATTN_FWD(12);
+  else if (nk <= 16) M3P_ATTN_FWD(16);
+  else return M3P_EINVAL;
+#undef M3P_ATTN_FWD
+  M3P_CHECK_LAUNCH();
+  return M3P_OK;
+}
+
+template <int DH>
+int launch_bwd(const bf16* qkv, const int* keylen, const bf16* ctx, const bf16* dctx, const float* lse, bf16* dqkv,
+               float* dbias, int B, int S, int H, int dmodel, float qscale, uint32_t seed, uint32_t thresh24,
+               float inv_keep, hipStream_t st) {
+  const int nk = (S + 31) / 32;
+  const size_t lds = (size_t)2 * nk * 32 * DH * 2 + (size_t)2 * nk * 32 * sizeof(float);
+#define M3P_ATTN_BWD(KT)                                                                                        \
+  do {                                                                                                          \
+    auto kern = attn_bwd_kernel<DH, KT>;                                                                        \
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    if (e != hipSuccess) return (int)e;                                                                         \
+    hipLaunchKernelGGL(kern, dim3(B* H), dim3(256), lds, st, qkv, keylen, ctx, dctx, lse, dqkv, dbias, S, H,    \
+                       dmodel, qscale, seed, thresh24, inv_keep);                                               \
+  } while (0)
+  if (nk <= 6) M3P_ATTN_BWD(6);
+  else if (nk <= 12) M3P_ATTN_BWD(12);
+  else return M3P_EINVAL;
+#undef M3P_ATTN_BWD
+  M3P_CHECK_LAUNCH();
+  return M3P_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int m3p_attn_fwd(const void* qkv, const int32_t* keylen, void* ctx, float* lse, int B, int S, int H, int dh,
+                 uint32_t seed, uint32_t thresh24, float inv_keep, void* stream) {
+  if (B <= 0 || S <= 0 || H <= 0 || S > 512) return M3P_EINVAL;
+  if (((uintptr_t)qkv & 15) || ((uintptr_t)ctx & 7)) return M3P_EINVAL;
+  const int dmodel = H * dh;
+  hipStream_t st = (hipStream_t)stream;
+  if (dh == 64) return launch_fwd<64>((const bf16*)qkv, keylen, (bf16*)ctx, lse, B, S, H, dmodel, seed, thresh24, inv_keep, st);
+  if (dh == 32) return launch_fwd<32>((const bf16*)qkv, keylen, (bf16*)ctx, lse, B, S, H, dmodel, seed, thresh24, inv_keep, st);
+  return M3P_EINVAL;
+}
+
+int m3p_attn_bwd(const void* qkv, const int32_t* keylen, const void* ctx, const void* dctx, const float* lse,
+                 void* dqkv, float* dbias_qkv, int B, int S, int H, int dh, float qscale, uint32_t seed,
+                 uint32_t thresh24, float inv_keep, void* stream) {
+  if (B <= 0 || S <= 0 || H <= 0 || S > 384) return M3P_EINVAL;
+  if (((uintptr_t)qkv & 15) || ((uintptr_t)ctx & 15) || ((uintptr_t)dctx & 15) || ((uintptr_t)dqkv & 7)) return M3P_EINVAL;
+  const int dmodel = H * dh;
+  hipStream_t st = (hipStream_t)stream;
+  if (dh == 64)
+    return launch_bwd<64>((const bf16*)qkv, keylen, (const bf16*)ctx, (const bf16*)dctx, lse, (bf16*)dqkv, dbias_qkv, B, S, H,
+                          dmodel, qscale, seed, thresh24, inv_keep, st);
+  if (dh == 32)
+    return launch_bwd<32>((const bf16*)qkv, keylen, (const bf16*)ctx, (const bf16*)dctx, lse, (bf16*)dqkv, dbias_qkv, B, S, H,
+                          dmodel, qscale, seed, thresh24, inv_keep, st);
+  return M3P_EINVAL;
+}
+
+}  // extern "C"

@@ -17,10 +17,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 
-// error codes of the C ABI (0 = ok); positive values are hipError_t
-#define M3P_OK 0
-#define M3P_EINVAL -1   // bad shape / alignment / unsupported size
-#define M3P_ENOTIMPL -2
+#include "../../include/m3p_hip.h"   // error codes + the C ABI being implemented
 
 #define M3P_CHECK_LAUNCH()                                   \
   do {                                                       \

@@ -37,6 +37,8 @@ SIGNATURES = {
     'm3p_gemm_wgrad_bf16': (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _f, _p]),
     'm3p_layernorm_fwd': (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p]),
     'm3p_layernorm_bwd': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _u32, _u32, _f, _p]),
+    'm3p_attn_fwd': (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _u32, _u32, _f, _p]),
+    'm3p_attn_bwd': (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _u32, _u32, _f, _p]),
     'm3p_probe_mfma_16x16x32': (_i, [_p, _p, _p, _p, _p]),
     'm3p_probe_tr16': (_i, [_p, _p, _p]),
 }

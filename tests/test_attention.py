@@ -1,0 +1,84 @@
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from tests.util import randn_bf16, randn_f32, rel_l2, max_abs
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref_attention(qkv, keylen, B, S, H, dh, keep=None, p=0.0):
+    """fp32 restatement of transformer.py:197-205 on an already-projected, q-prescaled qkv."""
+    d = H * dh
+    q, k, v = qkv.view(B, S, 3, H, dh).permute(2, 0, 3, 1, 4)      # (B,H,S,dh)
+    scores = q @ k.transpose(2, 3)
+    mask = torch.arange(S)[None, :] < keylen[:, None]
+    scores = scores.masked_fill(~mask[:, None, None, :], float('-inf'))
+    w = torch.softmax(scores, dim=-1)
+    lse = torch.logsumexp(scores, dim=-1)
+    if keep is not None:
+        w = w * keep / (1 - p)
+    ctx = (w @ v).transpose(1, 2).reshape(B * S, d)
+    return ctx, lse
+
+
+CASES = [(2, 74, 4, 32), (3, 164, 12, 64), (2, 16, 2, 64), (1, 116, 12, 64), (2, 200, 2, 64), (1, 356, 16, 64), (2, 33, 1, 32)]
+
+
+@pytest.mark.parametrize('B,S,H,dh', CASES)
+@pytest.mark.parametrize('p', [0.0, 0.1])
+def test_attention_fwd_bwd(B, S, H, dh, p):
+    from m3p_amd import ops, rng
+    d = H * dh
+    seed = 4242
+    qkv, qkvc = randn_bf16((B * S, 3 * d), 1, 0.7)
+    rs = np.random.RandomState(3)
+    keylen = torch.from_numpy(rs.randint(max(S // 2, 1), S + 1, size=B).astype(np.int32))
+    keylen[0] = S
+    ctx, lse = ops.attn_fwd(qkv, keylen.cuda(), B, S, H, dh, seed=seed, p_drop=p)
+    keep = None
+    if p > 0:
+        keep = torch.from_numpy(rng.keep_mask(B * H * S * S, seed, p, (B, H, S, S))).float()
+    x = qkvc.clone().requires_grad_(True)
+    ctx_ref, lse_ref = _ref_attention(x, keylen.long(), B, S, H, dh, keep, p)
+    assert rel_l2(ctx.float(), ctx_ref) < 6e-3
+    assert max_abs(lse, lse_ref) < 2e-3
+    if S > 384:
+        return
+    dctx, dctxc = randn_bf16((B * S, d), 7)
+    dbias = torch.zeros(3 * d, device='cuda')
+    dqkv = ops.attn_bwd(qkv, keylen.cuda(), ctx, dctx, lse, B, S, H, dh, dbias_qkv=dbias, seed=seed, p_drop=p)
+    ctx_ref.backward(dctxc)
+    g = x.grad.clone()
+    g[:, :d] *= 1.0 / math.sqrt(dh)       # kernel returns the gradient of the unscaled q projection
+    for name, sl in (('dq', slice(0, d)), ('dk', slice(d, 2 * d)), ('dv', slice(2 * d, 3 * d))):
+        assert rel_l2(dqkv[:, sl].float(), g[:, sl]) < 1.5e-2, name
+    assert rel_l2(dbias, dqkv.float().sum(0)) < 1e-4
+
+
+def test_attention_perf_smoke():
+    from m3p_amd import ops
+    B, S, H, dh = 256, 164, 12, 64
+    d = H * dh
+    qkv, _ = randn_bf16((B * S, 3 * d), 1, 0.7)
+    keylen = torch.full((B,), S, dtype=torch.int32, device='cuda')
+    for p in (0.0, 0.1):
+        ctx, lse = ops.attn_fwd(qkv, keylen, B, S, H, dh, seed=1, p_drop=p)
+        dctx = torch.randn_like(ctx)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            ops.attn_fwd(qkv, keylen, B, S, H, dh, seed=1, p_drop=p)
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        fl = 4.0 * B * H * S * S * dh
+        print('attn_fwd p=%.1f: %.3f ms  %.1f TF' % (p, ms, fl / ms / 1e9))
+        e0.record()
+        for _ in range(10):
+            ops.attn_bwd(qkv, keylen, ctx, dctx, lse, B, S, H, dh, seed=1, p_drop=p)
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        print('attn_bwd p=%.1f: %.3f ms  %.1f TF (algorithmic 2x fwd)' % (p, ms, 2 * fl / ms / 1e9))
