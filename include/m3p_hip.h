@@ -128,6 +128,86 @@ M3P_API int m3p_attn_bwd(const void* qkv, const int32_t* keylen, const void* ctx
                          float qscale, uint32_t seed, uint32_t thresh24, float inv_keep, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * Input assembly of jointfwd (transformer.py:901-943) and its backward
+ * ---------------------------------------------------------------------------------- */
+
+/* fp32 -> bf16 (the region features / any fp32 input that feeds a GEMM). n % 4 == 0. */
+M3P_API int m3p_cast_f32_bf16(const float* src, void* dst, long long n, void* stream);
+
+/* Builds the encoder input h[B*S, d] (bf16, batch-major rows b*S+s, S = R+T):
+ *   image rows s<R : LN_img(img_proj[s*B+b] + W_loc loc[s,b] + b_loc) -> dropout(seed_img)
+ *                    (BertImageEmbeddings.forward, transformer.py:257-268; img_proj is the
+ *                    W_img x + b GEMM output in the caller's sequence-major row order)
+ *   token rows     : emb[tok[t,b]]                                       (:913)
+ *   then + pos[s], * (s < totlen[b]), LN_emb, dropout(seed_emb)          (:936-943)
+ * Saves z (LN_emb input) / e (LN_img input) and the LayerNorm statistics for backward.
+ * tok int64 (T,B); emb bf16 [V,d]; pos,w_loc,b_loc,gammas,betas fp32; loc fp32 (R,B,5). */
+M3P_API int m3p_embed_assemble_fwd(const int64_t* tok, const void* emb_bf16, const float* pos,
+                                   const void* img_proj, const float* loc, const float* w_loc,
+                                   const float* b_loc, const float* g_img, const float* be_img,
+                                   const float* g_emb, const float* be_emb, const int32_t* totlen,
+                                   void* h, void* z, float* mean_emb, float* rstd_emb, void* e,
+                                   float* mean_img, float* rstd_img, int B, int T, int R, int d,
+                                   uint32_t seed_img, uint32_t seed_emb, uint32_t thresh24, float inv_keep,
+                                   void* stream);
+
+/* Backward of the above given dh[B*S,d].  Accumulates (fp32 atomics) into the parameter
+ * gradients d_g_emb,d_be_emb [d], d_pos [S,d] (first S rows of position_embeddings),
+ * d_emb [V,d] (scatter-add over token ids, rows of pad_index skipped like
+ * nn.Embedding(padding_idx)), d_g_img,d_be_img,d_b_img,d_b_loc [d], d_w_loc [d,5]; writes
+ * de [R*B,d] (bf16, gradient of img_proj, rows s*B+b) for the W_img weight-gradient GEMM.
+ * dz_scratch: bf16 [B*S,d] workspace. */
+M3P_API int m3p_embed_assemble_bwd(const void* dh, const void* z, const float* mean_emb, const float* rstd_emb,
+                                   const float* g_emb, const void* e, const float* mean_img,
+                                   const float* rstd_img, const float* g_img, const int64_t* tok,
+                                   const int32_t* totlen, const float* loc, void* dz_scratch, void* de,
+                                   float* d_g_emb, float* d_be_emb, float* d_pos, float* d_emb,
+                                   float* d_g_img, float* d_be_img, float* d_b_img, float* d_b_loc,
+                                   float* d_w_loc, int B, int T, int R, int d, int pad_index,
+                                   uint32_t seed_img, uint32_t seed_emb, uint32_t thresh24, float inv_keep,
+                                   void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Heads (TransformerModel.predict, transformer.py:1183-1214; PredLayer :104-117)
+ * ---------------------------------------------------------------------------------- */
+
+/* dst[i,:] = src[idx[i],:] — the boolean-mask gather of :1208 with precomputed row indices */
+M3P_API int m3p_gather_rows(const void* src, const int32_t* idx, void* dst, int n, int d, void* stream);
+/* dst[idx[i],:] += src[i,:] (idx unique) — its backward */
+M3P_API int m3p_scatter_add_rows(const void* src, const int32_t* idx, void* dst, int n, int d, void* stream);
+
+/* F.cross_entropy over bf16 logits [n_rows, ld] (V valid columns), per-row loss to
+ * row_loss, loss_sum += loss_scale * sum(row losses), and IN PLACE
+ * logits <- (softmax - onehot(target)) * grad_scale, padding columns [V, ld) zeroed. */
+M3P_API int m3p_ce_fwd_bwd(void* logits, int ld, int n_rows, int V, const int64_t* target, float* row_loss,
+                           float* loss_sum, float loss_scale, float grad_scale, void* stream);
+
+/* out[c] += scale * sum_r x[r,c] for c < ncols (x bf16 [n, ld]); scale read from the
+ * device scalar *scale_ptr (NULL = 1): the vocabulary-bias gradient colsum(dlogits). */
+M3P_API int m3p_colsum_bf16(const void* x, int ld, int n, int ncols, float* out, const float* scale_ptr,
+                            void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Optimizer path (Trainer.optimize xtrainer.py:205-243; Adam.step optim.py:45-86)
+ * ---------------------------------------------------------------------------------- */
+
+/* *out += sum(g^2) in double (clip_grad_norm_, xtrainer.py:225). n % 4 == 0. */
+M3P_API int m3p_sumsq_f32(const float* g, long long n, double* out, void* stream);
+
+/* One fused pass over a flat fp32 range:  g' = g * grad_scale * clip_coef,
+ *   clip_coef = min(1, max_norm / (sqrt(*gnorm_sq) * grad_scale + 1e-6))   (if gnorm_sq && max_norm > 0)
+ *   m = b1 m + (1-b1) g';  v = b2 v + (1-b2) g'^2;  p -= wd*lr*p;  p -= step_size * m / (sqrt(v) + eps)
+ * step_size = lr * sqrt(1-b2^t)/(1-b1^t) is computed by the caller (optim.py:78-80).
+ * Also refreshes the bf16 working copy w16 (if not NULL) and zeroes g (if zero_grad). */
+M3P_API int m3p_adam_step(float* p, float* g, float* m, float* v, void* w16, long long n, float lr, float beta1,
+                          float beta2, float eps, float weight_decay, float step_size, const double* gnorm_sq,
+                          float max_norm, float grad_scale, int zero_grad, void* stream);
+
+/* dst[c, r] = src[r, c] (bf16): transposed weight copies for the data-gradient GEMMs */
+M3P_API int m3p_transpose_bf16(const void* src, void* dst, int rows, int cols, int ld_src, int ld_dst,
+                               void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Hardware-semantics probes (used by tests/test_hw_probes.py only): each fills `out`
  * with what the instruction delivered so the test can compare with the documented map.
  * ---------------------------------------------------------------------------------- */

@@ -82,6 +82,10 @@ template <> struct Vec4<bf16> {
   }
 };
 
+__device__ __forceinline__ f32x4 round_bf16(f32x4 v) {
+  return f32x4{(float)(bf16)v[0], (float)(bf16)v[1], (float)(bf16)v[2], (float)(bf16)v[3]};
+}
+
 // XCD-aware remap of a 1-D block id: each of the 8 XCDs (private L2) gets a contiguous
 // run of logical ids; bijective for any grid size (cdna guide T1).
 __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {

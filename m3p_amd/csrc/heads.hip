@@ -1,0 +1,151 @@
+// Prediction heads of TransformerModel.predict (M3P/src/model/transformer.py:1183-1214):
+//   * row gather / scatter for the masked-LM positions (:1208 boolean-mask gather)
+//   * cross-entropy over the vocabulary logits (PredLayer.forward :104-117,
+//     F.cross_entropy(mean)) with the gradient written in place of the logits.
+// The vocabulary projection itself is m3p_gemm_nt_bf16 against the tied embedding.
+#include "common.hpp"
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+namespace {
+
+// dst[i,:] = src[idx[i],:]   (rows of d bf16, 8-byte chunks)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const bf16* __restrict__ src, const int32_t* __restrict__ idx,
+                                                          bf16* __restrict__ dst, int n, int d) {
+  const int nchunk = d >> 2;
+  const size_t total = (size_t)n * nchunk;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / nchunk), c = (int)(i - (size_t)r * nchunk);
+    *reinterpret_cast<bf16x4*>(dst + (size_t)r * d + 4 * c) =
+        *reinterpret_cast<const bf16x4*>(src + (size_t)idx[r] * d + 4 * c);
+  }
+}
+// dst[idx[i],:] += src[i,:]  (idx unique -> plain read-modify-write)
+__global__ __launch_bounds__(256) void scatter_add_rows_kernel(const bf16* __restrict__ src, const int32_t* __restrict__ idx,
+                                                               bf16* __restrict__ dst, int n, int d) {
+  const int nchunk = d >> 2;
+  const size_t total = (size_t)n * nchunk;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / nchunk), c = (int)(i - (size_t)r * nchunk);
+    bf16* p = dst + (size_t)idx[r] * d + 4 * c;
+    Vec4<bf16>::store(p, Vec4<bf16>::load(p) + Vec4<bf16>::load(src + (size_t)r * d + 4 * c));
+  }
+}
+
+// One block per row.  Online (max, sum-exp) pass over V bf16 logits, then the gradient
+// pass: dlogits = (softmax - onehot) * gscale, padding columns [V, ld) zeroed so the
+// gradient tensor can be contracted over the padded pitch.
+__global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(bf16* __restrict__ logits, int ld, int V,
+                                                         const int64_t* __restrict__ target, float* __restrict__ row_loss,
+                                                         float* __restrict__ loss_sum, float loss_scale, float gscale) {
+  __shared__ float s_m[4], s_s[4];
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
+  bf16* lr = logits + (size_t)row * ld;
+  const int nchunk = ld >> 2;
+  float m = -INFINITY, s = 0.f;
+  for (int c = tid; c < nchunk; c += 256) {
+    const f32x4 v = Vec4<bf16>::load(lr + 4 * c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (4 * c + j < V) {
+        const float x = v[j];
+        if (x > m) { s = s * __expf(m - x) + 1.f; m = x; }
+        else s += __expf(x - m);
+      }
+    }
+  }
+  // combine (m, s) pairs across the wave, then across the 4 waves
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s, o, 64);
+    const float mm = fmaxf(m, m2);
+    s = (m == -INFINITY ? 0.f : s * __expf(m - mm)) + (m2 == -INFINITY ? 0.f : s2 * __expf(m2 - mm));
+    m = mm;
+  }
+  if (lane == 0) { s_m[wib] = m; s_s[wib] = s; }
+  __syncthreads();
+  float M = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+  float Ssum = 0.f;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) Ssum += (s_m[w] == -INFINITY) ? 0.f : s_s[w] * __expf(s_m[w] - M);
+  const float lse = M + __logf(Ssum);
+  const int64_t tgt = target[row];
+  if (tid == 0) {
+    const float l = lse - (float)lr[tgt];
+    row_loss[row] = l;
+    unsafeAtomicAdd(loss_sum, l * loss_scale);
+  }
+  __syncthreads();   // row_loss read of lr[tgt] happens before the in-place overwrite below
+  for (int c = tid; c < nchunk; c += 256) {
+    const f32x4 v = Vec4<bf16>::load(lr + 4 * c);
+    f32x4 g;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = 4 * c + j;
+      float p = (col < V) ? __expf(v[j] - lse) : 0.f;
+      if (col == tgt) p -= 1.f;
+      g[j] = p * gscale;
+    }
+    Vec4<bf16>::store(lr + 4 * c, g);
+  }
+}
+
+// out[c] += scale * sum_r x[r, c]   (x bf16 [n, ld], c < ncols); rows split over gridDim.y
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ x, int ld, int n, int ncols,
+                                                     float* __restrict__ out, const float* __restrict__ scale_ptr) {
+  const int c4 = blockIdx.x * blockDim.x + threadIdx.x;
+  if (4 * c4 >= ncols) return;
+  const int rows_per = (n + gridDim.y - 1) / gridDim.y;
+  const int r0 = blockIdx.y * rows_per, r1 = min(n, r0 + rows_per);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int r = r0; r < r1; ++r) acc += Vec4<bf16>::load(x + (size_t)r * ld + 4 * c4);
+  const float sc = scale_ptr ? *scale_ptr : 1.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (4 * c4 + j < ncols) unsafeAtomicAdd(out + 4 * c4 + j, acc[j] * sc);
+}
+
+}  // namespace
+
+extern "C" {
+
+int m3p_colsum_bf16(const void* x, int ld, int n, int ncols, float* out, const float* scale_ptr, void* stream) {
+  if (n <= 0 || ncols <= 0 || (ld % 4) != 0 || ld < ((ncols + 3) / 4) * 4) return M3P_EINVAL;
+  const int c4 = (ncols + 3) / 4;
+  int ysplit = 1;
+  while (ysplit < 64 && ((c4 + 255) / 256) * ysplit < 1024 && n / (ysplit * 2) >= 16) ysplit *= 2;
+  hipLaunchKernelGGL(colsum_kernel, dim3((c4 + 255) / 256, ysplit), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, ld,
+                     n, ncols, out, scale_ptr);
+  M3P_CHECK_LAUNCH();
+  return M3P_OK;
+}
+
+int m3p_gather_rows(const void* src, const int32_t* idx, void* dst, int n, int d, void* stream) {
+  if (n <= 0) return M3P_OK;
+  if ((d % 4) != 0) return M3P_EINVAL;
+  const size_t total = (size_t)n * (d / 4);
+  const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)src, idx, (bf16*)dst, n, d);
+  M3P_CHECK_LAUNCH();
+  return M3P_OK;
+}
+
+int m3p_scatter_add_rows(const void* src, const int32_t* idx, void* dst, int n, int d, void* stream) {
+  if (n <= 0) return M3P_OK;
+  if ((d % 4) != 0) return M3P_EINVAL;
+  const size_t total = (size_t)n * (d / 4);
+  const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)src, idx, (bf16*)dst, n, d);
+  M3P_CHECK_LAUNCH();
+  return M3P_OK;
+}
+
+int m3p_ce_fwd_bwd(void* logits, int ld, int n_rows, int V, const int64_t* target, float* row_loss, float* loss_sum,
+                   float loss_scale, float grad_scale, void* stream) {
+  if (n_rows <= 0 || V <= 0 || ld < V || (ld % 4) != 0 || ((uintptr_t)logits & 7)) return M3P_EINVAL;
+  hipLaunchKernelGGL(ce_fwd_bwd_kernel, dim3(n_rows), dim3(256), 0, (hipStream_t)stream, (bf16*)logits, ld, V, target,
+                     row_loss, loss_sum, loss_scale, grad_scale);
+  M3P_CHECK_LAUNCH();
+  return M3P_OK;
+}
+
+}  // extern "C"

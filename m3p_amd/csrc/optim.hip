@@ -1,0 +1,115 @@
+// Optimizer path of Trainer.optimize (M3P/src/xtrainer.py:205-243) on flat fp32 arenas:
+//   * global gradient L2 norm (clip_grad_norm_, xtrainer.py:225) as one streaming reduction
+//   * Adam.step (M3P/src/optim.py:45-86) fused with the clip scaling, the refresh of the
+//     bf16 working copy the GEMMs read, and zero_grad — one pass over p, g, m, v.
+//   * bf16 transposes of the weight copies used by the data-gradient GEMMs.
+// All HBM-bound: 16-byte accesses, grid-stride.
+#include "common.hpp"
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+namespace {
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, size_t n4, double* __restrict__ out) {
+  __shared__ double red[4];
+  float acc = 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const f32x4 v = Vec4<float>::load(g + 4 * i);
+    acc += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = (double)acc;
+  __syncthreads();
+  if (threadIdx.x == 0) unsafeAtomicAdd(out, (red[0] + red[1]) + (red[2] + red[3]));
+}
+
+struct AdamArgs {
+  float* p; float* g; float* m; float* v; bf16* w16;
+  size_t n4;
+  float lr, beta1, beta2, eps, weight_decay, step_size;
+  const double* gnorm_sq;   // device scalar: sum of squares of ALL gradients (or NULL)
+  float max_norm;           // <= 0: no clipping
+  float grad_scale;         // extra multiplier on g (1/world for DP averaging, loss-scale inverse)
+  int zero_grad;
+};
+
+__global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
+  float coef = a.grad_scale;
+  if (a.gnorm_sq && a.max_norm > 0.f) {
+    // torch.nn.utils.clip_grad_norm_: coef = max_norm / (norm + 1e-6), clamped to 1
+    const float norm = (float)sqrt(*a.gnorm_sq) * a.grad_scale;
+    const float c = a.max_norm / (norm + 1e-6f);
+    coef *= (c < 1.f) ? c : 1.f;
+  }
+  const float ob1 = 1.f - a.beta1, ob2 = 1.f - a.beta2, wdl = a.weight_decay * a.lr;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n4; i += (size_t)gridDim.x * blockDim.x) {
+    f32x4 p = Vec4<float>::load(a.p + 4 * i);
+    const f32x4 g = Vec4<float>::load(a.g + 4 * i) * coef;
+    f32x4 m = Vec4<float>::load(a.m + 4 * i) * a.beta1 + g * ob1;
+    f32x4 v = Vec4<float>::load(a.v + 4 * i) * a.beta2 + g * g * ob2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float denom = sqrtf(v[j]) + a.eps;
+      if (wdl != 0.f) p[j] -= wdl * p[j];
+      p[j] -= a.step_size * (m[j] / denom);
+    }
+    Vec4<float>::store(a.p + 4 * i, p);
+    Vec4<float>::store(a.m + 4 * i, m);
+    Vec4<float>::store(a.v + 4 * i, v);
+    if (a.w16) Vec4<bf16>::store(a.w16 + 4 * i, p);
+    if (a.zero_grad) Vec4<float>::store(a.g + 4 * i, f32x4{0.f, 0.f, 0.f, 0.f});
+  }
+}
+
+// dst[c][r] = src[r][c], 64x64 tiles through LDS; ld_dst >= rows (pad columns untouched)
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16* __restrict__ src, bf16* __restrict__ dst,
+                                                             int rows, int cols, int ld_src, int ld_dst) {
+  __shared__ bf16 tile[64][66];
+  const int tr = blockIdx.y * 64, tc = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const int r = tr + i, c = tc + tx;
+    tile[i][tx] = (r < rows && c < cols) ? src[(size_t)r * ld_src + c] : (bf16)0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int c = tc + i, r = tr + tx;
+    if (c < cols && r < rows) dst[(size_t)c * ld_dst + r] = tile[tx][i];
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int m3p_sumsq_f32(const float* g, long long n, double* out, void* stream) {
+  if (n <= 0 || (n % 4) != 0 || ((uintptr_t)g & 15)) return M3P_EINVAL;
+  const size_t n4 = (size_t)n / 4;
+  const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, n4, out);
+  M3P_CHECK_LAUNCH();
+  return M3P_OK;
+}
+
+int m3p_adam_step(float* p, float* g, float* m, float* v, void* w16, long long n, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, float step_size, const double* gnorm_sq, float max_norm,
+                  float grad_scale, int zero_grad, void* stream) {
+  if (n <= 0 || (n % 4) != 0) return M3P_EINVAL;
+  if (((uintptr_t)p & 15) || ((uintptr_t)g & 15) || ((uintptr_t)m & 15) || ((uintptr_t)v & 15) || ((uintptr_t)w16 & 7))
+    return M3P_EINVAL;
+  AdamArgs a = {p, g, m, v, (bf16*)w16, (size_t)n / 4, lr, beta1, beta2, eps, weight_decay, step_size, gnorm_sq,
+                max_norm, grad_scale == 0.f ? 1.f : grad_scale, zero_grad};
+  const int blocks = (int)((a.n4 + 255) / 256 < 4096 ? (a.n4 + 255) / 256 : 4096);
+  hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+  M3P_CHECK_LAUNCH();
+  return M3P_OK;
+}
+
+int m3p_transpose_bf16(const void* src, void* dst, int rows, int cols, int ld_src, int ld_dst, void* stream) {
+  if (rows <= 0 || cols <= 0 || ld_src < cols || ld_dst < rows) return M3P_EINVAL;
+  hipLaunchKernelGGL(transpose_bf16_kernel, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16*)src, (bf16*)dst, rows, cols, ld_src, ld_dst);
+  M3P_CHECK_LAUNCH();
+  return M3P_OK;
+}
+
+}  // extern "C"

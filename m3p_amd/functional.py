@@ -1,0 +1,364 @@
+"""Host-side composition of the HIP kernels into the encoder forward/backward and the MLM
+head (autograd boundary).  Everything numeric happens in libm3p_hip.so; this file only
+sequences launches, owns the flat parameter/gradient arenas and tells autograd where the
+boundary is.
+
+Gradient convention ("main-grad"): parameter gradients are accumulated by the kernels
+straight into the fp32 gradient arena that ``param.grad`` views; the autograd Functions
+return ``None`` for parameters.  That is what lets the data-parallel reducer all-reduce a
+layer's gradients (one contiguous arena slice) the moment that layer's backward kernels
+are enqueued, and lets clip+Adam run as flat streaming kernels.
+"""
+import math
+from collections import OrderedDict
+
+import torch
+
+from . import lib as L
+from . import ops
+from . import rng
+
+BF16 = torch.bfloat16
+ALIGN = 64
+
+
+def _round_up(n, a):
+    return (n + a - 1) // a * a
+
+
+class Arena:
+    """Flat storage behind a TransformerModel's hot parameters (see model/transformer.py)."""
+
+    def __init__(self, model):
+        named = model.hot_named_parameters()
+        dev = model.embeddings.weight.device
+        self.device = dev
+        self.model = model
+        self.names = list(named.keys())
+        self.offsets = OrderedDict()
+        off = 0
+        for n, p in named.items():
+            self.offsets[n] = (off, p.numel(), tuple(p.shape))
+            off += _round_up(p.numel(), ALIGN)
+        self.total = off
+        self.master = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.w16 = torch.zeros(off, dtype=BF16, device=dev)
+        for n, p in named.items():
+            o, cnt, shape = self.offsets[n]
+            view = self.master[o:o + cnt].view(shape)
+            view.copy_(p.data)
+            p.data = view
+            p.grad = self.grad[o:o + cnt].view(shape)
+            p._m3p_arena = (self, n)
+        self.params = named
+        d, L_, V = model.dim, model.n_layers, model.n_words
+        self.V_pad = _round_up(V, 64)
+        # transposed bf16 copies for the data-gradient GEMMs
+        self.wt = {}
+        for i in range(L_):
+            self.wt[('qkv', i)] = torch.zeros((d, 3 * d), dtype=BF16, device=dev)
+            self.wt[('out', i)] = torch.zeros((d, d), dtype=BF16, device=dev)
+            self.wt[('lin1', i)] = torch.zeros((d, 4 * d), dtype=BF16, device=dev)
+            self.wt[('lin2', i)] = torch.zeros((4 * d, d), dtype=BF16, device=dev)
+        self.wt['emb'] = torch.zeros((d, self.V_pad), dtype=BF16, device=dev)   # pad columns stay zero
+        # contiguous arena ranges used as gradient buckets (reverse-backward order) and by the optimizer
+        self.layer_ranges = []
+        for i in range(L_):
+            a = self.offsets['attentions.%d.q_lin.weight' % i][0]
+            last = self.offsets['layer_norm2.%d.bias' % i]
+            self.layer_ranges.append((a, last[0] + _round_up(last[1], ALIGN)))
+        self.head_range = (self.offsets['pooled_layer.dense.weight'][0], self.total)
+        self.embed_range = (0, self.layer_ranges[0][0] if L_ else self.head_range[0])
+        self._cast_version = -1
+        self._transposes_stale = True
+        self.grads_known_zero = True
+        self.touched = set()   # names of parameters that received gradient since the last zero_grad
+        self._layer_names = [[n for n in self.names if n.startswith(('attentions.%d.' % i, 'layer_norm1.%d.' % i,
+                                                                     'ffns.%d.' % i, 'layer_norm2.%d.' % i))]
+                             for i in range(L_)]
+
+    def touch(self, *names):
+        self.touched.update(names)
+        self.grads_known_zero = False
+
+    def touch_layer(self, i):
+        self.touched.update(self._layer_names[i])
+        self.grads_known_zero = False
+
+    # ---- views
+    def w(self, name):
+        """bf16 working copy of a parameter."""
+        o, cnt, shape = self.offsets[name]
+        return self.w16[o:o + cnt].view(shape)
+
+    def g(self, name):
+        o, cnt, shape = self.offsets[name]
+        return self.grad[o:o + cnt].view(shape)
+
+    def p(self, name):
+        return self.params[name]
+
+    def qkv_w16(self, i):
+        o = self.offsets['attentions.%d.q_lin.weight' % i][0]
+        d = self.model.dim
+        return self.w16[o:o + 3 * d * d].view(3 * d, d)
+
+    def qkv_wgrad(self, i):
+        o = self.offsets['attentions.%d.q_lin.weight' % i][0]
+        d = self.model.dim
+        return self.grad[o:o + 3 * d * d].view(3 * d, d)
+
+    def qkv_bias(self, i, grad=False):
+        o = self.offsets['attentions.%d.q_lin.bias' % i][0]
+        d = self.model.dim
+        src = self.grad if grad else self.master
+        return src[o:o + 3 * d]
+
+    # ---- freshness of the bf16 copies
+    def mark_master_changed(self):
+        self._cast_version = -1
+        self._transposes_stale = True
+
+    def mark_updated_by_fused_optimizer(self):
+        """Adam wrote master and w16 together through raw pointers: only transposes are stale."""
+        self._cast_version = self.master._version
+        self._transposes_stale = True
+
+    def refresh(self):
+        if self._cast_version != self.master._version:
+            L.check(L.load().m3p_cast_f32_bf16(self.master.data_ptr(), self.w16.data_ptr(), self.total, L.stream()),
+                    'm3p_cast_f32_bf16')
+            self._cast_version = self.master._version
+            self._transposes_stale = True
+        if self._transposes_stale:
+            for i in range(self.model.n_layers):
+                ops.transpose_bf16(self.qkv_w16(i), self.wt[('qkv', i)])
+                ops.transpose_bf16(self.w('attentions.%d.out_lin.weight' % i), self.wt[('out', i)])
+                ops.transpose_bf16(self.w('ffns.%d.lin1.weight' % i), self.wt[('lin1', i)])
+                ops.transpose_bf16(self.w('ffns.%d.lin2.weight' % i), self.wt[('lin2', i)])
+            ops.transpose_bf16(self.w('embeddings.weight'), self.wt['emb'])
+            self._transposes_stale = False
+
+    def zero_grad(self):
+        if not self.grads_known_zero:
+            self.grad.zero_()
+            self.grads_known_zero = True
+        self.touched.clear()
+
+    def after_fused_step(self):
+        """The fused Adam kernel updated master + w16 and zeroed every touched gradient range."""
+        self.mark_updated_by_fused_optimizer()
+        self.touched.clear()
+        self.grads_known_zero = True
+
+
+def _site(kind, layer=0):
+    return {'img': 0, 'emb': 1}.get(kind, 8 + 4 * layer + {'attn_p': 0, 'attn_out': 1, 'ffn': 2}.get(kind, 3))
+
+
+class EncoderFn(torch.autograd.Function):
+    """Embedding assembly + n_layers post-LN transformer layers
+    (TransformerModel.jointfwd, M3P/src/model/transformer.py:901-958; with x_img=None the
+    text stream of crossfwd, :1050-1102).  ``anchor`` is any parameter: it only makes the
+    output require grad; parameter gradients are written to the arena (module docstring)."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, x, lengths, x_img, lengths_img, image_loc, p_drop, p_attn, seed_step):
+        ar = model.arena()
+        ar.refresh()
+        dev = ar.device
+        d, H, nL = model.dim, model.n_heads, model.n_layers
+        dh = d // H
+        T, B = x.shape
+        R = 0 if x_img is None else x_img.shape[0]
+        S = R + T
+        M = B * S
+        seed = lambda kind, i=0: rng.stream_seed(model.base_seed, seed_step, _site(kind, i))   # noqa: E731
+
+        x = x.to(dev).contiguous()
+        totlen = lengths if R == 0 else (lengths + lengths_img)
+        totlen = totlen.to(device=dev, dtype=torch.int32).contiguous()
+        rowmask = (torch.arange(S, device=dev, dtype=torch.int32)[None, :] < totlen[:, None]).to(torch.uint8).contiguous().view(-1)
+
+        ximg16 = img_proj = loc = None
+        if R > 0:
+            ximg16 = ops.cast_bf16(x_img.contiguous().view(R * B, 2048))
+            loc = image_loc.contiguous().float()
+            img_proj = ops.gemm_nt(ximg16, ar.w('image_embeddings.image_embeddings.weight'), L.EPI_BIAS,
+                                   bias=ar.p('image_embeddings.image_embeddings.bias'))
+        h, emb_saved = ops.embed_assemble_fwd(
+            x, ar.w('embeddings.weight'), ar.p('position_embeddings.weight'), img_proj, loc,
+            ar.p('image_embeddings.image_location_embeddings.weight'),
+            ar.p('image_embeddings.image_location_embeddings.bias'),
+            ar.p('image_embeddings.LayerNorm.weight'), ar.p('image_embeddings.LayerNorm.bias'),
+            ar.p('layer_norm_emb.weight'), ar.p('layer_norm_emb.bias'), totlen, B, T, R, d,
+            seed_img=seed('img'), seed_emb=seed('emb'), p_drop=p_drop)
+
+        saved_layers = []
+        qscale = 1.0 / math.sqrt(dh)
+        for i in range(nL):
+            a, f = 'attentions.%d.' % i, 'ffns.%d.' % i
+            qkv = ops.gemm_nt(h, ar.qkv_w16(i), L.EPI_BIAS, bias=ar.qkv_bias(i), scale_cols=d, scale=qscale)
+            ctxt, lse = ops.attn_fwd(qkv, totlen, B, S, H, dh, seed=seed('attn_p', i), p_drop=p_attn)
+            pre1 = ops.gemm_nt(ctxt, ar.w(a + 'out_lin.weight'), L.EPI_BIAS_DROP_RES, bias=ar.p(a + 'out_lin.bias'),
+                               aux=h, seed=seed('attn_out', i), p_drop=p_drop)
+            x1, mean1, rstd1 = ops.layernorm_fwd(pre1, ar.p('layer_norm1.%d.weight' % i), ar.p('layer_norm1.%d.bias' % i))
+            u = torch.empty((M, 4 * d), dtype=BF16, device=dev)
+            hact = ops.gemm_nt(x1, ar.w(f + 'lin1.weight'), L.EPI_BIAS_GELU, bias=ar.p(f + 'lin1.bias'), out2=u)
+            pre2 = ops.gemm_nt(hact, ar.w(f + 'lin2.weight'), L.EPI_BIAS_DROP_RES, bias=ar.p(f + 'lin2.bias'),
+                               aux=x1, seed=seed('ffn', i), p_drop=p_drop)
+            h_next, mean2, rstd2 = ops.layernorm_fwd(pre2, ar.p('layer_norm2.%d.weight' % i),
+                                                     ar.p('layer_norm2.%d.bias' % i), rowmask)
+            saved_layers.append((h, qkv, ctxt, lse, pre1, mean1, rstd1, x1, u, hact, pre2, mean2, rstd2))
+            h = h_next
+
+        ctx.model = model
+        ctx.dims = (B, T, R, S, d, H, dh, nL)
+        ctx.drop = (p_drop, p_attn, seed_step)
+        ctx.saved = (x, totlen, rowmask, ximg16, loc, emb_saved, saved_layers)
+        ctx.set_materialize_grads(False)
+        return h
+
+    @staticmethod
+    def backward(ctx, dout):
+        model = ctx.model
+        ar = model.arena()
+        B, T, R, S, d, H, dh, nL = ctx.dims
+        p_drop, p_attn, seed_step = ctx.drop
+        x, totlen, rowmask, ximg16, loc, emb_saved, saved_layers = ctx.saved
+        ctx.saved = None
+        seed = lambda kind, i=0: rng.stream_seed(model.base_seed, seed_step, _site(kind, i))   # noqa: E731
+        if dout is None:
+            return (None,) * 10
+        dh_ = dout.contiguous()
+        if dh_.dtype != BF16:
+            dh_ = dh_.to(BF16)
+        hook = model.ddp_hook
+        for i in reversed(range(nL)):
+            a, f = 'attentions.%d.' % i, 'ffns.%d.' % i
+            (h_in, qkv, ctxt, lse, pre1, mean1, rstd1, x1, u, hact, pre2, mean2, rstd2) = saved_layers[i]
+            saved_layers[i] = None
+            # LayerNorm2 (+ the layer-end mask) and the FFN dropout
+            dpre2, dY2 = ops.layernorm_bwd(dh_, None, pre2, ar.p('layer_norm2.%d.weight' % i), mean2, rstd2, rowmask,
+                                           ar.g('layer_norm2.%d.weight' % i), ar.g('layer_norm2.%d.bias' % i),
+                                           dbias_drop=ar.g(f + 'lin2.bias'), want_drop=p_drop > 0,
+                                           seed=seed('ffn', i), p_drop=p_drop)
+            if dY2 is None:
+                dY2 = dpre2
+            ops.gemm_wgrad(dY2, hact, ar.g(f + 'lin2.weight'))
+            dU = ops.gemm_nt(dY2, ar.wt[('lin2', i)], L.EPI_DGELU, aux=u, colsum=ar.g(f + 'lin1.bias'))
+            del hact, u, pre2
+            ops.gemm_wgrad(dU, x1, ar.g(f + 'lin1.weight'))
+            dx1 = ops.gemm_nt(dU, ar.wt[('lin1', i)], L.EPI_RES, aux=dpre2)
+            del dU, dpre2, dY2
+            # LayerNorm1 and the attention-output dropout
+            dpre1, dAO = ops.layernorm_bwd(dx1, None, pre1, ar.p('layer_norm1.%d.weight' % i), mean1, rstd1, None,
+                                           ar.g('layer_norm1.%d.weight' % i), ar.g('layer_norm1.%d.bias' % i),
+                                           dbias_drop=ar.g(a + 'out_lin.bias'), want_drop=p_drop > 0,
+                                           seed=seed('attn_out', i), p_drop=p_drop)
+            if dAO is None:
+                dAO = dpre1
+            ops.gemm_wgrad(dAO, ctxt, ar.g(a + 'out_lin.weight'))
+            dctx = ops.gemm_nt(dAO, ar.wt[('out', i)], L.EPI_NONE)
+            dqkv = ops.attn_bwd(qkv, totlen, ctxt, dctx, lse, B, S, H, dh, dbias_qkv=ar.qkv_bias(i, grad=True),
+                                seed=seed('attn_p', i), p_drop=p_attn)
+            ops.gemm_wgrad(dqkv, h_in, ar.qkv_wgrad(i))
+            dh_ = ops.gemm_nt(dqkv, ar.wt[('qkv', i)], L.EPI_RES, aux=dpre1)
+            del dqkv, dctx, dAO, dpre1, dx1
+            ar.touch_layer(i)
+            if hook is not None:
+                hook.layer_done(i)
+        grads = dict(
+            d_g_emb=ar.g('layer_norm_emb.weight'), d_be_emb=ar.g('layer_norm_emb.bias'),
+            d_pos=ar.g('position_embeddings.weight'), d_emb=ar.g('embeddings.weight'),
+            d_g_img=ar.g('image_embeddings.LayerNorm.weight'), d_be_img=ar.g('image_embeddings.LayerNorm.bias'),
+            d_b_img=ar.g('image_embeddings.image_embeddings.bias'),
+            d_b_loc=ar.g('image_embeddings.image_location_embeddings.bias'),
+            d_w_loc=ar.g('image_embeddings.image_location_embeddings.weight'))
+        de = ops.embed_assemble_bwd(dh_, emb_saved, ar.p('layer_norm_emb.weight'),
+                                    ar.p('image_embeddings.LayerNorm.weight'), x, totlen, loc, grads, B, T, R, d,
+                                    model.pad_index, seed_img=seed('img'), seed_emb=seed('emb'), p_drop=p_drop)
+        ar.touch('layer_norm_emb.weight', 'layer_norm_emb.bias', 'position_embeddings.weight', 'embeddings.weight')
+        if R > 0:
+            ops.gemm_wgrad(de, ximg16, ar.g('image_embeddings.image_embeddings.weight'))
+            ar.touch(*[n for n in ar.names if n.startswith('image_embeddings.')])
+        if hook is not None:
+            hook.embed_done()
+        return (None,) * 10
+
+
+class MLMHeadFn(torch.autograd.Function):
+    """predict() default branch: boolean-mask gather (transformer.py:1208), tied vocabulary
+    projection (:111, :728-729) and mean cross-entropy (:112).  The bf16 logits are turned
+    into their own gradient in place by the CE kernel, so backward is two GEMMs."""
+
+    @staticmethod
+    def forward(ctx, tensor, model, base, row_idx, y, scores_out):
+        ar = model.arena()
+        ar.refresh()
+        d, V = model.dim, model.n_words
+        n = int(y.shape[0])
+        hsel = ops.gather_rows(base, row_idx, n, d)
+        logits = torch.empty((n, ar.V_pad), dtype=BF16, device=hsel.device)
+        ops.gemm_nt(hsel, ar.w('embeddings.weight'), L.EPI_BIAS, bias=ar.p('pred_layer.proj.bias'), out=logits, n=V)
+        if scores_out is not None:
+            scores_out.append(logits[:, :V].float())
+        loss_sum, _ = ops.ce_fwd_bwd(logits, V, y, 1.0 / n, 1.0 / n)
+        ctx.model = model
+        ctx.saved = (hsel, logits, row_idx, tuple(tensor.shape), tuple(tensor.stride()), tensor.storage_offset(), base)
+        return loss_sum[0].clone()
+
+    @staticmethod
+    def backward(ctx, gloss):
+        model = ctx.model
+        ar = model.arena()
+        ar.touch('embeddings.weight', 'pred_layer.proj.bias')
+        d, V = model.dim, model.n_words
+        hsel, dlogits, row_idx, shape, stride, soff, base = ctx.saved
+        ctx.saved = None
+        n = hsel.shape[0]
+        g = gloss.reshape(1).float()
+        hs = (hsel.float() * g).to(BF16)
+        ops.gemm_wgrad(dlogits, hs, ar.g('embeddings.weight'), n=V, k=d)
+        ops.colsum(dlogits, V, ar.g('pred_layer.proj.bias'), scale=g)
+        dH = ops.gemm_nt(dlogits, ar.wt['emb'], L.EPI_NONE)
+        dH = (dH.float() * g).to(BF16)
+        # gradient wrt `tensor` (a strided view of the encoder output): build it on a zeroed
+        # twin of the underlying row buffer and hand autograd the same strided view of it
+        dbase = torch.zeros_like(base)
+        ops.scatter_add_rows(dH, row_idx, dbase, n, d)
+        dtensor = torch.as_strided(dbase, shape, stride, soff)
+        return dtensor, None, None, None, None, None
+
+
+def mlm_head(model, tensor, pred_mask, y, want_scores):
+    """Resolve ``tensor`` (T,B,d) — normally the view ``encoder_out[R:]`` — to rows of its
+    underlying contiguous [rows, d] buffer, so the gather reads the activation in place.
+    (The reference's host-side ``assert (y == pad).sum().item() == 0`` (:108) is a device
+    sync per step and is not reproduced.)"""
+    d = model.dim
+    assert tensor.dim() == 3 and tensor.shape[-1] == d and tensor.dtype == BF16, \
+        'predict() expects the bf16 encoder output (T, B, d)'
+    T, B, _ = tensor.shape
+    s0, s1, s2 = tensor.stride()
+    soff = tensor.storage_offset()
+    with torch.no_grad():
+        if s2 == 1 and s0 % d == 0 and s1 % d == 0 and soff % d == 0:
+            base = torch.as_strided(tensor, (tensor.untyped_storage().nbytes() // 2 // d, d), (d, 1), 0)
+        else:
+            base = None
+    if base is None:
+        tensor = tensor.contiguous()
+        with torch.no_grad():
+            base = tensor.view(T * B, d)
+        s0, s1, soff = B * d, d, 0
+    n = int(y.shape[0])
+    pm = pred_mask.to(tensor.device).reshape(-1)
+    # positions of the True entries in (t, b) order without a host sync: stable sort of ~mask
+    flat = torch.argsort((~pm.bool()).to(torch.uint8), stable=True)[:n]
+    t_idx, b_idx = flat // B, flat % B
+    row_idx = ((soff + t_idx * s0 + b_idx * s1) // d).to(torch.int32).contiguous()
+    scores_out = [] if want_scores else None
+    loss = MLMHeadFn.apply(tensor, model, base, row_idx, y.to(tensor.device), scores_out)
+    return loss, (scores_out[0] if want_scores else None)

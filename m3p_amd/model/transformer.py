@@ -1,0 +1,368 @@
+"""MI355X-native drop-in for the hot path of M3P's ``TransformerModel``
+(reference: M3P/src/model/transformer.py:610-1515).
+
+Same constructor, same ``model(mode, **kwargs)`` dispatcher, same attribute and
+state-dict names (so the released checkpoint loads and ``xtrainer.Trainer`` can drive it),
+but ``jointfwd`` / ``predict`` run on hand-written gfx950 kernels through the C ABI in
+``include/m3p_hip.h`` — there is no PyTorch fallback for those modes on a GPU.
+
+Memory design (288 GB HBM3E per GPU — spend it):
+  * every hot parameter is a *view* into one flat fp32 "master" arena; gradients live in a
+    second arena with the same layout (``param.grad`` are views), so the gradient
+    all-reduce, the global-norm clip and Adam are each a handful of flat streaming kernels;
+  * a bf16 working copy (same layout) feeds the MFMA GEMMs; q/k/v weights are adjacent so
+    the projection is ONE [3d, d] GEMM; transposed bf16 copies feed the data-gradient
+    GEMMs; both are refreshed by the optimizer kernel, not by a per-step cast pass;
+  * activations are bf16 [B*S, d] batch-major; everything a layer's backward needs is
+    kept resident (≈1 GB/layer at B=256) instead of being recomputed.
+"""
+import math
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import functional as Fn
+
+N_MAX_POSITIONS = 514  # transformer.py:16
+
+ALIGN = 64  # arena offsets in elements (256 B for fp32, 128 B for bf16)
+
+
+def Embedding(num_embeddings, embedding_dim, padding_idx=None):
+    """transformer.py:21-26: N(0, dim^-0.5) init, pad row zeroed."""
+    m = nn.Embedding(num_embeddings, embedding_dim, padding_idx=padding_idx)
+    nn.init.normal_(m.weight, mean=0, std=embedding_dim ** -0.5)
+    if padding_idx is not None:
+        nn.init.constant_(m.weight[padding_idx], 0)
+    return m
+
+
+def get_masks(slen, lengths, causal, k=None):
+    """transformer.py:59-78 (kept for callers that import it); the hot path does not sync."""
+    bs = lengths.size(0)
+    alen = torch.arange(slen, dtype=torch.long, device=lengths.device)
+    mask = alen < lengths[:, None]
+    if causal:
+        attn_mask = alen[None, None, :].repeat(bs, slen, 1) <= alen[None, :, None]
+    else:
+        attn_mask = mask
+    return mask, attn_mask
+
+
+class _Holder(nn.Module):
+    """Parameter container used to reproduce the reference's state-dict names for the
+    sub-modules the pre-training hot path never executes."""
+
+
+def _register_path(root, name, tensor):
+    parts = name.split('.')
+    mod = root
+    for p in parts[:-1]:
+        if not hasattr(mod, p):
+            mod.add_module(p, _Holder())
+        mod = getattr(mod, p)
+    mod.register_parameter(parts[-1], nn.Parameter(tensor))
+
+
+def _linear_init(out_f, in_f):
+    w = torch.empty(out_f, in_f)
+    nn.init.kaiming_uniform_(w, a=math.sqrt(5))
+    bound = 1 / math.sqrt(in_f)
+    b = torch.empty(out_f).uniform_(-bound, bound)
+    return w, b
+
+
+def cold_param_specs(dim, n_layers, refine_layers):
+    """(name, kind, shape...) of the reference's parameters that the MLM+ITM pre-training
+    step never touches (enumerated from the reference's state dict: AoA refiner
+    transformer.py:274-422, CrossAlignMatrix :425-473, VAE/latent :500-543, cross
+    attention :673-698, CLCM / MRFR / object heads :711-727)."""
+    specs = [('image_embeddings.image_distbution_embeddings', 'linear', dim, 1600)]
+    for i in range(refine_layers):
+        p = 'refine_embeddings.layers.%d.' % i
+        for j in range(3):
+            specs.append((p + 'self_attn.linears.%d' % j, 'linear', dim, dim))
+        specs.append((p + 'self_attn.aoa_layer.0', 'linear', 2 * dim, 2 * dim))
+        specs.append((p + 'feed_forward.lin1', 'linear', 4 * dim, dim))
+        specs.append((p + 'feed_forward.lin2', 'linear', dim, 4 * dim))
+        specs.append((p + 'sublayer.0.norm', 'ln', dim))
+        specs.append((p + 'sublayer.1.norm', 'ln', dim))
+    specs.append(('refine_embeddings.norm', 'ln', dim))
+    for n in ('att_weight_c', 'att_weight_q', 'att_weight_cq'):
+        specs.append(('cross_alignment.' + n, 'linear', 1, dim))
+    specs.append(('cross_alignment.align_output', 'linear', dim, dim))
+    specs.append(('cross_alignment.layer_norm', 'ln', dim))
+    for i in range(n_layers):
+        specs.append(('layer_norm15.%d' % i, 'ln', dim))
+    for i in range(n_layers):
+        for lin in ('q_lin', 'k_lin', 'v_lin', 'out_lin'):
+            specs.append(('encoder_attn.%d.%s' % (i, lin), 'linear', dim, dim))
+    for i in range(2):
+        specs.append(('latent_transforms.%d.x_to_mu' % i, 'linear', dim, dim))
+        specs.append(('latent_transforms.%d.x_to_logvar' % i, 'linear', dim, dim))
+        specs.append(('latent_transforms.%d.out_dense' % i, 'linear', dim, 2 * dim))
+    for i in range(2):
+        specs.append(('original_transforms.%d.dense' % i, 'linear', dim, dim))
+        specs.append(('original_transforms.%d.dense_mu' % i, 'linear', dim, dim))
+        specs.append(('original_transforms.%d.LayerNorm' % i, 'ln', dim))
+    specs.append(('pooled_layer2.dense', 'linear', dim, dim))
+    specs.append(('seq_relationship2', 'linear', 1, dim))
+    specs.append(('mrfr_dense', 'linear', 2048, dim))
+    specs.append(('transformer_obj.dense', 'linear', dim, dim))
+    specs.append(('transformer_obj.LayerNorm', 'ln', dim))
+    specs.append(('pred_obj_layer.proj', 'linear', 1600, dim))
+    return specs
+
+
+class PredLayer(nn.Module):
+    """transformer.py:81-124 (cross-entropy branch; adaptive softmax is out of scope)."""
+
+    def __init__(self, params):
+        super().__init__()
+        assert params.asm is False, 'adaptive softmax (asm) is outside the MI355X hot path'
+        self.asm = params.asm
+        self.n_words = params.n_words
+        self.pad_index = params.pad_index
+        self.proj = nn.Linear(params.emb_dim, params.n_words, bias=True)
+
+
+class BertImageEmbeddings(nn.Module):
+    """transformer.py:231-269 parameter holder (forward is fused into the assembly kernel)."""
+
+    def __init__(self, hidden_size):
+        super().__init__()
+        self.image_embeddings = nn.Linear(2048, hidden_size)
+        self.image_location_embeddings = nn.Linear(5, hidden_size)
+        self.LayerNorm = nn.LayerNorm(hidden_size, eps=1e-12)
+
+
+class _AttentionParams(nn.Module):
+    """MultiHeadAttention (transformer.py:127-147) parameter holder."""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.q_lin = nn.Linear(dim, dim)
+        self.k_lin = nn.Linear(dim, dim)
+        self.v_lin = nn.Linear(dim, dim)
+        self.out_lin = nn.Linear(dim, dim)
+
+
+class _FFNParams(nn.Module):
+    """TransformerFFN (transformer.py:213-221) parameter holder."""
+
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.lin1 = nn.Linear(dim, hidden)
+        self.lin2 = nn.Linear(hidden, dim)
+
+
+class _Pooler(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.dense = nn.Linear(dim, dim)
+
+
+class TransformerModel(nn.Module):
+    ATTRIBUTES = ['encoder', 'with_output', 'eos_index', 'pad_index', 'n_langs', 'n_words', 'dim', 'n_layers',
+                  'n_heads', 'hidden_dim', 'dropout', 'attention_dropout', 'asm', 'asm_cutoffs', 'asm_div_value']
+
+    def __init__(self, params, is_encoder, with_output, is_crossModal=False):
+        """Same signature and ``params`` fields as transformer.py:614-729."""
+        super().__init__()
+        self.is_encoder = is_encoder
+        self.is_decoder = not is_encoder
+        self.with_output = with_output
+        self.is_crossModal = is_crossModal
+        assert is_encoder and is_crossModal, \
+            'the MI355X hot path is the cross-modal encoder (the reference itself requires is_crossModal=True: ' \
+            'transformer.py:673-698)'
+
+        self.n_langs = params.n_langs
+        self.n_words = params.n_words
+        self.eos_index = params.eos_index
+        self.pad_index = params.pad_index
+        self.id2lang = params.id2lang
+        self.lang2id = params.lang2id
+        self.english_only = not (self.n_langs > 1)
+        assert len(self.id2lang) == len(self.lang2id) == self.n_langs
+
+        self.dim = params.emb_dim
+        self.hidden_dim = self.dim * 4
+        self.n_heads = params.n_heads
+        self.n_layers = params.n_layers
+        self.dropout = params.dropout
+        self.attention_dropout = params.attention_dropout
+        assert self.dim % self.n_heads == 0, 'transformer dim must be a multiple of n_heads'
+        assert self.dim // self.n_heads in (32, 64), 'attention kernels are built for head dims 32 and 64'
+        assert self.dim % 64 == 0
+        assert not params.sinusoidal_embeddings, 'sinusoidal positions are outside the hot path'
+        assert params.gelu_activation, 'the fused FFN epilogue is bias+GELU(erf)'
+        self.attention_setting = params.attention_setting
+        self.use_externel_att = params.use_externel_att
+
+        d = self.dim
+        self.position_embeddings = Embedding(N_MAX_POSITIONS, d)
+        if params.n_langs > 1:
+            self.cross_lang_embeddings = Embedding(self.n_langs, d)   # unused by jointfwd (:937-938)
+        self.embeddings = Embedding(self.n_words, d, padding_idx=self.pad_index)
+        self.layer_norm_emb = nn.LayerNorm(d, eps=1e-12)
+        self.image_embeddings = BertImageEmbeddings(d)
+
+        self.attentions = nn.ModuleList()
+        self.layer_norm1 = nn.ModuleList()
+        self.ffns = nn.ModuleList()
+        self.layer_norm2 = nn.ModuleList()
+        for _ in range(self.n_layers):
+            self.attentions.append(_AttentionParams(d))
+            self.layer_norm1.append(nn.LayerNorm(d, eps=1e-12))
+            self.ffns.append(_FFNParams(d, self.hidden_dim))
+            self.layer_norm2.append(nn.LayerNorm(d, eps=1e-12))
+        self.pooled_layer = _Pooler(d)
+        self.seq_relationship = nn.Linear(d, 1)
+
+        # reference parameters that exist but are never executed on this path
+        for spec in cold_param_specs(d, self.n_layers, params.refine_layers):
+            name, kind = spec[0], spec[1]
+            if kind == 'linear':
+                w, b = _linear_init(spec[2], spec[3])
+                _register_path(self, name + '.weight', w)
+                _register_path(self, name + '.bias', b)
+            else:
+                _register_path(self, name + '.weight', torch.ones(spec[2]))
+                _register_path(self, name + '.bias', torch.zeros(spec[2]))
+
+        if self.with_output:
+            self.pred_layer = PredLayer(params)
+            if params.share_inout_emb:
+                self.pred_layer.proj.weight = self.embeddings.weight   # transformer.py:728-729
+        self.share_inout_emb = bool(params.share_inout_emb)
+        assert self.share_inout_emb, 'the fused MLM head assumes the tied projection (share_inout_emb)'
+
+        self._arena = None
+        self.base_seed = 0x5EED
+        self._fwd_counter = 0
+        self.ddp_hook = None   # set by m3p_amd.distributed.DataParallel
+
+    # ------------------------------------------------------------------ arenas
+    def hot_named_parameters(self):
+        """Hot parameters in arena order; q/k/v weights (and biases) adjacent per layer."""
+        out = OrderedDict()
+        out['embeddings.weight'] = self.embeddings.weight
+        out['pred_layer.proj.bias'] = self.pred_layer.proj.bias
+        out['position_embeddings.weight'] = self.position_embeddings.weight
+        out['layer_norm_emb.weight'] = self.layer_norm_emb.weight
+        out['layer_norm_emb.bias'] = self.layer_norm_emb.bias
+        ie = self.image_embeddings
+        out['image_embeddings.image_embeddings.weight'] = ie.image_embeddings.weight
+        out['image_embeddings.image_embeddings.bias'] = ie.image_embeddings.bias
+        out['image_embeddings.image_location_embeddings.weight'] = ie.image_location_embeddings.weight
+        out['image_embeddings.image_location_embeddings.bias'] = ie.image_location_embeddings.bias
+        out['image_embeddings.LayerNorm.weight'] = ie.LayerNorm.weight
+        out['image_embeddings.LayerNorm.bias'] = ie.LayerNorm.bias
+        for i in range(self.n_layers):
+            a, f = self.attentions[i], self.ffns[i]
+            for lin in ('q_lin', 'k_lin', 'v_lin'):
+                out['attentions.%d.%s.weight' % (i, lin)] = getattr(a, lin).weight
+            for lin in ('q_lin', 'k_lin', 'v_lin'):
+                out['attentions.%d.%s.bias' % (i, lin)] = getattr(a, lin).bias
+            out['attentions.%d.out_lin.weight' % i] = a.out_lin.weight
+            out['attentions.%d.out_lin.bias' % i] = a.out_lin.bias
+            out['layer_norm1.%d.weight' % i] = self.layer_norm1[i].weight
+            out['layer_norm1.%d.bias' % i] = self.layer_norm1[i].bias
+            out['ffns.%d.lin1.weight' % i] = f.lin1.weight
+            out['ffns.%d.lin1.bias' % i] = f.lin1.bias
+            out['ffns.%d.lin2.weight' % i] = f.lin2.weight
+            out['ffns.%d.lin2.bias' % i] = f.lin2.bias
+            out['layer_norm2.%d.weight' % i] = self.layer_norm2[i].weight
+            out['layer_norm2.%d.bias' % i] = self.layer_norm2[i].bias
+        out['pooled_layer.dense.weight'] = self.pooled_layer.dense.weight
+        out['pooled_layer.dense.bias'] = self.pooled_layer.dense.bias
+        out['seq_relationship.weight'] = self.seq_relationship.weight
+        out['seq_relationship.bias'] = self.seq_relationship.bias
+        return out
+
+    def _apply(self, fn, *a, **kw):
+        super()._apply(fn, *a, **kw)
+        self._arena = None
+        if self.embeddings.weight.is_cuda:
+            self._arena = Fn.Arena(self)
+        return self
+
+    def arena(self):
+        if self._arena is None:
+            if not self.embeddings.weight.is_cuda:
+                raise RuntimeError('m3p_amd.TransformerModel runs on an MI355X only: call .cuda() first '
+                                   '(there is no CPU / eager fallback for the hot path)')
+            self._arena = Fn.Arena(self)
+        return self._arena
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        res = super().load_state_dict(state_dict, strict=strict, **kw)
+        if self._arena is not None:
+            self._arena.mark_master_changed()
+        return res
+
+    # ------------------------------------------------------------------ dispatcher
+    def forward(self, mode, **kwargs):
+        """transformer.py:731-751."""
+        if mode == 'jointfwd':
+            return self.jointfwd(**kwargs)
+        elif mode == 'predict':
+            return self.predict(**kwargs)
+        elif mode == 'crossfwd':
+            return self.crossfwd(**kwargs)
+        elif mode == 'transform':
+            return kwargs['tensor']   # transform_original is the identity (transformer.py:1176-1181)
+        elif mode in ('fwd', 'ImageEmbed', 'GAN'):
+            raise NotImplementedError("mode '%s' is outside the MI355X hot path (SURVEY.md §8f)" % mode)
+        raise Exception('Unknown mode: %s' % mode)
+
+    def _next_seed_step(self):
+        self._fwd_counter += 1
+        return self._fwd_counter
+
+    def jointfwd(self, x, lengths, x_img, lengths_img, causal=False, positions=None, langs=None,
+                 image_loc=None, refine_image=False, is_latent=False, text_embed=None):
+        """transformer.py:878-968.  x (T,B) int64, x_img (R,B,2048), image_loc (R,B,5) ->
+        (S=R+T, B, d) (a transposed view of the batch-major activation, like the reference)."""
+        assert not causal and not refine_image and not is_latent and text_embed is None, \
+            'causal / refine_image / is_latent / text_embed are outside the MI355X hot path'
+        T, B = x.size()
+        assert lengths.size(0) == B
+        R = x_img.size(0)
+        p = self.dropout if self.training else 0.0
+        pa = self.attention_dropout if self.training else 0.0
+        out = Fn.EncoderFn.apply(self.layer_norm_emb.weight, self, x, lengths, x_img, lengths_img, image_loc, p, pa,
+                                 self._next_seed_step())
+        return out.view(B, R + T, self.dim).transpose(0, 1)
+
+    def crossfwd(self, x, lengths, causal, stream_='text', src_enc=None, src_len=None, positions=None, langs=None,
+                 cache=None, enc_mask=None, image_loc=None, **kw):
+        """Text-only stream of transformer.py:970-1114 (the mlm_step caller, xtrainer.py:757)."""
+        assert stream_ == 'text' and not causal and src_enc is None and cache is None and positions is None, \
+            'only the text MLM stream of crossfwd is on the MI355X hot path'
+        T, B = x.size()
+        p = self.dropout if self.training else 0.0
+        pa = self.attention_dropout if self.training else 0.0
+        out = Fn.EncoderFn.apply(self.layer_norm_emb.weight, self, x, lengths, None, None, None, p, pa,
+                                 self._next_seed_step())
+        return out.view(B, T, self.dim).transpose(0, 1)
+
+    def predict(self, tensor, pred_mask=None, y=None, get_scores=None, is_obj=False, is_relation=False,
+                is_mrfr=False, is_clcm=False):
+        """transformer.py:1183-1214."""
+        if is_relation:
+            # BertPooler (:546-558) + seq_relationship: B x d work, negligible FLOPs — kept in
+            # fp32 torch ops on the GPU (master weights), gradients land in the same arena.
+            if torch.is_grad_enabled():
+                self.arena().touch('pooled_layer.dense.weight', 'pooled_layer.dense.bias',
+                                   'seq_relationship.weight', 'seq_relationship.bias')
+            first = tensor[:, 0].float()
+            pooled = torch.tanh(F.linear(first, self.pooled_layer.dense.weight, self.pooled_layer.dense.bias))
+            return F.linear(pooled, self.seq_relationship.weight, self.seq_relationship.bias)
+        if is_clcm or is_mrfr or is_obj:
+            raise NotImplementedError('CLCM / MRFR / MRM heads are SURVEY.md §8(f2) "next" rows')
+        loss, scores = Fn.mlm_head(self, tensor, pred_mask, y, bool(get_scores))
+        return scores, loss

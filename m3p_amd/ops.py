@@ -113,3 +113,105 @@ def attn_bwd(qkv, keylen, ctx, dctx, lse, B, S, H, dh, dbias_qkv=None, seed=0, p
                                L.thresh24(p_drop), 1.0 / (1.0 - p_drop) if p_drop > 0 else 1.0, L.stream())
     L.check(rc, 'm3p_attn_bwd')
     return dqkv
+
+
+def cast_bf16(x):
+    """fp32 -> bf16 through the HIP cast kernel (bf16 input is returned unchanged)."""
+    if x.dtype == BF16:
+        return x
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.numel() % 4 == 0
+    out = torch.empty(x.shape, dtype=BF16, device=x.device)
+    L.check(L.load().m3p_cast_f32_bf16(x.data_ptr(), out.data_ptr(), x.numel(), L.stream()), 'm3p_cast_f32_bf16')
+    return out
+
+
+def _drop_args(p):
+    return L.thresh24(p), (1.0 / (1.0 - p) if p > 0 else 1.0)
+
+
+def embed_assemble_fwd(tok, emb16, pos, img_proj, loc, w_loc, b_loc, g_img, be_img, g_emb, be_emb, totlen,
+                       B, T, R, d, seed_img=0, seed_emb=0, p_drop=0.0):
+    dev = emb16.device
+    S = R + T
+    h = torch.empty((B * S, d), dtype=BF16, device=dev)
+    z = torch.empty((B * S, d), dtype=BF16, device=dev)
+    mean_e = torch.empty(B * S, dtype=torch.float32, device=dev)
+    rstd_e = torch.empty(B * S, dtype=torch.float32, device=dev)
+    e = torch.empty((max(R * B, 1), d), dtype=BF16, device=dev)
+    mean_i = torch.empty(max(R * B, 1), dtype=torch.float32, device=dev)
+    rstd_i = torch.empty(max(R * B, 1), dtype=torch.float32, device=dev)
+    th, ik = _drop_args(p_drop)
+    rc = L.load().m3p_embed_assemble_fwd(
+        tok.data_ptr(), emb16.data_ptr(), pos.data_ptr(), L.ptr(img_proj), L.ptr(loc), w_loc.data_ptr(),
+        b_loc.data_ptr(), g_img.data_ptr(), be_img.data_ptr(), g_emb.data_ptr(), be_emb.data_ptr(), totlen.data_ptr(),
+        h.data_ptr(), z.data_ptr(), mean_e.data_ptr(), rstd_e.data_ptr(), e.data_ptr(), mean_i.data_ptr(),
+        rstd_i.data_ptr(), B, T, R, d, seed_img, seed_emb, th, ik, L.stream())
+    L.check(rc, 'm3p_embed_assemble_fwd')
+    return h, (z, mean_e, rstd_e, e, mean_i, rstd_i)
+
+
+def embed_assemble_bwd(dh, saved, g_emb, g_img, tok, totlen, loc, grads, B, T, R, d, pad_index,
+                       seed_img=0, seed_emb=0, p_drop=0.0):
+    """grads: dict of fp32 gradient views (d_g_emb, d_be_emb, d_pos, d_emb, d_g_img, d_be_img, d_b_img,
+    d_b_loc, d_w_loc).  Returns de (bf16 [R*B, d])."""
+    z, mean_e, rstd_e, e, mean_i, rstd_i = saved
+    dz = torch.empty_like(z)
+    de = torch.empty_like(e)
+    th, ik = _drop_args(p_drop)
+    rc = L.load().m3p_embed_assemble_bwd(
+        dh.data_ptr(), z.data_ptr(), mean_e.data_ptr(), rstd_e.data_ptr(), g_emb.data_ptr(), e.data_ptr(),
+        mean_i.data_ptr(), rstd_i.data_ptr(), g_img.data_ptr(), tok.data_ptr(), totlen.data_ptr(), L.ptr(loc),
+        dz.data_ptr(), de.data_ptr(), grads['d_g_emb'].data_ptr(), grads['d_be_emb'].data_ptr(),
+        grads['d_pos'].data_ptr(), grads['d_emb'].data_ptr(), grads['d_g_img'].data_ptr(),
+        grads['d_be_img'].data_ptr(), grads['d_b_img'].data_ptr(), grads['d_b_loc'].data_ptr(),
+        grads['d_w_loc'].data_ptr(), B, T, R, d, pad_index, seed_img, seed_emb, th, ik, L.stream())
+    L.check(rc, 'm3p_embed_assemble_bwd')
+    return de
+
+
+def gather_rows(src_base, idx, n, d):
+    out = torch.empty((n, d), dtype=BF16, device=idx.device)
+    L.check(L.load().m3p_gather_rows(src_base.data_ptr(), idx.data_ptr(), out.data_ptr(), n, d, L.stream()), 'm3p_gather_rows')
+    return out
+
+
+def scatter_add_rows(src, idx, dst_base, n, d):
+    L.check(L.load().m3p_scatter_add_rows(src.data_ptr(), idx.data_ptr(), dst_base.data_ptr(), n, d, L.stream()),
+            'm3p_scatter_add_rows')
+
+
+def ce_fwd_bwd(logits, V, target, loss_scale, grad_scale):
+    """In place: logits <- dlogits.  Returns (loss_sum [1] fp32, row_loss [n] fp32)."""
+    n, ld = logits.shape[0], logits.stride(0)
+    row_loss = torch.empty(n, dtype=torch.float32, device=logits.device)
+    loss_sum = torch.zeros(1, dtype=torch.float32, device=logits.device)
+    assert target.dtype == torch.int64
+    rc = L.load().m3p_ce_fwd_bwd(logits.data_ptr(), ld, n, V, target.data_ptr(), row_loss.data_ptr(),
+                                 loss_sum.data_ptr(), loss_scale, grad_scale, L.stream())
+    L.check(rc, 'm3p_ce_fwd_bwd')
+    return loss_sum, row_loss
+
+
+def colsum(x, ncols, out, scale=None):
+    rc = L.load().m3p_colsum_bf16(x.data_ptr(), x.stride(0), x.shape[0], ncols, out.data_ptr(), L.ptr(scale), L.stream())
+    L.check(rc, 'm3p_colsum_bf16')
+
+
+def sumsq(g, out):
+    L.check(L.load().m3p_sumsq_f32(g.data_ptr(), g.numel(), out.data_ptr(), L.stream()), 'm3p_sumsq_f32')
+
+
+def adam_step(p, g, m, v, w16, lr, beta1, beta2, eps, weight_decay, step_size, gnorm_sq=None, max_norm=0.0,
+              grad_scale=1.0, zero_grad=True):
+    n = p.numel()
+    rc = L.load().m3p_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), L.ptr(w16), n, lr, beta1, beta2,
+                                eps, weight_decay, step_size, L.ptr(gnorm_sq), max_norm, grad_scale, int(zero_grad),
+                                L.stream())
+    L.check(rc, 'm3p_adam_step')
+
+
+def transpose_bf16(src, dst):
+    """dst[c, r] = src[r, c]; dst may have a row pitch larger than rows (pad columns untouched)."""
+    rows, cols = src.shape
+    rc = L.load().m3p_transpose_bf16(src.data_ptr(), dst.data_ptr(), rows, cols, src.stride(0), dst.stride(0), L.stream())
+    L.check(rc, 'm3p_transpose_bf16')

@@ -1,0 +1,153 @@
+"""Parity of the row / reduction / optimizer kernels against the oracle (GPU)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.util import randn_bf16, randn_f32, rel_l2, max_abs
+
+pytestmark = pytest.mark.gpu
+BF16 = torch.bfloat16
+
+
+def test_cast_and_transpose():
+    from m3p_amd import ops
+    x, xc = randn_f32((37, 64), 1)
+    assert torch.equal(ops.cast_bf16(x).cpu(), xc.to(BF16))
+    a, ac = randn_bf16((130, 200), 2)
+    dst = torch.zeros((200, 136), dtype=BF16, device='cuda')
+    ops.transpose_bf16(a, dst)
+    assert torch.equal(dst[:, :130].cpu(), ac.to(BF16).t())
+    assert bool((dst[:, 130:] == 0).all())
+
+
+def test_gather_scatter_colsum():
+    from m3p_amd import ops
+    src, srcc = randn_bf16((50, 128), 1)
+    idx = torch.tensor([3, 49, 0, 17], dtype=torch.int32, device='cuda')
+    out = ops.gather_rows(src, idx, 4, 128)
+    assert torch.equal(out.cpu(), srcc.to(BF16)[idx.cpu().long()])
+    dst = torch.zeros((50, 128), dtype=BF16, device='cuda')
+    ops.scatter_add_rows(out, idx, dst, 4, 128)
+    ref = torch.zeros(50, 128); ref[idx.cpu().long()] = srcc[idx.cpu().long()]
+    assert torch.equal(dst.float().cpu(), ref)
+    x, xc = randn_bf16((333, 1024), 3)
+    cs = torch.zeros(1000, device='cuda')
+    sc = torch.tensor([0.5], device='cuda')
+    ops.colsum(x, 1000, cs, scale=sc)
+    assert rel_l2(cs, 0.5 * xc[:, :1000].sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize('n,V', [(9, 1000), (40, 250002), (3, 64)])
+def test_cross_entropy_fwd_bwd(n, V):
+    from m3p_amd import ops
+    ld = (V + 63) // 64 * 64
+    logits, lc = randn_bf16((n, ld), 1, 3.0)
+    y = torch.from_numpy(np.random.RandomState(2).randint(0, V, size=n)).long()
+    x = lc[:, :V].clone().requires_grad_(True)
+    ref = F.cross_entropy(x, y, reduction='mean')
+    ref.backward()
+    loss_sum, row_loss = ops.ce_fwd_bwd(logits, V, y.cuda(), 1.0 / n, 1.0 / n)
+    assert abs(float(loss_sum) - float(ref)) < 2e-4 * max(1.0, float(ref))
+    assert rel_l2(row_loss, F.cross_entropy(lc[:, :V], y, reduction='none')) < 1e-5
+    assert rel_l2(logits[:, :V].float(), x.grad) < 5e-3      # bf16 gradient storage
+    assert bool((logits[:, V:] == 0).all())
+
+
+def test_adam_step_matches_oracle():
+    from m3p_amd import ops
+    from oracle import ref_cpu as O
+    n = 4096 + 64
+    p, pc = randn_f32((n,), 1)
+    m = torch.zeros(n, device='cuda'); v = torch.zeros(n, device='cuda')
+    mc, vc = torch.zeros(n), torch.zeros(n)
+    w16 = torch.zeros(n, dtype=BF16, device='cuda')
+    gn = torch.zeros(1, dtype=torch.float64, device='cuda')
+    for step in range(1, 4):
+        g, gc = randn_f32((n,), 10 + step, 3.0)
+        gn.zero_()
+        ops.sumsq(g, gn)
+        assert abs(math.sqrt(float(gn)) - float(gc.double().norm())) < 1e-6 * float(gc.norm())
+        lr = 1e-2
+        b1, b2 = 0.9, 0.98
+        step_size = lr * math.sqrt(1 - b2 ** step) / (1 - b1 ** step)
+        ops.adam_step(p, g, m, v, w16, lr, b1, b2, 1e-8, 0.01, step_size, gnorm_sq=gn, max_norm=5.0, grad_scale=1.0)
+        (gcl,), _ = O.clip_grad_norm([gc], 5.0)
+        pc, mc, vc = O.adam_step(pc, gcl, mc, vc, step, lr, b1, b2, 1e-8, 0.01)
+        assert rel_l2(p, pc) < 1e-6
+        assert rel_l2(m, mc) < 1e-6 and rel_l2(v, vc) < 1e-6
+        assert torch.equal(w16.cpu(), p.cpu().to(BF16))
+        assert float(g.abs().max()) == 0.0    # zero_grad fused
+
+
+@pytest.mark.parametrize('p_drop', [0.0, 0.1])
+@pytest.mark.parametrize('B,T,R,d', [(8, 64, 10, 128), (5, 24, 36, 768), (4, 16, 0, 128)])
+def test_embed_assemble_fwd_bwd(B, T, R, d, p_drop):
+    from m3p_amd import ops, rng
+    from oracle import ref_cpu as O
+    V, S = 300, R + T
+    rs = np.random.RandomState(0)
+    tok = torch.from_numpy(rs.randint(0, V, size=(T, B))).long()
+    lens = torch.from_numpy(rs.randint(max(T // 2, 1), T + 1, size=B)).long()
+    for b in range(B):
+        tok[lens[b]:, b] = 1
+    totlen = (lens + R).int()
+    emb16, embc = randn_bf16((V, d), 1, 0.5)
+    pos, posc = randn_f32((S + 3, d), 2, 0.1)
+    w_loc, w_locc = randn_f32((d, 5), 3, 0.3)
+    b_loc, b_locc = randn_f32((d,), 4, 0.1)
+    g_img, g_imgc = randn_f32((d,), 5, 0.1); g_img += 1; g_imgc += 1
+    be_img, be_imgc = randn_f32((d,), 6, 0.1)
+    g_emb, g_embc = randn_f32((d,), 7, 0.1); g_emb += 1; g_embc += 1
+    be_emb, be_embc = randn_f32((d,), 8, 0.1)
+    img_proj = loc = None
+    if R > 0:
+        img_proj, img_projc = randn_bf16((R * B, d), 9)
+        loc, locc = randn_f32((R, B, 5), 10)
+    seed_i, seed_e = 111, 222
+    h, saved = ops.embed_assemble_fwd(tok.cuda(), emb16, pos, img_proj, loc, w_loc, b_loc, g_img, be_img, g_emb, be_emb,
+                                      totlen.cuda(), B, T, R, d, seed_img=seed_i, seed_emb=seed_e, p_drop=p_drop)
+    # oracle restatement of transformer.py:901-943 on the same (bf16-rounded) inputs
+    leaves = {k: t.clone().requires_grad_(True) for k, t in dict(
+        emb=embc, pos=posc, w_loc=w_locc, b_loc=b_locc, g_img=g_imgc, be_img=be_imgc, g_emb=g_embc, be_emb=be_embc).items()}
+    keep_i = keep_e = None
+    if p_drop > 0:
+        keep_e = torch.from_numpy(rng.keep_mask(B * S * d, seed_e, p_drop, (B, S, d))).float()
+        if R > 0:
+            keep_i = torch.from_numpy(rng.keep_mask(R * B * d, seed_i, p_drop, (R, B, d))).float().transpose(0, 1)
+    tokemb = F.embedding(tok.t(), leaves['emb'])
+    if R > 0:
+        ip = img_projc.clone().requires_grad_(True)
+        e = ip.view(R, B, d) + F.linear(locc, leaves['w_loc'], leaves['b_loc'])
+        im = O.layer_norm(e, leaves['g_img'], leaves['be_img']).transpose(0, 1)
+        im = O._drop(im, keep_i, p_drop)
+        z = torch.cat([im, tokemb], dim=1)
+    else:
+        z = tokemb
+    mask = (torch.arange(S)[None, :] < totlen[:, None].long()).float()
+    z = (z + leaves['pos'][:S][None]) * mask[..., None]
+    href = O._drop(O.layer_norm(z, leaves['g_emb'], leaves['be_emb']), keep_e, p_drop)
+    assert rel_l2(h.float().view(B, S, d), href) < 6e-3
+    # backward
+    dh, dhc = randn_bf16((B * S, d), 20)
+    grads = {k: torch.zeros(s, device='cuda') for k, s in dict(
+        d_g_emb=(d,), d_be_emb=(d,), d_pos=(S + 3, d), d_emb=(V, d), d_g_img=(d,), d_be_img=(d,), d_b_img=(d,),
+        d_b_loc=(d,), d_w_loc=(d, 5)).items()}
+    de = ops.embed_assemble_bwd(dh, saved, g_emb, g_img, tok.cuda(), totlen.cuda(), loc, grads, B, T, R, d, 1,
+                                seed_img=seed_i, seed_emb=seed_e, p_drop=p_drop)
+    href.backward(dhc.view(B, S, d))
+    tol = 1.5e-2
+    assert rel_l2(grads['d_g_emb'], leaves['g_emb'].grad) < tol
+    assert rel_l2(grads['d_be_emb'], leaves['be_emb'].grad) < tol
+    assert rel_l2(grads['d_pos'], leaves['pos'].grad) < tol
+    ge = leaves['emb'].grad.clone(); ge[1] = 0          # padding_idx row receives no gradient
+    assert rel_l2(grads['d_emb'], ge) < tol
+    if R > 0:
+        assert rel_l2(grads['d_g_img'], leaves['g_img'].grad) < tol
+        assert rel_l2(grads['d_be_img'], leaves['be_img'].grad) < tol
+        assert rel_l2(grads['d_b_loc'], leaves['b_loc'].grad) < tol
+        assert rel_l2(grads['d_b_img'], leaves['b_loc'].grad) < tol
+        assert rel_l2(grads['d_w_loc'], leaves['w_loc'].grad) < tol
+        assert rel_l2(de.float(), ip.grad) < tol
