@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""Headline benchmark: M3P pre-training sequences/s (BASELINE.json metric) on 1..8 MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = XTrainer.pretrain_under_step on a synthetic, device-resident batch of
+BASELINE.json configs[1] (12L/768d/12h, 36 regions + 128 tokens, V=250002, 19 masked
+tokens/sequence, ITM BCE, dropout 0.1, adam_inverse_sqrt + clip 5, bf16 compute with fp32
+master weights): jointfwd -> MLM + ITM losses -> backward (+ bucketed RCCL all-reduce for
+N>1) -> clip -> Adam.  Weak scaling: the per-GPU batch is fixed.
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     the dominant MFMA GEMM timed live with HIP events on its own stream
+  cpu_baseline the oracle (plain PyTorch fp32 CPU restatement) on the host cores, bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md; 2:1-sparse figure excluded)
+
+
+def flops_train_per_seq(d, L, T, R, V, n_pred):
+    """forward MACs = R(2048d+5d) + L[S(4d^2+2d*4d)+2S^2 d] + n_pred*d*V + d^2+d;
+    train FLOPs = 6 x MACs."""
+    S = T + R
+    macs = R * (2048 * d + 5 * d) + L * (S * (4 * d * d + 2 * d * 4 * d) + 2 * S * S * d) + n_pred * d * V + d * d + d
+    return 6.0 * macs
+
+
+def build(cfg, dropout, world, rank, local_rank):
+    from m3p_amd import synth
+    from m3p_amd.model.transformer import TransformerModel
+    from m3p_amd.trainer import XTrainer
+    P = synth.model_params(cfg['emb_dim'], cfg['n_heads'], cfg['n_layers'], cfg['n_words'], dropout=dropout,
+                           attention_dropout=dropout)
+    for k, v in dict(optimizer='adam_inverse_sqrt,beta1=0.9,beta2=0.98,lr=0.0001', clip_grad_norm=5, amp=1, fp16=True,
+                     accumulate_gradients=1, multi_gpu=world > 1, local_rank=local_rank, epoch_size=100000,
+                     cross_mlm_steps=[('google', 'img')], cross_mrm_steps=[], cross_mrfr_steps=[], cross_clcm_steps=[],
+                     sample_n=2, refine_image=False, multi_cls_loss_weight=0, bin_cls_loss_weight=1,
+                     batch_size=cfg['B'], dump_path='/tmp').items():
+        setattr(P, k, v)
+    torch.manual_seed(1234)   # identical random-init weights on every rank (then broadcast anyway)
+    model = TransformerModel(P, is_encoder=True, with_output=True, is_crossModal=True).cuda()
+    trainer = XTrainer(model, {}, P)
+    batch = synth.make_batch(cfg['T'], cfg['R'], cfg['B'], cfg['n_words'], cfg['n_pred'], seed=1000 + rank, ragged=False)
+    B, R = cfg['B'], cfg['R']
+    dev = torch.device('cuda', local_rank)
+    img = batch['x_img'].transpose(0, 1).contiguous().to(dev)           # (n, R, 2048) as the collate emits it
+    loc = batch['image_loc'].transpose(0, 1).contiguous().to(dev)
+    tup = ((batch['x'].to(dev), batch['lengths'].to(dev), batch['x_labels']),       # labels stay on the host (mask building)
+           (img, torch.ones(B, R, dtype=torch.long, device=dev), loc, None, batch['pos_labels'].tolist(), None, None))
+    return trainer, tup
+
+
+def cpu_baseline(cfg, seconds=20.0):
+    """The oracle's full training step on the host cores: same model shape, B=8 sample."""
+    from m3p_amd import synth
+    from oracle import ref_cpu as O
+    Bs = 8
+    P = synth.model_params(cfg['emb_dim'], cfg['n_heads'], cfg['n_layers'], cfg['n_words'])
+    shapes = synth.hot_param_shapes(P)
+    gen = torch.Generator().manual_seed(0)
+    sd = {k: torch.randn(tuple(s), generator=gen) * 0.02 for k, s in shapes.items()}
+    for k in sd:
+        if ('layer_norm' in k or 'LayerNorm' in k) and k.endswith('weight'):
+            sd[k] += 1
+    names = list(sd.keys())
+    batch = synth.make_batch(cfg['T'], cfg['R'], Bs, cfg['n_words'], cfg['n_pred'], seed=1000, ragged=False)
+    opt = O.AdamInvSqrt([sd[n] for n in names])
+    cores = torch.get_num_threads()
+    O.train_step(sd, names, opt, cfg['n_layers'], cfg['n_heads'], batch, cfg['R'], clip=5.0)   # warm-up
+    t0 = time.time()
+    n = 0
+    while True:
+        O.train_step(sd, names, opt, cfg['n_layers'], cfg['n_heads'], batch, cfg['R'], clip=5.0)
+        n += 1
+        if time.time() - t0 > seconds or n >= 20:
+            break
+    dt = time.time() - t0
+    return dict(value=round(Bs * n / dt, 3), unit='sequences/s', cores=cores, kind='port',
+                sample='%d full train steps (fwd+bwd+clip+Adam) of the same 12L/768d V=250002 model at B=%d, fp32, '
+                       'dropout 0 (oracle/ref_cpu.py)' % (n, Bs))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=256, help='sequences per GPU')
+    ap.add_argument('--config', default='cfg2')
+    ap.add_argument('--dropout', type=float, default=0.1)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    from m3p_amd import synth, ops
+    from m3p_amd.distributed import init_distributed_mode
+    import torch.distributed as dist
+    rank, local_rank, world = init_distributed_mode()
+    assert world == args.gpus or world == 1, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+    torch.cuda.set_device(local_rank)
+    cfg = dict(synth.CONFIGS[args.config])
+    cfg['B'] = args.batch
+    trainer, tup = build(cfg, args.dropout, world, rank, local_rank)
+
+    def step():
+        trainer.pretrain_under_step(tup, 'google', 't2i', 'en', 1.0, 1.0, 1.0, 1.0)
+        trainer.n_iter += 1
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    ops.PROFILE = {}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof, ops.PROFILE = ops.PROFILE, None
+    if world > 1:
+        t = torch.tensor([dt], device='cuda', dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        seqs = args.steps * cfg['B'] * world
+        value = seqs / dt
+        fl = flops_train_per_seq(cfg['emb_dim'], cfg['n_layers'], cfg['T'], cfg['R'], cfg['n_words'], cfg['n_pred'])
+        # dominant kernel: the (epilogue, M, N, K) GEMM instance with the largest summed event time
+        roof = None
+        if prof:
+            agg = {}
+            for key, evs in prof.items():
+                ms = [a.elapsed_time(b) for a, b in evs]
+                agg[key] = (sum(ms), len(ms))
+            key, (tot, cnt) = max(agg.items(), key=lambda kv: kv[1][0])
+            kind, M, N, K = key
+            avg_ms = tot / cnt
+            flops = 2.0 * M * N * K
+            ach = flops / (avg_ms * 1e-3) / 1e12
+            roof = dict(bound='mfma', achieved=round(ach, 1), peak=PEAK_BF16_TFLOPS, unit='TFLOP/s',
+                        frac=round(ach / PEAK_BF16_TFLOPS, 4), traffic=None,
+                        kernel='%s M=%d N=%d K=%d' % (kind, M, N, K), launches=cnt, avg_ms=round(avg_ms, 4),
+                        gemm_time_share=round(sum(v[0] for v in agg.values()) / (dt * 1e3), 3),
+                        step_frac=round(value / world * fl / 1e12 / PEAK_BF16_TFLOPS, 4))
+        out = dict(metric='pre-train samples/sec (whole node), 12L/768d seq=128+36', value=round(value, 2),
+                   unit='sequences/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
+                   ms_per_step=round(dt / args.steps * 1e3, 3), higher_is_better=True, scaling='weak',
+                   vs_baseline=None, dtype='bf16', data='synthetic',
+                   config=dict(workload='%s: %dL/%dd/%dh, %d regions + %d tokens, V=%d, %d MLM targets/seq + ITM BCE, '
+                                        'dropout %.2f, adam_inverse_sqrt + clip 5'
+                                        % (args.config, cfg['n_layers'], cfg['emb_dim'], cfg['n_heads'], cfg['R'], cfg['T'],
+                                           cfg['n_words'], cfg['n_pred'], args.dropout),
+                               per_gpu_batch=cfg['B'], global_batch=cfg['B'] * world, seq_len=cfg['T'] + cfg['R'],
+                               parallelism='dp%d' % world, flops_train_per_seq=fl),
+                   roofline=roof)
+        if world == 1 and not args.no_cpu_baseline:
+            del trainer
+            torch.cuda.empty_cache()
+            out['cpu_baseline'] = cpu_baseline(cfg)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -11,6 +11,27 @@ from . import lib as L
 
 BF16 = torch.bfloat16
 
+# bench.py sets this to a dict to time individual GEMM launches with HIP events recorded on
+# the launch stream: {(kind, M, N, K): [(start_event, end_event), ...]}
+PROFILE = None
+_EPI_NAMES = ['gemm_nt/none', 'gemm_nt/bias', 'gemm_nt/bias_gelu', 'gemm_nt/bias_drop_res', 'gemm_nt/res',
+              'gemm_nt/dgelu']
+
+
+def _prof_begin():
+    if PROFILE is None:
+        return None
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
+
+
+def _prof_end(e0, key):
+    if e0 is not None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        PROFILE.setdefault(key, []).append((e0, e1))
+
 
 def _chk_bf16(*ts):
     for t in ts:
@@ -43,9 +64,11 @@ def gemm_nt(a, w, epilogue=L.EPI_NONE, bias=None, aux=None, out=None, out2=None,
     ep.inv_keep = 1.0 / (1.0 - p_drop) if p_drop > 0 else 1.0
     if bias is not None:
         assert bias.dtype == torch.float32
+    e0 = _prof_begin()
     rc = L.load().m3p_gemm_nt_bf16(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(),
                                    out.stride(0), M, N, K, epilogue, C.byref(ep), L.stream())
     L.check(rc, 'm3p_gemm_nt_bf16')
+    _prof_end(e0, (_EPI_NAMES[epilogue], M, N, K))
     return out
 
 
@@ -57,9 +80,11 @@ def gemm_wgrad(dy, x, dw, alpha=1.0, n=None, k=None):
     N = dy.shape[1] if n is None else n
     K = x.shape[1] if k is None else k
     assert x.shape[0] == M and dw.shape[0] >= N and dw.shape[1] >= K
+    e0 = _prof_begin()
     rc = L.load().m3p_gemm_wgrad_bf16(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), dw.data_ptr(),
                                       dw.stride(0), M, N, K, alpha, L.stream())
     L.check(rc, 'm3p_gemm_wgrad_bf16')
+    _prof_end(e0, ('gemm_wgrad', M, N, K))
     return dw
 
 

@@ -76,8 +76,8 @@ def test_adam_step_matches_oracle():
         ops.adam_step(p, g, m, v, w16, lr, b1, b2, 1e-8, 0.01, step_size, gnorm_sq=gn, max_norm=5.0, grad_scale=1.0)
         (gcl,), _ = O.clip_grad_norm([gc], 5.0)
         pc, mc, vc = O.adam_step(pc, gcl, mc, vc, step, lr, b1, b2, 1e-8, 0.01)
-        assert rel_l2(p, pc) < 1e-6
-        assert rel_l2(m, mc) < 1e-6 and rel_l2(v, vc) < 1e-6
+        assert rel_l2(p, pc) < 2e-6
+        assert rel_l2(m, mc) < 2e-6 and rel_l2(v, vc) < 5e-6   # g*coef rounding enters v squared
         assert torch.equal(w16.cpu(), p.cpu().to(BF16))
         assert float(g.abs().max()) == 0.0    # zero_grad fused
 
