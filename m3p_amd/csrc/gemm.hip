@@ -254,12 +254,24 @@ void gemm_wgrad_kernel(const bf16* __restrict__ dY, int lddy, const bf16* __rest
   const int m_end = min(M, m_begin + m_chunk);
   if (m_begin >= m_end) return;
 
-  // staging: one wave instruction = 4 rows x 256 B; lane -> (row l>>4, chunk l&15)
+  // staging: one wave instruction = 4 rows x 256 B; lane -> (row l>>4, LDS chunk l&15).
+  // Bank swizzle for the transpose reads: a ds_read_b64_tr_b16 pass covers 32 lanes = 8 tile
+  // rows {8g + j : g in 0..1, j in 0..3} x one 32-B segment each; all rows sit on the same
+  // banks (256-B pitch), so the 32-B segment index is XORed with f(row) = (row & 3) |
+  // ((row >> 3) & 1) << 2, which is distinct for those 8 rows -> conflict-free.  The LDS-DMA
+  // writes lane-linear, so the permutation is applied to the SOURCE chunk (cdna guide rule 21).
   const int sr = lane >> 4, sc = lane & 15;
-  // clamp the 8-column chunk so a ragged N / K never reads past the row pitch
   const int n_chunks = (N + 7) / 8, k_chunks = (K + 7) / 8;
-  const int ycol = min(i0 / 8 + sc, n_chunks - 1) * 8;
-  const int xcol = min(j0 / 8 + sc, k_chunks - 1) * 8;
+  int ycol[4], xcol[4];   // per 4-row group handled by this wave (rb = wid + 4*i  ->  (rb >> 1) & 1 == (i*4 + wid) >> 1 & 1)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int rb = wid + i * 4;
+    const int f = sr | (((rb >> 1) & 1) << 2);
+    const int gc = sc ^ (f << 1);
+    // clamp the 8-column chunk so a ragged N / K never reads past the row pitch
+    ycol[i] = min(i0 / 8 + gc, n_chunks - 1) * 8;
+    xcol[i] = min(j0 / 8 + gc, k_chunks - 1) * 8;
+  }
 
   auto stage = [&](int mt, int s) {
     char* sy = smem + s * 2 * WG_TILE_BYTES;
@@ -271,14 +283,14 @@ void gemm_wgrad_kernel(const bf16* __restrict__ dY, int lddy, const bf16* __rest
       const int rb = wid + i * 4;            // group of 4 rows
       const int m = mbase + rb * 4 + sr;
       if (fullt) {
-        __builtin_amdgcn_global_load_lds(GLB_PTR(dY + (size_t)m * lddy + ycol), LDS_PTR(sy + rb * 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(GLB_PTR(X + (size_t)m * ldx + xcol), LDS_PTR(sx + rb * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(GLB_PTR(dY + (size_t)m * lddy + ycol[i]), LDS_PTR(sy + rb * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(GLB_PTR(X + (size_t)m * ldx + xcol[i]), LDS_PTR(sx + rb * 1024), 16, 0, 0);
       } else {
         // ragged last tile: rows >= m_end contribute zeros
         uint4 vy = make_uint4(0, 0, 0, 0), vx = make_uint4(0, 0, 0, 0);
         if (m < m_end) {
-          vy = *reinterpret_cast<const uint4*>(dY + (size_t)m * lddy + ycol);
-          vx = *reinterpret_cast<const uint4*>(X + (size_t)m * ldx + xcol);
+          vy = *reinterpret_cast<const uint4*>(dY + (size_t)m * lddy + ycol[i]);
+          vx = *reinterpret_cast<const uint4*>(X + (size_t)m * ldx + xcol[i]);
         }
         *reinterpret_cast<uint4*>(sy + rb * 1024 + lane * 16) = vy;
         *reinterpret_cast<uint4*>(sx + rb * 1024 + lane * 16) = vx;
@@ -289,9 +301,17 @@ void gemm_wgrad_kernel(const bf16* __restrict__ dY, int lddy, const bf16* __rest
   const int wi = wid >> 1, wj = wid & 1;
   const int ft = lane & 15, fg = lane >> 4;
   // tr16 address of lane (t,g) for k-step ks, half jj, sub-tile c:
-  //   row = ks*32 + g*8 + jj*4 + (t>>2);  col = wave_base + c*16 + (t&3)*4
-  const int y_off = (fg * 8 + (ft >> 2)) * WG_ROWB + (wi * 64 + (ft & 3) * 4) * 2;
-  const int x_off = WG_TILE_BYTES + (fg * 8 + (ft >> 2)) * WG_ROWB + (wj * 64 + (ft & 3) * 4) * 2;
+  //   row = ks*32 + g*8 + jj*4 + (t>>2);  col = wave_base + c*16 + (t&3)*4  (8-byte piece)
+  //   chunk = col / 8 swizzled with f(row) << 1, f(row) = (t>>2) | (g&1)<<2 for every ks, jj
+  const int frow = (fg * 8 + (ft >> 2)) * WG_ROWB;
+  const int fsw = ((ft >> 2) | ((fg & 1) << 2)) << 1;
+  int y_off[4], x_off[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int qy = wi * 8 + 2 * c + ((ft & 3) >> 1), qx = wj * 8 + 2 * c + ((ft & 3) >> 1);
+    y_off[c] = frow + ((qy ^ fsw) << 4) + ((ft & 1) << 3);
+    x_off[c] = WG_TILE_BYTES + frow + ((qx ^ fsw) << 4) + ((ft & 1) << 3);
+  }
 
   f32x4 acc[4][4];
 #pragma unroll
@@ -311,8 +331,8 @@ void gemm_wgrad_kernel(const bf16* __restrict__ dY, int lddy, const bf16* __rest
       bf16x8 yf[4], xf[4];
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        const char* py = sbase + y_off + ks * 32 * WG_ROWB + c * 32;
-        const char* px = sbase + x_off + ks * 32 * WG_ROWB + c * 32;
+        const char* py = sbase + y_off[c] + ks * 32 * WG_ROWB;
+        const char* px = sbase + x_off[c] + ks * 32 * WG_ROWB;
         bf16x4 y0 = lds_tr16(py), y1 = lds_tr16(py + 4 * WG_ROWB);
         bf16x4 x0 = lds_tr16(px), x1 = lds_tr16(px + 4 * WG_ROWB);
         yf[c] = bf16x8{y0[0], y0[1], y0[2], y0[3], y1[0], y1[1], y1[2], y1[3]};
