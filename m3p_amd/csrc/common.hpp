@@ -45,14 +45,32 @@ __host__ __device__ __forceinline__ bool m3p_keep(uint32_t idx, uint32_t seed, u
 // ---------------------------------------------------------------------------
 // math
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ float gelu_erf_f(float x) {
-  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+// erf-based GELU (M3P/src/model/transformer.py:48-56) in ~16 VALU ops instead of libm's erff:
+// Abramowitz-Stegun 7.1.26, |erf error| <= 1.5e-7 (two orders below bf16/fp32-accumulate
+// noise of the surrounding GEMM).  exp(-z^2), z = x/sqrt(2), is shared with the Gaussian pdf
+// of the derivative.  v_exp_f32 / v_rcp_f32 are the only transcendentals.
+struct GeluParts { float cdf; float pdf; };   // Phi(x) and phi(x)
+__device__ __forceinline__ GeluParts gelu_parts(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __frcp_rn(1.0f + 0.3275911f * z);
+  const float e = __expf(-z * z);   // = exp(-x^2/2)
+  float poly = 1.061405429f;
+  poly = poly * t - 1.453152027f;
+  poly = poly * t + 1.421413741f;
+  poly = poly * t - 0.284496736f;
+  poly = poly * t + 0.254829592f;
+  const float erf_abs = 1.0f - poly * t * e;            // erf(|x|/sqrt2)
+  const float cdf_abs = 0.5f + 0.5f * erf_abs;          // Phi(|x|)
+  GeluParts r;
+  r.cdf = (x >= 0.f) ? cdf_abs : 1.0f - cdf_abs;
+  r.pdf = 0.39894228040143267794f * e;
+  return r;
 }
-// d/dx [0.5 x (1 + erf(x/sqrt2))] = 0.5 (1 + erf(x/sqrt2)) + x * exp(-x^2/2) / sqrt(2 pi)
+__device__ __forceinline__ float gelu_erf_f(float x) { return x * gelu_parts(x).cdf; }
+// d/dx [x Phi(x)] = Phi(x) + x phi(x)
 __device__ __forceinline__ float gelu_erf_grad_f(float x) {
-  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
-  return cdf + x * pdf;
+  const GeluParts g = gelu_parts(x);
+  return g.cdf + x * g.pdf;
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -16,6 +16,9 @@
 #include "../../include/m3p_hip.h"
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
+static int g_variant = 1;  // debug: 0 = force the 128x128 2-stage kernel, 1 = persistent 256x128 ring for M >= 1024
+extern "C" __attribute__((visibility("default"))) void m3p_debug_set_variant(int v) { g_variant = v; }
+
 namespace {
 
 constexpr int BK = 64;            // contraction elements per LDS stage
@@ -205,9 +208,324 @@ void gemm_nt_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict_
   }
 }
 
+// ---------------------------------------------------------------------------------
+// NT kernel, ring version (the production path for large M): 256x128 output tile, 8 waves
+// (4 x 2, 64x64 each), three 48-KB LDS stages (144 of the CU's 160 KB).  HBM -> LDS loads run
+// TWO K-tiles ahead of the MFMAs and are retired with a COUNTED s_waitcnt vmcnt(6) (one
+// tile = 6 LDS-DMA instructions per wave stays in flight across the barrier), so the
+// workgroup never drains its memory pipeline inside the K loop; one raw s_barrier per K-tile.
+// MFMA operand fragments are double-buffered per 32-deep k-step: the ds_read_b128s of the
+// next k-step are issued before the 16 MFMAs of the current one.
+// ---------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------
+// Epilogue of an interior wave tile through LDS: the MFMA result layout gives a lane 4
+// consecutive columns of one row (8-byte pieces, 32-B row segments per store instruction);
+// staging 32 rows x 64 columns in LDS turns that into 16 bytes per lane and whole 128-B lines
+// per 8 lanes.  `half` selects rows [32*half, 32*half+32) of the 64x64 wave tile.
+// ---------------------------------------------------------------------------------
+constexpr int EP_PITCH = 144;                 // bytes per staged row: 128 + 16 (16-B aligned, rotates banks)
+constexpr int EP_HALF = 32 * EP_PITCH;        // 4608 B per wave half-tile
+
+template <int EPI>
+__device__ __forceinline__ void epilogue_half(const M3PEpilogue& ep, bf16* __restrict__ C, int ldc, int N,
+                                              int mw, int nw, int half, char* r1, const f32x4 (&acc)[4][4],
+                                              int lane, f32x4 (&csum)[4]) {
+  const int fr = lane & 15, fg = lane >> 4;
+  const int srow = lane >> 3, sch = lane & 7;
+  constexpr bool kAux = (EPI == M3P_EPI_BIAS_DROP_RES || EPI == M3P_EPI_RES || EPI == M3P_EPI_DGELU);
+  const float alpha = (ep.alpha == 0.f) ? 1.f : ep.alpha;
+  bf16x4 ukeep[2][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = nw + j * 16 + fg * 4;
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    if ((EPI == M3P_EPI_BIAS || EPI == M3P_EPI_BIAS_GELU || EPI == M3P_EPI_BIAS_DROP_RES) && ep.bias)
+      bias4 = *reinterpret_cast<const f32x4*>(ep.bias + n);
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii) {
+      const int i = 2 * half + ii;
+      const int rl = ii * 16 + fr;                  // row inside the staged half
+      const int mrow = mw + i * 16 + fr;            // global row
+      const int lo = rl * EP_PITCH + (j * 16 + fg * 4) * 2;
+      f32x4 v = acc[i][j];
+      if (EPI == M3P_EPI_NONE || EPI == M3P_EPI_BIAS || EPI == M3P_EPI_RES) v *= alpha;
+      v += bias4;
+      if (EPI == M3P_EPI_BIAS) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (n + r < ep.scale_cols) v[r] *= ep.scale;
+      }
+      if (EPI == M3P_EPI_BIAS_GELU) {
+        ukeep[ii][j] = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_erf_f((float)ukeep[ii][j][r]);
+      }
+      if (EPI == M3P_EPI_BIAS_DROP_RES && ep.thresh24) {
+        const uint32_t base = (uint32_t)mrow * (uint32_t)N + (uint32_t)n;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = m3p_keep(base + r, ep.seed, ep.thresh24) ? v[r] * ep.inv_keep : 0.f;
+      }
+      if (kAux) {
+        const bf16x4 t = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16*>(ep.aux) +
+                                                            (size_t)mrow * ep.ld_aux + n);
+        const f32x4 a = f32x4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
+        if (EPI == M3P_EPI_DGELU) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_grad_f(a[r]);
+        } else {
+          v += a;
+        }
+      }
+      const bf16x4 ob = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+      *reinterpret_cast<bf16x4*>(r1 + lo) = ob;
+      if (EPI == M3P_EPI_DGELU) csum[j] += f32x4{(float)ob[0], (float)ob[1], (float)ob[2], (float)ob[3]};
+    }
+  }
+  bf16* Cp = C + (size_t)(mw + 32 * half) * ldc + nw + sch * 8;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int row = it * 8 + srow;
+    *reinterpret_cast<uint4*>(Cp + (size_t)row * ldc) = *reinterpret_cast<const uint4*>(r1 + row * EP_PITCH + sch * 16);
+  }
+  if (EPI == M3P_EPI_BIAS_GELU) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii)
+        *reinterpret_cast<bf16x4*>(r1 + (ii * 16 + fr) * EP_PITCH + (j * 16 + fg * 4) * 2) = ukeep[ii][j];
+    bf16* Up = reinterpret_cast<bf16*>(ep.out2) + (size_t)(mw + 32 * half) * ep.ld_out2 + nw + sch * 8;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = it * 8 + srow;
+      *reinterpret_cast<uint4*>(Up + (size_t)row * ep.ld_out2) = *reinterpret_cast<const uint4*>(r1 + row * EP_PITCH + sch * 16);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// NT kernel, persistent ring version (the production path): one 8-wave workgroup per CU walks
+// a list of 256x128 output tiles; the K-tiles of all its output tiles form ONE continuous
+// stream through three 48-KB LDS stages (144 of the CU's 160 KB):
+//   * HBM -> LDS loads (global_load_lds) run TWO K-tiles ahead of the MFMAs — across output
+//     tile boundaries too, so the next tile's operands arrive during this tile's epilogue —
+//     and are retired with a COUNTED s_waitcnt vmcnt(6) (one K-tile = 6 LDS-DMA instructions
+//     per wave stays in flight across the barrier); one raw s_barrier per K-tile;
+//   * MFMA operand fragments are double-buffered per 32-deep k-step with inline-asm
+//     ds_read_b128 (our wait, not the compiler's): 8 reads are issued, the 16 MFMAs of the
+//     other fragment set hide them (cdna guide 5.7 form iii);
+//   * no per-tile workgroup launch (measured: 3.2 us of a 17 us tile), no drained pipeline;
+//   * the epilogue stages its bf16 tile in the LDS stage that was just consumed.
+// Tile order: round r of the persistent loop gives XCD x the 32 consecutive tile ids
+// [256 r + 32 x, +32): n-tiles of the same A row-panel share that XCD's L2.
+// ---------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(512)
+void gemm_nt_ring_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ W, int ldw,
+                         bf16* __restrict__ C, int ldc, int M, int N, int K, M3PEpilogue ep,
+                         int tiles_m, int tiles_n) {
+  constexpr int BM = 256, BN = 128, NWAVES = 8;
+  constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntiles = tiles_m * tiles_n;
+  const int nwg = gridDim.x;
+  // persistent schedule: sequence index q -> tile id
+  const int per_xcd = nwg >> 3;                       // workgroups per XCD (grid is a multiple of 8)
+  const int slot = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  auto tile_of = [&](int q) { return q * nwg + slot; };
+  const int my_tiles = (ntiles > slot) ? (ntiles - slot + nwg - 1) / nwg : 0;
+  if (my_tiles == 0) return;
+  const int nk = K / BK;
+  const int total = my_tiles * nk;
+
+  // ---- load cursor
+  const int sr = lane >> 3, sc = (lane & 7) ^ sr;
+  const bf16* a_src[4];
+  const bf16* w_src[2];
+  int l_q = 0, l_kt = 0;
+  auto set_load_tile = [&](int q) {
+    const int t = tile_of(q);
+    const int tm = t / tiles_n, tn = t - tm * tiles_n;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a_src[i] = A + (size_t)min(tm * BM + (wid + i * NWAVES) * 8 + sr, M - 1) * lda + sc * 8;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) w_src[i] = W + (size_t)min(tn * BN + (wid + i * NWAVES) * 8 + sr, N - 1) * ldw + sc * 8;
+  };
+  auto stage_next = [&](int s) {   // issue the loads of the next K-tile of the stream into stage s
+    char* sa = smem + s * STAGE;
+    char* sb = sa + A_BYTES;
+    const int k0 = l_kt * BK;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds(GLB_PTR(a_src[i] + k0), LDS_PTR(sa + (wid + i * NWAVES) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_global_load_lds(GLB_PTR(w_src[i] + k0), LDS_PTR(sb + (wid + i * NWAVES) * 1024), 16, 0, 0);
+    if (++l_kt == nk) { l_kt = 0; ++l_q; if (l_q < my_tiles) set_load_tile(l_q); }
+  };
+
+  // ---- fragment addressing
+  const int wm = wid >> 1, wn = wid & 1;
+  const int fr = lane & 15, fg = lane >> 4;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  uint32_t a_addr[2], b_addr[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int ch = ((fg + 4 * ks) ^ (fr & 7)) * 16;
+    a_addr[ks] = lds0 + (wm * 64 + fr) * ROWB + ch;
+    b_addr[ks] = lds0 + A_BYTES + (wn * 64 + fr) * ROWB + ch;
+  }
+#define M3P_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
+  auto read_set = [&](uint32_t aa, uint32_t ba, bf16x8 (&af)[4], bf16x8 (&wf)[4]) {
+    M3P_DSR(wf[0], ba, 0); M3P_DSR(af[0], aa, 0);
+    M3P_DSR(wf[1], ba, 2048); M3P_DSR(wf[2], ba, 4096); M3P_DSR(wf[3], ba, 6144);
+    M3P_DSR(af[1], aa, 2048); M3P_DSR(af[2], aa, 4096); M3P_DSR(af[3], aa, 6144);
+  };
+#define M3P_LGKM0() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto mfma_batch = [&](const bf16x8 (&af)[4], const bf16x8 (&wf)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+  };
+
+  // ---- prologue of the stream
+  set_load_tile(0);
+  stage_next(0);
+  if (total > 1) {
+    stage_next(1);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  bf16x8 af0[4], wf0[4], af1[4], wf1[4];
+  read_set(a_addr[0], b_addr[0], af0, wf0);
+  M3P_LGKM0();
+  int cur = 0;      // stage of the current K-tile
+  int c_q = 0, c_kt = 0;
+  const bool io_aligned = ((ldc & 7) == 0) && (((uintptr_t)C & 15) == 0) &&
+                          (!(EPI == M3P_EPI_BIAS_GELU) || (((ep.ld_out2 & 7) == 0) && (((uintptr_t)ep.out2 & 15) == 0))) &&
+                          (!ep.bias || (((uintptr_t)ep.bias & 15) == 0));
+  for (int step = 0; step < total; ++step) {
+    const int nxt = (cur == 2) ? 0 : cur + 1;
+    const int nx2 = (nxt == 2) ? 0 : nxt + 1;
+    const bool more2 = (step + 2 < total);
+    if (more2) stage_next(nx2);
+    read_set(a_addr[1] + cur * STAGE, b_addr[1] + cur * STAGE, af1, wf1);
+    __builtin_amdgcn_sched_barrier(0);   // reads first, then the MFMAs that hide them
+    mfma_batch(af0, wf0);
+    // k-step-1 fragments are in; every LDS read of this K-tile is complete; the next K-tile
+    // has landed for this wave -> publish
+    M3P_LGKM0();
+    if (more2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    read_set(a_addr[0] + nxt * STAGE, b_addr[0] + nxt * STAGE, af0, wf0);   // stale after the last K-tile: unused
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_batch(af1, wf1);
+    M3P_LGKM0();
+
+    if (++c_kt == nk) {
+      // ---- epilogue of output tile c_q; stage `cur` is free (all waves passed the barrier above)
+      c_kt = 0;
+      const int t = tile_of(c_q);
+      ++c_q;
+      const int tm = t / tiles_n, tn = t - tm * tiles_n;
+      const int m0 = tm * BM, n0 = tn * BN;
+      const int mw = m0 + wm * 64, nw = n0 + wn * 64;
+      f32x4 csum[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) csum[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const bool fast = io_aligned && (m0 + BM <= M) && (n0 + BN <= N);
+      if (fast) {
+        char* r1 = smem + cur * STAGE + wid * 6144;
+        epilogue_half<EPI>(ep, C, ldc, N, mw, nw, 0, r1, acc, lane, csum);
+        epilogue_half<EPI>(ep, C, ldc, N, mw, nw, 1, r1, acc, lane, csum);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            epilogue_store<EPI>(ep, C, ldc, M, N, mw + i * 16 + fr, nw + j * 16 + fg * 4, acc[i][j], csum[j]);
+      }
+      if (EPI == M3P_EPI_DGELU && ep.colsum) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float sfl = csum[j][r];
+            sfl += __shfl_xor(sfl, 1, 64); sfl += __shfl_xor(sfl, 2, 64);
+            sfl += __shfl_xor(sfl, 4, 64); sfl += __shfl_xor(sfl, 8, 64);
+            const int n = nw + j * 16 + fg * 4 + r;
+            if (fr == 0 && n < N) unsafeAtomicAdd(ep.colsum + n, sfl);
+          }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (step + 1 < total) {
+        // the staging region is the slot the next iteration's loads go into: nobody may issue
+        // them before every wave has finished its LDS round trip
+        M3P_LGKM0();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
+    }
+    cur = nxt;
+  }
+#undef M3P_DSR
+#undef M3P_LGKM0
+}
+
+static int num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+    if (n <= 0) n = 256;
+    n -= n % 8;   // the persistent schedule deals tiles out per XCD
+    if (n <= 0) n = 8;
+  }
+  return n;
+}
+
 template <int EPI>
 int launch_nt(const bf16* A, int lda, const bf16* W, int ldw, bf16* C, int ldc, int M, int N, int K,
               const M3PEpilogue& ep, hipStream_t st) {
+  if (M >= 1024 && g_variant >= 1) {
+    constexpr int BM = 256, BN = 128;
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+    const size_t lds = 3 * (BM + BN) * ROWB;
+    auto kern = gemm_nt_ring_kernel<EPI>;
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return (int)e;
+      attr_set = true;
+    }
+    int grid = num_cus();                       // one persistent workgroup per CU
+    const int ntiles = tiles_m * tiles_n;
+    if (ntiles < grid) grid = (ntiles + 7) / 8 * 8;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_m, tiles_n);
+    M3P_CHECK_LAUNCH();
+    return M3P_OK;
+  }
   constexpr int BM = 128, BN = 128;
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   const size_t lds = 2 * (BM + BN) * ROWB;
