@@ -679,6 +679,201 @@ void gemm_wgrad_kernel(const bf16* __restrict__ dY, int lddy, const bf16* __rest
     }
 }
 
+// ---------------------------------------------------------------------------------
+// Weight-gradient kernel, persistent stream-K ring version (production path when M % 64 == 0):
+// dW[i,j] += alpha * sum_m dY[m,i] X[m,j] with 256(i) x 128(j) output tiles.  The whole
+// contraction space (all output tiles x all 64-row K-tiles of M) is ONE stream, ordered
+// (m-chunk of 32 K-tiles, tile, K-tile) so that workgroups running side by side work on
+// neighbouring tiles of the same m-chunk and share their dY / X panels in L2; each of the
+// 256 persistent workgroups takes an equal contiguous share of the stream (stream-K: no
+// split-factor quantisation, the minimum number of fp32-atomic flushes) and runs it through
+// the same three-stage LDS ring / counted-vmcnt / double-buffered-fragment pipeline as the NT
+// kernel; fragments come out of LDS with ds_read_b64_tr_b16 (inline asm, conflict-free
+// through the source-side segment swizzle).
+// ---------------------------------------------------------------------------------
+constexpr int WR_I = 256, WR_J = 128;
+constexpr int WR_YROW = WR_I * 2, WR_XROW = WR_J * 2;             // 512 / 256 B per LDS row
+constexpr int WR_YB = BK * WR_YROW, WR_XB = BK * WR_XROW;         // 32 KB + 16 KB
+constexpr int WR_STAGE = WR_YB + WR_XB;
+constexpr int WR_CHUNK = 32;                                      // K-tiles per m-chunk
+
+struct WgCursor {
+  int c, t, mt, len;   // m-chunk, tile, K-tile inside the chunk, K-tiles in this chunk
+};
+
+__global__ __launch_bounds__(512)
+void gemm_wgrad_ring_kernel(const bf16* __restrict__ dY, int lddy, const bf16* __restrict__ X, int ldx,
+                            float* __restrict__ dW, int lddw, int M, int N, int K, float alpha,
+                            int tiles_i, int tiles_j) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntile = tiles_i * tiles_j;
+  const int nmt = M / BK;
+  const long long total_all = (long long)ntile * nmt;
+  const int nwg = gridDim.x;
+  const int per_xcd = nwg >> 3;
+  const int slot = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  const int g0 = (int)(total_all * slot / nwg), g1 = (int)(total_all * (slot + 1) / nwg);
+  const int total = g1 - g0;
+  if (total <= 0) return;
+
+  auto locate = [&](int g) {
+    WgCursor cu;
+    const int full = ntile * WR_CHUNK;
+    cu.c = g / full;
+    const int rem = g - cu.c * full;
+    cu.len = min(WR_CHUNK, nmt - cu.c * WR_CHUNK);
+    cu.t = rem / cu.len;
+    cu.mt = rem - cu.t * cu.len;
+    return cu;
+  };
+  auto advance = [&](WgCursor& cu) {
+    if (++cu.mt == cu.len) {
+      cu.mt = 0;
+      if (++cu.t == ntile) { cu.t = 0; ++cu.c; cu.len = min(WR_CHUNK, nmt - cu.c * WR_CHUNK); }
+    }
+  };
+
+  // ---- staging.  dY: one wave instruction = 2 rows x 512 B, lane -> (row l>>5, pos l&31);
+  //      X: 4 rows x 256 B, lane -> (row l>>4, pos l&15).  Segment swizzle as in the 128^2 kernel.
+  const int n_chunks = (N + 7) / 8, k_chunks = (K + 7) / 8;
+  WgCursor lc = locate(g0);
+  auto stage_next = [&](int s) {
+    char* sy = smem + s * WR_STAGE;
+    char* sx = sy + WR_YB;
+    const int ti = lc.t / tiles_j, tj = lc.t - ti * tiles_j;
+    const int mbase = (lc.c * WR_CHUNK + lc.mt) * BK;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rb = wid + i * 8;               // 2-row group 0..31
+      const int row = rb * 2 + (lane >> 5);
+      const int f = (row & 3) | (((row >> 3) & 1) << 2);
+      const int gc = (lane & 31) ^ (f << 1);
+      const int col = min(ti * (WR_I / 8) + gc, n_chunks - 1) * 8;
+      __builtin_amdgcn_global_load_lds(GLB_PTR(dY + (size_t)(mbase + row) * lddy + col), LDS_PTR(sy + rb * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int rb = wid + i * 8;               // 4-row group 0..15
+      const int row = rb * 4 + (lane >> 4);
+      const int f = (row & 3) | (((row >> 3) & 1) << 2);
+      const int gc = (lane & 15) ^ (f << 1);
+      const int col = min(tj * (WR_J / 8) + gc, k_chunks - 1) * 8;
+      __builtin_amdgcn_global_load_lds(GLB_PTR(X + (size_t)(mbase + row) * ldx + col), LDS_PTR(sx + rb * 1024), 16, 0, 0);
+    }
+    advance(lc);
+  };
+
+  // ---- fragment addressing (tr16): lane (t = l&15, g = l>>4) reads row g*8 + (t>>2) (+32 ks, +4 jj),
+  //      8-byte piece (t&3) of 16-column sub-tile c
+  const int wi = wid >> 1, wj = wid & 1;
+  const int ft = lane & 15, fg = lane >> 4;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const int frow = fg * 8 + (ft >> 2);
+  const int fsw = ((ft >> 2) | ((fg & 1) << 2)) << 1;
+  uint32_t y_addr[4], x_addr[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int qy = wi * 8 + 2 * c + ((ft & 3) >> 1), qx = wj * 8 + 2 * c + ((ft & 3) >> 1);
+    y_addr[c] = lds0 + frow * WR_YROW + ((qy ^ fsw) << 4) + ((ft & 1) << 3);
+    x_addr[c] = lds0 + WR_YB + frow * WR_XROW + ((qx ^ fsw) << 4) + ((ft & 1) << 3);
+  }
+#define M3P_TR(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
+  // k-step 0 / 1 of a stage: row offsets 0 / 32 rows; second half of a fragment: +4 rows
+  auto read_set0 = [&](uint32_t so, s16x4 (&y)[4][2], s16x4 (&x)[4][2]) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      M3P_TR(y[c][0], y_addr[c] + so, 0); M3P_TR(y[c][1], y_addr[c] + so, 2048);
+      M3P_TR(x[c][0], x_addr[c] + so, 0); M3P_TR(x[c][1], x_addr[c] + so, 1024);
+    }
+  };
+  auto read_set1 = [&](uint32_t so, s16x4 (&y)[4][2], s16x4 (&x)[4][2]) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      M3P_TR(y[c][0], y_addr[c] + so, 16384); M3P_TR(y[c][1], y_addr[c] + so, 18432);
+      M3P_TR(x[c][0], x_addr[c] + so, 8192); M3P_TR(x[c][1], x_addr[c] + so, 9216);
+    }
+  };
+#define M3P_LGKM0() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto frag = [](const s16x4 (&h)[2]) {
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(h[0], h[1], 0, 1, 2, 3, 4, 5, 6, 7));
+  };
+  auto mfma_batch = [&](const s16x4 (&y)[4][2], const s16x4 (&x)[4][2]) {
+    bf16x8 yf[4], xf[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { yf[c] = frag(y[c]); xf[c] = frag(x[c]); }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[a], xf[b], acc[a][b], 0, 0, 0);
+  };
+
+  stage_next(0);
+  if (total > 1) {
+    stage_next(1);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  s16x4 y0[4][2], x0[4][2], y1[4][2], x1[4][2];
+  read_set0(0, y0, x0);
+  M3P_LGKM0();
+  WgCursor cc = locate(g0);
+  int cur = 0;
+  for (int step = 0; step < total; ++step) {
+    const int nxt = (cur == 2) ? 0 : cur + 1;
+    const int nx2 = (nxt == 2) ? 0 : nxt + 1;
+    const bool more2 = (step + 2 < total);
+    if (more2) stage_next(nx2);
+    read_set1(cur * WR_STAGE, y1, x1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_batch(y0, x0);
+    M3P_LGKM0();
+    if (more2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    read_set0(nxt * WR_STAGE, y0, x0);   // stale after the last K-tile: unused
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_batch(y1, x1);
+    M3P_LGKM0();
+
+    const bool last_of_tile = (cc.mt + 1 == cc.len) || (step + 1 == total);
+    if (last_of_tile) {
+      // flush this (tile, chunk) segment: D[i][j], lane holds j = l&15, i = 4*(l>>4)+r
+      const int ti = cc.t / tiles_j, tj = cc.t - ti * tiles_j;
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const int j = tj * WR_J + wj * 64 + b * 16 + ft;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = ti * WR_I + wi * 64 + a * 16 + fg * 4 + r;
+            if (i < N && j < K) unsafeAtomicAdd(dW + (size_t)i * lddw + j, alpha * acc[a][b][r]);
+            acc[a][b][r] = 0.f;
+          }
+        }
+    }
+    advance(cc);
+    cur = nxt;
+  }
+#undef M3P_TR
+#undef M3P_LGKM0
+}
+
 }  // namespace
 
 extern "C" {
@@ -712,6 +907,20 @@ int m3p_gemm_wgrad_bf16(const void* dY, int lddy, const void* X, int ldx, float*
   if (M <= 0 || N <= 0 || K <= 0 || (lddy % 8) != 0 || (ldx % 8) != 0) return M3P_EINVAL;
   if (lddy < ((N + 7) / 8) * 8 || ldx < ((K + 7) / 8) * 8) return M3P_EINVAL;
   if (((uintptr_t)dY & 15) || ((uintptr_t)X & 15)) return M3P_EINVAL;
+  if (g_variant >= 1 && (M % BK) == 0 && M >= 4096) {
+    const int ti = (N + WR_I - 1) / WR_I, tj = (K + WR_J - 1) / WR_J;
+    const size_t lds = 3 * WR_STAGE;
+    static bool attr_set_r = false;
+    if (!attr_set_r) {
+      hipError_t e = hipFuncSetAttribute((const void*)gemm_wgrad_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return (int)e;
+      attr_set_r = true;
+    }
+    hipLaunchKernelGGL(gemm_wgrad_ring_kernel, dim3(num_cus()), dim3(512), lds, (hipStream_t)stream, (const bf16*)dY, lddy,
+                       (const bf16*)X, ldx, dW, lddw, M, N, K, alpha, ti, tj);
+    M3P_CHECK_LAUNCH();
+    return M3P_OK;
+  }
   const int tiles_i = (N + WG_T - 1) / WG_T, tiles_j = (K + WG_T - 1) / WG_T;
   const int ntile = tiles_i * tiles_j;
   // split the contraction so that ~2 blocks per CU are in flight; chunk is a multiple of 64

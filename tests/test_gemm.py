@@ -9,7 +9,7 @@ from tests.util import randn_bf16, randn_f32, rel_l2, max_abs
 pytestmark = pytest.mark.gpu
 
 SHAPES = [(128, 128, 64), (592, 384, 128), (300, 1000, 128), (41, 130, 192), (1024, 768, 768), (256, 3072, 768),
-          (520, 768, 3072)]
+          (520, 768, 3072), (2048 + 40, 1000, 128), (4096, 2304, 768), (9216, 768, 2048), (70000, 128, 64)]
 
 
 def _tol(K):
@@ -95,7 +95,8 @@ def test_gemm_nt_res_and_dgelu():
 
 
 @pytest.mark.parametrize('M,N,K', [(64, 128, 128), (592, 384, 128), (1000, 100, 72), (4100, 768, 768), (131, 40, 264),
-                                   (8200, 3072, 768)])
+                                   (8200, 3072, 768), (8192, 768, 768), (4288, 2304, 768), (4096, 1000, 72),
+                                   (16384, 256, 128), (4864, 5008, 768)])
 def test_gemm_wgrad(M, N, K):
     from m3p_amd import ops
     dy, dyc = randn_bf16((M, (N + 7) // 8 * 8), 1)
