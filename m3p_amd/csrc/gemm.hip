@@ -683,10 +683,13 @@ void gemm_wgrad_kernel(const bf16* __restrict__ dY, int lddy, const bf16* __rest
 // Weight-gradient kernel, persistent stream-K ring version (production path when M % 64 == 0):
 // dW[i,j] += alpha * sum_m dY[m,i] X[m,j] with 256(i) x 128(j) output tiles.  The whole
 // contraction space (all output tiles x all 64-row K-tiles of M) is ONE stream, ordered
-// (m-chunk of 32 K-tiles, tile, K-tile) so that workgroups running side by side work on
-// neighbouring tiles of the same m-chunk and share their dY / X panels in L2; each of the
-// 256 persistent workgroups takes an equal contiguous share of the stream (stream-K: no
-// split-factor quantisation, the minimum number of fp32-atomic flushes) and runs it through
+// (m-chunk, tile, K-tile) with the chunk length equal to one workgroup's share of the stream:
+// workgroup w then owns exactly (chunk w / ntile, tile w % ntile), so the 32 workgroups of an
+// XCD walk the SAME rows of M at the same time on 32 neighbouring tiles and share their
+// dY / X row blocks in that XCD's L2 (measured: L2 hit rate 5 % -> see DESIGN.md with a
+// 32-K-tile chunk, every operand byte came from the fabric).  The ragged last chunk is
+// dealt out stream-K style, so every workgroup still gets an equal share (no split-factor
+// quantisation) and at most a few fp32-atomic flushes.  Each workgroup runs its share through
 // the same three-stage LDS ring / counted-vmcnt / double-buffered-fragment pipeline as the NT
 // kernel; fragments come out of LDS with ds_read_b64_tr_b16 (inline asm, conflict-free
 // through the source-side segment swizzle).
@@ -695,7 +698,6 @@ constexpr int WR_I = 256, WR_J = 128;
 constexpr int WR_YROW = WR_I * 2, WR_XROW = WR_J * 2;             // 512 / 256 B per LDS row
 constexpr int WR_YB = BK * WR_YROW, WR_XB = BK * WR_XROW;         // 32 KB + 16 KB
 constexpr int WR_STAGE = WR_YB + WR_XB;
-constexpr int WR_CHUNK = 32;                                      // K-tiles per m-chunk
 
 struct WgCursor {
   int c, t, mt, len;   // m-chunk, tile, K-tile inside the chunk, K-tiles in this chunk
@@ -704,7 +706,7 @@ struct WgCursor {
 __global__ __launch_bounds__(512)
 void gemm_wgrad_ring_kernel(const bf16* __restrict__ dY, int lddy, const bf16* __restrict__ X, int ldx,
                             float* __restrict__ dW, int lddw, int M, int N, int K, float alpha,
-                            int tiles_i, int tiles_j) {
+                            int tiles_i, int tiles_j, int WR_CHUNK) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -714,12 +716,29 @@ void gemm_wgrad_ring_kernel(const bf16* __restrict__ dY, int lddy, const bf16* _
   const int nwg = gridDim.x;
   const int per_xcd = nwg >> 3;
   const int slot = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-  const int g0 = (int)(total_all * slot / nwg), g1 = (int)(total_all * (slot + 1) / nwg);
-  const int total = g1 - g0;
-  if (total <= 0) return;
+  // Two schedules.  Few tiles / long M (every layer weight): stream-K with chunk == share, see
+  // above.  Many tiles / short M (the tied vocabulary matrix: 5862 tiles, 76 K-tiles): tiles
+  // are dealt round-robin (WR_CHUNK == 0), each done over all of M by one workgroup, so that
+  // an XCD's 32 workgroups hold 32 consecutive tiles = the six j-tiles of ~5 dY panels.
+  const bool rr = (WR_CHUNK == 0);
+  int g0, total;
+  if (rr) {
+    const int my_tiles = (ntile > slot) ? (ntile - slot + nwg - 1) / nwg : 0;
+    if (my_tiles == 0) return;
+    g0 = 0;
+    total = my_tiles * nmt;
+  } else {
+    // shares are whole chunk strips: workgroup `slot` owns stream positions [slot*share, +share)
+    const long long share = (total_all + nwg - 1) / nwg;
+    const long long g0l = share * slot;
+    if (g0l >= total_all) return;
+    g0 = (int)g0l;
+    total = (int)((g0l + share <= total_all ? g0l + share : total_all) - g0l);
+  }
 
   auto locate = [&](int g) {
     WgCursor cu;
+    if (rr) { cu.c = 0; cu.t = slot; cu.mt = 0; cu.len = nmt; return cu; }
     const int full = ntile * WR_CHUNK;
     cu.c = g / full;
     const int rem = g - cu.c * full;
@@ -731,6 +750,7 @@ void gemm_wgrad_ring_kernel(const bf16* __restrict__ dY, int lddy, const bf16* _
   auto advance = [&](WgCursor& cu) {
     if (++cu.mt == cu.len) {
       cu.mt = 0;
+      if (rr) { cu.t += nwg; return; }
       if (++cu.t == ntile) { cu.t = 0; ++cu.c; cu.len = min(WR_CHUNK, nmt - cu.c * WR_CHUNK); }
     }
   };
@@ -743,7 +763,7 @@ void gemm_wgrad_ring_kernel(const bf16* __restrict__ dY, int lddy, const bf16* _
     char* sy = smem + s * WR_STAGE;
     char* sx = sy + WR_YB;
     const int ti = lc.t / tiles_j, tj = lc.t - ti * tiles_j;
-    const int mbase = (lc.c * WR_CHUNK + lc.mt) * BK;
+    const int mbase = (lc.c * WR_CHUNK + lc.mt) * BK;   // (c == 0 in round-robin mode)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int rb = wid + i * 8;               // 2-row group 0..31
@@ -916,8 +936,13 @@ int m3p_gemm_wgrad_bf16(const void* dY, int lddy, const void* X, int ldx, float*
       if (e != hipSuccess) return (int)e;
       attr_set_r = true;
     }
-    hipLaunchKernelGGL(gemm_wgrad_ring_kernel, dim3(num_cus()), dim3(512), lds, (hipStream_t)stream, (const bf16*)dY, lddy,
-                       (const bf16*)X, ldx, dW, lddw, M, N, K, alpha, ti, tj);
+    const int grid = num_cus();
+    const int nmt = M / BK;
+    long long share = ((long long)ti * tj * nmt + grid - 1) / grid;
+    int chunk = (int)(share < nmt ? (share < 1 ? 1 : share) : nmt);
+    if ((long long)ti * tj >= 4LL * grid) chunk = 0;   // many tiles: round-robin whole tiles
+    hipLaunchKernelGGL(gemm_wgrad_ring_kernel, dim3(grid), dim3(512), lds, (hipStream_t)stream, (const bf16*)dY, lddy,
+                       (const bf16*)X, ldx, dW, lddw, M, N, K, alpha, ti, tj, chunk);
     M3P_CHECK_LAUNCH();
     return M3P_OK;
   }
