@@ -1,0 +1,101 @@
+"""Host-side logic that needs no GPU: optimizer spec parsing / lr schedule, collate,
+mask building, the dropout RNG twin, arena layout bookkeeping."""
+import numpy as np
+import pytest
+import torch
+
+from m3p_amd import rng, synth
+
+
+def test_get_optimizer_spec_and_schedule():
+    from m3p_amd.optim import get_optimizer, AdamInverseSqrtWithWarmup
+    p = [torch.nn.Parameter(torch.zeros(4))]
+    opt = get_optimizer(p, 'adam_inverse_sqrt,beta1=0.9,beta2=0.98,lr=0.0001')
+    assert isinstance(opt, AdamInverseSqrtWithWarmup)
+    g = opt.param_groups[0]
+    assert g['betas'] == (0.9, 0.98) and g['lr'] == 1e-7 and g['num_updates'] == 0
+    assert abs(opt.get_lr_for_step(1) - 1.24975e-07) < 1e-15
+    assert abs(opt.get_lr_for_step(4000) - 1e-4) < 1e-12
+    assert abs(opt.get_lr_for_step(16000) - 0.5e-4) < 1e-12
+    with pytest.raises(Exception):
+        get_optimizer(p, 'adam,foo=1')
+    with pytest.raises(Exception):
+        get_optimizer(p, 'nosuch,lr=1')
+    # eager state like the reference (optim.py:35-40)
+    assert opt.state[p[0]]['step'] == 0 and opt.state[p[0]]['exp_avg'].shape == (4,)
+
+
+def test_cpu_fallback_param_path_matches_oracle():
+    """Parameters outside any arena take the reference loop (kept for completeness)."""
+    from m3p_amd.optim import get_optimizer
+    from oracle import ref_cpu as O
+    w = torch.nn.Parameter(torch.tensor([0.5, -1.0, 2.0]))
+    opt = get_optimizer([w], 'adam,lr=0.01,beta1=0.9,beta2=0.98,weight_decay=0.01')
+    p, m, v = w.detach().clone(), torch.zeros(3), torch.zeros(3)
+    for step in range(1, 4):
+        g = torch.tensor([0.1 * step, -0.2, 0.3])
+        w.grad = g.clone()
+        opt.step()
+        p, m, v = O.adam_step(p, g, m, v, step, 0.01, 0.9, 0.98, 1e-8, 0.01)
+        assert torch.allclose(w.detach(), p, rtol=1e-6, atol=1e-8)
+
+
+def test_batch_sentences_v2_and_get_mask():
+    from m3p_amd.trainer import batch_sentences_v2
+    sents = [np.array([5, 6, 7]), np.array([9]), np.array([], dtype=np.int64)]
+    labels = [[-1, 6, -1], [9], []]
+    x, lens, lab = batch_sentences_v2(sents, labels)
+    assert lens.tolist() == [5, 3, 2] and x.shape == (5, 3)
+    assert x[:, 0].tolist() == [0, 5, 6, 7, 2] and x[:, 1].tolist() == [0, 9, 2, 1, 1] and x[:, 2].tolist() == [0, 2, 1, 1, 1]
+    assert lab[:, 0].tolist() == [-1, -1, 6, -1, -1]
+    pm = lab != -1
+    y = lab[lab > 0]
+    assert int(pm.sum()) == 2 and y.tolist() == [9, 6] or y.tolist() == [6, 9]
+
+
+def test_rng_twin_statistics_and_determinism():
+    k1 = rng.keep_mask(200000, 123, 0.1)
+    k2 = rng.keep_mask(200000, 123, 0.1)
+    assert np.array_equal(k1, k2)
+    assert abs(k1.mean() - 0.9) < 3e-3
+    k3 = rng.keep_mask(200000, 124, 0.1)
+    assert abs((k1 == k3).mean() - (0.81 + 0.01)) < 5e-3          # independent streams
+    assert rng.keep_mask(1000, 5, 0.0).all()
+    assert rng.stream_seed(1, 2, 3) != rng.stream_seed(1, 2, 4) != rng.stream_seed(1, 3, 3)
+    # known-answer for the hash itself (pins the C and NumPy versions to each other)
+    assert int(rng.hash32(np.array([0, 1, 12345], dtype=np.uint64), 0)[0]) == 0
+    h = rng.hash32(np.array([1], dtype=np.uint64), 7)[0]
+    x = (1 * 0x9E3779B1 + 7) & 0xFFFFFFFF
+    x ^= x >> 16; x = (x * 0x21f0aaad) & 0xFFFFFFFF; x ^= x >> 15; x = (x * 0x735a2d97) & 0xFFFFFFFF; x ^= x >> 15
+    assert int(h) == x
+
+
+def test_synthetic_batch_contract():
+    cfg = synth.CONFIGS['cfg1']
+    b = synth.make_batch(cfg['T'], cfg['R'], cfg['B'], cfg['n_words'], cfg['n_pred'])
+    assert b['x'].shape == (cfg['T'], cfg['B']) and b['x'].dtype == torch.int64
+    assert int(b['lengths'].max()) == cfg['T'] and (b['x'][0] == 0).all()
+    assert int(b['pred_mask'].sum()) == b['y'].numel() == cfg['n_pred'] * cfg['B']
+    assert (b['y'] >= 4).all() and (b['x'][b['pred_mask']] == cfg['n_words'] - 1).all()
+    assert torch.allclose(b['x_img'].norm(dim=-1), torch.ones(cfg['R'], cfg['B']), atol=1e-5)
+    for i in range(cfg['B']):
+        n = int(b['lengths'][i])
+        assert b['x'][n - 1, i] == 2 and (b['x'][n:, i] == 1).all()
+
+
+def test_model_constructs_on_cpu_with_reference_names():
+    """Constructor + state-dict surface work without a GPU; running the hot path does not."""
+    from m3p_amd.model.transformer import TransformerModel
+    P = synth.model_params(64, 2, 2, 120, refine_layers=1)
+    m = TransformerModel(P, is_encoder=True, with_output=True, is_crossModal=True)
+    sd = m.state_dict()
+    for k, shape in synth.hot_param_shapes(P).items():
+        assert tuple(sd[k].shape) == tuple(shape), k
+    assert 'refine_embeddings.layers.0.self_attn.aoa_layer.0.weight' in sd
+    assert m.pred_layer.proj.weight is m.embeddings.weight
+    assert float(m.embeddings.weight[P.pad_index].abs().sum()) == 0.0
+    with pytest.raises(RuntimeError):
+        m('jointfwd', x=torch.zeros(4, 2, dtype=torch.long), lengths=torch.tensor([4, 4]),
+          x_img=torch.zeros(2, 2, 2048), lengths_img=torch.tensor([2, 2]), image_loc=torch.zeros(2, 2, 5))
+    with pytest.raises(NotImplementedError):
+        m('fwd', x=None)
