@@ -74,6 +74,12 @@ typedef struct M3PEpilogue {
 M3P_API int m3p_gemm_nt_bf16(const void* A, int lda, const void* W, int ldw, void* C, int ldc,
                              int M, int N, int K, int epilogue, const M3PEpilogue* ep, void* stream);
 
+/* Stream-K variant with fp32 accumulate output: Cf[M,N] (fp32, pitch ldc) += alpha * A Wᵀ.
+ * For few-tile / very-long-K problems — the data gradient of the tied vocabulary
+ * projection (autograd of transformer.py:111: M = n_pred, N = d, K = V_pad). */
+M3P_API int m3p_gemm_nt_streamk_f32(const void* A, int lda, const void* W, int ldw, float* C, int ldc,
+                                    int M, int N, int K, float alpha, void* stream);
+
 /* Weight gradient: dW[N,K] (fp32, pitch lddw) += alpha * sum_m dY[m,n] * X[m,k]
  * (dY bf16 [M,N] pitch lddy, X bf16 [M,K] pitch ldx).  Accumulates with fp32 atomics
  * (split over M to fill 256 CUs), so dW must hold the running gradient (zero after

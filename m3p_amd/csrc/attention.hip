@@ -272,13 +272,17 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
       kf[kk] = *reinterpret_cast<const bf16x8*>(Kg + (size_t)keyc * ld + 32 * kk + 8 * fg);
       vf[kk] = *reinterpret_cast<const bf16x8*>(Vg + (size_t)keyc * ld + 32 * kk + 8 * fg);
     }
-    // P / dS for all queries against this key block: tile t covers queries 16t..16t+15,
-    // lane holds query 16t + 4fg + r for key column fq
-    f32x4 pd[2 * KT], ds[2 * KT];
+    // dV^T[d][key] = sum_q dO[q][d] Pd[q][key] ; dK^T[d][key] = sum_q Q[q][d] dS[q][key]
+    // streamed over 32-query steps: P / dS of a step are produced (lane = key column, query
+    // 16t + 4fg + r) and consumed as MFMA B operands at once — nothing S x S is held
+    f32x4 dv[Cf::NT], dk[Cf::NT];
 #pragma unroll
-    for (int t = 0; t < 2 * KT; ++t) {
-      pd[t] = ds[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (t < nt) {
+    for (int n = 0; n < Cf::NT; ++n) dv[n] = dk[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kq = 0; kq < nk; ++kq) {
+      f32x4 pd2[2], ds2[2];
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const int t = 2 * kq + hf;
         f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < Cf::KK; ++kk) {
@@ -298,30 +302,22 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
             pdrop = keep ? p * inv_keep : 0.f;
             dpr = keep ? dpr * inv_keep : 0.f;
           }
-          pd[t][r] = pdrop;
-          ds[t][r] = p * (dpr - sD[q]);
+          pd2[hf][r] = pdrop;
+          ds2[hf][r] = p * (dpr - sD[q]);
         }
       }
-    }
-    // dV^T[d][key] = sum_q dO[q][d] Pd[q][key] ; dK^T[d][key] = sum_q Q[q][d] dS[q][key]
-    f32x4 dv[Cf::NT], dk[Cf::NT];
+      const bf16x8 pfrag = bf16x8{(bf16)pd2[0][0], (bf16)pd2[0][1], (bf16)pd2[0][2], (bf16)pd2[0][3],
+                                  (bf16)pd2[1][0], (bf16)pd2[1][1], (bf16)pd2[1][2], (bf16)pd2[1][3]};
+      const bf16x8 sfrag = bf16x8{(bf16)ds2[0][0], (bf16)ds2[0][1], (bf16)ds2[0][2], (bf16)ds2[0][3],
+                                  (bf16)ds2[1][0], (bf16)ds2[1][1], (bf16)ds2[1][2], (bf16)ds2[1][3]};
 #pragma unroll
-    for (int n = 0; n < Cf::NT; ++n) dv[n] = dk[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kk = 0; kk < KT; ++kk) {
-      if (kk < nk) {
-        const f32x4 a = pd[2 * kk], c = pd[2 * kk + 1], e = ds[2 * kk], f = ds[2 * kk + 1];
-        const bf16x8 pfrag = bf16x8{(bf16)a[0], (bf16)a[1], (bf16)a[2], (bf16)a[3], (bf16)c[0], (bf16)c[1], (bf16)c[2], (bf16)c[3]};
-        const bf16x8 sfrag = bf16x8{(bf16)e[0], (bf16)e[1], (bf16)e[2], (bf16)e[3], (bf16)f[0], (bf16)f[1], (bf16)f[2], (bf16)f[3]};
-#pragma unroll
-        for (int n = 0; n < Cf::NT; ++n) {
-          const char* pq = s0 + kk * 32 * Cf::ROWB + t_off[n];
-          const char* pdo = s1 + kk * 32 * Cf::ROWB + t_off[n];
-          const bf16x8 qT = cat8(lds_tr16(pq), lds_tr16(pq + 16 * Cf::ROWB));
-          const bf16x8 dT = cat8(lds_tr16(pdo), lds_tr16(pdo + 16 * Cf::ROWB));
-          dv[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dT, pfrag, dv[n], 0, 0, 0);
-          dk[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qT, sfrag, dk[n], 0, 0, 0);
-        }
+      for (int n = 0; n < Cf::NT; ++n) {
+        const char* pq = s0 + kq * 32 * Cf::ROWB + t_off[n];
+        const char* pdo = s1 + kq * 32 * Cf::ROWB + t_off[n];
+        const bf16x8 qT = cat8(lds_tr16(pq), lds_tr16(pq + 16 * Cf::ROWB));
+        const bf16x8 dT = cat8(lds_tr16(pdo), lds_tr16(pdo + 16 * Cf::ROWB));
+        dv[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dT, pfrag, dv[n], 0, 0, 0);
+        dk[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qT, sfrag, dk[n], 0, 0, 0);
       }
     }
     if (key < S) {
@@ -362,11 +358,15 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
     }
     const float lq = sL[q], dq_ = sD[q];
     const uint32_t rbase = (uint32_t)((b * H + h) * S + qc) * (uint32_t)S;
-    f32x4 ds[2 * KT];
+    // dQ^T[d][q] = sum_key K[key][d] dS[q][key], streamed over 32-key steps
+    f32x4 dq[Cf::NT];
 #pragma unroll
-    for (int t = 0; t < 2 * KT; ++t) {
-      ds[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (t < nt) {
+    for (int n = 0; n < Cf::NT; ++n) dq[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kq = 0; kq < nk; ++kq) {
+      f32x4 ds2[2];
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const int t = 2 * kq + hf;
         f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < Cf::KK; ++kk) {
@@ -381,25 +381,16 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
           const float p = (key < klen) ? __expf(sc[r] - lq) : 0.f;
           float dpr = dp[r];
           if (thresh24) dpr = m3p_keep(rbase + (uint32_t)min(key, S - 1), seed, thresh24) ? dpr * inv_keep : 0.f;
-          ds[t][r] = p * (dpr - dq_);
+          ds2[hf][r] = p * (dpr - dq_);
         }
       }
-    }
-    // dQ^T[d][q] = sum_key K[key][d] dS[q][key]
-    f32x4 dq[Cf::NT];
+      const bf16x8 sfrag = bf16x8{(bf16)ds2[0][0], (bf16)ds2[0][1], (bf16)ds2[0][2], (bf16)ds2[0][3],
+                                  (bf16)ds2[1][0], (bf16)ds2[1][1], (bf16)ds2[1][2], (bf16)ds2[1][3]};
 #pragma unroll
-    for (int n = 0; n < Cf::NT; ++n) dq[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kk = 0; kk < KT; ++kk) {
-      if (kk < nk) {
-        const f32x4 e = ds[2 * kk], f = ds[2 * kk + 1];
-        const bf16x8 sfrag = bf16x8{(bf16)e[0], (bf16)e[1], (bf16)e[2], (bf16)e[3], (bf16)f[0], (bf16)f[1], (bf16)f[2], (bf16)f[3]};
-#pragma unroll
-        for (int n = 0; n < Cf::NT; ++n) {
-          const char* pk = s0 + kk * 32 * Cf::ROWB + t_off[n];
-          const bf16x8 kT = cat8(lds_tr16(pk), lds_tr16(pk + 16 * Cf::ROWB));
-          dq[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kT, sfrag, dq[n], 0, 0, 0);
-        }
+      for (int n = 0; n < Cf::NT; ++n) {
+        const char* pk = s0 + kq * 32 * Cf::ROWB + t_off[n];
+        const bf16x8 kT = cat8(lds_tr16(pk), lds_tr16(pk + 16 * Cf::ROWB));
+        dq[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kT, sfrag, dq[n], 0, 0, 0);
       }
     }
     if (q < S) {
@@ -472,8 +463,7 @@ int launch_bwd(const bf16* qkv, const int* keylen, const bf16* ctx, const bf16* 
     hipLaunchKernelGGL(kern, dim3(B* H), dim3(256), lds, st, qkv, keylen, ctx, dctx, lse, dqkv, dbias, S, H,    \
                        dmodel, qscale, seed, thresh24, inv_keep);                                               \
   } while (0)
-  if (nk <= 6) M3P_ATTN_BWD(6);
-  else if (nk <= 12) M3P_ATTN_BWD(12);
+  if (nk <= 16) M3P_ATTN_BWD(16);
   else return M3P_EINVAL;
 #undef M3P_ATTN_BWD
   M3P_CHECK_LAUNCH();
@@ -498,7 +488,7 @@ int m3p_attn_fwd(const void* qkv, const int32_t* keylen, void* ctx, float* lse, 
 int m3p_attn_bwd(const void* qkv, const int32_t* keylen, const void* ctx, const void* dctx, const float* lse,
                  void* dqkv, float* dbias_qkv, int B, int S, int H, int dh, float qscale, uint32_t seed,
                  uint32_t thresh24, float inv_keep, void* stream) {
-  if (B <= 0 || S <= 0 || H <= 0 || S > 384) return M3P_EINVAL;
+  if (B <= 0 || S <= 0 || H <= 0 || S > 512) return M3P_EINVAL;
   if (((uintptr_t)qkv & 15) || ((uintptr_t)ctx & 15) || ((uintptr_t)dctx & 15) || ((uintptr_t)dqkv & 7)) return M3P_EINVAL;
   const int dmodel = H * dh;
   hipStream_t st = (hipStream_t)stream;

@@ -322,7 +322,7 @@ template <int EPI>
 __global__ __launch_bounds__(512)
 void gemm_nt_ring_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ W, int ldw,
                          bf16* __restrict__ C, int ldc, int M, int N, int K, M3PEpilogue ep,
-                         int tiles_m, int tiles_n) {
+                         int tiles_m, int tiles_n, int m_fast) {
   constexpr int BM = 256, BN = 128, NWAVES = 8;
   constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -330,6 +330,12 @@ void gemm_nt_ring_kernel(const bf16* __restrict__ A, int lda, const bf16* __rest
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ntiles = tiles_m * tiles_n;
+  // tile id -> (tm, tn): n-fastest shares the A row-panel between neighbours (weights small
+  // enough for L2/MALL); m-fastest shares the W panel instead (vocabulary projection: W = 384 MB)
+  auto split_tile = [&](int t, int& tm, int& tn) {
+    if (m_fast) { tn = t / tiles_m; tm = t - tn * tiles_m; }
+    else { tm = t / tiles_n; tn = t - tm * tiles_n; }
+  };
   const int nwg = gridDim.x;
   // persistent schedule: sequence index q -> tile id
   const int per_xcd = nwg >> 3;                       // workgroups per XCD (grid is a multiple of 8)
@@ -347,7 +353,8 @@ void gemm_nt_ring_kernel(const bf16* __restrict__ A, int lda, const bf16* __rest
   int l_q = 0, l_kt = 0;
   auto set_load_tile = [&](int q) {
     const int t = tile_of(q);
-    const int tm = t / tiles_n, tn = t - tm * tiles_n;
+    int tm, tn;
+    split_tile(t, tm, tn);
 #pragma unroll
     for (int i = 0; i < 4; ++i) a_src[i] = A + (size_t)min(tm * BM + (wid + i * NWAVES) * 8 + sr, M - 1) * lda + sc * 8;
 #pragma unroll
@@ -444,7 +451,8 @@ void gemm_nt_ring_kernel(const bf16* __restrict__ A, int lda, const bf16* __rest
       c_kt = 0;
       const int t = tile_of(c_q);
       ++c_q;
-      const int tm = t / tiles_n, tn = t - tm * tiles_n;
+      int tm, tn;
+      split_tile(t, tm, tn);
       const int m0 = tm * BM, n0 = tn * BN;
       const int mw = m0 + wm * 64, nw = n0 + wn * 64;
       f32x4 csum[4];
@@ -492,6 +500,162 @@ void gemm_nt_ring_kernel(const bf16* __restrict__ A, int lda, const bf16* __rest
 #undef M3P_LGKM0
 }
 
+struct WgCursor {
+  int c, t, mt, len;   // chunk, tile, K-tile inside the chunk, K-tiles in this chunk
+};
+
+// ---------------------------------------------------------------------------------
+// NT kernel, stream-K version with fp32 atomic output: Cf[M,N] += alpha * A[M,K] W[N,K]^T for
+// few-tile / very-long-K problems (the data gradient of the vocabulary projection:
+// M = n_pred = 4864, N = 768, K = V_pad = 250 048 -> only 114 tiles of 256x128 but 3907
+// K-tiles each).  The (k-chunk, tile, K-tile) stream is dealt out exactly like the
+// weight-gradient kernel's: chunk = one workgroup's share, so all 256 CUs are busy and the six
+// N-tiles that share an A panel walk the same K range at the same time (A — the 2.4 GB
+// dlogits — is then read from HBM once instead of six times).  Same ring pipeline as
+// gemm_nt_ring_kernel; partial tiles are flushed with fp32 atomics.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(512)
+void gemm_nt_streamk_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ W, int ldw,
+                            float* __restrict__ Cf, int ldc, int M, int N, int K, float alpha,
+                            int tiles_m, int tiles_n, int CHUNK) {
+  constexpr int BM = 256, BN = 128, NWAVES = 8;
+  constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntile = tiles_m * tiles_n;
+  const int nk = K / BK;
+  const long long total_all = (long long)ntile * nk;
+  const int nwg = gridDim.x;
+  const int per_xcd = nwg >> 3;
+  const int slot = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  const long long share = (total_all + nwg - 1) / nwg;
+  const long long g0l = share * slot;
+  if (g0l >= total_all) return;
+  const int total = (int)((g0l + share <= total_all ? g0l + share : total_all) - g0l);
+
+  auto locate = [&](long long g) {
+    WgCursor cu;
+    const long long full = (long long)ntile * CHUNK;
+    cu.c = (int)(g / full);
+    const int rem = (int)(g - cu.c * full);
+    cu.len = min(CHUNK, nk - cu.c * CHUNK);
+    cu.t = rem / cu.len;
+    cu.mt = rem - cu.t * cu.len;
+    return cu;
+  };
+  auto advance = [&](WgCursor& cu) {
+    if (++cu.mt == cu.len) {
+      cu.mt = 0;
+      if (++cu.t == ntile) { cu.t = 0; ++cu.c; cu.len = min(CHUNK, nk - cu.c * CHUNK); }
+    }
+  };
+
+  const int sr = lane >> 3, sc = (lane & 7) ^ sr;
+  WgCursor lc = locate(g0l);
+  auto stage_next = [&](int s) {
+    char* sa = smem + s * STAGE;
+    char* sb = sa + A_BYTES;
+    const int tm = lc.t / tiles_n, tn = lc.t - tm * tiles_n;
+    const int k0 = (lc.c * CHUNK + lc.mt) * BK + sc * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = min(tm * BM + (wid + i * NWAVES) * 8 + sr, M - 1);
+      __builtin_amdgcn_global_load_lds(GLB_PTR(A + (size_t)row * lda + k0), LDS_PTR(sa + (wid + i * NWAVES) * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = min(tn * BN + (wid + i * NWAVES) * 8 + sr, N - 1);
+      __builtin_amdgcn_global_load_lds(GLB_PTR(W + (size_t)row * ldw + k0), LDS_PTR(sb + (wid + i * NWAVES) * 1024), 16, 0, 0);
+    }
+    advance(lc);
+  };
+
+  const int wm = wid >> 1, wn = wid & 1;
+  const int fr = lane & 15, fg = lane >> 4;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  uint32_t a_addr[2], b_addr[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int ch = ((fg + 4 * ks) ^ (fr & 7)) * 16;
+    a_addr[ks] = lds0 + (wm * 64 + fr) * ROWB + ch;
+    b_addr[ks] = lds0 + A_BYTES + (wn * 64 + fr) * ROWB + ch;
+  }
+#define M3P_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
+  auto read_set = [&](uint32_t aa, uint32_t ba, bf16x8 (&af)[4], bf16x8 (&wf)[4]) {
+    M3P_DSR(wf[0], ba, 0); M3P_DSR(af[0], aa, 0);
+    M3P_DSR(wf[1], ba, 2048); M3P_DSR(wf[2], ba, 4096); M3P_DSR(wf[3], ba, 6144);
+    M3P_DSR(af[1], aa, 2048); M3P_DSR(af[2], aa, 4096); M3P_DSR(af[3], aa, 6144);
+  };
+#define M3P_LGKM0() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto mfma_batch = [&](const bf16x8 (&af)[4], const bf16x8 (&wf)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+  };
+
+  stage_next(0);
+  if (total > 1) {
+    stage_next(1);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  bf16x8 af0[4], wf0[4], af1[4], wf1[4];
+  read_set(a_addr[0], b_addr[0], af0, wf0);
+  M3P_LGKM0();
+  WgCursor cc = locate(g0l);
+  int cur = 0;
+  for (int step = 0; step < total; ++step) {
+    const int nxt = (cur == 2) ? 0 : cur + 1;
+    const int nx2 = (nxt == 2) ? 0 : nxt + 1;
+    const bool more2 = (step + 2 < total);
+    if (more2) stage_next(nx2);
+    read_set(a_addr[1] + cur * STAGE, b_addr[1] + cur * STAGE, af1, wf1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_batch(af0, wf0);
+    M3P_LGKM0();
+    if (more2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    read_set(a_addr[0] + nxt * STAGE, b_addr[0] + nxt * STAGE, af0, wf0);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_batch(af1, wf1);
+    M3P_LGKM0();
+    if ((cc.mt + 1 == cc.len) || (step + 1 == total)) {
+      const int tm = cc.t / tiles_n, tn = cc.t - tm * tiles_n;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = tm * BM + wm * 64 + i * 16 + fr;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int n = tn * BN + wn * 64 + j * 16 + fg * 4;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (m < M && n + r < N) unsafeAtomicAdd(Cf + (size_t)m * ldc + n + r, alpha * acc[i][j][r]);
+            acc[i][j][r] = 0.f;
+          }
+        }
+      }
+    }
+    advance(cc);
+    cur = nxt;
+  }
+#undef M3P_DSR
+#undef M3P_LGKM0
+}
+
 static int num_cus() {
   static int n = 0;
   if (n == 0) {
@@ -522,7 +686,9 @@ int launch_nt(const bf16* A, int lda, const bf16* W, int ldw, bf16* C, int ldc, 
     int grid = num_cus();                       // one persistent workgroup per CU
     const int ntiles = tiles_m * tiles_n;
     if (ntiles < grid) grid = (ntiles + 7) / 8 * 8;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_m, tiles_n);
+    const long long wbytes = 2LL * N * K, abytes = 2LL * M * K;
+    const int m_fast = (wbytes > (64LL << 20) && abytes < wbytes) ? 1 : 0;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_m, tiles_n, m_fast);
     M3P_CHECK_LAUNCH();
     return M3P_OK;
   }
@@ -698,10 +864,6 @@ constexpr int WR_I = 256, WR_J = 128;
 constexpr int WR_YROW = WR_I * 2, WR_XROW = WR_J * 2;             // 512 / 256 B per LDS row
 constexpr int WR_YB = BK * WR_YROW, WR_XB = BK * WR_XROW;         // 32 KB + 16 KB
 constexpr int WR_STAGE = WR_YB + WR_XB;
-
-struct WgCursor {
-  int c, t, mt, len;   // m-chunk, tile, K-tile inside the chunk, K-tiles in this chunk
-};
 
 __global__ __launch_bounds__(512)
 void gemm_wgrad_ring_kernel(const bf16* __restrict__ dY, int lddy, const bf16* __restrict__ X, int ldx,
@@ -920,6 +1082,28 @@ int m3p_gemm_nt_bf16(const void* A, int lda, const void* W, int ldw, void* C, in
     case M3P_EPI_DGELU: return launch_nt<M3P_EPI_DGELU>(a, lda, w, ldw, c, ldc, M, N, K, ep, st);
     default: return M3P_EINVAL;
   }
+}
+
+int m3p_gemm_nt_streamk_f32(const void* A, int lda, const void* W, int ldw, float* C, int ldc, int M, int N, int K,
+                            float alpha, void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || (K % BK) != 0 || (lda % 8) != 0 || (ldw % 8) != 0) return M3P_EINVAL;
+  if (((uintptr_t)A & 15) || ((uintptr_t)W & 15)) return M3P_EINVAL;
+  const int tiles_m = (M + 255) / 256, tiles_n = (N + 127) / 128;
+  const size_t lds = 3 * (256 + 128) * ROWB;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_streamk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const int grid = num_cus();
+  const int nk = K / BK;
+  long long share = ((long long)tiles_m * tiles_n * nk + grid - 1) / grid;
+  const int chunk = (int)(share < nk ? (share < 1 ? 1 : share) : nk);
+  hipLaunchKernelGGL(gemm_nt_streamk_kernel, dim3(grid), dim3(512), lds, (hipStream_t)stream, (const bf16*)A, lda,
+                     (const bf16*)W, ldw, C, ldc, M, N, K, alpha, tiles_m, tiles_n, chunk);
+  M3P_CHECK_LAUNCH();
+  return M3P_OK;
 }
 
 int m3p_gemm_wgrad_bf16(const void* dY, int lddy, const void* X, int ldx, float* dW, int lddw, int M, int N, int K,

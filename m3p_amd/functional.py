@@ -322,8 +322,9 @@ class MLMHeadFn(torch.autograd.Function):
         hs = (hsel.float() * g).to(BF16)
         ops.gemm_wgrad(dlogits, hs, ar.g('embeddings.weight'), n=V, k=d)
         ops.colsum(dlogits, V, ar.g('pred_layer.proj.bias'), scale=g)
-        dH = ops.gemm_nt(dlogits, ar.wt['emb'], L.EPI_NONE)
-        dH = (dH.float() * g).to(BF16)
+        dH32 = torch.zeros((n, d), dtype=torch.float32, device=dlogits.device)
+        ops.gemm_nt_streamk(dlogits, ar.wt['emb'], dH32)
+        dH = (dH32 * g).to(BF16)
         # gradient wrt `tensor` (a strided view of the encoder output): build it on a zeroed
         # twin of the underlying row buffer and hand autograd the same strided view of it
         dbase = torch.zeros_like(base)

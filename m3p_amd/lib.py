@@ -34,6 +34,7 @@ _p, _i, _f, _u32 = C.c_void_p, C.c_int, C.c_float, C.c_uint32
 SIGNATURES = {
     'm3p_version': (C.c_char_p, []),
     'm3p_gemm_nt_bf16': (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, C.POINTER(Epilogue), _p]),
+    'm3p_gemm_nt_streamk_f32': (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _f, _p]),
     'm3p_gemm_wgrad_bf16': (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _f, _p]),
     'm3p_layernorm_fwd': (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p]),
     'm3p_layernorm_bwd': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _u32, _u32, _f, _p]),

@@ -72,6 +72,20 @@ def gemm_nt(a, w, epilogue=L.EPI_NONE, bias=None, aux=None, out=None, out2=None,
     return out
 
 
+def gemm_nt_streamk(a, w, out_f32, alpha=1.0):
+    """out_f32[M,N] (fp32) += alpha * a[M,K] @ w[N,K]^T  (stream-K, fp32 atomics)."""
+    _chk_bf16(a, w)
+    M, K = a.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and out_f32.dtype == torch.float32 and out_f32.shape == (M, N)
+    e0 = _prof_begin()
+    rc = L.load().m3p_gemm_nt_streamk_f32(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), out_f32.data_ptr(),
+                                          out_f32.stride(0), M, N, K, alpha, L.stream())
+    L.check(rc, 'm3p_gemm_nt_streamk_f32')
+    _prof_end(e0, ('gemm_nt/streamk', M, N, K))
+    return out_f32
+
+
 def gemm_wgrad(dy, x, dw, alpha=1.0, n=None, k=None):
     """dw[N,K] (fp32) += alpha * dy[M,N]^T @ x[M,K]."""
     _chk_bf16(dy, x)

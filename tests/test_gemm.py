@@ -136,3 +136,14 @@ def test_gemm_perf_smoke():
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 10
         print('gemm_wgrad M=%d N=%d K=%d: %.3f ms  %.1f TF' % (M, N, K, ms, 2.0 * M * N * K / ms / 1e9))
+
+
+@pytest.mark.parametrize('M,N,K', [(300, 768, 4096), (4864, 768, 25024), (1000, 130, 640)])
+def test_gemm_nt_streamk(M, N, K):
+    from m3p_amd import ops
+    a, ac = randn_bf16((M, K), 1, 0.5)
+    w, wc = randn_bf16((N, K), 2, 0.05)
+    out = torch.ones((M, N), dtype=torch.float32, device='cuda')
+    ops.gemm_nt_streamk(a, w, out, alpha=0.5)
+    ref = 1.0 + 0.5 * (ac.double() @ wc.double().t())
+    assert rel_l2(out, ref) < 1e-5
