@@ -221,14 +221,14 @@ void gemm_nt_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict_
 // Epilogue of an interior wave tile through LDS: the MFMA result layout gives a lane 4
 // consecutive columns of one row (8-byte pieces, 32-B row segments per store instruction);
 // staging 32 rows x 64 columns in LDS turns that into 16 bytes per lane and whole 128-B lines
-// per 8 lanes.  `half` selects rows [32*half, 32*half+32) of the 64x64 wave tile.
+// per 8 lanes.  `rows` are two 16-row MFMA tile rows (x 4 column tiles) starting at global row mrow0.
 // ---------------------------------------------------------------------------------
 constexpr int EP_PITCH = 144;                 // bytes per staged row: 128 + 16 (16-B aligned, rotates banks)
 constexpr int EP_HALF = 32 * EP_PITCH;        // 4608 B per wave half-tile
 
 template <int EPI>
 __device__ __forceinline__ void epilogue_half(const M3PEpilogue& ep, bf16* __restrict__ C, int ldc, int N,
-                                              int mw, int nw, int half, char* r1, const f32x4 (&acc)[4][4],
+                                              int mrow0, int nw, char* r1, const f32x4 (&rows)[2][4],
                                               int lane, f32x4 (&csum)[4]) {
   const int fr = lane & 15, fg = lane >> 4;
   const int srow = lane >> 3, sch = lane & 7;
@@ -243,11 +243,10 @@ __device__ __forceinline__ void epilogue_half(const M3PEpilogue& ep, bf16* __res
       bias4 = *reinterpret_cast<const f32x4*>(ep.bias + n);
 #pragma unroll
     for (int ii = 0; ii < 2; ++ii) {
-      const int i = 2 * half + ii;
       const int rl = ii * 16 + fr;                  // row inside the staged half
-      const int mrow = mw + i * 16 + fr;            // global row
+      const int mrow = mrow0 + rl;                  // global row
       const int lo = rl * EP_PITCH + (j * 16 + fg * 4) * 2;
-      f32x4 v = acc[i][j];
+      f32x4 v = rows[ii][j];
       if (EPI == M3P_EPI_NONE || EPI == M3P_EPI_BIAS || EPI == M3P_EPI_RES) v *= alpha;
       v += bias4;
       if (EPI == M3P_EPI_BIAS) {
@@ -281,7 +280,7 @@ __device__ __forceinline__ void epilogue_half(const M3PEpilogue& ep, bf16* __res
       if (EPI == M3P_EPI_DGELU) csum[j] += f32x4{(float)ob[0], (float)ob[1], (float)ob[2], (float)ob[3]};
     }
   }
-  bf16* Cp = C + (size_t)(mw + 32 * half) * ldc + nw + sch * 8;
+  bf16* Cp = C + (size_t)mrow0 * ldc + nw + sch * 8;
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
     const int row = it * 8 + srow;
@@ -293,7 +292,7 @@ __device__ __forceinline__ void epilogue_half(const M3PEpilogue& ep, bf16* __res
 #pragma unroll
       for (int ii = 0; ii < 2; ++ii)
         *reinterpret_cast<bf16x4*>(r1 + (ii * 16 + fr) * EP_PITCH + (j * 16 + fg * 4) * 2) = ukeep[ii][j];
-    bf16* Up = reinterpret_cast<bf16*>(ep.out2) + (size_t)(mw + 32 * half) * ep.ld_out2 + nw + sch * 8;
+    bf16* Up = reinterpret_cast<bf16*>(ep.out2) + (size_t)mrow0 * ep.ld_out2 + nw + sch * 8;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int row = it * 8 + srow;
@@ -332,9 +331,240 @@ void gemm_nt_ring_kernel(const bf16* __restrict__ A, int lda, const bf16* __rest
   const int ntiles = tiles_m * tiles_n;
   // tile id -> (tm, tn): n-fastest shares the A row-panel between neighbours (weights small
   // enough for L2/MALL); m-fastest shares the W panel instead (vocabulary projection: W = 384 MB)
+  // strips pay off once a full row of n-tiles no longer fits beside the A panels (measured:
+  // 24 n-tiles 805 -> 914 TF with 8-wide strips; 18 n-tiles lose ~5 %, so those stay n-fastest)
+  const int n_strips = (tiles_n >= 24) ? (tiles_n + 7) / 8 : 1;
+  const int strip_w = (tiles_n + n_strips - 1) / n_strips;
+  // (default order: strips of ~8 n-tiles walked m-major, so the 32 consecutive tiles an XCD
+  //  holds in one round form a ~4 x 8 block: 4 A row-panels + 8 W panels are live per XCD
+  //  instead of 1.3 + 24 -> fewer unique bytes per step in the 4-MB L2)
   auto split_tile = [&](int t, int& tm, int& tn) {
-    if (m_fast) { tn = t / tiles_m; tm = t - tn * tiles_m; }
-    else { tm = t / tiles_n; tn = t - tm * tiles_n; }
+    if (m_fast) { tn = t / tiles_m; tm = t - tn * tiles_m; return; }
+    const int strip = t / (tiles_m * strip_w);
+    const int rem = t - strip * tiles_m * strip_w;
+    const int bn = min(strip_w, tiles_n - strip * strip_w);
+    tm = rem / bn;
+    tn = strip * strip_w + (rem - tm * bn);
+  };
+  const int nwg = gridDim.x;
+  // persistent schedule: sequence index q -> tile id
+  const int per_xcd = nwg >> 3;                       // workgroups per XCD (grid is a multiple of 8)
+  const int slot = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  auto tile_of = [&](int q) { return q * nwg + slot; };
+  const int my_tiles = (ntiles > slot) ? (ntiles - slot + nwg - 1) / nwg : 0;
+  if (my_tiles == 0) return;
+  const int nk = K / BK;
+  const int total = my_tiles * nk;
+
+  // ---- load cursor
+  const int sr = lane >> 3, sc = (lane & 7) ^ sr;
+  const bf16* a_src[4];
+  const bf16* w_src[2];
+  int l_q = 0, l_kt = 0;
+  auto set_load_tile = [&](int q) {
+    const int t = tile_of(q);
+    int tm, tn;
+    split_tile(t, tm, tn);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a_src[i] = A + (size_t)min(tm * BM + (wid + i * NWAVES) * 8 + sr, M - 1) * lda + sc * 8;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) w_src[i] = W + (size_t)min(tn * BN + (wid + i * NWAVES) * 8 + sr, N - 1) * ldw + sc * 8;
+  };
+  // one K-tile of the stream = 6 LDS-DMA instructions per wave (4 of A, 2 of W).  They are
+  // issued ONE AT A TIME between groups of MFMAs (issue_load(s, 0..5)): the CU's texture path
+  // takes ~16 cycles per 1-KiB instruction, and a wave that sits in a burst of six cannot
+  // issue its own MFMAs meanwhile (measured: 19 % of wave time in the issue burst, 21 % at the
+  // barrier waiting for the waves still issuing).
+  auto issue_load = [&](int s, int piece) {
+    char* sa = smem + s * STAGE;
+    const int k0 = l_kt * BK;
+    if (piece < 4)
+      __builtin_amdgcn_global_load_lds(GLB_PTR(a_src[piece] + k0), LDS_PTR(sa + (wid + piece * NWAVES) * 1024), 16, 0, 0);
+    else
+      __builtin_amdgcn_global_load_lds(GLB_PTR(w_src[piece - 4] + k0), LDS_PTR(sa + A_BYTES + (wid + (piece - 4) * NWAVES) * 1024), 16, 0, 0);
+  };
+  auto load_done = [&]() {
+    if (++l_kt == nk) { l_kt = 0; ++l_q; if (l_q < my_tiles) set_load_tile(l_q); }
+  };
+  auto stage_next = [&](int s) {
+#pragma unroll
+    for (int pc = 0; pc < 6; ++pc) issue_load(s, pc);
+    load_done();
+  };
+
+  // ---- fragment addressing
+  const int wm = wid >> 1, wn = wid & 1;
+  const int fr = lane & 15, fg = lane >> 4;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  uint32_t a_addr[2], b_addr[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int ch = ((fg + 4 * ks) ^ (fr & 7)) * 16;
+    a_addr[ks] = lds0 + (wm * 64 + fr) * ROWB + ch;
+    b_addr[ks] = lds0 + A_BYTES + (wn * 64 + fr) * ROWB + ch;
+  }
+#define M3P_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
+  auto read_set = [&](uint32_t aa, uint32_t ba, bf16x8 (&af)[4], bf16x8 (&wf)[4]) {
+    M3P_DSR(wf[0], ba, 0); M3P_DSR(af[0], aa, 0);
+    M3P_DSR(wf[1], ba, 2048); M3P_DSR(wf[2], ba, 4096); M3P_DSR(wf[3], ba, 6144);
+    M3P_DSR(af[1], aa, 2048); M3P_DSR(af[2], aa, 4096); M3P_DSR(af[3], aa, 6144);
+  };
+#define M3P_LGKM0() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto mfma_batch = [&](const bf16x8 (&af)[4], const bf16x8 (&wf)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+  };
+  // The two waves that share a SIMD (w and w+4) issue their LDS-DMA bursts at DIFFERENT
+  // points of the step: waves 0-3 at the top (tile step+2, two tiles ahead, vmcnt(6)), waves
+  // 4-7 right after the mid-step barrier (same tile, one step of flight time, vmcnt(0) at the
+  // next mid-step wait).  A burst costs the issuing wave ~400 cycles during which it cannot
+  // issue MFMAs; staggered, its SIMD partner is in an MFMA batch meanwhile.
+  const bool late_loader = (wid >= 4);
+
+  // ---- prologue of the stream
+  set_load_tile(0);
+  stage_next(0);
+  if (total > 1) {
+    stage_next(1);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  bf16x8 af0[4], wf0[4], af1[4], wf1[4];
+  read_set(a_addr[0], b_addr[0], af0, wf0);
+  M3P_LGKM0();
+  int cur = 0;      // stage of the current K-tile
+  int c_q = 0, c_kt = 0;
+  const bool io_aligned = ((ldc & 7) == 0) && (((uintptr_t)C & 15) == 0) &&
+                          (!(EPI == M3P_EPI_BIAS_GELU) || (((ep.ld_out2 & 7) == 0) && (((uintptr_t)ep.out2 & 15) == 0))) &&
+                          (!ep.bias || (((uintptr_t)ep.bias & 15) == 0));
+  for (int step = 0; step < total; ++step) {
+    const int nxt = (cur == 2) ? 0 : cur + 1;
+    const int nx2 = (nxt == 2) ? 0 : nxt + 1;
+    const bool more2 = (step + 2 < total);
+    if (more2 && !late_loader) stage_next(nx2);
+    read_set(a_addr[1] + cur * STAGE, b_addr[1] + cur * STAGE, af1, wf1);
+    __builtin_amdgcn_sched_barrier(0);   // reads first, then the MFMAs that hide them
+    mfma_batch(af0, wf0);
+    // k-step-1 fragments are in; every LDS read of this K-tile is complete; the next K-tile
+    // has landed for this wave -> publish
+    M3P_LGKM0();
+    if (more2 && !late_loader) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    read_set(a_addr[0] + nxt * STAGE, b_addr[0] + nxt * STAGE, af0, wf0);   // stale after the last K-tile: unused
+    __builtin_amdgcn_sched_barrier(0);
+    if (more2 && late_loader) stage_next(nx2);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_batch(af1, wf1);
+    M3P_LGKM0();
+
+    if (++c_kt == nk) {
+      // ---- epilogue of output tile c_q; stage `cur` is free (all waves passed the barrier above)
+      c_kt = 0;
+      const int t = tile_of(c_q);
+      ++c_q;
+      int tm, tn;
+      split_tile(t, tm, tn);
+      const int m0 = tm * BM, n0 = tn * BN;
+      const int mw = m0 + wm * 64, nw = n0 + wn * 64;
+      f32x4 csum[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) csum[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const bool fast = io_aligned && (m0 + BM <= M) && (n0 + BN <= N);
+      if (fast) {
+        char* r1 = smem + cur * STAGE + wid * 6144;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          f32x4 rows[2][4];
+#pragma unroll
+          for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rows[ii][j] = acc[2 * hf + ii][j];
+          epilogue_half<EPI>(ep, C, ldc, N, mw + 32 * hf, nw, r1, rows, lane, csum);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            epilogue_store<EPI>(ep, C, ldc, M, N, mw + i * 16 + fr, nw + j * 16 + fg * 4, acc[i][j], csum[j]);
+      }
+      if (EPI == M3P_EPI_DGELU && ep.colsum) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float sfl = csum[j][r];
+            sfl += __shfl_xor(sfl, 1, 64); sfl += __shfl_xor(sfl, 2, 64);
+            sfl += __shfl_xor(sfl, 4, 64); sfl += __shfl_xor(sfl, 8, 64);
+            const int n = nw + j * 16 + fg * 4 + r;
+            if (fr == 0 && n < N) unsafeAtomicAdd(ep.colsum + n, sfl);
+          }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (step + 1 < total) {
+        // the staging region is the slot the next iteration's loads go into: nobody may issue
+        // them before every wave has finished its LDS round trip
+        M3P_LGKM0();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
+    }
+    cur = nxt;
+  }
+#undef M3P_DSR
+#undef M3P_LGKM0
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512)
+void gemm_nt_ring_timeline_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ W, int ldw,
+                         bf16* __restrict__ C, int ldc, int M, int N, int K, M3PEpilogue ep,
+                         int tiles_m, int tiles_n, int m_fast, unsigned long long* __restrict__ dbg) {
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t0 = __builtin_amdgcn_s_memtime(), t1;
+#define TSEG(k) do { t1 = __builtin_amdgcn_s_memtime(); tacc[k] += t1 - t0; t0 = t1; } while (0)
+  constexpr int BM = 256, BN = 128, NWAVES = 8;
+  constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntiles = tiles_m * tiles_n;
+  // tile id -> (tm, tn): n-fastest shares the A row-panel between neighbours (weights small
+  // enough for L2/MALL); m-fastest shares the W panel instead (vocabulary projection: W = 384 MB)
+  // strips pay off once a full row of n-tiles no longer fits beside the A panels (measured:
+  // 24 n-tiles 805 -> 914 TF with 8-wide strips; 18 n-tiles lose ~5 %, so those stay n-fastest)
+  const int n_strips = (tiles_n >= 24) ? (tiles_n + 7) / 8 : 1;
+  const int strip_w = (tiles_n + n_strips - 1) / n_strips;
+  // (default order: strips of ~8 n-tiles walked m-major, so the 32 consecutive tiles an XCD
+  //  holds in one round form a ~4 x 8 block: 4 A row-panels + 8 W panels are live per XCD
+  //  instead of 1.3 + 24 -> fewer unique bytes per step in the 4-MB L2)
+  auto split_tile = [&](int t, int& tm, int& tn) {
+    if (m_fast) { tn = t / tiles_m; tm = t - tn * tiles_m; return; }
+    const int strip = t / (tiles_m * strip_w);
+    const int rem = t - strip * tiles_m * strip_w;
+    const int bn = min(strip_w, tiles_n - strip * strip_w);
+    tm = rem / bn;
+    tn = strip * strip_w + (rem - tm * bn);
   };
   const int nwg = gridDim.x;
   // persistent schedule: sequence index q -> tile id
@@ -429,22 +659,30 @@ void gemm_nt_ring_kernel(const bf16* __restrict__ A, int lda, const bf16* __rest
     const int nxt = (cur == 2) ? 0 : cur + 1;
     const int nx2 = (nxt == 2) ? 0 : nxt + 1;
     const bool more2 = (step + 2 < total);
+    TSEG(7);
     if (more2) stage_next(nx2);
     read_set(a_addr[1] + cur * STAGE, b_addr[1] + cur * STAGE, af1, wf1);
     __builtin_amdgcn_sched_barrier(0);   // reads first, then the MFMAs that hide them
+    TSEG(0);
     mfma_batch(af0, wf0);
+    __builtin_amdgcn_sched_barrier(0);
+    TSEG(1);
     // k-step-1 fragments are in; every LDS read of this K-tile is complete; the next K-tile
     // has landed for this wave -> publish
     M3P_LGKM0();
+    TSEG(2);
     if (more2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TSEG(3);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
+    TSEG(4);
     read_set(a_addr[0] + nxt * STAGE, b_addr[0] + nxt * STAGE, af0, wf0);   // stale after the last K-tile: unused
     __builtin_amdgcn_sched_barrier(0);
     mfma_batch(af1, wf1);
     M3P_LGKM0();
+    TSEG(5);
 
     if (++c_kt == nk) {
       // ---- epilogue of output tile c_q; stage `cur` is free (all waves passed the barrier above)
@@ -461,8 +699,15 @@ void gemm_nt_ring_kernel(const bf16* __restrict__ A, int lda, const bf16* __rest
       const bool fast = io_aligned && (m0 + BM <= M) && (n0 + BN <= N);
       if (fast) {
         char* r1 = smem + cur * STAGE + wid * 6144;
-        epilogue_half<EPI>(ep, C, ldc, N, mw, nw, 0, r1, acc, lane, csum);
-        epilogue_half<EPI>(ep, C, ldc, N, mw, nw, 1, r1, acc, lane, csum);
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          f32x4 rows[2][4];
+#pragma unroll
+          for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rows[ii][j] = acc[2 * hf + ii][j];
+          epilogue_half<EPI>(ep, C, ldc, N, mw + 32 * hf, nw, r1, rows, lane, csum);
+        }
       } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -494,8 +739,13 @@ void gemm_nt_ring_kernel(const bf16* __restrict__ A, int lda, const bf16* __rest
         asm volatile("" ::: "memory");
       }
     }
+    TSEG(6);
     cur = nxt;
   }
+  if (dbg && lane == 0) {
+    for (int k = 0; k < 8; ++k) dbg[((size_t)blockIdx.x * 8 + wid) * 8 + k] = tacc[k];
+  }
+#undef TSEG
 #undef M3P_DSR
 #undef M3P_LGKM0
 }
@@ -1063,7 +1313,7 @@ extern "C" {
 int m3p_gemm_nt_bf16(const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K,
                      int epilogue, const M3PEpilogue* ep_in, void* stream) {
   if (M <= 0 || N <= 0 || K <= 0 || (K % BK) != 0 || (lda % 8) != 0 || (ldw % 8) != 0 || (ldc % 4) != 0)
-    return M3P_EINVAL;
+    return M3P_EINVAL;   // (K % 64 == 0 also covers the 32-deep stages of the 256x256 kernel)
   if (((uintptr_t)A & 15) || ((uintptr_t)W & 15) || ((uintptr_t)C & 7)) return M3P_EINVAL;
   M3PEpilogue ep = {};
   if (ep_in) ep = *ep_in;
@@ -1082,6 +1332,18 @@ int m3p_gemm_nt_bf16(const void* A, int lda, const void* W, int ldw, void* C, in
     case M3P_EPI_DGELU: return launch_nt<M3P_EPI_DGELU>(a, lda, w, ldw, c, ldc, M, N, K, ep, st);
     default: return M3P_EINVAL;
   }
+}
+
+__attribute__((visibility("default"))) int m3p_debug_gemm_timeline(const void* A, int lda, const void* W, int ldw, void* C, int ldc,
+                                                                   int M, int N, int K, unsigned long long* dbg, void* stream) {
+  M3PEpilogue ep = {};
+  const int tiles_m = (M + 255) / 256, tiles_n = (N + 127) / 128;
+  const size_t lds = 3 * (256 + 128) * ROWB;
+  auto kern = gemm_nt_ring_timeline_kernel<M3P_EPI_NONE>;
+  hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(kern, dim3(num_cus()), dim3(512), lds, (hipStream_t)stream, (const bf16*)A, lda, (const bf16*)W, ldw,
+                     (bf16*)C, ldc, M, N, K, ep, tiles_m, tiles_n, 0, dbg);
+  return (int)hipGetLastError();
 }
 
 int m3p_gemm_nt_streamk_f32(const void* A, int lda, const void* W, int ldw, float* C, int ldc, int M, int N, int K,
