@@ -209,6 +209,14 @@ M3P_API int m3p_adam_step(float* p, float* g, float* m, float* v, void* w16, lon
                           float beta2, float eps, float weight_decay, float step_size, const double* gnorm_sq,
                           float max_norm, float grad_scale, int zero_grad, void* stream);
 
+/* h = gelu_erf(u) elementwise (transformer.py:56 applied to the lin1 output :223-224), bf16,
+ * n % 8 == 0.  Used instead of M3P_EPI_BIAS_GELU when the GEMM is persistent. */
+M3P_API int m3p_gelu_fwd(const void* u, void* h, long long n, void* stream);
+
+/* Batched form of m3p_transpose_bf16: desc = n_desc x {src ptr, dst ptr, rows, cols, ld_src,
+ * ld_dst} as int64 in device memory; max_tiles >= max over matrices of ceil(rows/64)*ceil(cols/64). */
+M3P_API int m3p_transpose_batch_bf16(const long long* desc, int n_desc, int max_tiles, void* stream);
+
 /* dst[c, r] = src[r, c] (bf16): transposed weight copies for the data-gradient GEMMs */
 M3P_API int m3p_transpose_bf16(const void* src, void* dst, int rows, int cols, int ld_src, int ld_dst,
                                void* stream);

@@ -77,9 +77,61 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16* __restr
   }
 }
 
+// batched variant: desc[i] = {src, dst, rows, cols, ld_src, ld_dst} (int64 each), one grid.y slice per matrix
+__global__ __launch_bounds__(256) void transpose_batch_kernel(const long long* __restrict__ desc) {
+  __shared__ bf16 tile[64][66];
+  const long long* dsc = desc + 6 * blockIdx.y;
+  const bf16* src = reinterpret_cast<const bf16*>(dsc[0]);
+  bf16* dst = reinterpret_cast<bf16*>(dsc[1]);
+  const int rows = (int)dsc[2], cols = (int)dsc[3], ld_src = (int)dsc[4], ld_dst = (int)dsc[5];
+  const int tiles_c = (cols + 63) / 64, tiles_r = (rows + 63) / 64;
+  if ((int)blockIdx.x >= tiles_c * tiles_r) return;
+  const int tr = (blockIdx.x / tiles_c) * 64, tc = (blockIdx.x % tiles_c) * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const int r = tr + i, c = tc + tx;
+    tile[i][tx] = (r < rows && c < cols) ? src[(size_t)r * ld_src + c] : (bf16)0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int c = tc + i, r = tr + tx;
+    if (c < cols && r < rows) dst[(size_t)c * ld_dst + r] = tile[tx][i];
+  }
+}
+
+// h = gelu_erf(u), bf16 in/out, 16-byte accesses (the FFN activation as its own streaming
+// pass: 129 M elements at HBM speed cost less than the same VALU work serialised behind the
+// MFMA stream of the persistent GEMM — see DESIGN.md)
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const bf16* __restrict__ u, bf16* __restrict__ h, size_t n8) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(u + 8 * i);
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (bf16)gelu_erf_f((float)v[j]);
+    *reinterpret_cast<bf16x8*>(h + 8 * i) = o;
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int m3p_gelu_fwd(const void* u, void* h, long long n, void* stream) {
+  if (n <= 0 || (n % 8) != 0 || ((uintptr_t)u & 15) || ((uintptr_t)h & 15)) return M3P_EINVAL;
+  const size_t n8 = (size_t)n / 8;
+  const int blocks = (int)((n8 + 255) / 256 < 8192 ? (n8 + 255) / 256 : 8192);
+  hipLaunchKernelGGL(gelu_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)u, (bf16*)h, n8);
+  M3P_CHECK_LAUNCH();
+  return M3P_OK;
+}
+
+int m3p_transpose_batch_bf16(const long long* desc, int n_desc, int max_tiles, void* stream) {
+  if (n_desc <= 0 || max_tiles <= 0) return M3P_EINVAL;
+  hipLaunchKernelGGL(transpose_batch_kernel, dim3(max_tiles, n_desc), dim3(256), 0, (hipStream_t)stream, desc);
+  M3P_CHECK_LAUNCH();
+  return M3P_OK;
+}
+
 
 int m3p_sumsq_f32(const float* g, long long n, double* out, void* stream) {
   if (n <= 0 || (n % 4) != 0 || ((uintptr_t)g & 15)) return M3P_EINVAL;

@@ -72,6 +72,7 @@ class Arena:
         self.embed_range = (0, self.layer_ranges[0][0] if L_ else self.head_range[0])
         self._cast_version = -1
         self._transposes_stale = True
+        self._tdesc = None
         self.grads_known_zero = True
         self.touched = set()   # names of parameters that received gradient since the last zero_grad
         self._layer_names = [[n for n in self.names if n.startswith(('attentions.%d.' % i, 'layer_norm1.%d.' % i,
@@ -132,11 +133,20 @@ class Arena:
             self._cast_version = self.master._version
             self._transposes_stale = True
         if self._transposes_stale:
-            for i in range(self.model.n_layers):
-                ops.transpose_bf16(self.qkv_w16(i), self.wt[('qkv', i)])
-                ops.transpose_bf16(self.w('attentions.%d.out_lin.weight' % i), self.wt[('out', i)])
-                ops.transpose_bf16(self.w('ffns.%d.lin1.weight' % i), self.wt[('lin1', i)])
-                ops.transpose_bf16(self.w('ffns.%d.lin2.weight' % i), self.wt[('lin2', i)])
+            if self._tdesc is None:
+                rows = []
+                mt = 1
+                for i in range(self.model.n_layers):
+                    for src, dst in ((self.qkv_w16(i), self.wt[('qkv', i)]),
+                                     (self.w('attentions.%d.out_lin.weight' % i), self.wt[('out', i)]),
+                                     (self.w('ffns.%d.lin1.weight' % i), self.wt[('lin1', i)]),
+                                     (self.w('ffns.%d.lin2.weight' % i), self.wt[('lin2', i)])):
+                        r, c = src.shape
+                        rows.append([src.data_ptr(), dst.data_ptr(), r, c, src.stride(0), dst.stride(0)])
+                        mt = max(mt, ((r + 63) // 64) * ((c + 63) // 64))
+                self._tdesc = (torch.tensor(rows, dtype=torch.int64, device=self.device), len(rows), mt) if rows else ()
+            if self._tdesc:
+                ops.transpose_batch(*self._tdesc)
             ops.transpose_bf16(self.w('embeddings.weight'), self.wt['emb'])
             self._transposes_stale = False
 
@@ -204,8 +214,13 @@ class EncoderFn(torch.autograd.Function):
             pre1 = ops.gemm_nt(ctxt, ar.w(a + 'out_lin.weight'), L.EPI_BIAS_DROP_RES, bias=ar.p(a + 'out_lin.bias'),
                                aux=h, seed=seed('attn_out', i), p_drop=p_drop)
             x1, mean1, rstd1 = ops.layernorm_fwd(pre1, ar.p('layer_norm1.%d.weight' % i), ar.p('layer_norm1.%d.bias' % i))
-            u = torch.empty((M, 4 * d), dtype=BF16, device=dev)
-            hact = ops.gemm_nt(x1, ar.w(f + 'lin1.weight'), L.EPI_BIAS_GELU, bias=ar.p(f + 'lin1.bias'), out2=u)
+            if M >= 1024:
+                # persistent GEMM: bias in the epilogue, GELU as its own HBM-speed pass
+                u = ops.gemm_nt(x1, ar.w(f + 'lin1.weight'), L.EPI_BIAS, bias=ar.p(f + 'lin1.bias'))
+                hact = ops.gelu_fwd(u)
+            else:
+                u = torch.empty((M, 4 * d), dtype=BF16, device=dev)
+                hact = ops.gemm_nt(x1, ar.w(f + 'lin1.weight'), L.EPI_BIAS_GELU, bias=ar.p(f + 'lin1.bias'), out2=u)
             pre2 = ops.gemm_nt(hact, ar.w(f + 'lin2.weight'), L.EPI_BIAS_DROP_RES, bias=ar.p(f + 'lin2.bias'),
                                aux=x1, seed=seed('ffn', i), p_drop=p_drop)
             h_next, mean2, rstd2 = ops.layernorm_fwd(pre2, ar.p('layer_norm2.%d.weight' % i),

@@ -254,3 +254,13 @@ def transpose_bf16(src, dst):
     rows, cols = src.shape
     rc = L.load().m3p_transpose_bf16(src.data_ptr(), dst.data_ptr(), rows, cols, src.stride(0), dst.stride(0), L.stream())
     L.check(rc, 'm3p_transpose_bf16')
+
+
+def gelu_fwd(u):
+    h = torch.empty_like(u)
+    L.check(L.load().m3p_gelu_fwd(u.data_ptr(), h.data_ptr(), u.numel(), L.stream()), 'm3p_gelu_fwd')
+    return h
+
+
+def transpose_batch(desc, n_desc, max_tiles):
+    L.check(L.load().m3p_transpose_batch_bf16(desc.data_ptr(), n_desc, max_tiles, L.stream()), 'm3p_transpose_batch_bf16')

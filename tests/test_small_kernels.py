@@ -151,3 +151,18 @@ def test_embed_assemble_fwd_bwd(B, T, R, d, p_drop):
         assert rel_l2(grads['d_b_img'], leaves['b_loc'].grad) < tol
         assert rel_l2(grads['d_w_loc'], leaves['w_loc'].grad) < tol
         assert rel_l2(de.float(), ip.grad) < tol
+
+
+def test_gelu_fwd_and_batched_transpose():
+    from m3p_amd import ops
+    from oracle import ref_cpu as O
+    u, uc = randn_bf16((1000, 64), 1, 2.0)
+    h = ops.gelu_fwd(u)
+    assert rel_l2(h.float(), O.gelu_erf(uc)) < 4e-3
+    a, ac = randn_bf16((130, 200), 2)
+    b, bc = randn_bf16((64, 64), 3)
+    da = torch.zeros((200, 130), dtype=BF16, device='cuda'); db = torch.zeros((64, 64), dtype=BF16, device='cuda')
+    desc = torch.tensor([[a.data_ptr(), da.data_ptr(), 130, 200, 200, 130], [b.data_ptr(), db.data_ptr(), 64, 64, 64, 64]],
+                        dtype=torch.int64, device='cuda')
+    ops.transpose_batch(desc, 2, 12)
+    assert torch.equal(da.cpu(), ac.to(BF16).t()) and torch.equal(db.cpu(), bc.to(BF16).t())
