@@ -17,6 +17,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with two extra o
 import argparse
 import json
 import os
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC for RCCL across processes
 import sys
 import time
 
@@ -153,9 +154,14 @@ def main():
             avg_ms = tot / cnt
             flops = 2.0 * M * N * K
             ach = flops / (avg_ms * 1e-3) / 1e12
+            kname = '%s M=%d N=%d K=%d' % (kind, M, N, K)
+            traffic = None
+            tpath = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
+            if os.path.exists(tpath):   # HBM bytes/launch from the committed rocprofv3 --pmc passes of this command
+                traffic = json.load(open(tpath)).get('bench_keys', {}).get(kname)
             roof = dict(bound='mfma', achieved=round(ach, 1), peak=PEAK_BF16_TFLOPS, unit='TFLOP/s',
-                        frac=round(ach / PEAK_BF16_TFLOPS, 4), traffic=None,
-                        kernel='%s M=%d N=%d K=%d' % (kind, M, N, K), launches=cnt, avg_ms=round(avg_ms, 4),
+                        frac=round(ach / PEAK_BF16_TFLOPS, 4), traffic=traffic,
+                        kernel=kname, launches=cnt, avg_ms=round(avg_ms, 4),
                         gemm_time_share=round(sum(v[0] for v in agg.values()) / (dt * 1e3), 3),
                         step_frac=round(value / world * fl / 1e12 / PEAK_BF16_TFLOPS, 4))
         out = dict(metric='pre-train samples/sec (whole node), 12L/768d seq=128+36', value=round(value, 2),
