@@ -423,12 +423,10 @@ void gemm_nt_ring_kernel(const bf16* __restrict__ A, int lda, const bf16* __rest
       for (int j = 0; j < 4; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
   };
-  // The two waves that share a SIMD (w and w+4) issue their LDS-DMA bursts at DIFFERENT
-  // points of the step: waves 0-3 at the top (tile step+2, two tiles ahead, vmcnt(6)), waves
-  // 4-7 right after the mid-step barrier (same tile, one step of flight time, vmcnt(0) at the
-  // next mid-step wait).  A burst costs the issuing wave ~400 cycles during which it cannot
-  // issue MFMAs; staggered, its SIMD partner is in an MFMA batch meanwhile.
-  const bool late_loader = (wid >= 4);
+  // (Tried and measured neutral-to-negative on MI355X, kept out: issuing the six LDS-DMAs one
+  //  at a time between MFMAs; giving the two waves of a SIMD different burst positions —
+  //  before/after MFMA batch 1, or after the mid-step barrier; a 256x256 tile with 32-deep
+  //  stages.  See DESIGN.md §4 "what did not work".)
 
   // ---- prologue of the stream
   set_load_tile(0);
@@ -454,21 +452,19 @@ void gemm_nt_ring_kernel(const bf16* __restrict__ A, int lda, const bf16* __rest
     const int nxt = (cur == 2) ? 0 : cur + 1;
     const int nx2 = (nxt == 2) ? 0 : nxt + 1;
     const bool more2 = (step + 2 < total);
-    if (more2 && !late_loader) stage_next(nx2);
+    if (more2) stage_next(nx2);
     read_set(a_addr[1] + cur * STAGE, b_addr[1] + cur * STAGE, af1, wf1);
     __builtin_amdgcn_sched_barrier(0);   // reads first, then the MFMAs that hide them
     mfma_batch(af0, wf0);
     // k-step-1 fragments are in; every LDS read of this K-tile is complete; the next K-tile
-    // has landed for this wave -> publish
+    // has landed for this wave (the 6 LDS-DMAs just issued stay in flight) -> publish
     M3P_LGKM0();
-    if (more2 && !late_loader) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    if (more2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     read_set(a_addr[0] + nxt * STAGE, b_addr[0] + nxt * STAGE, af0, wf0);   // stale after the last K-tile: unused
-    __builtin_amdgcn_sched_barrier(0);
-    if (more2 && late_loader) stage_next(nx2);
     __builtin_amdgcn_sched_barrier(0);
     mfma_batch(af1, wf1);
     M3P_LGKM0();
