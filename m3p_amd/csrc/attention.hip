@@ -222,6 +222,8 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
   char* s1 = smem + tile_bytes;       // phase A: dO  | phase B: V
   float* sL = reinterpret_cast<float*>(smem + 2 * tile_bytes);
   float* sD = sL + nk * 32;
+  float* sB = sD + nk * 32;           // [3][DH] bias-gradient accumulators (q | k | v), LDS atomics
+  for (int i = tid; i < 3 * DH; i += 256) sB[i] = 0.f;
 
   const int fq = lane & 15, fg = lane >> 4;
   int r_off[Cf::KK];   // row-major fragment (row 16t + fq, chunk 4kk + fg)
@@ -254,24 +256,24 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
   // ================= phase A: dV, dK (wave owns key blocks) =================
   stage_rows<DH>(Qg, ld, S, nk * 32, s0, wid, lane);
   stage_rows<DH>(dOg, (size_t)dmodel, S, nk * 32, s1, wid, lane);
-  __syncthreads();
-
-  float bsum_k[Cf::NT][4], bsum_v[Cf::NT][4];   // bias-gradient partial sums (columns 16n+4fg+r)
-#pragma unroll
-  for (int n = 0; n < Cf::NT; ++n)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) bsum_k[n][r] = bsum_v[n][r] = 0.f;
-
-  for (int kb = wid; kb < nt; kb += 4) {
-    const int key = kb * 16 + fq;            // this lane's key column
-    const int keyc = min(key, S - 1);
-    const bool kvalid = key < klen;
-    bf16x8 kf[Cf::KK], vf[Cf::KK];
+  // this wave's first K / V fragments do not depend on LDS: fetch them under the staging latency
+  bf16x8 kf[Cf::KK], vf[Cf::KK];
+  auto load_kv = [&](int kb) {
+    const int keyc = min(kb * 16 + fq, S - 1);
 #pragma unroll
     for (int kk = 0; kk < Cf::KK; ++kk) {
       kf[kk] = *reinterpret_cast<const bf16x8*>(Kg + (size_t)keyc * ld + 32 * kk + 8 * fg);
       vf[kk] = *reinterpret_cast<const bf16x8*>(Vg + (size_t)keyc * ld + 32 * kk + 8 * fg);
     }
+  };
+  if (wid < nt) load_kv(wid);
+  __syncthreads();
+
+  for (int kb = wid; kb < nt; kb += 4) {
+    const int key = kb * 16 + fq;            // this lane's key column
+    const int keyc = min(key, S - 1);
+    const bool kvalid = key < klen;
+    if (kb != wid) load_kv(kb);
     // dV^T[d][key] = sum_q dO[q][d] Pd[q][key] ; dK^T[d][key] = sum_q Q[q][d] dS[q][key]
     // streamed over 32-query steps: P / dS of a step are produced (lane = key column, query
     // 16t + 4fg + r) and consumed as MFMA B operands at once — nothing S x S is held
@@ -329,8 +331,13 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
         const bf16x4 vb4 = bf16x4{(bf16)dv[n][0], (bf16)dv[n][1], (bf16)dv[n][2], (bf16)dv[n][3]};
         *reinterpret_cast<bf16x4*>(pk + 16 * n) = kb4;
         *reinterpret_cast<bf16x4*>(pv + 16 * n) = vb4;
+        if (dbias_qkv) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { bsum_k[n][r] += (float)kb4[r]; bsum_v[n][r] += (float)vb4[r]; }
+          for (int r = 0; r < 4; ++r) {
+            atomicAdd(sB + DH + 16 * n + 4 * fg + r, (float)kb4[r]);
+            atomicAdd(sB + 2 * DH + 16 * n + 4 * fg + r, (float)vb4[r]);
+          }
+        }
       }
     }
   }
@@ -339,23 +346,22 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
   // ================= phase B: dQ (wave owns query blocks) =================
   stage_rows<DH>(Kg, ld, S, nk * 32, s0, wid, lane);
   stage_rows<DH>(Vg, ld, S, nk * 32, s1, wid, lane);
-  __syncthreads();
-
-  float bsum_q[Cf::NT][4];
-#pragma unroll
-  for (int n = 0; n < Cf::NT; ++n)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) bsum_q[n][r] = 0.f;
-
-  for (int qb = wid; qb < nt; qb += 4) {
-    const int q = qb * 16 + fq;
-    const int qc = min(q, S - 1);
-    bf16x8 qf[Cf::KK], df[Cf::KK];
+  bf16x8 qf[Cf::KK], df[Cf::KK];
+  auto load_qd = [&](int qb) {
+    const int qc = min(qb * 16 + fq, S - 1);
 #pragma unroll
     for (int kk = 0; kk < Cf::KK; ++kk) {
       qf[kk] = *reinterpret_cast<const bf16x8*>(Qg + (size_t)qc * ld + 32 * kk + 8 * fg);
       df[kk] = *reinterpret_cast<const bf16x8*>(dOg + (size_t)qc * dmodel + 32 * kk + 8 * fg);
     }
+  };
+  if (wid < nt) load_qd(wid);
+  __syncthreads();
+
+  for (int qb = wid; qb < nt; qb += 4) {
+    const int q = qb * 16 + fq;
+    const int qc = min(q, S - 1);
+    if (qb != wid) load_qd(qb);
     const float lq = sL[q], dq_ = sD[q];
     const uint32_t rbase = (uint32_t)((b * H + h) * S + qc) * (uint32_t)S;
     // dQ^T[d][q] = sum_key K[key][d] dS[q][key], streamed over 32-key steps
@@ -400,30 +406,21 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
         const bf16x4 qb4 = bf16x4{(bf16)(dq[n][0] * qscale), (bf16)(dq[n][1] * qscale), (bf16)(dq[n][2] * qscale),
                                   (bf16)(dq[n][3] * qscale)};
         *reinterpret_cast<bf16x4*>(pq + 16 * n) = qb4;
+        if (dbias_qkv) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) bsum_q[n][r] += (float)qb4[r];
+          for (int r = 0; r < 4; ++r) atomicAdd(sB + 16 * n + 4 * fg + r, (float)qb4[r]);
+        }
       }
     }
   }
 
   // ---- bias gradients: column sums of the bf16 dQ/dK/dV this block wrote
   if (dbias_qkv) {
-#pragma unroll
-    for (int n = 0; n < Cf::NT; ++n)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float a = bsum_q[n][r], c = bsum_k[n][r], e = bsum_v[n][r];
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-          a += __shfl_xor(a, o, 64); c += __shfl_xor(c, o, 64); e += __shfl_xor(e, o, 64);
-        }
-        if (fq == 0) {
-          const int col = h * DH + 16 * n + 4 * fg + r;
-          atomicAdd(dbias_qkv + col, a);
-          atomicAdd(dbias_qkv + dmodel + col, c);
-          atomicAdd(dbias_qkv + 2 * dmodel + col, e);
-        }
-      }
+    __syncthreads();
+    for (int i = tid; i < 3 * DH; i += 256) {
+      const int part = i / DH, c = i - part * DH;
+      atomicAdd(dbias_qkv + part * dmodel + h * DH + c, sB[i]);
+    }
   }
 }
 
@@ -454,7 +451,7 @@ int launch_bwd(const bf16* qkv, const int* keylen, const bf16* ctx, const bf16* 
                float* dbias, int B, int S, int H, int dmodel, float qscale, uint32_t seed, uint32_t thresh24,
                float inv_keep, hipStream_t st) {
   const int nk = (S + 31) / 32;
-  const size_t lds = (size_t)2 * nk * 32 * DH * 2 + (size_t)2 * nk * 32 * sizeof(float);
+  const size_t lds = (size_t)2 * nk * 32 * DH * 2 + (size_t)2 * nk * 32 * sizeof(float) + 3 * DH * sizeof(float);
 #define M3P_ATTN_BWD(KT)                                                                                        \
   do {                                                                                                          \
     auto kern = attn_bwd_kernel<DH, KT>;                                                                        \
