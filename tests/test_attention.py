@@ -66,7 +66,7 @@ def test_attention_perf_smoke():
     keylen = torch.full((B,), S, dtype=torch.int32, device='cuda')
     for p in (0.0, 0.1):
         ctx, lse = ops.attn_fwd(qkv, keylen, B, S, H, dh, seed=1, p_drop=p)
-        dctx = torch.randn_like(ctx)
+        dctx = torch.randn_like(ctx); dbias = torch.zeros(3 * d, device="cuda")
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -78,7 +78,7 @@ def test_attention_perf_smoke():
         print('attn_fwd p=%.1f: %.3f ms  %.1f TF' % (p, ms, fl / ms / 1e9))
         e0.record()
         for _ in range(10):
-            ops.attn_bwd(qkv, keylen, ctx, dctx, lse, B, S, H, dh, seed=1, p_drop=p)
+            ops.attn_bwd(qkv, keylen, ctx, dctx, lse, B, S, H, dh, dbias_qkv=dbias, seed=1, p_drop=p)
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 10
         print('attn_bwd p=%.1f: %.3f ms  %.1f TF (algorithmic 2x fwd)' % (p, ms, 2 * fl / ms / 1e9))
