@@ -226,7 +226,31 @@ def gen_unit_goldens():
     print('units.npz ok')
 
 
+def gen_text_and_itm_goldens():
+    """crossfwd text stream (mlm_step) and the sample_n = 4 relation loss (t2i/i2t fine-tune)."""
+    cfg = synth.CONFIGS['cfg1']
+    m, P, hot = build_reference_model(cfg)
+    m.eval()
+    batch = synth.make_batch(cfg['T'], cfg['R'], cfg['B'], cfg['n_words'], cfg['n_pred'])
+    g = {}
+    with torch.no_grad():
+        out = m('crossfwd', stream_='text', x=batch['x'], lengths=batch['lengths'], positions=None, langs=None, causal=False)
+        scores, mlm = m('predict', tensor=out, pred_mask=batch['pred_mask'], y=batch['y'], get_scores=True)
+        g['text_out'] = out.numpy()
+        g['text_mlm_loss'] = mlm.numpy()
+        joint = m('jointfwd', x=batch['x'], lengths=batch['lengths'], x_img=batch['x_img'], lengths_img=batch['lengths_img'],
+                  causal=False, langs=None, image_loc=batch['image_loc'], refine_image=False)
+        rel = m('predict', tensor=joint.transpose(0, 1), is_relation=True)
+        pos = torch.tensor([2, 0])      # B = 8 -> two groups of sample_n = 4
+        g['rel4_pos'] = pos.numpy()
+        g['rel4_ce'] = torch.nn.functional.cross_entropy(rel.view(-1, 4), pos).numpy()
+        g['rel4_bce'] = torch.nn.functional.binary_cross_entropy_with_logits(rel.view(-1), torch.eye(4)[pos].reshape(-1)).numpy()
+    np.savez_compressed(os.path.join(OUT, 'cfg1_text_itm.npz'), **g)
+    print('cfg1_text_itm.npz: text mlm %.6f rel4 ce %.6f bce %.6f' % (float(g['text_mlm_loss']), float(g['rel4_ce']), float(g['rel4_bce'])))
+
+
 if __name__ == '__main__':
+    gen_text_and_itm_goldens()
     gen_unit_goldens()
     gen_model_goldens()
     gen_trainer_goldens()

@@ -149,6 +149,35 @@ def jointfwd(sd, n_layers, n_heads, x, lengths, x_img, lengths_img, image_loc,
     return h.transpose(0, 1)
 
 
+def crossfwd_text(sd, n_layers, n_heads, x, lengths, dropout=0.0, attention_dropout=0.0, keeps=None):
+    """TransformerModel.crossfwd(stream_='text', causal=False, positions=None, langs=None):
+    transformer.py:1050-1102 — the text-only stream behind Trainer.mlm_step (xtrainer.py:757).
+    Differs from jointfwd in the order at the input: Emb[x] + Pos -> LN_emb -> dropout -> *mask
+    (:1055-1062), then the same post-LN layers.  x (T, B) -> (T, B, d)."""
+    keeps = keeps or {}
+    T, B = x.shape
+    mask, attn_mask = get_masks(T, lengths)
+    h = F.embedding(x.t(), sd['embeddings.weight']) + sd['position_embeddings.weight'][:T][None]
+    h = layer_norm(h, sd['layer_norm_emb.weight'], sd['layer_norm_emb.bias'])
+    h = _drop(h, keeps.get('emb'), dropout)
+    h = h * mask[..., None].to(h.dtype)
+    for i in range(n_layers):
+        a = 'attentions.%d.' % i
+        attn = multi_head_attention(
+            h, attn_mask,
+            sd[a + 'q_lin.weight'], sd[a + 'q_lin.bias'], sd[a + 'k_lin.weight'], sd[a + 'k_lin.bias'],
+            sd[a + 'v_lin.weight'], sd[a + 'v_lin.bias'], sd[a + 'out_lin.weight'], sd[a + 'out_lin.bias'],
+            n_heads, p_attn=attention_dropout, keep_attn=keeps.get(('attn_p', i)))
+        attn = _drop(attn, keeps.get(('attn_out', i)), dropout)
+        h = layer_norm(h + attn, sd['layer_norm1.%d.weight' % i], sd['layer_norm1.%d.bias' % i])
+        f = 'ffns.%d.' % i
+        h = h + transformer_ffn(h, sd[f + 'lin1.weight'], sd[f + 'lin1.bias'], sd[f + 'lin2.weight'],
+                                sd[f + 'lin2.bias'], p=dropout, keep=keeps.get(('ffn', i)))
+        h = layer_norm(h, sd['layer_norm2.%d.weight' % i], sd['layer_norm2.%d.bias' % i])
+        h = h * mask[..., None].to(h.dtype)
+    return h.transpose(0, 1)
+
+
 # ----------------------------------------------------------------------------
 # heads: TransformerModel.predict
 # ----------------------------------------------------------------------------

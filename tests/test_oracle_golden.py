@@ -162,3 +162,19 @@ def test_recall_at_k():
     s = torch.tensor([[0.1, 0.9, 0.3], [0.8, 0.1, 0.2], [0.2, 0.3, 0.1]])
     r = O.recall_at_k(s, torch.tensor([1, 2, 0]), ks=(1, 2))
     assert abs(r[1] - 1 / 3) < 1e-6 and abs(r[2] - 1.0) < 1e-6
+
+
+def test_crossfwd_text_and_rel4(golden_dir):
+    """Text-only stream (mlm_step) and the sample_n = 4 relation losses against the reference."""
+    g = _load(golden_dir, 'cfg1_text_itm.npz')
+    cfg, P, sd, batch = _cfg1_setup()
+    out = O.crossfwd_text(sd, cfg['n_layers'], cfg['n_heads'], batch['x'], batch['lengths'])
+    assert rel_l2(out, g['text_out']) < 1e-5
+    _, mlm = O.predict_mlm(sd, out, batch['pred_mask'], batch['y'])
+    assert abs(float(mlm) - float(g['text_mlm_loss'])) < 1e-5
+    joint = O.jointfwd(sd, cfg['n_layers'], cfg['n_heads'], batch['x'], batch['lengths'], batch['x_img'],
+                       batch['lengths_img'], batch['image_loc'])
+    rel = O.predict_relation(sd, joint.transpose(0, 1))
+    pos = _t(g['rel4_pos'])
+    assert abs(float(O.itm_loss(rel, pos, 4, 1.0, 0.0)) - float(g['rel4_ce'])) < 1e-5
+    assert abs(float(O.itm_loss(rel, pos, 4, 0.0, 1.0)) - float(g['rel4_bce'])) < 1e-5
