@@ -152,6 +152,103 @@ void ln_bwd_kernel(const bf16* __restrict__ dy_a, const bf16* __restrict__ dy_b,
   }
 }
 
+// Backward, wide variant for d = 256 * NC (768, 1024): HALF a wave per row with 16-byte
+// accesses (8 bf16 per lane per chunk), so a wave keeps two rows and twice the bytes in flight;
+// row reductions are xor-shuffles over 32 lanes.  Same arithmetic as ln_bwd_kernel.
+template <int NC>
+__global__ __launch_bounds__(256)
+void ln_bwd_hw_kernel(const bf16* __restrict__ dy_a, const bf16* __restrict__ dy_b, const bf16* __restrict__ x,
+                      const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd,
+                      const uint8_t* __restrict__ rowmask, bf16* __restrict__ dx, bf16* __restrict__ dx_drop,
+                      float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dbias_drop,
+                      int rows, uint32_t seed, uint32_t thresh24, float inv_keep) {
+  constexpr int D = 256 * NC;
+  __shared__ float red[8][D];
+  const int sub = threadIdx.x & 31, hw = threadIdx.x >> 5;   // 8 half-waves per block
+  const int ghw = blockIdx.x * 8 + hw, nhw = gridDim.x * 8;
+  const float inv_d = 1.0f / (float)D;
+  float g[NC][8], acc_g[NC][8], acc_b[NC][8], acc_d[NC][8];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = (sub + 32 * i) * 8;
+    const f32x4 g0 = Vec4<float>::load(gamma + c), g1 = Vec4<float>::load(gamma + c + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { g[i][e] = g0[e]; g[i][4 + e] = g1[e]; }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc_g[i][e] = acc_b[i][e] = acc_d[i][e] = 0.f;
+  }
+  auto hsum = [](float v) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+  };
+  for (int r = ghw; r < rows; r += nhw) {
+    const size_t ro = (size_t)r * D;
+    const float mu = mean[r], rs = rstd[r];
+    const float mk = rowmask ? (rowmask[r] ? 1.f : 0.f) : 1.f;
+    float dyv[NC][8], xh[NC][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int c = (sub + 32 * i) * 8;
+      bf16x8 a = *reinterpret_cast<const bf16x8*>(dy_a + ro + c);
+      const bf16x8 xv = *reinterpret_cast<const bf16x8*>(x + ro + c);
+      bf16x8 b2;
+      if (dy_b) b2 = *reinterpret_cast<const bf16x8*>(dy_b + ro + c);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float dv = (float)a[e];
+        if (dy_b) dv += (float)b2[e];
+        dv *= mk;
+        const float xe = ((float)xv[e] - mu) * rs;
+        dyv[i][e] = dv; xh[i][e] = xe;
+        const float gd = dv * g[i][e];
+        s1 += gd; s2 += gd * xe;
+        acc_g[i][e] += dv * xe;
+        acc_b[i][e] += dv;
+      }
+    }
+    const float c1 = hsum(s1) * inv_d, c2 = hsum(s2) * inv_d;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int c = (sub + 32 * i) * 8;
+      bf16x8 ob, odb;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ob[e] = (bf16)((dyv[i][e] * g[i][e] - c1 - xh[i][e] * c2) * rs);
+      *reinterpret_cast<bf16x8*>(dx + ro + c) = ob;
+      if (dx_drop || dbias_drop) {
+        const uint32_t base = (uint32_t)r * (uint32_t)D + (uint32_t)c;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const bool keep = thresh24 ? m3p_keep(base + e, seed, thresh24) : true;
+          odb[e] = (bf16)(keep ? (float)ob[e] * (thresh24 ? inv_keep : 1.f) : 0.f);
+          acc_d[i][e] += (float)odb[e];
+        }
+        if (dx_drop) *reinterpret_cast<bf16x8*>(dx_drop + ro + c) = odb;
+      }
+    }
+  }
+  float* const outs[3] = {dgamma, dbeta, dbias_drop};
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    if (outs[q] == nullptr) continue;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int c = (sub + 32 * i) * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red[hw][c + e] = (q == 0) ? acc_g[i][e] : (q == 1) ? acc_b[i][e] : acc_d[i][e];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += 256) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) t += red[w][c];
+      unsafeAtomicAdd(outs[q] + c, t);
+    }
+    __syncthreads();
+  }
+}
+
 inline int ln_ni(int d) { return (d + 255) / 256; }
 
 }  // namespace
@@ -186,8 +283,21 @@ int m3p_layernorm_bwd(const void* dy_a, const void* dy_b, const void* x, const f
   if (rows <= 0 || d <= 0 || (d % 4) != 0 || d > 2048) return M3P_EINVAL;
   if (!dy_a || !x || !dx || !dgamma || !dbeta) return M3P_EINVAL;
   if (((uintptr_t)x & 7) || ((uintptr_t)dy_a & 7) || ((uintptr_t)dx & 7) || ((uintptr_t)gamma & 15)) return M3P_EINVAL;
-  const int blocks = min((rows + 3) / 4, 1024);
   hipStream_t st = (hipStream_t)stream;
+  if ((d == 768 || d == 1024) && !(((uintptr_t)x | (uintptr_t)dy_a | (uintptr_t)dx | (uintptr_t)dy_b | (uintptr_t)dx_drop) & 15)) {
+    const int blocks_hw = min((rows + 7) / 8, 512);   // fewer blocks: the 3*d end-of-block atomics hit the same 2304 addresses
+    if (d == 768)
+      hipLaunchKernelGGL(ln_bwd_hw_kernel<3>, dim3(blocks_hw), dim3(256), 0, st, (const bf16*)dy_a, (const bf16*)dy_b,
+                         (const bf16*)x, gamma, mean, rstd, rowmask, (bf16*)dx, (bf16*)dx_drop, dgamma, dbeta, dbias_drop,
+                         rows, seed, thresh24, inv_keep);
+    else
+      hipLaunchKernelGGL(ln_bwd_hw_kernel<4>, dim3(blocks_hw), dim3(256), 0, st, (const bf16*)dy_a, (const bf16*)dy_b,
+                         (const bf16*)x, gamma, mean, rstd, rowmask, (bf16*)dx, (bf16*)dx_drop, dgamma, dbeta, dbias_drop,
+                         rows, seed, thresh24, inv_keep);
+    M3P_CHECK_LAUNCH();
+    return M3P_OK;
+  }
+  const int blocks = min((rows + 3) / 4, 512);
 #define M3P_LN_BWD(NI)                                                                                     \
   hipLaunchKernelGGL(ln_bwd_kernel<NI>, dim3(blocks), dim3(256), 0, st, (const bf16*)dy_a,                 \
                      (const bf16*)dy_b, (const bf16*)x, gamma, mean, rstd, rowmask, (bf16*)dx,              \

@@ -56,3 +56,25 @@ def test_layernorm_bwd_dropout_branch():
     assert torch.equal(dxd.cpu(), exp)
     assert abs(float(keep.float().mean()) - (1 - p)) < 5e-3
     assert rel_l2(dbias, exp.float().sum(0)) < 1e-5
+
+
+def test_layernorm_perf_smoke():
+    from m3p_amd import ops
+    rows, d = 41984, 768
+    x, _ = randn_bf16((rows, d), 1)
+    g, _ = randn_f32((d,), 2, 0.1); g += 1
+    b, _ = randn_f32((d,), 3, 0.1)
+    y, mean, rstd = ops.layernorm_fwd(x, g, b)
+    dy, _ = randn_bf16((rows, d), 5)
+    dg = torch.zeros(d, device='cuda'); db = torch.zeros(d, device='cuda'); dbias = torch.zeros(d, device='cuda')
+    for name, fn in (('ln_fwd', lambda: ops.layernorm_fwd(x, g, b)),
+                     ('ln_bwd+drop', lambda: ops.layernorm_bwd(dy, None, x, g, mean, rstd, None, dg, db, dbias_drop=dbias, want_drop=True, seed=3, p_drop=0.1))):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        print('%s [%d x %d]: %.1f us' % (name, rows, d, e0.elapsed_time(e1) * 100))
