@@ -183,7 +183,7 @@ M3P_API int m3p_gather_rows(const void* src, const int32_t* idx, void* dst, int 
 M3P_API int m3p_scatter_add_rows(const void* src, const int32_t* idx, void* dst, int n, int d, void* stream);
 
 /* F.cross_entropy over bf16 logits [n_rows, ld] (V valid columns), per-row loss to
- * row_loss, loss_sum += loss_scale * sum(row losses), and IN PLACE
+ * row_loss, loss_sum += loss_scale * sum(row losses) if loss_sum != NULL, and IN PLACE
  * logits <- (softmax - onehot(target)) * grad_scale, padding columns [V, ld) zeroed. */
 M3P_API int m3p_ce_fwd_bwd(void* logits, int ld, int n_rows, int V, const int64_t* target, float* row_loss,
                            float* loss_sum, float loss_scale, float grad_scale, void* stream);

@@ -72,7 +72,9 @@ __global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(bf16* __restrict__ logi
   if (tid == 0) {
     const float l = lse - (float)lr[tgt];
     row_loss[row] = l;
-    unsafeAtomicAdd(loss_sum, l * loss_scale);
+    // (one atomic per row on a single address serialises ~5k adds; callers that want the
+    //  mean reduce row_loss themselves and pass loss_sum = NULL)
+    if (loss_sum) unsafeAtomicAdd(loss_sum, l * loss_scale);
   }
   __syncthreads();   // row_loss read of lr[tgt] happens before the in-place overwrite below
   for (int c = tid; c < nchunk; c += 256) {
