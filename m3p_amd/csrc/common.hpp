@@ -52,7 +52,7 @@ __host__ __device__ __forceinline__ bool m3p_keep(uint32_t idx, uint32_t seed, u
 struct GeluParts { float cdf; float pdf; };   // Phi(x) and phi(x)
 __device__ __forceinline__ GeluParts gelu_parts(float x) {
   const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __frcp_rn(1.0f + 0.3275911f * z);
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);   // v_rcp_f32 (1 ulp); __frcp_rn expands to a 10-op IEEE divide
   const float e = __expf(-z * z);   // = exp(-x^2/2)
   float poly = 1.061405429f;
   poly = poly * t - 1.453152027f;

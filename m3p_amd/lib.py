@@ -10,7 +10,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libm3p_hip.so')
+# M3P_HIP_LIB: developer override used for A/B runs of two builds inside one GPU session
+LIB_PATH = os.environ.get('M3P_HIP_LIB') or os.path.join(_HERE, 'libm3p_hip.so')
 
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_DROP_RES, EPI_RES, EPI_DGELU = range(6)
 
