@@ -12,12 +12,14 @@
 // again on the ds_read_b128 (cdna guide rule 21), which makes the fragment reads
 // conflict-free.  Block ids are remapped so each XCD (private L2) walks a contiguous run
 // of tiles that share their A row-panel.
+#include <type_traits>
 #include "common.hpp"
 #include "../../include/m3p_hip.h"
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
-static int g_variant = 1;  // debug: 0 = force the 128x128 2-stage kernel, 1 = persistent 256x128 ring for M >= 1024
-extern "C" __attribute__((visibility("default"))) void m3p_debug_set_variant(int v) { g_variant = v; }
+static int g_variant = 1;  // debug: 0 = force the 128x128 2-stage kernel, 1 = auto (ring / w4 by shape), 2 = force w4, 3 = force ring
+static int g_ablate = 0;  // debug: timeline kernels only (bit0 = no fragment reads, bit1 = no LDS-DMA)
+extern "C" __attribute__((visibility("default"))) void m3p_debug_set_variant(int v) { g_variant = v & 0xff; g_ablate = v >> 8; }
 
 namespace {
 
@@ -902,6 +904,346 @@ void gemm_nt_streamk_kernel(const bf16* __restrict__ A, int lda, const bf16* __r
 #undef M3P_LGKM0
 }
 
+// ---------------------------------------------------------------------------------
+// NT kernel, "w4" version: 256x256 output tile, FOUR waves (one per SIMD), each wave owns a
+// 128x128 sub-tile = 8x8 MFMA tiles (256 accumulator registers of the 512 a lone wave has).
+// Why: with 64x64 per wave (ring kernel above) every 32-deep k-step makes a wave read
+// (64+64) rows x 64 B from LDS for 16 MFMAs; eight waves then pull 128 KB of LDS reads per
+// 64-deep K-tile = 1024 clocks at the LDS's 128 B/clk - exactly the 1030 clocks the MFMAs
+// of that K-tile need, before the 48 KB of LDS-DMA writes are even counted.  The ring
+// kernel is LDS-bandwidth bound (measured 2057 clk per K-tile).  128x128 per wave halves
+// LDS bytes per FLOP, 256x256 halves HBM/L2 -> LDS bytes per FLOP:
+//     per 32-deep K-tile: 64 KB of fragment reads + 32 KB DMA writes vs 1024 MFMA clocks.
+// Pipeline: K-tiles are 32 deep (64-B rows, two rows per 128-B LDS line, XOR swizzle over
+// the 8 16-B slots of a line), FOUR 32-KB stages; iteration j computes K-tile j from
+// registers, reads the fragments of K-tile j+1 from LDS between its MFMAs (one ds_read_b128
+// per 4 MFMAs) and issues the LDS-DMAs of K-tile j+4 into the stage K-tile j occupied (read
+// during iteration j-1).  A K-tile therefore has three iterations (~3000 clk) to arrive;
+// one s_barrier per iteration.  The epilogue runs from a private 4.5-KB staging area per
+// wave, so the stream of loads never stops at output-tile boundaries.
+// ---------------------------------------------------------------------------------
+template <int EPI, bool TL = false, int ABL = 0>
+__global__ __launch_bounds__(256)
+void gemm_nt_w4_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ W, int ldw,
+                       bf16* __restrict__ C, int ldc, int M, int N, int K, M3PEpilogue ep,
+                       int tiles_m, int tiles_n, int m_fast, unsigned long long* __restrict__ dbg = nullptr) {
+  // TL: debug instantiation that accumulates s_memtime per pipeline segment (tools/gemm_timeline.py)
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tl0 = TL ? __builtin_amdgcn_s_memtime() : 0, tl1;
+#define W4_TSEG(k) do { if (TL) { tl1 = __builtin_amdgcn_s_memtime(); tacc[k] += tl1 - tl0; tl0 = tl1; } } while (0)
+  constexpr int BM = 256, BN = 256, KT = 32, NST = 4;
+  constexpr int A_BYTES = BM * KT * 2, STAGE = (BM + BN) * KT * 2;     // 16 KB, 32 KB
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntiles = tiles_m * tiles_n;
+  const int n_strips = (tiles_n >= 12) ? (tiles_n + 3) / 4 : 1;
+  const int strip_w = (tiles_n + n_strips - 1) / n_strips;
+  auto split_tile = [&](int t, int& tm, int& tn) {
+    if (m_fast) { tn = t / tiles_m; tm = t - tn * tiles_m; return; }
+    const int strip = t / (tiles_m * strip_w);
+    const int rem = t - strip * tiles_m * strip_w;
+    const int bn = min(strip_w, tiles_n - strip * strip_w);
+    tm = rem / bn;
+    tn = strip * strip_w + (rem - tm * bn);
+  };
+  const int nwg = gridDim.x;
+  const int per_xcd = nwg >> 3;
+  const int slot = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  auto tile_of = [&](int q) { return q * nwg + slot; };
+  const int my_tiles = (ntiles > slot) ? (ntiles - slot + nwg - 1) / nwg : 0;
+  if (my_tiles == 0) return;
+  const int nk = K / KT;
+  const int total = my_tiles * nk;
+
+  // ---- load cursor.  One LDS-DMA instruction = 1 KB = 8 LDS lines = 16 tile rows; lane l
+  // fills slot (l & 7) of line (l >> 3), which must hold 16-B chunk c8 = slot ^ (line & 7),
+  // i.e. row 2*line + (c8 >> 2), k-chunk c8 & 3.
+  const int l_line = lane >> 3;
+  const int l_c8 = (lane & 7) ^ l_line;
+  const int l_row = 2 * l_line + (l_c8 >> 2);
+  const int l_col = (l_c8 & 3) * 8;
+  const bf16* a_src[4];
+  const bf16* w_src[4];
+  int l_q = 0, l_kt = 0;
+  auto set_load_tile = [&](int q) {
+    int tm, tn;
+    split_tile(tile_of(q), tm, tn);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      a_src[i] = A + (size_t)min(tm * BM + (wid + 4 * i) * 16 + l_row, M - 1) * lda + l_col;
+      w_src[i] = W + (size_t)min(tn * BN + (wid + 4 * i) * 16 + l_row, N - 1) * ldw + l_col;
+    }
+  };
+  auto issue_load = [&](int s, int piece) {
+    char* sa = smem + s * STAGE;
+    const int k0 = l_kt * KT;
+    if (piece < 4)
+      __builtin_amdgcn_global_load_lds(GLB_PTR(a_src[piece] + k0), LDS_PTR(sa + (wid + 4 * piece) * 1024), 16, 0, 0);
+    else
+      __builtin_amdgcn_global_load_lds(GLB_PTR(w_src[piece - 4] + k0), LDS_PTR(sa + A_BYTES + (wid + 4 * (piece - 4)) * 1024), 16, 0, 0);
+  };
+  auto load_done = [&]() {
+    if (++l_kt == nk) { l_kt = 0; ++l_q; if (l_q < my_tiles) set_load_tile(l_q); }
+  };
+
+  // ---- fragment addressing
+  const int wm = wid >> 1, wn = wid & 1;
+  const int fr = lane & 15, fg = lane >> 4;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const uint32_t f_sw = (uint32_t)(((((fr & 1) << 2) | fg) ^ (fr >> 1)) * 16);
+  const uint32_t a_base = lds0 + (wm * 64 + (fr >> 1)) * 128 + f_sw;
+  const uint32_t b_base = lds0 + A_BYTES + (wn * 64 + (fr >> 1)) * 128 + f_sw;
+#define W4_DSR(dst, addr, off) do { if (!(ABL & 1)) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr)); } while (0)
+#define W4_LGKM0() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+
+  // The 256 accumulator registers live in a[0:255] under OUR control: every MFMA and every
+  // accumulator read is inline asm with literal AGPR numbers (tile (i,j) = a[(8i+j)*4 .. +3]).
+  // Left to the register allocator (builtin MFMAs, or asm with "+a" operands) the compiler
+  // shuffled accumulators between AGPRs, VGPRs and scratch inside the K loop.  The compiler
+  // itself never allocates AGPRs in this kernel (checked in the ISA: no v_accvgpr_* outside
+  // ASMSTART/ASMEND); the empty asm below makes the kernel descriptor reserve all 256.
+  asm volatile("" ::: "a0", "a255");
+#define W4_ACC(I, J) "a[((" #I ")*8+(" #J "))*4:((" #I ")*8+(" #J "))*4+3]"
+#define W4_MFMA4(I, J0)                                                              \
+  asm volatile("v_mfma_f32_16x16x32_bf16 " W4_ACC(I, J0) ", %1, %0, " W4_ACC(I, J0) "\n\t"           \
+               "v_mfma_f32_16x16x32_bf16 " W4_ACC(I, J0 + 1) ", %2, %0, " W4_ACC(I, J0 + 1) "\n\t"   \
+               "v_mfma_f32_16x16x32_bf16 " W4_ACC(I, J0 + 2) ", %3, %0, " W4_ACC(I, J0 + 2) "\n\t"   \
+               "v_mfma_f32_16x16x32_bf16 " W4_ACC(I, J0 + 3) ", %4, %0, " W4_ACC(I, J0 + 3)          \
+               :: "v"(fac[I]), "v"(fwc[J0]), "v"(fwc[J0 + 1]), "v"(fwc[J0 + 2]), "v"(fwc[J0 + 3]))
+#define W4_MFMA4_FIRST(I, J0)                                                        \
+  asm volatile("v_mfma_f32_16x16x32_bf16 " W4_ACC(I, J0) ", %1, %0, 0\n\t"           \
+               "v_mfma_f32_16x16x32_bf16 " W4_ACC(I, J0 + 1) ", %2, %0, 0\n\t"       \
+               "v_mfma_f32_16x16x32_bf16 " W4_ACC(I, J0 + 2) ", %3, %0, 0\n\t"       \
+               "v_mfma_f32_16x16x32_bf16 " W4_ACC(I, J0 + 3) ", %4, %0, 0"           \
+               :: "v"(fac[I]), "v"(fwc[J0]), "v"(fwc[J0 + 1]), "v"(fwc[J0 + 2]), "v"(fwc[J0 + 3]))
+  // one iteration: 16 groups of {1 fragment read of the NEXT K-tile, (every other group) one
+  // LDS-DMA of K-tile +4, 4 MFMAs of the current K-tile}
+  // One iteration = 64 MFMAs (16 clocks each in the matrix pipe) with the 16 fragment reads of
+  // the next K-tile and the 8 LDS-DMAs of K-tile +4 slotted in singly: this wave is alone on
+  // its SIMD, so whatever it issues between two MFMAs must fit in the 16-clock shadow of the
+  // previous one (measured with 2 reads + 1 DMA per 4 MFMAs: 1448 clocks per iteration
+  // instead of 1024 - a 1-KB LDS/DMA instruction takes 8-16 clocks to issue).
+  // (loads past the end of this workgroup's stream are still issued - from the last valid
+  //  K-tile, into a stage nobody reads again - so the loop body has a single shape and the
+  //  counted vmcnt stays a constant)
+#define W4_M(I, J) do { if (FIRST) asm volatile("v_mfma_f32_16x16x32_bf16 " W4_ACC(I, J) ", %1, %0, 0" :: "v"(fac[I]), "v"(fwc[J])); \
+                        else asm volatile("v_mfma_f32_16x16x32_bf16 " W4_ACC(I, J) ", %1, %0, " W4_ACC(I, J) :: "v"(fac[I]), "v"(fwc[J])); } while (0)
+#define W4_L(PIECE) do { if (!(ABL & 2)) issue_load(s_load, PIECE); __builtin_amdgcn_sched_barrier(0); } while (0)
+  auto body = [&](auto first_c, const bf16x8 (&fac)[8], const bf16x8 (&fwc)[8], bf16x8 (&fan)[8], bf16x8 (&fwn)[8],
+                  int s_load, int s_next) {
+    constexpr bool FIRST = decltype(first_c)::value;   // first K-tile of an output tile: C operand = 0
+    const uint32_t ra = a_base + s_next * STAGE, rb = b_base + s_next * STAGE;
+    __builtin_amdgcn_sched_barrier(0);
+    W4_M(0, 0); W4_DSR(fwn[0], rb, 0);
+    W4_M(0, 1);
+    W4_M(0, 2); W4_DSR(fwn[1], rb, 1024);
+    W4_M(0, 3);
+    W4_M(0, 4); W4_DSR(fwn[2], rb, 2048);
+    W4_M(0, 5);
+    W4_M(0, 6); W4_DSR(fwn[3], rb, 3072);
+    W4_M(0, 7);
+    W4_M(1, 0); W4_DSR(fwn[4], rb, 4096);
+    W4_M(1, 1);
+    W4_M(1, 2); W4_DSR(fwn[5], rb, 5120);
+    W4_M(1, 3);
+    W4_M(1, 4); W4_DSR(fwn[6], rb, 6144);
+    W4_M(1, 5);
+    W4_M(1, 6); W4_DSR(fwn[7], rb, 7168);
+    W4_M(1, 7);
+    W4_M(2, 0); W4_DSR(fan[0], ra, 0);
+    W4_M(2, 1);
+    W4_M(2, 2); W4_DSR(fan[1], ra, 1024);
+    W4_M(2, 3);
+    W4_M(2, 4); W4_DSR(fan[2], ra, 2048);
+    W4_M(2, 5);
+    W4_M(2, 6); W4_DSR(fan[3], ra, 3072);
+    W4_M(2, 7);
+    W4_M(3, 0); W4_DSR(fan[4], ra, 4096);
+    W4_M(3, 1);
+    W4_M(3, 2); W4_DSR(fan[5], ra, 5120);
+    W4_M(3, 3);
+    W4_M(3, 4); W4_DSR(fan[6], ra, 6144);
+    W4_M(3, 5);
+    W4_M(3, 6); W4_DSR(fan[7], ra, 7168);
+    W4_M(3, 7);
+    W4_M(4, 0); W4_L(0);
+    W4_M(4, 1);
+    W4_M(4, 2);
+    W4_M(4, 3);
+    W4_M(4, 4); W4_L(1);
+    W4_M(4, 5);
+    W4_M(4, 6);
+    W4_M(4, 7);
+    W4_M(5, 0); W4_L(2);
+    W4_M(5, 1);
+    W4_M(5, 2);
+    W4_M(5, 3);
+    W4_M(5, 4); W4_L(3);
+    W4_M(5, 5);
+    W4_M(5, 6);
+    W4_M(5, 7);
+    W4_M(6, 0); W4_L(4);
+    W4_M(6, 1);
+    W4_M(6, 2);
+    W4_M(6, 3);
+    W4_M(6, 4); W4_L(5);
+    W4_M(6, 5);
+    W4_M(6, 6);
+    W4_M(6, 7);
+    W4_M(7, 0); W4_L(6);
+    W4_M(7, 1);
+    W4_M(7, 2);
+    W4_M(7, 3);
+    W4_M(7, 4); W4_L(7);
+    W4_M(7, 5);
+    W4_M(7, 6);
+    W4_M(7, 7);
+    __builtin_amdgcn_sched_barrier(0);
+    load_done();
+    W4_TSEG(0);
+    W4_LGKM0();
+    W4_TSEG(1);
+  };
+  // vmcnt retires in order and counts stores too.  Right after an epilogue the 32 C-tile stores
+  // of this wave are YOUNGER than the K-tiles in flight; waiting with the plain count would
+  // drain the whole prefetch queue (and the stores) at every output tile.  For the three
+  // publishes that follow a fast-path epilogue the count is raised by those 32 stores (a
+  // lower bound on the memory instructions the epilogue issued, so never too lax).
+  int post_ep = 0;
+#define W4_PUBLISH() do {                                                     \
+    if (post_ep > 0) { --post_ep; asm volatile("s_waitcnt vmcnt(48)" ::: "memory"); } \
+    else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");                    \
+    W4_TSEG(2);                                                               \
+    __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");              \
+    W4_TSEG(3); } while (0)
+
+  // ---- prologue: K-tiles 0..3 into stages 0..3
+  set_load_tile(0);
+#pragma unroll
+  for (int t = 0; t < NST; ++t) {
+#pragma unroll
+    for (int pc = 0; pc < 8; ++pc) issue_load(t, pc);
+    load_done();
+  }
+  asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  bf16x8 fa0[8], fw0[8], fa1[8], fw1[8];
+  W4_DSR(fw0[0], b_base, 0); W4_DSR(fw0[1], b_base, 1024); W4_DSR(fw0[2], b_base, 2048); W4_DSR(fw0[3], b_base, 3072);
+  W4_DSR(fw0[4], b_base, 4096); W4_DSR(fw0[5], b_base, 5120); W4_DSR(fw0[6], b_base, 6144); W4_DSR(fw0[7], b_base, 7168);
+  W4_DSR(fa0[0], a_base, 0); W4_DSR(fa0[1], a_base, 1024); W4_DSR(fa0[2], a_base, 2048); W4_DSR(fa0[3], a_base, 3072);
+  W4_DSR(fa0[4], a_base, 4096); W4_DSR(fa0[5], a_base, 5120); W4_DSR(fa0[6], a_base, 6144); W4_DSR(fa0[7], a_base, 7168);
+  W4_LGKM0();
+  W4_PUBLISH();      // K-tile 1 visible; stage 0 fully read by every wave
+
+  int c_q = 0, c_kt = 0;
+  const bool io_aligned = ((ldc & 7) == 0) && (((uintptr_t)C & 15) == 0) &&
+                          (!(EPI == M3P_EPI_BIAS_GELU) || (((ep.ld_out2 & 7) == 0) && (((uintptr_t)ep.out2 & 15) == 0))) &&
+                          (!ep.bias || (((uintptr_t)ep.bias & 15) == 0));
+  char* r1 = smem + NST * STAGE + wid * EP_HALF;
+  // nk is even (K % 64 == 0): output tiles start on even and end on odd K-tiles
+  for (int step = 0; step < total; step += 2) {
+    const int s0 = step & 3;
+    if (c_kt == 0) body(std::true_type{}, fa0, fw0, fa1, fw1, s0, s0 + 1);
+    else body(std::false_type{}, fa0, fw0, fa1, fw1, s0, s0 + 1);
+    W4_PUBLISH();
+    body(std::false_type{}, fa1, fw1, fa0, fw0, s0 + 1, (s0 + 2) & 3);
+    c_kt += 2;
+    W4_TSEG(5);
+    if (c_kt == nk) {
+      // ---- epilogue of output tile c_q out of the wave-private staging area; the K-tile
+      // stream (three tiles ahead) keeps landing meanwhile
+      c_kt = 0;
+      // the compiler's hazard recogniser does not see the asm MFMAs: the wait for the last
+      // accumulator write before v_accvgpr_read is ours
+      asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+      int tm, tn;
+      split_tile(tile_of(c_q), tm, tn);
+      ++c_q;
+      const int m0 = tm * BM, n0 = tn * BN;
+      const int mw = m0 + wm * 128, nw = n0 + wn * 128;
+      const bool fast = io_aligned && (m0 + BM <= M) && (n0 + BN <= N);
+      post_ep = fast ? 3 : 0;
+      f32x4 csum[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) csum[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma nounroll
+      for (int p = 0; p < 8; ++p) {
+        const int ch = p >> 2, rg = p & 3;        // column half outer: the bias-gradient sums run over rows
+        f32x4 rows[2][4];
+#define W4_RD(II, JJ, I, J)                                                         \
+  asm volatile("v_accvgpr_read_b32 %0, a[((" #I ")*8+(" #J "))*4+0]\n\t"                \
+               "v_accvgpr_read_b32 %1, a[((" #I ")*8+(" #J "))*4+1]\n\t"                \
+               "v_accvgpr_read_b32 %2, a[((" #I ")*8+(" #J "))*4+2]\n\t"                \
+               "v_accvgpr_read_b32 %3, a[((" #I ")*8+(" #J "))*4+3]"                    \
+               : "=v"(t0), "=v"(t1), "=v"(t2), "=v"(t3));                           \
+  rows[II][JJ] = f32x4{t0, t1, t2, t3}
+#define W4_SLICE(RG, CH)                                                                      \
+  W4_RD(0, 0, 2 * RG, 4 * CH); W4_RD(0, 1, 2 * RG, 4 * CH + 1); W4_RD(0, 2, 2 * RG, 4 * CH + 2); W4_RD(0, 3, 2 * RG, 4 * CH + 3); \
+  W4_RD(1, 0, 2 * RG + 1, 4 * CH); W4_RD(1, 1, 2 * RG + 1, 4 * CH + 1); W4_RD(1, 2, 2 * RG + 1, 4 * CH + 2); W4_RD(1, 3, 2 * RG + 1, 4 * CH + 3)
+        float t0, t1, t2, t3;
+        switch (p) {
+          case 0: W4_SLICE(0, 0); break;
+          case 1: W4_SLICE(1, 0); break;
+          case 2: W4_SLICE(2, 0); break;
+          case 3: W4_SLICE(3, 0); break;
+          case 4: W4_SLICE(0, 1); break;
+          case 5: W4_SLICE(1, 1); break;
+          case 6: W4_SLICE(2, 1); break;
+          default: W4_SLICE(3, 1); break;
+        }
+#undef W4_SLICE
+#undef W4_RD
+        const int mrow0 = mw + 32 * rg, ncol0 = nw + 64 * ch;
+        if (fast) {
+          epilogue_half<EPI>(ep, C, ldc, N, mrow0, ncol0, r1, rows, lane, csum);
+        } else {
+#pragma unroll
+          for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+              epilogue_store<EPI>(ep, C, ldc, M, N, mrow0 + ii * 16 + fr, ncol0 + jj * 16 + fg * 4, rows[ii][jj], csum[jj]);
+        }
+        if (EPI == M3P_EPI_DGELU && rg == 3) {
+          if (ep.colsum) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                float sfl = csum[j][r];
+                sfl += __shfl_xor(sfl, 1, 64); sfl += __shfl_xor(sfl, 2, 64);
+                sfl += __shfl_xor(sfl, 4, 64); sfl += __shfl_xor(sfl, 8, 64);
+                const int n = ncol0 + j * 16 + fg * 4 + r;
+                if (fr == 0 && n < N) unsafeAtomicAdd(ep.colsum + n, sfl);
+              }
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) csum[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+    }
+    W4_TSEG(4);
+    W4_PUBLISH();
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // junk loads of the tail must not outlive the LDS allocation
+  if (TL) {
+    W4_TSEG(6);
+    if (lane == 0)
+      for (int k = 0; k < 8; ++k) dbg[((size_t)blockIdx.x * 8 + wid) * 8 + k] = tacc[k];
+  }
+#undef W4_TSEG
+#undef W4_PUBLISH
+#undef W4_ACC
+#undef W4_MFMA4_FIRST
+#undef W4_DSR
+#undef W4_LGKM0
+#undef W4_MFMA4
+#undef W4_M
+#undef W4_L
+}
+
 static int num_cus() {
   static int n = 0;
   if (n == 0) {
@@ -918,6 +1260,29 @@ static int num_cus() {
 template <int EPI>
 int launch_nt(const bf16* A, int lda, const bf16* W, int ldw, bf16* C, int ldc, int M, int N, int K,
               const M3PEpilogue& ep, hipStream_t st) {
+  // deep contractions go to the 4-wave 256x256 kernel (measured on M=41984: K=3072,N=768 +5 %;
+  // K=768 shapes are equal or a little slower there, they stay on the 8-wave ring kernel)
+  const bool deep = (K >= 1536) && (N >= 512);
+  if (M >= 1024 && (g_variant == 2 || (g_variant == 1 && deep)) && (K % 64) == 0 && (lda % 8) == 0 && (ldw % 8) == 0) {
+    constexpr int BM = 256, BN = 256;
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+    const size_t lds = 4 * (BM + BN) * 64 + 4 * EP_HALF;
+    auto kern = gemm_nt_w4_kernel<EPI, false>;
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return (int)e;
+      attr_set = true;
+    }
+    int grid = num_cus();
+    const int ntiles = tiles_m * tiles_n;
+    if (ntiles < grid) grid = (ntiles + 7) / 8 * 8;
+    const long long wbytes = 2LL * N * K, abytes = 2LL * M * K;
+    const int m_fast = (wbytes > (64LL << 20) && abytes < wbytes) ? 1 : 0;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_m, tiles_n, m_fast, (unsigned long long*)nullptr);
+    M3P_CHECK_LAUNCH();
+    return M3P_OK;
+  }
   if (M >= 1024 && g_variant >= 1) {
     constexpr int BM = 256, BN = 128;
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
@@ -1542,6 +1907,18 @@ int m3p_gemm_nt_bf16(const void* A, int lda, const void* W, int ldw, void* C, in
 __attribute__((visibility("default"))) int m3p_debug_gemm_timeline(const void* A, int lda, const void* W, int ldw, void* C, int ldc,
                                                                    int M, int N, int K, unsigned long long* dbg, void* stream) {
   M3PEpilogue ep = {};
+  if (g_variant == 2) {
+    const int tm = (M + 255) / 256, tn = (N + 255) / 256;
+    const size_t lds4 = 4 * 512 * 64 + 4 * EP_HALF;
+    auto k4 = gemm_nt_w4_kernel<M3P_EPI_NONE, true, 0>;
+    if (g_ablate == 1) k4 = gemm_nt_w4_kernel<M3P_EPI_NONE, true, 1>;
+    if (g_ablate == 2) k4 = gemm_nt_w4_kernel<M3P_EPI_NONE, true, 2>;
+    if (g_ablate == 3) k4 = gemm_nt_w4_kernel<M3P_EPI_NONE, true, 3>;
+    hipFuncSetAttribute((const void*)k4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
+    hipLaunchKernelGGL(k4, dim3(num_cus()), dim3(256), lds4, (hipStream_t)stream, (const bf16*)A, lda, (const bf16*)W, ldw,
+                       (bf16*)C, ldc, M, N, K, ep, tm, tn, 0, dbg);
+    return (int)hipGetLastError();
+  }
   const int tiles_m = (M + 255) / 256, tiles_n = (N + 127) / 128;
   const size_t lds = 3 * (256 + 128) * ROWB;
   auto kern = gemm_nt_ring_timeline_kernel<M3P_EPI_NONE>;

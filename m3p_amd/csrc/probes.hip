@@ -55,3 +55,99 @@ int m3p_probe_tr16(const void* tile, void* out, void* stream) {
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------
+// Issue-cost probe (debug export, not part of the ABI header): one wave per SIMD runs
+// `iters` rounds of {8 independent MFMAs, one memory instruction of kind `mode`} and
+// reports its s_memtime ticks.  mode 0: none; 1: global_load_lds vaddr64; 2: global_load_lds
+// saddr + 32-bit offset; 3: global_load_dwordx4 -> VGPR; 4: buffer_load_dwordx4 ... lds;
+// 5: ds_read_b128.
+// ---------------------------------------------------------------------------------
+namespace {
+template <int MODE>
+__global__ __launch_bounds__(256) void probe_issue_kernel(const bf16* __restrict__ src, unsigned long long* __restrict__ out,
+                                                          int iters) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const bf16* p = src + ((size_t)blockIdx.x * 4 + wid) * 4096 + lane * 8;   // 1 KB per wave round-robin over 8 KB
+  const uint32_t lds_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem + wid * 8192;
+  bf16x8 fa, fb;
+  for (int i = 0; i < 8; ++i) { fa[i] = (bf16)1.0f; fb[i] = (bf16)0.5f; }
+  f32x4 acc[8];
+  for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 sink = fa;
+  uint4 gsink = {0, 0, 0, 0};
+  // buffer resource for mode 4
+  __attribute__((ext_vector_type(4))) uint32_t rsrc;
+  rsrc[0] = (uint32_t)(uintptr_t)src; rsrc[1] = (uint32_t)((uintptr_t)src >> 32); rsrc[2] = 0x7fffffff; rsrc[3] = 0x00020000;
+  const uint32_t voff = (uint32_t)((((size_t)blockIdx.x * 4 + wid) * 4096 + lane * 8) * 2);
+  uint32_t dummy = lane, d1 = lane, d2 = lane, d3 = lane;
+  const uint32_t inv_addr = lds_addr + lane * 16;
+  if (MODE == 7) asm volatile("s_mov_b32 m0, %0" :: "s"(lds_addr));
+  __syncthreads();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < iters; ++it) {
+    const int sub = (it & 3) * 512;   // elements: 1 KB steps inside the wave's 8-KB window
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[k]) : "v"(fa), "v"(fb));
+    if (MODE == 1) {
+      __builtin_amdgcn_global_load_lds(GLB_PTR(p + sub), LDS_PTR(smem + wid * 8192 + (it & 3) * 1024), 16, 0, 0);
+    } else if (MODE == 2) {
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                   :: "v"(voff + sub * 2), "s"(src), "s"(lds_addr + (it & 3) * 1024) : "memory");
+    } else if (MODE == 3) {
+      uint4 v;
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(v) : "v"(p + sub) : "memory");
+      if ((it & 7) == 7) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); gsink.x ^= v.x; }
+    } else if (MODE == 4) {
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
+                   :: "v"(voff + sub * 2), "s"(rsrc), "s"(lds_addr + (it & 3) * 1024) : "memory");
+    } else if (MODE == 5) {
+      bf16x8 r;
+      asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(lds_addr + lane * 16 + (it & 3) * 1024));
+      if ((it & 7) == 7) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); sink[0] += r[0]; }
+    }
+    else if (MODE == 6) {
+      asm volatile("v_add_u32 %0, %0, 1" : "+v"(dummy));
+    } else if (MODE == 7) {
+      asm volatile("global_load_lds_dwordx4 %0, off" :: "v"(p) : "memory");      // m0 set once outside the loop
+    } else if (MODE == 8) {
+      bf16x8 r;
+      asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(inv_addr));
+      if ((it & 7) == 7) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); sink[0] += r[0]; }
+    } else if (MODE == 9) {
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" :: "s"(lds_addr + (it & 3) * 1024));
+    } else if (MODE == 10) {
+      asm volatile("v_add_u32 %0, %0, 1\n\tv_add_u32 %1, %1, 1\n\tv_add_u32 %2, %2, 1\n\tv_add_u32 %3, %3, 1" : "+v"(dummy), "+v"(d1), "+v"(d2), "+v"(d3));
+    }
+    if ((MODE == 1 || MODE == 2 || MODE == 4 || MODE == 7) && (it & 7) == 7) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  float s = (float)sink[0] + (float)gsink.x + (float)(dummy + d1 + d2 + d3);
+  for (int i = 0; i < 8; ++i) s += acc[i][0];
+  if (lane == 0) { out[(blockIdx.x * 4 + wid) * 2] = t1 - t0; out[(blockIdx.x * 4 + wid) * 2 + 1] = (unsigned long long)s; }
+}
+}  // namespace
+
+extern "C" __attribute__((visibility("default"))) int m3p_debug_probe_issue(int mode, const void* src, unsigned long long* out,
+                                                                            int iters, int nblocks, void* stream) {
+  const size_t lds = 4 * 8192;
+#define LAUNCH(MODE) hipLaunchKernelGGL(probe_issue_kernel<MODE>, dim3(nblocks), dim3(256), lds, (hipStream_t)stream, (const bf16*)src, out, iters)
+  switch (mode) {
+    case 0: LAUNCH(0); break;
+    case 1: LAUNCH(1); break;
+    case 2: LAUNCH(2); break;
+    case 3: LAUNCH(3); break;
+    case 4: LAUNCH(4); break;
+    case 5: LAUNCH(5); break;
+    case 6: LAUNCH(6); break;
+    case 7: LAUNCH(7); break;
+    case 8: LAUNCH(8); break;
+    case 9: LAUNCH(9); break;
+    default: LAUNCH(10); break;
+  }
+#undef LAUNCH
+  return (int)hipGetLastError();
+}

@@ -74,6 +74,8 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the .so is stale
         fn.restype = res
         fn.argtypes = args
+    if os.environ.get('M3P_VARIANT'):      # developer switch between GEMM kernel generations (A/B runs)
+        lib.m3p_debug_set_variant(int(os.environ['M3P_VARIANT']))
     _lib = lib
     return lib
 

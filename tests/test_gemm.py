@@ -147,3 +147,42 @@ def test_gemm_nt_streamk(M, N, K):
     ops.gemm_nt_streamk(a, w, out, alpha=0.5)
     ref = 1.0 + 0.5 * (ac.double() @ wc.double().t())
     assert rel_l2(out, ref) < 1e-5
+
+
+@pytest.mark.parametrize('M,N,K', [(1024, 768, 3072), (1024 + 40, 1000, 128), (2560, 512, 2304), (1300, 2304 + 8, 1536)])
+def test_gemm_nt_four_wave_kernel(M, N, K):
+    """The 256x256 four-wave kernel (deep-K shapes pick it automatically) against the fp32 product,
+    every epilogue, full and ragged tiles; forced through the developer switch so shallow K runs it too."""
+    from m3p_amd import ops, rng, lib as L
+    lib = L.load()
+    a, ac = randn_bf16((M, K), 1)
+    w, wc = randn_bf16((N, K), 2, 0.05)
+    bias, bc = randn_f32((N,), 3)
+    r, rc = randn_bf16((M, N), 4)
+    prod = ac @ wc.t()
+    lib.m3p_debug_set_variant(2)
+    try:
+        c = ops.gemm_nt(a, w, L.EPI_NONE)
+        assert rel_l2(c.float(), prod) < 4e-3
+        c = ops.gemm_nt(a, w, L.EPI_BIAS, bias=bias, scale_cols=N // 3, scale=0.125)
+        ref = prod + bc
+        ref[:, :N // 3] *= 0.125
+        assert rel_l2(c.float(), ref) < 4e-3
+        u = torch.empty((M, N), dtype=torch.bfloat16, device='cuda')
+        h = ops.gemm_nt(a, w, L.EPI_BIAS_GELU, bias=bias, out2=u)
+        assert rel_l2(u.float(), prod + bc) < 4e-3
+        uf = u.float().cpu().double()
+        assert rel_l2(h.float(), (0.5 * uf * (1 + torch.erf(uf / math.sqrt(2)))).float()) < 4e-3
+        c = ops.gemm_nt(a, w, L.EPI_BIAS_DROP_RES, bias=bias, aux=r, seed=99, p_drop=0.1)
+        keep = torch.from_numpy(rng.keep_mask(M * N, 99, 0.1, (M, N)))
+        assert rel_l2(c.float(), (prod + bc) * keep / 0.9 + rc) < 4e-3
+        c = ops.gemm_nt(a, w, L.EPI_RES, aux=r, alpha=0.5)
+        assert rel_l2(c.float(), 0.5 * prod + rc) < 4e-3
+        cs = torch.zeros(N, device='cuda')
+        c = ops.gemm_nt(a, w, L.EPI_DGELU, aux=r, colsum=cs)
+        x = rc.double()
+        dg = 0.5 * (1 + torch.erf(x / math.sqrt(2))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi)
+        assert rel_l2(c.float(), prod.double() * dg) < 4e-3
+        assert rel_l2(cs, c.float().sum(0)) < 1e-4
+    finally:
+        lib.m3p_debug_set_variant(1)

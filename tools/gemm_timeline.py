@@ -17,6 +17,9 @@ for _ in range(3):
 torch.cuda.synchronize()
 d = dbg.view(256, 8, 8).double()
 names = ['issue loads+reads', 'mfma batch1', 'lgkm wait', 'vmcnt wait', 'barrier', 'reads+mfma batch2+lgkm', 'epilogue/loop tail', 'loop head']
+if int(os.environ.get('M3P_VARIANT', '1')) & 0xff == 2:      # 4-wave kernel: waves 4..7 do not exist
+    d = d[:, :4]
+    names = ['groups (reads+dma+mfma issue)', 'lgkm wait', 'vmcnt wait', 'barrier', 'epilogue', 'loop glue', 'drain', '-']
 tot = d.sum(-1).mean()
 print('shape', M, N, K, ' mean cycles per wave: %.0f' % tot)
 for k, n in enumerate(names):
