@@ -126,8 +126,10 @@ M3P_API int m3p_attn_fwd(const void* qkv, const int32_t* keylen, void* ctx, floa
 
 /* Backward: given dctx (bf16 [B*S, H*dh]) writes dqkv (bf16 [B*S, 3*H*dh]; the q block is
  * multiplied by qscale = 1/sqrt(dh) so it is the gradient of the *unscaled* projection)
- * and, if dbias_qkv != NULL, accumulates (atomics) the column sums of dqkv into the fp32
- * [3*H*dh] bias gradient of the fused q/k/v projection.  Scores are recomputed from
+ * and, if dbias_qkv != NULL, accumulates (atomics) the column sums of the q and v blocks of
+ * dqkv into the fp32 [3*H*dh] bias gradient of the fused q/k/v projection.  The k block of
+ * the bias gradient is left untouched: it is identically 0 (softmax is invariant to a
+ * per-query shift of the scores; the reference's value there is fp32 noise).  Scores are recomputed from
  * qkv + lse (nothing S x S is ever stored).  S <= 384. */
 M3P_API int m3p_attn_bwd(const void* qkv, const int32_t* keylen, const void* ctx, const void* dctx,
                          const float* lse, void* dqkv, float* dbias_qkv, int B, int S, int H, int dh,

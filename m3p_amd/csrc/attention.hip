@@ -192,7 +192,7 @@ void attn_fwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
 // The scores are recomputed in both phases: MFMA time is cheap here, LDS transposes are not.
 // ---------------------------------------------------------------------------------------
 template <int DH, int KT>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256, 3)   // 3 waves per SIMD: three 49-KB workgroups per CU
 void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keylen, const bf16* __restrict__ ctx,
                      const bf16* __restrict__ dctx, const float* __restrict__ lse, bf16* __restrict__ dqkv,
                      float* __restrict__ dbias_qkv, int S, int H, int dmodel, float qscale, uint32_t seed,
@@ -224,19 +224,31 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
   float* sD = sL + nk * 32;
   const int fq = lane & 15, fg = lane >> 4;
   float* sB = sD + nk * 32;           // [4 waves][3][DH] bias-gradient accumulators (q | k | v), one slot per wave
-  for (int i = tid; i < 4 * 3 * DH; i += 256) sB[i] = 0.f;
   float* sBw = sB + wid * 3 * DH;
-  // column sum over the 16 lanes (fq) that hold different rows of the same 4 columns, then one
-  // plain LDS read-modify-write by lane fq == 0 into this wave's slot (LDS float atomics with 16
-  // lanes on one address measured 2.2x slower for the whole kernel)
-  auto bias_acc = [&](int part, int n, const bf16x4& v4) {
+  // bias gradients = column sums of the bf16 dQ/dK/dV rows this block writes.  Each lane keeps
+  // running sums of ITS rows in registers (part x d-tile x 4 columns); the reduction over the
+  // 16 lanes (fq) that hold different rows of the same columns happens once per wave at the
+  // end of the kernel (doing the shuffles + LDS update per 16-row block cost 93 of 386 us).
+  // The k-bias gradient is identically zero (softmax is invariant to a per-query shift of the
+  // scores, so sum_key dS[q][key] = 0): it is written as exact 0 instead of the rounding
+  // noise a column sum of bf16 dK rows would give.
+  f32x4 bsum[Cf::NT];       // phase A: v-bias sums, flushed to LDS, then reused for q in phase B
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float sfl = (float)v4[r];
-      sfl += __shfl_xor(sfl, 1, 64); sfl += __shfl_xor(sfl, 2, 64);
-      sfl += __shfl_xor(sfl, 4, 64); sfl += __shfl_xor(sfl, 8, 64);
-      if (fq == 0) sBw[part * DH + 16 * n + 4 * fg + r] += sfl;
-    }
+  for (int n = 0; n < Cf::NT; ++n) bsum[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto bias_acc = [&](int n, const bf16x4& v4) {
+    bsum[n] += f32x4{(float)v4[0], (float)v4[1], (float)v4[2], (float)v4[3]};
+  };
+  auto bias_flush = [&](int part) {
+#pragma unroll
+    for (int n = 0; n < Cf::NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float sfl = bsum[n][r];
+        sfl += __shfl_xor(sfl, 1, 64); sfl += __shfl_xor(sfl, 2, 64);
+        sfl += __shfl_xor(sfl, 4, 64); sfl += __shfl_xor(sfl, 8, 64);
+        if (fq == 0) sBw[part * DH + 16 * n + 4 * fg + r] = sfl;
+        bsum[n][r] = 0.f;
+      }
   };
 
   int r_off[Cf::KK];   // row-major fragment (row 16t + fq, chunk 4kk + fg)
@@ -350,11 +362,11 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
 #pragma unroll
       for (int n = 0; n < Cf::NT; ++n) {
         const bool ok = key < S;
-        bias_acc(1, n, ok ? bf16x4{(bf16)dk[n][0], (bf16)dk[n][1], (bf16)dk[n][2], (bf16)dk[n][3]} : bf16x4{0, 0, 0, 0});
-        bias_acc(2, n, ok ? bf16x4{(bf16)dv[n][0], (bf16)dv[n][1], (bf16)dv[n][2], (bf16)dv[n][3]} : bf16x4{0, 0, 0, 0});
+        bias_acc(n, ok ? bf16x4{(bf16)dv[n][0], (bf16)dv[n][1], (bf16)dv[n][2], (bf16)dv[n][3]} : bf16x4{0, 0, 0, 0});
       }
     }
   }
+  if (dbias_qkv) bias_flush(2);
   __syncthreads();   // everyone done with Q / dO tiles
 
   // ================= phase B: dQ (wave owns query blocks) =================
@@ -426,19 +438,21 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
 #pragma unroll
       for (int n = 0; n < Cf::NT; ++n) {
         const bool ok = q < S;
-        bias_acc(0, n, ok ? bf16x4{(bf16)(dq[n][0] * qscale), (bf16)(dq[n][1] * qscale), (bf16)(dq[n][2] * qscale),
+        bias_acc(n, ok ? bf16x4{(bf16)(dq[n][0] * qscale), (bf16)(dq[n][1] * qscale), (bf16)(dq[n][2] * qscale),
                                    (bf16)(dq[n][3] * qscale)} : bf16x4{0, 0, 0, 0});
       }
     }
   }
 
-  // ---- bias gradients: column sums of the bf16 dQ/dK/dV this block wrote
+  // ---- bias gradients: column sums of the bf16 dQ / dV rows this block wrote (k: zero, see above)
   if (dbias_qkv) {
+    bias_flush(0);
     __syncthreads();
     for (int i = tid; i < 3 * DH; i += 256) {
       const int part = i / DH, c = i - part * DH;
-      atomicAdd(dbias_qkv + part * dmodel + h * DH + c,
-                (sB[i] + sB[3 * DH + i]) + (sB[6 * DH + i] + sB[9 * DH + i]));
+      if (part != 1)
+        atomicAdd(dbias_qkv + part * dmodel + h * DH + c,
+                  (sB[i] + sB[3 * DH + i]) + (sB[6 * DH + i] + sB[9 * DH + i]));
     }
   }
 }

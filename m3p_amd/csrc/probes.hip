@@ -121,6 +121,17 @@ __global__ __launch_bounds__(256) void probe_issue_kernel(const bf16* __restrict
     } else if (MODE == 10) {
       asm volatile("v_add_u32 %0, %0, 1\n\tv_add_u32 %1, %1, 1\n\tv_add_u32 %2, %2, 1\n\tv_add_u32 %3, %3, 1" : "+v"(dummy), "+v"(d1), "+v"(d2), "+v"(d3));
     }
+    else if (MODE == 11) {
+      asm volatile("v_mul_lo_u32 %0, %0, %4\n\tv_mul_lo_u32 %1, %1, %4\n\tv_mul_lo_u32 %2, %2, %4\n\tv_mul_lo_u32 %3, %3, %4" : "+v"(dummy), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(0x9E3779B1u));
+    } else if (MODE == 12) {
+      asm volatile("v_mul_u32_u24 %0, %0, %4\n\tv_mul_u32_u24 %1, %1, %4\n\tv_mul_u32_u24 %2, %2, %4\n\tv_mul_u32_u24 %3, %3, %4" : "+v"(dummy), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(0x9E3779u));
+    } else if (MODE == 13) {
+      asm volatile("v_exp_f32 %0, %0\n\tv_exp_f32 %1, %1\n\tv_exp_f32 %2, %2\n\tv_exp_f32 %3, %3" : "+v"(dummy), "+v"(d1), "+v"(d2), "+v"(d3));
+    } else if (MODE == 14) {
+      asm volatile("v_mad_u32_u24 %0, %0, %4, %1\n\tv_mad_u32_u24 %1, %1, %4, %2\n\tv_mad_u32_u24 %2, %2, %4, %3\n\tv_mad_u32_u24 %3, %3, %4, %0" : "+v"(dummy), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(0x9E3779u));
+    } else if (MODE == 15) {
+      asm volatile("v_mul_hi_u32 %0, %0, %4\n\tv_mul_hi_u32 %1, %1, %4\n\tv_mul_hi_u32 %2, %2, %4\n\tv_mul_hi_u32 %3, %3, %4" : "+v"(dummy), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(0x9E3779B1u));
+    }
     if ((MODE == 1 || MODE == 2 || MODE == 4 || MODE == 7) && (it & 7) == 7) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -146,7 +157,12 @@ extern "C" __attribute__((visibility("default"))) int m3p_debug_probe_issue(int 
     case 7: LAUNCH(7); break;
     case 8: LAUNCH(8); break;
     case 9: LAUNCH(9); break;
-    default: LAUNCH(10); break;
+    case 10: LAUNCH(10); break;
+    case 11: LAUNCH(11); break;
+    case 12: LAUNCH(12); break;
+    case 13: LAUNCH(13); break;
+    case 14: LAUNCH(14); break;
+    default: LAUNCH(15); break;
   }
 #undef LAUNCH
   return (int)hipGetLastError();

@@ -55,7 +55,12 @@ def test_attention_fwd_bwd(B, S, H, dh, p):
     g[:, :d] *= 1.0 / math.sqrt(dh)       # kernel returns the gradient of the unscaled q projection
     for name, sl in (('dq', slice(0, d)), ('dk', slice(d, 2 * d)), ('dv', slice(2 * d, 3 * d))):
         assert rel_l2(dqkv[:, sl].float(), g[:, sl]) < 1.5e-2, name
-    assert rel_l2(dbias, dqkv.float().sum(0)) < 1e-4
+    cs = dqkv.float().sum(0)
+    assert rel_l2(dbias[:d], cs[:d]) < 1e-4 and rel_l2(dbias[2 * d:], cs[2 * d:]) < 1e-4   # column sums of the rows it wrote
+    # k-bias: softmax shift invariance makes the true gradient 0 (the fp32 reference gives ~1e-7 noise);
+    # the kernel writes exact zeros rather than the bf16 rounding noise of its dK rows
+    assert bool((dbias[d:2 * d] == 0).all())
+    assert float(g[:, d:2 * d].sum(0).abs().max()) < 1e-3 * float(g[:, d:2 * d].abs().sum(0).max())
 
 
 def test_attention_perf_smoke():
