@@ -121,8 +121,13 @@ M3P_API int m3p_layernorm_bwd(const void* dy_a, const void* dy_b, const void* x,
  * probabilities with stream (seed, thresh24) indexed ((b*H+h)*S+q)*S+key, context = P v.
  * ctx bf16 [B*S, H*dh] token-major; lse fp32 [B,H,S] = log-sum-exp saved for backward.
  * dh in {32, 64}, S <= 512. */
-M3P_API int m3p_attn_fwd(const void* qkv, const int32_t* keylen, void* ctx, float* lse, int B, int S, int H,
-                         int dh, uint32_t seed, uint32_t thresh24, float inv_keep, void* stream);
+M3P_API int m3p_attn_fwd(const void* qkv, const int32_t* keylen, void* ctx, float* lse, uint64_t* keepmask,
+                         int B, int S, int H, int dh, uint32_t seed, uint32_t thresh24, float inv_keep,
+                         void* stream);
+/* keepmask (nullable): if given and thresh24 != 0, the forward also leaves the dropout keep
+ * bits, [B*H][nt][nt][4] 64-bit words with nt = ceil(S/16); word [qb][t][r] bit l is the
+ * keep decision of (query 16qb + (l & 15), key 16t + 4(l >> 4) + r).  m3p_attn_bwd given the
+ * same buffer tests bits instead of regenerating the hash twice per (query, key) pair. */
 
 /* Backward: given dctx (bf16 [B*S, H*dh]) writes dqkv (bf16 [B*S, 3*H*dh]; the q block is
  * multiplied by qscale = 1/sqrt(dh) so it is the gradient of the *unscaled* projection)
@@ -132,8 +137,9 @@ M3P_API int m3p_attn_fwd(const void* qkv, const int32_t* keylen, void* ctx, floa
  * per-query shift of the scores; the reference's value there is fp32 noise).  Scores are recomputed from
  * qkv + lse (nothing S x S is ever stored).  S <= 384. */
 M3P_API int m3p_attn_bwd(const void* qkv, const int32_t* keylen, const void* ctx, const void* dctx,
-                         const float* lse, void* dqkv, float* dbias_qkv, int B, int S, int H, int dh,
-                         float qscale, uint32_t seed, uint32_t thresh24, float inv_keep, void* stream);
+                         const float* lse, const uint64_t* keepmask, void* dqkv, float* dbias_qkv, int B, int S,
+                         int H, int dh, float qscale, uint32_t seed, uint32_t thresh24, float inv_keep,
+                         void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Input assembly of jointfwd (transformer.py:901-943) and its backward

@@ -17,6 +17,10 @@
 //   * output is token-major [M, d] (head-interleaved) so out_lin consumes it directly.
 #include "common.hpp"
 
+#ifndef M3P_ATTN_SKIP_PAD
+#define M3P_ATTN_SKIP_PAD 1
+#endif
+
 namespace {
 
 template <int DH> struct AttnCfg {
@@ -56,11 +60,11 @@ __device__ __forceinline__ void stage_rows(const bf16* __restrict__ g, size_t ld
 // ---------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------
-template <int DH, int KT>
+template <int DH, int KT, bool DROP>
 __global__ __launch_bounds__(256)
 void attn_fwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keylen, bf16* __restrict__ ctx,
-                     float* __restrict__ lse, int S, int H, int dmodel, uint32_t seed, uint32_t thresh24,
-                     float inv_keep) {
+                     float* __restrict__ lse, unsigned long long* __restrict__ keepmask, int S, int H, int dmodel,
+                     uint32_t seed, uint32_t thresh24, float inv_keep) {
   using Cf = AttnCfg<DH>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -111,45 +115,70 @@ void attn_fwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
         }
       }
     }
-    // ---- softmax over keys (key = 16t + 4fg + r) for query column fq
+    // ---- softmax over keys (key = 16t + 4fg + r) for query column fq; tiles t >= nt are padding
+    constexpr float kLog2e = 1.4426950408889634f;
     float mx = -INFINITY;
 #pragma unroll
     for (int t = 0; t < 2 * KT; ++t)
+      if (t < nt) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = 16 * t + 4 * fg + r;
-        const float v = (key < klen) ? s[t][r] : -INFINITY;
-        s[t][r] = v;
-        mx = fmaxf(mx, v);
+        for (int r = 0; r < 4; ++r) {
+          const int key = 16 * t + 4 * fg + r;
+          const float v = (key < klen) ? s[t][r] : -INFINITY;
+          s[t][r] = v;
+          mx = fmaxf(mx, v);
+        }
       }
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mx2 = mx * kLog2e;
     float sum = 0.f;
 #pragma unroll
     for (int t = 0; t < 2 * KT; ++t)
+      if (t < nt) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float p = __expf(s[t][r] - mx);
-        s[t][r] = p;
-        sum += p;
+        for (int r = 0; r < 4; ++r) {
+          const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][r], kLog2e, -mx2));   // = exp(s - mx)
+          s[t][r] = p;
+          sum += p;
+        }
       }
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.0f / sum;
     const uint32_t rbase = (uint32_t)((b * H + h) * S + qc) * (uint32_t)S;
+    // keep-mask words for backward: word [qb][t][r], bit l = keep(query 16qb + (l & 15),
+    // key 16t + 4(l >> 4) + r) - the compare's lane mask as it comes out of the VALU
+    unsigned long long* mrow = keepmask ? keepmask + ((size_t)(b * H + h) * nt + qb) * nt * 4 : nullptr;
     bf16x8 pf[KT];
 #pragma unroll
     for (int kk = 0; kk < KT; ++kk) {
       float p[8];
+      unsigned long long kw[8];
+      const float invk = DROP ? inv * inv_keep : inv;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int t = 2 * kk + (j >> 2), r = j & 3;
-        float v = s[t][r] * inv;
-        if (thresh24) {
-          const int key = 16 * t + 4 * fg + r;
-          v = m3p_keep(rbase + (uint32_t)key, seed, thresh24) ? v * inv_keep : 0.f;
+        float v = 0.f;
+        kw[j] = 0;
+        if (t < nt) {
+          v = s[t][r] * invk;
+          if (DROP) {
+            const int key = 16 * t + 4 * fg + r;
+            const bool keep = m3p_keep(rbase + (uint32_t)key, seed, thresh24);
+            kw[j] = __builtin_amdgcn_ballot_w64(keep);
+            v = keep ? v : 0.f;
+          }
         }
         p[j] = v;
+      }
+      if (DROP && mrow && lane == 0) {
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+          if (2 * kk + hf < nt) {
+            unsigned long long* mp = mrow + (2 * kk + hf) * 4;
+            mp[0] = kw[4 * hf + 0]; mp[1] = kw[4 * hf + 1]; mp[2] = kw[4 * hf + 2]; mp[3] = kw[4 * hf + 3];
+          }
       }
       pf[kk] = bf16x8{(bf16)p[0], (bf16)p[1], (bf16)p[2], (bf16)p[3], (bf16)p[4], (bf16)p[5], (bf16)p[6], (bf16)p[7]};
     }
@@ -191,10 +220,16 @@ void attn_fwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
 //   (lane = query column) so dS^T feeds dQ^T = K^T dS^T from registers.
 // The scores are recomputed in both phases: MFMA time is cheap here, LDS transposes are not.
 // ---------------------------------------------------------------------------------------
-template <int DH, int KT>
+// DROP: attention dropout active (compile-time: as a runtime flag the compiler turned it into
+// per-element selects over both variants).  MASK (implies DROP): keep bits from the forward pass.
+// NKC: number of 32-row steps known at compile time (6 = the M3P sequence, 36 regions + 128 tokens,
+// padded to 192) so both streaming loops unroll and every LDS address becomes base + immediate
+// (the rolled loop spent 28 of its ~110 VALU instructions per step on address updates); 0 = runtime.
+template <int DH, int KT, bool DROP, bool MASK, int NKC>
 __global__ __launch_bounds__(256, 3)   // 3 waves per SIMD: three 49-KB workgroups per CU
 void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keylen, const bf16* __restrict__ ctx,
-                     const bf16* __restrict__ dctx, const float* __restrict__ lse, bf16* __restrict__ dqkv,
+                     const bf16* __restrict__ dctx, const float* __restrict__ lse,
+                     const unsigned long long* __restrict__ keepmask, bf16* __restrict__ dqkv,
                      float* __restrict__ dbias_qkv, int S, int H, int dmodel, float qscale, uint32_t seed,
                      uint32_t thresh24, float inv_keep) {
   using Cf = AttnCfg<DH>;
@@ -203,7 +238,7 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.x / H, h = blockIdx.x - b * H;
   const int nt = (S + 15) >> 4;
-  const int nk = (S + 31) >> 5;
+  const int nk = NKC ? NKC : ((S + 31) >> 5);
   const size_t ld = 3 * (size_t)dmodel;
   const bf16* Qg = qkv + (size_t)b * S * ld + h * DH;
   const bf16* Kg = Qg + dmodel;
@@ -215,6 +250,9 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
   bf16* dVg = dQg + 2 * dmodel;
   const float* lse_bh = lse + (size_t)(b * H + h) * S;
   const int klen = keylen[b];
+  // MASK: the forward pass left the dropout keep bits of this head (m3p_attn_fwd keepmask); both
+  // phases then test a bit instead of re-hashing every (query, key) pair twice (~14 VALU ops each)
+  const unsigned long long* mbh = MASK ? keepmask + (size_t)(b * H + h) * nt * nt * 4 : nullptr;
 
   // LDS: two [nk*32][DH] bf16 tiles + lse[nk*32] + D[nk*32] (fp32)
   const int tile_bytes = nk * 32 * Cf::ROWB;
@@ -260,6 +298,9 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
   for (int n = 0; n < Cf::NT; ++n)
     t_off[n] = trow * Cf::ROWB + Cf::swz(2 * n + ((fq & 3) >> 1), trow) * 16 + 8 * (fq & 1);
 
+  constexpr float kLog2e = 1.4426950408889634f;
+  constexpr float kMasked = -1.0e30f;    // score of a masked key: exp2 of it is exactly 0
+  const uint32_t inv_keep_bits = __builtin_bit_cast(uint32_t, inv_keep);
   // ---- prologue: D[q] = rowsum(dO * O), lse -> LDS (padded rows: D = 0, lse = +inf so P = 0)
   for (int q = tid; q < nk * 32; q += 256) {
     float dsum = 0.f, l = INFINITY;
@@ -273,7 +314,7 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
 #pragma unroll
         for (int e = 0; e < 8; ++e) dsum += (float)ov[e] * (float)dv[e];
       }
-      l = lse_bh[q];
+      l = lse_bh[q] * kLog2e;          // probabilities are rebuilt as exp2(S log2e - lse log2e): fma + v_exp
     }
     sD[q] = dsum;
     sL[q] = l;
@@ -297,7 +338,7 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
   for (int kb = wid; kb < nt; kb += 4) {
     const int key = kb * 16 + fq;            // this lane's key column
     const int keyc = min(key, S - 1);
-    const bool kvalid = key < klen;
+    const float kbias = (key < klen) ? 0.f : kMasked;
     if (kb != wid) load_kv(kb);
     // dV^T[d][key] = sum_q dO[q][d] Pd[q][key] ; dK^T[d][key] = sum_q Q[q][d] dS[q][key]
     // streamed over 32-query steps: P / dS of a step are produced (lane = key column, query
@@ -305,12 +346,22 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
     f32x4 dv[Cf::NT], dk[Cf::NT];
 #pragma unroll
     for (int n = 0; n < Cf::NT; ++n) dv[n] = dk[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll(NKC ? NKC : 1)
     for (int kq = 0; kq < nk; ++kq) {
       f32x4 pd2[2], ds2[2];
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         const int t = 2 * kq + hf;
-        f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+        if (M3P_ATTN_SKIP_PAD && !MASK && t >= nt) {      // query tile that is pure padding (measured slower with MASK) (S = 164: rows 176..191): contributes zeros
+          pd2[hf] = ds2[hf] = f32x4{0.f, 0.f, 0.f, 0.f};
+          continue;
+        }
+        // a masked key column starts its score accumulator at -1e30 (no per-element select);
+        // without dropout dPd - D comes straight out of the MFMA (accumulator starts at -D[q])
+        const f32x4 dneg = f32x4{-sD[16 * t + 4 * fg + 0], -sD[16 * t + 4 * fg + 1], -sD[16 * t + 4 * fg + 2],
+                                 -sD[16 * t + 4 * fg + 3]};
+        f32x4 sc = {kbias, kbias, kbias, kbias};
+        f32x4 dp = DROP ? f32x4{0.f, 0.f, 0.f, 0.f} : dneg;
 #pragma unroll
         for (int kk = 0; kk < Cf::KK; ++kk) {
           const bf16x8 qf = *reinterpret_cast<const bf16x8*>(s0 + t * 16 * Cf::ROWB + r_off[kk]);
@@ -318,19 +369,30 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
           sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf[kk], sc, 0, 0, 0);   // S[q][key]
           dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, vf[kk], dp, 0, 0, 0);   // dPd[q][key]
         }
+        uint32_t kbits = 0;
+        if (MASK) {
+          // forward layout: word [qb = t][tile = kb][r = key & 3], bit (q & 15) + 16 ((key & 15) >> 2)
+          const unsigned long long w = mbh[((size_t)min(t, nt - 1) * nt + kb) * 4 + (fq & 3)];
+          kbits = (uint32_t)(w >> (4 * fg + 16 * (fq >> 2)));
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int q = 16 * t + 4 * fg + r;
-          const float p = kvalid ? __expf(sc[r] - sL[q]) : 0.f;     // padded q: lse=+inf -> 0
-          float pdrop = p, dpr = dp[r];
-          if (thresh24) {
-            const uint32_t idx = (uint32_t)((b * H + h) * S + min(q, S - 1)) * (uint32_t)S + (uint32_t)keyc;
-            const bool keep = m3p_keep(idx, seed, thresh24);
-            pdrop = keep ? p * inv_keep : 0.f;
-            dpr = keep ? dpr * inv_keep : 0.f;
+          const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[r], kLog2e, -sL[q]));   // padded q: lse = +inf -> 0
+          if (DROP) {
+            float kfac;      // inv_keep if kept, else 0
+            if (MASK) {
+              kfac = __builtin_bit_cast(float, (uint32_t)__builtin_amdgcn_sbfe(kbits, r, 1) & inv_keep_bits);
+            } else {
+              const uint32_t idx = (uint32_t)((b * H + h) * S + min(q, S - 1)) * (uint32_t)S + (uint32_t)keyc;
+              kfac = m3p_keep(idx, seed, thresh24) ? inv_keep : 0.f;
+            }
+            pd2[hf][r] = p * kfac;
+            ds2[hf][r] = p * __builtin_fmaf(dp[r], kfac, dneg[r]);
+          } else {
+            pd2[hf][r] = p;
+            ds2[hf][r] = p * dp[r];
           }
-          pd2[hf][r] = pdrop;
-          ds2[hf][r] = p * (dpr - sD[q]);
         }
       }
       const bf16x8 pfrag = bf16x8{(bf16)pd2[0][0], (bf16)pd2[0][1], (bf16)pd2[0][2], (bf16)pd2[0][3],
@@ -346,6 +408,7 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
         dv[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dT, pfrag, dv[n], 0, 0, 0);
         dk[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qT, sfrag, dk[n], 0, 0, 0);
       }
+      if (NKC) __builtin_amdgcn_sched_barrier(0);   // unrolled steps stay in order: no register blow-up from hoisted loads
     }
     if (key < S) {
       bf16* pk = dKg + (size_t)key * ld + 4 * fg;
@@ -388,18 +451,24 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
     const int q = qb * 16 + fq;
     const int qc = min(q, S - 1);
     if (qb != wid) load_qd(qb);
-    const float lq = sL[q], dq_ = sD[q];
+    const float lq = sL[q], dq_ = sD[q];      // lse (log2 units) and D of this lane's query
     const uint32_t rbase = (uint32_t)((b * H + h) * S + qc) * (uint32_t)S;
     // dQ^T[d][q] = sum_key K[key][d] dS[q][key], streamed over 32-key steps
     f32x4 dq[Cf::NT];
 #pragma unroll
     for (int n = 0; n < Cf::NT; ++n) dq[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll(NKC ? NKC : 1)
     for (int kq = 0; kq < nk; ++kq) {
       f32x4 ds2[2];
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         const int t = 2 * kq + hf;
-        f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+        if (M3P_ATTN_SKIP_PAD && !MASK && t >= nt) {      // key tile beyond the sequence
+          ds2[hf] = f32x4{0.f, 0.f, 0.f, 0.f};
+          continue;
+        }
+        f32x4 sc = {0.f, 0.f, 0.f, 0.f};
+        f32x4 dp = DROP ? f32x4{0.f, 0.f, 0.f, 0.f} : f32x4{-dq_, -dq_, -dq_, -dq_};
 #pragma unroll
         for (int kk = 0; kk < Cf::KK; ++kk) {
           const bf16x8 kf = *reinterpret_cast<const bf16x8*>(s0 + t * 16 * Cf::ROWB + r_off[kk]);
@@ -407,13 +476,24 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
           sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], sc, 0, 0, 0);   // S^T[key][q]
           dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, df[kk], dp, 0, 0, 0);   // dPd^T[key][q]
         }
+        const unsigned long long* mw = MASK ? mbh + ((size_t)qb * nt + min(t, nt - 1)) * 4 : nullptr;   // wave-uniform
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int key = 16 * t + 4 * fg + r;
-          const float p = (key < klen) ? __expf(sc[r] - lq) : 0.f;
-          float dpr = dp[r];
-          if (thresh24) dpr = m3p_keep(rbase + (uint32_t)min(key, S - 1), seed, thresh24) ? dpr * inv_keep : 0.f;
-          ds2[hf][r] = p * (dpr - dq_);
+          float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[r], kLog2e, -lq));
+          p = (key < klen) ? p : 0.f;
+          if (DROP) {
+            float kfac;
+            if (MASK) {
+              // this lane's own bit of the forward ballot: the 64-bit word IS the select mask
+              asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(kfac) : "v"(inv_keep), "s"(mw[r]));
+            } else {
+              kfac = m3p_keep(rbase + (uint32_t)min(key, S - 1), seed, thresh24) ? inv_keep : 0.f;
+            }
+            ds2[hf][r] = p * __builtin_fmaf(dp[r], kfac, -dq_);
+          } else {
+            ds2[hf][r] = p * dp[r];
+          }
         }
       }
       const bf16x8 sfrag = bf16x8{(bf16)ds2[0][0], (bf16)ds2[0][1], (bf16)ds2[0][2], (bf16)ds2[0][3],
@@ -424,6 +504,7 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
         const bf16x8 kT = cat8(lds_tr16(pk), lds_tr16(pk + 16 * Cf::ROWB));
         dq[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kT, sfrag, dq[n], 0, 0, 0);
       }
+      if (NKC) __builtin_amdgcn_sched_barrier(0);
     }
     if (q < S) {
       bf16* pq = dQg + (size_t)q * ld + 4 * fg;
@@ -458,16 +539,16 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
 }
 
 template <int DH>
-int launch_fwd(const bf16* qkv, const int* keylen, bf16* ctx, float* lse, int B, int S, int H, int dmodel,
-               uint32_t seed, uint32_t thresh24, float inv_keep, hipStream_t st) {
+int launch_fwd(const bf16* qkv, const int* keylen, bf16* ctx, float* lse, unsigned long long* keepmask, int B, int S, int H,
+               int dmodel, uint32_t seed, uint32_t thresh24, float inv_keep, hipStream_t st) {
   const int nt = (S + 15) / 16, nk = (S + 31) / 32;
   const size_t lds = (size_t)(nt * 16 + nk * 32) * DH * 2;
 #define M3P_ATTN_FWD(KT)                                                                                        \
   do {                                                                                                          \
-    auto kern = attn_fwd_kernel<DH, KT>;                                                                        \
+    auto kern = thresh24 ? attn_fwd_kernel<DH, KT, true> : attn_fwd_kernel<DH, KT, false>;                                                                        \
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     if (e != hipSuccess) return (int)e;                                                                         \
-    hipLaunchKernelGGL(kern, dim3(B* H), dim3(256), lds, st, qkv, keylen, ctx, lse, S, H, dmodel, seed,         \
+    hipLaunchKernelGGL(kern, dim3(B* H), dim3(256), lds, st, qkv, keylen, ctx, lse, keepmask, S, H, dmodel, seed, \
                        thresh24, inv_keep);                                                                     \
   } while (0)
   if (nk <= 6) M3P_ATTN_FWD(6);
@@ -480,21 +561,24 @@ int launch_fwd(const bf16* qkv, const int* keylen, bf16* ctx, float* lse, int B,
 }
 
 template <int DH>
-int launch_bwd(const bf16* qkv, const int* keylen, const bf16* ctx, const bf16* dctx, const float* lse, bf16* dqkv,
-               float* dbias, int B, int S, int H, int dmodel, float qscale, uint32_t seed, uint32_t thresh24,
-               float inv_keep, hipStream_t st) {
+int launch_bwd(const bf16* qkv, const int* keylen, const bf16* ctx, const bf16* dctx, const float* lse,
+               const unsigned long long* keepmask, bf16* dqkv, float* dbias, int B, int S, int H, int dmodel, float qscale,
+               uint32_t seed, uint32_t thresh24, float inv_keep, hipStream_t st) {
   const int nk = (S + 31) / 32;
   const size_t lds = (size_t)2 * nk * 32 * DH * 2 + (size_t)2 * nk * 32 * sizeof(float) + 12 * DH * sizeof(float);
-#define M3P_ATTN_BWD(KT)                                                                                        \
+#define M3P_ATTN_BWD(KT, DROP, MASK)                                                                            \
   do {                                                                                                          \
-    auto kern = attn_bwd_kernel<DH, KT>;                                                                        \
+    auto kern = attn_bwd_kernel<DH, KT, DROP, MASK, 0>;                                                         \
+    if (nk == 6) kern = attn_bwd_kernel<DH, KT, DROP, MASK, 6>;                                                                  \
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     if (e != hipSuccess) return (int)e;                                                                         \
-    hipLaunchKernelGGL(kern, dim3(B* H), dim3(256), lds, st, qkv, keylen, ctx, dctx, lse, dqkv, dbias, S, H,    \
+    hipLaunchKernelGGL(kern, dim3(B* H), dim3(256), lds, st, qkv, keylen, ctx, dctx, lse, keepmask, dqkv, dbias, S, H, \
                        dmodel, qscale, seed, thresh24, inv_keep);                                               \
   } while (0)
-  if (nk <= 16) M3P_ATTN_BWD(16);
-  else return M3P_EINVAL;
+  if (nk > 16) return M3P_EINVAL;
+  if (!thresh24) M3P_ATTN_BWD(16, false, false);
+  else if (keepmask) M3P_ATTN_BWD(16, true, true);
+  else M3P_ATTN_BWD(16, true, false);
 #undef M3P_ATTN_BWD
   M3P_CHECK_LAUNCH();
   return M3P_OK;
@@ -504,29 +588,29 @@ int launch_bwd(const bf16* qkv, const int* keylen, const bf16* ctx, const bf16* 
 
 extern "C" {
 
-int m3p_attn_fwd(const void* qkv, const int32_t* keylen, void* ctx, float* lse, int B, int S, int H, int dh,
+int m3p_attn_fwd(const void* qkv, const int32_t* keylen, void* ctx, float* lse, uint64_t* keepmask, int B, int S, int H, int dh,
                  uint32_t seed, uint32_t thresh24, float inv_keep, void* stream) {
   if (B <= 0 || S <= 0 || H <= 0 || S > 512) return M3P_EINVAL;
   if (((uintptr_t)qkv & 15) || ((uintptr_t)ctx & 7)) return M3P_EINVAL;
   const int dmodel = H * dh;
   hipStream_t st = (hipStream_t)stream;
-  if (dh == 64) return launch_fwd<64>((const bf16*)qkv, keylen, (bf16*)ctx, lse, B, S, H, dmodel, seed, thresh24, inv_keep, st);
-  if (dh == 32) return launch_fwd<32>((const bf16*)qkv, keylen, (bf16*)ctx, lse, B, S, H, dmodel, seed, thresh24, inv_keep, st);
+  if (dh == 64) return launch_fwd<64>((const bf16*)qkv, keylen, (bf16*)ctx, lse, (unsigned long long*)keepmask, B, S, H, dmodel, seed, thresh24, inv_keep, st);
+  if (dh == 32) return launch_fwd<32>((const bf16*)qkv, keylen, (bf16*)ctx, lse, (unsigned long long*)keepmask, B, S, H, dmodel, seed, thresh24, inv_keep, st);
   return M3P_EINVAL;
 }
 
 int m3p_attn_bwd(const void* qkv, const int32_t* keylen, const void* ctx, const void* dctx, const float* lse,
-                 void* dqkv, float* dbias_qkv, int B, int S, int H, int dh, float qscale, uint32_t seed,
-                 uint32_t thresh24, float inv_keep, void* stream) {
+                 const uint64_t* keepmask, void* dqkv, float* dbias_qkv, int B, int S, int H, int dh, float qscale,
+                 uint32_t seed, uint32_t thresh24, float inv_keep, void* stream) {
   if (B <= 0 || S <= 0 || H <= 0 || S > 512) return M3P_EINVAL;
   if (((uintptr_t)qkv & 15) || ((uintptr_t)ctx & 15) || ((uintptr_t)dctx & 15) || ((uintptr_t)dqkv & 7)) return M3P_EINVAL;
   const int dmodel = H * dh;
   hipStream_t st = (hipStream_t)stream;
   if (dh == 64)
-    return launch_bwd<64>((const bf16*)qkv, keylen, (const bf16*)ctx, (const bf16*)dctx, lse, (bf16*)dqkv, dbias_qkv, B, S, H,
+    return launch_bwd<64>((const bf16*)qkv, keylen, (const bf16*)ctx, (const bf16*)dctx, lse, (const unsigned long long*)keepmask, (bf16*)dqkv, dbias_qkv, B, S, H,
                           dmodel, qscale, seed, thresh24, inv_keep, st);
   if (dh == 32)
-    return launch_bwd<32>((const bf16*)qkv, keylen, (const bf16*)ctx, (const bf16*)dctx, lse, (bf16*)dqkv, dbias_qkv, B, S, H,
+    return launch_bwd<32>((const bf16*)qkv, keylen, (const bf16*)ctx, (const bf16*)dctx, lse, (const unsigned long long*)keepmask, (bf16*)dqkv, dbias_qkv, B, S, H,
                           dmodel, qscale, seed, thresh24, inv_keep, st);
   return M3P_EINVAL;
 }

@@ -210,7 +210,9 @@ class EncoderFn(torch.autograd.Function):
         for i in range(nL):
             a, f = 'attentions.%d.' % i, 'ffns.%d.' % i
             qkv = ops.gemm_nt(h, ar.qkv_w16(i), L.EPI_BIAS, bias=ar.qkv_bias(i), scale_cols=d, scale=qscale)
-            ctxt, lse = ops.attn_fwd(qkv, totlen, B, S, H, dh, seed=seed('attn_p', i), p_drop=p_attn)
+            ctxt, lse, kmask = ops.attn_fwd(qkv, totlen, B, S, H, dh, seed=seed('attn_p', i), p_drop=p_attn,
+                                            want_mask=True)
+            lse = (lse, kmask)      # the dropout keep bits travel with the log-sum-exp to backward
             pre1 = ops.gemm_nt(ctxt, ar.w(a + 'out_lin.weight'), L.EPI_BIAS_DROP_RES, bias=ar.p(a + 'out_lin.bias'),
                                aux=h, seed=seed('attn_out', i), p_drop=p_drop)
             x1, mean1, rstd1 = ops.layernorm_fwd(pre1, ar.p('layer_norm1.%d.weight' % i), ar.p('layer_norm1.%d.bias' % i))
@@ -276,8 +278,8 @@ class EncoderFn(torch.autograd.Function):
                 dAO = dpre1
             ops.gemm_wgrad(dAO, ctxt, ar.g(a + 'out_lin.weight'))
             dctx = ops.gemm_nt(dAO, ar.wt[('out', i)], L.EPI_NONE)
-            dqkv = ops.attn_bwd(qkv, totlen, ctxt, dctx, lse, B, S, H, dh, dbias_qkv=ar.qkv_bias(i, grad=True),
-                                seed=seed('attn_p', i), p_drop=p_attn)
+            dqkv = ops.attn_bwd(qkv, totlen, ctxt, dctx, lse[0], B, S, H, dh, dbias_qkv=ar.qkv_bias(i, grad=True),
+                                seed=seed('attn_p', i), p_drop=p_attn, keepmask=lse[1])
             ops.gemm_wgrad(dqkv, h_in, ar.qkv_wgrad(i))
             dh_ = ops.gemm_nt(dqkv, ar.wt[('qkv', i)], L.EPI_RES, aux=dpre1)
             del dqkv, dctx, dAO, dpre1, dx1

@@ -131,24 +131,29 @@ def layernorm_bwd(dy_a, dy_b, x, gamma, mean, rstd, rowmask, dgamma, dbeta, dbia
     return dx, dx_drop
 
 
-def attn_fwd(qkv, keylen, B, S, H, dh, seed=0, p_drop=0.0):
-    """qkv bf16 [B*S, 3*H*dh] -> (ctx bf16 [B*S, H*dh], lse fp32 [B,H,S])."""
+def attn_fwd(qkv, keylen, B, S, H, dh, seed=0, p_drop=0.0, want_mask=False):
+    """qkv bf16 [B*S, 3*H*dh] -> (ctx bf16 [B*S, H*dh], lse fp32 [B,H,S]) and, with want_mask, the dropout
+    keep-bit words for attn_bwd (None when p_drop == 0)."""
     _chk_bf16(qkv)
     assert qkv.is_contiguous() and qkv.shape == (B * S, 3 * H * dh) and keylen.dtype == torch.int32
     ctx = torch.empty((B * S, H * dh), dtype=BF16, device=qkv.device)
     lse = torch.empty((B, H, S), dtype=torch.float32, device=qkv.device)
-    rc = L.load().m3p_attn_fwd(qkv.data_ptr(), keylen.data_ptr(), ctx.data_ptr(), lse.data_ptr(), B, S, H, dh,
+    mask = None
+    if want_mask and p_drop > 0:
+        nt = (S + 15) // 16
+        mask = torch.empty((B * H, nt, nt, 4), dtype=torch.int64, device=qkv.device)
+    rc = L.load().m3p_attn_fwd(qkv.data_ptr(), keylen.data_ptr(), ctx.data_ptr(), lse.data_ptr(), L.ptr(mask), B, S, H, dh,
                                seed, L.thresh24(p_drop), 1.0 / (1.0 - p_drop) if p_drop > 0 else 1.0, L.stream())
     L.check(rc, 'm3p_attn_fwd')
-    return ctx, lse
+    return (ctx, lse, mask) if want_mask else (ctx, lse)
 
 
-def attn_bwd(qkv, keylen, ctx, dctx, lse, B, S, H, dh, dbias_qkv=None, seed=0, p_drop=0.0):
+def attn_bwd(qkv, keylen, ctx, dctx, lse, B, S, H, dh, dbias_qkv=None, seed=0, p_drop=0.0, keepmask=None):
     _chk_bf16(qkv, ctx, dctx)
     assert dctx.is_contiguous() and ctx.is_contiguous()
     dqkv = torch.empty_like(qkv)
     rc = L.load().m3p_attn_bwd(qkv.data_ptr(), keylen.data_ptr(), ctx.data_ptr(), dctx.data_ptr(), lse.data_ptr(),
-                               dqkv.data_ptr(), L.ptr(dbias_qkv), B, S, H, dh, 1.0 / (dh ** 0.5), seed,
+                               L.ptr(keepmask), dqkv.data_ptr(), L.ptr(dbias_qkv), B, S, H, dh, 1.0 / (dh ** 0.5), seed,
                                L.thresh24(p_drop), 1.0 / (1.0 - p_drop) if p_drop > 0 else 1.0, L.stream())
     L.check(rc, 'm3p_attn_bwd')
     return dqkv

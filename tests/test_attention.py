@@ -50,6 +50,15 @@ def test_attention_fwd_bwd(B, S, H, dh, p):
     dctx, dctxc = randn_bf16((B * S, d), 7)
     dbias = torch.zeros(3 * d, device='cuda')
     dqkv = ops.attn_bwd(qkv, keylen.cuda(), ctx, dctx, lse, B, S, H, dh, dbias_qkv=dbias, seed=seed, p_drop=p)
+    if p > 0:
+        # same backward fed with the keep bits the forward pass recorded instead of re-hashing: bit-identical
+        ctx2, lse2, kmask = ops.attn_fwd(qkv, keylen.cuda(), B, S, H, dh, seed=seed, p_drop=p, want_mask=True)
+        assert torch.equal(ctx2, ctx) and torch.equal(lse2, lse)
+        dbias2 = torch.zeros(3 * d, device='cuda')
+        dqkv2 = ops.attn_bwd(qkv, keylen.cuda(), ctx, dctx, lse, B, S, H, dh, dbias_qkv=dbias2, seed=seed, p_drop=p,
+                             keepmask=kmask)
+        assert torch.equal(dqkv2, dqkv)
+        assert rel_l2(dbias2, dbias) < 1e-6
     ctx_ref.backward(dctxc)
     g = x.grad.clone()
     g[:, :d] *= 1.0 / math.sqrt(dh)       # kernel returns the gradient of the unscaled q projection

@@ -20,8 +20,10 @@ def t(fn, n=20):
     return e0.elapsed_time(e1) / n * 1000
 
 for p in (0.1, 0.0):
-    ctx, lse = ops.attn_fwd(qkv, keylen, B, S, H, dh, seed=5, p_drop=p)
+    ctx, lse, km = ops.attn_fwd(qkv, keylen, B, S, H, dh, seed=5, p_drop=p, want_mask=True)
     us_f = t(lambda: ops.attn_fwd(qkv, keylen, B, S, H, dh, seed=5, p_drop=p))
+    us_fm = t(lambda: ops.attn_fwd(qkv, keylen, B, S, H, dh, seed=5, p_drop=p, want_mask=True))
     us_b = t(lambda: ops.attn_bwd(qkv, keylen, ctx, dctx, lse, B, S, H, dh, dbias_qkv=dbias, seed=5, p_drop=p))
+    us_bm = t(lambda: ops.attn_bwd(qkv, keylen, ctx, dctx, lse, B, S, H, dh, dbias_qkv=dbias, seed=5, p_drop=p, keepmask=km))
     us_b0 = t(lambda: ops.attn_bwd(qkv, keylen, ctx, dctx, lse, B, S, H, dh, dbias_qkv=None, seed=5, p_drop=p))
-    print('p_drop=%.1f  fwd %.1f us   bwd %.1f us   bwd(no dbias) %.1f us' % (p, us_f, us_b, us_b0), flush=True)
+    print('p_drop=%.1f  fwd %.1f us (with mask out %.1f)   bwd %.1f us (mask in %.1f)   bwd(no dbias) %.1f us' % (p, us_f, us_fm, us_b, us_bm, us_b0), flush=True)
