@@ -970,19 +970,31 @@ void gemm_nt_w4_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
   auto set_load_tile = [&](int q) {
     int tm, tn;
     split_tile(tile_of(q), tm, tn);
+    // wave w stages rows [64w, 64w+64) of both operands into ONE contiguous 8-KB slice of the
+    // stage: [A rows, 4 KB | W rows, 4 KB].  The instruction's immediate offset moves the LDS
+    // destination together with the global source (probed: tools/probe_dma_offset.py), so all
+    // eight LDS-DMAs of a K-tile share one M0 (slice + 4096) and differ only in the immediate
+    // -4096..3072; the source pointers are pre-compensated by the same amount.  (Setting M0 per
+    // instruction cost s_add + s_nop ~ 16-24 issue clocks each on a wave that is alone on its SIMD.)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      a_src[i] = A + (size_t)min(tm * BM + (wid + 4 * i) * 16 + l_row, M - 1) * lda + l_col;
-      w_src[i] = W + (size_t)min(tn * BN + (wid + 4 * i) * 16 + l_row, N - 1) * ldw + l_col;
+      a_src[i] = A + (size_t)min(tm * BM + wid * 64 + i * 16 + l_row, M - 1) * lda + l_col - (-4096 + 1024 * i) / 2;
+      w_src[i] = W + (size_t)min(tn * BN + wid * 64 + i * 16 + l_row, N - 1) * ldw + l_col - (1024 * i) / 2;
     }
   };
   auto issue_load = [&](int s, int piece) {
-    char* sa = smem + s * STAGE;
-    const int k0 = l_kt * KT;
-    if (piece < 4)
-      __builtin_amdgcn_global_load_lds(GLB_PTR(a_src[piece] + k0), LDS_PTR(sa + (wid + 4 * piece) * 1024), 16, 0, 0);
-    else
-      __builtin_amdgcn_global_load_lds(GLB_PTR(w_src[piece - 4] + k0), LDS_PTR(sa + A_BYTES + (wid + 4 * (piece - 4)) * 1024), 16, 0, 0);
+    char* sl = smem + s * STAGE + wid * 8192 + 4096;
+    const int k0 = (ABL & 4) ? 0 : l_kt * KT;        // ABL 4: every K-tile re-reads the first one (cache-resident)
+    switch (piece) {
+      case 0: __builtin_amdgcn_global_load_lds(GLB_PTR(a_src[0] + k0), LDS_PTR(sl), 16, -4096, 0); break;
+      case 1: __builtin_amdgcn_global_load_lds(GLB_PTR(a_src[1] + k0), LDS_PTR(sl), 16, -3072, 0); break;
+      case 2: __builtin_amdgcn_global_load_lds(GLB_PTR(a_src[2] + k0), LDS_PTR(sl), 16, -2048, 0); break;
+      case 3: __builtin_amdgcn_global_load_lds(GLB_PTR(a_src[3] + k0), LDS_PTR(sl), 16, -1024, 0); break;
+      case 4: __builtin_amdgcn_global_load_lds(GLB_PTR(w_src[0] + k0), LDS_PTR(sl), 16, 0, 0); break;
+      case 5: __builtin_amdgcn_global_load_lds(GLB_PTR(w_src[1] + k0), LDS_PTR(sl), 16, 1024, 0); break;
+      case 6: __builtin_amdgcn_global_load_lds(GLB_PTR(w_src[2] + k0), LDS_PTR(sl), 16, 2048, 0); break;
+      default: __builtin_amdgcn_global_load_lds(GLB_PTR(w_src[3] + k0), LDS_PTR(sl), 16, 3072, 0); break;
+    }
   };
   auto load_done = [&]() {
     if (++l_kt == nk) { l_kt = 0; ++l_q; if (l_q < my_tiles) set_load_tile(l_q); }
@@ -993,8 +1005,9 @@ void gemm_nt_w4_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
   const int fr = lane & 15, fg = lane >> 4;
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const uint32_t f_sw = (uint32_t)(((((fr & 1) << 2) | fg) ^ (fr >> 1)) * 16);
-  const uint32_t a_base = lds0 + (wm * 64 + (fr >> 1)) * 128 + f_sw;
-  const uint32_t b_base = lds0 + A_BYTES + (wn * 64 + (fr >> 1)) * 128 + f_sw;
+  // rows 128 wm + 16 i + fr of A live in slices 2 wm + (i >> 2): fragment i at (i >> 2) * 8192 + (i & 3) * 1024
+  const uint32_t a_base = lds0 + (2 * wm) * 8192 + (fr >> 1) * 128 + f_sw;
+  const uint32_t b_base = lds0 + (2 * wn) * 8192 + 4096 + (fr >> 1) * 128 + f_sw;
 #define W4_DSR(dst, addr, off) do { if (!(ABL & 1)) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr)); } while (0)
 #define W4_LGKM0() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 
@@ -1044,13 +1057,13 @@ void gemm_nt_w4_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
     W4_M(0, 5);
     W4_M(0, 6); W4_DSR(fwn[3], rb, 3072);
     W4_M(0, 7);
-    W4_M(1, 0); W4_DSR(fwn[4], rb, 4096);
+    W4_M(1, 0); W4_DSR(fwn[4], rb, 8192);
     W4_M(1, 1);
-    W4_M(1, 2); W4_DSR(fwn[5], rb, 5120);
+    W4_M(1, 2); W4_DSR(fwn[5], rb, 9216);
     W4_M(1, 3);
-    W4_M(1, 4); W4_DSR(fwn[6], rb, 6144);
+    W4_M(1, 4); W4_DSR(fwn[6], rb, 10240);
     W4_M(1, 5);
-    W4_M(1, 6); W4_DSR(fwn[7], rb, 7168);
+    W4_M(1, 6); W4_DSR(fwn[7], rb, 11264);
     W4_M(1, 7);
     W4_M(2, 0); W4_DSR(fan[0], ra, 0);
     W4_M(2, 1);
@@ -1060,13 +1073,13 @@ void gemm_nt_w4_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
     W4_M(2, 5);
     W4_M(2, 6); W4_DSR(fan[3], ra, 3072);
     W4_M(2, 7);
-    W4_M(3, 0); W4_DSR(fan[4], ra, 4096);
+    W4_M(3, 0); W4_DSR(fan[4], ra, 8192);
     W4_M(3, 1);
-    W4_M(3, 2); W4_DSR(fan[5], ra, 5120);
+    W4_M(3, 2); W4_DSR(fan[5], ra, 9216);
     W4_M(3, 3);
-    W4_M(3, 4); W4_DSR(fan[6], ra, 6144);
+    W4_M(3, 4); W4_DSR(fan[6], ra, 10240);
     W4_M(3, 5);
-    W4_M(3, 6); W4_DSR(fan[7], ra, 7168);
+    W4_M(3, 6); W4_DSR(fan[7], ra, 11264);
     W4_M(3, 7);
     W4_M(4, 0); W4_L(0);
     W4_M(4, 1);
@@ -1132,9 +1145,9 @@ void gemm_nt_w4_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
   asm volatile("" ::: "memory");
   bf16x8 fa0[8], fw0[8], fa1[8], fw1[8];
   W4_DSR(fw0[0], b_base, 0); W4_DSR(fw0[1], b_base, 1024); W4_DSR(fw0[2], b_base, 2048); W4_DSR(fw0[3], b_base, 3072);
-  W4_DSR(fw0[4], b_base, 4096); W4_DSR(fw0[5], b_base, 5120); W4_DSR(fw0[6], b_base, 6144); W4_DSR(fw0[7], b_base, 7168);
+  W4_DSR(fw0[4], b_base, 8192); W4_DSR(fw0[5], b_base, 9216); W4_DSR(fw0[6], b_base, 10240); W4_DSR(fw0[7], b_base, 11264);
   W4_DSR(fa0[0], a_base, 0); W4_DSR(fa0[1], a_base, 1024); W4_DSR(fa0[2], a_base, 2048); W4_DSR(fa0[3], a_base, 3072);
-  W4_DSR(fa0[4], a_base, 4096); W4_DSR(fa0[5], a_base, 5120); W4_DSR(fa0[6], a_base, 6144); W4_DSR(fa0[7], a_base, 7168);
+  W4_DSR(fa0[4], a_base, 8192); W4_DSR(fa0[5], a_base, 9216); W4_DSR(fa0[6], a_base, 10240); W4_DSR(fa0[7], a_base, 11264);
   W4_LGKM0();
   W4_PUBLISH();      // K-tile 1 visible; stage 0 fully read by every wave
 
@@ -1914,6 +1927,7 @@ __attribute__((visibility("default"))) int m3p_debug_gemm_timeline(const void* A
     if (g_ablate == 1) k4 = gemm_nt_w4_kernel<M3P_EPI_NONE, true, 1>;
     if (g_ablate == 2) k4 = gemm_nt_w4_kernel<M3P_EPI_NONE, true, 2>;
     if (g_ablate == 3) k4 = gemm_nt_w4_kernel<M3P_EPI_NONE, true, 3>;
+    if (g_ablate == 4) k4 = gemm_nt_w4_kernel<M3P_EPI_NONE, true, 4>;
     hipFuncSetAttribute((const void*)k4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
     hipLaunchKernelGGL(k4, dim3(num_cus()), dim3(256), lds4, (hipStream_t)stream, (const bf16*)A, lda, (const bf16*)W, ldw,
                        (bf16*)C, ldc, M, N, K, ep, tm, tn, 0, dbg);

@@ -167,3 +167,92 @@ extern "C" __attribute__((visibility("default"))) int m3p_debug_probe_issue(int 
 #undef LAUNCH
   return (int)hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------------
+// Semantics probe (debug export): does the immediate offset of global_load_lds_dwordx4 move
+// the LDS destination as well as the global source?  One wave loads 1 KB from src + 2048
+// with offset:1024 into an 8-KB zeroed LDS window whose M0 base is window + 512; the whole
+// window is copied out so the host can see where the KB landed.
+// ---------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(64) void probe_dma_offset_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) uint32_t win[2048];
+  const int lane = threadIdx.x;
+  for (int i = lane; i < 2048; i += 64) win[i] = 0xdeadbeefu;
+  __syncthreads();
+  const uint32_t lds_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)win + 512;
+  const uint32_t* p = src + 512 + lane * 4;     // byte address src + 2048 + lane*16
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off offset:1024\n\ts_waitcnt vmcnt(0)"
+               :: "v"(p), "s"(lds_addr) : "memory");
+  __syncthreads();
+  for (int i = lane; i < 2048; i += 64) out[i] = win[i];
+}
+}  // namespace
+
+extern "C" __attribute__((visibility("default"))) int m3p_debug_probe_dma_offset(const void* src, void* out, void* stream) {
+  hipLaunchKernelGGL(probe_dma_offset_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const uint32_t*)src, (uint32_t*)out);
+  return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------
+// Ingest probe (debug export): how many bytes per clock can one CU pull out of L2?  Every
+// workgroup (4 waves) streams `rounds` x 32 KB; the 32 workgroups of an XCD walk the same
+// 2-MB window (L2-resident).  mode 0: global_load_lds 16 B/lane, 128-B row segments (a wave
+// instruction = 8 rows x 128 B with a row pitch of 6 KB); mode 1: same with 64-B row segments
+// (16 rows x 64 B); mode 2: global_load_dwordx4 into VGPRs, 128-B segments; mode 3: mode 0 but
+// fully contiguous 1 KB per instruction.
+// ---------------------------------------------------------------------------------
+namespace {
+template <int MODE>
+__global__ __launch_bounds__(256) void probe_ingest_kernel(const char* __restrict__ src, unsigned long long* __restrict__ out,
+                                                           int rounds) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int xcd = blockIdx.x & 7;
+  const char* base = src + (size_t)xcd * (2u << 20);
+  constexpr int PITCH = 6144;
+  uint4 sink = {0, 0, 0, 0};
+  __syncthreads();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int r = 0; r < rounds; ++r) {
+    // 32 KB per round per workgroup = 8 instructions per wave
+    const int win = ((r * 37 + (blockIdx.x >> 3) * 5) & 63) * 32768;        // 64 windows of 32 KB inside the 2 MB
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int q = wid * 8 + i;        // instruction index 0..31 inside the round
+      const char* p;
+      if (MODE == 0 || MODE == 2) p = base + ((win / PITCH) * PITCH + (size_t)(q * 8 + (lane >> 3)) * PITCH + (lane & 7) * 16) % (2u << 20);
+      else if (MODE == 1) p = base + ((win / PITCH) * PITCH + (size_t)(q * 16 + (lane >> 2)) * PITCH + (lane & 3) * 16) % (2u << 20);
+      else p = base + win + q * 1024 + lane * 16;
+      if (MODE == 2) {
+        uint4 v;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(v) : "v"(p) : "memory");   // result never read: issue + return only
+      } else {
+        __builtin_amdgcn_global_load_lds(GLB_PTR(p), LDS_PTR(smem + (r & 3) * 32768 + q * 1024), 16, 0, 0);
+      }
+    }
+    if (r >= 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  if (lane == 0) out[blockIdx.x * 4 + wid] = t1 - t0 + sink.x;
+}
+}  // namespace
+
+extern "C" __attribute__((visibility("default"))) int m3p_debug_probe_ingest(int mode, const void* src, unsigned long long* out,
+                                                                             int rounds, int nblocks, void* stream) {
+  const size_t lds = 4 * 32768;
+#define LAUNCH(MODE)                                                                                                   \
+  do {                                                                                                                 \
+    hipFuncSetAttribute((const void*)probe_ingest_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL(probe_ingest_kernel<MODE>, dim3(nblocks), dim3(256), lds, (hipStream_t)stream, (const char*)src, out, rounds); \
+  } while (0)
+  switch (mode) {
+    case 0: LAUNCH(0); break;
+    case 1: LAUNCH(1); break;
+    case 2: LAUNCH(2); break;
+    default: LAUNCH(3); break;
+  }
+#undef LAUNCH
+  return (int)hipGetLastError();
+}
