@@ -904,35 +904,46 @@ void gemm_nt_streamk_kernel(const bf16* __restrict__ A, int lda, const bf16* __r
 #undef M3P_LGKM0
 }
 
+// W4-BEGIN (generated by tools/gen/gen_w4.py from tools/gen/w4_template.hip - edit those)
 // ---------------------------------------------------------------------------------
 // NT kernel, "w4" version: 256x256 output tile, FOUR waves (one per SIMD), each wave owns a
 // 128x128 sub-tile = 8x8 MFMA tiles (256 accumulator registers of the 512 a lone wave has).
 // Why: with 64x64 per wave (ring kernel above) every 32-deep k-step makes a wave read
 // (64+64) rows x 64 B from LDS for 16 MFMAs; eight waves then pull 128 KB of LDS reads per
 // 64-deep K-tile = 1024 clocks at the LDS's 128 B/clk - exactly the 1030 clocks the MFMAs
-// of that K-tile need, before the 48 KB of LDS-DMA writes are even counted.  The ring
-// kernel is LDS-bandwidth bound (measured 2057 clk per K-tile).  128x128 per wave halves
-// LDS bytes per FLOP, 256x256 halves HBM/L2 -> LDS bytes per FLOP:
-//     per 32-deep K-tile: 64 KB of fragment reads + 32 KB DMA writes vs 1024 MFMA clocks.
-// Pipeline: K-tiles are 32 deep (64-B rows, two rows per 128-B LDS line, XOR swizzle over
-// the 8 16-B slots of a line), FOUR 32-KB stages; iteration j computes K-tile j from
-// registers, reads the fragments of K-tile j+1 from LDS between its MFMAs (one ds_read_b128
-// per 4 MFMAs) and issues the LDS-DMAs of K-tile j+4 into the stage K-tile j occupied (read
-// during iteration j-1).  A K-tile therefore has three iterations (~3000 clk) to arrive;
-// one s_barrier per iteration.  The epilogue runs from a private 4.5-KB staging area per
-// wave, so the stream of loads never stops at output-tile boundaries.
+// of that K-tile need, before the 48 KB of LDS-DMA writes are even counted: the ring kernel
+// is LDS-bandwidth bound (measured 2057 clk per K-tile).  128x128 per wave halves LDS bytes
+// per FLOP, 256x256 halves L2 -> LDS bytes per FLOP (64 KB per 2048 MFMA clocks = 32 B/clk/CU).
+// K-tiles are 64 deep with full 128-B rows: the first version of this kernel staged 32-deep
+// tiles (64-B row segments) and stalled on L2 ingest - tools/probe_ingest.py measures
+// 33 B/clk/CU for LDS-DMA with 64-B segments against 64 B/clk/CU with 128-B segments.
+// Pipeline (two 64-KB stages, one s_barrier per 128 MFMAs):
+//   phase 1 of K-tile j: 64 MFMAs on k-step 0 (registers) | ds_read k-step 1 of tile j
+//                        | the last LDS-DMAs of tile j+1
+//   mid:  lgkmcnt(0), vmcnt -> tile j+1 has landed, s_barrier (everyone is done with stage j)
+//   phase 2: 64 MFMAs on k-step 1 | ds_read k-step 0 of tile j+1 | first LDS-DMAs of tile j+2
+//            into stage j
+// The 16 LDS-DMAs of a K-tile are spread over phase 2 and the start of the next phase 1: issued
+// back to back in phase 2 alone they ask the texture path for its full 64 B/clk and the issuing
+// waves (alone on their SIMDs, nothing else to run) stall on the queue.  Memory instructions
+// themselves are free in the shadow of an MFMA (tools/probe_issue2.py: +1 clock per 8 MFMAs).
+// One M0 per operand and K-tile: LDS destinations are selected by the immediate offset, which
+// moves source and destination together (tools/probe_dma_offset.py).
+// The epilogue runs from a private 4.5-KB staging area per wave; the loads of the next
+// output tile are already in flight under it.
 // ---------------------------------------------------------------------------------
 template <int EPI, bool TL = false, int ABL = 0>
 __global__ __launch_bounds__(256)
 void gemm_nt_w4_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ W, int ldw,
                        bf16* __restrict__ C, int ldc, int M, int N, int K, M3PEpilogue ep,
                        int tiles_m, int tiles_n, int m_fast, unsigned long long* __restrict__ dbg = nullptr) {
-  // TL: debug instantiation that accumulates s_memtime per pipeline segment (tools/gemm_timeline.py)
+  // TL: debug instantiation that accumulates s_memtime per pipeline segment (tools/gemm_timeline.py);
+  // ABL (TL only): bit 0 = no fragment reads, bit 1 = no LDS-DMA, bit 2 = every K-tile re-reads the first
   unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tl0 = TL ? __builtin_amdgcn_s_memtime() : 0, tl1;
 #define W4_TSEG(k) do { if (TL) { tl1 = __builtin_amdgcn_s_memtime(); tacc[k] += tl1 - tl0; tl0 = tl1; } } while (0)
-  constexpr int BM = 256, BN = 256, KT = 32, NST = 4;
-  constexpr int A_BYTES = BM * KT * 2, STAGE = (BM + BN) * KT * 2;     // 16 KB, 32 KB
+  constexpr int BM = 256, BN = 256, KT = 64;
+  constexpr int A_BYTES = BM * KT * 2, STAGE = (BM + BN) * KT * 2;     // 32 KB, 64 KB
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -957,57 +968,56 @@ void gemm_nt_w4_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
   const int nk = K / KT;
   const int total = my_tiles * nk;
 
-  // ---- load cursor.  One LDS-DMA instruction = 1 KB = 8 LDS lines = 16 tile rows; lane l
-  // fills slot (l & 7) of line (l >> 3), which must hold 16-B chunk c8 = slot ^ (line & 7),
-  // i.e. row 2*line + (c8 >> 2), k-chunk c8 & 3.
-  const int l_line = lane >> 3;
-  const int l_c8 = (lane & 7) ^ l_line;
-  const int l_row = 2 * l_line + (l_c8 >> 2);
-  const int l_col = (l_c8 & 3) * 8;
-  const bf16* a_src[4];
-  const bf16* w_src[4];
+  // ---- load cursor.  One LDS-DMA instruction = 1 KB = 8 tile rows of 128 B; lane l fills slot
+  // (l & 7) of row (l >> 3), which must hold 16-B chunk slot ^ (row & 7).  Wave w stages rows
+  // [64w, 64w + 64) of each operand = one contiguous 8-KB slice per operand: M0 = slice + 4096,
+  // the eight instructions differ only in the immediate -4096..3072 (sources pre-compensated:
+  // the +2048 elements in the base pointers and the -512 per row group undo the immediates).
+  const int l_row = lane >> 3;
+  const int l_col = ((lane & 7) ^ l_row) * 8;
+  // (only full tiles come here - the launcher sends ragged shapes to the ring kernel - so the
+  //  eight row groups of a slice are a uniform stride apart and two pointers are enough)
+  const bf16* a_src0;
+  const bf16* w_src0;
+  const long a_step = 8 * (long)lda - 512, w_step = 8 * (long)ldw - 512;     // next row group, next immediate
   int l_q = 0, l_kt = 0;
   auto set_load_tile = [&](int q) {
     int tm, tn;
     split_tile(tile_of(q), tm, tn);
-    // wave w stages rows [64w, 64w+64) of both operands into ONE contiguous 8-KB slice of the
-    // stage: [A rows, 4 KB | W rows, 4 KB].  The instruction's immediate offset moves the LDS
-    // destination together with the global source (probed: tools/probe_dma_offset.py), so all
-    // eight LDS-DMAs of a K-tile share one M0 (slice + 4096) and differ only in the immediate
-    // -4096..3072; the source pointers are pre-compensated by the same amount.  (Setting M0 per
-    // instruction cost s_add + s_nop ~ 16-24 issue clocks each on a wave that is alone on its SIMD.)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      a_src[i] = A + (size_t)min(tm * BM + wid * 64 + i * 16 + l_row, M - 1) * lda + l_col - (-4096 + 1024 * i) / 2;
-      w_src[i] = W + (size_t)min(tn * BN + wid * 64 + i * 16 + l_row, N - 1) * ldw + l_col - (1024 * i) / 2;
-    }
+    a_src0 = A + (size_t)(tm * BM + wid * 64 + l_row) * lda + l_col + 2048;
+    w_src0 = W + (size_t)(tn * BN + wid * 64 + l_row) * ldw + l_col + 2048;
   };
+#define W4_LD1(PTR, IMM) __builtin_amdgcn_global_load_lds(GLB_PTR(PTR), LDS_PTR(sl), 16, IMM, 0)
   auto issue_load = [&](int s, int piece) {
-    char* sl = smem + s * STAGE + wid * 8192 + 4096;
-    const int k0 = (ABL & 4) ? 0 : l_kt * KT;        // ABL 4: every K-tile re-reads the first one (cache-resident)
-    switch (piece) {
-      case 0: __builtin_amdgcn_global_load_lds(GLB_PTR(a_src[0] + k0), LDS_PTR(sl), 16, -4096, 0); break;
-      case 1: __builtin_amdgcn_global_load_lds(GLB_PTR(a_src[1] + k0), LDS_PTR(sl), 16, -3072, 0); break;
-      case 2: __builtin_amdgcn_global_load_lds(GLB_PTR(a_src[2] + k0), LDS_PTR(sl), 16, -2048, 0); break;
-      case 3: __builtin_amdgcn_global_load_lds(GLB_PTR(a_src[3] + k0), LDS_PTR(sl), 16, -1024, 0); break;
-      case 4: __builtin_amdgcn_global_load_lds(GLB_PTR(w_src[0] + k0), LDS_PTR(sl), 16, 0, 0); break;
-      case 5: __builtin_amdgcn_global_load_lds(GLB_PTR(w_src[1] + k0), LDS_PTR(sl), 16, 1024, 0); break;
-      case 6: __builtin_amdgcn_global_load_lds(GLB_PTR(w_src[2] + k0), LDS_PTR(sl), 16, 2048, 0); break;
-      default: __builtin_amdgcn_global_load_lds(GLB_PTR(w_src[3] + k0), LDS_PTR(sl), 16, 3072, 0); break;
+    const int k0 = (ABL & 4) ? 0 : l_kt * KT;
+    char* sl = smem + s * STAGE + (piece < 8 ? 0 : A_BYTES) + wid * 8192 + 4096;
+    const bf16* src = (piece < 8) ? a_src0 + (k0 + (piece & 7) * a_step) : w_src0 + (k0 + (piece & 7) * w_step);
+    switch (piece & 7) {
+      case 0: W4_LD1(src, -4096); break;
+      case 1: W4_LD1(src, -3072); break;
+      case 2: W4_LD1(src, -2048); break;
+      case 3: W4_LD1(src, -1024); break;
+      case 4: W4_LD1(src, 0); break;
+      case 5: W4_LD1(src, 1024); break;
+      case 6: W4_LD1(src, 2048); break;
+      default: W4_LD1(src, 3072); break;
     }
   };
   auto load_done = [&]() {
     if (++l_kt == nk) { l_kt = 0; ++l_q; if (l_q < my_tiles) set_load_tile(l_q); }
   };
 
-  // ---- fragment addressing
+  // ---- fragment addressing (as in the ring kernel: 128-B rows, chunk ^= row & 7)
   const int wm = wid >> 1, wn = wid & 1;
   const int fr = lane & 15, fg = lane >> 4;
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-  const uint32_t f_sw = (uint32_t)(((((fr & 1) << 2) | fg) ^ (fr >> 1)) * 16);
-  // rows 128 wm + 16 i + fr of A live in slices 2 wm + (i >> 2): fragment i at (i >> 2) * 8192 + (i & 3) * 1024
-  const uint32_t a_base = lds0 + (2 * wm) * 8192 + (fr >> 1) * 128 + f_sw;
-  const uint32_t b_base = lds0 + (2 * wn) * 8192 + 4096 + (fr >> 1) * 128 + f_sw;
+  uint32_t a_addr[2], b_addr[2];      // per k-step; fragment i at + i * 2048, stage at + s * STAGE
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int ch = ((fg + 4 * ks) ^ (fr & 7)) * 16;
+    a_addr[ks] = lds0 + (wm * 128 + fr) * 128 + ch;
+    b_addr[ks] = lds0 + A_BYTES + (wn * 128 + fr) * 128 + ch;
+  }
 #define W4_DSR(dst, addr, off) do { if (!(ABL & 1)) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr)); } while (0)
 #define W4_LGKM0() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 
@@ -1019,155 +1029,199 @@ void gemm_nt_w4_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
   // ASMSTART/ASMEND); the empty asm below makes the kernel descriptor reserve all 256.
   asm volatile("" ::: "a0", "a255");
 #define W4_ACC(I, J) "a[((" #I ")*8+(" #J "))*4:((" #I ")*8+(" #J "))*4+3]"
-#define W4_MFMA4(I, J0)                                                              \
-  asm volatile("v_mfma_f32_16x16x32_bf16 " W4_ACC(I, J0) ", %1, %0, " W4_ACC(I, J0) "\n\t"           \
-               "v_mfma_f32_16x16x32_bf16 " W4_ACC(I, J0 + 1) ", %2, %0, " W4_ACC(I, J0 + 1) "\n\t"   \
-               "v_mfma_f32_16x16x32_bf16 " W4_ACC(I, J0 + 2) ", %3, %0, " W4_ACC(I, J0 + 2) "\n\t"   \
-               "v_mfma_f32_16x16x32_bf16 " W4_ACC(I, J0 + 3) ", %4, %0, " W4_ACC(I, J0 + 3)          \
-               :: "v"(fac[I]), "v"(fwc[J0]), "v"(fwc[J0 + 1]), "v"(fwc[J0 + 2]), "v"(fwc[J0 + 3]))
-#define W4_MFMA4_FIRST(I, J0)                                                        \
-  asm volatile("v_mfma_f32_16x16x32_bf16 " W4_ACC(I, J0) ", %1, %0, 0\n\t"           \
-               "v_mfma_f32_16x16x32_bf16 " W4_ACC(I, J0 + 1) ", %2, %0, 0\n\t"       \
-               "v_mfma_f32_16x16x32_bf16 " W4_ACC(I, J0 + 2) ", %3, %0, 0\n\t"       \
-               "v_mfma_f32_16x16x32_bf16 " W4_ACC(I, J0 + 3) ", %4, %0, 0"           \
-               :: "v"(fac[I]), "v"(fwc[J0]), "v"(fwc[J0 + 1]), "v"(fwc[J0 + 2]), "v"(fwc[J0 + 3]))
-  // one iteration: 16 groups of {1 fragment read of the NEXT K-tile, (every other group) one
-  // LDS-DMA of K-tile +4, 4 MFMAs of the current K-tile}
-  // One iteration = 64 MFMAs (16 clocks each in the matrix pipe) with the 16 fragment reads of
-  // the next K-tile and the 8 LDS-DMAs of K-tile +4 slotted in singly: this wave is alone on
-  // its SIMD, so whatever it issues between two MFMAs must fit in the 16-clock shadow of the
-  // previous one (measured with 2 reads + 1 DMA per 4 MFMAs: 1448 clocks per iteration
-  // instead of 1024 - a 1-KB LDS/DMA instruction takes 8-16 clocks to issue).
-  // (loads past the end of this workgroup's stream are still issued - from the last valid
-  //  K-tile, into a stage nobody reads again - so the loop body has a single shape and the
-  //  counted vmcnt stays a constant)
-#define W4_M(I, J) do { if (FIRST) asm volatile("v_mfma_f32_16x16x32_bf16 " W4_ACC(I, J) ", %1, %0, 0" :: "v"(fac[I]), "v"(fwc[J])); \
-                        else asm volatile("v_mfma_f32_16x16x32_bf16 " W4_ACC(I, J) ", %1, %0, " W4_ACC(I, J) :: "v"(fac[I]), "v"(fwc[J])); } while (0)
-#define W4_L(PIECE) do { if (!(ABL & 2)) issue_load(s_load, PIECE); __builtin_amdgcn_sched_barrier(0); } while (0)
-  auto body = [&](auto first_c, const bf16x8 (&fac)[8], const bf16x8 (&fwc)[8], bf16x8 (&fan)[8], bf16x8 (&fwn)[8],
-                  int s_load, int s_next) {
-    constexpr bool FIRST = decltype(first_c)::value;   // first K-tile of an output tile: C operand = 0
-    const uint32_t ra = a_base + s_next * STAGE, rb = b_base + s_next * STAGE;
-    __builtin_amdgcn_sched_barrier(0);
-    W4_M(0, 0); W4_DSR(fwn[0], rb, 0);
-    W4_M(0, 1);
-    W4_M(0, 2); W4_DSR(fwn[1], rb, 1024);
-    W4_M(0, 3);
-    W4_M(0, 4); W4_DSR(fwn[2], rb, 2048);
-    W4_M(0, 5);
-    W4_M(0, 6); W4_DSR(fwn[3], rb, 3072);
-    W4_M(0, 7);
-    W4_M(1, 0); W4_DSR(fwn[4], rb, 8192);
-    W4_M(1, 1);
-    W4_M(1, 2); W4_DSR(fwn[5], rb, 9216);
-    W4_M(1, 3);
-    W4_M(1, 4); W4_DSR(fwn[6], rb, 10240);
-    W4_M(1, 5);
-    W4_M(1, 6); W4_DSR(fwn[7], rb, 11264);
-    W4_M(1, 7);
-    W4_M(2, 0); W4_DSR(fan[0], ra, 0);
-    W4_M(2, 1);
-    W4_M(2, 2); W4_DSR(fan[1], ra, 1024);
-    W4_M(2, 3);
-    W4_M(2, 4); W4_DSR(fan[2], ra, 2048);
-    W4_M(2, 5);
-    W4_M(2, 6); W4_DSR(fan[3], ra, 3072);
-    W4_M(2, 7);
-    W4_M(3, 0); W4_DSR(fan[4], ra, 8192);
-    W4_M(3, 1);
-    W4_M(3, 2); W4_DSR(fan[5], ra, 9216);
-    W4_M(3, 3);
-    W4_M(3, 4); W4_DSR(fan[6], ra, 10240);
-    W4_M(3, 5);
-    W4_M(3, 6); W4_DSR(fan[7], ra, 11264);
-    W4_M(3, 7);
-    W4_M(4, 0); W4_L(0);
-    W4_M(4, 1);
-    W4_M(4, 2);
-    W4_M(4, 3);
-    W4_M(4, 4); W4_L(1);
-    W4_M(4, 5);
-    W4_M(4, 6);
-    W4_M(4, 7);
-    W4_M(5, 0); W4_L(2);
-    W4_M(5, 1);
-    W4_M(5, 2);
-    W4_M(5, 3);
-    W4_M(5, 4); W4_L(3);
-    W4_M(5, 5);
-    W4_M(5, 6);
-    W4_M(5, 7);
-    W4_M(6, 0); W4_L(4);
-    W4_M(6, 1);
-    W4_M(6, 2);
-    W4_M(6, 3);
-    W4_M(6, 4); W4_L(5);
-    W4_M(6, 5);
-    W4_M(6, 6);
-    W4_M(6, 7);
-    W4_M(7, 0); W4_L(6);
-    W4_M(7, 1);
-    W4_M(7, 2);
-    W4_M(7, 3);
-    W4_M(7, 4); W4_L(7);
-    W4_M(7, 5);
-    W4_M(7, 6);
-    W4_M(7, 7);
-    __builtin_amdgcn_sched_barrier(0);
-    load_done();
-    W4_TSEG(0);
-    W4_LGKM0();
-    W4_TSEG(1);
-  };
-  // vmcnt retires in order and counts stores too.  Right after an epilogue the 32 C-tile stores
-  // of this wave are YOUNGER than the K-tiles in flight; waiting with the plain count would
-  // drain the whole prefetch queue (and the stores) at every output tile.  For the three
-  // publishes that follow a fast-path epilogue the count is raised by those 32 stores (a
-  // lower bound on the memory instructions the epilogue issued, so never too lax).
-  int post_ep = 0;
-#define W4_PUBLISH() do {                                                     \
-    if (post_ep > 0) { --post_ep; asm volatile("s_waitcnt vmcnt(48)" ::: "memory"); } \
-    else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");                    \
-    W4_TSEG(2);                                                               \
-    __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");              \
-    W4_TSEG(3); } while (0)
+#define W4_M(FA, FW, I, J) do { if (FIRST) asm volatile("v_mfma_f32_16x16x32_bf16 " W4_ACC(I, J) ", %1, %0, 0" :: "v"(FA[I]), "v"(FW[J])); \
+                                else asm volatile("v_mfma_f32_16x16x32_bf16 " W4_ACC(I, J) ", %1, %0, " W4_ACC(I, J) :: "v"(FA[I]), "v"(FW[J])); } while (0)
+#define W4_L(PIECE) do { if (!(ABL & 2)) issue_load(s_cur, PIECE); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define W4_LP(PIECE) do { if (!(ABL & 2) && pend) issue_load(s_cur ^ 1, PIECE); __builtin_amdgcn_sched_barrier(0); } while (0)
 
-  // ---- prologue: K-tiles 0..3 into stages 0..3
+  bf16x8 fa0[8], fw0[8], fa1[8], fw1[8];
+  // phase 1: k-step 0 of the current K-tile from registers; fetch its k-step 1 fragments; finish
+  // the LDS-DMA list phase 2 of the previous iteration started (`pend`)
+  auto phase1 = [&](auto first_c, int s_cur, bool pend) {
+    constexpr bool FIRST = decltype(first_c)::value;   // first K-tile of an output tile: C operand = 0
+    const uint32_t ra1 = a_addr[1] + s_cur * STAGE, rb1 = b_addr[1] + s_cur * STAGE;
+    __builtin_amdgcn_sched_barrier(0);
+    W4_M(fa0, fw0, 0, 0);
+    W4_M(fa0, fw0, 0, 1); W4_DSR(fw1[0], rb1, 0);
+    W4_M(fa0, fw0, 0, 2); W4_LP(11);
+    W4_M(fa0, fw0, 0, 3); W4_DSR(fw1[1], rb1, 2048);
+    W4_M(fa0, fw0, 0, 4);
+    W4_M(fa0, fw0, 0, 5); W4_DSR(fw1[2], rb1, 4096);
+    W4_M(fa0, fw0, 0, 6); W4_LP(12);
+    W4_M(fa0, fw0, 0, 7); W4_DSR(fw1[3], rb1, 6144);
+    W4_M(fa0, fw0, 1, 0);
+    W4_M(fa0, fw0, 1, 1); W4_DSR(fw1[4], rb1, 8192);
+    W4_M(fa0, fw0, 1, 2); W4_LP(13);
+    W4_M(fa0, fw0, 1, 3); W4_DSR(fw1[5], rb1, 10240);
+    W4_M(fa0, fw0, 1, 4);
+    W4_M(fa0, fw0, 1, 5); W4_DSR(fw1[6], rb1, 12288);
+    W4_M(fa0, fw0, 1, 6); W4_LP(14);
+    W4_M(fa0, fw0, 1, 7); W4_DSR(fw1[7], rb1, 14336);
+    W4_M(fa0, fw0, 2, 0);
+    W4_M(fa0, fw0, 2, 1); W4_DSR(fa1[0], ra1, 0);
+    W4_M(fa0, fw0, 2, 2); W4_LP(15);
+    W4_M(fa0, fw0, 2, 3); W4_DSR(fa1[1], ra1, 2048);
+    W4_M(fa0, fw0, 2, 4);
+    W4_M(fa0, fw0, 2, 5); W4_DSR(fa1[2], ra1, 4096);
+    W4_M(fa0, fw0, 2, 6);
+    W4_M(fa0, fw0, 2, 7); W4_DSR(fa1[3], ra1, 6144);
+    W4_M(fa0, fw0, 3, 0);
+    W4_M(fa0, fw0, 3, 1); W4_DSR(fa1[4], ra1, 8192);
+    W4_M(fa0, fw0, 3, 2);
+    W4_M(fa0, fw0, 3, 3); W4_DSR(fa1[5], ra1, 10240);
+    W4_M(fa0, fw0, 3, 4);
+    W4_M(fa0, fw0, 3, 5); W4_DSR(fa1[6], ra1, 12288);
+    W4_M(fa0, fw0, 3, 6);
+    W4_M(fa0, fw0, 3, 7); W4_DSR(fa1[7], ra1, 14336);
+    W4_M(fa0, fw0, 4, 0);
+    W4_M(fa0, fw0, 4, 1);
+    W4_M(fa0, fw0, 4, 2);
+    W4_M(fa0, fw0, 4, 3);
+    W4_M(fa0, fw0, 4, 4);
+    W4_M(fa0, fw0, 4, 5);
+    W4_M(fa0, fw0, 4, 6);
+    W4_M(fa0, fw0, 4, 7);
+    W4_M(fa0, fw0, 5, 0);
+    W4_M(fa0, fw0, 5, 1);
+    W4_M(fa0, fw0, 5, 2);
+    W4_M(fa0, fw0, 5, 3);
+    W4_M(fa0, fw0, 5, 4);
+    W4_M(fa0, fw0, 5, 5);
+    W4_M(fa0, fw0, 5, 6);
+    W4_M(fa0, fw0, 5, 7);
+    W4_M(fa0, fw0, 6, 0);
+    W4_M(fa0, fw0, 6, 1);
+    W4_M(fa0, fw0, 6, 2);
+    W4_M(fa0, fw0, 6, 3);
+    W4_M(fa0, fw0, 6, 4);
+    W4_M(fa0, fw0, 6, 5);
+    W4_M(fa0, fw0, 6, 6);
+    W4_M(fa0, fw0, 6, 7);
+    W4_M(fa0, fw0, 7, 0);
+    W4_M(fa0, fw0, 7, 1);
+    W4_M(fa0, fw0, 7, 2);
+    W4_M(fa0, fw0, 7, 3);
+    W4_M(fa0, fw0, 7, 4);
+    W4_M(fa0, fw0, 7, 5);
+    W4_M(fa0, fw0, 7, 6);
+    W4_M(fa0, fw0, 7, 7);
+    __builtin_amdgcn_sched_barrier(0);
+    if (pend) load_done();
+  };
+  // phase 2: k-step 1; the stage just vacated by everyone (barrier) starts receiving K-tile +2,
+  // and k-step 0 of the next K-tile comes out of the other stage
+  auto phase2 = [&](int s_cur) {
+    constexpr bool FIRST = false;
+    const uint32_t ra0n = a_addr[0] + (s_cur ^ 1) * STAGE, rb0n = b_addr[0] + (s_cur ^ 1) * STAGE;
+    __builtin_amdgcn_sched_barrier(0);
+    W4_M(fa1, fw1, 0, 0); W4_L(0);
+    W4_M(fa1, fw1, 0, 1); W4_DSR(fw0[0], rb0n, 0);
+    W4_M(fa1, fw1, 0, 2);
+    W4_M(fa1, fw1, 0, 3); W4_DSR(fw0[1], rb0n, 2048);
+    W4_M(fa1, fw1, 0, 4);
+    W4_M(fa1, fw1, 0, 5); W4_DSR(fw0[2], rb0n, 4096);
+    W4_M(fa1, fw1, 0, 6); W4_L(1);
+    W4_M(fa1, fw1, 0, 7); W4_DSR(fw0[3], rb0n, 6144);
+    W4_M(fa1, fw1, 1, 0);
+    W4_M(fa1, fw1, 1, 1); W4_DSR(fw0[4], rb0n, 8192);
+    W4_M(fa1, fw1, 1, 2);
+    W4_M(fa1, fw1, 1, 3); W4_DSR(fw0[5], rb0n, 10240);
+    W4_M(fa1, fw1, 1, 4); W4_L(2);
+    W4_M(fa1, fw1, 1, 5); W4_DSR(fw0[6], rb0n, 12288);
+    W4_M(fa1, fw1, 1, 6);
+    W4_M(fa1, fw1, 1, 7); W4_DSR(fw0[7], rb0n, 14336);
+    W4_M(fa1, fw1, 2, 0);
+    W4_M(fa1, fw1, 2, 1); W4_DSR(fa0[0], ra0n, 0);
+    W4_M(fa1, fw1, 2, 2); W4_L(3);
+    W4_M(fa1, fw1, 2, 3); W4_DSR(fa0[1], ra0n, 2048);
+    W4_M(fa1, fw1, 2, 4);
+    W4_M(fa1, fw1, 2, 5); W4_DSR(fa0[2], ra0n, 4096);
+    W4_M(fa1, fw1, 2, 6);
+    W4_M(fa1, fw1, 2, 7); W4_DSR(fa0[3], ra0n, 6144);
+    W4_M(fa1, fw1, 3, 0); W4_L(4);
+    W4_M(fa1, fw1, 3, 1); W4_DSR(fa0[4], ra0n, 8192);
+    W4_M(fa1, fw1, 3, 2);
+    W4_M(fa1, fw1, 3, 3); W4_DSR(fa0[5], ra0n, 10240);
+    W4_M(fa1, fw1, 3, 4);
+    W4_M(fa1, fw1, 3, 5); W4_DSR(fa0[6], ra0n, 12288);
+    W4_M(fa1, fw1, 3, 6); W4_L(5);
+    W4_M(fa1, fw1, 3, 7); W4_DSR(fa0[7], ra0n, 14336);
+    W4_M(fa1, fw1, 4, 0);
+    W4_M(fa1, fw1, 4, 1);
+    W4_M(fa1, fw1, 4, 2);
+    W4_M(fa1, fw1, 4, 3);
+    W4_M(fa1, fw1, 4, 4); W4_L(6);
+    W4_M(fa1, fw1, 4, 5);
+    W4_M(fa1, fw1, 4, 6);
+    W4_M(fa1, fw1, 4, 7);
+    W4_M(fa1, fw1, 5, 0);
+    W4_M(fa1, fw1, 5, 1);
+    W4_M(fa1, fw1, 5, 2); W4_L(7);
+    W4_M(fa1, fw1, 5, 3);
+    W4_M(fa1, fw1, 5, 4);
+    W4_M(fa1, fw1, 5, 5);
+    W4_M(fa1, fw1, 5, 6);
+    W4_M(fa1, fw1, 5, 7);
+    W4_M(fa1, fw1, 6, 0); W4_L(8);
+    W4_M(fa1, fw1, 6, 1);
+    W4_M(fa1, fw1, 6, 2);
+    W4_M(fa1, fw1, 6, 3);
+    W4_M(fa1, fw1, 6, 4);
+    W4_M(fa1, fw1, 6, 5);
+    W4_M(fa1, fw1, 6, 6); W4_L(9);
+    W4_M(fa1, fw1, 6, 7);
+    W4_M(fa1, fw1, 7, 0);
+    W4_M(fa1, fw1, 7, 1);
+    W4_M(fa1, fw1, 7, 2);
+    W4_M(fa1, fw1, 7, 3);
+    W4_M(fa1, fw1, 7, 4);
+    W4_M(fa1, fw1, 7, 5);
+    W4_M(fa1, fw1, 7, 6); W4_L(10);
+    W4_M(fa1, fw1, 7, 7);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // ---- prologue: K-tiles 0 and 1 into stages 0 and 1
   set_load_tile(0);
 #pragma unroll
-  for (int t = 0; t < NST; ++t) {
+  for (int t = 0; t < 2; ++t) {
 #pragma unroll
-    for (int pc = 0; pc < 8; ++pc) issue_load(t, pc);
+    for (int pc = 0; pc < 16; ++pc) issue_load(t, pc);
     load_done();
   }
-  asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-  bf16x8 fa0[8], fw0[8], fa1[8], fw1[8];
-  W4_DSR(fw0[0], b_base, 0); W4_DSR(fw0[1], b_base, 1024); W4_DSR(fw0[2], b_base, 2048); W4_DSR(fw0[3], b_base, 3072);
-  W4_DSR(fw0[4], b_base, 8192); W4_DSR(fw0[5], b_base, 9216); W4_DSR(fw0[6], b_base, 10240); W4_DSR(fw0[7], b_base, 11264);
-  W4_DSR(fa0[0], a_base, 0); W4_DSR(fa0[1], a_base, 1024); W4_DSR(fa0[2], a_base, 2048); W4_DSR(fa0[3], a_base, 3072);
-  W4_DSR(fa0[4], a_base, 8192); W4_DSR(fa0[5], a_base, 9216); W4_DSR(fa0[6], a_base, 10240); W4_DSR(fa0[7], a_base, 11264);
+  W4_DSR(fw0[0], b_addr[0], 0); W4_DSR(fw0[1], b_addr[0], 2048); W4_DSR(fw0[2], b_addr[0], 4096); W4_DSR(fw0[3], b_addr[0], 6144);
+  W4_DSR(fw0[4], b_addr[0], 8192); W4_DSR(fw0[5], b_addr[0], 10240); W4_DSR(fw0[6], b_addr[0], 12288); W4_DSR(fw0[7], b_addr[0], 14336);
+  W4_DSR(fa0[0], a_addr[0], 0); W4_DSR(fa0[1], a_addr[0], 2048); W4_DSR(fa0[2], a_addr[0], 4096); W4_DSR(fa0[3], a_addr[0], 6144);
+  W4_DSR(fa0[4], a_addr[0], 8192); W4_DSR(fa0[5], a_addr[0], 10240); W4_DSR(fa0[6], a_addr[0], 12288); W4_DSR(fa0[7], a_addr[0], 14336);
   W4_LGKM0();
-  W4_PUBLISH();      // K-tile 1 visible; stage 0 fully read by every wave
 
   int c_q = 0, c_kt = 0;
   const bool io_aligned = ((ldc & 7) == 0) && (((uintptr_t)C & 15) == 0) &&
                           (!(EPI == M3P_EPI_BIAS_GELU) || (((ep.ld_out2 & 7) == 0) && (((uintptr_t)ep.out2 & 15) == 0))) &&
                           (!ep.bias || (((uintptr_t)ep.bias & 15) == 0));
-  char* r1 = smem + NST * STAGE + wid * EP_HALF;
-  // nk is even (K % 64 == 0): output tiles start on even and end on odd K-tiles
-  for (int step = 0; step < total; step += 2) {
-    const int s0 = step & 3;
-    if (c_kt == 0) body(std::true_type{}, fa0, fw0, fa1, fw1, s0, s0 + 1);
-    else body(std::false_type{}, fa0, fw0, fa1, fw1, s0, s0 + 1);
-    W4_PUBLISH();
-    body(std::false_type{}, fa1, fw1, fa0, fw0, s0 + 1, (s0 + 2) & 3);
-    c_kt += 2;
-    W4_TSEG(5);
-    if (c_kt == nk) {
-      // ---- epilogue of output tile c_q out of the wave-private staging area; the K-tile
-      // stream (three tiles ahead) keeps landing meanwhile
+  char* r1 = smem + 2 * STAGE + wid * EP_HALF;
+  for (int step = 0; step < total; ++step) {
+    const int s_cur = step & 1;
+    if (c_kt == 0) phase1(std::true_type{}, s_cur, step > 0);
+    else phase1(std::false_type{}, s_cur, step > 0);
+    W4_TSEG(0);
+    W4_LGKM0();
+    W4_TSEG(1);
+    // everything this wave has in flight is K-tile step+1 (and older epilogue stores)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    W4_TSEG(2);
+    __builtin_amdgcn_s_barrier();      // K-tile step+1 visible to all; stage s_cur fully read by all
+    asm volatile("" ::: "memory");
+    W4_TSEG(3);
+    phase2(s_cur);
+    W4_TSEG(0);
+    W4_LGKM0();
+    W4_TSEG(1);
+    if (++c_kt == nk) {
+      // ---- epilogue of output tile c_q out of the wave-private staging area
       c_kt = 0;
       // the compiler's hazard recogniser does not see the asm MFMAs: the wait for the last
       // accumulator write before v_accvgpr_read is ours
@@ -1178,7 +1232,6 @@ void gemm_nt_w4_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
       const int m0 = tm * BM, n0 = tn * BN;
       const int mw = m0 + wm * 128, nw = n0 + wn * 128;
       const bool fast = io_aligned && (m0 + BM <= M) && (n0 + BN <= N);
-      post_ep = fast ? 3 : 0;
       f32x4 csum[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) csum[j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1187,10 +1240,10 @@ void gemm_nt_w4_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
         const int ch = p >> 2, rg = p & 3;        // column half outer: the bias-gradient sums run over rows
         f32x4 rows[2][4];
 #define W4_RD(II, JJ, I, J)                                                         \
-  asm volatile("v_accvgpr_read_b32 %0, a[((" #I ")*8+(" #J "))*4+0]\n\t"                \
-               "v_accvgpr_read_b32 %1, a[((" #I ")*8+(" #J "))*4+1]\n\t"                \
-               "v_accvgpr_read_b32 %2, a[((" #I ")*8+(" #J "))*4+2]\n\t"                \
-               "v_accvgpr_read_b32 %3, a[((" #I ")*8+(" #J "))*4+3]"                    \
+  asm volatile("v_accvgpr_read_b32 %0, a[((" #I ")*8+(" #J "))*4+0]\n\t"            \
+               "v_accvgpr_read_b32 %1, a[((" #I ")*8+(" #J "))*4+1]\n\t"            \
+               "v_accvgpr_read_b32 %2, a[((" #I ")*8+(" #J "))*4+2]\n\t"            \
+               "v_accvgpr_read_b32 %3, a[((" #I ")*8+(" #J "))*4+3]"                \
                : "=v"(t0), "=v"(t1), "=v"(t2), "=v"(t3));                           \
   rows[II][JJ] = f32x4{t0, t1, t2, t3}
 #define W4_SLICE(RG, CH)                                                                      \
@@ -1236,9 +1289,8 @@ void gemm_nt_w4_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
           for (int j = 0; j < 4; ++j) csum[j] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
       }
+      W4_TSEG(4);
     }
-    W4_TSEG(4);
-    W4_PUBLISH();
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // junk loads of the tail must not outlive the LDS allocation
   if (TL) {
@@ -1247,16 +1299,16 @@ void gemm_nt_w4_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
       for (int k = 0; k < 8; ++k) dbg[((size_t)blockIdx.x * 8 + wid) * 8 + k] = tacc[k];
   }
 #undef W4_TSEG
-#undef W4_PUBLISH
+#undef W4_LD1
 #undef W4_ACC
-#undef W4_MFMA4_FIRST
 #undef W4_DSR
 #undef W4_LGKM0
-#undef W4_MFMA4
 #undef W4_M
 #undef W4_L
+#undef W4_LP
 }
 
+// W4-END
 static int num_cus() {
   static int n = 0;
   if (n == 0) {
@@ -1273,13 +1325,15 @@ static int num_cus() {
 template <int EPI>
 int launch_nt(const bf16* A, int lda, const bf16* W, int ldw, bf16* C, int ldc, int M, int N, int K,
               const M3PEpilogue& ep, hipStream_t st) {
-  // deep contractions go to the 4-wave 256x256 kernel (measured on M=41984: K=3072,N=768 +5 %;
-  // K=768 shapes are equal or a little slower there, they stay on the 8-wave ring kernel)
-  const bool deep = (K >= 1536) && (N >= 512);
-  if (M >= 1024 && (g_variant == 2 || (g_variant == 1 && deep)) && (K % 64) == 0 && (lda % 8) == 0 && (ldw % 8) == 0) {
+  // full-tile shapes go to the 4-wave 256x256 kernel (measured on M=41984 against the 8-wave ring
+  // kernel: K=3072,N=768 1000 vs 855 TF; N=3072,K=768 910 vs 815; 768x768 980 vs 925); ragged
+  // shapes and the vocabulary projection's m-fast order stay on the ring kernel
+  const bool deep = (N >= 512) && (2LL * N * K <= (64LL << 20)) && EPI != M3P_EPI_DGELU;   // (dGELU epilogue: 240 VGPRs there, measured slower in the step)
+  if (M >= 1024 && (g_variant == 2 || (g_variant == 1 && deep)) && (K % 64) == 0 && (lda % 8) == 0 && (ldw % 8) == 0 &&
+      (M % 256) == 0 && (N % 256) == 0) {
     constexpr int BM = 256, BN = 256;
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
-    const size_t lds = 4 * (BM + BN) * 64 + 4 * EP_HALF;
+    const size_t lds = 2 * (BM + BN) * 128 + 4 * EP_HALF;
     auto kern = gemm_nt_w4_kernel<EPI, false>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -1922,7 +1976,7 @@ __attribute__((visibility("default"))) int m3p_debug_gemm_timeline(const void* A
   M3PEpilogue ep = {};
   if (g_variant == 2) {
     const int tm = (M + 255) / 256, tn = (N + 255) / 256;
-    const size_t lds4 = 4 * 512 * 64 + 4 * EP_HALF;
+    const size_t lds4 = 2 * 512 * 128 + 4 * EP_HALF;
     auto k4 = gemm_nt_w4_kernel<M3P_EPI_NONE, true, 0>;
     if (g_ablate == 1) k4 = gemm_nt_w4_kernel<M3P_EPI_NONE, true, 1>;
     if (g_ablate == 2) k4 = gemm_nt_w4_kernel<M3P_EPI_NONE, true, 2>;

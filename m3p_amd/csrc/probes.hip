@@ -81,6 +81,8 @@ __global__ __launch_bounds__(256) void probe_issue_kernel(const bf16* __restrict
   __attribute__((ext_vector_type(4))) uint32_t rsrc;
   rsrc[0] = (uint32_t)(uintptr_t)src; rsrc[1] = (uint32_t)((uintptr_t)src >> 32); rsrc[2] = 0x7fffffff; rsrc[3] = 0x00020000;
   const uint32_t voff = (uint32_t)((((size_t)blockIdx.x * 4 + wid) * 4096 + lane * 8) * 2);
+  typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+  u32x4 wdata = {(uint32_t)lane, 1u, 2u, 3u};
   uint32_t dummy = lane, d1 = lane, d2 = lane, d3 = lane;
   const uint32_t inv_addr = lds_addr + lane * 16;
   if (MODE == 7) asm volatile("s_mov_b32 m0, %0" :: "s"(lds_addr));
@@ -97,9 +99,16 @@ __global__ __launch_bounds__(256) void probe_issue_kernel(const bf16* __restrict
       asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
                    :: "v"(voff + sub * 2), "s"(src), "s"(lds_addr + (it & 3) * 1024) : "memory");
     } else if (MODE == 3) {
-      uint4 v;
+      u32x4 v;
       asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(v) : "v"(p + sub) : "memory");
-      if ((it & 7) == 7) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); gsink.x ^= v.x; }
+      if ((it & 7) == 7) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+    } else if (MODE == 16) {
+      asm volatile("ds_write_b128 %0, %1" :: "v"(inv_addr), "v"(wdata) : "memory");
+      if ((it & 7) == 7) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+    } else if (MODE == 17) {
+      u32x4 v;
+      asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(v) : "v"(voff + sub * 2), "s"(src) : "memory");
+      if ((it & 7) == 7) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
     } else if (MODE == 4) {
       asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
                    :: "v"(voff + sub * 2), "s"(rsrc), "s"(lds_addr + (it & 3) * 1024) : "memory");
@@ -132,7 +141,7 @@ __global__ __launch_bounds__(256) void probe_issue_kernel(const bf16* __restrict
     } else if (MODE == 15) {
       asm volatile("v_mul_hi_u32 %0, %0, %4\n\tv_mul_hi_u32 %1, %1, %4\n\tv_mul_hi_u32 %2, %2, %4\n\tv_mul_hi_u32 %3, %3, %4" : "+v"(dummy), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(0x9E3779B1u));
     }
-    if ((MODE == 1 || MODE == 2 || MODE == 4 || MODE == 7) && (it & 7) == 7) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if ((MODE == 1 || MODE == 2 || MODE == 4 || MODE == 7) && (it & 7) == 7) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -162,7 +171,9 @@ extern "C" __attribute__((visibility("default"))) int m3p_debug_probe_issue(int 
     case 12: LAUNCH(12); break;
     case 13: LAUNCH(13); break;
     case 14: LAUNCH(14); break;
-    default: LAUNCH(15); break;
+    case 15: LAUNCH(15); break;
+    case 16: LAUNCH(16); break;
+    default: LAUNCH(17); break;
   }
 #undef LAUNCH
   return (int)hipGetLastError();
@@ -225,7 +236,8 @@ __global__ __launch_bounds__(256) void probe_ingest_kernel(const char* __restric
       else if (MODE == 1) p = base + ((win / PITCH) * PITCH + (size_t)(q * 16 + (lane >> 2)) * PITCH + (lane & 3) * 16) % (2u << 20);
       else p = base + win + q * 1024 + lane * 16;
       if (MODE == 2) {
-        uint4 v;
+        typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+        u32x4 v;
         asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(v) : "v"(p) : "memory");   // result never read: issue + return only
       } else {
         __builtin_amdgcn_global_load_lds(GLB_PTR(p), LDS_PTR(smem + (r & 3) * 32768 + q * 1024), 16, 0, 0);
@@ -252,6 +264,75 @@ extern "C" __attribute__((visibility("default"))) int m3p_debug_probe_ingest(int
     case 1: LAUNCH(1); break;
     case 2: LAUNCH(2); break;
     default: LAUNCH(3); break;
+  }
+#undef LAUNCH
+  return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------
+// Cleaner issue-cost probe: 8 unrolled rounds of {8 MFMAs, one memory instruction} per loop
+// trip, waits only once per trip with generous counts (no latency exposure, no per-round
+// branch).  mode 0 none, 1 LDS-DMA (invariant M0, vaddr64 invariant), 2 global_load_dwordx4
+// saddr + voff (invariant), 3 ds_read_b128, 4 ds_write_b128, 5 global_load vaddr64 invariant,
+// 6 LDS-DMA with per-round v_lshl_add_u64 address update.
+// ---------------------------------------------------------------------------------
+namespace {
+typedef __attribute__((ext_vector_type(4))) uint32_t pu32x4;
+template <int MODE>
+__global__ __launch_bounds__(256) void probe_issue2_kernel(const bf16* __restrict__ src, unsigned long long* __restrict__ out,
+                                                           int trips) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const bf16* p = src + ((size_t)blockIdx.x * 4 + wid) * 4096 + lane * 8;
+  const uint32_t lds_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem + wid * 8192;
+  const uint32_t inv_addr = lds_addr + lane * 16;
+  const uint32_t voff = (uint32_t)((((size_t)blockIdx.x * 4 + wid) * 4096 + lane * 8) * 2);
+  bf16x8 fa, fb;
+  for (int i = 0; i < 8; ++i) { fa[i] = (bf16)1.0f; fb[i] = (bf16)0.5f; }
+  f32x4 acc[8];
+  for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  pu32x4 wdata = {(uint32_t)lane, 1u, 2u, 3u};
+  asm volatile("s_mov_b32 m0, %0" :: "s"(lds_addr));
+  const bf16* pp = p;
+  __syncthreads();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < trips; ++it) {
+#pragma unroll
+    for (int rd = 0; rd < 8; ++rd) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[k]) : "v"(fa), "v"(fb));
+      if (MODE == 1) asm volatile("global_load_lds_dwordx4 %0, off" :: "v"(p) : "memory");
+      else if (MODE == 2) { pu32x4 v; asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(v) : "v"(voff), "s"(src) : "memory"); }
+      else if (MODE == 3) { bf16x8 r; asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(inv_addr)); }
+      else if (MODE == 4) asm volatile("ds_write_b128 %0, %1" :: "v"(inv_addr), "v"(wdata) : "memory");
+      else if (MODE == 5) { pu32x4 v; asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(v) : "v"(p) : "memory"); }
+      else if (MODE == 6) {
+        asm volatile("v_lshl_add_u64 %0, %0, 0, %1\n\tglobal_load_lds_dwordx4 %0, off" : "+v"(pp) : "s"((unsigned long long)((rd & 1) ? 1024 : -1024)) : "memory");
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(32) lgkmcnt(8)" ::: "memory");
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  float s = 0.f;
+  for (int i = 0; i < 8; ++i) s += acc[i][0];
+  if (lane == 0) { out[(blockIdx.x * 4 + wid) * 2] = t1 - t0; out[(blockIdx.x * 4 + wid) * 2 + 1] = (unsigned long long)s; }
+}
+}  // namespace
+
+extern "C" __attribute__((visibility("default"))) int m3p_debug_probe_issue2(int mode, const void* src, unsigned long long* out,
+                                                                             int trips, int nblocks, void* stream) {
+  const size_t lds = 4 * 8192;
+#define LAUNCH(MODE) hipLaunchKernelGGL(probe_issue2_kernel<MODE>, dim3(nblocks), dim3(256), lds, (hipStream_t)stream, (const bf16*)src, out, trips)
+  switch (mode) {
+    case 0: LAUNCH(0); break;
+    case 1: LAUNCH(1); break;
+    case 2: LAUNCH(2); break;
+    case 3: LAUNCH(3); break;
+    case 4: LAUNCH(4); break;
+    case 5: LAUNCH(5); break;
+    default: LAUNCH(6); break;
   }
 #undef LAUNCH
   return (int)hipGetLastError();

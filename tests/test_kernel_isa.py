@@ -1,0 +1,41 @@
+"""Build-time invariants of the generated ISA (no GPU needed: hipcc cross-compiles gfx950).
+
+The four-wave GEMM keeps its 256 accumulators in AGPRs through inline asm with literal register
+numbers.  That is only sound while the compiler itself never touches an AGPR (spill-to-AGPR) or
+scratch in that kernel; this test disassembles every instantiation and checks exactly that."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = '/opt/rocm/bin/hipcc'
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason='hipcc not installed')
+def test_w4_gemm_accumulators_are_ours(tmp_path):
+    out = tmp_path / 'gemm.s'
+    cmd = [HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-munsafe-fp-atomics', '-ffp-contract=fast',
+           '-Wno-unused-result', '--cuda-device-only', '-S', os.path.join(ROOT, 'm3p_amd', 'csrc', 'gemm.hip'), '-o', str(out)]
+    subprocess.run(cmd, check=True, capture_output=True, timeout=600)
+    text = out.read_text().splitlines()
+    starts = [i for i, l in enumerate(text) if re.match(r'^_ZN\S*gemm_nt_w4_kernelILi\dELb0ELi0E\S*:', l)]
+    assert len(starts) == 6, 'expected the six epilogue instantiations of the production kernel'
+    for st in starts:
+        name = text[st].split(':')[0]
+        in_asm, bad, n_mfma = False, [], 0
+        for l in text[st + 1:]:
+            if l.startswith('\t.amdhsa_kernel') or l.startswith('.Lfunc_end'):
+                break
+            if 'ASMSTART' in l:
+                in_asm = True
+            elif 'ASMEND' in l:
+                in_asm = False
+            elif in_asm and 'v_mfma' in l:
+                n_mfma += 1
+            elif not in_asm and ('v_accvgpr' in l or 'scratch_' in l):
+                bad.append(l.strip())
+        assert not bad, '%s: compiler-generated AGPR / scratch traffic: %s' % (name, bad[:3])
+        assert n_mfma >= 3 * 64, name     # phase 1 (first / accumulate) + phase 2

@@ -12,8 +12,8 @@ nb = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 iters = 2048
 src = torch.randn(nb * 4 * 4096 + 65536, device='cuda').to(torch.bfloat16)
 out = torch.zeros(nb * 4 * 2, dtype=torch.int64, device='cuda')
-names = ['none', 'global_load_lds vaddr64', 'global_load_lds saddr+voff32', 'global_load_dwordx4 -> vgpr', 'buffer_load_dwordx4 lds', 'ds_read_b128', '1 valu', 'glds invariant addr+m0', 'ds_read invariant addr', 's_mov m0 + s_nop', '4 valu', '4 v_mul_lo_u32', '4 v_mul_u32_u24', '4 v_exp_f32', '4 v_mad_u32_u24', '4 v_mul_hi_u32']
-modes = [int(x) for x in sys.argv[2].split(',')] if len(sys.argv) > 2 else range(16)
+names = ['none', 'global_load_lds vaddr64', 'global_load_lds saddr+voff32', 'global_load_dwordx4 -> vgpr', 'buffer_load_dwordx4 lds', 'ds_read_b128', '1 valu', 'glds invariant addr+m0', 'ds_read invariant addr', 's_mov m0 + s_nop', '4 valu', '4 v_mul_lo_u32', '4 v_mul_u32_u24', '4 v_exp_f32', '4 v_mad_u32_u24', '4 v_mul_hi_u32', 'ds_write_b128', 'global_load_dwordx4 saddr+voff -> vgpr']
+modes = [int(x) for x in sys.argv[2].split(',')] if len(sys.argv) > 2 else range(18)
 for mode in modes:
     for _ in range(2):
         rc = f(mode, src.data_ptr(), out.data_ptr(), iters, nb, L.stream())
