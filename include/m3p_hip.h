@@ -46,7 +46,8 @@ enum {
   M3P_EPI_BIAS_GELU = 2,     /* u = acc + bias -> out2 (bf16); C = gelu_erf(u)           */
   M3P_EPI_BIAS_DROP_RES = 3, /* C = dropout(acc + bias) + aux                            */
   M3P_EPI_RES = 4,           /* C = alpha*acc + aux                                      */
-  M3P_EPI_DGELU = 5          /* C = acc * gelu_erf'(aux); colsum[n] += sum_m C (optional) */
+  M3P_EPI_DGELU = 5,         /* C = acc * gelu_erf'(aux); colsum[n] += sum_m C (optional) */
+  M3P_EPI_MUL = 6            /* C = acc * aux;            colsum[n] += sum_m C (optional) */
 };
 
 typedef struct M3PEpilogue {
@@ -218,8 +219,10 @@ M3P_API int m3p_adam_step(float* p, float* g, float* m, float* v, void* w16, lon
                           float max_norm, float grad_scale, int zero_grad, void* stream);
 
 /* h = gelu_erf(u) elementwise (transformer.py:56 applied to the lin1 output :223-224), bf16,
- * n % 8 == 0.  Used instead of M3P_EPI_BIAS_GELU when the GEMM is persistent. */
-M3P_API int m3p_gelu_fwd(const void* u, void* h, long long n, void* stream);
+ * n % 8 == 0.  Used instead of M3P_EPI_BIAS_GELU when the GEMM is persistent.
+ * dh (nullable, may alias u): also writes gelu_erf'(u) in bf16, which the backward FFN dgrad
+ * then applies with M3P_EPI_MUL instead of recomputing the derivative in the GEMM epilogue. */
+M3P_API int m3p_gelu_fwd(const void* u, void* h, void* dh, long long n, void* stream);
 
 /* Batched form of m3p_transpose_bf16: desc = n_desc x {src ptr, dst ptr, rows, cols, ld_src,
  * ld_dst} as int64 in device memory; max_tiles >= max over matrices of ceil(rows/64)*ceil(cols/64). */

@@ -68,7 +68,7 @@ __device__ __forceinline__ void epilogue_store(const M3PEpilogue& ep, bf16* __re
       for (int r = 0; r < 4; ++r) v[r] = m3p_keep(base + r, ep.seed, ep.thresh24) ? v[r] * ep.inv_keep : 0.f;
     }
   }
-  if (EPI == M3P_EPI_BIAS_DROP_RES || EPI == M3P_EPI_RES || EPI == M3P_EPI_DGELU) {
+  if (EPI == M3P_EPI_BIAS_DROP_RES || EPI == M3P_EPI_RES || EPI == M3P_EPI_DGELU || EPI == M3P_EPI_MUL) {
     const bf16* X = reinterpret_cast<const bf16*>(ep.aux) + (size_t)m * ep.ld_aux + n;
     float a[4] = {0.f, 0.f, 0.f, 0.f};
     if (full) { bf16x4 t = *reinterpret_cast<const bf16x4*>(X); a[0] = (float)t[0]; a[1] = (float)t[1]; a[2] = (float)t[2]; a[3] = (float)t[3]; }
@@ -77,6 +77,9 @@ __device__ __forceinline__ void epilogue_store(const M3PEpilogue& ep, bf16* __re
     if (EPI == M3P_EPI_DGELU) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_grad_f(a[r]);
+    } else if (EPI == M3P_EPI_MUL) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] *= a[r];
     } else {
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] += a[r];
@@ -89,7 +92,7 @@ __device__ __forceinline__ void epilogue_store(const M3PEpilogue& ep, bf16* __re
   if (full) *reinterpret_cast<bf16x4*>(Cp) = bf16x4{o[0], o[1], o[2], o[3]};
   else
     for (int r = 0; r < 4; ++r) if (n + r < N) Cp[r] = o[r];
-  if (EPI == M3P_EPI_DGELU) {
+  if (EPI == M3P_EPI_DGELU || EPI == M3P_EPI_MUL) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) csum[r] += (n + r < N) ? (float)o[r] : 0.f;
   }
@@ -194,7 +197,7 @@ void gemm_nt_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict_
       epilogue_store<EPI>(ep, C, ldc, M, N, m, n, acc[i][j], csum[j]);
     }
   }
-  if (EPI == M3P_EPI_DGELU && ep.colsum) {
+  if ((EPI == M3P_EPI_DGELU || EPI == M3P_EPI_MUL) && ep.colsum) {
     // reduce over the 16 lanes that share fg (different rows), then one atomic per column
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -234,7 +237,7 @@ __device__ __forceinline__ void epilogue_half(const M3PEpilogue& ep, bf16* __res
                                               int lane, f32x4 (&csum)[4]) {
   const int fr = lane & 15, fg = lane >> 4;
   const int srow = lane >> 3, sch = lane & 7;
-  constexpr bool kAux = (EPI == M3P_EPI_BIAS_DROP_RES || EPI == M3P_EPI_RES || EPI == M3P_EPI_DGELU);
+  constexpr bool kAux = (EPI == M3P_EPI_BIAS_DROP_RES || EPI == M3P_EPI_RES || EPI == M3P_EPI_DGELU || EPI == M3P_EPI_MUL);
   const float alpha = (ep.alpha == 0.f) ? 1.f : ep.alpha;
   bf16x4 ukeep[2][4];
 #pragma unroll
@@ -273,13 +276,15 @@ __device__ __forceinline__ void epilogue_half(const M3PEpilogue& ep, bf16* __res
         if (EPI == M3P_EPI_DGELU) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_grad_f(a[r]);
+        } else if (EPI == M3P_EPI_MUL) {
+          v *= a;
         } else {
           v += a;
         }
       }
       const bf16x4 ob = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
       *reinterpret_cast<bf16x4*>(r1 + lo) = ob;
-      if (EPI == M3P_EPI_DGELU) csum[j] += f32x4{(float)ob[0], (float)ob[1], (float)ob[2], (float)ob[3]};
+      if (EPI == M3P_EPI_DGELU || EPI == M3P_EPI_MUL) csum[j] += f32x4{(float)ob[0], (float)ob[1], (float)ob[2], (float)ob[3]};
     }
   }
   bf16* Cp = C + (size_t)mrow0 * ldc + nw + sch * 8;
@@ -502,7 +507,7 @@ void gemm_nt_ring_kernel(const bf16* __restrict__ A, int lda, const bf16* __rest
           for (int j = 0; j < 4; ++j)
             epilogue_store<EPI>(ep, C, ldc, M, N, mw + i * 16 + fr, nw + j * 16 + fg * 4, acc[i][j], csum[j]);
       }
-      if (EPI == M3P_EPI_DGELU && ep.colsum) {
+      if ((EPI == M3P_EPI_DGELU || EPI == M3P_EPI_MUL) && ep.colsum) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -713,7 +718,7 @@ void gemm_nt_ring_timeline_kernel(const bf16* __restrict__ A, int lda, const bf1
           for (int j = 0; j < 4; ++j)
             epilogue_store<EPI>(ep, C, ldc, M, N, mw + i * 16 + fr, nw + j * 16 + fg * 4, acc[i][j], csum[j]);
       }
-      if (EPI == M3P_EPI_DGELU && ep.colsum) {
+      if ((EPI == M3P_EPI_DGELU || EPI == M3P_EPI_MUL) && ep.colsum) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -1272,7 +1277,7 @@ void gemm_nt_w4_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
             for (int jj = 0; jj < 4; ++jj)
               epilogue_store<EPI>(ep, C, ldc, M, N, mrow0 + ii * 16 + fr, ncol0 + jj * 16 + fg * 4, rows[ii][jj], csum[jj]);
         }
-        if (EPI == M3P_EPI_DGELU && rg == 3) {
+        if ((EPI == M3P_EPI_DGELU || EPI == M3P_EPI_MUL) && rg == 3) {
           if (ep.colsum) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -1954,7 +1959,7 @@ int m3p_gemm_nt_bf16(const void* A, int lda, const void* W, int ldw, void* C, in
   if (((uintptr_t)A & 15) || ((uintptr_t)W & 15) || ((uintptr_t)C & 7)) return M3P_EINVAL;
   M3PEpilogue ep = {};
   if (ep_in) ep = *ep_in;
-  if ((epilogue == M3P_EPI_BIAS_DROP_RES || epilogue == M3P_EPI_RES || epilogue == M3P_EPI_DGELU) &&
+  if ((epilogue == M3P_EPI_BIAS_DROP_RES || epilogue == M3P_EPI_RES || epilogue == M3P_EPI_DGELU || epilogue == M3P_EPI_MUL) &&
       (!ep.aux || (ep.ld_aux % 4) != 0))
     return M3P_EINVAL;
   if (epilogue == M3P_EPI_BIAS_GELU && (!ep.out2 || (ep.ld_out2 % 4) != 0)) return M3P_EINVAL;
@@ -1967,6 +1972,7 @@ int m3p_gemm_nt_bf16(const void* A, int lda, const void* W, int ldw, void* C, in
     case M3P_EPI_BIAS_DROP_RES: return launch_nt<M3P_EPI_BIAS_DROP_RES>(a, lda, w, ldw, c, ldc, M, N, K, ep, st);
     case M3P_EPI_RES: return launch_nt<M3P_EPI_RES>(a, lda, w, ldw, c, ldc, M, N, K, ep, st);
     case M3P_EPI_DGELU: return launch_nt<M3P_EPI_DGELU>(a, lda, w, ldw, c, ldc, M, N, K, ep, st);
+    case M3P_EPI_MUL: return launch_nt<M3P_EPI_MUL>(a, lda, w, ldw, c, ldc, M, N, K, ep, st);
     default: return M3P_EINVAL;
   }
 }

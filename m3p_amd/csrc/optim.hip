@@ -102,13 +102,20 @@ __global__ __launch_bounds__(256) void transpose_batch_kernel(const long long* _
 // h = gelu_erf(u), bf16 in/out, 16-byte accesses (the FFN activation as its own streaming
 // pass: 129 M elements at HBM speed cost less than the same VALU work serialised behind the
 // MFMA stream of the persistent GEMM — see DESIGN.md)
-__global__ __launch_bounds__(256) void gelu_fwd_kernel(const bf16* __restrict__ u, bf16* __restrict__ h, size_t n8) {
+template <bool GRAD>
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const bf16* u, bf16* __restrict__ h, bf16* dh, size_t n8) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
     const bf16x8 v = *reinterpret_cast<const bf16x8*>(u + 8 * i);
-    bf16x8 o;
+    bf16x8 o, d;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (bf16)gelu_erf_f((float)v[j]);
+    for (int j = 0; j < 8; ++j) {
+      const float x = (float)v[j];
+      const GeluParts g = gelu_parts(x);        // Phi(x), phi(x) share one exp
+      o[j] = (bf16)(x * g.cdf);
+      if (GRAD) d[j] = (bf16)(g.cdf + x * g.pdf);
+    }
     *reinterpret_cast<bf16x8*>(h + 8 * i) = o;
+    if (GRAD) *reinterpret_cast<bf16x8*>(dh + 8 * i) = d;     // may overwrite u: each thread has read its 8 values
   }
 }
 
@@ -116,11 +123,14 @@ __global__ __launch_bounds__(256) void gelu_fwd_kernel(const bf16* __restrict__ 
 
 extern "C" {
 
-int m3p_gelu_fwd(const void* u, void* h, long long n, void* stream) {
-  if (n <= 0 || (n % 8) != 0 || ((uintptr_t)u & 15) || ((uintptr_t)h & 15)) return M3P_EINVAL;
+int m3p_gelu_fwd(const void* u, void* h, void* dh, long long n, void* stream) {
+  if (n <= 0 || (n % 8) != 0 || ((uintptr_t)u & 15) || ((uintptr_t)h & 15) || ((uintptr_t)dh & 15)) return M3P_EINVAL;
   const size_t n8 = (size_t)n / 8;
   const int blocks = (int)((n8 + 255) / 256 < 8192 ? (n8 + 255) / 256 : 8192);
-  hipLaunchKernelGGL(gelu_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)u, (bf16*)h, n8);
+  if (dh)
+    hipLaunchKernelGGL(gelu_fwd_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)u, (bf16*)h, (bf16*)dh, n8);
+  else
+    hipLaunchKernelGGL(gelu_fwd_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)u, (bf16*)h, (bf16*)nullptr, n8);
   M3P_CHECK_LAUNCH();
   return M3P_OK;
 }

@@ -10,6 +10,7 @@ layer's gradients (one contiguous arena slice) the moment that layer's backward 
 are enqueued, and lets clip+Adam run as flat streaming kernels.
 """
 import math
+import os
 from collections import OrderedDict
 
 import torch
@@ -25,6 +26,10 @@ ALIGN = 64
 def _round_up(n, a):
     return (n + a - 1) // a * a
 
+
+# developer switch for A/B runs: 1 = gelu_fwd also leaves gelu'(u) in u's buffer and the dgrad uses EPI_MUL;
+# 0 (default) = the dgrad epilogue recomputes gelu'(u) (EPI_DGELU).  -40 us per dgrad, +40 us per gelu pass.
+_GELU_GRAD_IN_FWD = os.environ.get('M3P_GELU_GRAD_IN_FWD', '0') != '0'   # measured equal in the step (47.97 vs 47.97 ms): off
 
 class Arena:
     """Flat storage behind a TransformerModel's hot parameters (see model/transformer.py)."""
@@ -218,8 +223,10 @@ class EncoderFn(torch.autograd.Function):
             x1, mean1, rstd1 = ops.layernorm_fwd(pre1, ar.p('layer_norm1.%d.weight' % i), ar.p('layer_norm1.%d.bias' % i))
             if M >= 1024:
                 # persistent GEMM: bias in the epilogue, GELU as its own HBM-speed pass
+                # The same pass leaves gelu'(u) in u's buffer: the backward dgrad then only multiplies
+                # (EPI_MUL, runs on the four-wave GEMM) instead of evaluating erf/exp in its epilogue.
                 u = ops.gemm_nt(x1, ar.w(f + 'lin1.weight'), L.EPI_BIAS, bias=ar.p(f + 'lin1.bias'))
-                hact = ops.gelu_fwd(u)
+                hact = ops.gelu_fwd(u, grad_inplace=_GELU_GRAD_IN_FWD)
             else:
                 u = torch.empty((M, 4 * d), dtype=BF16, device=dev)
                 hact = ops.gemm_nt(x1, ar.w(f + 'lin1.weight'), L.EPI_BIAS_GELU, bias=ar.p(f + 'lin1.bias'), out2=u)
@@ -242,6 +249,7 @@ class EncoderFn(torch.autograd.Function):
         model = ctx.model
         ar = model.arena()
         B, T, R, S, d, H, dh, nL = ctx.dims
+        M = B * S
         p_drop, p_attn, seed_step = ctx.drop
         x, totlen, rowmask, ximg16, loc, emb_saved, saved_layers = ctx.saved
         ctx.saved = None
@@ -264,7 +272,8 @@ class EncoderFn(torch.autograd.Function):
             if dY2 is None:
                 dY2 = dpre2
             ops.gemm_wgrad(dY2, hact, ar.g(f + 'lin2.weight'))
-            dU = ops.gemm_nt(dY2, ar.wt[('lin2', i)], L.EPI_DGELU, aux=u, colsum=ar.g(f + 'lin1.bias'))
+            dU = ops.gemm_nt(dY2, ar.wt[('lin2', i)], L.EPI_MUL if (M >= 1024 and _GELU_GRAD_IN_FWD) else L.EPI_DGELU, aux=u,
+                             colsum=ar.g(f + 'lin1.bias'))      # u holds gelu'(u) on the persistent path
             del hact, u, pre2
             ops.gemm_wgrad(dU, x1, ar.g(f + 'lin1.weight'))
             dx1 = ops.gemm_nt(dU, ar.wt[('lin1', i)], L.EPI_RES, aux=dpre2)

@@ -15,7 +15,7 @@ BF16 = torch.bfloat16
 # the launch stream: {(kind, M, N, K): [(start_event, end_event), ...]}
 PROFILE = None
 _EPI_NAMES = ['gemm_nt/none', 'gemm_nt/bias', 'gemm_nt/bias_gelu', 'gemm_nt/bias_drop_res', 'gemm_nt/res',
-              'gemm_nt/dgelu']
+              'gemm_nt/dgelu', 'gemm_nt/mul']
 
 
 def _prof_begin():
@@ -261,9 +261,11 @@ def transpose_bf16(src, dst):
     L.check(rc, 'm3p_transpose_bf16')
 
 
-def gelu_fwd(u):
+def gelu_fwd(u, grad_inplace=False):
+    """h = gelu_erf(u).  With grad_inplace, u is overwritten by gelu_erf'(u) (bf16) for EPI_MUL in backward."""
     h = torch.empty_like(u)
-    L.check(L.load().m3p_gelu_fwd(u.data_ptr(), h.data_ptr(), u.numel(), L.stream()), 'm3p_gelu_fwd')
+    L.check(L.load().m3p_gelu_fwd(u.data_ptr(), h.data_ptr(), u.data_ptr() if grad_inplace else None, u.numel(), L.stream()),
+            'm3p_gelu_fwd')
     return h
 
 

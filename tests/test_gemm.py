@@ -184,5 +184,9 @@ def test_gemm_nt_four_wave_kernel(M, N, K):
         dg = 0.5 * (1 + torch.erf(x / math.sqrt(2))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi)
         assert rel_l2(c.float(), prod.double() * dg) < 4e-3
         assert rel_l2(cs, c.float().sum(0)) < 1e-4
+        cs = torch.zeros(N, device='cuda')
+        c = ops.gemm_nt(a, w, L.EPI_MUL, aux=r, colsum=cs)
+        assert rel_l2(c.float(), prod * rc) < 4e-3
+        assert rel_l2(cs, c.float().sum(0)) < 1e-4
     finally:
         lib.m3p_debug_set_variant(1)

@@ -159,6 +159,13 @@ def test_gelu_fwd_and_batched_transpose():
     u, uc = randn_bf16((1000, 64), 1, 2.0)
     h = ops.gelu_fwd(u)
     assert rel_l2(h.float(), O.gelu_erf(uc)) < 4e-3
+    # same pass with the derivative written over u (what the training path saves for backward)
+    u2 = u.clone()
+    h2 = ops.gelu_fwd(u2, grad_inplace=True)
+    assert torch.equal(h2, h)
+    x = uc.double().requires_grad_(True)
+    (0.5 * x * (1 + torch.erf(x / 2 ** 0.5))).sum().backward()
+    assert rel_l2(u2.float(), x.grad) < 4e-3
     a, ac = randn_bf16((130, 200), 2)
     b, bc = randn_bf16((64, 64), 3)
     da = torch.zeros((200, 130), dtype=BF16, device='cuda'); db = torch.zeros((64, 64), dtype=BF16, device='cuda')

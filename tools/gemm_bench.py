@@ -23,7 +23,7 @@ w = (torch.randn(N, K, device='cuda') * 0.05).to(torch.bfloat16)
 out = torch.empty(M, N, dtype=torch.bfloat16, device='cuda')
 bias = torch.randn(N, device='cuda')
 u = torch.empty(M, N, dtype=torch.bfloat16, device='cuda') if epi in (2,) else None
-aux = torch.randn(M, N, device='cuda').to(torch.bfloat16) if epi in (3, 4, 5) else None
+aux = torch.randn(M, N, device='cuda').to(torch.bfloat16) if epi in (3, 4, 5, 6) else None
 dw = torch.zeros(N, K, device='cuda')
 
 

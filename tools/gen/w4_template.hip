@@ -239,7 +239,7 @@ void gemm_nt_w4_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
             for (int jj = 0; jj < 4; ++jj)
               epilogue_store<EPI>(ep, C, ldc, M, N, mrow0 + ii * 16 + fr, ncol0 + jj * 16 + fg * 4, rows[ii][jj], csum[jj]);
         }
-        if (EPI == M3P_EPI_DGELU && rg == 3) {
+        if ((EPI == M3P_EPI_DGELU || EPI == M3P_EPI_MUL) && rg == 3) {
           if (ep.colsum) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
