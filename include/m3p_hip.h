@@ -31,6 +31,7 @@ extern "C" {
 #define M3P_OK 0
 #define M3P_EINVAL (-1)
 #define M3P_ENOTIMPL (-2)
+#define M3P_ENOMEM (-3)   /* an internal scratch allocation failed */
 
 /* library / build identification: returns a static string "m3p_hip <ver> gfx950" */
 M3P_API const char* m3p_version(void);

@@ -82,7 +82,7 @@ def load():
 
 def check(code, what):
     if code != 0:
-        kind = {-1: 'M3P_EINVAL (bad shape/alignment)', -2: 'M3P_ENOTIMPL'}.get(code, 'hipError_t %d' % code)
+        kind = {-1: 'M3P_EINVAL (bad shape/alignment)', -2: 'M3P_ENOTIMPL', -3: 'M3P_ENOMEM'}.get(code, 'hipError_t %d' % code)
         raise M3PError('%s failed: %s' % (what, kind))
 
 

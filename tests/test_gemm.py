@@ -96,7 +96,8 @@ def test_gemm_nt_res_and_dgelu():
 
 @pytest.mark.parametrize('M,N,K', [(64, 128, 128), (592, 384, 128), (1000, 100, 72), (4100, 768, 768), (131, 40, 264),
                                    (8200, 3072, 768), (8192, 768, 768), (4288, 2304, 768), (4096, 1000, 72),
-                                   (16384, 256, 128), (4864, 5008, 768)])
+                                   (16384, 256, 128), (4864, 5008, 768), (4096, 3072, 768), (8192, 768, 3072),
+                                   (4160, 1024, 1024)])
 def test_gemm_wgrad(M, N, K):
     from m3p_amd import ops
     dy, dyc = randn_bf16((M, (N + 7) // 8 * 8), 1)

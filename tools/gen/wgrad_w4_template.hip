@@ -1,0 +1,319 @@
+// ---------------------------------------------------------------------------------
+// Weight-gradient kernel, four-wave version of the stream-K ring kernel below/above:
+// dW[i,j] += alpha * sum_m dY[m,i] X[m,j] with 256(i) x 256(j) output tiles, 128x128 per wave
+// (accumulators pinned in AGPRs as in gemm_nt_w4_kernel), 64-row K-tiles of M in two 64-KB LDS
+// stages ([64 m][256 cols] bf16, 512-B rows for both operands), the same two-phase schedule
+// (one s_barrier per 128 MFMAs, LDS-DMAs of K-tile +2 spread over phase 2 and the next phase 1).
+// Both operands are contraction-strided, so fragments come out of LDS through
+// ds_read_b64_tr_b16 with the 32-B-segment swizzle of the ring kernel.  Stream-K bookkeeping
+// (chunk == one workgroup's share, round-robin for many tiles) is the ring kernel's; a segment
+// ends with fp32 atomics straight from the AGPRs, the next one starts with C = 0.
+// Full tiles only (N % 256 == 0, K % 256 == 0, M % 64 == 0): everything else stays on the ring kernel.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void gemm_wgrad_w4_kernel(const bf16* __restrict__ dY, int lddy, const bf16* __restrict__ X, int ldx,
+                          float* __restrict__ dW, int lddw, int M, int N, int K, float alpha,
+                          int tiles_i, int tiles_j, int WR_CHUNK, float* __restrict__ ws, int* __restrict__ ws_tile,
+                          int dbg_flags) {
+  constexpr int TI = 256, TJ = 256, KT = 64;
+  constexpr int ROWB = 512;                          // bytes per LDS row of either operand
+  constexpr int Y_BYTES = KT * ROWB, STAGE = 2 * Y_BYTES;      // 32 KB, 64 KB
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntile = tiles_i * tiles_j;
+  const int nmt = M / KT;
+  const long long total_all = (long long)ntile * nmt;
+  const int nwg = gridDim.x;
+  const int per_xcd = nwg >> 3;
+  const int slot = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  // Schedule.  Few tiles / long M (every layer weight): each workgroup owns ONE (tile, M-chunk)
+  // segment: C = nwg / ntile chunks per tile, slot = chunk * ntile + tile, so the 32 workgroups of
+  // an XCD walk the same rows of M on neighbouring tiles and share them in L2, and every
+  // workgroup flushes exactly once.  (Dealing the ragged remainder out stream-K style left two
+  // workgroups with 18 tile flushes each: 340 us for a 150-us kernel.)  nwg - C * ntile
+  // workgroups stay idle (1.6 % for 36 tiles).  Many tiles (WR_CHUNK == 0): whole tiles round-robin.
+  const bool rr = (WR_CHUNK == 0);
+  // first-segment partials go to this workgroup's private slot of the workspace with plain stores
+  // (ws_tile[slot] = tile id, -1 = nothing there); wgrad_reduce_kernel folds the slots into dW.
+  if (ws && tid == 0) ws_tile[slot] = -1;
+  int total, seg_tile, seg_m0, seg_len;
+  if (rr) {
+    const int my_tiles = (ntile > slot) ? (ntile - slot + nwg - 1) / nwg : 0;
+    if (my_tiles == 0) return;
+    total = my_tiles * nmt;
+    seg_tile = slot; seg_m0 = 0; seg_len = nmt;
+  } else {
+    const int C = max(nwg / ntile, 1);
+    if (slot >= C * ntile) return;
+    const int c = slot / ntile;
+    seg_tile = slot - c * ntile;
+    seg_m0 = (int)((long long)c * nmt / C);
+    seg_len = (int)((long long)(c + 1) * nmt / C) - seg_m0;
+    total = seg_len;
+    if (total <= 0) return;
+  }
+  (void)total_all;
+  auto locate = [&](int) {
+    WgCursor cu;
+    cu.c = 0; cu.t = seg_tile; cu.mt = 0; cu.len = seg_len;
+    return cu;
+  };
+  auto advance = [&](WgCursor& cu) {
+    if (++cu.mt == cu.len) { cu.mt = 0; cu.t += nwg; }     // (round-robin mode: next tile; otherwise the stream ends here)
+  };
+  const int g0 = 0;
+
+  // ---- staging.  One wave instruction = 2 rows x 512 B: lane -> (row l >> 5, 16-B slot l & 31).
+  // Wave w stages rows [16w, 16w + 16) of each operand = one contiguous 8-KB slice (M0 trick as
+  // in the NT kernel).  Segment swizzle of the ring kernel: slot ^= 2 * ((row & 3) | ((row >> 3) & 1) << 2).
+  WgCursor lc = locate(g0);
+  int l_issued = 0;
+  const int l_hi = lane >> 5, l_pos = lane & 31;
+  int y_off[8], x_off[8];      // element offsets of this lane's 16 bytes inside the K-tile, immediates compensated
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const int row = wid * 16 + 2 * p + l_hi;
+    const int f = (row & 3) | (((row >> 3) & 1) << 2);
+    const int gc = l_pos ^ (f << 1);
+    y_off[p] = row * lddy + gc * 8 - (-4096 + 1024 * p) / 2;
+    x_off[p] = row * ldx + gc * 8 - (-4096 + 1024 * p) / 2;
+  }
+  const bf16* y_base;
+  const bf16* x_base;
+  auto set_load_ktile = [&]() {
+    const int ti = lc.t / tiles_j, tj = lc.t - ti * tiles_j;
+    const size_t mbase = (size_t)(seg_m0 + lc.mt) * KT;
+    y_base = dY + mbase * lddy + ti * TI;
+    x_base = X + mbase * ldx + tj * TJ;
+  };
+  set_load_ktile();
+#define WG_LD1(PTR, IMM) __builtin_amdgcn_global_load_lds(GLB_PTR(PTR), LDS_PTR(sl), 16, IMM, 0)
+  auto issue_load = [&](int s, int piece) {
+    char* sl = smem + s * STAGE + (piece < 8 ? 0 : Y_BYTES) + wid * 8192 + 4096;
+    const bf16* src = (piece < 8) ? y_base + y_off[piece & 7] : x_base + x_off[piece & 7];
+    switch (piece & 7) {
+      case 0: WG_LD1(src, -4096); break;
+      case 1: WG_LD1(src, -3072); break;
+      case 2: WG_LD1(src, -2048); break;
+      case 3: WG_LD1(src, -1024); break;
+      case 4: WG_LD1(src, 0); break;
+      case 5: WG_LD1(src, 1024); break;
+      case 6: WG_LD1(src, 2048); break;
+      default: WG_LD1(src, 3072); break;
+    }
+  };
+  auto load_done = [&]() {
+    // past the end of this workgroup's stream the last K-tile is re-loaded into a stage nobody
+    // reads again (keeps the loop body and the vmcnt bookkeeping uniform)
+    if (++l_issued < total) { advance(lc); set_load_ktile(); }
+  };
+
+  // ---- fragment addressing (tr16): lane (t = l & 15, g = l >> 4) reads row 8g + (t >> 2) (+4 for the
+  // second half, +32 for k-step 1), 8-byte piece (t & 3) of 16-column sub-tile c
+  const int wi = wid >> 1, wj = wid & 1;
+  const int ft = lane & 15, fg = lane >> 4;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const int frow = fg * 8 + (ft >> 2);
+  const int fsw = ((ft >> 2) | ((fg & 1) << 2)) << 1;
+  uint32_t y_addr[8], x_addr[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const int qy = wi * 16 + 2 * c + ((ft & 3) >> 1), qx = wj * 16 + 2 * c + ((ft & 3) >> 1);
+    y_addr[c] = lds0 + frow * ROWB + ((qy ^ fsw) << 4) + ((ft & 1) << 3);
+    x_addr[c] = lds0 + Y_BYTES + frow * ROWB + ((qx ^ fsw) << 4) + ((ft & 1) << 3);
+  }
+  // one fragment = two tr16 reads (rows +0 / +4); OFF selects the k-step (0 / 16384)
+#define WG_TR2(LO, HI, ADDR, OFF) asm volatile("ds_read_b64_tr_b16 %0, %2 offset:" #OFF "\n\tds_read_b64_tr_b16 %1, %2 offset:" #OFF "+2048" \
+                                               : "=v"(LO), "=v"(HI) : "v"(ADDR))
+#define WG_LGKM0() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+
+  asm volatile("" ::: "a0", "a255");     // reserve all 256 AGPRs (see gemm_nt_w4_kernel)
+  // acc tile (b, a) = a[((b)*8+(a))*4 .. +3] holds D[i = 16a + 4(l >> 4) + r][j = 16b + (l & 15)]
+#define WG_ACC(B, A) "a[((" #B ")*8+(" #A "))*4:((" #B ")*8+(" #A "))*4+3]"
+#define WG_M(YF, XF, B, A) do { if (FIRST) asm volatile("v_mfma_f32_16x16x32_bf16 " WG_ACC(B, A) ", %0, %1, 0" :: "v"(YF[A]), "v"(XF[B])); \
+                                else asm volatile("v_mfma_f32_16x16x32_bf16 " WG_ACC(B, A) ", %0, %1, " WG_ACC(B, A) :: "v"(YF[A]), "v"(XF[B])); } while (0)
+#define WG_L(PIECE) do { if (!(dbg_flags & 2)) issue_load(s_cur, PIECE); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define WG_LP(PIECE) do { if (pend && !(dbg_flags & 2)) issue_load(s_cur ^ 1, PIECE); __builtin_amdgcn_sched_barrier(0); } while (0)
+  auto frag = [](const s16x4& lo, const s16x4& hi) {
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+  };
+
+  s16x4 yl[8], yh[8], xl[8], xh[8];     // raw halves of the fragments being fetched
+  bf16x8 yf0[8], xf0[8], yf1[8], xf1[8];
+  auto phase1 = [&](auto first_c, int s_cur, bool pend) {
+    constexpr bool FIRST = decltype(first_c)::value;
+    const uint32_t so = s_cur * STAGE;
+    __builtin_amdgcn_sched_barrier(0);
+@PHASE1@
+    __builtin_amdgcn_sched_barrier(0);
+    if (pend) load_done();
+  };
+  auto phase2 = [&](int s_cur) {
+    constexpr bool FIRST = false;
+    const uint32_t so = (s_cur ^ 1) * STAGE;
+    __builtin_amdgcn_sched_barrier(0);
+@PHASE2@
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // ---- prologue: K-tiles 0 and 1 of the stream into stages 0 and 1
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+#pragma unroll
+    for (int pc = 0; pc < 16; ++pc) issue_load(t, pc);
+    load_done();
+  }
+  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    WG_TR2(yl[c], yh[c], y_addr[c], 0);
+    WG_TR2(xl[c], xh[c], x_addr[c], 0);
+  }
+  WG_LGKM0();
+#pragma unroll
+  for (int c = 0; c < 8; ++c) { yf0[c] = frag(yl[c], yh[c]); xf0[c] = frag(xl[c], xh[c]); }
+
+  WgCursor cc = locate(g0);
+  bool first = true;
+  int n_seg = 0;
+  for (int step = 0; step < total; ++step) {
+    const int s_cur = step & 1;
+    if (first) phase1(std::true_type{}, s_cur, step > 0);
+    else phase1(std::false_type{}, s_cur, step > 0);
+    first = false;
+    WG_LGKM0();
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { yf1[c] = frag(yl[c], yh[c]); xf1[c] = frag(xl[c], xh[c]); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();      // K-tile step+1 visible to all; stage s_cur fully read by all
+    asm volatile("" ::: "memory");
+    phase2(s_cur);
+    WG_LGKM0();
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { yf0[c] = frag(yl[c], yh[c]); xf0[c] = frag(xl[c], xh[c]); }
+
+    const bool last_of_tile = (cc.mt + 1 == cc.len) || (step + 1 == total);
+    if (last_of_tile) {
+      // flush this (tile, chunk) segment with fp32 atomics; the next segment starts from C = 0
+      asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");     // asm MFMAs: the accumulator-read hazard is ours
+      const int ti = cc.t / tiles_j, tj = cc.t - ti * tiles_j;
+      float* dbase = dW + (size_t)(ti * TI + wi * 128 + fg * 4) * lddw + tj * TJ + wj * 128 + ft;
+      const bool to_ws = (ws != nullptr) && !rr && n_seg == 0 && (step + 1 == total);
+      if (to_ws) {       // (only the last segment of a workgroup: no K-tile is in flight towards the stages any more)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
+      // the workgroups that share this output tile (one per chunk of M) flush at about the same
+      // time: each starts at a different 16-column group so they do not queue on the same lines
+#pragma nounroll
+      for (int bb = 0; bb < 8; ++bb) {
+        const int b = to_ws ? bb : ((bb + slot) & 7);
+        float v[32];
+#define WG_RD8(B)                                                                                   \
+  _Pragma("unroll") for (int q = 0; q < 32; ++q) v[q] = 0.f;                                        \
+  asm volatile("v_accvgpr_read_b32 %0, a[(" #B ")*32+0]\n\tv_accvgpr_read_b32 %1, a[(" #B ")*32+1]\n\t"   \
+               "v_accvgpr_read_b32 %2, a[(" #B ")*32+2]\n\tv_accvgpr_read_b32 %3, a[(" #B ")*32+3]\n\t"   \
+               "v_accvgpr_read_b32 %4, a[(" #B ")*32+4]\n\tv_accvgpr_read_b32 %5, a[(" #B ")*32+5]\n\t"   \
+               "v_accvgpr_read_b32 %6, a[(" #B ")*32+6]\n\tv_accvgpr_read_b32 %7, a[(" #B ")*32+7]"       \
+               : "=v"(v[0]), "=v"(v[1]), "=v"(v[2]), "=v"(v[3]), "=v"(v[4]), "=v"(v[5]), "=v"(v[6]), "=v"(v[7]));   \
+  asm volatile("v_accvgpr_read_b32 %0, a[(" #B ")*32+8]\n\tv_accvgpr_read_b32 %1, a[(" #B ")*32+9]\n\t"   \
+               "v_accvgpr_read_b32 %2, a[(" #B ")*32+10]\n\tv_accvgpr_read_b32 %3, a[(" #B ")*32+11]\n\t" \
+               "v_accvgpr_read_b32 %4, a[(" #B ")*32+12]\n\tv_accvgpr_read_b32 %5, a[(" #B ")*32+13]\n\t" \
+               "v_accvgpr_read_b32 %6, a[(" #B ")*32+14]\n\tv_accvgpr_read_b32 %7, a[(" #B ")*32+15]"     \
+               : "=v"(v[8]), "=v"(v[9]), "=v"(v[10]), "=v"(v[11]), "=v"(v[12]), "=v"(v[13]), "=v"(v[14]), "=v"(v[15])); \
+  asm volatile("v_accvgpr_read_b32 %0, a[(" #B ")*32+16]\n\tv_accvgpr_read_b32 %1, a[(" #B ")*32+17]\n\t" \
+               "v_accvgpr_read_b32 %2, a[(" #B ")*32+18]\n\tv_accvgpr_read_b32 %3, a[(" #B ")*32+19]\n\t" \
+               "v_accvgpr_read_b32 %4, a[(" #B ")*32+20]\n\tv_accvgpr_read_b32 %5, a[(" #B ")*32+21]\n\t" \
+               "v_accvgpr_read_b32 %6, a[(" #B ")*32+22]\n\tv_accvgpr_read_b32 %7, a[(" #B ")*32+23]"     \
+               : "=v"(v[16]), "=v"(v[17]), "=v"(v[18]), "=v"(v[19]), "=v"(v[20]), "=v"(v[21]), "=v"(v[22]), "=v"(v[23])); \
+  asm volatile("v_accvgpr_read_b32 %0, a[(" #B ")*32+24]\n\tv_accvgpr_read_b32 %1, a[(" #B ")*32+25]\n\t" \
+               "v_accvgpr_read_b32 %2, a[(" #B ")*32+26]\n\tv_accvgpr_read_b32 %3, a[(" #B ")*32+27]\n\t" \
+               "v_accvgpr_read_b32 %4, a[(" #B ")*32+28]\n\tv_accvgpr_read_b32 %5, a[(" #B ")*32+29]\n\t" \
+               "v_accvgpr_read_b32 %6, a[(" #B ")*32+30]\n\tv_accvgpr_read_b32 %7, a[(" #B ")*32+31]"     \
+               : "=v"(v[24]), "=v"(v[25]), "=v"(v[26]), "=v"(v[27]), "=v"(v[28]), "=v"(v[29]), "=v"(v[30]), "=v"(v[31]))
+        switch (b) {
+          case 0: { WG_RD8(0); } break;
+          case 1: { WG_RD8(1); } break;
+          case 2: { WG_RD8(2); } break;
+          case 3: { WG_RD8(3); } break;
+          case 4: { WG_RD8(4); } break;
+          case 5: { WG_RD8(5); } break;
+          case 6: { WG_RD8(6); } break;
+          default: { WG_RD8(7); } break;
+        }
+#undef WG_RD8
+        if (to_ws) {
+          // through this wave's LDS patch (the K loop is over: the stages are free) so that the
+          // workspace is written in full 128-B lines: lanes hold columns, lines run along rows.
+          // 4-byte stores in 64-B pieces left the kernel waiting ~150 us after its last wave.
+          float* lw = reinterpret_cast<float*>(smem) + wid * (128 * 36) + (fg * 4) * 36 + (b & 1) * 16 + ft;
+#pragma unroll
+          for (int a = 0; a < 8; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) lw[(a * 16 + r) * 36] = v[a * 4 + r];
+          if (b & 1) {
+            // patch = 128 rows x 32 columns (pitch 36 words); one instruction moves 8 rows x 128 B
+            const float* lr = reinterpret_cast<const float*>(smem) + wid * (128 * 36) + (lane >> 3) * 36 + (lane & 7) * 4;
+            float* wrow = ws + (size_t)slot * (TI * TJ + 272) + (size_t)(wi * 128 + (lane >> 3)) * TJ + wj * 128 + (b >> 1) * 32 + (lane & 7) * 4;
+#pragma unroll
+            for (int it = 0; it < 16; ++it)
+              *reinterpret_cast<f32x4*>(wrow + it * 8 * TJ) = *reinterpret_cast<const f32x4*>(lr + it * 8 * 36);
+          }
+        } else {
+          float* dcol = dbase + b * 16;
+#pragma unroll
+          for (int a = 0; a < 8; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (!(dbg_flags & 1)) unsafeAtomicAdd(dcol + (size_t)(a * 16 + r) * lddw, alpha * v[a * 4 + r]);
+        }
+      }
+      if (to_ws && tid == 0) ws_tile[slot] = cc.t;
+      ++n_seg;
+      first = true;
+    }
+    advance(cc);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // junk loads of the tail must not outlive the LDS allocation
+#undef WG_LD1
+#undef WG_TR2
+#undef WG_LGKM0
+#undef WG_ACC
+#undef WG_M
+#undef WG_L
+#undef WG_LP
+}
+
+// dW[tile] += alpha * sum of the workspace slots that hold a partial of that tile.
+// grid = (16 row groups, ntile); block = 256 threads, each 4 rows x 4 consecutive columns.
+__global__ __launch_bounds__(256)
+void wgrad_reduce_kernel(const float* __restrict__ ws, const int* __restrict__ ws_tile, int nslots,
+                         float* __restrict__ dW, int lddw, int tiles_j, float alpha) {
+  const int t = blockIdx.y, rg = blockIdx.x;
+  const int ti = t / tiles_j, tj = t - ti * tiles_j;
+  const int col = (threadIdx.x & 63) * 4, row0 = rg * 16 + (threadIdx.x >> 6) * 4;
+  f32x4 acc[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bool any = false;
+  for (int s = 0; s < nslots; ++s) {
+    if (ws_tile[s] != t) continue;
+    any = true;
+    const float* p = ws + (size_t)s * (65536 + 272) + row0 * 256 + col;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] += *reinterpret_cast<const f32x4*>(p + r * 256);
+  }
+  if (!any) return;
+  float* d = dW + (size_t)(ti * 256 + row0) * lddw + tj * 256 + col;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    f32x4 v = *reinterpret_cast<f32x4*>(d + (size_t)r * lddw);
+    v += alpha * acc[r];
+    *reinterpret_cast<f32x4*>(d + (size_t)r * lddw) = v;
+  }
+}
+
