@@ -194,7 +194,8 @@ M3P_API int m3p_scatter_add_rows(const void* src, const int32_t* idx, void* dst,
 
 /* F.cross_entropy over bf16 logits [n_rows, ld] (V valid columns), per-row loss to
  * row_loss, loss_sum += loss_scale * sum(row losses) if loss_sum != NULL, and IN PLACE
- * logits <- (softmax - onehot(target)) * grad_scale, padding columns [V, ld) zeroed. */
+ * logits <- (softmax - onehot(target)) * grad_scale, padding columns [V, ld) zeroed.
+ * ld % 8 == 0, logits 16-byte aligned. */
 M3P_API int m3p_ce_fwd_bwd(void* logits, int ld, int n_rows, int V, const int64_t* target, float* row_loss,
                            float* loss_sum, float loss_scale, float grad_scale, void* stream);
 

@@ -31,29 +31,39 @@ __global__ __launch_bounds__(256) void scatter_add_rows_kernel(const bf16* __res
   }
 }
 
-// One block per row.  Online (max, sum-exp) pass over V bf16 logits, then the gradient
-// pass: dlogits = (softmax - onehot) * gscale, padding columns [V, ld) zeroed so the
-// gradient tensor can be contracted over the padded pitch.
-__global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(bf16* __restrict__ logits, int ld, int V,
-                                                         const int64_t* __restrict__ target, float* __restrict__ row_loss,
-                                                         float* __restrict__ loss_sum, float loss_scale, float gscale) {
-  __shared__ float s_m[4], s_s[4];
+// One 1024-thread block per row (a 500-KB row of V = 250 002 bf16 logits: 16 waves keep enough
+// 16-byte loads in flight to stream it at HBM speed, and the second pass re-reads it while it is
+// still in the last-level cache).  Pass 1: per-thread running (max, sum-exp) updated once per 8
+// logits (one rescale per group instead of one exp-or-branch per element), combined across the
+// block.  Pass 2: dlogits = (softmax - onehot) * gscale in place, padding columns [V, ld) zeroed
+// so the gradient tensor can be contracted over the padded pitch.
+__global__ __launch_bounds__(1024) void ce_fwd_bwd_kernel(bf16* __restrict__ logits, int ld, int V,
+                                                          const int64_t* __restrict__ target, float* __restrict__ row_loss,
+                                                          float* __restrict__ loss_sum, float loss_scale, float gscale) {
+  __shared__ float s_m[16], s_s[16];
+  constexpr float kLog2e = 1.4426950408889634f;
   const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
   bf16* lr = logits + (size_t)row * ld;
-  const int nchunk = ld >> 2;
-  float m = -INFINITY, s = 0.f;
-  for (int c = tid; c < nchunk; c += 256) {
-    const f32x4 v = Vec4<bf16>::load(lr + 4 * c);
+  const int nchunk = ld >> 3;                  // 8 logits = 16 bytes (ld % 8 == 0 checked by the launcher)
+  float m = -INFINITY, s = 0.f;               // running max and sum of exp(x - m)
+  for (int c = tid; c < nchunk; c += 1024) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(lr + 8 * c);
+    float x[8];
+    float gm = -INFINITY;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (4 * c + j < V) {
-        const float x = v[j];
-        if (x > m) { s = s * __expf(m - x) + 1.f; m = x; }
-        else s += __expf(x - m);
-      }
+    for (int j = 0; j < 8; ++j) {
+      x[j] = (8 * c + j < V) ? (float)v[j] : -INFINITY;
+      gm = fmaxf(gm, x[j]);
     }
+    if (gm > m) {                              // rare after the first few groups
+      s *= __builtin_amdgcn_exp2f((m - gm) * kLog2e);      // m = -inf: exp2(-inf) = 0, s is 0 anyway
+      m = gm;
+    }
+    const float mb = m * kLog2e;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += __builtin_amdgcn_exp2f(__builtin_fmaf(x[j], kLog2e, -mb));
   }
-  // combine (m, s) pairs across the wave, then across the 4 waves
+  // combine (m, s) pairs across the wave, then across the 16 waves
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s, o, 64);
@@ -63,10 +73,12 @@ __global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(bf16* __restrict__ logi
   }
   if (lane == 0) { s_m[wib] = m; s_s[wib] = s; }
   __syncthreads();
-  float M = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+  float M = -INFINITY;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) M = fmaxf(M, s_m[w]);
   float Ssum = 0.f;
 #pragma unroll
-  for (int w = 0; w < 4; ++w) Ssum += (s_m[w] == -INFINITY) ? 0.f : s_s[w] * __expf(s_m[w] - M);
+  for (int w = 0; w < 16; ++w) Ssum += (s_m[w] == -INFINITY) ? 0.f : s_s[w] * __expf(s_m[w] - M);
   const float lse = M + __logf(Ssum);
   const int64_t tgt = target[row];
   if (tid == 0) {
@@ -77,17 +89,18 @@ __global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(bf16* __restrict__ logi
     if (loss_sum) unsafeAtomicAdd(loss_sum, l * loss_scale);
   }
   __syncthreads();   // row_loss read of lr[tgt] happens before the in-place overwrite below
-  for (int c = tid; c < nchunk; c += 256) {
-    const f32x4 v = Vec4<bf16>::load(lr + 4 * c);
-    f32x4 g;
+  const float lb = lse * kLog2e;
+  for (int c = tid; c < nchunk; c += 1024) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(lr + 8 * c);
+    bf16x8 g;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int col = 4 * c + j;
-      float p = (col < V) ? __expf(v[j] - lse) : 0.f;
+    for (int j = 0; j < 8; ++j) {
+      const int col = 8 * c + j;
+      float p = (col < V) ? __builtin_amdgcn_exp2f(__builtin_fmaf((float)v[j], kLog2e, -lb)) : 0.f;
       if (col == tgt) p -= 1.f;
-      g[j] = p * gscale;
+      g[j] = (bf16)(p * gscale);
     }
-    Vec4<bf16>::store(lr + 4 * c, g);
+    *reinterpret_cast<bf16x8*>(lr + 8 * c) = g;
   }
 }
 
@@ -143,8 +156,8 @@ int m3p_scatter_add_rows(const void* src, const int32_t* idx, void* dst, int n, 
 
 int m3p_ce_fwd_bwd(void* logits, int ld, int n_rows, int V, const int64_t* target, float* row_loss, float* loss_sum,
                    float loss_scale, float grad_scale, void* stream) {
-  if (n_rows <= 0 || V <= 0 || ld < V || (ld % 4) != 0 || ((uintptr_t)logits & 7)) return M3P_EINVAL;
-  hipLaunchKernelGGL(ce_fwd_bwd_kernel, dim3(n_rows), dim3(256), 0, (hipStream_t)stream, (bf16*)logits, ld, V, target,
+  if (n_rows <= 0 || V <= 0 || ld < V || (ld % 8) != 0 || ((uintptr_t)logits & 15)) return M3P_EINVAL;
+  hipLaunchKernelGGL(ce_fwd_bwd_kernel, dim3(n_rows), dim3(1024), 0, (hipStream_t)stream, (bf16*)logits, ld, V, target,
                      row_loss, loss_sum, loss_scale, grad_scale);
   M3P_CHECK_LAUNCH();
   return M3P_OK;
