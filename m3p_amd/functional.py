@@ -359,6 +359,40 @@ class MLMHeadFn(torch.autograd.Function):
         return dtensor, None, None, None, None, None
 
 
+class ItmHeadFn(torch.autograd.Function):
+    """BertPooler + seq_relationship (transformer.py:546-558, :1194-1197) on the HIP kernels of
+    csrc/itm.hip: scores[b] = w2 . tanh(W1 first[b] + b1) + b2 in fp32 on the master weights.
+    Parameter gradients accumulate straight into the gradient arena (main-grad)."""
+
+    @staticmethod
+    def forward(ctx, first, model):
+        ar = model.arena()
+        W1, b1 = ar.p('pooled_layer.dense.weight'), ar.p('pooled_layer.dense.bias')
+        w2, b2 = ar.p('seq_relationship.weight'), ar.p('seq_relationship.bias')
+        pooled, scores = ops.itm_head_fwd(first, W1.detach(), b1.detach(), w2.detach().view(-1), b2.detach())
+        ctx.model = model
+        ctx.saved = (first, pooled)
+        ctx.set_materialize_grads(False)
+        return scores.view(-1, 1)
+
+    @staticmethod
+    def backward(ctx, dscores):
+        if dscores is None:
+            return None, None
+        model = ctx.model
+        ar = model.arena()
+        first, pooled = ctx.saved
+        ctx.saved = None
+        ds = dscores.reshape(-1).float().contiguous()
+        dh, dpre16, h16 = ops.itm_head_bwd(ds, first, pooled, ar.p('pooled_layer.dense.weight').detach(),
+                                           ar.p('seq_relationship.weight').detach().view(-1),
+                                           ar.g('pooled_layer.dense.bias'), ar.g('seq_relationship.weight').view(-1),
+                                           ar.g('seq_relationship.bias'))
+        ops.gemm_wgrad(dpre16, h16, ar.g('pooled_layer.dense.weight'))
+        ar.touch('pooled_layer.dense.weight', 'pooled_layer.dense.bias', 'seq_relationship.weight', 'seq_relationship.bias')
+        return dh, None
+
+
 def mlm_head(model, tensor, pred_mask, y, want_scores):
     """Resolve ``tensor`` (T,B,d) — normally the view ``encoder_out[R:]`` — to rows of its
     underlying contiguous [rows, d] buffer, so the gather reads the activation in place.

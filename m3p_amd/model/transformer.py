@@ -354,14 +354,14 @@ class TransformerModel(nn.Module):
                 is_mrfr=False, is_clcm=False):
         """transformer.py:1183-1214."""
         if is_relation:
-            # BertPooler (:546-558) + seq_relationship: B x d work, negligible FLOPs — kept in
-            # fp32 torch ops on the GPU (master weights), gradients land in the same arena.
-            if torch.is_grad_enabled():
-                self.arena().touch('pooled_layer.dense.weight', 'pooled_layer.dense.bias',
-                                   'seq_relationship.weight', 'seq_relationship.bias')
-            first = tensor[:, 0].float()
-            pooled = torch.tanh(F.linear(first, self.pooled_layer.dense.weight, self.pooled_layer.dense.bias))
-            return F.linear(pooled, self.seq_relationship.weight, self.seq_relationship.bias)
+            # BertPooler (:546-558) + seq_relationship on the HIP kernels of csrc/itm.hip (fp32 math on
+            # the master weights; the score stays on the device - the reference moves it to the CPU)
+            first = tensor[:, 0]
+            if first.dtype != Fn.BF16:
+                first = first.to(Fn.BF16)
+            if first.stride(-1) != 1:
+                first = first.contiguous()
+            return Fn.ItmHeadFn.apply(first, self)
         if is_clcm or is_mrfr or is_obj:
             raise NotImplementedError('CLCM / MRFR / MRM heads are SURVEY.md §8(f2) "next" rows')
         loss, scores = Fn.mlm_head(self, tensor, pred_mask, y, bool(get_scores))

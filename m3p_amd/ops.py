@@ -271,3 +271,33 @@ def gelu_fwd(u, grad_inplace=False):
 
 def transpose_batch(desc, n_desc, max_tiles):
     L.check(L.load().m3p_transpose_batch_bf16(desc.data_ptr(), n_desc, max_tiles, L.stream()), 'm3p_transpose_batch_bf16')
+
+
+def itm_head_fwd(first, W1, b1, w2, b2):
+    """first: bf16 [B, d] view (row stride arbitrary, unit column stride) of hidden[:, 0]; returns
+    (pooled fp32 [B, d], scores fp32 [B])."""
+    _chk_bf16(first)
+    B, d = first.shape
+    assert first.stride(1) == 1
+    pooled = torch.empty((B, d), dtype=torch.float32, device=first.device)
+    scores = torch.empty((B,), dtype=torch.float32, device=first.device)
+    rc = L.load().m3p_itm_head_fwd(first.data_ptr(), first.stride(0), W1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
+                                   b2.data_ptr(), pooled.data_ptr(), scores.data_ptr(), B, d, L.stream())
+    L.check(rc, 'm3p_itm_head_fwd')
+    return pooled, scores
+
+
+def itm_head_bwd(dscores, first, pooled, W1, w2, db1, dw2, db2):
+    """Returns (dh bf16 [B, d], dpre16, h16); accumulates db1, dw2, db2 (fp32) in place."""
+    B, d = first.shape
+    dev = first.device
+    dh = torch.empty((B, d), dtype=BF16, device=dev)
+    dpre16 = torch.empty((B, d), dtype=BF16, device=dev)
+    h16 = torch.empty((B, d), dtype=BF16, device=dev)
+    assert dscores.dtype == torch.float32 and dscores.is_contiguous() and dscores.numel() == B
+    rc = L.load().m3p_itm_head_bwd(dscores.data_ptr(), first.data_ptr(), first.stride(0), pooled.data_ptr(), W1.data_ptr(),
+                                   w2.data_ptr(), dh.data_ptr(), dpre16.data_ptr(), h16.data_ptr(), db1.data_ptr(),
+                                   dw2.data_ptr(), db2.data_ptr(), B, d, L.stream())
+    L.check(rc, 'm3p_itm_head_bwd')
+    return dh, dpre16, h16
+
