@@ -194,18 +194,18 @@ M3P_API int m3p_scatter_add_rows(const void* src, const int32_t* idx, void* dst,
 
 /* ----------------------------------------------------------------------------------
  * ITM head: transformer.py:546-558 (BertPooler: tanh(dense(hidden[:, 0]))) followed by
- * :1194-1197 (seq_relationship Linear(d, 1)).  h: bf16, row b at h + b*ld_h (position 0 of
- * sequence b - the first image region); W1 [d,d], b1 [d], w2 [d], b2 [1] fp32 master weights.
- * forward: pooled fp32 [B,d] (saved for backward), scores fp32 [B].
- * backward: dscores fp32 [B] -> dh bf16 [B,d] (gradient of the B selected rows), ACCUMULATES
- * db1, dw2, db2 (fp32), and leaves bf16 dpre16 [B,d] = dL/d(pre-tanh) and h16 [B,d] = a
- * contiguous copy of the input rows: dW1 += dpre16^T h16 is one m3p_gemm_wgrad_bf16 call.
+ * :1194-1197 (seq_relationship Linear(d, 1)); position 0 of a joint sequence is the first
+ * image region.  The d x d products run on the GEMMs above:
+ *   forward   pre = m3p_gemm_nt_bf16(h0 [B,d], W1 [d,d], M3P_EPI_BIAS b1)            (bf16 [B,d])
+ *             m3p_itm_score_fwd: pooled = tanh(pre) (fp32 [B,d], saved), scores = w2 . pooled + b2
+ *   backward  m3p_itm_score_bwd(dscores [B]): dpre = dscore w2 (1 - pooled^2) as bf16 [B,d] and
+ *             transposed [d, ldt >= B]; ACCUMULATES db1, dw2 [d], db2 [1] (fp32)
+ *             dW1 += m3p_gemm_wgrad_bf16(dY = dpre16, X = h0);  dh0 = m3p_gemm_wgrad_bf16(dY = dpreT16, X = W1)
  * ---------------------------------------------------------------------------------- */
-M3P_API int m3p_itm_head_fwd(const void* h, int ld_h, const float* W1, const float* b1, const float* w2, const float* b2,
-                             float* pooled, float* scores, int B, int d, void* stream);
-M3P_API int m3p_itm_head_bwd(const float* dscores, const void* h, int ld_h, const float* pooled, const float* W1,
-                             const float* w2, void* dh, void* dpre16, void* h16, float* db1, float* dw2, float* db2,
-                             int B, int d, void* stream);
+M3P_API int m3p_itm_score_fwd(const void* pre, const float* w2, const float* b2, float* pooled, float* scores, int B,
+                              int d, void* stream);
+M3P_API int m3p_itm_score_bwd(const float* dscores, const float* pooled, const float* w2, void* dpre16, void* dpreT16,
+                              int ldt, float* db1, float* dw2, float* db2, int B, int d, void* stream);
 
 /* F.cross_entropy over bf16 logits [n_rows, ld] (V valid columns), per-row loss to
  * row_loss, loss_sum += loss_scale * sum(row losses) if loss_sum != NULL, and IN PLACE

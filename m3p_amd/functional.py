@@ -360,18 +360,18 @@ class MLMHeadFn(torch.autograd.Function):
 
 
 class ItmHeadFn(torch.autograd.Function):
-    """BertPooler + seq_relationship (transformer.py:546-558, :1194-1197) on the HIP kernels of
-    csrc/itm.hip: scores[b] = w2 . tanh(W1 first[b] + b1) + b2 in fp32 on the master weights.
-    Parameter gradients accumulate straight into the gradient arena (main-grad)."""
+    """BertPooler + seq_relationship (transformer.py:546-558, :1194-1197): the d x d products on the
+    bf16 GEMMs, tanh / score / derivative glue in csrc/itm.hip.  Parameter gradients accumulate
+    straight into the gradient arena (main-grad)."""
 
     @staticmethod
     def forward(ctx, first, model):
         ar = model.arena()
-        W1, b1 = ar.p('pooled_layer.dense.weight'), ar.p('pooled_layer.dense.bias')
-        w2, b2 = ar.p('seq_relationship.weight'), ar.p('seq_relationship.bias')
-        pooled, scores = ops.itm_head_fwd(first, W1.detach(), b1.detach(), w2.detach().view(-1), b2.detach())
+        h16, pooled, scores = ops.itm_head_fwd(first, ar.w('pooled_layer.dense.weight'), ar.p('pooled_layer.dense.bias').detach(),
+                                               ar.p('seq_relationship.weight').detach().view(-1),
+                                               ar.p('seq_relationship.bias').detach())
         ctx.model = model
-        ctx.saved = (first, pooled)
+        ctx.saved = (h16, pooled)
         ctx.set_materialize_grads(False)
         return scores.view(-1, 1)
 
@@ -381,14 +381,13 @@ class ItmHeadFn(torch.autograd.Function):
             return None, None
         model = ctx.model
         ar = model.arena()
-        first, pooled = ctx.saved
+        h16, pooled = ctx.saved
         ctx.saved = None
         ds = dscores.reshape(-1).float().contiguous()
-        dh, dpre16, h16 = ops.itm_head_bwd(ds, first, pooled, ar.p('pooled_layer.dense.weight').detach(),
-                                           ar.p('seq_relationship.weight').detach().view(-1),
-                                           ar.g('pooled_layer.dense.bias'), ar.g('seq_relationship.weight').view(-1),
-                                           ar.g('seq_relationship.bias'))
-        ops.gemm_wgrad(dpre16, h16, ar.g('pooled_layer.dense.weight'))
+        dh = ops.itm_head_bwd(ds, h16, pooled, ar.w('pooled_layer.dense.weight'),
+                              ar.p('seq_relationship.weight').detach().view(-1),
+                              ar.g('pooled_layer.dense.weight'), ar.g('pooled_layer.dense.bias'),
+                              ar.g('seq_relationship.weight').view(-1), ar.g('seq_relationship.bias'))
         ar.touch('pooled_layer.dense.weight', 'pooled_layer.dense.bias', 'seq_relationship.weight', 'seq_relationship.bias')
         return dh, None
 

@@ -273,31 +273,33 @@ def transpose_batch(desc, n_desc, max_tiles):
     L.check(L.load().m3p_transpose_batch_bf16(desc.data_ptr(), n_desc, max_tiles, L.stream()), 'm3p_transpose_batch_bf16')
 
 
-def itm_head_fwd(first, W1, b1, w2, b2):
-    """first: bf16 [B, d] view (row stride arbitrary, unit column stride) of hidden[:, 0]; returns
-    (pooled fp32 [B, d], scores fp32 [B])."""
-    _chk_bf16(first)
+def itm_head_fwd(first, W1_16, b1, w2, b2):
+    """first: bf16 [B, d] (hidden[:, 0]); W1_16: bf16 [d, d] working copy of pooled_layer.dense.weight.
+    Returns (h16 contiguous bf16 copy of the input rows, pooled fp32 [B, d], scores fp32 [B])."""
+    _chk_bf16(first, W1_16)
     B, d = first.shape
-    assert first.stride(1) == 1
+    h16 = first.contiguous()
+    pre = gemm_nt(h16, W1_16, L.EPI_BIAS, bias=b1)
     pooled = torch.empty((B, d), dtype=torch.float32, device=first.device)
     scores = torch.empty((B,), dtype=torch.float32, device=first.device)
-    rc = L.load().m3p_itm_head_fwd(first.data_ptr(), first.stride(0), W1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
-                                   b2.data_ptr(), pooled.data_ptr(), scores.data_ptr(), B, d, L.stream())
-    L.check(rc, 'm3p_itm_head_fwd')
-    return pooled, scores
+    rc = L.load().m3p_itm_score_fwd(pre.data_ptr(), w2.data_ptr(), b2.data_ptr(), pooled.data_ptr(), scores.data_ptr(),
+                                    B, d, L.stream())
+    L.check(rc, 'm3p_itm_score_fwd')
+    return h16, pooled, scores
 
 
-def itm_head_bwd(dscores, first, pooled, W1, w2, db1, dw2, db2):
-    """Returns (dh bf16 [B, d], dpre16, h16); accumulates db1, dw2, db2 (fp32) in place."""
-    B, d = first.shape
-    dev = first.device
-    dh = torch.empty((B, d), dtype=BF16, device=dev)
+def itm_head_bwd(dscores, h16, pooled, W1_16, w2, dW1, db1, dw2, db2):
+    """Returns dh bf16 [B, d]; accumulates dW1 [d,d], db1, dw2 [d], db2 [1] (fp32) in place."""
+    B, d = h16.shape
+    dev = h16.device
+    ldt = (B + 7) // 8 * 8
     dpre16 = torch.empty((B, d), dtype=BF16, device=dev)
-    h16 = torch.empty((B, d), dtype=BF16, device=dev)
+    dpreT16 = torch.zeros((d, ldt), dtype=BF16, device=dev)
     assert dscores.dtype == torch.float32 and dscores.is_contiguous() and dscores.numel() == B
-    rc = L.load().m3p_itm_head_bwd(dscores.data_ptr(), first.data_ptr(), first.stride(0), pooled.data_ptr(), W1.data_ptr(),
-                                   w2.data_ptr(), dh.data_ptr(), dpre16.data_ptr(), h16.data_ptr(), db1.data_ptr(),
-                                   dw2.data_ptr(), db2.data_ptr(), B, d, L.stream())
-    L.check(rc, 'm3p_itm_head_bwd')
-    return dh, dpre16, h16
-
+    rc = L.load().m3p_itm_score_bwd(dscores.data_ptr(), pooled.data_ptr(), w2.data_ptr(), dpre16.data_ptr(),
+                                    dpreT16.data_ptr(), ldt, db1.data_ptr(), dw2.data_ptr(), db2.data_ptr(), B, d, L.stream())
+    L.check(rc, 'm3p_itm_score_bwd')
+    gemm_wgrad(dpre16, h16, dW1)                         # dW1[j][k] += sum_b dpre[b][j] h[b][k]
+    dh32 = torch.zeros((B, d), dtype=torch.float32, device=dev)
+    gemm_wgrad(dpreT16, W1_16, dh32, n=B)                # dh[b][k]  = sum_j dpre[b][j] W1[j][k]
+    return dh32.to(BF16)

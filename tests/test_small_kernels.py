@@ -177,26 +177,25 @@ def test_gelu_fwd_and_batched_transpose():
 
 @pytest.mark.parametrize('B,S,d', [(6, 5, 128), (256, 3, 768)])
 def test_itm_head_fwd_bwd(B, S, d):
-    """BertPooler + seq_relationship kernels (csrc/itm.hip) against fp32 torch on the same bf16 input rows."""
+    """BertPooler + seq_relationship (GEMMs + csrc/itm.hip glue) against fp32 torch on the same bf16 inputs."""
     from m3p_amd import ops
     hid, hc = randn_bf16((B, S, d), 1)                      # (B, S, d): the head reads position 0 of each sequence
-    W1, W1c = randn_f32((d, d), 2, 0.05)
+    W16, W1c = randn_bf16((d, d), 2, 0.05)                  # the GEMMs read the bf16 working copy of the weight
     b1, b1c = randn_f32((d,), 3, 0.1)
     w2, w2c = randn_f32((d,), 4, 0.1)
     b2, b2c = randn_f32((1,), 5)
     first = hid[:, 0]
-    pooled, scores = ops.itm_head_fwd(first, W1, b1, w2, b2)
+    h16, pooled, scores = ops.itm_head_fwd(first, W16, b1, w2, b2)
     x = hc[:, 0].clone().requires_grad_(True)
     P = [t.clone().requires_grad_(True) for t in (W1c, b1c, w2c, b2c)]
     ref_pooled = torch.tanh(F.linear(x, P[0], P[1]))
     ref = F.linear(ref_pooled, P[2].view(1, -1), P[3]).view(-1)
-    assert rel_l2(pooled, ref_pooled.detach()) < 1e-5 and rel_l2(scores, ref.detach()) < 1e-5
+    assert rel_l2(pooled, ref_pooled.detach()) < 4e-3 and rel_l2(scores, ref.detach()) < 4e-3   # bf16 pre-activation
     ds, dsc = randn_f32((B,), 6)
     ref.backward(dsc)
     db1 = torch.zeros(d, device='cuda'); dw2 = torch.zeros(d, device='cuda'); db2 = torch.zeros(1, device='cuda')
     dW1 = torch.zeros((d, d), device='cuda')
-    dh, dpre16, h16 = ops.itm_head_bwd(ds, first, pooled, W1, w2, db1, dw2, db2)
-    ops.gemm_wgrad(dpre16, h16, dW1)
-    assert rel_l2(dh.float(), x.grad) < 6e-3                 # bf16 storage of the row gradient
-    assert rel_l2(db1, P[1].grad) < 1e-5 and rel_l2(dw2, P[2].grad) < 1e-5 and rel_l2(db2, P[3].grad) < 1e-5
-    assert rel_l2(dW1, P[0].grad) < 6e-3                     # bf16 operands of the weight-gradient GEMM
+    dh = ops.itm_head_bwd(ds, h16, pooled, W16, w2, dW1, db1, dw2, db2)
+    assert rel_l2(dh.float(), x.grad) < 8e-3
+    assert rel_l2(db1, P[1].grad) < 6e-3 and rel_l2(dw2, P[2].grad) < 6e-3 and rel_l2(db2, P[3].grad) < 1e-5
+    assert rel_l2(dW1, P[0].grad) < 8e-3

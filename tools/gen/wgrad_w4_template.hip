@@ -300,7 +300,9 @@ void wgrad_reduce_kernel(const float* __restrict__ ws, const int* __restrict__ w
 #pragma unroll
   for (int r = 0; r < 4; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
   bool any = false;
-  for (int s = 0; s < nslots; ++s) {
+  // the producer of chunk c of tile t is workgroup slot c * ntile + t (see gemm_wgrad_w4_kernel)
+  const int ntile = gridDim.y;
+  for (int s = t; s < nslots; s += ntile) {
     if (ws_tile[s] != t) continue;
     any = true;
     const float* p = ws + (size_t)s * (65536 + 272) + row0 * 256 + col;
