@@ -13,6 +13,10 @@
 #include "common.hpp"
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
+#ifndef M3P_EMB_BWD_BLOCKS
+#define M3P_EMB_BWD_BLOCKS 512
+#endif
+
 namespace {
 
 constexpr float kEps = 1e-12f;
@@ -222,14 +226,23 @@ __global__ __launch_bounds__(256) void embed_bwd_rows_kernel(EmbedBwdArgs a) {
         acc_p[i] += o;
         if (s < a.R) {
           Vec4<bf16>::store(a.dz + m * d + 4 * c, o);
-        } else if (id != a.pad_index && mk != 0.f) {
-          float* de = a.d_emb + (size_t)id * d + 4 * c;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) unsafeAtomicAdd(de + j, o[j]);
+        } else {
+          *reinterpret_cast<f32x4*>(&red[wib][4 * c]) = o;       // this wave's row, re-read below dword-contiguous
         }
       }
     }
+    if (s >= a.R && id != a.pad_index && mk != 0.f) {
+      // scatter-add into the embedding gradient: one atomic instruction = 64 CONSECUTIVE floats (two
+      // full 128-B lines) instead of 64 float4-strided ones (eight partial lines)
+      float* de = a.d_emb + (size_t)id * d;
+#pragma unroll
+      for (int k = 0; k < 4 * NI; ++k) {
+        const int e = lane + 64 * k;
+        if (e < d) unsafeAtomicAdd(de + e, red[wib][e]);
+      }
+    }
   }
+  __syncthreads();     // the row buffers double as the block-reduction scratch below
   block_reduce_atomic<NI>(red, acc_g, a.d_g_emb, d, lane, wib);
   block_reduce_atomic<NI>(red, acc_b, a.d_be_emb, d, lane, wib);
   block_reduce_atomic<NI>(red, acc_p, a.d_pos + (size_t)s * d, d, lane, wib);
@@ -374,7 +387,7 @@ int m3p_embed_assemble_bwd(const void* dh, const void* z, const float* mean_emb,
                            uint32_t thresh24, float inv_keep, void* stream) {
   if (B <= 0 || T < 0 || R < 0 || d <= 0 || (d % 4) != 0 || d > 1024) return M3P_EINVAL;
   int bsplit = 1;
-  while (bsplit < 16 && (R + T) * bsplit < 512 && B / (4 * bsplit) >= 8) bsplit *= 2;
+  while (bsplit < 16 && (R + T) * bsplit < M3P_EMB_BWD_BLOCKS && B / (4 * bsplit) >= 8) bsplit *= 2;
   EmbedBwdArgs a = {(const bf16*)dh, (const bf16*)z, mean_emb, rstd_emb, g_emb, (const bf16*)e, mean_img, rstd_img, g_img,
                     tok, totlen, loc, (bf16*)dz_scratch, (bf16*)de, d_g_emb, d_be_emb, d_pos, d_emb,
                     d_g_img, d_be_img, d_b_img, d_b_loc, d_w_loc, B, T, R, d, pad_index, bsplit,
