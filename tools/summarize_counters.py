@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Turns gpurun_out/counters/ (tools/collect_counters.sh) into profiles/r01_traffic.json and
+profiles/r01_counters.md: per kernel, launches per step, average duration, HBM bytes per launch
+(2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md, calibrated on the GELU
+pass), achieved HBM GB/s, and MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES)."""
+import collections, csv, glob, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(ROOT, 'gpurun_out', 'counters')
+
+def counters(sub):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(os.path.join(src, sub, '*', '*counter_collection.csv')):
+        for r in csv.DictReader(open(f)):
+            acc[r['Kernel_Name']][r['Counter_Name']].append(float(r['Counter_Value']))
+    return acc
+
+stats = {}
+for f in glob.glob(os.path.join(src, 'stats', '*', '*kernel_stats.csv')):
+    for r in csv.DictReader(open(f)):
+        stats[r['Name']] = (int(r['Calls']), float(r['AverageNs']))
+fetch, write, sq = counters('fetch'), counters('write'), counters('sq')
+steps = 4.0          # bench.py --steps 3 --warmup 1
+rows, kernels = [], {}
+for name, (calls, avg_ns) in sorted(stats.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
+    fk = fetch.get(name, {}).get('FETCH_SIZE')
+    wk = write.get(name, {}).get('WRITE_SIZE')
+    if not fk or not wk or calls * avg_ns < 2e5:
+        continue
+    f_kb, w_kb = sum(fk) / len(fk), sum(wk) / len(wk)
+    hbm = (2 * f_kb + w_kb) * 1024
+    s = sq.get(name, {})
+    mf = s.get('SQ_VALU_MFMA_BUSY_CYCLES'); bc = s.get('SQ_BUSY_CU_CYCLES')
+    util = (sum(mf) / len(mf)) / (4.0 * sum(bc) / len(bc)) if mf and bc and sum(bc) > 0 else None
+    wc = s.get('SQ_WAVE_CYCLES'); wa = s.get('SQ_WAIT_ANY')
+    wait = (sum(wa) / sum(wc)) if wc and wa and sum(wc) > 0 else None
+    kernels[name[:90]] = dict(launches=calls, fetch_kb=round(f_kb, 1), write_kb=round(w_kb, 1), hbm_bytes_per_launch=int(hbm))
+    rows.append((name, calls / steps, avg_ns / 1e3, hbm, hbm / avg_ns, util, wait))
+
+dg = [k for k in kernels if 'gemm_nt_ring_kernel<5>' in k]
+bench_keys = {'gemm_nt/dgelu M=41984 N=3072 K=768': kernels[dg[0]]['hbm_bytes_per_launch']} if dg else {}
+note = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, tools/collect_counters.sh) of `python bench.py --steps 3 "
+        "--warmup 1 --no-cpu-baseline`; values are KB per launch averaged over all launches of the kernel. hbm_bytes = (2*FETCH_SIZE + "
+        "WRITE_SIZE)*1024: the x2 on FETCH_SIZE is the gfx950 correction of MI355X_MICROARCH.md (HBM section), calibrated here on "
+        "gelu_fwd_kernel (streams 258 MB in, 258 MB out).")
+json.dump(dict(_note=note, kernels=kernels, bench_keys=bench_keys), open(os.path.join(ROOT, 'profiles', 'r01_traffic.json'), 'w'), indent=1)
+with open(os.path.join(ROOT, 'profiles', 'r01_counters.md'), 'w') as o:
+    o.write('# Round 1 - per-kernel counters of one cfg2 training step (MI355X, rocprofv3, separate --pmc passes)\n\n')
+    o.write('Collected by `tools/collect_counters.sh`, summarised by `tools/summarize_counters.py`.  Durations come from the plain\n'
+            '`--kernel-trace --stats` pass (counter passes serialise kernels).  HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE (gfx950\n'
+            'correction, MI355X_MICROARCH.md); HBM GB/s = bytes / duration against the 8 TB/s peak (about 6.3 TB/s achievable).\n'
+            'MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES): the share of SIMD-cycles, at the clock the\n'
+            'kernel actually ran at, in which the matrix pipe was busy.  wait = SQ_WAIT_ANY / SQ_WAVE_CYCLES.\n\n')
+    o.write('| kernel | launches / step | avg us | HBM MB / launch | HBM GB/s | MFMA util | wait |\n|---|---|---|---|---|---|---|\n')
+    for name, lps, us, hbm, gbs, util, wait in rows:
+        short = name.replace('(anonymous namespace)::', '').replace('void ', '')
+        short = short.split('(')[0][:60]
+        o.write('| `%s` | %.1f | %.1f | %.1f | %.0f | %s | %s |\n' % (short, lps, us, hbm / 1e6, gbs, '%.1f %%' % (100 * util) if util is not None else '-',
+                                                                      '%.0f %%' % (100 * wait) if wait is not None else '-'))
+print('wrote profiles/r01_traffic.json, profiles/r01_counters.md;', len(rows), 'kernels')
