@@ -18,8 +18,11 @@ _EPI_NAMES = ['gemm_nt/none', 'gemm_nt/bias', 'gemm_nt/bias_gelu', 'gemm_nt/bias
               'gemm_nt/dgelu', 'gemm_nt/mul']
 
 
-def _prof_begin():
-    if PROFILE is None:
+PROFILE_ONLY = None     # if set: the one (kind, M, N, K) instance that is timed (bench.py: the dominant kernel)
+
+
+def _prof_begin(key=None):
+    if PROFILE is None or (PROFILE_ONLY is not None and key != PROFILE_ONLY):
         return None
     e = torch.cuda.Event(enable_timing=True)
     e.record()
@@ -64,7 +67,7 @@ def gemm_nt(a, w, epilogue=L.EPI_NONE, bias=None, aux=None, out=None, out2=None,
     ep.inv_keep = 1.0 / (1.0 - p_drop) if p_drop > 0 else 1.0
     if bias is not None:
         assert bias.dtype == torch.float32
-    e0 = _prof_begin()
+    e0 = _prof_begin((_EPI_NAMES[epilogue], M, N, K))
     rc = L.load().m3p_gemm_nt_bf16(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(),
                                    out.stride(0), M, N, K, epilogue, C.byref(ep), L.stream())
     L.check(rc, 'm3p_gemm_nt_bf16')
@@ -78,7 +81,7 @@ def gemm_nt_streamk(a, w, out_f32, alpha=1.0):
     M, K = a.shape
     N = w.shape[0]
     assert w.shape[1] == K and out_f32.dtype == torch.float32 and out_f32.shape == (M, N)
-    e0 = _prof_begin()
+    e0 = _prof_begin(('gemm_nt/streamk', M, N, K))
     rc = L.load().m3p_gemm_nt_streamk_f32(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), out_f32.data_ptr(),
                                           out_f32.stride(0), M, N, K, alpha, L.stream())
     L.check(rc, 'm3p_gemm_nt_streamk_f32')
@@ -94,7 +97,7 @@ def gemm_wgrad(dy, x, dw, alpha=1.0, n=None, k=None):
     N = dy.shape[1] if n is None else n
     K = x.shape[1] if k is None else k
     assert x.shape[0] == M and dw.shape[0] >= N and dw.shape[1] >= K
-    e0 = _prof_begin()
+    e0 = _prof_begin(('gemm_wgrad', M, N, K))
     rc = L.load().m3p_gemm_wgrad_bf16(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), dw.data_ptr(),
                                       dw.stride(0), M, N, K, alpha, L.stream())
     L.check(rc, 'm3p_gemm_wgrad_bf16')
