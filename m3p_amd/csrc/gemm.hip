@@ -565,226 +565,6 @@ void gemm_nt_ring_kernel(const bf16* __restrict__ A, int lda, const bf16* __rest
 #undef M3P_LGKM0
 }
 
-template <int EPI>
-__global__ __launch_bounds__(512)
-void gemm_nt_ring_timeline_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ W, int ldw,
-                         bf16* __restrict__ C, int ldc, int M, int N, int K, M3PEpilogue ep,
-                         int tiles_m, int tiles_n, int m_fast, unsigned long long* __restrict__ dbg) {
-  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned long long t0 = __builtin_amdgcn_s_memtime(), t1;
-#define TSEG(k) do { t1 = __builtin_amdgcn_s_memtime(); tacc[k] += t1 - t0; t0 = t1; } while (0)
-  constexpr int BM = 256, BN = 128, NWAVES = 8;
-  constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ntiles = tiles_m * tiles_n;
-  // tile id -> (tm, tn): n-fastest shares the A row-panel between neighbours (weights small
-  // enough for L2/MALL); m-fastest shares the W panel instead (vocabulary projection: W = 384 MB)
-  // strips pay off once a full row of n-tiles no longer fits beside the A panels (measured:
-  // 24 n-tiles 805 -> 914 TF with 8-wide strips; 18 n-tiles lose ~5 %, so those stay n-fastest)
-  const int n_strips = (tiles_n >= 24) ? (tiles_n + 7) / 8 : 1;
-  const int strip_w = (tiles_n + n_strips - 1) / n_strips;
-  // (default order: strips of ~8 n-tiles walked m-major, so the 32 consecutive tiles an XCD
-  //  holds in one round form a ~4 x 8 block: 4 A row-panels + 8 W panels are live per XCD
-  //  instead of 1.3 + 24 -> fewer unique bytes per step in the 4-MB L2)
-  auto split_tile = [&](int t, int& tm, int& tn) {
-    if (m_fast) { tn = t / tiles_m; tm = t - tn * tiles_m; return; }
-    const int strip = t / (tiles_m * strip_w);
-    const int rem = t - strip * tiles_m * strip_w;
-    const int bn = min(strip_w, tiles_n - strip * strip_w);
-    tm = rem / bn;
-    tn = strip * strip_w + (rem - tm * bn);
-  };
-  const int nwg = gridDim.x;
-  // persistent schedule: sequence index q -> tile id
-  const int per_xcd = nwg >> 3;                       // workgroups per XCD (grid is a multiple of 8)
-  const int slot = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-  auto tile_of = [&](int q) { return q * nwg + slot; };
-  const int my_tiles = (ntiles > slot) ? (ntiles - slot + nwg - 1) / nwg : 0;
-  if (my_tiles == 0) return;
-  const int nk = K / BK;
-  const int total = my_tiles * nk;
-
-  // ---- load cursor
-  const int sr = lane >> 3, sc = (lane & 7) ^ sr;
-  const bf16* a_src[4];
-  const bf16* w_src[2];
-  int l_q = 0, l_kt = 0;
-  auto set_load_tile = [&](int q) {
-    const int t = tile_of(q);
-    int tm, tn;
-    split_tile(t, tm, tn);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) a_src[i] = A + (size_t)min(tm * BM + (wid + i * NWAVES) * 8 + sr, M - 1) * lda + sc * 8;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) w_src[i] = W + (size_t)min(tn * BN + (wid + i * NWAVES) * 8 + sr, N - 1) * ldw + sc * 8;
-  };
-  auto stage_next = [&](int s) {   // issue the loads of the next K-tile of the stream into stage s
-    char* sa = smem + s * STAGE;
-    char* sb = sa + A_BYTES;
-    const int k0 = l_kt * BK;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_global_load_lds(GLB_PTR(a_src[i] + k0), LDS_PTR(sa + (wid + i * NWAVES) * 1024), 16, 0, 0);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-      __builtin_amdgcn_global_load_lds(GLB_PTR(w_src[i] + k0), LDS_PTR(sb + (wid + i * NWAVES) * 1024), 16, 0, 0);
-    if (++l_kt == nk) { l_kt = 0; ++l_q; if (l_q < my_tiles) set_load_tile(l_q); }
-  };
-
-  // ---- fragment addressing
-  const int wm = wid >> 1, wn = wid & 1;
-  const int fr = lane & 15, fg = lane >> 4;
-  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-  uint32_t a_addr[2], b_addr[2];
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
-    const int ch = ((fg + 4 * ks) ^ (fr & 7)) * 16;
-    a_addr[ks] = lds0 + (wm * 64 + fr) * ROWB + ch;
-    b_addr[ks] = lds0 + A_BYTES + (wn * 64 + fr) * ROWB + ch;
-  }
-#define M3P_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
-  auto read_set = [&](uint32_t aa, uint32_t ba, bf16x8 (&af)[4], bf16x8 (&wf)[4]) {
-    M3P_DSR(wf[0], ba, 0); M3P_DSR(af[0], aa, 0);
-    M3P_DSR(wf[1], ba, 2048); M3P_DSR(wf[2], ba, 4096); M3P_DSR(wf[3], ba, 6144);
-    M3P_DSR(af[1], aa, 2048); M3P_DSR(af[2], aa, 4096); M3P_DSR(af[3], aa, 6144);
-  };
-#define M3P_LGKM0() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  auto mfma_batch = [&](const bf16x8 (&af)[4], const bf16x8 (&wf)[4]) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
-  };
-
-  // ---- prologue of the stream
-  set_load_tile(0);
-  stage_next(0);
-  if (total > 1) {
-    stage_next(1);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-
-  bf16x8 af0[4], wf0[4], af1[4], wf1[4];
-  read_set(a_addr[0], b_addr[0], af0, wf0);
-  M3P_LGKM0();
-  int cur = 0;      // stage of the current K-tile
-  int c_q = 0, c_kt = 0;
-  const bool io_aligned = ((ldc & 7) == 0) && (((uintptr_t)C & 15) == 0) &&
-                          (!(EPI == M3P_EPI_BIAS_GELU) || (((ep.ld_out2 & 7) == 0) && (((uintptr_t)ep.out2 & 15) == 0))) &&
-                          (!ep.bias || (((uintptr_t)ep.bias & 15) == 0));
-  for (int step = 0; step < total; ++step) {
-    const int nxt = (cur == 2) ? 0 : cur + 1;
-    const int nx2 = (nxt == 2) ? 0 : nxt + 1;
-    const bool more2 = (step + 2 < total);
-    TSEG(7);
-    if (more2) stage_next(nx2);
-    read_set(a_addr[1] + cur * STAGE, b_addr[1] + cur * STAGE, af1, wf1);
-    __builtin_amdgcn_sched_barrier(0);   // reads first, then the MFMAs that hide them
-    TSEG(0);
-    mfma_batch(af0, wf0);
-    __builtin_amdgcn_sched_barrier(0);
-    TSEG(1);
-    // k-step-1 fragments are in; every LDS read of this K-tile is complete; the next K-tile
-    // has landed for this wave -> publish
-    M3P_LGKM0();
-    TSEG(2);
-    if (more2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    TSEG(3);
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    TSEG(4);
-    read_set(a_addr[0] + nxt * STAGE, b_addr[0] + nxt * STAGE, af0, wf0);   // stale after the last K-tile: unused
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_batch(af1, wf1);
-    M3P_LGKM0();
-    TSEG(5);
-
-    if (++c_kt == nk) {
-      // ---- epilogue of output tile c_q; stage `cur` is free (all waves passed the barrier above)
-      c_kt = 0;
-      const int t = tile_of(c_q);
-      ++c_q;
-      int tm, tn;
-      split_tile(t, tm, tn);
-      const int m0 = tm * BM, n0 = tn * BN;
-      const int mw = m0 + wm * 64, nw = n0 + wn * 64;
-      f32x4 csum[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) csum[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const bool fast = io_aligned && (m0 + BM <= M) && (n0 + BN <= N);
-      if (fast) {
-        char* r1 = smem + cur * STAGE + wid * 6144;
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-          f32x4 rows[2][4];
-#pragma unroll
-          for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) rows[ii][j] = acc[2 * hf + ii][j];
-          f32x4 biasv[4];
-          bf16x4 auxv[2][4];
-          load_bias4<EPI>(ep, nw, lane, biasv);
-          load_aux<EPI>(ep, mw + 32 * hf, nw, lane, auxv);
-          epilogue_half<EPI>(ep, C, ldc, N, mw + 32 * hf, nw, r1, rows, biasv, auxv, lane, csum);
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            epilogue_store<EPI>(ep, C, ldc, M, N, mw + i * 16 + fr, nw + j * 16 + fg * 4, acc[i][j], csum[j]);
-      }
-      if ((EPI == M3P_EPI_DGELU || EPI == M3P_EPI_MUL) && ep.colsum) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float sfl = csum[j][r];
-            sfl += __shfl_xor(sfl, 1, 64); sfl += __shfl_xor(sfl, 2, 64);
-            sfl += __shfl_xor(sfl, 4, 64); sfl += __shfl_xor(sfl, 8, 64);
-            const int n = nw + j * 16 + fg * 4 + r;
-            if (fr == 0 && n < N) unsafeAtomicAdd(ep.colsum + n, sfl);
-          }
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (step + 1 < total) {
-        // the staging region is the slot the next iteration's loads go into: nobody may issue
-        // them before every wave has finished its LDS round trip
-        M3P_LGKM0();
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-      }
-    }
-    TSEG(6);
-    cur = nxt;
-  }
-  if (dbg && lane == 0) {
-    for (int k = 0; k < 8; ++k) dbg[((size_t)blockIdx.x * 8 + wid) * 8 + k] = tacc[k];
-  }
-#undef TSEG
-#undef M3P_DSR
-#undef M3P_LGKM0
-}
-
 struct WgCursor {
   int c, t, mt, len;   // chunk, tile, K-tile inside the chunk, K-tiles in this chunk
 };
@@ -2240,215 +2020,6 @@ void gemm_wgrad_ring_kernel(const bf16* __restrict__ dY, int lddy, const bf16* _
 #undef M3P_LGKM0
 }
 
-__global__ __launch_bounds__(512)
-void gemm_wgrad_ring_timeline_kernel(const bf16* __restrict__ dY, int lddy, const bf16* __restrict__ X, int ldx,
-                            float* __restrict__ dW, int lddw, int M, int N, int K, float alpha,
-                            int tiles_i, int tiles_j, int WR_CHUNK, unsigned long long* __restrict__ dbg) {
-  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned long long t0 = __builtin_amdgcn_s_memtime(), t1;
-#define TSEG(k) do { t1 = __builtin_amdgcn_s_memtime(); tacc[k] += t1 - t0; t0 = t1; } while (0)
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ntile = tiles_i * tiles_j;
-  const int nmt = M / BK;
-  const long long total_all = (long long)ntile * nmt;
-  const int nwg = gridDim.x;
-  const int per_xcd = nwg >> 3;
-  const int slot = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-  // Two schedules.  Few tiles / long M (every layer weight): stream-K with chunk == share, see
-  // above.  Many tiles / short M (the tied vocabulary matrix: 5862 tiles, 76 K-tiles): tiles
-  // are dealt round-robin (WR_CHUNK == 0), each done over all of M by one workgroup, so that
-  // an XCD's 32 workgroups hold 32 consecutive tiles = the six j-tiles of ~5 dY panels.
-  const bool rr = (WR_CHUNK == 0);
-  int g0, total;
-  if (rr) {
-    const int my_tiles = (ntile > slot) ? (ntile - slot + nwg - 1) / nwg : 0;
-    if (my_tiles == 0) return;
-    g0 = 0;
-    total = my_tiles * nmt;
-  } else {
-    // shares are whole chunk strips: workgroup `slot` owns stream positions [slot*share, +share)
-    const long long share = (total_all + nwg - 1) / nwg;
-    const long long g0l = share * slot;
-    if (g0l >= total_all) return;
-    g0 = (int)g0l;
-    total = (int)((g0l + share <= total_all ? g0l + share : total_all) - g0l);
-  }
-
-  auto locate = [&](int g) {
-    WgCursor cu;
-    if (rr) { cu.c = 0; cu.t = slot; cu.mt = 0; cu.len = nmt; return cu; }
-    const int full = ntile * WR_CHUNK;
-    cu.c = g / full;
-    const int rem = g - cu.c * full;
-    cu.len = min(WR_CHUNK, nmt - cu.c * WR_CHUNK);
-    cu.t = rem / cu.len;
-    cu.mt = rem - cu.t * cu.len;
-    return cu;
-  };
-  auto advance = [&](WgCursor& cu) {
-    if (++cu.mt == cu.len) {
-      cu.mt = 0;
-      if (rr) { cu.t += nwg; return; }
-      if (++cu.t == ntile) { cu.t = 0; ++cu.c; cu.len = min(WR_CHUNK, nmt - cu.c * WR_CHUNK); }
-    }
-  };
-
-  // ---- staging.  dY: one wave instruction = 2 rows x 512 B, lane -> (row l>>5, pos l&31);
-  //      X: 4 rows x 256 B, lane -> (row l>>4, pos l&15).  Segment swizzle as in the 128^2 kernel.
-  const int n_chunks = (N + 7) / 8, k_chunks = (K + 7) / 8;
-  WgCursor lc = locate(g0);
-  auto stage_next = [&](int s) {
-    char* sy = smem + s * WR_STAGE;
-    char* sx = sy + WR_YB;
-    const int ti = lc.t / tiles_j, tj = lc.t - ti * tiles_j;
-    const int mbase = (lc.c * WR_CHUNK + lc.mt) * BK;   // (c == 0 in round-robin mode)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int rb = wid + i * 8;               // 2-row group 0..31
-      const int row = rb * 2 + (lane >> 5);
-      const int f = (row & 3) | (((row >> 3) & 1) << 2);
-      const int gc = (lane & 31) ^ (f << 1);
-      const int col = min(ti * (WR_I / 8) + gc, n_chunks - 1) * 8;
-      __builtin_amdgcn_global_load_lds(GLB_PTR(dY + (size_t)(mbase + row) * lddy + col), LDS_PTR(sy + rb * 1024), 16, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int rb = wid + i * 8;               // 4-row group 0..15
-      const int row = rb * 4 + (lane >> 4);
-      const int f = (row & 3) | (((row >> 3) & 1) << 2);
-      const int gc = (lane & 15) ^ (f << 1);
-      const int col = min(tj * (WR_J / 8) + gc, k_chunks - 1) * 8;
-      __builtin_amdgcn_global_load_lds(GLB_PTR(X + (size_t)(mbase + row) * ldx + col), LDS_PTR(sx + rb * 1024), 16, 0, 0);
-    }
-    advance(lc);
-  };
-
-  // ---- fragment addressing (tr16): lane (t = l&15, g = l>>4) reads row g*8 + (t>>2) (+32 ks, +4 jj),
-  //      8-byte piece (t&3) of 16-column sub-tile c
-  const int wi = wid >> 1, wj = wid & 1;
-  const int ft = lane & 15, fg = lane >> 4;
-  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-  const int frow = fg * 8 + (ft >> 2);
-  const int fsw = ((ft >> 2) | ((fg & 1) << 2)) << 1;
-  uint32_t y_addr[4], x_addr[4];
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    const int qy = wi * 8 + 2 * c + ((ft & 3) >> 1), qx = wj * 8 + 2 * c + ((ft & 3) >> 1);
-    y_addr[c] = lds0 + frow * WR_YROW + ((qy ^ fsw) << 4) + ((ft & 1) << 3);
-    x_addr[c] = lds0 + WR_YB + frow * WR_XROW + ((qx ^ fsw) << 4) + ((ft & 1) << 3);
-  }
-#define M3P_TR(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
-  // k-step 0 / 1 of a stage: row offsets 0 / 32 rows; second half of a fragment: +4 rows
-  auto read_set0 = [&](uint32_t so, s16x4 (&y)[4][2], s16x4 (&x)[4][2]) {
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      M3P_TR(y[c][0], y_addr[c] + so, 0); M3P_TR(y[c][1], y_addr[c] + so, 2048);
-      M3P_TR(x[c][0], x_addr[c] + so, 0); M3P_TR(x[c][1], x_addr[c] + so, 1024);
-    }
-  };
-  auto read_set1 = [&](uint32_t so, s16x4 (&y)[4][2], s16x4 (&x)[4][2]) {
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      M3P_TR(y[c][0], y_addr[c] + so, 16384); M3P_TR(y[c][1], y_addr[c] + so, 18432);
-      M3P_TR(x[c][0], x_addr[c] + so, 8192); M3P_TR(x[c][1], x_addr[c] + so, 9216);
-    }
-  };
-#define M3P_LGKM0() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-  auto frag = [](const s16x4 (&h)[2]) {
-    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(h[0], h[1], 0, 1, 2, 3, 4, 5, 6, 7));
-  };
-  auto mfma_batch = [&](const s16x4 (&y)[4][2], const s16x4 (&x)[4][2]) {
-    bf16x8 yf[4], xf[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) { yf[c] = frag(y[c]); xf[c] = frag(x[c]); }
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int b = 0; b < 4; ++b)
-        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[a], xf[b], acc[a][b], 0, 0, 0);
-  };
-
-  stage_next(0);
-  if (total > 1) {
-    stage_next(1);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-
-  s16x4 y0[4][2], x0[4][2], y1[4][2], x1[4][2];
-  read_set0(0, y0, x0);
-  M3P_LGKM0();
-  WgCursor cc = locate(g0);
-  int cur = 0;
-  for (int step = 0; step < total; ++step) {
-    const int nxt = (cur == 2) ? 0 : cur + 1;
-    const int nx2 = (nxt == 2) ? 0 : nxt + 1;
-    const bool more2 = (step + 2 < total);
-    TSEG(7);
-    if (more2) stage_next(nx2);
-    __builtin_amdgcn_sched_barrier(0);
-    TSEG(0);
-    read_set1(cur * WR_STAGE, y1, x1);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_batch(y0, x0);
-    __builtin_amdgcn_sched_barrier(0);
-    TSEG(1);
-    M3P_LGKM0();
-    TSEG(2);
-    if (more2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    TSEG(3);
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    TSEG(4);
-    read_set0(nxt * WR_STAGE, y0, x0);   // stale after the last K-tile: unused
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_batch(y1, x1);
-    M3P_LGKM0();
-    TSEG(5);
-
-    const bool last_of_tile = (cc.mt + 1 == cc.len) || (step + 1 == total);
-    if (last_of_tile) {
-      // flush this (tile, chunk) segment: D[i][j], lane holds j = l&15, i = 4*(l>>4)+r
-      const int ti = cc.t / tiles_j, tj = cc.t - ti * tiles_j;
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          const int j = tj * WR_J + wj * 64 + b * 16 + ft;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int i = ti * WR_I + wi * 64 + a * 16 + fg * 4 + r;
-            if (i < N && j < K) unsafeAtomicAdd(dW + (size_t)i * lddw + j, alpha * acc[a][b][r]);
-            acc[a][b][r] = 0.f;
-          }
-        }
-    }
-    advance(cc);
-    TSEG(6);
-    cur = nxt;
-  }
-  if (dbg && lane == 0) {
-    for (int k = 0; k < 8; ++k) dbg[((size_t)blockIdx.x * 8 + wid) * 8 + k] = tacc[k];
-  }
-#undef TSEG
-#undef M3P_TR
-#undef M3P_LGKM0
-}
-
-
 }  // namespace
 
 extern "C" {
@@ -2480,42 +2051,23 @@ int m3p_gemm_nt_bf16(const void* A, int lda, const void* W, int ldw, void* C, in
 
 __attribute__((visibility("default"))) int m3p_debug_gemm_timeline(const void* A, int lda, const void* W, int ldw, void* C, int ldc,
                                                                    int M, int N, int K, unsigned long long* dbg, void* stream) {
+  // (only the four-wave kernel carries timeline instrumentation; full 256x256 tiles, K % 64 == 0)
+  if ((M % 256) || (N % 256) || (K % 64)) return M3P_EINVAL;
   M3PEpilogue ep = {};
-  if (g_variant == 2) {
-    const int tm = (M + 255) / 256, tn = (N + 255) / 256;
-    const size_t lds4 = 2 * 512 * 128 + 4 * EP_HALF;
-    auto k4 = gemm_nt_w4_kernel<M3P_EPI_NONE, true, 0>;
-    if (g_ablate == 1) k4 = gemm_nt_w4_kernel<M3P_EPI_NONE, true, 1>;
-    if (g_ablate == 2) k4 = gemm_nt_w4_kernel<M3P_EPI_NONE, true, 2>;
-    if (g_ablate == 3) k4 = gemm_nt_w4_kernel<M3P_EPI_NONE, true, 3>;
-    if (g_ablate == 4) k4 = gemm_nt_w4_kernel<M3P_EPI_NONE, true, 4>;
-    hipFuncSetAttribute((const void*)k4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
-    hipLaunchKernelGGL(k4, dim3(num_cus()), dim3(256), lds4, (hipStream_t)stream, (const bf16*)A, lda, (const bf16*)W, ldw,
-                       (bf16*)C, ldc, M, N, K, ep, tm, tn, 0, dbg);
-    return (int)hipGetLastError();
-  }
-  const int tiles_m = (M + 255) / 256, tiles_n = (N + 127) / 128;
-  const size_t lds = 3 * (256 + 128) * ROWB;
-  auto kern = gemm_nt_ring_timeline_kernel<M3P_EPI_NONE>;
-  hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(kern, dim3(num_cus()), dim3(512), lds, (hipStream_t)stream, (const bf16*)A, lda, (const bf16*)W, ldw,
-                     (bf16*)C, ldc, M, N, K, ep, tiles_m, tiles_n, 0, dbg);
+  const int tm = M / 256, tn = N / 256;
+  const size_t lds4 = 2 * 512 * 128 + 4 * EP_HALF;
+  auto k4 = gemm_nt_w4_kernel<M3P_EPI_NONE, true, 0>;
+  if (g_ablate == 1) k4 = gemm_nt_w4_kernel<M3P_EPI_NONE, true, 1>;
+  if (g_ablate == 2) k4 = gemm_nt_w4_kernel<M3P_EPI_NONE, true, 2>;
+  if (g_ablate == 3) k4 = gemm_nt_w4_kernel<M3P_EPI_NONE, true, 3>;
+  if (g_ablate == 4) k4 = gemm_nt_w4_kernel<M3P_EPI_NONE, true, 4>;
+  hipFuncSetAttribute((const void*)k4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
+  hipLaunchKernelGGL(k4, dim3(num_cus()), dim3(256), lds4, (hipStream_t)stream, (const bf16*)A, lda, (const bf16*)W, ldw,
+                     (bf16*)C, ldc, M, N, K, ep, tm, tn, 0, dbg);
   return (int)hipGetLastError();
 }
 
-__attribute__((visibility("default"))) int m3p_debug_wgrad_timeline(const void* dY, int lddy, const void* X, int ldx, float* dW, int lddw,
-                                                                    int M, int N, int K, unsigned long long* dbg, void* stream) {
-  const int ti = (N + WR_I - 1) / WR_I, tj = (K + WR_J - 1) / WR_J;
-  const size_t lds = 3 * WR_STAGE;
-  hipFuncSetAttribute((const void*)gemm_wgrad_ring_timeline_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  const int grid = num_cus();
-  const int nmt = M / BK;
-  long long share = ((long long)ti * tj * nmt + grid - 1) / grid;
-  int chunk = (int)(share < nmt ? (share < 1 ? 1 : share) : nmt);
-  hipLaunchKernelGGL(gemm_wgrad_ring_timeline_kernel, dim3(grid), dim3(512), lds, (hipStream_t)stream, (const bf16*)dY, lddy,
-                     (const bf16*)X, ldx, dW, lddw, M, N, K, 1.0f, ti, tj, chunk, dbg);
-  return (int)hipGetLastError();
-}
+
 
 int m3p_gemm_nt_streamk_f32(const void* A, int lda, const void* W, int ldw, float* C, int ldc, int M, int N, int K,
                             float alpha, void* stream) {

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Per-wave s_memtime breakdown of the persistent ring NT kernel (debug build hook)."""
+"""Per-wave s_memtime breakdown of the four-wave NT GEMM (debug instantiation; M3P_VARIANT high byte = ablation:
+256 no fragment reads, 512 no LDS-DMA, 1024 every K-tile re-reads the first)."""
 import ctypes as C, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -16,10 +17,8 @@ for _ in range(3):
     rc = f(a.data_ptr(), K, w.data_ptr(), K, out.data_ptr(), N, M, N, K, dbg.data_ptr(), L.stream())
 torch.cuda.synchronize()
 d = dbg.view(256, 8, 8).double()
-names = ['issue loads+reads', 'mfma batch1', 'lgkm wait', 'vmcnt wait', 'barrier', 'reads+mfma batch2+lgkm', 'epilogue/loop tail', 'loop head']
-if int(os.environ.get('M3P_VARIANT', '1')) & 0xff == 2:      # 4-wave kernel: waves 4..7 do not exist
-    d = d[:, :4]
-    names = ['groups (reads+dma+mfma issue)', 'lgkm wait', 'vmcnt wait', 'barrier', 'epilogue', 'loop glue', 'drain', '-']
+d = d[:, :4]       # four waves per workgroup
+names = ['groups (reads+dma+mfma issue)', 'lgkm wait', 'vmcnt wait', 'barrier', 'epilogue', 'loop glue', 'drain', '-']
 tot = d.sum(-1).mean()
 print('shape', M, N, K, ' mean cycles per wave: %.0f' % tot)
 for k, n in enumerate(names):
