@@ -4,14 +4,21 @@
 //   gemm_wgrad: dW[N,K] += dY[M,N]^T x X[M,K]      both operands contraction-strided,
 //               fragments come out of LDS through ds_read_b64_tr_b16 (hardware transpose)
 //
-// Common structure: 128x128 output tile, 4 waves (2x2), each wave 64x64 = 4x4 tiles of
-// v_mfma_f32_16x16x32_bf16; contraction step 64 per LDS stage, two stages, HBM -> LDS by
-// global_load_lds_dwordx4 (no VGPR round trip), one barrier per stage.  The LDS image of a
+// Kernels, in the order the launchers prefer them:
+//   gemm_nt_w4_kernel / gemm_wgrad_w4_kernel   four waves, 256x256 tile, 128x128 per wave with the
+//       256 accumulators pinned in AGPRs, 64-deep K-tiles in two 64-KB LDS stages; full-tile shapes.
+//       Their bodies (the MFMA / memory-instruction schedule) are generated: tools/gen/gen_w4.py.
+//   gemm_nt_ring_kernel / gemm_wgrad_ring_kernel   eight waves, 256x128 tile, 64x64 per wave,
+//       three-stage 48-KB ring; ragged shapes, the dGELU epilogue, the vocabulary matrices.
+//   gemm_nt_streamk_kernel   contraction-split NT with fp32 atomics (vocabulary data gradient).
+//   gemm_nt_kernel / gemm_wgrad_kernel   128x128, two stages: small-M fallbacks.
+// Common: v_mfma_f32_16x16x32_bf16 with swapped operands (a lane owns 4 consecutive output
+// columns), HBM -> LDS by global_load_lds_dwordx4 (no VGPR round trip).  The LDS image of a
 // K-contiguous tile is [rows][64] bf16 (128 B rows); because an LDS-DMA writes lane-linear,
 // the bank swizzle (16-B chunk ^= row & 7) is applied to the per-lane SOURCE address and
 // again on the ds_read_b128 (cdna guide rule 21), which makes the fragment reads
-// conflict-free.  Block ids are remapped so each XCD (private L2) walks a contiguous run
-// of tiles that share their A row-panel.
+// conflict-free.  Persistent kernels deal tiles so that each XCD (private L2) walks a
+// strip-blocked run of tiles that share their operand panels.
 #include <type_traits>
 #include "common.hpp"
 #include "../../include/m3p_hip.h"
