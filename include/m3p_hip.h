@@ -81,6 +81,12 @@ M3P_API int m3p_gemm_nt_bf16(const void* A, int lda, const void* W, int ldw, voi
  * projection (autograd of transformer.py:111: M = n_pred, N = d, K = V_pad). */
 M3P_API int m3p_gemm_nt_streamk_f32(const void* A, int lda, const void* W, int ldw, float* C, int ldc,
                                     int M, int N, int K, float alpha, void* stream);
+/* Same with the second operand given as W[K, N] (row = contraction index): Cf += alpha * A W.
+ * This is how the vocabulary data gradient dH = dlogits . E reads the embedding matrix E[V, d]
+ * in place (no transposed copy).  K may exceed the number of valid rows of W (V padded to a
+ * multiple of 64): rows >= k_valid are not read - the matching columns of A must be zeros. */
+M3P_API int m3p_gemm_nn_streamk_f32(const void* A, int lda, const void* W, int ldw, int k_valid, float* C,
+                                    int ldc, int M, int N, int K, float alpha, void* stream);
 
 /* Weight gradient: dW[N,K] (fp32, pitch lddw) += alpha * sum_m dY[m,n] * X[m,k]
  * (dY bf16 [M,N] pitch lddy, X bf16 [M,K] pitch ldx).  Accumulates with fp32 atomics

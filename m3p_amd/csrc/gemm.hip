@@ -586,10 +586,16 @@ struct WgCursor {
 // dlogits — is then read from HBM once instead of six times).  Same ring pipeline as
 // gemm_nt_ring_kernel; partial tiles are flushed with fp32 atomics.
 // ---------------------------------------------------------------------------------
+// W_KN: the second operand is given as W[K, N] (row = contraction index, N contiguous) instead of
+// W[N, K]: its 64 x 128 tile is staged with 256-B rows and read through ds_read_b64_tr_b16 like the X
+// operand of the weight-gradient kernel, so the vocabulary data gradient dH = dlogits . E reads the
+// embedding matrix as it is (no transposed copy; rows >= k_valid - the padding of V - are clamped:
+// their dlogits columns are exact zeros).
+template <bool W_KN>
 __global__ __launch_bounds__(512)
 void gemm_nt_streamk_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ W, int ldw,
                             float* __restrict__ Cf, int ldc, int M, int N, int K, float alpha,
-                            int tiles_m, int tiles_n, int CHUNK) {
+                            int tiles_m, int tiles_n, int CHUNK, int k_valid) {
   constexpr int BM = 256, BN = 128, NWAVES = 8;
   constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -637,8 +643,18 @@ void gemm_nt_streamk_kernel(const bf16* __restrict__ A, int lda, const bf16* __r
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int row = min(tn * BN + (wid + i * NWAVES) * 8 + sr, N - 1);
-      __builtin_amdgcn_global_load_lds(GLB_PTR(W + (size_t)row * ldw + k0), LDS_PTR(sb + (wid + i * NWAVES) * 1024), 16, 0, 0);
+      if (W_KN) {
+        const int rb = wid + i * NWAVES;            // 4-row group of the 64 x 128 tile
+        const int row = rb * 4 + (lane >> 4);
+        const int f = (row & 3) | (((row >> 3) & 1) << 2);
+        const int gc = (lane & 15) ^ (f << 1);
+        const int col = min(tn * (BN / 8) + gc, (N + 7) / 8 - 1) * 8;
+        const int krow = min((lc.c * CHUNK + lc.mt) * BK + row, k_valid - 1);
+        __builtin_amdgcn_global_load_lds(GLB_PTR(W + (size_t)krow * ldw + col), LDS_PTR(sb + rb * 1024), 16, 0, 0);
+      } else {
+        const int row = min(tn * BN + (wid + i * NWAVES) * 8 + sr, N - 1);
+        __builtin_amdgcn_global_load_lds(GLB_PTR(W + (size_t)row * ldw + k0), LDS_PTR(sb + (wid + i * NWAVES) * 1024), 16, 0, 0);
+      }
     }
     advance(lc);
   };
@@ -653,11 +669,30 @@ void gemm_nt_streamk_kernel(const bf16* __restrict__ A, int lda, const bf16* __r
     a_addr[ks] = lds0 + (wm * 64 + fr) * ROWB + ch;
     b_addr[ks] = lds0 + A_BYTES + (wn * 64 + fr) * ROWB + ch;
   }
+  // W_KN fragments: tr16 addressing of the weight-gradient kernel's X operand (256-B rows)
+  const int t_row = fg * 8 + (fr >> 2);
+  const int t_sw = ((fr >> 2) | ((fg & 1) << 2)) << 1;
+  uint32_t x_addr[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int qx = wn * 8 + 2 * c + ((fr & 3) >> 1);
+    x_addr[c] = lds0 + A_BYTES + t_row * 256 + ((qx ^ t_sw) << 4) + ((fr & 1) << 3);
+  }
 #define M3P_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
-  auto read_set = [&](uint32_t aa, uint32_t ba, bf16x8 (&af)[4], bf16x8 (&wf)[4]) {
-    M3P_DSR(wf[0], ba, 0); M3P_DSR(af[0], aa, 0);
-    M3P_DSR(wf[1], ba, 2048); M3P_DSR(wf[2], ba, 4096); M3P_DSR(wf[3], ba, 6144);
-    M3P_DSR(af[1], aa, 2048); M3P_DSR(af[2], aa, 4096); M3P_DSR(af[3], aa, 6144);
+#define M3P_TRH(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
+  // ks = 0 / 1 selects the 32-deep k-step; so = byte offset of the stage
+  auto read_set = [&](int ks, uint32_t so, bf16x8 (&af)[4], bf16x8 (&wf)[4], s16x4 (&wh)[4][2]) {
+    const uint32_t aa = a_addr[ks] + so, ba = b_addr[ks] + so;
+    if (W_KN) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (ks == 0) { M3P_TRH(wh[c][0], x_addr[c] + so, 0); M3P_TRH(wh[c][1], x_addr[c] + so, 1024); }
+        else { M3P_TRH(wh[c][0], x_addr[c] + so, 8192); M3P_TRH(wh[c][1], x_addr[c] + so, 9216); }
+      }
+    } else {
+      M3P_DSR(wf[0], ba, 0); M3P_DSR(wf[1], ba, 2048); M3P_DSR(wf[2], ba, 4096); M3P_DSR(wf[3], ba, 6144);
+    }
+    M3P_DSR(af[0], aa, 0); M3P_DSR(af[1], aa, 2048); M3P_DSR(af[2], aa, 4096); M3P_DSR(af[3], aa, 6144);
   };
 #define M3P_LGKM0() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
   f32x4 acc[4][4];
@@ -665,7 +700,11 @@ void gemm_nt_streamk_kernel(const bf16* __restrict__ A, int lda, const bf16* __r
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  auto mfma_batch = [&](const bf16x8 (&af)[4], const bf16x8 (&wf)[4]) {
+  auto mfma_batch = [&](const bf16x8 (&af)[4], const bf16x8 (&wf_in)[4], const s16x4 (&wh)[4][2]) {
+    bf16x8 wf[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      wf[j] = W_KN ? __builtin_bit_cast(bf16x8, __builtin_shufflevector(wh[j][0], wh[j][1], 0, 1, 2, 3, 4, 5, 6, 7)) : wf_in[j];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -683,7 +722,8 @@ void gemm_nt_streamk_kernel(const bf16* __restrict__ A, int lda, const bf16* __r
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   bf16x8 af0[4], wf0[4], af1[4], wf1[4];
-  read_set(a_addr[0], b_addr[0], af0, wf0);
+  s16x4 wh0[4][2], wh1[4][2];
+  read_set(0, 0, af0, wf0, wh0);
   M3P_LGKM0();
   WgCursor cc = locate(g0l);
   int cur = 0;
@@ -692,18 +732,18 @@ void gemm_nt_streamk_kernel(const bf16* __restrict__ A, int lda, const bf16* __r
     const int nx2 = (nxt == 2) ? 0 : nxt + 1;
     const bool more2 = (step + 2 < total);
     if (more2) stage_next(nx2);
-    read_set(a_addr[1] + cur * STAGE, b_addr[1] + cur * STAGE, af1, wf1);
+    read_set(1, cur * STAGE, af1, wf1, wh1);
     __builtin_amdgcn_sched_barrier(0);
-    mfma_batch(af0, wf0);
+    mfma_batch(af0, wf0, wh0);
     M3P_LGKM0();
     if (more2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    read_set(a_addr[0] + nxt * STAGE, b_addr[0] + nxt * STAGE, af0, wf0);
+    read_set(0, nxt * STAGE, af0, wf0, wh0);
     __builtin_amdgcn_sched_barrier(0);
-    mfma_batch(af1, wf1);
+    mfma_batch(af1, wf1, wh1);
     M3P_LGKM0();
     if ((cc.mt + 1 == cc.len) || (step + 1 == total)) {
       const int tm = cc.t / tiles_n, tn = cc.t - tm * tiles_n;
@@ -725,6 +765,7 @@ void gemm_nt_streamk_kernel(const bf16* __restrict__ A, int lda, const bf16* __r
     cur = nxt;
   }
 #undef M3P_DSR
+#undef M3P_TRH
 #undef M3P_LGKM0
 }
 
@@ -2076,26 +2117,34 @@ __attribute__((visibility("default"))) int m3p_debug_gemm_timeline(const void* A
 
 
 
-int m3p_gemm_nt_streamk_f32(const void* A, int lda, const void* W, int ldw, float* C, int ldc, int M, int N, int K,
-                            float alpha, void* stream) {
+static int launch_streamk(const void* A, int lda, const void* W, int ldw, float* C, int ldc, int M, int N, int K, float alpha,
+                          bool w_kn, int k_valid, void* stream) {
   if (M <= 0 || N <= 0 || K <= 0 || (K % BK) != 0 || (lda % 8) != 0 || (ldw % 8) != 0) return M3P_EINVAL;
   if (((uintptr_t)A & 15) || ((uintptr_t)W & 15)) return M3P_EINVAL;
+  if (w_kn && (k_valid <= 0 || k_valid > K)) return M3P_EINVAL;
   const int tiles_m = (M + 255) / 256, tiles_n = (N + 127) / 128;
   const size_t lds = 3 * (256 + 128) * ROWB;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_streamk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  auto kern = w_kn ? gemm_nt_streamk_kernel<true> : gemm_nt_streamk_kernel<false>;
+  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return (int)e;
   const int grid = num_cus();
   const int nk = K / BK;
   long long share = ((long long)tiles_m * tiles_n * nk + grid - 1) / grid;
   const int chunk = (int)(share < nk ? (share < 1 ? 1 : share) : nk);
-  hipLaunchKernelGGL(gemm_nt_streamk_kernel, dim3(grid), dim3(512), lds, (hipStream_t)stream, (const bf16*)A, lda,
-                     (const bf16*)W, ldw, C, ldc, M, N, K, alpha, tiles_m, tiles_n, chunk);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, (hipStream_t)stream, (const bf16*)A, lda, (const bf16*)W, ldw, C, ldc,
+                     M, N, K, alpha, tiles_m, tiles_n, chunk, k_valid);
   M3P_CHECK_LAUNCH();
   return M3P_OK;
+}
+
+int m3p_gemm_nt_streamk_f32(const void* A, int lda, const void* W, int ldw, float* C, int ldc, int M, int N, int K,
+                            float alpha, void* stream) {
+  return launch_streamk(A, lda, W, ldw, C, ldc, M, N, K, alpha, false, K, stream);
+}
+
+int m3p_gemm_nn_streamk_f32(const void* A, int lda, const void* W, int ldw, int k_valid, float* C, int ldc, int M, int N,
+                            int K, float alpha, void* stream) {
+  return launch_streamk(A, lda, W, ldw, C, ldc, M, N, K, alpha, true, k_valid, stream);
 }
 
 int m3p_gemm_wgrad_bf16(const void* dY, int lddy, const void* X, int ldx, float* dW, int lddw, int M, int N, int K,

@@ -66,7 +66,6 @@ class Arena:
             self.wt[('out', i)] = torch.zeros((d, d), dtype=BF16, device=dev)
             self.wt[('lin1', i)] = torch.zeros((d, 4 * d), dtype=BF16, device=dev)
             self.wt[('lin2', i)] = torch.zeros((4 * d, d), dtype=BF16, device=dev)
-        self.wt['emb'] = torch.zeros((d, self.V_pad), dtype=BF16, device=dev)   # pad columns stay zero
         # contiguous arena ranges used as gradient buckets (reverse-backward order) and by the optimizer
         self.layer_ranges = []
         for i in range(L_):
@@ -152,7 +151,6 @@ class Arena:
                 self._tdesc = (torch.tensor(rows, dtype=torch.int64, device=self.device), len(rows), mt) if rows else ()
             if self._tdesc:
                 ops.transpose_batch(*self._tdesc)
-            ops.transpose_bf16(self.w('embeddings.weight'), self.wt['emb'])
             self._transposes_stale = False
 
     def zero_grad(self):
@@ -349,7 +347,7 @@ class MLMHeadFn(torch.autograd.Function):
         ops.gemm_wgrad(dlogits, hs, ar.g('embeddings.weight'), n=V, k=d)
         ops.colsum(dlogits, V, ar.g('pred_layer.proj.bias'), scale=g)
         dH32 = torch.zeros((n, d), dtype=torch.float32, device=dlogits.device)
-        ops.gemm_nt_streamk(dlogits, ar.wt['emb'], dH32)
+        ops.gemm_nn_streamk(dlogits, ar.w('embeddings.weight'), dH32)     # E [V, d] read in place: no transposed copy
         dH = (dH32 * g).to(BF16)
         # gradient wrt `tensor` (a strided view of the encoder output): build it on a zeroed
         # twin of the underlying row buffer and hand autograd the same strided view of it

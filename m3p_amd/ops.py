@@ -89,6 +89,21 @@ def gemm_nt_streamk(a, w, out_f32, alpha=1.0):
     return out_f32
 
 
+def gemm_nn_streamk(a, w_kn, out_f32, alpha=1.0):
+    """out_f32[M,N] (fp32) += alpha * a[M,K] @ w_kn[:K]  with w_kn [k_valid <= K, N] row-major (stream-K, fp32
+    atomics); columns k_valid..K of ``a`` must be zeros."""
+    _chk_bf16(a, w_kn)
+    M, K = a.shape
+    k_valid, N = w_kn.shape
+    assert k_valid <= K and out_f32.dtype == torch.float32 and out_f32.shape == (M, N) and w_kn.stride(1) == 1
+    e0 = _prof_begin(('gemm_nt/streamk', M, N, K))
+    rc = L.load().m3p_gemm_nn_streamk_f32(a.data_ptr(), a.stride(0), w_kn.data_ptr(), w_kn.stride(0), k_valid,
+                                          out_f32.data_ptr(), out_f32.stride(0), M, N, K, alpha, L.stream())
+    L.check(rc, 'm3p_gemm_nn_streamk_f32')
+    _prof_end(e0, ('gemm_nt/streamk', M, N, K))
+    return out_f32
+
+
 def gemm_wgrad(dy, x, dw, alpha=1.0, n=None, k=None):
     """dw[N,K] (fp32) += alpha * dy[M,N]^T @ x[M,K]."""
     _chk_bf16(dy, x)

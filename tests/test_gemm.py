@@ -191,3 +191,26 @@ def test_gemm_nt_four_wave_kernel(M, N, K):
         assert rel_l2(cs, c.float().sum(0)) < 1e-4
     finally:
         lib.m3p_debug_set_variant(1)
+
+
+@pytest.mark.parametrize('M,N,K,kv', [(300, 768, 4096, 4096), (4864, 768, 25024, 25002), (1000, 130, 640, 601)])
+def test_gemm_nn_streamk(M, N, K, kv):
+    """Cf += alpha * A[M,K] W[K,N] with W row-major in the contraction index (the vocabulary data gradient reads the
+    embedding matrix in place); rows kv..K of W do not exist, the matching columns of A are zero."""
+    from m3p_amd import ops
+    a, ac = randn_bf16((M, K), 1)
+    a[:, kv:] = 0
+    ac[:, kv:] = 0
+    w, wc = randn_bf16((kv, (N + 7) // 8 * 8), 2, 0.05)
+    w = w[:, :N] if N % 8 == 0 else w
+    out = torch.ones((M, N), dtype=torch.float32, device='cuda')
+    if N % 8 == 0:
+        ops.gemm_nn_streamk(a, w, out, alpha=0.5)
+        ref = 1.0 + 0.5 * (ac[:, :kv].double() @ wc[:, :N].double())
+        assert rel_l2(out, ref) < 1e-5
+    else:
+        wv = w[:, :N]                       # view with pitch (N + 7) // 8 * 8
+        ops.gemm_nn_streamk(a, wv, out, alpha=0.5)
+        ref = 1.0 + 0.5 * (ac[:, :kv].double() @ wc[:, :N].double())
+        assert rel_l2(out, ref) < 1e-5
+
