@@ -95,8 +95,8 @@ def cpu_baseline(cfg, seconds=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=10)   # (the engine clock needs a few hundred ms of load to ramp up from idle)
     ap.add_argument('--batch', type=int, default=256, help='sequences per GPU')
     ap.add_argument('--config', default='cfg2')
     ap.add_argument('--dropout', type=float, default=0.1)
