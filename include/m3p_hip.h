@@ -247,6 +247,16 @@ M3P_API int m3p_adam_step(float* p, float* g, float* m, float* v, void* w16, lon
  * then applies with M3P_EPI_MUL instead of recomputing the derivative in the GEMM epilogue. */
 M3P_API int m3p_gelu_fwd(const void* u, void* h, void* dh, long long n, void* stream);
 
+/* du = dy * gelu_erf'(u) elementwise (backward of the GELU inside BertPredictionHeadTransform,
+ * transformer.py:595-606, for the masked-region classification head), bf16, n % 8 == 0. */
+M3P_API int m3p_gelu_bwd(const void* dy, const void* u, void* du, long long n, void* stream);
+
+/* Masked-region feature regression loss (F.mse_loss of xtrainer.py:2346 on the gathered masked rows):
+ * row_sq[i] = sum_j (pred[i][j] - tgt[i][j])^2 (the caller divides the total by rows*cols) and
+ * dpred[i][j] = 2 (pred - tgt) * grad_scale.  pred/dpred bf16 (pitch ld_pred), tgt fp32 (pitch ld_tgt). */
+M3P_API int m3p_mse_fwd_bwd(const void* pred, int ld_pred, const float* tgt, int ld_tgt, void* dpred, float* row_sq,
+                            int rows, int cols, float grad_scale, void* stream);
+
 /* Batched form of m3p_transpose_bf16: desc = n_desc x {src ptr, dst ptr, rows, cols, ld_src,
  * ld_dst} as int64 in device memory; max_tiles >= max over matrices of ceil(rows/64)*ceil(cols/64). */
 M3P_API int m3p_transpose_batch_bf16(const long long* desc, int n_desc, int max_tiles, void* stream);

@@ -119,9 +119,65 @@ __global__ __launch_bounds__(256) void gelu_fwd_kernel(const bf16* u, bf16* __re
   }
 }
 
+// du = dy * gelu_erf'(u): backward of a GELU that sits between a Linear and a LayerNorm
+// (BertPredictionHeadTransform, transformer.py:595-606), bf16 in/out, 16-byte accesses
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ u,
+                                                       bf16* __restrict__ du, size_t n8) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+    const bf16x8 g = *reinterpret_cast<const bf16x8*>(dy + 8 * i);
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(u + 8 * i);
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (bf16)((float)g[j] * gelu_erf_grad_f((float)v[j]));
+    *reinterpret_cast<bf16x8*>(du + 8 * i) = o;
+  }
+}
+
+// Masked-region feature regression loss (xtrainer.py:2346): one wave per row,
+// row_sq[i] = sum_j (pred[i][j] - tgt[i][j])^2 and dpred = 2 (pred - tgt) * gscale in bf16.
+__global__ __launch_bounds__(256) void mse_fwd_bwd_kernel(const bf16* __restrict__ pred, int ld_pred, const float* __restrict__ tgt,
+                                                          int ld_tgt, bf16* __restrict__ dpred, float* __restrict__ row_sq,
+                                                          int rows, int cols, float gscale) {
+  const int lane = threadIdx.x & 63;
+  const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (row >= rows) return;
+  const bf16* pr = pred + (size_t)row * ld_pred;
+  const float* tr = tgt + (size_t)row * ld_tgt;
+  bf16* dr = dpred + (size_t)row * ld_pred;
+  float acc = 0.f;
+  for (int c = lane * 4; c < cols; c += 256) {
+    const f32x4 p = Vec4<bf16>::load(pr + c);
+    const f32x4 t = *reinterpret_cast<const f32x4*>(tr + c);
+    const f32x4 e = p - t;
+    acc += (e[0] * e[0] + e[1] * e[1]) + (e[2] * e[2] + e[3] * e[3]);
+    Vec4<bf16>::store(dr + c, e * (2.f * gscale));
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) row_sq[row] = acc;
+}
+
 }  // namespace
 
 extern "C" {
+
+int m3p_gelu_bwd(const void* dy, const void* u, void* du, long long n, void* stream) {
+  if (n <= 0 || (n % 8) != 0 || ((uintptr_t)dy & 15) || ((uintptr_t)u & 15) || ((uintptr_t)du & 15)) return M3P_EINVAL;
+  const size_t n8 = (size_t)n / 8;
+  const int blocks = (int)((n8 + 255) / 256 < 8192 ? (n8 + 255) / 256 : 8192);
+  hipLaunchKernelGGL(gelu_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)dy, (const bf16*)u, (bf16*)du, n8);
+  M3P_CHECK_LAUNCH();
+  return M3P_OK;
+}
+
+int m3p_mse_fwd_bwd(const void* pred, int ld_pred, const float* tgt, int ld_tgt, void* dpred, float* row_sq, int rows,
+                    int cols, float grad_scale, void* stream) {
+  if (rows <= 0 || cols <= 0 || (cols % 4) != 0 || (ld_pred % 4) != 0 || (ld_tgt % 4) != 0) return M3P_EINVAL;
+  if (((uintptr_t)pred & 7) || ((uintptr_t)dpred & 7) || ((uintptr_t)tgt & 15)) return M3P_EINVAL;
+  hipLaunchKernelGGL(mse_fwd_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16*)pred, ld_pred, tgt,
+                     ld_tgt, (bf16*)dpred, row_sq, rows, cols, grad_scale);
+  M3P_CHECK_LAUNCH();
+  return M3P_OK;
+}
 
 int m3p_gelu_fwd(const void* u, void* h, void* dh, long long n, void* stream) {
   if (n <= 0 || (n % 8) != 0 || ((uintptr_t)u & 15) || ((uintptr_t)h & 15) || ((uintptr_t)dh & 15)) return M3P_EINVAL;

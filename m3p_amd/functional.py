@@ -357,6 +357,144 @@ class MLMHeadFn(torch.autograd.Function):
         return dtensor, None, None, None, None, None
 
 
+def _as_row_buffer(tensor, d):
+    """``tensor`` (.., d) - normally a strided view of the encoder output - as rows of its underlying
+    contiguous [rows, d] buffer: returns (tensor, base, element strides of the leading dims, storage offset).
+    Falls back to a contiguous copy when the view is not row-aligned."""
+    strides, soff = tensor.stride(), tensor.storage_offset()
+    with torch.no_grad():
+        ok = strides[-1] == 1 and all(st % d == 0 for st in strides[:-1]) and soff % d == 0
+        base = torch.as_strided(tensor, (tensor.untyped_storage().nbytes() // 2 // d, d), (d, 1), 0) if ok else None
+    if base is None:
+        tensor = tensor.contiguous()
+        with torch.no_grad():
+            base = tensor.view(-1, d)
+        strides, soff = tensor.stride(), 0
+    return tensor, base, strides, soff
+
+
+def _scatter_rows_grad(dH, row_idx, base, shape, stride, soff):
+    """Gradient wrt a strided view of a row buffer: zeroed twin of the buffer + scatter-add of the selected rows."""
+    dbase = torch.zeros_like(base)
+    ops.scatter_add_rows(dH, row_idx, dbase, dH.shape[0], dH.shape[1])
+    return torch.as_strided(dbase, shape, stride, soff)
+
+
+class ObjHeadFn(torch.autograd.Function):
+    """Masked-region classification (MRM): predict(is_obj=True), transformer.py:1205-1210 =
+    BertPredictionHeadTransform (:595-606: dense, erf-GELU, LayerNorm eps 1e-12) + ObjPredLayer (:575-584:
+    Linear(d, 1600), mean CE with ignore_index = -1).  Only the masked rows (label != -1) are gathered and
+    pushed through the head - the others do not enter the ignore_index mean.  GEMMs + LayerNorm + CE
+    are the kernels of the encoder / MLM head; GELU backward is m3p_gelu_bwd."""
+
+    @staticmethod
+    def forward(ctx, tensor, model, base, row_idx, y):
+        ar = model.arena()
+        ar.refresh()
+        d = model.dim
+        n = int(y.shape[0])
+        hsel = ops.gather_rows(base, row_idx, n, d)
+        u = torch.empty((n, d), dtype=BF16, device=hsel.device)
+        t = ops.gemm_nt(hsel, ar.w('transformer_obj.dense.weight'), L.EPI_BIAS_GELU, bias=ar.p('transformer_obj.dense.bias'), out2=u)
+        x1, mean, rstd = ops.layernorm_fwd(t, ar.p('transformer_obj.LayerNorm.weight'), ar.p('transformer_obj.LayerNorm.bias'))
+        logits = ops.gemm_nt(x1, ar.w('pred_obj_layer.proj.weight'), L.EPI_BIAS, bias=ar.p('pred_obj_layer.proj.bias'))
+        loss_sum, _ = ops.ce_fwd_bwd(logits, logits.shape[1], y, 1.0 / n, 1.0 / n)
+        ctx.model = model
+        ctx.saved = (hsel, u, t, mean, rstd, x1, logits, row_idx, tuple(tensor.shape), tuple(tensor.stride()),
+                     tensor.storage_offset(), base)
+        return loss_sum[0].clone()
+
+    @staticmethod
+    def backward(ctx, gloss):
+        model = ctx.model
+        ar = model.arena()
+        hsel, u, t, mean, rstd, x1, dlogits, row_idx, shape, stride, soff, base = ctx.saved
+        ctx.saved = None
+        n, d = hsel.shape
+        g = gloss.reshape(1).float()
+        dev = hsel.device
+        ar.touch('transformer_obj.dense.weight', 'transformer_obj.dense.bias', 'transformer_obj.LayerNorm.weight',
+                 'transformer_obj.LayerNorm.bias', 'pred_obj_layer.proj.weight', 'pred_obj_layer.proj.bias')
+        nobj = dlogits.shape[1]
+        ops.gemm_wgrad(dlogits, (x1.float() * g).to(BF16), ar.g('pred_obj_layer.proj.weight'))
+        ops.colsum(dlogits, nobj, ar.g('pred_obj_layer.proj.bias'), scale=g)
+        dx1 = torch.zeros((n, d), dtype=torch.float32, device=dev)
+        ops.gemm_nn_streamk(dlogits, ar.w('pred_obj_layer.proj.weight'), dx1)
+        dx1 = (dx1 * g).to(BF16)
+        dt, _ = ops.layernorm_bwd(dx1, None, t, ar.p('transformer_obj.LayerNorm.weight'), mean, rstd, None,
+                                  ar.g('transformer_obj.LayerNorm.weight'), ar.g('transformer_obj.LayerNorm.bias'))
+        du = ops.gelu_bwd(dt, u)
+        ops.gemm_wgrad(du, hsel, ar.g('transformer_obj.dense.weight'))
+        ops.colsum(du, d, ar.g('transformer_obj.dense.bias'))
+        dH = torch.zeros((n, d), dtype=torch.float32, device=dev)
+        ops.gemm_nn_streamk(du, ar.w('transformer_obj.dense.weight'), dH)
+        return _scatter_rows_grad(dH.to(BF16), row_idx, base, shape, stride, soff), None, None, None, None
+
+
+class MrfrHeadFn(torch.autograd.Function):
+    """Masked-region feature regression (MRFR): predict(is_mrfr=True) = mrfr_dense (transformer.py:1202-1204)
+    on the masked regions + F.mse_loss against their original 2048-d features (xtrainer.py:2332-2352)."""
+
+    @staticmethod
+    def forward(ctx, tensor, model, base, row_idx, target):
+        ar = model.arena()
+        ar.refresh()
+        d = model.dim
+        n = int(target.shape[0])
+        hsel = ops.gather_rows(base, row_idx, n, d)
+        reg = ops.gemm_nt(hsel, ar.w('mrfr_dense.weight'), L.EPI_BIAS, bias=ar.p('mrfr_dense.bias'))
+        sq, dreg = ops.mse_fwd_bwd(reg, target, 1.0 / (n * reg.shape[1]))
+        ctx.model = model
+        ctx.saved = (hsel, dreg, row_idx, tuple(tensor.shape), tuple(tensor.stride()), tensor.storage_offset(), base)
+        return (sq[0] / (n * reg.shape[1])).clone()
+
+    @staticmethod
+    def backward(ctx, gloss):
+        model = ctx.model
+        ar = model.arena()
+        hsel, dreg, row_idx, shape, stride, soff, base = ctx.saved
+        ctx.saved = None
+        n, d = hsel.shape
+        g = gloss.reshape(1).float()
+        ar.touch('mrfr_dense.weight', 'mrfr_dense.bias')
+        ops.gemm_wgrad(dreg, (hsel.float() * g).to(BF16), ar.g('mrfr_dense.weight'))
+        ops.colsum(dreg, dreg.shape[1], ar.g('mrfr_dense.bias'), scale=g)
+        dH = torch.zeros((n, d), dtype=torch.float32, device=hsel.device)
+        ops.gemm_nn_streamk(dreg, ar.w('mrfr_dense.weight'), dH)
+        return _scatter_rows_grad((dH * g).to(BF16), row_idx, base, shape, stride, soff), None, None, None, None
+
+
+def _masked_region_rows(tensor, labels, d):
+    """labels (B*R,) with -1 = not masked (host tensor preferred: no device sync) -> (tensor, base, int32 row
+    indices of the masked (b, r) positions inside the row buffer, their labels on the device)."""
+    assert tensor.dim() == 3 and tensor.shape[-1] == d and tensor.dtype == BF16
+    B, R, _ = tensor.shape
+    tensor, base, strides, soff = _as_row_buffer(tensor, d)
+    lab = labels.reshape(-1)
+    pos = torch.nonzero(lab.cpu() != -1).view(-1)        # host side: labels come from the data pipeline
+    b_idx, r_idx = pos // R, pos % R
+    row_idx = ((soff + b_idx * strides[0] + r_idx * strides[1]) // d).to(torch.int32).to(tensor.device)
+    return tensor, base, row_idx, pos
+
+
+def mrm_head(model, tensor, y_all):
+    """predict(is_obj=True): tensor (B, R, d) bf16 image part of the encoder output, y_all (B*R,) int64."""
+    tensor, base, row_idx, pos = _masked_region_rows(tensor, y_all, model.dim)
+    assert pos.numel() > 0, 'no masked region in the batch'
+    y = y_all.reshape(-1).cpu()[pos].to(tensor.device)
+    return ObjHeadFn.apply(tensor, model, base, row_idx, y)
+
+
+def mrfr_head(model, tensor, obj_labels, ori_att_feats):
+    """MRFR loss of xtrainer.py:2332-2352 on the masked regions of tensor (B, R, d)."""
+    tensor, base, row_idx, pos = _masked_region_rows(tensor, obj_labels, model.dim)
+    if pos.numel() == 0:
+        return torch.zeros((), dtype=torch.float32, device=tensor.device)
+    feats = ori_att_feats.reshape(-1, ori_att_feats.shape[-1])
+    target = feats[pos.to(feats.device)].to(device=tensor.device, dtype=torch.float32).contiguous()
+    return MrfrHeadFn.apply(tensor, model, base, row_idx, target)
+
+
 class ItmHeadFn(torch.autograd.Function):
     """BertPooler + seq_relationship (transformer.py:546-558, :1194-1197): the d x d products on the
     bf16 GEMMs, tanh / score / derivative glue in csrc/itm.hip.  Parameter gradients accumulate

@@ -53,6 +53,8 @@ SIGNATURES = {
     'm3p_adam_step': (_i, [_p, _p, _p, _p, _p, C.c_longlong, _f, _f, _f, _f, _f, _f, _p, _f, _f, _i, _p]),
     'm3p_itm_score_fwd': (_i, [_p, _p, _p, _p, _p, _i, _i, _p]),
     'm3p_itm_score_bwd': (_i, [_p, _p, _p, _p, _p, _i, _p, _p, _p, _i, _i, _p]),
+    'm3p_gelu_bwd': (_i, [_p, _p, _p, C.c_longlong, _p]),
+    'm3p_mse_fwd_bwd': (_i, [_p, _i, _p, _i, _p, _p, _i, _i, _f, _p]),
     'm3p_gelu_fwd': (_i, [_p, _p, _p, C.c_longlong, _p]),
     'm3p_transpose_batch_bf16': (_i, [_p, _i, _i, _p]),
     'm3p_transpose_bf16': (_i, [_p, _p, _i, _i, _i, _i, _p]),

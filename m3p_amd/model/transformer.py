@@ -281,6 +281,13 @@ class TransformerModel(nn.Module):
         out['pooled_layer.dense.bias'] = self.pooled_layer.dense.bias
         out['seq_relationship.weight'] = self.seq_relationship.weight
         out['seq_relationship.bias'] = self.seq_relationship.bias
+        # masked-region heads: trained only when cross_mrm_steps / cross_mrfr_steps are set,
+        # otherwise never touched (Adam and the clip norm skip untouched ranges)
+        own = dict(self.named_parameters())
+        for name in ('transformer_obj.dense.weight', 'transformer_obj.dense.bias', 'transformer_obj.LayerNorm.weight',
+                     'transformer_obj.LayerNorm.bias', 'pred_obj_layer.proj.weight', 'pred_obj_layer.proj.bias',
+                     'mrfr_dense.weight', 'mrfr_dense.bias'):
+            out[name] = own[name]
         return out
 
     def _apply(self, fn, *a, **kw):
@@ -362,7 +369,14 @@ class TransformerModel(nn.Module):
             if first.stride(-1) != 1:
                 first = first.contiguous()
             return Fn.ItmHeadFn.apply(first, self)
-        if is_clcm or is_mrfr or is_obj:
-            raise NotImplementedError('CLCM / MRFR / MRM heads are SURVEY.md §8(f2) "next" rows')
+        if is_obj:
+            # transformer.py:1205-1210: (scores, loss) of the masked-region classification head; scores are
+            # not materialised for all B*R rows (only the masked rows enter the ignore_index mean)
+            return None, Fn.mrm_head(self, tensor, y)
+        if is_mrfr:
+            raise NotImplementedError('predict(is_mrfr=True) returns the regression of every region in the reference; '
+                                      'the fused masked loss is m3p_amd.functional.mrfr_head (used by XTrainer)')
+        if is_clcm:
+            raise NotImplementedError('the CLCM head is a SURVEY.md §8(f2) "next" row')
         loss, scores = Fn.mlm_head(self, tensor, pred_mask, y, bool(get_scores))
         return scores, loss

@@ -321,3 +321,26 @@ def itm_head_bwd(dscores, h16, pooled, W1_16, w2, dW1, db1, dw2, db2):
     dh32 = torch.zeros((B, d), dtype=torch.float32, device=dev)
     gemm_wgrad(dpreT16, W1_16, dh32, n=B)                # dh[b][k]  = sum_j dpre[b][j] W1[j][k]
     return dh32.to(BF16)
+
+
+def gelu_bwd(dy, u):
+    """du = dy * gelu_erf'(u) (bf16)."""
+    _chk_bf16(dy, u)
+    assert dy.shape == u.shape and dy.is_contiguous() and u.is_contiguous()
+    du = torch.empty_like(dy)
+    L.check(L.load().m3p_gelu_bwd(dy.data_ptr(), u.data_ptr(), du.data_ptr(), dy.numel(), L.stream()), 'm3p_gelu_bwd')
+    return du
+
+
+def mse_fwd_bwd(pred, tgt, grad_scale):
+    """pred bf16 [n, c], tgt fp32 [n, c] -> (sum of squared errors as a 1-element fp32 tensor, dpred bf16 = 2 (pred - tgt) grad_scale)."""
+    _chk_bf16(pred)
+    n, c = pred.shape
+    assert tgt.shape == (n, c) and tgt.dtype == torch.float32 and pred.stride(1) == 1 and tgt.stride(1) == 1
+    dpred = torch.empty_like(pred)
+    row_sq = torch.empty((n,), dtype=torch.float32, device=pred.device)
+    rc = L.load().m3p_mse_fwd_bwd(pred.data_ptr(), pred.stride(0), tgt.data_ptr(), tgt.stride(0), dpred.data_ptr(),
+                                  row_sq.data_ptr(), n, c, grad_scale, L.stream())
+    L.check(rc, 'm3p_mse_fwd_bwd')
+    return row_sq.sum().reshape(1), dpred
+

@@ -89,6 +89,36 @@ def hot_param_shapes(p):
     return out
 
 
+def region_head_param_shapes(p):
+    """Parameters of the two masked-region objectives: MRM = BertPredictionHeadTransform
+    (transformer.py:595-606) + ObjPredLayer (:562-584); MRFR = mrfr_dense (:718).  Kept apart from
+    hot_param_shapes so that the golden weight stream of the MLM+ITM goldens does not move."""
+    d = p.emb_dim
+    out = OrderedDict()
+    out['transformer_obj.dense.weight'] = (d, d)
+    out['transformer_obj.dense.bias'] = (d,)
+    out['transformer_obj.LayerNorm.weight'] = (d,)
+    out['transformer_obj.LayerNorm.bias'] = (d,)
+    out['pred_obj_layer.proj.weight'] = (1600, d)
+    out['pred_obj_layer.proj.bias'] = (1600,)
+    out['mrfr_dense.weight'] = (2048, d)
+    out['mrfr_dense.bias'] = (2048,)
+    return out
+
+
+def make_region_targets(R, B, seed=2468, p_mask=0.3, n_objs=1600):
+    """Synthetic MRM / MRFR targets: obj_labels (B, R) int64, -1 = region not masked, else the object class
+    of the masked region (xtrainer.py:2263, 2325-2328); ori_att_feats (B, R, 2048) fp32 = the original region
+    features the MRFR head regresses (xtrainer.py:2337-2346).  At least one region per batch is masked."""
+    rs = np.random.RandomState(seed)
+    masked = rs.rand(B, R) < p_mask
+    masked[0, 0] = True
+    labels = np.where(masked, rs.randint(0, n_objs, size=(B, R)), -1).astype(np.int64)
+    feats = rs.standard_normal((B, R, 2048)).astype(np.float32)
+    feats /= np.linalg.norm(feats, axis=-1, keepdims=True)
+    return dict(obj_labels=torch.from_numpy(labels), ori_att_feats=torch.from_numpy(feats))
+
+
 def golden_weight(name, shape, rs, scale=0.02):
     """One tensor of the golden weight stream: N(0,1)*scale, LayerNorm gains 1+that
     (SURVEY §8c 'Golden inputs')."""

@@ -237,7 +237,6 @@ class XTrainer(Trainer):
         model = self.model
         model.train()
         assert task_name == 't2i' or len(params.cross_clcm_steps) == 0, 'CLCM is a SURVEY §8(f2) "next" row'
-        assert len(params.cross_mrm_steps) == 0 and len(params.cross_mrfr_steps) == 0, 'MRM/MRFR are "next" rows'
         if task_name == 't2i':
             (x1, len1, x1_labels), (img, img_mask, img_loc, obj_labels, pos_labels, ori_att_feats, img_ids) = _batch
         else:
@@ -260,6 +259,17 @@ class XTrainer(Trainer):
             _, loss = model('predict', tensor=_text_out, pred_mask=pred_mask_text, y=y_text, get_scores=False)
             self._stat('CMLM-%s' % dataset, loss)
             total_loss = total_loss + lambda_coeff_mlm * loss
+        _img_out = encoder_outputs[:R].transpose(0, 1)          # (B, R, d), xtrainer.py:2288-2289
+        has_masked_region = bool((obj_labels != -1).any()) if torch.is_tensor(obj_labels) else False   # host tensor
+        if len(params.cross_mrm_steps) > 0 and has_masked_region:          # xtrainer.py:2320-2328
+            _, loss = model('predict', tensor=_img_out, pred_mask=None, y=obj_labels.reshape(-1), get_scores=False, is_obj=True)
+            self._stat('MRM-%s' % dataset, loss)
+            total_loss = total_loss + lambda_coeff_mrm * loss
+        if len(params.cross_mrfr_steps) > 0 and has_masked_region:         # xtrainer.py:2330-2352
+            from . import functional as Fn
+            loss = Fn.mrfr_head(model.module if hasattr(model, 'module') else model, _img_out, obj_labels, ori_att_feats)
+            self._stat('MRFR-%s' % dataset, loss)
+            total_loss = total_loss + lambda_coeff_mrfr * loss
         relation_scores = model('predict', tensor=encoder_outputs.transpose(0, 1), is_relation=True)
         loss = self._itm_loss(relation_scores, pos_labels)
         self._stat('%s-%s' % (task_name, dataset), loss)

@@ -249,7 +249,43 @@ def gen_text_and_itm_goldens():
     print('cfg1_text_itm.npz: text mlm %.6f rel4 ce %.6f bce %.6f' % (float(g['text_mlm_loss']), float(g['rel4_ce']), float(g['rel4_bce'])))
 
 
+def gen_region_head_goldens():
+    """MRM + MRFR heads on the cfg1 batch: the reference's predict(is_obj=True) /
+    predict(is_mrfr=True) and the trainer's masked MSE, with gradients of the head parameters and
+    of the encoder output they read."""
+    cfg = synth.CONFIGS['cfg1']
+    m, P, hot = build_reference_model(cfg)
+    m.eval()
+    rshapes = synth.region_head_param_shapes(P)
+    rsd = synth.golden_state_dict(rshapes, seed=4321, pad_index=None)
+    own = dict(m.named_parameters())
+    with torch.no_grad():
+        for k, v in rsd.items():
+            assert tuple(own[k].shape) == tuple(v.shape), (k, own[k].shape, v.shape)
+            own[k].copy_(v)
+    batch = synth.make_batch(cfg['T'], cfg['R'], cfg['B'], cfg['n_words'], cfg['n_pred'])
+    tg = synth.make_region_targets(cfg['R'], cfg['B'])
+    R = cfg['R']
+    for p_ in m.parameters():
+        p_.grad = None
+    out = m('jointfwd', x=batch['x'], lengths=batch['lengths'], x_img=batch['x_img'], lengths_img=batch['lengths_img'],
+            causal=False, langs=None, image_loc=batch['image_loc'], refine_image=False)
+    img_out = out[:R].transpose(0, 1).detach().clone().requires_grad_(True)
+    scores, mrm = m('predict', tensor=img_out, pred_mask=None, y=tg['obj_labels'].view(-1), get_scores=False, is_obj=True)
+    reg = m('predict', tensor=img_out, is_mrfr=True)
+    mask = tg['obj_labels'].reshape(-1) != -1
+    mrfr = torch.nn.functional.mse_loss(reg.reshape(-1, 2048)[mask], tg['ori_att_feats'].reshape(-1, 2048)[mask])
+    (mrm + mrfr).backward()
+    g = {'img_out': img_out.detach().numpy(), 'mrm_scores': scores.detach().numpy(), 'mrm_loss': mrm.detach().numpy(),
+         'mrfr_reg': reg.detach().numpy(), 'mrfr_loss': mrfr.detach().numpy(), 'd_img_out': img_out.grad.numpy()}
+    for k in rshapes:
+        g['grad/' + k] = own[k].grad.numpy()
+    np.savez_compressed(os.path.join(OUT, 'cfg1_region_heads.npz'), **g)
+    print('cfg1_region_heads.npz: mrm %.6f mrfr %.6f' % (float(mrm), float(mrfr)))
+
+
 if __name__ == '__main__':
+    gen_region_head_goldens()
     gen_text_and_itm_goldens()
     gen_unit_goldens()
     gen_model_goldens()

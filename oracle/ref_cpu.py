@@ -202,6 +202,37 @@ def predict_relation(sd, tensor):
     return F.linear(pooled, sd['seq_relationship.weight'], sd['seq_relationship.bias'])
 
 
+def bert_head_transform(sd, x, prefix='transformer_obj.'):
+    """BertPredictionHeadTransform.forward, transformer.py:595-606: LayerNorm(gelu(dense(x))), eps 1e-12."""
+    h = gelu_erf(F.linear(x, sd[prefix + 'dense.weight'], sd[prefix + 'dense.bias']))
+    return layer_norm(h, sd[prefix + 'LayerNorm.weight'], sd[prefix + 'LayerNorm.bias'])
+
+
+def predict_obj(sd, tensor, y):
+    """predict(is_obj=True), transformer.py:1205-1210 + ObjPredLayer.forward :575-584 (masked region
+    modelling): tensor (B, R, d) image part of the encoder output, batch-major; y (B*R,) object class of the
+    masked regions, -1 elsewhere; scores over 1600 classes, mean CE with ignore_index = -1."""
+    h = bert_head_transform(sd, tensor)
+    scores = F.linear(h, sd['pred_obj_layer.proj.weight'], sd['pred_obj_layer.proj.bias']).view(-1, 1600)
+    loss = F.cross_entropy(scores.float(), y, reduction='mean', ignore_index=-1)
+    return scores, loss
+
+
+def predict_mrfr(sd, tensor):
+    """predict(is_mrfr=True), transformer.py:1202-1204: mrfr_dense(tensor) -> (B, R, 2048)."""
+    return F.linear(tensor, sd['mrfr_dense.weight'], sd['mrfr_dense.bias'])
+
+
+def mrfr_loss(reg, obj_labels, ori_att_feats):
+    """xtrainer.py:2332-2352: MSE between the regressed and the original features of the masked regions."""
+    mask = obj_labels.reshape(-1) != -1
+    pred = reg.reshape(-1, 2048)[mask]
+    tgt = ori_att_feats.reshape(-1, 2048)[mask]
+    if pred.shape[0] == 0:
+        return torch.zeros((), dtype=reg.dtype)
+    return F.mse_loss(pred.float(), tgt.float())
+
+
 def itm_loss(relation_scores, pos_labels, sample_n, multi_w, bin_w):
     """XTrainer.pretrain_under_step ITM loss, M3P/src/xtrainer.py:2357-2372:
     CE over groups of sample_n scores + BCE-with-logits against the one-hot of the
@@ -213,10 +244,11 @@ def itm_loss(relation_scores, pos_labels, sample_n, multi_w, bin_w):
 
 
 def pretrain_losses(sd, n_layers, n_heads, batch, R, sample_n=2, multi_w=0.0, bin_w=1.0,
-                    with_itm=True, dropout=0.0, attention_dropout=0.0, keeps=None):
+                    with_itm=True, dropout=0.0, attention_dropout=0.0, keeps=None, with_mrm=False, with_mrfr=False):
     """The loss half of XTrainer.pretrain_under_step (xtrainer.py:2281-2375) for the
-    MLM (+ITM) objective: jointfwd -> text slice out[R:] -> MLM CE; whole sequence,
-    batch-major -> relation scores -> ITM loss; total = mlm + rel (lambdas = 1)."""
+    MLM (+MRM, +MRFR, +ITM) objective: jointfwd -> text slice out[R:] -> MLM CE; image slice out[:R],
+    batch-major -> masked-region classification / feature regression; whole sequence, batch-major ->
+    relation scores -> ITM loss; total = sum (lambdas = 1)."""
     out = jointfwd(sd, n_layers, n_heads, batch['x'], batch['lengths'], batch['x_img'],
                    batch['lengths_img'], batch['image_loc'], dropout, attention_dropout, keeps)
     res = {'out': out}
@@ -225,6 +257,15 @@ def pretrain_losses(sd, n_layers, n_heads, batch, R, sample_n=2, multi_w=0.0, bi
         _, mlm = predict_mlm(sd, out[R:], batch['pred_mask'], batch['y'])
         res['mlm'] = mlm
         total = total + mlm
+    img_out = out[:R].transpose(0, 1)          # (B, R, d), xtrainer.py:2288-2289
+    if with_mrm:
+        _, mrm = predict_obj(sd, img_out, batch['obj_labels'].reshape(-1))
+        res['mrm'] = mrm
+        total = total + mrm
+    if with_mrfr:
+        mrfr = mrfr_loss(predict_mrfr(sd, img_out), batch['obj_labels'], batch['ori_att_feats'])
+        res['mrfr'] = mrfr
+        total = total + mrfr
     if with_itm:
         rel = predict_relation(sd, out.transpose(0, 1))
         itm = itm_loss(rel, batch['pos_labels'], sample_n, multi_w, bin_w)

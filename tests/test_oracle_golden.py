@@ -178,3 +178,24 @@ def test_crossfwd_text_and_rel4(golden_dir):
     pos = _t(g['rel4_pos'])
     assert abs(float(O.itm_loss(rel, pos, 4, 1.0, 0.0)) - float(g['rel4_ce'])) < 1e-5
     assert abs(float(O.itm_loss(rel, pos, 4, 0.0, 1.0)) - float(g['rel4_bce'])) < 1e-5
+
+
+def test_region_heads_mrm_mrfr(golden_dir):
+    """MRM (BertPredictionHeadTransform + ObjPredLayer, ignore_index CE) and MRFR (mrfr_dense + masked MSE):
+    the oracle's restatement against the reference's own outputs and gradients."""
+    g = _load(golden_dir, 'cfg1_region_heads.npz')
+    cfg = synth.CONFIGS['cfg1']
+    P = synth.model_params(cfg['emb_dim'], cfg['n_heads'], cfg['n_layers'], cfg['n_words'])
+    rshapes = synth.region_head_param_shapes(P)
+    sd = {k: v.clone().requires_grad_(True) for k, v in synth.golden_state_dict(rshapes, seed=4321, pad_index=None).items()}
+    tg = synth.make_region_targets(cfg['R'], cfg['B'])
+    x = _t(g['img_out']).clone().requires_grad_(True)
+    scores, mrm = O.predict_obj(sd, x, tg['obj_labels'].reshape(-1))
+    reg = O.predict_mrfr(sd, x)
+    mrfr = O.mrfr_loss(reg, tg['obj_labels'], tg['ori_att_feats'])
+    assert rel_l2(scores.detach(), g['mrm_scores']) < 1e-6 and abs(float(mrm) - float(g['mrm_loss'])) < 1e-6
+    assert rel_l2(reg.detach(), g['mrfr_reg']) < 1e-6 and abs(float(mrfr) - float(g['mrfr_loss'])) < 1e-7
+    (mrm + mrfr).backward()
+    assert rel_l2(x.grad, g['d_img_out']) < 1e-5
+    for k in rshapes:
+        assert rel_l2(sd[k].grad, g['grad/' + k]) < 1e-5, k

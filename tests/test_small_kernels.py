@@ -199,3 +199,21 @@ def test_itm_head_fwd_bwd(B, S, d):
     assert rel_l2(dh.float(), x.grad) < 8e-3
     assert rel_l2(db1, P[1].grad) < 6e-3 and rel_l2(dw2, P[2].grad) < 6e-3 and rel_l2(db2, P[3].grad) < 1e-5
     assert rel_l2(dW1, P[0].grad) < 8e-3
+
+
+def test_gelu_bwd_and_mse_kernels():
+    from m3p_amd import ops
+    dy, dyc = randn_bf16((77, 128), 1)
+    u, uc = randn_bf16((77, 128), 2, 2.0)
+    du = ops.gelu_bwd(dy, u)
+    x = uc.double().requires_grad_(True)
+    (0.5 * x * (1 + torch.erf(x / 2 ** 0.5))).backward(dyc.double())
+    assert rel_l2(du.float(), x.grad) < 4e-3
+    pred, pc = randn_bf16((23, 2048), 3)
+    tgt, tc = randn_f32((23, 2048), 4)
+    sq, dpred = ops.mse_fwd_bwd(pred, tgt, 1.0 / (23 * 2048))
+    p = pc.clone().requires_grad_(True)
+    ref = F.mse_loss(p, tc)
+    ref.backward()
+    assert abs(float(sq) / (23 * 2048) - float(ref)) < 1e-5 * float(ref)
+    assert rel_l2(dpred.float(), p.grad) < 4e-3
