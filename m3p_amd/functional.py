@@ -496,17 +496,19 @@ def mrfr_head(model, tensor, obj_labels, ori_att_feats):
 
 
 class ItmHeadFn(torch.autograd.Function):
-    """BertPooler + seq_relationship (transformer.py:546-558, :1194-1197): the d x d products on the
-    bf16 GEMMs, tanh / score / derivative glue in csrc/itm.hip.  Parameter gradients accumulate
-    straight into the gradient arena (main-grad)."""
+    """BertPooler + relation head: (pooled_layer, seq_relationship) for ITM (transformer.py:546-558, :1194-1197)
+    or (pooled_layer2, seq_relationship2) for the CLCM pass (:1198-1201).  The d x d products run on the bf16
+    GEMMs, tanh / score / derivative glue in csrc/itm.hip.  Parameter gradients accumulate straight into the
+    gradient arena (main-grad)."""
 
     @staticmethod
-    def forward(ctx, first, model):
+    def forward(ctx, first, model, pooler='pooled_layer', rel='seq_relationship'):
         ar = model.arena()
-        h16, pooled, scores = ops.itm_head_fwd(first, ar.w('pooled_layer.dense.weight'), ar.p('pooled_layer.dense.bias').detach(),
-                                               ar.p('seq_relationship.weight').detach().view(-1),
-                                               ar.p('seq_relationship.bias').detach())
+        ar.refresh()
+        h16, pooled, scores = ops.itm_head_fwd(first, ar.w(pooler + '.dense.weight'), ar.p(pooler + '.dense.bias').detach(),
+                                               ar.p(rel + '.weight').detach().view(-1), ar.p(rel + '.bias').detach())
         ctx.model = model
+        ctx.names = (pooler, rel)
         ctx.saved = (h16, pooled)
         ctx.set_materialize_grads(False)
         return scores.view(-1, 1)
@@ -514,18 +516,18 @@ class ItmHeadFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dscores):
         if dscores is None:
-            return None, None
+            return None, None, None, None
         model = ctx.model
         ar = model.arena()
+        pooler, rel = ctx.names
         h16, pooled = ctx.saved
         ctx.saved = None
         ds = dscores.reshape(-1).float().contiguous()
-        dh = ops.itm_head_bwd(ds, h16, pooled, ar.w('pooled_layer.dense.weight'),
-                              ar.p('seq_relationship.weight').detach().view(-1),
-                              ar.g('pooled_layer.dense.weight'), ar.g('pooled_layer.dense.bias'),
-                              ar.g('seq_relationship.weight').view(-1), ar.g('seq_relationship.bias'))
-        ar.touch('pooled_layer.dense.weight', 'pooled_layer.dense.bias', 'seq_relationship.weight', 'seq_relationship.bias')
-        return dh, None
+        dh = ops.itm_head_bwd(ds, h16, pooled, ar.w(pooler + '.dense.weight'), ar.p(rel + '.weight').detach().view(-1),
+                              ar.g(pooler + '.dense.weight'), ar.g(pooler + '.dense.bias'),
+                              ar.g(rel + '.weight').view(-1), ar.g(rel + '.bias'))
+        ar.touch(pooler + '.dense.weight', pooler + '.dense.bias', rel + '.weight', rel + '.bias')
+        return dh, None, None, None
 
 
 def mlm_head(model, tensor, pred_mask, y, want_scores):

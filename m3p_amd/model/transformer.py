@@ -286,7 +286,8 @@ class TransformerModel(nn.Module):
         own = dict(self.named_parameters())
         for name in ('transformer_obj.dense.weight', 'transformer_obj.dense.bias', 'transformer_obj.LayerNorm.weight',
                      'transformer_obj.LayerNorm.bias', 'pred_obj_layer.proj.weight', 'pred_obj_layer.proj.bias',
-                     'mrfr_dense.weight', 'mrfr_dense.bias'):
+                     'mrfr_dense.weight', 'mrfr_dense.bias', 'pooled_layer2.dense.weight', 'pooled_layer2.dense.bias',
+                     'seq_relationship2.weight', 'seq_relationship2.bias'):
             out[name] = own[name]
         return out
 
@@ -360,14 +361,16 @@ class TransformerModel(nn.Module):
     def predict(self, tensor, pred_mask=None, y=None, get_scores=None, is_obj=False, is_relation=False,
                 is_mrfr=False, is_clcm=False):
         """transformer.py:1183-1214."""
-        if is_relation:
-            # BertPooler (:546-558) + seq_relationship on the HIP kernels of csrc/itm.hip (fp32 math on
-            # the master weights; the score stays on the device - the reference moves it to the CPU)
+        if is_relation or is_clcm:
+            # BertPooler (:546-558) + seq_relationship (:1194-1197), or the second pair for the CLCM pass
+            # (:1198-1201): GEMMs + csrc/itm.hip; the score stays on the device (the reference moves it to the CPU)
             first = tensor[:, 0]
             if first.dtype != Fn.BF16:
                 first = first.to(Fn.BF16)
             if first.stride(-1) != 1:
                 first = first.contiguous()
+            if is_clcm:
+                return Fn.ItmHeadFn.apply(first, self, 'pooled_layer2', 'seq_relationship2')
             return Fn.ItmHeadFn.apply(first, self)
         if is_obj:
             # transformer.py:1205-1210: (scores, loss) of the masked-region classification head; scores are
@@ -376,7 +379,5 @@ class TransformerModel(nn.Module):
         if is_mrfr:
             raise NotImplementedError('predict(is_mrfr=True) returns the regression of every region in the reference; '
                                       'the fused masked loss is m3p_amd.functional.mrfr_head (used by XTrainer)')
-        if is_clcm:
-            raise NotImplementedError('the CLCM head is a SURVEY.md §8(f2) "next" row')
         loss, scores = Fn.mlm_head(self, tensor, pred_mask, y, bool(get_scores))
         return scores, loss

@@ -106,6 +106,17 @@ def region_head_param_shapes(p):
     return out
 
 
+def clcm_head_param_shapes(p):
+    """Second pooler + relation head of the cross-lingual contrastive pass (transformer.py:715-716, :1198-1201)."""
+    d = p.emb_dim
+    out = OrderedDict()
+    out['pooled_layer2.dense.weight'] = (d, d)
+    out['pooled_layer2.dense.bias'] = (d,)
+    out['seq_relationship2.weight'] = (1, d)
+    out['seq_relationship2.bias'] = (1,)
+    return out
+
+
 def make_region_targets(R, B, seed=2468, p_mask=0.3, n_objs=1600):
     """Synthetic MRM / MRFR targets: obj_labels (B, R) int64, -1 = region not masked, else the object class
     of the masked region (xtrainer.py:2263, 2325-2328); ori_att_feats (B, R, 2048) fp32 = the original region

@@ -236,7 +236,6 @@ class XTrainer(Trainer):
         params = self.params
         model = self.model
         model.train()
-        assert task_name == 't2i' or len(params.cross_clcm_steps) == 0, 'CLCM is a SURVEY §8(f2) "next" row'
         if task_name == 't2i':
             (x1, len1, x1_labels), (img, img_mask, img_loc, obj_labels, pos_labels, ori_att_feats, img_ids) = _batch
         else:
@@ -274,6 +273,16 @@ class XTrainer(Trainer):
         loss = self._itm_loss(relation_scores, pos_labels)
         self._stat('%s-%s' % (task_name, dataset), loss)
         total_loss = total_loss + lambda_coeff_rel * loss
+
+        if task_name == 'i2t' and len(params.cross_clcm_steps) > 0:        # xtrainer.py:2379-2393
+            x2c, len2c = to_cuda(x2, len2)
+            encoder_outputs2 = model('jointfwd', x=x2c, lengths=len2c, x_img=x_img, lengths_img=img_len, causal=False,
+                                     langs=None, image_loc=img_loc, refine_image=params.refine_image)
+            relation_scores2 = model('predict', tensor=encoder_outputs2.transpose(0, 1), is_clcm=True)
+            target2 = torch.as_tensor(clcm_labels).reshape(-1).to(device=relation_scores2.device, dtype=torch.float32)
+            loss = F.binary_cross_entropy_with_logits(relation_scores2.view(-1).float(), target2)
+            self._stat('CLCM-%s' % dataset, loss)
+            total_loss = total_loss + loss
 
         self.optimize(total_loss)
         self.n_sentences += params.batch_size

@@ -284,7 +284,40 @@ def gen_region_head_goldens():
     print('cfg1_region_heads.npz: mrm %.6f mrfr %.6f' % (float(mrm), float(mrfr)))
 
 
+def gen_clcm_goldens():
+    """CLCM second pass: reference jointfwd on (regions, second caption) + predict(is_clcm=True)
+    + BCE, with the gradients of the second head and a few encoder parameters."""
+    cfg = synth.CONFIGS['cfg1']
+    m, P, hot = build_reference_model(cfg)
+    m.eval()
+    cshapes = synth.clcm_head_param_shapes(P)
+    csd = synth.golden_state_dict(cshapes, seed=9753, pad_index=None)
+    own = dict(m.named_parameters())
+    with torch.no_grad():
+        for k, v in csd.items():
+            assert tuple(own[k].shape) == tuple(v.shape), (k, own[k].shape, v.shape)
+            own[k].copy_(v)
+    batch = synth.make_batch(cfg['T'], cfg['R'], cfg['B'], cfg['n_words'], cfg['n_pred'])
+    b2 = synth.make_batch(cfg['T'], cfg['R'], cfg['B'], cfg['n_words'], cfg['n_pred'], seed=8642)   # the other caption
+    clcm_labels = torch.tensor([1, 0, 0, 1, 1, 0, 1, 0])
+    for p_ in m.parameters():
+        p_.grad = None
+    out2 = m('jointfwd', x=b2['x'], lengths=b2['lengths'], x_img=batch['x_img'], lengths_img=batch['lengths_img'],
+             causal=False, langs=None, image_loc=batch['image_loc'], refine_image=False)
+    rel2 = m('predict', tensor=out2.transpose(0, 1), is_clcm=True)
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(rel2.view(-1), clcm_labels.float())
+    loss.backward()
+    g = {'clcm_labels': clcm_labels.numpy(), 'rel2': rel2.detach().numpy(), 'clcm_loss': loss.detach().numpy()}
+    for k in cshapes:
+        g['grad/' + k] = own[k].grad.numpy()
+    for k in ('layer_norm2.1.weight', 'attentions.0.q_lin.bias', 'ffns.1.lin2.bias'):
+        g['grad/' + k] = own[k].grad.numpy()
+    np.savez_compressed(os.path.join(OUT, 'cfg1_clcm.npz'), **g)
+    print('cfg1_clcm.npz: clcm bce %.6f' % float(loss))
+
+
 if __name__ == '__main__':
+    gen_clcm_goldens()
     gen_region_head_goldens()
     gen_text_and_itm_goldens()
     gen_unit_goldens()

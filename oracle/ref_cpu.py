@@ -233,6 +233,21 @@ def mrfr_loss(reg, obj_labels, ori_att_feats):
     return F.mse_loss(pred.float(), tgt.float())
 
 
+def predict_clcm(sd, tensor):
+    """predict(is_clcm=True): transformer.py:1198-1201 - the second BertPooler + Linear(d, 1) on the joint
+    encoding of the images with the OTHER caption (xtrainer.py:2379-2393)."""
+    pooled = torch.tanh(F.linear(tensor[:, 0], sd['pooled_layer2.dense.weight'], sd['pooled_layer2.dense.bias']))
+    return F.linear(pooled, sd['seq_relationship2.weight'], sd['seq_relationship2.bias'])
+
+
+def clcm_loss(sd, n_layers, n_heads, batch, x2, len2, clcm_labels):
+    """The CLCM second pass of pretrain_under_step (i2t task, xtrainer.py:2379-2393): jointfwd of the same
+    regions with caption x2, relation scores through the second head, BCE-with-logits against clcm_labels."""
+    out2 = jointfwd(sd, n_layers, n_heads, x2, len2, batch['x_img'], batch['lengths_img'], batch['image_loc'])
+    rel2 = predict_clcm(sd, out2.transpose(0, 1))
+    return F.binary_cross_entropy_with_logits(rel2.view(-1).float(), clcm_labels.view(-1).float()), rel2
+
+
 def itm_loss(relation_scores, pos_labels, sample_n, multi_w, bin_w):
     """XTrainer.pretrain_under_step ITM loss, M3P/src/xtrainer.py:2357-2372:
     CE over groups of sample_n scores + BCE-with-logits against the one-hot of the

@@ -199,3 +199,20 @@ def test_region_heads_mrm_mrfr(golden_dir):
     assert rel_l2(x.grad, g['d_img_out']) < 1e-5
     for k in rshapes:
         assert rel_l2(sd[k].grad, g['grad/' + k]) < 1e-5, k
+
+
+def test_clcm_second_pass(golden_dir):
+    """CLCM (xtrainer.py:2379-2393): second jointfwd on (regions, other caption) + predict(is_clcm=True) + BCE."""
+    g = _load(golden_dir, 'cfg1_clcm.npz')
+    cfg = synth.CONFIGS['cfg1']
+    P = synth.model_params(cfg['emb_dim'], cfg['n_heads'], cfg['n_layers'], cfg['n_words'])
+    sd = dict(synth.golden_state_dict(synth.hot_param_shapes(P)))
+    sd.update(synth.golden_state_dict(synth.clcm_head_param_shapes(P), seed=9753, pad_index=None))
+    sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    batch = synth.make_batch(cfg['T'], cfg['R'], cfg['B'], cfg['n_words'], cfg['n_pred'])
+    b2 = synth.make_batch(cfg['T'], cfg['R'], cfg['B'], cfg['n_words'], cfg['n_pred'], seed=8642)
+    loss, rel2 = O.clcm_loss(sd, cfg['n_layers'], cfg['n_heads'], batch, b2['x'], b2['lengths'], _t(g['clcm_labels']))
+    assert rel_l2(rel2.detach(), g['rel2']) < 1e-5 and abs(float(loss) - float(g['clcm_loss'])) < 1e-6
+    loss.backward()
+    for k in [k[5:] for k in g if k.startswith('grad/')]:
+        assert rel_l2(sd[k].grad, g['grad/' + k]) < 1e-4, k
