@@ -238,6 +238,30 @@ void gemm_nt_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict_
 constexpr int EP_PITCH = 144;                 // bytes per staged row: 128 + 16 (16-B aligned, rotates banks)
 constexpr int EP_HALF = 32 * EP_PITCH;        // 4608 B per wave half-tile
 
+// gelu_erf'(u) of a bf16 u is a function of 16 bits: the dGELU epilogue looks it up instead of
+// evaluating erf/exp (~20 exposed VALU instructions per element).  The table covers |u| in
+// [2^-15, 8) (exponents -15..2 x 128 mantissas = 2304 fp32 entries, 9 KB of LDS), holds exactly what
+// gelu_erf_grad_f returns for that bf16 value, gelu'(-u) = 1 - gelu'(u); below 2^-15 the linear
+// term 0.5 + 0.79788 u is exact to 1e-13, from 8 up the derivative is 1 to 1e-14.
+#ifndef M3P_DGELU_LUT
+#define M3P_DGELU_LUT 1
+#endif
+constexpr int GELU_TAB_LO = 0x3800, GELU_TAB_HI = 0x4100, GELU_TAB_N = GELU_TAB_HI - GELU_TAB_LO;
+__device__ __forceinline__ void gelu_grad_table_fill(float* tab, int tid, int nthreads) {
+  for (int i = tid; i < GELU_TAB_N; i += nthreads) {
+    const uint16_t bits = (uint16_t)(GELU_TAB_LO + i);
+    tab[i] = gelu_erf_grad_f((float)__builtin_bit_cast(bf16, bits));
+  }
+}
+__device__ __forceinline__ float gelu_grad_lookup(const float* tab, bf16 u) {
+  const uint32_t b = __builtin_bit_cast(uint16_t, u);
+  const int a = (int)(b & 0x7FFFu);
+  float t = tab[min(max(a - GELU_TAB_LO, 0), GELU_TAB_N - 1)];
+  if (a < GELU_TAB_LO) t = 0.5f + 0.79788456f * fabsf((float)u);
+  if (a >= GELU_TAB_HI) t = 1.0f;
+  return (b & 0x8000u) ? 1.0f - t : t;
+}
+
 // bias values of the four 16-column tiles starting at column nw for this lane (columns nw + 16 j + 4 (lane >> 4) ..+3)
 template <int EPI>
 __device__ __forceinline__ void load_bias4(const M3PEpilogue& ep, int nw, int lane, f32x4 (&biasv)[4]) {
@@ -264,7 +288,8 @@ __device__ __forceinline__ void load_aux(const M3PEpilogue& ep, int mrow0, int n
 template <int EPI>
 __device__ __forceinline__ void epilogue_half(const M3PEpilogue& ep, bf16* __restrict__ C, int ldc, int N,
                                               int mrow0, int nw, char* r1, const f32x4 (&rows)[2][4],
-                                              const f32x4 (&biasv)[4], const bf16x4 (&auxv)[2][4], int lane, f32x4 (&csum)[4]) {
+                                              const f32x4 (&biasv)[4], const bf16x4 (&auxv)[2][4], int lane, f32x4 (&csum)[4],
+                                              const float* gtab = nullptr) {
   const int fr = lane & 15, fg = lane >> 4;
   const int srow = lane >> 3, sch = lane & 7;
   constexpr bool kAux = (EPI == M3P_EPI_BIAS_DROP_RES || EPI == M3P_EPI_RES || EPI == M3P_EPI_DGELU || EPI == M3P_EPI_MUL);
@@ -305,8 +330,13 @@ __device__ __forceinline__ void epilogue_half(const M3PEpilogue& ep, bf16* __res
         const bf16x4 t = auxv[ii][j];       // residual / pre-activation tile, fetched by the caller ahead of time
         const f32x4 a = f32x4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
         if (EPI == M3P_EPI_DGELU) {
+          if (gtab) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_grad_f(a[r]);
+            for (int r = 0; r < 4; ++r) v[r] *= gelu_grad_lookup(gtab, t[r]);
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_grad_f(a[r]);
+          }
         } else if (EPI == M3P_EPI_MUL) {
           v *= a;
         } else {
@@ -391,6 +421,9 @@ void gemm_nt_ring_kernel(const bf16* __restrict__ A, int lda, const bf16* __rest
   auto tile_of = [&](int q) { return q * nwg + slot; };
   const int my_tiles = (ntiles > slot) ? (ntiles - slot + nwg - 1) / nwg : 0;
   if (my_tiles == 0) return;
+  // dGELU: derivative table behind the three stages (visible to everyone after the first K-tile barrier)
+  float* gtab = (EPI == M3P_EPI_DGELU && M3P_DGELU_LUT) ? reinterpret_cast<float*>(smem + 3 * STAGE) : nullptr;
+  if (EPI == M3P_EPI_DGELU && M3P_DGELU_LUT) gelu_grad_table_fill(gtab, tid, 512);
   const int nk = K / BK;
   const int total = my_tiles * nk;
 
@@ -533,7 +566,7 @@ void gemm_nt_ring_kernel(const bf16* __restrict__ A, int lda, const bf16* __rest
           bf16x4 auxv[2][4];
           load_bias4<EPI>(ep, nw, lane, biasv);
           load_aux<EPI>(ep, mw + 32 * hf, nw, lane, auxv);
-          epilogue_half<EPI>(ep, C, ldc, N, mw + 32 * hf, nw, r1, rows, biasv, auxv, lane, csum);
+          epilogue_half<EPI>(ep, C, ldc, N, mw + 32 * hf, nw, r1, rows, biasv, auxv, lane, csum, gtab);
         }
       } else {
 #pragma unroll
@@ -1236,7 +1269,7 @@ int launch_nt(const bf16* A, int lda, const bf16* W, int ldw, bf16* C, int ldc, 
   if (M >= 1024 && g_variant >= 1) {
     constexpr int BM = 256, BN = 128;
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
-    const size_t lds = 3 * (BM + BN) * ROWB;
+    const size_t lds = 3 * (BM + BN) * ROWB + (EPI == M3P_EPI_DGELU && M3P_DGELU_LUT ? GELU_TAB_N * sizeof(float) : 0);
     auto kern = gemm_nt_ring_kernel<EPI>;
     static bool attr_set = false;
     if (!attr_set) {
