@@ -23,6 +23,15 @@
 
 namespace {
 
+// -DM3P_ATTN_TL: debug build that stamps s_memtime at the forward kernel's phase boundaries
+// (tools/attn_timeline.py reads them back through m3p_debug_attn_timeline).
+#ifdef M3P_ATTN_TL
+__device__ unsigned long long g_attn_tl[4096 * 4 * 16];
+#define ATL(k) do { if (blockIdx.x < 4096 && lane == 0) g_attn_tl[(blockIdx.x * 4 + wid) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define ATL(k) do { } while (0)
+#endif
+
 template <int DH> struct AttnCfg {
   static constexpr int ROWB = DH * 2;        // bytes per K/V row in LDS
   static constexpr int CH = DH / 8;          // 16-B chunks per row
@@ -60,8 +69,10 @@ __device__ __forceinline__ void stage_rows(const bf16* __restrict__ g, size_t ld
 // ---------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------
-template <int DH, int KT, bool DROP>
-__global__ __launch_bounds__(256)
+// NTC: number of 16-key tiles known at compile time (11 = the M3P sequence, 36 regions + 128 tokens = 164 keys) so the
+// per-tile guards fold away (they compiled to ~90 uniform branches and the SGPR pressure behind ~220 lane spills); 0 = runtime.
+template <int DH, int KT, bool DROP, int NTC>
+__global__ __launch_bounds__(256, 3)   // three ~48-KB workgroups per CU (S = 164): 168 registers per lane
 void attn_fwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keylen, bf16* __restrict__ ctx,
                      float* __restrict__ lse, unsigned long long* __restrict__ keepmask, int S, int H, int dmodel,
                      uint32_t seed, uint32_t thresh24, float inv_keep) {
@@ -70,20 +81,36 @@ void attn_fwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.x / H, h = blockIdx.x - b * H;
-  const int nt = (S + 15) >> 4;    // 16-key tiles == 16-query blocks
-  const int nk = (S + 31) >> 5;    // 32-key MFMA steps of P V
+  const int nt = NTC ? NTC : (S + 15) >> 4;    // 16-key tiles == 16-query blocks
+  const int nk = (nt + 1) >> 1;                // 32-key MFMA steps of P V
   const size_t ld = 3 * (size_t)dmodel;
   const bf16* Qg = qkv + (size_t)b * S * ld + h * DH;
   const bf16* Kg = Qg + dmodel;
   const bf16* Vg = Qg + 2 * dmodel;
   char* sK = smem;
   char* sV = smem + nt * 16 * Cf::ROWB;
+  ATL(0);
+#ifdef M3P_ATTN_TL
+  if (blockIdx.x < 4096 && lane == 0) g_attn_tl[(blockIdx.x * 4 + wid) * 16 + 14] = __builtin_amdgcn_s_memrealtime();
+#endif
   stage_rows<DH>(Kg, ld, S, nt * 16, sK, wid, lane);
   stage_rows<DH>(Vg, ld, S, nk * 32, sV, wid, lane);
-  const int klen = keylen[b];
-  __syncthreads();
-
   const int fq = lane & 15, fg = lane >> 4;
+  // query blocks go round-robin over the four waves; the starting wave rotates with the workgroup id so
+  // that the waves with one block fewer (nt % 4 != 0) do not always land on the same SIMDs of a CU
+  const int wrot = (wid + (blockIdx.x >> 3)) & 3;
+  bf16x8 qnext[Cf::KK];
+  {
+    const int qc0 = min(wrot * 16 + fq, S - 1);
+#pragma unroll
+    for (int kk = 0; kk < Cf::KK; ++kk)
+      qnext[kk] = *reinterpret_cast<const bf16x8*>(Qg + (size_t)qc0 * ld + 32 * kk + 8 * fg);
+  }
+  const int klen = keylen[b];
+  ATL(1);
+  __syncthreads();
+  ATL(2);
+
   // K fragment: row 16t + fq, chunk (4kk + fg) swizzled with row & 7 == fq & 7
   int k_off[Cf::KK];
 #pragma unroll
@@ -95,39 +122,50 @@ void attn_fwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
   for (int n = 0; n < Cf::NT; ++n)
     v_off[n] = vrow * Cf::ROWB + Cf::swz(2 * n + ((fq & 3) >> 1), vrow) * 16 + 8 * (fq & 1);
 
-  for (int qb = wid; qb < nt; qb += 4) {
+  for (int qb = wrot; qb < nt; qb += 4) {
     const int q = qb * 16 + fq;
     const int qc = min(q, S - 1);
     bf16x8 qf[Cf::KK];
 #pragma unroll
-    for (int kk = 0; kk < Cf::KK; ++kk)
-      qf[kk] = *reinterpret_cast<const bf16x8*>(Qg + (size_t)qc * ld + 32 * kk + 8 * fg);
+    for (int kk = 0; kk < Cf::KK; ++kk) qf[kk] = qnext[kk];
+    {  // prefetch the next block's Q fragments: the global-load latency hides behind this block's work
+      const int qcn = min(q + 64, S - 1);
+#pragma unroll
+      for (int kk = 0; kk < Cf::KK; ++kk)
+        qnext[kk] = *reinterpret_cast<const bf16x8*>(Qg + (size_t)qcn * ld + 32 * kk + 8 * fg);
+    }
 
     f32x4 s[2 * KT];
 #pragma unroll
-    for (int t = 0; t < 2 * KT; ++t) {
-      s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (t < nt) {
+    for (int t = 0; t < 2 * KT; ++t) s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // k-step outermost: consecutive MFMAs write different tiles (no dependent-issue bubbles)
 #pragma unroll
-        for (int kk = 0; kk < Cf::KK; ++kk) {
+    for (int kk = 0; kk < Cf::KK; ++kk) {
+#pragma unroll
+      for (int t = 0; t < 2 * KT; ++t)
+        if (t < nt) {
           const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + t * 16 * Cf::ROWB + k_off[kk]);
           s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], s[t], 0, 0, 0);
         }
-      }
     }
+    if (qb == wrot) ATL(3);
     // ---- softmax over keys (key = 16t + 4fg + r) for query column fq; tiles t >= nt are padding
     constexpr float kLog2e = 1.4426950408889634f;
     float mx = -INFINITY;
+    // keys >= klen are masked to -inf.  Only the tile that straddles klen (and padded tiles behind it) needs
+    // per-element compares: the test per tile is wave-uniform.  (Written per element, the 4 nt compares are
+    // loop-invariant lane masks: the compiler hoisted them into ~90 SGPRs and spilled those to VGPR lanes.)
+    int klen_it = klen;
+    asm volatile("" : "+s"(klen_it));
 #pragma unroll
     for (int t = 0; t < 2 * KT; ++t)
       if (t < nt) {
+        if (16 * t + 16 > klen_it) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = 16 * t + 4 * fg + r;
-          const float v = (key < klen) ? s[t][r] : -INFINITY;
-          s[t][r] = v;
-          mx = fmaxf(mx, v);
+          for (int r = 0; r < 4; ++r) s[t][r] = (16 * t + 4 * fg + r < klen_it) ? s[t][r] : -INFINITY;
         }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[t][r]);
       }
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
@@ -146,42 +184,51 @@ void attn_fwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.0f / sum;
+    if (qb == wrot) ATL(4);
     const uint32_t rbase = (uint32_t)((b * H + h) * S + qc) * (uint32_t)S;
+    const uint32_t thr32 = thresh24 << 8;   // (hash >> 8) >= thresh24  <=>  hash >= thresh24 << 8  (thresh24 < 2^24: p < 1)
     // keep-mask words for backward: word [qb][t][r], bit l = keep(query 16qb + (l & 15),
     // key 16t + 4(l >> 4) + r) - the compare's lane mask as it comes out of the VALU
     unsigned long long* mrow = keepmask ? keepmask + ((size_t)(b * H + h) * nt + qb) * nt * 4 : nullptr;
+    // The ballot of compare (t, r) is dropped into lane (4t + r) & 63 of a register pair (v_writelane), so a
+    // query block's words leave as one coalesced 8-byte-per-lane store (single-lane 16-byte stores cost 19 us).
+    constexpr int MW = (8 * KT + 63) / 64;
+    uint32_t mlo[MW], mhi[MW];
+#pragma unroll
+    for (int g = 0; g < MW; ++g) mlo[g] = mhi[g] = 0u;
     bf16x8 pf[KT];
 #pragma unroll
     for (int kk = 0; kk < KT; ++kk) {
       float p[8];
-      unsigned long long kw[8];
       const float invk = DROP ? inv * inv_keep : inv;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int t = 2 * kk + (j >> 2), r = j & 3;
         float v = 0.f;
-        kw[j] = 0;
         if (t < nt) {
           v = s[t][r] * invk;
           if (DROP) {
             const int key = 16 * t + 4 * fg + r;
-            const bool keep = m3p_keep(rbase + (uint32_t)key, seed, thresh24);
-            kw[j] = __builtin_amdgcn_ballot_w64(keep);
+            const bool keep = m3p_hash32(rbase + (uint32_t)key, seed) >= thr32;   // == m3p_keep(idx, seed, thresh24)
+            const unsigned long long kw = __builtin_amdgcn_ballot_w64(keep);
+            // (s_nop: a v_writelane that reads an SGPR the v_cmp just wrote gets the stale value without wait
+            //  states - measured; the assembler does not insert them for inline asm)
+            asm("s_nop 3\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4"
+                : "+v"(mlo[(4 * t + r) >> 6]), "+v"(mhi[(4 * t + r) >> 6])
+                : "s"((uint32_t)kw), "s"((uint32_t)(kw >> 32)), "i"((4 * t + r) & 63));
             v = keep ? v : 0.f;
           }
         }
         p[j] = v;
       }
-      if (DROP && mrow && lane == 0) {
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf)
-          if (2 * kk + hf < nt) {
-            unsigned long long* mp = mrow + (2 * kk + hf) * 4;
-            mp[0] = kw[4 * hf + 0]; mp[1] = kw[4 * hf + 1]; mp[2] = kw[4 * hf + 2]; mp[3] = kw[4 * hf + 3];
-          }
-      }
       pf[kk] = bf16x8{(bf16)p[0], (bf16)p[1], (bf16)p[2], (bf16)p[3], (bf16)p[4], (bf16)p[5], (bf16)p[6], (bf16)p[7]};
     }
+    if (DROP && mrow) {
+#pragma unroll
+      for (int g = 0; g < MW; ++g)
+        if (64 * g + lane < 4 * nt) mrow[64 * g + lane] = ((unsigned long long)mhi[g] << 32) | mlo[g];
+    }
+    if (qb == wrot) ATL(5);
     // ---- O^T[d][q] = sum_key V[key][d] P[q][key]
     f32x4 o[Cf::NT];
 #pragma unroll
@@ -197,6 +244,7 @@ void attn_fwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
         }
       }
     }
+    if (qb == wrot) ATL(6);
     if (q < S) {
       bf16* op = ctx + (size_t)(b * S + q) * dmodel + h * DH + 4 * fg;
 #pragma unroll
@@ -204,7 +252,12 @@ void attn_fwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
         *reinterpret_cast<bf16x4*>(op + 16 * n) = bf16x4{(bf16)o[n][0], (bf16)o[n][1], (bf16)o[n][2], (bf16)o[n][3]};
       if (fg == 0) lse[(size_t)(b * H + h) * S + q] = mx + __logf(sum);
     }
+    if (qb == wrot) ATL(7);
   }
+  ATL(8);
+#ifdef M3P_ATTN_TL
+  if (blockIdx.x < 4096 && lane == 0) g_attn_tl[(blockIdx.x * 4 + wid) * 16 + 15] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // ---------------------------------------------------------------------------------------
@@ -545,7 +598,8 @@ int launch_fwd(const bf16* qkv, const int* keylen, bf16* ctx, float* lse, unsign
   const size_t lds = (size_t)(nt * 16 + nk * 32) * DH * 2;
 #define M3P_ATTN_FWD(KT)                                                                                        \
   do {                                                                                                          \
-    auto kern = thresh24 ? attn_fwd_kernel<DH, KT, true> : attn_fwd_kernel<DH, KT, false>;                                                                        \
+    auto kern = thresh24 ? attn_fwd_kernel<DH, KT, true, 0> : attn_fwd_kernel<DH, KT, false, 0>;                                                                \
+    if (nt == 11 && KT == 6) kern = thresh24 ? attn_fwd_kernel<DH, 6, true, 11> : attn_fwd_kernel<DH, 6, false, 11>;                                                                        \
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     if (e != hipSuccess) return (int)e;                                                                         \
     hipLaunchKernelGGL(kern, dim3(B* H), dim3(256), lds, st, qkv, keylen, ctx, lse, keepmask, S, H, dmodel, seed, \
@@ -587,6 +641,17 @@ int launch_bwd(const bf16* qkv, const int* keylen, const bf16* ctx, const bf16* 
 }  // namespace
 
 extern "C" {
+
+// debug (only with -DM3P_ATTN_TL): copies the forward kernel's phase stamps ([4096 WGs][4 waves][16] u64)
+__attribute__((visibility("default"))) int m3p_debug_attn_timeline(void* out, size_t bytes) {
+#ifdef M3P_ATTN_TL
+  if (bytes > sizeof(g_attn_tl)) return M3P_EINVAL;
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_attn_tl), bytes);
+#else
+  (void)out; (void)bytes;
+  return M3P_EINVAL;
+#endif
+}
 
 int m3p_attn_fwd(const void* qkv, const int32_t* keylen, void* ctx, float* lse, uint64_t* keepmask, int B, int S, int H, int dh,
                  uint32_t seed, uint32_t thresh24, float inv_keep, void* stream) {
