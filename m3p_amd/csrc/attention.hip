@@ -278,7 +278,9 @@ void attn_fwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
 // NKC: number of 32-row steps known at compile time (6 = the M3P sequence, 36 regions + 128 tokens,
 // padded to 192) so both streaming loops unroll and every LDS address becomes base + immediate
 // (the rolled loop spent 28 of its ~110 VALU instructions per step on address updates); 0 = runtime.
-template <int DH, int KT, bool DROP, bool MASK, int NKC>
+// NTC: number of 16-row tiles known at compile time as well (11 for S = 164): keep-bit word addresses become
+// immediates off one pointer instead of per-tile scalar arithmetic held in (spilled) SGPRs.
+template <int DH, int KT, bool DROP, bool MASK, int NKC, int NTC>
 __global__ __launch_bounds__(256, 3)   // 3 waves per SIMD: three 49-KB workgroups per CU
 void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keylen, const bf16* __restrict__ ctx,
                      const bf16* __restrict__ dctx, const float* __restrict__ lse,
@@ -290,7 +292,7 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.x / H, h = blockIdx.x - b * H;
-  const int nt = (S + 15) >> 4;
+  const int nt = NTC ? NTC : ((S + 15) >> 4);
   const int nk = NKC ? NKC : ((S + 31) >> 5);
   const size_t ld = 3 * (size_t)dmodel;
   const bf16* Qg = qkv + (size_t)b * S * ld + h * DH;
@@ -402,26 +404,39 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
 #pragma unroll(NKC ? NKC : 1)
     for (int kq = 0; kq < nk; ++kq) {
       f32x4 pd2[2], ds2[2];
+      // the four MFMA chains of a step (scores and dPd of both 16-query tiles) are issued interleaved, k-step
+      // outermost, so that no MFMA waits on the one just issued
+      f32x4 scA[2], dpA[2], dnegA[2];
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         const int t = 2 * kq + hf;
-        if (M3P_ATTN_SKIP_PAD && !MASK && t >= nt) {      // query tile that is pure padding (measured slower with MASK) (S = 164: rows 176..191): contributes zeros
+        // a masked key column starts its score accumulator at -1e30 (no per-element select);
+        // without dropout dPd - D comes straight out of the MFMA (accumulator starts at -D[q])
+        dnegA[hf] = f32x4{-sD[16 * t + 4 * fg + 0], -sD[16 * t + 4 * fg + 1], -sD[16 * t + 4 * fg + 2],
+                          -sD[16 * t + 4 * fg + 3]};
+        scA[hf] = f32x4{kbias, kbias, kbias, kbias};
+        dpA[hf] = DROP ? f32x4{0.f, 0.f, 0.f, 0.f} : dnegA[hf];
+      }
+#pragma unroll
+      for (int kk = 0; kk < Cf::KK; ++kk) {
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          const int t = 2 * kq + hf;
+          if (M3P_ATTN_SKIP_PAD && !MASK && t >= nt) continue;   // query tile that is pure padding (S = 164: rows 176..191)
+          const bf16x8 qf = *reinterpret_cast<const bf16x8*>(s0 + t * 16 * Cf::ROWB + r_off[kk]);
+          const bf16x8 df = *reinterpret_cast<const bf16x8*>(s1 + t * 16 * Cf::ROWB + r_off[kk]);
+          scA[hf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf[kk], scA[hf], 0, 0, 0);   // S[q][key]
+          dpA[hf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, vf[kk], dpA[hf], 0, 0, 0);   // dPd[q][key]
+        }
+      }
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const int t = 2 * kq + hf;
+        if (M3P_ATTN_SKIP_PAD && !MASK && t >= nt) {      // (skipping the padded tile measured slower with MASK): contributes zeros
           pd2[hf] = ds2[hf] = f32x4{0.f, 0.f, 0.f, 0.f};
           continue;
         }
-        // a masked key column starts its score accumulator at -1e30 (no per-element select);
-        // without dropout dPd - D comes straight out of the MFMA (accumulator starts at -D[q])
-        const f32x4 dneg = f32x4{-sD[16 * t + 4 * fg + 0], -sD[16 * t + 4 * fg + 1], -sD[16 * t + 4 * fg + 2],
-                                 -sD[16 * t + 4 * fg + 3]};
-        f32x4 sc = {kbias, kbias, kbias, kbias};
-        f32x4 dp = DROP ? f32x4{0.f, 0.f, 0.f, 0.f} : dneg;
-#pragma unroll
-        for (int kk = 0; kk < Cf::KK; ++kk) {
-          const bf16x8 qf = *reinterpret_cast<const bf16x8*>(s0 + t * 16 * Cf::ROWB + r_off[kk]);
-          const bf16x8 df = *reinterpret_cast<const bf16x8*>(s1 + t * 16 * Cf::ROWB + r_off[kk]);
-          sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf[kk], sc, 0, 0, 0);   // S[q][key]
-          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, vf[kk], dp, 0, 0, 0);   // dPd[q][key]
-        }
+        const f32x4 dneg = dnegA[hf], sc = scA[hf], dp = dpA[hf];
         uint32_t kbits = 0;
         if (MASK) {
           // forward layout: word [qb = t][tile = kb][r = key & 3], bit (q & 15) + 16 ((key & 15) >> 2)
@@ -505,6 +520,8 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
     const int qc = min(q, S - 1);
     if (qb != wid) load_qd(qb);
     const float lq = sL[q], dq_ = sD[q];      // lse (log2 units) and D of this lane's query
+    int klen_it = klen;
+    asm volatile("" : "+s"(klen_it));   // opaque per query block: keeps the key-mask tests inside the loop
     const uint32_t rbase = (uint32_t)((b * H + h) * S + qc) * (uint32_t)S;
     // dQ^T[d][q] = sum_key K[key][d] dS[q][key], streamed over 32-key steps
     f32x4 dq[Cf::NT];
@@ -513,28 +530,45 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
 #pragma unroll(NKC ? NKC : 1)
     for (int kq = 0; kq < nk; ++kq) {
       f32x4 ds2[2];
+      f32x4 scB[2], dpB[2];
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        scB[hf] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dpB[hf] = DROP ? f32x4{0.f, 0.f, 0.f, 0.f} : f32x4{-dq_, -dq_, -dq_, -dq_};
+      }
+#pragma unroll
+      for (int kk = 0; kk < Cf::KK; ++kk) {
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          const int t = 2 * kq + hf;
+          if (M3P_ATTN_SKIP_PAD && !MASK && t >= nt) continue;   // key tile beyond the sequence
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(s0 + t * 16 * Cf::ROWB + r_off[kk]);
+          const bf16x8 vf = *reinterpret_cast<const bf16x8*>(s1 + t * 16 * Cf::ROWB + r_off[kk]);
+          scB[hf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], scB[hf], 0, 0, 0);   // S^T[key][q]
+          dpB[hf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, df[kk], dpB[hf], 0, 0, 0);   // dPd^T[key][q]
+        }
+      }
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         const int t = 2 * kq + hf;
-        if (M3P_ATTN_SKIP_PAD && !MASK && t >= nt) {      // key tile beyond the sequence
+        if (M3P_ATTN_SKIP_PAD && !MASK && t >= nt) {
           ds2[hf] = f32x4{0.f, 0.f, 0.f, 0.f};
           continue;
         }
-        f32x4 sc = {0.f, 0.f, 0.f, 0.f};
-        f32x4 dp = DROP ? f32x4{0.f, 0.f, 0.f, 0.f} : f32x4{-dq_, -dq_, -dq_, -dq_};
-#pragma unroll
-        for (int kk = 0; kk < Cf::KK; ++kk) {
-          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(s0 + t * 16 * Cf::ROWB + r_off[kk]);
-          const bf16x8 vf = *reinterpret_cast<const bf16x8*>(s1 + t * 16 * Cf::ROWB + r_off[kk]);
-          sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], sc, 0, 0, 0);   // S^T[key][q]
-          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, df[kk], dp, 0, 0, 0);   // dPd^T[key][q]
-        }
+        f32x4 sc = scB[hf];
+        const f32x4 dp = dpB[hf];
         const unsigned long long* mw = MASK ? mbh + ((size_t)qb * nt + min(t, nt - 1)) * 4 : nullptr;   // wave-uniform
+        // keys >= klen: only the tile straddling klen (or behind it) needs per-element tests (wave-uniform branch;
+        // per-element compares are loop-invariant lane masks the compiler hoists into spilled SGPRs)
+        if (16 * t + 16 > klen_it) {
+          asm volatile("");   // (keeps this a branch: if-converted it is 2 VALU ops on every element)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sc[r] = (16 * t + 4 * fg + r < klen_it) ? sc[r] : kMasked;
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int key = 16 * t + 4 * fg + r;
-          float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[r], kLog2e, -lq));
-          p = (key < klen) ? p : 0.f;
+          const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[r], kLog2e, -lq));
           if (DROP) {
             float kfac;
             if (MASK) {
@@ -622,8 +656,8 @@ int launch_bwd(const bf16* qkv, const int* keylen, const bf16* ctx, const bf16* 
   const size_t lds = (size_t)2 * nk * 32 * DH * 2 + (size_t)2 * nk * 32 * sizeof(float) + 12 * DH * sizeof(float);
 #define M3P_ATTN_BWD(KT, DROP, MASK)                                                                            \
   do {                                                                                                          \
-    auto kern = attn_bwd_kernel<DH, KT, DROP, MASK, 0>;                                                         \
-    if (nk == 6) kern = attn_bwd_kernel<DH, KT, DROP, MASK, 6>;                                                                  \
+    auto kern = attn_bwd_kernel<DH, KT, DROP, MASK, 0, 0>;                                                      \
+    if (nk == 6) kern = (S + 15) / 16 == 11 ? attn_bwd_kernel<DH, KT, DROP, MASK, 6, 11> : attn_bwd_kernel<DH, KT, DROP, MASK, 6, 0>;                                                                  \
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     if (e != hipSuccess) return (int)e;                                                                         \
     hipLaunchKernelGGL(kern, dim3(B* H), dim3(256), lds, st, qkv, keylen, ctx, dctx, lse, keepmask, dqkv, dbias, S, H, \
