@@ -285,6 +285,29 @@ __device__ __forceinline__ void load_aux(const M3PEpilogue& ep, int mrow0, int n
     for (int j = 0; j < 4; ++j) auxv[ii][j] = *reinterpret_cast<const bf16x4*>(X + (size_t)(ii * 16) * ep.ld_aux + j * 16);
 }
 
+// The same aux half-tile fetched as whole 128-byte row segments (16 B per lane, 8 lanes per row, 4 instructions
+// instead of 8) and transposed into the accumulator layout through the wave-private staging rows `r1`; load_aux's
+// direct form touches sixteen 32-byte row pieces per instruction.  Measured: dGELU 0.349 -> 0.340 ms, the
+// residual epilogues unchanged (the aux tile costs ~60 us per 41984 x 3072 GEMM either way - see DESIGN.md).
+template <int EPI>
+__device__ __forceinline__ void load_aux_rows(const M3PEpilogue& ep, int mrow0, int nw, int lane, char* r1, bf16x4 (&auxv)[2][4]) {
+  constexpr bool kAux = (EPI == M3P_EPI_BIAS_DROP_RES || EPI == M3P_EPI_RES || EPI == M3P_EPI_DGELU || EPI == M3P_EPI_MUL);
+  if (!kAux) return;
+  const int srow = lane >> 3, sch = lane & 7;
+  const bf16* X = reinterpret_cast<const bf16*>(ep.aux) + (size_t)(mrow0 + srow) * ep.ld_aux + nw + sch * 8;
+  uint4 t[4];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) t[it] = *reinterpret_cast<const uint4*>(X + (size_t)(it * 8) * ep.ld_aux);
+#pragma unroll
+  for (int it = 0; it < 4; ++it) *reinterpret_cast<uint4*>(r1 + (it * 8 + srow) * EP_PITCH + sch * 16) = t[it];
+  const int fr = lane & 15, fg = lane >> 4;
+#pragma unroll
+  for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      auxv[ii][j] = *reinterpret_cast<const bf16x4*>(r1 + (ii * 16 + fr) * EP_PITCH + (j * 16 + fg * 4) * 2);
+}
+
 template <int EPI>
 __device__ __forceinline__ void epilogue_half(const M3PEpilogue& ep, bf16* __restrict__ C, int ldc, int N,
                                               int mrow0, int nw, char* r1, const f32x4 (&rows)[2][4],
@@ -518,7 +541,8 @@ void gemm_nt_ring_kernel(const bf16* __restrict__ A, int lda, const bf16* __rest
   int c_q = 0, c_kt = 0;
   const bool io_aligned = ((ldc & 7) == 0) && (((uintptr_t)C & 15) == 0) &&
                           (!(EPI == M3P_EPI_BIAS_GELU) || (((ep.ld_out2 & 7) == 0) && (((uintptr_t)ep.out2 & 15) == 0))) &&
-                          (!ep.bias || (((uintptr_t)ep.bias & 15) == 0));
+                          (!ep.bias || (((uintptr_t)ep.bias & 15) == 0)) &&
+                          (!ep.aux || (((ep.ld_aux & 7) == 0) && (((uintptr_t)ep.aux & 15) == 0)));
   for (int step = 0; step < total; ++step) {
     const int nxt = (cur == 2) ? 0 : cur + 1;
     const int nx2 = (nxt == 2) ? 0 : nxt + 1;
@@ -565,7 +589,7 @@ void gemm_nt_ring_kernel(const bf16* __restrict__ A, int lda, const bf16* __rest
           f32x4 biasv[4];
           bf16x4 auxv[2][4];
           load_bias4<EPI>(ep, nw, lane, biasv);
-          load_aux<EPI>(ep, mw + 32 * hf, nw, lane, auxv);
+          load_aux_rows<EPI>(ep, mw + 32 * hf, nw, lane, r1, auxv);
           epilogue_half<EPI>(ep, C, ldc, N, mw + 32 * hf, nw, r1, rows, biasv, auxv, lane, csum, gtab);
         }
       } else {
@@ -1099,7 +1123,8 @@ void gemm_nt_w4_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
   int c_q = 0, c_kt = 0;
   const bool io_aligned = ((ldc & 7) == 0) && (((uintptr_t)C & 15) == 0) &&
                           (!(EPI == M3P_EPI_BIAS_GELU) || (((ep.ld_out2 & 7) == 0) && (((uintptr_t)ep.out2 & 15) == 0))) &&
-                          (!ep.bias || (((uintptr_t)ep.bias & 15) == 0));
+                          (!ep.bias || (((uintptr_t)ep.bias & 15) == 0)) &&
+                          (!ep.aux || (((ep.ld_aux & 7) == 0) && (((uintptr_t)ep.aux & 15) == 0)));
   char* r1 = smem + 2 * STAGE + wid * EP_HALF;
   f32x4 bias_lo[4], bias_hi[4];
 #pragma unroll
@@ -1153,7 +1178,12 @@ void gemm_nt_w4_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
         // (fetching the residual / pre-activation tile of piece p+1 during piece p was measured
         //  neutral for the dropout-residual epilogue and 3 % slower for the plain residual one)
         bf16x4 aux_cur[2][4];
-        if (fast) load_aux<EPI>(ep, mw + 32 * rg, nw + 64 * ch, lane, aux_cur);
+        if (fast) {
+          // (dGELU / MUL here are never launched - launch_nt keeps it on the eight-wave kernel - and the 16 extra
+          //  transient registers of the row-wise fetch make the compiler spill into our AGPRs)
+          if (EPI == M3P_EPI_DGELU || EPI == M3P_EPI_MUL) load_aux<EPI>(ep, mw + 32 * rg, nw + 64 * ch, lane, aux_cur);
+          else load_aux_rows<EPI>(ep, mw + 32 * rg, nw + 64 * ch, lane, r1, aux_cur);
+        }
         f32x4 rows[2][4];
 #define W4_RD(II, JJ, I, J)                                                         \
   asm volatile("v_accvgpr_read_b32 %0, a[((" #I ")*8+(" #J "))*4+0]\n\t"            \

@@ -168,7 +168,8 @@ void gemm_nt_w4_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
   int c_q = 0, c_kt = 0;
   const bool io_aligned = ((ldc & 7) == 0) && (((uintptr_t)C & 15) == 0) &&
                           (!(EPI == M3P_EPI_BIAS_GELU) || (((ep.ld_out2 & 7) == 0) && (((uintptr_t)ep.out2 & 15) == 0))) &&
-                          (!ep.bias || (((uintptr_t)ep.bias & 15) == 0));
+                          (!ep.bias || (((uintptr_t)ep.bias & 15) == 0)) &&
+                          (!ep.aux || (((ep.ld_aux & 7) == 0) && (((uintptr_t)ep.aux & 15) == 0)));
   char* r1 = smem + 2 * STAGE + wid * EP_HALF;
   f32x4 bias_lo[4], bias_hi[4];
 #pragma unroll
@@ -222,7 +223,12 @@ void gemm_nt_w4_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
         // (fetching the residual / pre-activation tile of piece p+1 during piece p was measured
         //  neutral for the dropout-residual epilogue and 3 % slower for the plain residual one)
         bf16x4 aux_cur[2][4];
-        if (fast) load_aux<EPI>(ep, mw + 32 * rg, nw + 64 * ch, lane, aux_cur);
+        if (fast) {
+          // (dGELU / MUL here are never launched - launch_nt keeps it on the eight-wave kernel - and the 16 extra
+          //  transient registers of the row-wise fetch make the compiler spill into our AGPRs)
+          if (EPI == M3P_EPI_DGELU || EPI == M3P_EPI_MUL) load_aux<EPI>(ep, mw + 32 * rg, nw + 64 * ch, lane, aux_cur);
+          else load_aux_rows<EPI>(ep, mw + 32 * rg, nw + 64 * ch, lane, r1, aux_cur);
+        }
         f32x4 rows[2][4];
 #define W4_RD(II, JJ, I, J)                                                         \
   asm volatile("v_accvgpr_read_b32 %0, a[((" #I ")*8+(" #J "))*4+0]\n\t"            \
