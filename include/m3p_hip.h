@@ -163,7 +163,10 @@ M3P_API int m3p_cast_f32_bf16(const float* src, void* dst, long long n, void* st
  *   token rows     : emb[tok[t,b]]                                       (:913)
  *   then + pos[s], * (s < totlen[b]), LN_emb, dropout(seed_emb)          (:936-943)
  * Saves z (LN_emb input) / e (LN_img input) and the LayerNorm statistics for backward.
- * tok int64 (T,B); emb bf16 [V,d]; pos,w_loc,b_loc,gammas,betas fp32; loc fp32 (R,B,5). */
+ * tok int64 (T,B); emb bf16 [V,d]; pos,w_loc,b_loc,gammas,betas fp32; loc fp32 (R,B,5).
+ * img_rows (nullable): bf16 [B*R, d], row b*R + r - the image rows to use INSTEAD of computing them
+ * (jointfwd with refine_image=True, transformer.py:905-906: m3p_embed_image_rows_fwd -> AoA refiner ->
+ * here); e / mean_img / rstd_img are then left untouched. */
 M3P_API int m3p_embed_assemble_fwd(const int64_t* tok, const void* emb_bf16, const float* pos,
                                    const void* img_proj, const float* loc, const float* w_loc,
                                    const float* b_loc, const float* g_img, const float* be_img,
@@ -171,14 +174,26 @@ M3P_API int m3p_embed_assemble_fwd(const int64_t* tok, const void* emb_bf16, con
                                    void* h, void* z, float* mean_emb, float* rstd_emb, void* e,
                                    float* mean_img, float* rstd_img, int B, int T, int R, int d,
                                    uint32_t seed_img, uint32_t seed_emb, uint32_t thresh24, float inv_keep,
-                                   void* stream);
+                                   const void* img_rows, void* stream);
+
+/* The image rows alone: img_rows[b*R + r, :] = dropout(LN_img(img_proj[r*B+b] + W_loc loc[r,b] + b_loc))
+ * (BertImageEmbeddings.forward, transformer.py:247-269) as their own bf16 [B*R, d] tensor, batch-major - the
+ * input of the AoA refiner (refine_image=True).  Saves e / mean_img / rstd_img like m3p_embed_assemble_fwd. */
+M3P_API int m3p_embed_image_rows_fwd(const void* img_proj, const float* loc, const float* w_loc, const float* b_loc,
+                                     const float* g_img, const float* be_img, void* e, float* mean_img,
+                                     float* rstd_img, void* img_rows, int B, int R, int d, uint32_t seed_img,
+                                     uint32_t thresh24, float inv_keep, void* stream);
 
 /* Backward of the above given dh[B*S,d].  Accumulates (fp32 atomics) into the parameter
  * gradients d_g_emb,d_be_emb [d], d_pos [S,d] (first S rows of position_embeddings),
  * d_emb [V,d] (scatter-add over token ids, rows of pad_index skipped like
  * nn.Embedding(padding_idx)), d_g_img,d_be_img,d_b_img,d_b_loc [d], d_w_loc [d,5]; writes
  * de [R*B,d] (bf16, gradient of img_proj, rows s*B+b) for the W_img weight-gradient GEMM.
- * dz_scratch: bf16 [B*S,d] workspace. */
+ * dz_scratch: bf16 [B*S,d] workspace.
+ * phase: 0 = everything.  With the AoA refiner between the image rows and the assembly the two halves run
+ * separately: 1 = LN_emb / position / token part only - leaves the gradient of the image rows in
+ * dz_scratch[b*S + r]; the caller takes it through the refiner's backward, writes the result back to the same
+ * rows, then 2 = image part only (dropout + LN_img + location embedding -> de and their parameter gradients). */
 M3P_API int m3p_embed_assemble_bwd(const void* dh, const void* z, const float* mean_emb, const float* rstd_emb,
                                    const float* g_emb, const void* e, const float* mean_img,
                                    const float* rstd_img, const float* g_img, const int64_t* tok,
@@ -187,7 +202,7 @@ M3P_API int m3p_embed_assemble_bwd(const void* dh, const void* z, const float* m
                                    float* d_g_img, float* d_be_img, float* d_b_img, float* d_b_loc,
                                    float* d_w_loc, int B, int T, int R, int d, int pad_index,
                                    uint32_t seed_img, uint32_t seed_emb, uint32_t thresh24, float inv_keep,
-                                   void* stream);
+                                   int phase, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Heads (TransformerModel.predict, transformer.py:1183-1214; PredLayer :104-117)
@@ -256,6 +271,25 @@ M3P_API int m3p_gelu_bwd(const void* dy, const void* u, void* du, long long n, v
  * dpred[i][j] = 2 (pred - tgt) * grad_scale.  pred/dpred bf16 (pitch ld_pred), tgt fp32 (pitch ld_tgt). */
 M3P_API int m3p_mse_fwd_bwd(const void* pred, int ld_pred, const float* tgt, int ld_tgt, void* dpred, float* row_sq,
                             int rows, int cols, float grad_scale, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * AoA image refiner (AoA_Refiner_Core, transformer.py:287-422): the elementwise passes its GEMMs,
+ * LayerNorms, attention and GELU (all the encoder's kernels) leave over.
+ * ---------------------------------------------------------------------------------- */
+
+/* y[r][c] = (res ? res[r][c] : 0) + dropout(x[r][c]) on a [rows, cols] bf16 view (pitches ldx / ldres / ldy,
+ * cols % 4 == 0).  The keep decision of element (r, c) is m3p_keep(r * rng_ld + rng_col0 + c, seed, thresh24)
+ * (thresh24 = 0: no dropout), so the two halves of torch.cat([x, q], -1) can be dropped by two calls into one
+ * [rows, 2d] buffer (rng_ld = 2d, rng_col0 = 0 / d) and backward regenerates the same mask.  y may alias x.
+ * SublayerConnection.forward (:392-394), MultiHeadedDotAttention's dropout_aoa (:366), TransformerFFN (:226). */
+M3P_API int m3p_dropout_rows(const void* x, int ldx, const void* res, int ldres, void* y, int ldy, int rows, int cols,
+                             uint32_t rng_ld, uint32_t rng_col0, uint32_t seed, uint32_t thresh24, float inv_keep,
+                             void* stream);
+
+/* nn.GLU of the AoA layer (:317): ab bf16 [rows, 2d] (pitch ld_ab) -> y[rows, d] = ab[:, :d] * sigmoid(ab[:, d:]) */
+M3P_API int m3p_glu_fwd(const void* ab, int ld_ab, void* y, int rows, int d, void* stream);
+/* dab[:, :d] = dy * sigmoid(b);  dab[:, d:] = dy * a * sigmoid(b) * (1 - sigmoid(b))   (dab pitch = ld_ab) */
+M3P_API int m3p_glu_bwd(const void* ab, int ld_ab, const void* dy, void* dab, int rows, int d, void* stream);
 
 /* Batched form of m3p_transpose_bf16: desc = n_desc x {src ptr, dst ptr, rows, cols, ld_src,
  * ld_dst} as int64 in device memory; max_tiles >= max over matrices of ceil(rows/64)*ceil(cols/64). */

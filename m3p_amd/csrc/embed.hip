@@ -56,6 +56,11 @@ struct EmbedFwdArgs {
   float* mean_img; float* rstd_img;   // [R*B]
   int B, T, R, d;
   uint32_t seed_img, seed_emb, thresh24; float inv_keep;
+  // AoA refiner hook (jointfwd's refine_image=True, transformer.py:905-906): the image rows leave after their
+  // LayerNorm + dropout, go through the refiner, and come back in place of the computed ones.
+  //   img_mode 0: none.  1: image rows only (T = 0): write them to img_rows [B*R, d] (row b*R + r) and stop.
+  //   2: take the image rows from img_rows instead of computing them (e / mean_img / rstd_img untouched).
+  bf16* img_rows; int img_mode;
 };
 
 template <int NI>
@@ -67,9 +72,16 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(EmbedFwdArgs a) {
   const float inv_d = 1.0f / (float)d;
   for (int m = wave; m < a.B * S; m += nwaves) {
     const int b = m / S, s = m - b * S;
-    const float mk = (s < a.totlen[b]) ? 1.f : 0.f;
+    const float mk = (a.img_mode == 1 || s < a.totlen[b]) ? 1.f : 0.f;
     f32x4 v[NI];
-    if (s < a.R) {
+    if (s < a.R && a.img_mode == 2) {
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (c < nchunk) v[i] = Vec4<bf16>::load(a.img_rows + ((size_t)b * a.R + s) * d + 4 * c);
+      }
+    } else if (s < a.R) {
       const int ri = s * a.B + b;
       float lc[5];
 #pragma unroll
@@ -105,8 +117,10 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(EmbedFwdArgs a) {
             for (int j = 0; j < 4; ++j) o[j] = m3p_keep(base + j, a.seed_img, a.thresh24) ? o[j] * a.inv_keep : 0.f;
           }
           v[i] = o;
+          if (a.img_mode == 1) Vec4<bf16>::store(a.img_rows + ((size_t)b * a.R + s) * d + 4 * c, o);
         }
       }
+      if (a.img_mode == 1) continue;
     } else {
       const int64_t id = a.tok[(size_t)(s - a.R) * a.B + b];
 #pragma unroll
@@ -342,6 +356,7 @@ __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restr
 
 inline int ni_of(int d) { return (d + 255) / 256; }
 
+int launch_embed_fwd(const EmbedFwdArgs& a, void* stream);
 }  // namespace
 
 extern "C" {
@@ -360,11 +375,31 @@ int m3p_embed_assemble_fwd(const int64_t* tok, const void* emb_bf16, const float
                            const float* be_img, const float* g_emb, const float* be_emb, const int32_t* totlen,
                            void* h, void* z, float* mean_emb, float* rstd_emb, void* e, float* mean_img,
                            float* rstd_img, int B, int T, int R, int d, uint32_t seed_img, uint32_t seed_emb,
-                           uint32_t thresh24, float inv_keep, void* stream) {
+                           uint32_t thresh24, float inv_keep, const void* img_rows, void* stream) {
   if (B <= 0 || T < 0 || R < 0 || d <= 0 || (d % 4) != 0 || d > 1024) return M3P_EINVAL;
+  if (img_rows && ((uintptr_t)img_rows & 7)) return M3P_EINVAL;
   EmbedFwdArgs a = {tok, (const bf16*)emb_bf16, pos, (const bf16*)img_proj, loc, w_loc, b_loc, g_img, be_img, g_emb, be_emb,
                     totlen, (bf16*)h, (bf16*)z, mean_emb, rstd_emb, (bf16*)e, mean_img, rstd_img, B, T, R, d,
-                    seed_img, seed_emb, thresh24, inv_keep};
+                    seed_img, seed_emb, thresh24, inv_keep, (bf16*)const_cast<void*>(img_rows), img_rows ? 2 : 0};
+  return launch_embed_fwd(a, stream);
+}
+
+int m3p_embed_image_rows_fwd(const void* img_proj, const float* loc, const float* w_loc, const float* b_loc,
+                             const float* g_img, const float* be_img, void* e, float* mean_img, float* rstd_img,
+                             void* img_rows, int B, int R, int d, uint32_t seed_img, uint32_t thresh24, float inv_keep,
+                             void* stream) {
+  if (B <= 0 || R <= 0 || d <= 0 || (d % 4) != 0 || d > 1024 || !img_rows || ((uintptr_t)img_rows & 7)) return M3P_EINVAL;
+  EmbedFwdArgs a = {nullptr, nullptr, nullptr, (const bf16*)img_proj, loc, w_loc, b_loc, g_img, be_img, nullptr, nullptr,
+                    nullptr, nullptr, nullptr, nullptr, nullptr, (bf16*)e, mean_img, rstd_img, B, 0, R, d,
+                    seed_img, 0u, thresh24, inv_keep, (bf16*)img_rows, 1};
+  return launch_embed_fwd(a, stream);
+}
+
+}  // extern "C"
+
+namespace {
+int launch_embed_fwd(const EmbedFwdArgs& a, void* stream) {
+  const int B = a.B, T = a.T, R = a.R, d = a.d;
   const int rows = B * (R + T);
   const int blocks = (rows + 3) / 4 < 4096 ? (rows + 3) / 4 : 4096;
   hipStream_t st = (hipStream_t)stream;
@@ -377,6 +412,9 @@ int m3p_embed_assemble_fwd(const int64_t* tok, const void* emb_bf16, const float
   M3P_CHECK_LAUNCH();
   return M3P_OK;
 }
+}  // namespace
+
+extern "C" {
 
 int m3p_embed_assemble_bwd(const void* dh, const void* z, const float* mean_emb, const float* rstd_emb,
                            const float* g_emb, const void* e, const float* mean_img, const float* rstd_img,
@@ -384,8 +422,8 @@ int m3p_embed_assemble_bwd(const void* dh, const void* z, const float* mean_emb,
                            void* dz_scratch, void* de, float* d_g_emb, float* d_be_emb, float* d_pos, float* d_emb,
                            float* d_g_img, float* d_be_img, float* d_b_img, float* d_b_loc, float* d_w_loc,
                            int B, int T, int R, int d, int pad_index, uint32_t seed_img, uint32_t seed_emb,
-                           uint32_t thresh24, float inv_keep, void* stream) {
-  if (B <= 0 || T < 0 || R < 0 || d <= 0 || (d % 4) != 0 || d > 1024) return M3P_EINVAL;
+                           uint32_t thresh24, float inv_keep, int phase, void* stream) {
+  if (B <= 0 || T < 0 || R < 0 || d <= 0 || (d % 4) != 0 || d > 1024 || phase < 0 || phase > 2) return M3P_EINVAL;
   int bsplit = 1;
   while (bsplit < 16 && (R + T) * bsplit < M3P_EMB_BWD_BLOCKS && B / (4 * bsplit) >= 8) bsplit *= 2;
   EmbedBwdArgs a = {(const bf16*)dh, (const bf16*)z, mean_emb, rstd_emb, g_emb, (const bf16*)e, mean_img, rstd_img, g_img,
@@ -396,8 +434,8 @@ int m3p_embed_assemble_bwd(const void* dh, const void* z, const float* mean_emb,
   const int S = R + T;
 #define M3P_EMB_BWD(NI)                                                                              \
   do {                                                                                               \
-    hipLaunchKernelGGL(embed_bwd_rows_kernel<NI>, dim3(S* bsplit), dim3(256), 0, st, a);             \
-    if (R > 0) hipLaunchKernelGGL(embed_bwd_img_kernel<NI>, dim3(R* bsplit), dim3(256), 0, st, a);   \
+    if (phase != 2) hipLaunchKernelGGL(embed_bwd_rows_kernel<NI>, dim3(S* bsplit), dim3(256), 0, st, a);             \
+    if (R > 0 && phase != 1) hipLaunchKernelGGL(embed_bwd_img_kernel<NI>, dim3(R* bsplit), dim3(256), 0, st, a);   \
   } while (0)
   switch (ni_of(d)) {
     case 1: M3P_EMB_BWD(1); break;

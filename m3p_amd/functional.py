@@ -114,6 +114,23 @@ class Arena:
         d = self.model.dim
         return self.grad[o:o + 3 * d * d].view(3 * d, d)
 
+    # AoA refiner layer i: the three input projections are adjacent in the arena like q/k/v of an encoder layer
+    def ref_qkv_w16(self, i):
+        o = self.offsets['refine_embeddings.layers.%d.self_attn.linears.0.weight' % i][0]
+        d = self.model.dim
+        return self.w16[o:o + 3 * d * d].view(3 * d, d)
+
+    def ref_qkv_wgrad(self, i):
+        o = self.offsets['refine_embeddings.layers.%d.self_attn.linears.0.weight' % i][0]
+        d = self.model.dim
+        return self.grad[o:o + 3 * d * d].view(3 * d, d)
+
+    def ref_qkv_bias(self, i, grad=False):
+        o = self.offsets['refine_embeddings.layers.%d.self_attn.linears.0.bias' % i][0]
+        d = self.model.dim
+        src = self.grad if grad else self.master
+        return src[o:o + 3 * d]
+
     def qkv_bias(self, i, grad=False):
         o = self.offsets['attentions.%d.q_lin.bias' % i][0]
         d = self.model.dim
@@ -170,6 +187,103 @@ def _site(kind, layer=0):
     return {'img': 0, 'emb': 1}.get(kind, 8 + 4 * layer + {'attn_p': 0, 'attn_out': 1, 'ffn': 2}.get(kind, 3))
 
 
+_REF_SITE0 = 1 << 20   # dropout sites of the refiner: _REF_SITE0 + 8 * layer + {0 attention probabilities, 1 AoA
+                        # input, 2 attention sublayer, 3 TransformerFFN's own, 4 FFN sublayer}
+
+
+def _transposed(w):
+    """bf16 [n, k] -> fresh [k, n] (the refiner's weights are small: transposed per use instead of kept)."""
+    wt = torch.empty((w.shape[1], w.shape[0]), dtype=BF16, device=w.device)
+    ops.transpose_bf16(w, wt)
+    return wt
+
+
+def refiner_fwd(model, x, keylen, B, R, seed_step, p):
+    """AoA_Refiner_Core.forward (transformer.py:410-422) on the image rows x (bf16 [B*R, d], rows b*R + r):
+    per layer  x = x + drop(AoA(LN_a(x)));  x = x + drop(FFN(LN_b(x)))  (pre-norm SublayerConnection :381-394),
+    then the final LayerNorm.  AoA (MultiHeadedDotAttention with do_aoa, :327-371): q/k/v projections of the
+    normed rows, softmax(q k^T / sqrt(d_k), key mask) with dropout, GLU(Linear(dropout(cat[attended, normed]))).
+    p: the refiner's dropout rate - the reference hard-codes 0.1 through its constructor defaults (:288,:411,:662),
+    independent of params.dropout.  Returns (rows, saved)."""
+    ar = model.arena()
+    d, H = model.dim, model.n_heads
+    dh = d // H
+    M = B * R
+    qscale = 1.0 / math.sqrt(dh)
+    seed = lambda i, k: rng.stream_seed(model.base_seed, seed_step, _REF_SITE0 + 8 * i + k)   # noqa: E731
+    layers = []
+    for i in range(model.n_refine_layers):
+        pre = 'refine_embeddings.layers.%d.' % i
+        xn, mean_a, rstd_a = ops.layernorm_fwd(x, ar.p(pre + 'sublayer.0.norm.weight'), ar.p(pre + 'sublayer.0.norm.bias'))
+        qkv = ops.gemm_nt(xn, ar.ref_qkv_w16(i), L.EPI_BIAS, bias=ar.ref_qkv_bias(i), scale_cols=d, scale=qscale)
+        ctxt, lse, kmask = ops.attn_fwd(qkv, keylen, B, R, H, dh, seed=seed(i, 0), p_drop=p, want_mask=True)
+        cat = torch.empty((M, 2 * d), dtype=BF16, device=x.device)
+        ops.dropout_rows(ctxt, p, seed(i, 1), out=cat[:, :d], rng_ld=2 * d, rng_col0=0)
+        ops.dropout_rows(xn, p, seed(i, 1), out=cat[:, d:], rng_ld=2 * d, rng_col0=d)
+        ab = ops.gemm_nt(cat, ar.w(pre + 'self_attn.aoa_layer.0.weight'), L.EPI_BIAS,
+                         bias=ar.p(pre + 'self_attn.aoa_layer.0.bias'))
+        x1 = ops.dropout_rows(ops.glu_fwd(ab), p, seed(i, 2), res=x)
+        xn2, mean_b, rstd_b = ops.layernorm_fwd(x1, ar.p(pre + 'sublayer.1.norm.weight'), ar.p(pre + 'sublayer.1.norm.bias'))
+        u = torch.empty((M, 4 * d), dtype=BF16, device=x.device)
+        hact = ops.gemm_nt(xn2, ar.w(pre + 'feed_forward.lin1.weight'), L.EPI_BIAS_GELU,
+                           bias=ar.p(pre + 'feed_forward.lin1.bias'), out2=u)
+        t = ops.gemm_nt(hact, ar.w(pre + 'feed_forward.lin2.weight'), L.EPI_BIAS, bias=ar.p(pre + 'feed_forward.lin2.bias'))
+        if p > 0:
+            ops.dropout_rows(t, p, seed(i, 3), out=t)            # TransformerFFN.forward's dropout (:226) ...
+        x2 = ops.dropout_rows(t, p, seed(i, 4), res=x1)          # ... then the sublayer's (:394)
+        layers.append((x, mean_a, rstd_a, xn, qkv, ctxt, lse, kmask, cat, ab, x1, mean_b, rstd_b, xn2, u, hact))
+        x = x2
+    out, mean_f, rstd_f = ops.layernorm_fwd(x, ar.p('refine_embeddings.norm.weight'), ar.p('refine_embeddings.norm.bias'))
+    return out, (layers, x, mean_f, rstd_f)
+
+
+def refiner_bwd(model, dout, saved, keylen, B, R, seed_step, p):
+    """Gradient of refiner_fwd's input; parameter gradients go to the arena."""
+    ar = model.arena()
+    d, H = model.dim, model.n_heads
+    dh = d // H
+    seed = lambda i, k: rng.stream_seed(model.base_seed, seed_step, _REF_SITE0 + 8 * i + k)   # noqa: E731
+    layers, x_last, mean_f, rstd_f = saved
+    dx, _ = ops.layernorm_bwd(dout, None, x_last, ar.p('refine_embeddings.norm.weight'), mean_f, rstd_f, None,
+                              ar.g('refine_embeddings.norm.weight'), ar.g('refine_embeddings.norm.bias'))
+    for i in reversed(range(model.n_refine_layers)):
+        pre = 'refine_embeddings.layers.%d.' % i
+        (x, mean_a, rstd_a, xn, qkv, ctxt, lse, kmask, cat, ab, x1, mean_b, rstd_b, xn2, u, hact) = layers[i]
+        layers[i] = None
+        # ---- x2 = x1 + drop4(drop3(hact W2^T + b2))
+        dt = ops.dropout_rows(dx, p, seed(i, 4))
+        if p > 0:
+            ops.dropout_rows(dt, p, seed(i, 3), out=dt)
+        ops.colsum(dt, d, ar.g(pre + 'feed_forward.lin2.bias'))
+        ops.gemm_wgrad(dt, hact, ar.g(pre + 'feed_forward.lin2.weight'))
+        du = ops.gemm_nt(dt, _transposed(ar.w(pre + 'feed_forward.lin2.weight')), L.EPI_DGELU, aux=u,
+                         colsum=ar.g(pre + 'feed_forward.lin1.bias'))
+        ops.gemm_wgrad(du, xn2, ar.g(pre + 'feed_forward.lin1.weight'))
+        dxn2 = ops.gemm_nt(du, _transposed(ar.w(pre + 'feed_forward.lin1.weight')), L.EPI_NONE)
+        dln, _ = ops.layernorm_bwd(dxn2, None, x1, ar.p(pre + 'sublayer.1.norm.weight'), mean_b, rstd_b, None,
+                                   ar.g(pre + 'sublayer.1.norm.weight'), ar.g(pre + 'sublayer.1.norm.bias'))
+        dx1 = ops.dropout_rows(dln, 0.0, 0, res=dx)               # residual: dx1 = dx + dLN
+        del dt, du, dxn2, dln, u, hact, xn2
+        # ---- x1 = x + drop2(GLU(cat W_aoa^T + b)),  cat = drop1([ctx | xn])
+        dy = ops.dropout_rows(dx1, p, seed(i, 2))
+        dab = ops.glu_bwd(ab, dy)
+        ops.colsum(dab, 2 * d, ar.g(pre + 'self_attn.aoa_layer.0.bias'))
+        ops.gemm_wgrad(dab, cat, ar.g(pre + 'self_attn.aoa_layer.0.weight'))
+        dcat = ops.gemm_nt(dab, _transposed(ar.w(pre + 'self_attn.aoa_layer.0.weight')), L.EPI_NONE)
+        dctx = ops.dropout_rows(dcat[:, :d], p, seed(i, 1), rng_ld=2 * d, rng_col0=0)
+        dxn_cat = ops.dropout_rows(dcat[:, d:], p, seed(i, 1), rng_ld=2 * d, rng_col0=d)
+        dqkv = ops.attn_bwd(qkv, keylen, ctxt, dctx, lse, B, R, H, dh, dbias_qkv=ar.ref_qkv_bias(i, grad=True),
+                            seed=seed(i, 0), p_drop=p, keepmask=kmask)
+        ops.gemm_wgrad(dqkv, xn, ar.ref_qkv_wgrad(i))
+        dxn = ops.gemm_nt(dqkv, _transposed(ar.ref_qkv_w16(i)), L.EPI_RES, aux=dxn_cat)
+        dln, _ = ops.layernorm_bwd(dxn, None, x, ar.p(pre + 'sublayer.0.norm.weight'), mean_a, rstd_a, None,
+                                   ar.g(pre + 'sublayer.0.norm.weight'), ar.g(pre + 'sublayer.0.norm.bias'))
+        dx = ops.dropout_rows(dln, 0.0, 0, res=dx1)
+        del dy, dab, dcat, dctx, dxn_cat, dqkv, dxn, dln, dx1
+    ar.touch(*[n for n in ar.names if n.startswith('refine_embeddings.')])
+    return dx
+
+
 class EncoderFn(torch.autograd.Function):
     """Embedding assembly + n_layers post-LN transformer layers
     (TransformerModel.jointfwd, M3P/src/model/transformer.py:901-958; with x_img=None the
@@ -177,7 +291,7 @@ class EncoderFn(torch.autograd.Function):
     output require grad; parameter gradients are written to the arena (module docstring)."""
 
     @staticmethod
-    def forward(ctx, anchor, model, x, lengths, x_img, lengths_img, image_loc, p_drop, p_attn, seed_step):
+    def forward(ctx, anchor, model, x, lengths, x_img, lengths_img, image_loc, p_drop, p_attn, seed_step, p_refine=None):
         ar = model.arena()
         ar.refresh()
         dev = ar.device
@@ -200,13 +314,22 @@ class EncoderFn(torch.autograd.Function):
             loc = image_loc.contiguous().float()
             img_proj = ops.gemm_nt(ximg16, ar.w('image_embeddings.image_embeddings.weight'), L.EPI_BIAS,
                                    bias=ar.p('image_embeddings.image_embeddings.bias'))
+        # refine_image (transformer.py:905-906): the image rows take a detour through the AoA refiner
+        img_rows = img_saved = ref_saved = keylen_img = None
+        if p_refine is not None and R > 0:
+            rows, img_saved = ops.embed_image_rows_fwd(
+                img_proj, loc, ar.p('image_embeddings.image_location_embeddings.weight'),
+                ar.p('image_embeddings.image_location_embeddings.bias'), ar.p('image_embeddings.LayerNorm.weight'),
+                ar.p('image_embeddings.LayerNorm.bias'), B, R, d, seed_img=seed('img'), p_drop=p_drop)
+            keylen_img = lengths_img.to(device=dev, dtype=torch.int32).contiguous()
+            img_rows, ref_saved = refiner_fwd(model, rows, keylen_img, B, R, seed_step, p_refine)
         h, emb_saved = ops.embed_assemble_fwd(
             x, ar.w('embeddings.weight'), ar.p('position_embeddings.weight'), img_proj, loc,
             ar.p('image_embeddings.image_location_embeddings.weight'),
             ar.p('image_embeddings.image_location_embeddings.bias'),
             ar.p('image_embeddings.LayerNorm.weight'), ar.p('image_embeddings.LayerNorm.bias'),
             ar.p('layer_norm_emb.weight'), ar.p('layer_norm_emb.bias'), totlen, B, T, R, d,
-            seed_img=seed('img'), seed_emb=seed('emb'), p_drop=p_drop)
+            seed_img=seed('img'), seed_emb=seed('emb'), p_drop=p_drop, img_rows=img_rows, img_saved=img_saved)
 
         saved_layers = []
         qscale = 1.0 / math.sqrt(dh)
@@ -239,6 +362,7 @@ class EncoderFn(torch.autograd.Function):
         ctx.dims = (B, T, R, S, d, H, dh, nL)
         ctx.drop = (p_drop, p_attn, seed_step)
         ctx.saved = (x, totlen, rowmask, ximg16, loc, emb_saved, saved_layers)
+        ctx.refine = (ref_saved, keylen_img, p_refine)
         ctx.set_materialize_grads(False)
         return h
 
@@ -252,8 +376,10 @@ class EncoderFn(torch.autograd.Function):
         x, totlen, rowmask, ximg16, loc, emb_saved, saved_layers = ctx.saved
         ctx.saved = None
         seed = lambda kind, i=0: rng.stream_seed(model.base_seed, seed_step, _site(kind, i))   # noqa: E731
+        ref_saved, keylen_img, p_refine = ctx.refine
+        ctx.refine = None
         if dout is None:
-            return (None,) * 10
+            return (None,) * 11
         dh_ = dout.contiguous()
         if dh_.dtype != BF16:
             dh_ = dh_.to(BF16)
@@ -302,14 +428,16 @@ class EncoderFn(torch.autograd.Function):
             d_w_loc=ar.g('image_embeddings.image_location_embeddings.weight'))
         de = ops.embed_assemble_bwd(dh_, emb_saved, ar.p('layer_norm_emb.weight'),
                                     ar.p('image_embeddings.LayerNorm.weight'), x, totlen, loc, grads, B, T, R, d,
-                                    model.pad_index, seed_img=seed('img'), seed_emb=seed('emb'), p_drop=p_drop)
+                                    model.pad_index, seed_img=seed('img'), seed_emb=seed('emb'), p_drop=p_drop,
+                                    img_rows_bwd=None if ref_saved is None else
+                                    (lambda g: refiner_bwd(model, g, ref_saved, keylen_img, B, R, seed_step, p_refine)))
         ar.touch('layer_norm_emb.weight', 'layer_norm_emb.bias', 'position_embeddings.weight', 'embeddings.weight')
         if R > 0:
             ops.gemm_wgrad(de, ximg16, ar.g('image_embeddings.image_embeddings.weight'))
             ar.touch(*[n for n in ar.names if n.startswith('image_embeddings.')])
         if hook is not None:
             hook.embed_done()
-        return (None,) * 10
+        return (None,) * 11
 
 
 class MLMHeadFn(torch.autograd.Function):

@@ -199,6 +199,10 @@ class TransformerModel(nn.Module):
         assert self.dim % 64 == 0
         assert not params.sinusoidal_embeddings, 'sinusoidal positions are outside the hot path'
         assert params.gelu_activation, 'the fused FFN epilogue is bias+GELU(erf)'
+        self.n_refine_layers = int(params.refine_layers)
+        # the reference builds its refiner with the constructor defaults dropout=0.1 (transformer.py:288,411,662),
+        # whatever params.dropout says
+        self.refine_dropout = 0.1
         self.attention_setting = params.attention_setting
         self.use_externel_att = params.use_externel_att
 
@@ -261,6 +265,20 @@ class TransformerModel(nn.Module):
         out['image_embeddings.image_location_embeddings.bias'] = ie.image_location_embeddings.bias
         out['image_embeddings.LayerNorm.weight'] = ie.LayerNorm.weight
         out['image_embeddings.LayerNorm.bias'] = ie.LayerNorm.bias
+        # AoA refiner (jointfwd(refine_image=True)): inside the embedding gradient bucket - its
+        # gradients are the last ones backward produces; the three input projections adjacent like q/k/v
+        own = dict(self.named_parameters())
+        for i in range(self.n_refine_layers):
+            pre = 'refine_embeddings.layers.%d.' % i
+            names = [pre + 'self_attn.linears.%d.weight' % j for j in range(3)] + \
+                    [pre + 'self_attn.linears.%d.bias' % j for j in range(3)]
+            for sub in ('self_attn.aoa_layer.0', 'feed_forward.lin1', 'feed_forward.lin2', 'sublayer.0.norm', 'sublayer.1.norm'):
+                names += [pre + sub + '.weight', pre + sub + '.bias']
+            for n in names:
+                out[n] = own[n]
+        if self.n_refine_layers:
+            out['refine_embeddings.norm.weight'] = own['refine_embeddings.norm.weight']
+            out['refine_embeddings.norm.bias'] = own['refine_embeddings.norm.bias']
         for i in range(self.n_layers):
             a, f = self.attentions[i], self.ffns[i]
             for lin in ('q_lin', 'k_lin', 'v_lin'):
@@ -283,7 +301,6 @@ class TransformerModel(nn.Module):
         out['seq_relationship.bias'] = self.seq_relationship.bias
         # masked-region heads: trained only when cross_mrm_steps / cross_mrfr_steps are set,
         # otherwise never touched (Adam and the clip norm skip untouched ranges)
-        own = dict(self.named_parameters())
         for name in ('transformer_obj.dense.weight', 'transformer_obj.dense.bias', 'transformer_obj.LayerNorm.weight',
                      'transformer_obj.LayerNorm.bias', 'pred_obj_layer.proj.weight', 'pred_obj_layer.proj.bias',
                      'mrfr_dense.weight', 'mrfr_dense.bias', 'pooled_layer2.dense.weight', 'pooled_layer2.dense.bias',
@@ -335,15 +352,19 @@ class TransformerModel(nn.Module):
                  image_loc=None, refine_image=False, is_latent=False, text_embed=None):
         """transformer.py:878-968.  x (T,B) int64, x_img (R,B,2048), image_loc (R,B,5) ->
         (S=R+T, B, d) (a transposed view of the batch-major activation, like the reference)."""
-        assert not causal and not refine_image and not is_latent and text_embed is None, \
-            'causal / refine_image / is_latent / text_embed are outside the MI355X hot path'
+        assert not causal and not is_latent and text_embed is None, \
+            'causal / is_latent / text_embed are outside the MI355X hot path'
         T, B = x.size()
         assert lengths.size(0) == B
         R = x_img.size(0)
         p = self.dropout if self.training else 0.0
         pa = self.attention_dropout if self.training else 0.0
+        p_ref = None
+        if refine_image:     # AoA refiner on the image rows (transformer.py:905-906)
+            assert self.n_refine_layers > 0, 'refine_image=True needs params.refine_layers > 0'
+            p_ref = self.refine_dropout if self.training else 0.0
         out = Fn.EncoderFn.apply(self.layer_norm_emb.weight, self, x, lengths, x_img, lengths_img, image_loc, p, pa,
-                                 self._next_seed_step())
+                                 self._next_seed_step(), p_ref)
         return out.view(B, R + T, self.dim).transpose(0, 1)
 
     def crossfwd(self, x, lengths, causal, stream_='text', src_enc=None, src_len=None, positions=None, langs=None,

@@ -192,41 +192,77 @@ def _drop_args(p):
 
 
 def embed_assemble_fwd(tok, emb16, pos, img_proj, loc, w_loc, b_loc, g_img, be_img, g_emb, be_emb, totlen,
-                       B, T, R, d, seed_img=0, seed_emb=0, p_drop=0.0):
+                       B, T, R, d, seed_img=0, seed_emb=0, p_drop=0.0, img_rows=None, img_saved=None):
+    """img_rows (bf16 [B*R, d], rows b*R + r) replaces the computed image rows (AoA refiner output); img_saved is
+    then the (e, mean_i, rstd_i) triple embed_image_rows_fwd returned for backward."""
     dev = emb16.device
     S = R + T
     h = torch.empty((B * S, d), dtype=BF16, device=dev)
     z = torch.empty((B * S, d), dtype=BF16, device=dev)
     mean_e = torch.empty(B * S, dtype=torch.float32, device=dev)
     rstd_e = torch.empty(B * S, dtype=torch.float32, device=dev)
-    e = torch.empty((max(R * B, 1), d), dtype=BF16, device=dev)
-    mean_i = torch.empty(max(R * B, 1), dtype=torch.float32, device=dev)
-    rstd_i = torch.empty(max(R * B, 1), dtype=torch.float32, device=dev)
+    if img_rows is not None:
+        assert img_rows.dtype == BF16 and img_rows.is_contiguous() and img_rows.shape == (B * R, d)
+        e, mean_i, rstd_i = img_saved
+    else:
+        e = torch.empty((max(R * B, 1), d), dtype=BF16, device=dev)
+        mean_i = torch.empty(max(R * B, 1), dtype=torch.float32, device=dev)
+        rstd_i = torch.empty(max(R * B, 1), dtype=torch.float32, device=dev)
     th, ik = _drop_args(p_drop)
     rc = L.load().m3p_embed_assemble_fwd(
         tok.data_ptr(), emb16.data_ptr(), pos.data_ptr(), L.ptr(img_proj), L.ptr(loc), w_loc.data_ptr(),
         b_loc.data_ptr(), g_img.data_ptr(), be_img.data_ptr(), g_emb.data_ptr(), be_emb.data_ptr(), totlen.data_ptr(),
         h.data_ptr(), z.data_ptr(), mean_e.data_ptr(), rstd_e.data_ptr(), e.data_ptr(), mean_i.data_ptr(),
-        rstd_i.data_ptr(), B, T, R, d, seed_img, seed_emb, th, ik, L.stream())
+        rstd_i.data_ptr(), B, T, R, d, seed_img, seed_emb, th, ik, L.ptr(img_rows), L.stream())
     L.check(rc, 'm3p_embed_assemble_fwd')
     return h, (z, mean_e, rstd_e, e, mean_i, rstd_i)
 
 
+def embed_image_rows_fwd(img_proj, loc, w_loc, b_loc, g_img, be_img, B, R, d, seed_img=0, p_drop=0.0):
+    """Image rows after LayerNorm + dropout as their own tensor (bf16 [B*R, d], rows b*R + r) and the saved
+    (e, mean_i, rstd_i) for backward."""
+    dev = img_proj.device
+    e = torch.empty((R * B, d), dtype=BF16, device=dev)
+    mean_i = torch.empty(R * B, dtype=torch.float32, device=dev)
+    rstd_i = torch.empty(R * B, dtype=torch.float32, device=dev)
+    rows = torch.empty((B * R, d), dtype=BF16, device=dev)
+    th, ik = _drop_args(p_drop)
+    rc = L.load().m3p_embed_image_rows_fwd(img_proj.data_ptr(), loc.data_ptr(), w_loc.data_ptr(), b_loc.data_ptr(),
+                                           g_img.data_ptr(), be_img.data_ptr(), e.data_ptr(), mean_i.data_ptr(),
+                                           rstd_i.data_ptr(), rows.data_ptr(), B, R, d, seed_img, th, ik, L.stream())
+    L.check(rc, 'm3p_embed_image_rows_fwd')
+    return rows, (e, mean_i, rstd_i)
+
+
 def embed_assemble_bwd(dh, saved, g_emb, g_img, tok, totlen, loc, grads, B, T, R, d, pad_index,
-                       seed_img=0, seed_emb=0, p_drop=0.0):
+                       seed_img=0, seed_emb=0, p_drop=0.0, img_rows_bwd=None):
     """grads: dict of fp32 gradient views (d_g_emb, d_be_emb, d_pos, d_emb, d_g_img, d_be_img, d_b_img,
-    d_b_loc, d_w_loc).  Returns de (bf16 [R*B, d])."""
+    d_b_loc, d_w_loc).  Returns de (bf16 [R*B, d]).
+    img_rows_bwd (refine_image): callable taking the gradient of the refined image rows (bf16 [B*R, d]) and
+    returning the gradient of the refiner's input; run between the two halves of the backward."""
     z, mean_e, rstd_e, e, mean_i, rstd_i = saved
     dz = torch.empty_like(z)
     de = torch.empty_like(e)
     th, ik = _drop_args(p_drop)
+    if img_rows_bwd is not None:
+        args = (dh.data_ptr(), z.data_ptr(), mean_e.data_ptr(), rstd_e.data_ptr(), g_emb.data_ptr(), e.data_ptr(),
+                mean_i.data_ptr(), rstd_i.data_ptr(), g_img.data_ptr(), tok.data_ptr(), totlen.data_ptr(), L.ptr(loc),
+                dz.data_ptr(), de.data_ptr(), grads['d_g_emb'].data_ptr(), grads['d_be_emb'].data_ptr(),
+                grads['d_pos'].data_ptr(), grads['d_emb'].data_ptr(), grads['d_g_img'].data_ptr(),
+                grads['d_be_img'].data_ptr(), grads['d_b_img'].data_ptr(), grads['d_b_loc'].data_ptr(),
+                grads['d_w_loc'].data_ptr(), B, T, R, d, pad_index, seed_img, seed_emb, th, ik)
+        L.check(L.load().m3p_embed_assemble_bwd(*args, 1, L.stream()), 'm3p_embed_assemble_bwd')
+        dz_img = dz.view(B, R + T, d)[:, :R, :]
+        dz_img.copy_(img_rows_bwd(dz_img.contiguous().view(B * R, d)).view(B, R, d))
+        L.check(L.load().m3p_embed_assemble_bwd(*args, 2, L.stream()), 'm3p_embed_assemble_bwd')
+        return de
     rc = L.load().m3p_embed_assemble_bwd(
         dh.data_ptr(), z.data_ptr(), mean_e.data_ptr(), rstd_e.data_ptr(), g_emb.data_ptr(), e.data_ptr(),
         mean_i.data_ptr(), rstd_i.data_ptr(), g_img.data_ptr(), tok.data_ptr(), totlen.data_ptr(), L.ptr(loc),
         dz.data_ptr(), de.data_ptr(), grads['d_g_emb'].data_ptr(), grads['d_be_emb'].data_ptr(),
         grads['d_pos'].data_ptr(), grads['d_emb'].data_ptr(), grads['d_g_img'].data_ptr(),
         grads['d_be_img'].data_ptr(), grads['d_b_img'].data_ptr(), grads['d_b_loc'].data_ptr(),
-        grads['d_w_loc'].data_ptr(), B, T, R, d, pad_index, seed_img, seed_emb, th, ik, L.stream())
+        grads['d_w_loc'].data_ptr(), B, T, R, d, pad_index, seed_img, seed_emb, th, ik, 0, L.stream())
     L.check(rc, 'm3p_embed_assemble_bwd')
     return de
 
@@ -344,3 +380,40 @@ def mse_fwd_bwd(pred, tgt, grad_scale):
     L.check(rc, 'm3p_mse_fwd_bwd')
     return row_sq.sum().reshape(1), dpred
 
+
+
+def dropout_rows(x, p_drop, seed, res=None, out=None, rng_ld=None, rng_col0=0):
+    """out = (res or 0) + dropout(x) on a 2-D bf16 view (last dim contiguous; x / res / out may be column slices of
+    wider buffers).  The keep bit of element (r, c) is rng.keep(r * rng_ld + rng_col0 + c): rng_ld defaults to
+    x.shape[1].  out may be x."""
+    _chk_bf16(x)
+    rows, cols = x.shape
+    assert x.stride(1) == 1 and (res is None or (res.dtype == BF16 and res.stride(1) == 1 and res.shape == x.shape))
+    if out is None:
+        out = torch.empty((rows, cols), dtype=BF16, device=x.device)
+    assert out.dtype == BF16 and out.stride(1) == 1 and out.shape == x.shape
+    th, ik = _drop_args(p_drop)
+    rc = L.load().m3p_dropout_rows(x.data_ptr(), x.stride(0), L.ptr(res), res.stride(0) if res is not None else 0,
+                                   out.data_ptr(), out.stride(0), rows, cols, cols if rng_ld is None else rng_ld, rng_col0,
+                                   seed, th, ik, L.stream())
+    L.check(rc, 'm3p_dropout_rows')
+    return out
+
+
+def glu_fwd(ab):
+    """nn.GLU: ab bf16 [rows, 2d] -> ab[:, :d] * sigmoid(ab[:, d:])."""
+    _chk_bf16(ab)
+    rows, d2 = ab.shape
+    assert ab.is_contiguous() and d2 % 2 == 0
+    y = torch.empty((rows, d2 // 2), dtype=BF16, device=ab.device)
+    L.check(L.load().m3p_glu_fwd(ab.data_ptr(), d2, y.data_ptr(), rows, d2 // 2, L.stream()), 'm3p_glu_fwd')
+    return y
+
+
+def glu_bwd(ab, dy):
+    _chk_bf16(ab, dy)
+    rows, d2 = ab.shape
+    assert ab.is_contiguous() and dy.is_contiguous() and dy.shape == (rows, d2 // 2)
+    dab = torch.empty_like(ab)
+    L.check(L.load().m3p_glu_bwd(ab.data_ptr(), d2, dy.data_ptr(), dab.data_ptr(), rows, d2 // 2, L.stream()), 'm3p_glu_bwd')
+    return dab

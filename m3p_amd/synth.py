@@ -117,6 +117,30 @@ def clcm_head_param_shapes(p):
     return out
 
 
+def refiner_param_shapes(p):
+    """AoA_Refiner_Core parameters (transformer.py:287-422, built at :662 with params.refine_layers layers) in the
+    reference's state-dict naming."""
+    d = p.emb_dim
+    out = OrderedDict()
+    for i in range(p.refine_layers):
+        pre = 'refine_embeddings.layers.%d.' % i
+        for j in range(3):
+            out[pre + 'self_attn.linears.%d.weight' % j] = (d, d)
+            out[pre + 'self_attn.linears.%d.bias' % j] = (d,)
+        out[pre + 'self_attn.aoa_layer.0.weight'] = (2 * d, 2 * d)
+        out[pre + 'self_attn.aoa_layer.0.bias'] = (2 * d,)
+        out[pre + 'feed_forward.lin1.weight'] = (4 * d, d)
+        out[pre + 'feed_forward.lin1.bias'] = (4 * d,)
+        out[pre + 'feed_forward.lin2.weight'] = (d, 4 * d)
+        out[pre + 'feed_forward.lin2.bias'] = (d,)
+        for k in (0, 1):
+            out[pre + 'sublayer.%d.norm.weight' % k] = (d,)
+            out[pre + 'sublayer.%d.norm.bias' % k] = (d,)
+    out['refine_embeddings.norm.weight'] = (d,)
+    out['refine_embeddings.norm.bias'] = (d,)
+    return out
+
+
 def make_region_targets(R, B, seed=2468, p_mask=0.3, n_objs=1600):
     """Synthetic MRM / MRFR targets: obj_labels (B, R) int64, -1 = region not masked, else the object class
     of the masked region (xtrainer.py:2263, 2325-2328); ori_att_feats (B, R, 2048) fp32 = the original region

@@ -316,7 +316,61 @@ def gen_clcm_goldens():
     print('cfg1_clcm.npz: clcm bce %.6f' % float(loss))
 
 
+def gen_refiner_goldens():
+    """AoA refiner: the reference's jointfwd(refine_image=True) with params.refine_layers = 2 on the
+    cfg1 batch (eval mode: the refiner's dropouts are hard-wired to 0.1 in train mode), MLM + ITM losses and the
+    gradients of every refiner parameter and of a few parameters up- and downstream of it; plus the refiner
+    module alone on a random (B, R, d) input with a ragged region mask."""
+    from src.model.transformer import TransformerModel
+    cfg = synth.CONFIGS['cfg1']
+    P = synth.model_params(cfg['emb_dim'], cfg['n_heads'], cfg['n_layers'], cfg['n_words'], refine_layers=2)
+    torch.manual_seed(0)
+    m = TransformerModel(P, is_encoder=True, with_output=True, is_crossModal=True)
+    shapes = synth.hot_param_shapes(P)
+    rshapes = synth.refiner_param_shapes(P)
+    own = dict(m.named_parameters())
+    with torch.no_grad():
+        for sd_ in (synth.golden_state_dict(shapes), synth.golden_state_dict(rshapes, seed=2468, pad_index=None)):
+            for k, v in sd_.items():
+                assert tuple(own[k].shape) == tuple(v.shape), (k, own[k].shape, v.shape)
+                own[k].copy_(v)
+    assert set(n for n in own if n.startswith('refine_embeddings.')) == set(rshapes), 'refiner parameter enumeration'
+    m.eval()
+    batch = synth.make_batch(cfg['T'], cfg['R'], cfg['B'], cfg['n_words'], cfg['n_pred'])
+    R = cfg['R']
+    out = m('jointfwd', x=batch['x'], lengths=batch['lengths'], x_img=batch['x_img'], lengths_img=batch['lengths_img'],
+            causal=False, langs=None, image_loc=batch['image_loc'], refine_image=True)
+    _, mlm = m('predict', tensor=out[R:], pred_mask=batch['pred_mask'], y=batch['y'], get_scores=False)
+    rel = m('predict', tensor=out.transpose(0, 1), is_relation=True)
+    onehot = torch.eye(2)[batch['pos_labels']].reshape(-1)
+    bce = torch.nn.functional.binary_cross_entropy_with_logits(rel.view(-1), onehot)
+    (mlm + bce).backward()
+    g = {'out': out.detach().numpy(), 'mlm_loss': mlm.detach().numpy(), 'itm_bce': bce.detach().numpy()}
+    for k in list(rshapes) + ['image_embeddings.image_embeddings.weight', 'image_embeddings.LayerNorm.weight',
+                              'image_embeddings.image_location_embeddings.weight', 'layer_norm_emb.weight',
+                              'attentions.0.q_lin.weight', 'position_embeddings.weight']:
+        # (copies: the module-alone backward below accumulates into the same .grad storage)
+        g['grad/' + k] = (own[k].grad if k != 'position_embeddings.weight' else own[k].grad[:R + cfg['T']]).clone().numpy()
+    # the module alone, ragged mask
+    rs = np.random.RandomState(97)
+    B = cfg['B']
+    xin = torch.from_numpy(rs.standard_normal((B, R, cfg['emb_dim'])).astype(np.float32)).requires_grad_(True)
+    lens = torch.from_numpy(rs.randint(R // 2, R + 1, size=B)).long()
+    mask = torch.arange(R)[None, :] < lens[:, None]
+    y = m.refine_embeddings(xin, mask)
+    wgt = torch.from_numpy(rs.standard_normal(tuple(y.shape)).astype(np.float32))
+    (y * wgt).sum().backward()
+    g.update({'unit_x': xin.detach().numpy(), 'unit_lens': lens.numpy(), 'unit_y': y.detach().numpy(), 'unit_w': wgt.numpy(),
+              'unit_dx': xin.grad.numpy()})
+    np.savez_compressed(os.path.join(OUT, 'cfg1_refiner.npz'), **g)
+    print('cfg1_refiner.npz: mlm %.6f itm %.6f' % (float(mlm), float(bce)))
+
+
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'refiner':
+        gen_refiner_goldens()
+        sys.exit(0)
+    gen_refiner_goldens()
     gen_clcm_goldens()
     gen_region_head_goldens()
     gen_text_and_itm_goldens()

@@ -103,9 +103,48 @@ def image_embeddings(sd, x_img, loc, p=0.0, keep=None, prefix='image_embeddings.
 # the encoder: TransformerModel.jointfwd
 # ----------------------------------------------------------------------------
 
+def aoa_refiner(sd, x, attn_mask, n_refine_layers, n_heads, p=0.0, keeps=None, prefix='refine_embeddings.'):
+    """AoA_Refiner_Core.forward, transformer.py:410-422 (built at :662; applied to the image rows by
+    jointfwd(refine_image=True), :905-906).  x (B, R, d), attn_mask (B, R) bool -> (B, R, d).
+    Per layer (AoA_Refiner_Layer :405-407 over pre-norm SublayerConnection :392-394):
+      x = x + drop(AoA(LN_a(x)))  with AoA = MultiHeadedDotAttention(do_aoa=1) :327-371:
+            q, k, v = linears[0..2](xn)  -> heads of d_k = d / h                      (:352-354)
+            P = dropout(softmax(q k^T / sqrt(d_k), masked_fill(mask == 0, -inf)))      (attention_sub :274-284)
+            out = GLU(Linear_{2d -> 2d}(dropout_aoa(cat([P v, xn], -1))))              (:364-366)
+      x = x + drop(FFN(LN_b(x)))  with TransformerFFN (:222-227: lin2(gelu(lin1)), then its own dropout)
+    then the final LayerNorm (:422).  All dropout rates are the constructor defaults 0.1 in the reference
+    (:288, :411 - not params.dropout); ``p`` here, with optional keep masks
+    keeps[('ref_attn_p', i) | ('ref_aoa', i) | ('ref_sub0', i) | ('ref_ffn', i) | ('ref_sub1', i)]."""
+    keeps = keeps or {}
+    B, R, d = x.shape
+    dk = d // n_heads
+
+    def heads(t):
+        return t.view(B, R, n_heads, dk).transpose(1, 2)
+
+    for i in range(n_refine_layers):
+        pre = prefix + 'layers.%d.' % i
+        xn = layer_norm(x, sd[pre + 'sublayer.0.norm.weight'], sd[pre + 'sublayer.0.norm.bias'])
+        q, k, v = [heads(F.linear(xn, sd[pre + 'self_attn.linears.%d.weight' % j], sd[pre + 'self_attn.linears.%d.bias' % j]))
+                   for j in range(3)]
+        scores = torch.matmul(q, k.transpose(-2, -1)) / math.sqrt(dk)
+        scores = scores.masked_fill(~attn_mask[:, None, None, :], -float('inf'))
+        pa = _drop(F.softmax(scores, dim=-1), keeps.get(('ref_attn_p', i)), p)
+        att = torch.matmul(pa, v).transpose(1, 2).contiguous().view(B, R, d)
+        cat = _drop(torch.cat([att, xn], -1), keeps.get(('ref_aoa', i)), p)
+        ab = F.linear(cat, sd[pre + 'self_attn.aoa_layer.0.weight'], sd[pre + 'self_attn.aoa_layer.0.bias'])
+        x = x + _drop(F.glu(ab, dim=-1), keeps.get(('ref_sub0', i)), p)
+        xn = layer_norm(x, sd[pre + 'sublayer.1.norm.weight'], sd[pre + 'sublayer.1.norm.bias'])
+        f = transformer_ffn(xn, sd[pre + 'feed_forward.lin1.weight'], sd[pre + 'feed_forward.lin1.bias'],
+                            sd[pre + 'feed_forward.lin2.weight'], sd[pre + 'feed_forward.lin2.bias'],
+                            p=p, keep=keeps.get(('ref_ffn', i)))
+        x = x + _drop(f, keeps.get(('ref_sub1', i)), p)
+    return layer_norm(x, sd[prefix + 'norm.weight'], sd[prefix + 'norm.bias'])
+
+
 def jointfwd(sd, n_layers, n_heads, x, lengths, x_img, lengths_img, image_loc,
-             dropout=0.0, attention_dropout=0.0, keeps=None, text_embed=None):
-    """TransformerModel.jointfwd, transformer.py:878-968 (refine_image=False).
+             dropout=0.0, attention_dropout=0.0, keeps=None, text_embed=None, refine_layers=0, refine_dropout=0.0):
+    """TransformerModel.jointfwd, transformer.py:878-968 (refine_layers > 0: with refine_image=True).
 
     x (T, B) int64; x_img (R, B, 2048); image_loc (R, B, 5) -> (S=R+T, B, d).
     Order of operations reproduced exactly:
@@ -123,6 +162,9 @@ def jointfwd(sd, n_layers, n_heads, x, lengths, x_img, lengths_img, image_loc,
     img = image_embeddings(sd, x_img.transpose(0, 1), image_loc.transpose(0, 1),
                            p=dropout, keep=keeps.get('img'))
     R = img.shape[1]
+    if refine_layers:      # refine_image=True (:903-906): the refiner sees the image rows under their own length mask
+        _, img_attn_mask = get_masks(R, lengths_img)
+        img = aoa_refiner(sd, img, img_attn_mask, refine_layers, n_heads, p=refine_dropout, keeps=keeps)
     tok = text_embed if text_embed is not None else F.embedding(xt, sd['embeddings.weight'])
     S = R + T
     mask, attn_mask = get_masks(S, lengths_img + lengths)
@@ -259,13 +301,15 @@ def itm_loss(relation_scores, pos_labels, sample_n, multi_w, bin_w):
 
 
 def pretrain_losses(sd, n_layers, n_heads, batch, R, sample_n=2, multi_w=0.0, bin_w=1.0,
-                    with_itm=True, dropout=0.0, attention_dropout=0.0, keeps=None, with_mrm=False, with_mrfr=False):
+                    with_itm=True, dropout=0.0, attention_dropout=0.0, keeps=None, with_mrm=False, with_mrfr=False,
+                    refine_layers=0, refine_dropout=0.0):
     """The loss half of XTrainer.pretrain_under_step (xtrainer.py:2281-2375) for the
     MLM (+MRM, +MRFR, +ITM) objective: jointfwd -> text slice out[R:] -> MLM CE; image slice out[:R],
     batch-major -> masked-region classification / feature regression; whole sequence, batch-major ->
     relation scores -> ITM loss; total = sum (lambdas = 1)."""
     out = jointfwd(sd, n_layers, n_heads, batch['x'], batch['lengths'], batch['x_img'],
-                   batch['lengths_img'], batch['image_loc'], dropout, attention_dropout, keeps)
+                   batch['lengths_img'], batch['image_loc'], dropout, attention_dropout, keeps,
+                   refine_layers=refine_layers, refine_dropout=refine_dropout)
     res = {'out': out}
     total = 0
     if batch['pred_mask'].any():

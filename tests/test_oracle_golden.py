@@ -216,3 +216,37 @@ def test_clcm_second_pass(golden_dir):
     loss.backward()
     for k in [k[5:] for k in g if k.startswith('grad/')]:
         assert rel_l2(sd[k].grad, g['grad/' + k]) < 1e-4, k
+
+
+def test_aoa_refiner_vs_reference(golden_dir):
+    """AoA refiner: the restatement against what the reference computed - the module alone on a
+    ragged region mask, and jointfwd(refine_image=True) with its losses and gradients."""
+    g = _load(golden_dir, 'cfg1_refiner.npz')
+    cfg = synth.CONFIGS['cfg1']
+    P = synth.model_params(cfg['emb_dim'], cfg['n_heads'], cfg['n_layers'], cfg['n_words'], refine_layers=2)
+    sd = dict(synth.golden_state_dict(synth.hot_param_shapes(P)))
+    sd.update(synth.golden_state_dict(synth.refiner_param_shapes(P), seed=2468, pad_index=None))
+    sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    # the module alone
+    x = _t(g['unit_x']).clone().requires_grad_(True)
+    R = x.shape[1]
+    mask = torch.arange(R)[None, :] < _t(g['unit_lens'])[:, None]
+    y = O.aoa_refiner(sd, x, mask, 2, cfg['n_heads'])
+    assert rel_l2(y.detach(), g['unit_y']) < 1e-5
+    (y * _t(g['unit_w'])).sum().backward()
+    assert rel_l2(x.grad, g['unit_dx']) < 1e-4
+    for v in sd.values():
+        v.grad = None
+    # inside jointfwd
+    batch = synth.make_batch(cfg['T'], cfg['R'], cfg['B'], cfg['n_words'], cfg['n_pred'])
+    res = O.pretrain_losses(sd, cfg['n_layers'], cfg['n_heads'], batch, cfg['R'], refine_layers=2)
+    assert rel_l2(res['out'].detach(), g['out']) < 1e-5
+    assert abs(float(res['mlm']) - float(g['mlm_loss'])) < 1e-5 and abs(float(res['itm']) - float(g['itm_bce'])) < 1e-6
+    res['total'].backward()
+    S = cfg['R'] + cfg['T']
+    for k in [k[5:] for k in g if k.startswith('grad/')]:
+        own = sd[k].grad[:S] if k == 'position_embeddings.weight' else sd[k].grad
+        if k.endswith('self_attn.linears.1.bias'):     # key bias: the true gradient is 0 (softmax shift invariance)
+            assert float(own.norm()) < 1e-9 and float(np.linalg.norm(g['grad/' + k])) < 1e-9, k
+            continue
+        assert rel_l2(own, g['grad/' + k]) < 2e-4, k

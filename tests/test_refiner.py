@@ -1,0 +1,187 @@
+"""AoA image refiner on the MI355X path (jointfwd(refine_image=True), transformer.py:287-422,
+:905-906): the two elementwise kernels against NumPy / torch, the refiner alone with its dropouts on against
+the oracle fed with the same keep masks, and the whole jointfwd + losses + gradients against the reference's
+golden vectors and the oracle.  bf16 bars of SURVEY 8c."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from m3p_amd import synth
+from tests.util import rel_l2, max_abs, randn_bf16
+
+pytestmark = pytest.mark.gpu
+
+
+def test_dropout_rows_views_and_residual():
+    from m3p_amd import ops, rng
+    rows, d, seed, p = 37, 96, 777, 0.25
+    x0, x0c = randn_bf16((rows, d), 1)
+    x1, x1c = randn_bf16((rows, d), 2)
+    cat = torch.zeros((rows, 2 * d), dtype=torch.bfloat16, device='cuda')
+    ops.dropout_rows(x0, p, seed, out=cat[:, :d], rng_ld=2 * d, rng_col0=0)
+    ops.dropout_rows(x1, p, seed, out=cat[:, d:], rng_ld=2 * d, rng_col0=d)
+    keep = torch.from_numpy(rng.keep_mask(rows * 2 * d, seed, p, (rows, 2 * d))).float()
+    ref = (torch.cat([x0c, x1c], 1) * keep / (1 - p)).to(torch.bfloat16).float()
+    assert torch.equal(cat.float().cpu(), ref)
+    assert 0.7 < float(keep.mean()) < 0.8
+    # backward of the concatenation: the halves of a [rows, 2d] gradient through the same mask
+    g, gc = randn_bf16((rows, 2 * d), 3)
+    gl = ops.dropout_rows(g[:, :d], p, seed, rng_ld=2 * d, rng_col0=0)
+    gr = ops.dropout_rows(g[:, d:], p, seed, rng_ld=2 * d, rng_col0=d)
+    refg = (gc * keep / (1 - p)).to(torch.bfloat16).float()
+    assert torch.equal(gl.float().cpu(), refg[:, :d]) and torch.equal(gr.float().cpu(), refg[:, d:])
+    # residual form, in place, and p = 0 (a plain add)
+    res, resc = randn_bf16((rows, d), 4)
+    y = ops.dropout_rows(x0, p, seed + 1, res=res)
+    k2 = torch.from_numpy(rng.keep_mask(rows * d, seed + 1, p, (rows, d))).float()
+    ref2 = ((x0c * k2 / (1 - p)).to(torch.bfloat16).float() + resc).to(torch.bfloat16).float()
+    assert torch.equal(y.float().cpu(), ref2)
+    z = x0.clone()
+    ops.dropout_rows(z, p, seed + 1, out=z)
+    assert torch.equal(z.float().cpu(), (x0c * k2 / (1 - p)).to(torch.bfloat16).float())
+    assert torch.equal(ops.dropout_rows(x0, 0.0, 0, res=res).float().cpu(), (x0c + resc).to(torch.bfloat16).float())
+
+
+def test_glu_fwd_bwd():
+    from m3p_amd import ops
+    rows, d = 50, 128
+    ab, abc = randn_bf16((rows, 2 * d), 5, 1.5)
+    dy, dyc = randn_bf16((rows, d), 6)
+    y = ops.glu_fwd(ab)
+    x = abc.clone().requires_grad_(True)
+    ref = torch.nn.functional.glu(x, dim=-1)
+    assert rel_l2(y.float(), ref) < 4e-3
+    ref.backward(dyc)
+    dab = ops.glu_bwd(ab, dy)
+    assert rel_l2(dab.float(), x.grad) < 6e-3
+
+
+def _check_refiner_grads(own_grads, ref_grads, tol_1d=5e-2, tol_2d=5e-2):
+    """relL2 <= 5e-2 per parameter, except
+    * q / k projections whose true gradient is at noise level (near-uniform attention at the 0.02-scale golden
+      weights: 3-5 orders below the value projection's; the key bias is exactly 0): absolute bar against the
+      value-bias gradient;
+    * tol_1d / tol_2d for the bias-type / matrix parameters where the test says so (column sums over few rows that cancel to a
+      fraction of their terms amplify the bf16 rounding of the summed rows)."""
+    vb = float(torch.as_tensor(ref_grads['refine_embeddings.layers.0.self_attn.linears.2.bias']).norm())
+    bad = []
+    for n, gref in ref_grads.items():
+        gm, gref = own_grads[n], torch.as_tensor(gref)
+        assert gm is not None, n
+        if ('.self_attn.linears.0.' in n or '.self_attn.linears.1.' in n) and float(gref.norm()) < 1e-2 * vb:
+            assert float(gm.float().norm()) < 3e-2 * vb, n
+            continue
+        err = rel_l2(gm, gref)
+        if err > (tol_1d if gref.dim() == 1 else tol_2d):
+            bad.append((n, err))
+    assert not bad, bad
+
+
+def _build(cfg, n_refine, refine_dropout=0.0, dropout=0.0):
+    from m3p_amd.model.transformer import TransformerModel
+    P = synth.model_params(cfg['emb_dim'], cfg['n_heads'], cfg['n_layers'], cfg['n_words'], dropout=dropout,
+                           attention_dropout=dropout, refine_layers=n_refine)
+    torch.manual_seed(0)
+    m = TransformerModel(P, is_encoder=True, with_output=True, is_crossModal=True)
+    sd = dict(synth.golden_state_dict(synth.hot_param_shapes(P)))
+    sd.update(synth.golden_state_dict(synth.refiner_param_shapes(P), seed=2468, pad_index=None))
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected
+    m.refine_dropout = refine_dropout
+    return m.cuda(), P, sd
+
+
+def _losses(m, batch, R, sample_n=2):
+    dev = 'cuda'
+    out = m('jointfwd', x=batch['x'].to(dev), lengths=batch['lengths'].to(dev), x_img=batch['x_img'].to(dev),
+            lengths_img=batch['lengths_img'].to(dev), causal=False, langs=None, image_loc=batch['image_loc'].to(dev),
+            refine_image=True)
+    _, mlm = m('predict', tensor=out[R:], pred_mask=batch['pred_mask'].to(dev), y=batch['y'].to(dev), get_scores=False)
+    rel = m('predict', tensor=out.transpose(0, 1), is_relation=True)
+    onehot = torch.eye(sample_n, device=dev)[batch['pos_labels'].to(dev)].reshape(-1)
+    bce = torch.nn.functional.binary_cross_entropy_with_logits(rel.view(-1).float(), onehot)
+    return out, mlm, bce
+
+
+def test_refine_image_forward_and_grads_vs_reference_golden(golden_dir):
+    g = dict(np.load(os.path.join(golden_dir, 'cfg1_refiner.npz')))
+    cfg = synth.CONFIGS['cfg1']
+    m, P, sd = _build(cfg, 2)
+    m.train()
+    batch = synth.make_batch(cfg['T'], cfg['R'], cfg['B'], cfg['n_words'], cfg['n_pred'])
+    m.arena().zero_grad()
+    out, mlm, bce = _losses(m, batch, cfg['R'])
+    assert rel_l2(out.float(), g['out']) < 1e-2
+    assert abs(float(mlm) - float(g['mlm_loss'])) < 5e-3 and abs(float(bce) - float(g['itm_bce'])) < 5e-3
+    (mlm + bce).backward()
+    torch.cuda.synchronize()
+    own = dict(m.named_parameters())
+    S = cfg['R'] + cfg['T']
+    ref = {k[5:]: torch.from_numpy(v) for k, v in g.items() if k.startswith('grad/')}
+    mine = {k: (own[k].grad[:S] if k == 'position_embeddings.weight' else own[k].grad) for k in ref}
+    # 1-D parameters: 80 image rows (B = 8 x R = 10) whose column sums cancel to ~1/8 of the uncancelled scale
+    # (|d norm.bias| = 0.014 against |d norm.weight| = 0.116): measured 0.09-0.11, all rounding of the bf16 rows;
+    # (matrices: lin2.weight 0.056, the rest < 5e-2); the d = 768 / 216-row case below holds 5e-2 on every parameter
+    _check_refiner_grads(mine, ref, tol_1d=1.5e-1, tol_2d=7e-2)
+
+
+def test_refine_image_gradients_vs_oracle_mid():
+    """cfg2 width (d = 768, 12 heads, 36 regions), 2 encoder + 2 refiner layers, ragged text."""
+    from oracle import ref_cpu as O
+    cfg = dict(emb_dim=768, n_heads=12, n_layers=2, n_words=5000, T=40, R=36, B=6, n_pred=6)
+    m, P, sd = _build(cfg, 2)
+    m.train()
+    batch = synth.make_batch(cfg['T'], cfg['R'], cfg['B'], cfg['n_words'], cfg['n_pred'], seed=7)
+    m.arena().zero_grad()
+    out, mlm, bce = _losses(m, batch, cfg['R'])
+    (mlm + bce).backward()
+    torch.cuda.synchronize()
+    names = list(sd.keys())
+    leaves = {n: sd[n].clone().requires_grad_(True) for n in names}
+    res = O.pretrain_losses(leaves, cfg['n_layers'], cfg['n_heads'], batch, cfg['R'], refine_layers=2)
+    grads = dict(zip(names, torch.autograd.grad(res['total'], [leaves[n] for n in names])))
+    assert rel_l2(out.float(), res['out']) < 1e-2
+    assert abs(float(mlm) - float(res['mlm'])) < 5e-3 and abs(float(bce) - float(res['itm'])) < 5e-3
+    own = dict(m.named_parameters())
+    ref = {n: grads[n] for n in names if n.startswith('refine_embeddings.') or n.startswith('image_embeddings.')}
+    _check_refiner_grads({n: own[n].grad for n in ref}, ref)
+
+
+def test_refiner_alone_with_dropout_vs_oracle_masks():
+    """functional.refiner_fwd / refiner_bwd at p = 0.1 (the reference's hard-wired rate) against the oracle driven
+    by the keep masks the NumPy twin of the device RNG produces for the same (seed, site) streams."""
+    from oracle import ref_cpu as O
+    from m3p_amd import functional as Fn, rng
+    cfg = dict(emb_dim=256, n_heads=4, n_layers=1, n_words=500, T=8, R=20, B=5, n_pred=2)
+    m, P, sd = _build(cfg, 2)
+    B, R, d, H = cfg['B'], cfg['R'], cfg['emb_dim'], cfg['n_heads']
+    p, step = 0.1, 5
+    x, xc = randn_bf16((B * R, d), 11)
+    lens = torch.tensor([20, 13, 20, 17, 11], dtype=torch.int32)
+    dy, dyc = randn_bf16((B * R, d), 12, 0.1)
+    ar = m.arena()
+    ar.refresh()
+    ar.zero_grad()
+    y, saved = Fn.refiner_fwd(m, x, lens.cuda(), B, R, step, p)
+    dx = Fn.refiner_bwd(m, dy, saved, lens.cuda(), B, R, step, p)
+    torch.cuda.synchronize()
+    keeps = {}
+    for i in range(2):
+        sdl = lambda k: rng.stream_seed(m.base_seed, step, Fn._REF_SITE0 + 8 * i + k)   # noqa: E731
+        keeps[('ref_attn_p', i)] = torch.from_numpy(rng.keep_mask(B * H * R * R, sdl(0), p, (B, H, R, R)))
+        keeps[('ref_aoa', i)] = torch.from_numpy(rng.keep_mask(B * R * 2 * d, sdl(1), p, (B, R, 2 * d)))
+        keeps[('ref_sub0', i)] = torch.from_numpy(rng.keep_mask(B * R * d, sdl(2), p, (B, R, d)))
+        keeps[('ref_ffn', i)] = torch.from_numpy(rng.keep_mask(B * R * d, sdl(3), p, (B, R, d)))
+        keeps[('ref_sub1', i)] = torch.from_numpy(rng.keep_mask(B * R * d, sdl(4), p, (B, R, d)))
+    leaves = {n: v.clone().requires_grad_(True) for n, v in sd.items() if n.startswith('refine_embeddings.')}
+    xin = xc.view(B, R, d).clone().requires_grad_(True)
+    mask = torch.arange(R)[None, :] < lens.long()[:, None]
+    yref = O.aoa_refiner(leaves, xin, mask, 2, H, p=p, keeps=keeps)
+    assert rel_l2(y.float(), yref.reshape(B * R, d)) < 1e-2
+    names = list(leaves)
+    grads = torch.autograd.grad((yref * dyc.view(B, R, d)).sum(), [xin] + [leaves[n] for n in names])
+    assert rel_l2(dx.float(), grads[0].reshape(B * R, d)) < 3e-2
+    own = dict(m.named_parameters())
+    _check_refiner_grads({n: own[n].grad for n in names}, dict(zip(names, grads[1:])))
