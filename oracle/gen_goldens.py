@@ -366,10 +366,31 @@ def gen_refiner_goldens():
     print('cfg1_refiner.npz: mlm %.6f itm %.6f' % (float(mlm), float(bce)))
 
 
+def gen_state_dict_enumeration():
+    """Checkpoint interop: every key and shape of the reference model's state_dict() - what a
+    released checkpoint's 'model' entry holds (xtrainer.py:517-529) - for a small geometry with a refiner."""
+    from src.model.transformer import TransformerModel
+    P = synth.model_params(64, 2, 2, 120, refine_layers=1)
+    m = TransformerModel(P, is_encoder=True, with_output=True, is_crossModal=True)
+    sd = m.state_dict()
+    keys = sorted(sd.keys())
+    shapes = np.zeros((len(keys), 2), dtype=np.int64)
+    for i, k in enumerate(keys):
+        sh = tuple(sd[k].shape)
+        shapes[i, :len(sh)] = sh
+    np.savez_compressed(os.path.join(OUT, 'state_dict_enum.npz'), keys=np.array(keys), shapes=shapes,
+                        geometry=np.array([64, 2, 2, 120, 1]))
+    print('state_dict_enum.npz: %d entries' % len(keys))
+
+
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'enum':
+        gen_state_dict_enumeration()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'refiner':
         gen_refiner_goldens()
         sys.exit(0)
+    gen_state_dict_enumeration()
     gen_refiner_goldens()
     gen_clcm_goldens()
     gen_region_head_goldens()

@@ -99,3 +99,47 @@ def test_model_constructs_on_cpu_with_reference_names():
           x_img=torch.zeros(2, 2, 2048), lengths_img=torch.tensor([2, 2]), image_loc=torch.zeros(2, 2, 5))
     with pytest.raises(NotImplementedError):
         m('fwd', x=None)
+
+
+def test_state_dict_is_the_reference_enumeration_and_checkpoints_round_trip(golden_dir, tmp_path):
+    """Checkpoint interop: our state_dict() has exactly the reference model's keys and shapes
+    (tests/golden/state_dict_enum.npz, recorded from the reference), so a released checkpoint's 'model' entry loads
+    strictly; 'module.'-prefixed keys (saved from under DDP, model/__init__.py:99-100) and the reference's
+    {'model': ..., 'params': ...} layout (xtrainer.py:517-529) go through save_model / reload_checkpoint."""
+    import os
+    import numpy as np
+    from types import SimpleNamespace
+    from m3p_amd.model.transformer import TransformerModel
+    from m3p_amd.trainer import XTrainer
+    g = np.load(os.path.join(golden_dir, 'state_dict_enum.npz'))
+    d, h, nl, V, nref = (int(v) for v in g['geometry'])
+    P = synth.model_params(d, h, nl, V, refine_layers=nref)
+    m = TransformerModel(P, is_encoder=True, with_output=True, is_crossModal=True)
+    sd = m.state_dict()
+    ref = {str(k): tuple(int(v) for v in s if v) for k, s in zip(g['keys'], g['shapes'])}
+    assert sorted(sd.keys()) == sorted(ref.keys())
+    for k, shape in ref.items():
+        assert tuple(sd[k].shape) == shape, k
+    # a checkpoint in the reference's layout with DDP-prefixed keys
+    torch.manual_seed(3)
+    want = {k: torch.randn_like(v) for k, v in sd.items()}
+    want['pred_layer.proj.weight'] = want['embeddings.weight']          # tied (transformer.py:728-729)
+    path = os.path.join(str(tmp_path), 'checkpoint.pth')
+    torch.save({'model': {'module.' + k: v for k, v in want.items()}, 'params': dict(P.__dict__), 'epoch': 4,
+                'n_total_iter': 17, 'model_optimizer': {'param_groups': [{'num_updates': 123, 'lr': 0.0}]}}, path)
+    for k, v in dict(optimizer='adam_inverse_sqrt,beta1=0.9,beta2=0.98,lr=0.0001', clip_grad_norm=5, amp=-1, fp16=False,
+                     accumulate_gradients=1, multi_gpu=False, local_rank=0, epoch_size=10, batch_size=2,
+                     dump_path=str(tmp_path)).items():
+        setattr(P, k, v)
+    tr = XTrainer(m, {}, P)
+    tr.reload_checkpoint(path)
+    got = m.state_dict()
+    for k, v in want.items():
+        assert torch.equal(got[k], v), k
+    assert tr.epoch == 5 and tr.n_total_iter == 17
+    grp = tr.optimizers['model'].param_groups[0]
+    assert grp['num_updates'] == 123 and abs(grp['lr'] - tr.optimizers['model'].get_lr_for_step(123)) < 1e-12
+    out = tr.save_model('best')
+    back = torch.load(out, map_location='cpu', weights_only=False)
+    assert set(back.keys()) == {'model', 'params'} and sorted(back['model'].keys()) == sorted(ref.keys())
+    assert all(torch.equal(back['model'][k], want[k]) for k in want)
