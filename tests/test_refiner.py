@@ -185,3 +185,47 @@ def test_refiner_alone_with_dropout_vs_oracle_masks():
     assert rel_l2(dx.float(), grads[0].reshape(B * R, d)) < 3e-2
     own = dict(m.named_parameters())
     _check_refiner_grads({n: own[n].grad for n in names}, dict(zip(names, grads[1:])))
+
+
+def test_pretrain_under_step_with_refine_image_trains_the_refiner():
+    """XTrainer.pretrain_under_step with params.refine_image=True (the reference parser's default, train_x.py:285):
+    three optimizer steps with every dropout on; the refiner's parameters move, stay finite, and the run is
+    repeatable from the same seeds."""
+    from m3p_amd.model.transformer import TransformerModel
+    from m3p_amd.trainer import XTrainer
+    cfg = dict(emb_dim=256, n_heads=4, n_layers=2, n_words=2000, T=16, R=12, B=8, n_pred=3)
+
+    def run():
+        P = synth.model_params(cfg['emb_dim'], cfg['n_heads'], cfg['n_layers'], cfg['n_words'], dropout=0.1,
+                               attention_dropout=0.1, refine_layers=2)
+        for k, v in dict(optimizer='adam_inverse_sqrt,beta1=0.9,beta2=0.98,lr=0.0001', clip_grad_norm=5, amp=1, fp16=True,
+                         accumulate_gradients=1, multi_gpu=False, local_rank=0, epoch_size=100000,
+                         cross_mlm_steps=[('google', 'img')], cross_mrm_steps=[], cross_mrfr_steps=[], cross_clcm_steps=[],
+                         sample_n=2, refine_image=True, multi_cls_loss_weight=0, bin_cls_loss_weight=1,
+                         batch_size=cfg['B'], dump_path='/tmp').items():
+            setattr(P, k, v)
+        torch.manual_seed(1234)
+        model = TransformerModel(P, is_encoder=True, with_output=True, is_crossModal=True).cuda()
+        tr = XTrainer(model, {}, P)
+        batch = synth.make_batch(cfg['T'], cfg['R'], cfg['B'], cfg['n_words'], cfg['n_pred'], seed=31, ragged=True)
+        B, R = cfg['B'], cfg['R']
+        img = batch['x_img'].transpose(0, 1).contiguous().cuda()
+        loc = batch['image_loc'].transpose(0, 1).contiguous().cuda()
+        tup = ((batch['x'].cuda(), batch['lengths'].cuda(), batch['x_labels']),
+               (img, torch.ones(B, R, dtype=torch.long, device='cuda'), loc, None, batch['pos_labels'].tolist(), None, None))
+        names = [n for n, _ in model.named_parameters() if n.startswith('refine_embeddings.')]
+        before = {n: p.detach().float().clone() for n, p in model.named_parameters() if n in names}
+        for _ in range(3):
+            tr.pretrain_under_step(tup, 'google', 't2i', 'en', 1.0, 1.0, 1.0, 1.0)
+            tr.n_iter += 1
+        torch.cuda.synchronize()
+        after = {n: p.detach().float().clone() for n, p in model.named_parameters() if n in names}
+        return before, after
+
+    b1, a1 = run()
+    moved = [n for n in a1 if float((a1[n] - b1[n]).abs().max()) > 0]
+    assert all(torch.isfinite(v).all() for v in a1.values())
+    assert len(moved) >= len(a1) - 4, sorted(set(a1) - set(moved))      # (the two key biases have zero gradient)
+    b2, a2 = run()
+    for n in a1:
+        assert rel_l2(a2[n] - b2[n], a1[n] - b1[n]) < 5e-2 or float((a1[n] - b1[n]).abs().max()) < 1e-6, n
