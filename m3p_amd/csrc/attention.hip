@@ -27,7 +27,7 @@ namespace {
 // (tools/attn_timeline.py reads them back through m3p_debug_attn_timeline).
 #ifdef M3P_ATTN_TL
 __device__ unsigned long long g_attn_tl[4096 * 4 * 16];
-#define ATL(k) do { if (blockIdx.x < 4096 && lane == 0) g_attn_tl[(blockIdx.x * 4 + wid) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define ATL(k) do { if (blockIdx.x < 4096 && lane == 0 && wid < 4) g_attn_tl[(blockIdx.x * 4 + wid) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define ATL(k) do { } while (0)
 #endif
@@ -54,11 +54,11 @@ __device__ __forceinline__ bf16x8 cat8(bf16x4 a, bf16x4 b) {
 // are `ld` elements apart into LDS as [nrows][DH] with the chunk swizzle.
 template <int DH>
 __device__ __forceinline__ void stage_rows(const bf16* __restrict__ g, size_t ld, int S, int nrows, char* lds,
-                                           int wid, int lane) {
+                                           int wid, int lane, int nwaves = 4) {
   using Cf = AttnCfg<DH>;
   const int rin = lane / Cf::CH, c = lane % Cf::CH;
   const int ninstr = (nrows + Cf::RPI - 1) / Cf::RPI;
-  for (int i = wid; i < ninstr; i += 4) {
+  for (int i = wid; i < ninstr; i += nwaves) {
     const int row = i * Cf::RPI + rin;
     const int gr = min(row, S - 1);
     const int gc = Cf::swz(c, row);
@@ -71,8 +71,11 @@ __device__ __forceinline__ void stage_rows(const bf16* __restrict__ g, size_t ld
 // ---------------------------------------------------------------------------------------
 // NTC: number of 16-key tiles known at compile time (11 = the M3P sequence, 36 regions + 128 tokens = 164 keys) so the
 // per-tile guards fold away (they compiled to ~90 uniform branches and the SGPR pressure behind ~220 lane spills); 0 = runtime.
-template <int DH, int KT, bool DROP, int NTC>
-__global__ __launch_bounds__(256, 3)   // three ~48-KB workgroups per CU (S = 164): 168 registers per lane
+// NW: waves per workgroup.  4 with three ~48-KB workgroups per CU at S = 164 (168 registers per lane); 8 for long
+// sequences whose K + V tiles leave room for one workgroup per CU only (S = 356: 96 KB) - two waves per SIMD
+// instead of one to hide each other's latencies.
+template <int DH, int KT, bool DROP, int NTC, int NW = 4>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 3)
 void attn_fwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keylen, bf16* __restrict__ ctx,
                      float* __restrict__ lse, unsigned long long* __restrict__ keepmask, int S, int H, int dmodel,
                      uint32_t seed, uint32_t thresh24, float inv_keep) {
@@ -91,14 +94,14 @@ void attn_fwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
   char* sV = smem + nt * 16 * Cf::ROWB;
   ATL(0);
 #ifdef M3P_ATTN_TL
-  if (blockIdx.x < 4096 && lane == 0) g_attn_tl[(blockIdx.x * 4 + wid) * 16 + 14] = __builtin_amdgcn_s_memrealtime();
+  if (blockIdx.x < 4096 && lane == 0 && wid < 4) g_attn_tl[(blockIdx.x * 4 + wid) * 16 + 14] = __builtin_amdgcn_s_memrealtime();
 #endif
-  stage_rows<DH>(Kg, ld, S, nt * 16, sK, wid, lane);
-  stage_rows<DH>(Vg, ld, S, nk * 32, sV, wid, lane);
+  stage_rows<DH>(Kg, ld, S, nt * 16, sK, wid, lane, NW);
+  stage_rows<DH>(Vg, ld, S, nk * 32, sV, wid, lane, NW);
   const int fq = lane & 15, fg = lane >> 4;
-  // query blocks go round-robin over the four waves; the starting wave rotates with the workgroup id so
+  // query blocks go round-robin over the waves; the starting wave rotates with the workgroup id so
   // that the waves with one block fewer (nt % 4 != 0) do not always land on the same SIMDs of a CU
-  const int wrot = (wid + (blockIdx.x >> 3)) & 3;
+  const int wrot = (wid + (blockIdx.x >> 3)) & (NW - 1);
   bf16x8 qnext[Cf::KK];
   {
     const int qc0 = min(wrot * 16 + fq, S - 1);
@@ -122,14 +125,14 @@ void attn_fwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
   for (int n = 0; n < Cf::NT; ++n)
     v_off[n] = vrow * Cf::ROWB + Cf::swz(2 * n + ((fq & 3) >> 1), vrow) * 16 + 8 * (fq & 1);
 
-  for (int qb = wrot; qb < nt; qb += 4) {
+  for (int qb = wrot; qb < nt; qb += NW) {
     const int q = qb * 16 + fq;
     const int qc = min(q, S - 1);
     bf16x8 qf[Cf::KK];
 #pragma unroll
     for (int kk = 0; kk < Cf::KK; ++kk) qf[kk] = qnext[kk];
     {  // prefetch the next block's Q fragments: the global-load latency hides behind this block's work
-      const int qcn = min(q + 64, S - 1);
+      const int qcn = min(q + 16 * NW, S - 1);
 #pragma unroll
       for (int kk = 0; kk < Cf::KK; ++kk)
         qnext[kk] = *reinterpret_cast<const bf16x8*>(Qg + (size_t)qcn * ld + 32 * kk + 8 * fg);
@@ -256,7 +259,7 @@ void attn_fwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
   }
   ATL(8);
 #ifdef M3P_ATTN_TL
-  if (blockIdx.x < 4096 && lane == 0) g_attn_tl[(blockIdx.x * 4 + wid) * 16 + 15] = __builtin_amdgcn_s_memrealtime();
+  if (blockIdx.x < 4096 && lane == 0 && wid < 4) g_attn_tl[(blockIdx.x * 4 + wid) * 16 + 15] = __builtin_amdgcn_s_memrealtime();
 #endif
 }
 
@@ -280,8 +283,8 @@ void attn_fwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
 // (the rolled loop spent 28 of its ~110 VALU instructions per step on address updates); 0 = runtime.
 // NTC: number of 16-row tiles known at compile time as well (11 for S = 164): keep-bit word addresses become
 // immediates off one pointer instead of per-tile scalar arithmetic held in (spilled) SGPRs.
-template <int DH, int KT, bool DROP, bool MASK, int NKC, int NTC>
-__global__ __launch_bounds__(256, 3)   // 3 waves per SIMD: three 49-KB workgroups per CU
+template <int DH, int KT, bool DROP, bool MASK, int NKC, int NTC, int NW = 4>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 3)   // NW = 4: three 49-KB workgroups per CU; 8: one ~100-KB workgroup (long S)
 void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keylen, const bf16* __restrict__ ctx,
                      const bf16* __restrict__ dctx, const float* __restrict__ lse,
                      const unsigned long long* __restrict__ keepmask, bf16* __restrict__ dqkv,
@@ -316,7 +319,7 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
   float* sL = reinterpret_cast<float*>(smem + 2 * tile_bytes);
   float* sD = sL + nk * 32;
   const int fq = lane & 15, fg = lane >> 4;
-  float* sB = sD + nk * 32;           // [4 waves][3][DH] bias-gradient accumulators (q | k | v), one slot per wave
+  float* sB = sD + nk * 32;           // [NW waves][3][DH] bias-gradient accumulators (q | k | v), one slot per wave
   float* sBw = sB + wid * 3 * DH;
   // bias gradients = column sums of the bf16 dQ/dK/dV rows this block writes.  Each lane keeps
   // running sums of ITS rows in registers (part x d-tile x 4 columns); the reduction over the
@@ -357,7 +360,7 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
   constexpr float kMasked = -1.0e30f;    // score of a masked key: exp2 of it is exactly 0
   const uint32_t inv_keep_bits = __builtin_bit_cast(uint32_t, inv_keep);
   // ---- prologue: D[q] = rowsum(dO * O), lse -> LDS (padded rows: D = 0, lse = +inf so P = 0)
-  for (int q = tid; q < nk * 32; q += 256) {
+  for (int q = tid; q < nk * 32; q += NW * 64) {
     float dsum = 0.f, l = INFINITY;
     if (q < S) {
       const bf16* op = Og + (size_t)q * dmodel;
@@ -375,8 +378,8 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
     sL[q] = l;
   }
   // ================= phase A: dV, dK (wave owns key blocks) =================
-  stage_rows<DH>(Qg, ld, S, nk * 32, s0, wid, lane);
-  stage_rows<DH>(dOg, (size_t)dmodel, S, nk * 32, s1, wid, lane);
+  stage_rows<DH>(Qg, ld, S, nk * 32, s0, wid, lane, NW);
+  stage_rows<DH>(dOg, (size_t)dmodel, S, nk * 32, s1, wid, lane, NW);
   // this wave's first K / V fragments do not depend on LDS: fetch them under the staging latency
   bf16x8 kf[Cf::KK], vf[Cf::KK];
   auto load_kv = [&](int kb) {
@@ -390,7 +393,7 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
   if (wid < nt) load_kv(wid);
   __syncthreads();
 
-  for (int kb = wid; kb < nt; kb += 4) {
+  for (int kb = wid; kb < nt; kb += NW) {
     const int key = kb * 16 + fq;            // this lane's key column
     const int keyc = min(key, S - 1);
     const float kbias = (key < klen) ? 0.f : kMasked;
@@ -501,8 +504,8 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
   __syncthreads();   // everyone done with Q / dO tiles
 
   // ================= phase B: dQ (wave owns query blocks) =================
-  stage_rows<DH>(Kg, ld, S, nk * 32, s0, wid, lane);
-  stage_rows<DH>(Vg, ld, S, nk * 32, s1, wid, lane);
+  stage_rows<DH>(Kg, ld, S, nk * 32, s0, wid, lane, NW);
+  stage_rows<DH>(Vg, ld, S, nk * 32, s1, wid, lane, NW);
   bf16x8 qf[Cf::KK], df[Cf::KK];
   auto load_qd = [&](int qb) {
     const int qc = min(qb * 16 + fq, S - 1);
@@ -515,7 +518,7 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
   if (wid < nt) load_qd(wid);
   __syncthreads();
 
-  for (int qb = wid; qb < nt; qb += 4) {
+  for (int qb = wid; qb < nt; qb += NW) {
     const int q = qb * 16 + fq;
     const int qc = min(q, S - 1);
     if (qb != wid) load_qd(qb);
@@ -616,11 +619,14 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
   if (dbias_qkv) {
     bias_flush(0);
     __syncthreads();
-    for (int i = tid; i < 3 * DH; i += 256) {
+    for (int i = tid; i < 3 * DH; i += NW * 64) {
       const int part = i / DH, c = i - part * DH;
-      if (part != 1)
-        atomicAdd(dbias_qkv + part * dmodel + h * DH + c,
-                  (sB[i] + sB[3 * DH + i]) + (sB[6 * DH + i] + sB[9 * DH + i]));
+      if (part != 1) {
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; w += 2) tot += sB[w * 3 * DH + i] + sB[(w + 1) * 3 * DH + i];
+        atomicAdd(dbias_qkv + part * dmodel + h * DH + c, tot);
+      }
     }
   }
 }
@@ -630,13 +636,15 @@ int launch_fwd(const bf16* qkv, const int* keylen, bf16* ctx, float* lse, unsign
                int dmodel, uint32_t seed, uint32_t thresh24, float inv_keep, hipStream_t st) {
   const int nt = (S + 15) / 16, nk = (S + 31) / 32;
   const size_t lds = (size_t)(nt * 16 + nk * 32) * DH * 2;
+  const bool wide = 2 * lds > 160 * 1024;   // a second workgroup would not fit: run eight waves in the one that does
 #define M3P_ATTN_FWD(KT)                                                                                        \
   do {                                                                                                          \
-    auto kern = thresh24 ? attn_fwd_kernel<DH, KT, true, 0> : attn_fwd_kernel<DH, KT, false, 0>;                                                                \
-    if (nt == 11 && KT == 6) kern = thresh24 ? attn_fwd_kernel<DH, 6, true, 11> : attn_fwd_kernel<DH, 6, false, 11>;                                                                        \
+    auto kern = thresh24 ? attn_fwd_kernel<DH, KT, true, 0> : attn_fwd_kernel<DH, KT, false, 0>;                 \
+    if (nt == 11 && KT == 6) kern = thresh24 ? attn_fwd_kernel<DH, 6, true, 11> : attn_fwd_kernel<DH, 6, false, 11>; \
+    if (wide) kern = thresh24 ? attn_fwd_kernel<DH, KT, true, 0, 8> : attn_fwd_kernel<DH, KT, false, 0, 8>;       \
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     if (e != hipSuccess) return (int)e;                                                                         \
-    hipLaunchKernelGGL(kern, dim3(B* H), dim3(256), lds, st, qkv, keylen, ctx, lse, keepmask, S, H, dmodel, seed, \
+    hipLaunchKernelGGL(kern, dim3(B* H), dim3(wide ? 512 : 256), lds, st, qkv, keylen, ctx, lse, keepmask, S, H, dmodel, seed, \
                        thresh24, inv_keep);                                                                     \
   } while (0)
   if (nk <= 6) M3P_ATTN_FWD(6);
@@ -653,14 +661,16 @@ int launch_bwd(const bf16* qkv, const int* keylen, const bf16* ctx, const bf16* 
                const unsigned long long* keepmask, bf16* dqkv, float* dbias, int B, int S, int H, int dmodel, float qscale,
                uint32_t seed, uint32_t thresh24, float inv_keep, hipStream_t st) {
   const int nk = (S + 31) / 32;
-  const size_t lds = (size_t)2 * nk * 32 * DH * 2 + (size_t)2 * nk * 32 * sizeof(float) + 12 * DH * sizeof(float);
+  const bool wide = (size_t)2 * ((size_t)2 * nk * 32 * DH * 2) > 160 * 1024;   // one workgroup per CU anyway: eight waves
+  const size_t lds = (size_t)2 * nk * 32 * DH * 2 + (size_t)2 * nk * 32 * sizeof(float) + (wide ? 24 : 12) * DH * sizeof(float);
 #define M3P_ATTN_BWD(KT, DROP, MASK)                                                                            \
   do {                                                                                                          \
     auto kern = attn_bwd_kernel<DH, KT, DROP, MASK, 0, 0>;                                                      \
+    if (wide) kern = attn_bwd_kernel<DH, KT, DROP, MASK, 0, 0, 8>;                                              \
     if (nk == 6) kern = (S + 15) / 16 == 11 ? attn_bwd_kernel<DH, KT, DROP, MASK, 6, 11> : attn_bwd_kernel<DH, KT, DROP, MASK, 6, 0>;                                                                  \
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     if (e != hipSuccess) return (int)e;                                                                         \
-    hipLaunchKernelGGL(kern, dim3(B* H), dim3(256), lds, st, qkv, keylen, ctx, dctx, lse, keepmask, dqkv, dbias, S, H, \
+    hipLaunchKernelGGL(kern, dim3(B* H), dim3(wide ? 512 : 256), lds, st, qkv, keylen, ctx, dctx, lse, keepmask, dqkv, dbias, S, H, \
                        dmodel, qscale, seed, thresh24, inv_keep);                                               \
   } while (0)
   if (nk > 16) return M3P_EINVAL;
