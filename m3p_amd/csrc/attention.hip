@@ -356,6 +356,10 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
   for (int n = 0; n < Cf::NT; ++n)
     t_off[n] = trow * Cf::ROWB + Cf::swz(2 * n + ((fq & 3) >> 1), trow) * 16 + 8 * (fq & 1);
 
+  // 16-row tile t lies wholly behind the sequence (S = 164: the 12th tile, rows 176..191, of the six 32-row steps):
+  // with the tile count known at compile time the code for it simply is not generated; as a run-time test it was
+  // only worth it without the keep-bit words (measured slower with them)
+#define PAD_TILE(t) (NTC ? (t) >= NTC : (M3P_ATTN_SKIP_PAD && !MASK && (t) >= nt))
   constexpr float kLog2e = 1.4426950408889634f;
   constexpr float kMasked = -1.0e30f;    // score of a masked key: exp2 of it is exactly 0
   const uint32_t inv_keep_bits = __builtin_bit_cast(uint32_t, inv_keep);
@@ -425,7 +429,7 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
           const int t = 2 * kq + hf;
-          if (M3P_ATTN_SKIP_PAD && !MASK && t >= nt) continue;   // query tile that is pure padding (S = 164: rows 176..191)
+          if (PAD_TILE(t)) continue;   // query tile that is pure padding (S = 164: rows 176..191)
           const bf16x8 qf = *reinterpret_cast<const bf16x8*>(s0 + t * 16 * Cf::ROWB + r_off[kk]);
           const bf16x8 df = *reinterpret_cast<const bf16x8*>(s1 + t * 16 * Cf::ROWB + r_off[kk]);
           scA[hf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf[kk], scA[hf], 0, 0, 0);   // S[q][key]
@@ -435,7 +439,7 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         const int t = 2 * kq + hf;
-        if (M3P_ATTN_SKIP_PAD && !MASK && t >= nt) {      // (skipping the padded tile measured slower with MASK): contributes zeros
+        if (PAD_TILE(t)) {      // (skipping the padded tile measured slower with MASK): contributes zeros
           pd2[hf] = ds2[hf] = f32x4{0.f, 0.f, 0.f, 0.f};
           continue;
         }
@@ -544,7 +548,7 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
           const int t = 2 * kq + hf;
-          if (M3P_ATTN_SKIP_PAD && !MASK && t >= nt) continue;   // key tile beyond the sequence
+          if (PAD_TILE(t)) continue;   // key tile beyond the sequence
           const bf16x8 kf = *reinterpret_cast<const bf16x8*>(s0 + t * 16 * Cf::ROWB + r_off[kk]);
           const bf16x8 vf = *reinterpret_cast<const bf16x8*>(s1 + t * 16 * Cf::ROWB + r_off[kk]);
           scB[hf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], scB[hf], 0, 0, 0);   // S^T[key][q]
@@ -554,7 +558,7 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         const int t = 2 * kq + hf;
-        if (M3P_ATTN_SKIP_PAD && !MASK && t >= nt) {
+        if (PAD_TILE(t)) {
           ds2[hf] = f32x4{0.f, 0.f, 0.f, 0.f};
           continue;
         }
@@ -630,6 +634,8 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
     }
   }
 }
+
+#undef PAD_TILE
 
 template <int DH>
 int launch_fwd(const bf16* qkv, const int* keylen, bf16* ctx, float* lse, unsigned long long* keepmask, int B, int S, int H,
