@@ -392,6 +392,10 @@ __device__ __forceinline__ void epilogue_half(const M3PEpilogue& ep, bf16* __res
   }
 }
 
+#ifdef M3P_RING_TL
+__device__ unsigned long long g_ring_tl[256 * 8 * 8];   // debug build: per-wave cycle sums of the eight-wave kernel's segments
+#endif
+
 // ---------------------------------------------------------------------------------
 // NT kernel, persistent ring version (the production path): one 8-wave workgroup per CU walks
 // a list of 256x128 output tiles; the K-tiles of all its output tiles form ONE continuous
@@ -543,6 +547,30 @@ void gemm_nt_ring_kernel(const bf16* __restrict__ A, int lda, const bf16* __rest
                           (!(EPI == M3P_EPI_BIAS_GELU) || (((ep.ld_out2 & 7) == 0) && (((uintptr_t)ep.out2 & 15) == 0))) &&
                           (!ep.bias || (((uintptr_t)ep.bias & 15) == 0)) &&
                           (!ep.aux || (((ep.ld_aux & 7) == 0) && (((uintptr_t)ep.aux & 15) == 0)));
+  f32x4 csum[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) csum[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int csum_nw = -1;            // first column of the 64-wide block the sums belong to
+  auto flush_csum = [&]() {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float sfl = csum[j][r];
+        sfl += __shfl_xor(sfl, 1, 64); sfl += __shfl_xor(sfl, 2, 64);
+        sfl += __shfl_xor(sfl, 4, 64); sfl += __shfl_xor(sfl, 8, 64);
+        const int n = csum_nw + j * 16 + fg * 4 + r;
+        if (fr == 0 && n < N) unsafeAtomicAdd(ep.colsum + n, sfl);
+        csum[j][r] = 0.f;
+      }
+  };
+#ifdef M3P_RING_TL
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tl0 = __builtin_amdgcn_s_memtime(), tl1;
+#define RING_TSEG(k) do { tl1 = __builtin_amdgcn_s_memtime(); tacc[k] += tl1 - tl0; tl0 = tl1; } while (0)
+#else
+#define RING_TSEG(k) do { } while (0)
+#endif
   for (int step = 0; step < total; ++step) {
     const int nxt = (cur == 2) ? 0 : cur + 1;
     const int nx2 = (nxt == 2) ? 0 : nxt + 1;
@@ -565,6 +593,7 @@ void gemm_nt_ring_kernel(const bf16* __restrict__ A, int lda, const bf16* __rest
     M3P_LGKM0();
 
     if (++c_kt == nk) {
+      RING_TSEG(0);
       // ---- epilogue of output tile c_q; stage `cur` is free (all waves passed the barrier above)
       c_kt = 0;
       const int t = tile_of(c_q);
@@ -573,9 +602,14 @@ void gemm_nt_ring_kernel(const bf16* __restrict__ A, int lda, const bf16* __rest
       split_tile(t, tm, tn);
       const int m0 = tm * BM, n0 = tn * BN;
       const int mw = m0 + wm * 64, nw = n0 + wn * 64;
-      f32x4 csum[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) csum[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // column sums (bias gradient of the dGELU / MUL epilogues) stay in registers across this workgroup's tiles
+      // and are flushed when its column block changes: with the strip order that is once per strip, not once
+      // per tile (per tile the 64 shuffles + 16 atomics cost 5.4 k cycles, and the atomics - older than the next
+      // K-tile's LDS-DMAs in the vmcnt order - stalled the K loop: +29 % on the whole launch)
+      if ((EPI == M3P_EPI_DGELU || EPI == M3P_EPI_MUL) && ep.colsum && csum_nw != nw) {
+        if (csum_nw >= 0) flush_csum();
+        csum_nw = nw;
+      }
       const bool fast = io_aligned && (m0 + BM <= M) && (n0 + BN <= N);
       if (fast) {
         char* r1 = smem + cur * STAGE + wid * 6144;
@@ -589,8 +623,14 @@ void gemm_nt_ring_kernel(const bf16* __restrict__ A, int lda, const bf16* __rest
           f32x4 biasv[4];
           bf16x4 auxv[2][4];
           load_bias4<EPI>(ep, nw, lane, biasv);
+          RING_TSEG(1);
           load_aux_rows<EPI>(ep, mw + 32 * hf, nw, lane, r1, auxv);
+#ifdef M3P_RING_TL
+          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+          RING_TSEG(2);
           epilogue_half<EPI>(ep, C, ldc, N, mw + 32 * hf, nw, r1, rows, biasv, auxv, lane, csum, gtab);
+          RING_TSEG(3);
         }
       } else {
 #pragma unroll
@@ -599,18 +639,7 @@ void gemm_nt_ring_kernel(const bf16* __restrict__ A, int lda, const bf16* __rest
           for (int j = 0; j < 4; ++j)
             epilogue_store<EPI>(ep, C, ldc, M, N, mw + i * 16 + fr, nw + j * 16 + fg * 4, acc[i][j], csum[j]);
       }
-      if ((EPI == M3P_EPI_DGELU || EPI == M3P_EPI_MUL) && ep.colsum) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float sfl = csum[j][r];
-            sfl += __shfl_xor(sfl, 1, 64); sfl += __shfl_xor(sfl, 2, 64);
-            sfl += __shfl_xor(sfl, 4, 64); sfl += __shfl_xor(sfl, 8, 64);
-            const int n = nw + j * 16 + fg * 4 + r;
-            if (fr == 0 && n < N) unsafeAtomicAdd(ep.colsum + n, sfl);
-          }
-      }
+      RING_TSEG(4);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -622,9 +651,17 @@ void gemm_nt_ring_kernel(const bf16* __restrict__ A, int lda, const bf16* __rest
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
       }
+      RING_TSEG(5);
     }
     cur = nxt;
   }
+  if ((EPI == M3P_EPI_DGELU || EPI == M3P_EPI_MUL) && ep.colsum && csum_nw >= 0) flush_csum();
+#ifdef M3P_RING_TL
+  RING_TSEG(0);
+  if (lane == 0 && EPI == M3P_EPI_DGELU)
+    for (int k = 0; k < 8; ++k) g_ring_tl[(blockIdx.x * 8 + wid) * 8 + k] = tacc[k];
+#endif
+#undef RING_TSEG
 #undef M3P_DSR
 #undef M3P_LGKM0
 }
@@ -2158,6 +2195,19 @@ int m3p_gemm_nt_bf16(const void* A, int lda, const void* W, int ldw, void* C, in
     case M3P_EPI_MUL: return launch_nt<M3P_EPI_MUL>(a, lda, w, ldw, c, ldc, M, N, K, ep, st);
     default: return M3P_EINVAL;
   }
+}
+
+// debug (only with -DM3P_RING_TL): per-wave cycle sums of the last dGELU launch of the eight-wave kernel
+// [256 workgroups][8 waves][8 segments]: 0 K loop, 1 bias / row copies, 2 aux fetch + wait, 3 epilogue half (compute,
+// staging, stores), 4 column sums, 5 zeroing + end barrier  (tools/ring_timeline.py)
+__attribute__((visibility("default"))) int m3p_debug_ring_timeline(void* out, size_t bytes) {
+#ifdef M3P_RING_TL
+  if (bytes > sizeof(g_ring_tl)) return M3P_EINVAL;
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ring_tl), bytes);
+#else
+  (void)out; (void)bytes;
+  return M3P_EINVAL;
+#endif
 }
 
 __attribute__((visibility("default"))) int m3p_debug_gemm_timeline(const void* A, int lda, const void* W, int ldw, void* C, int ldc,
