@@ -240,26 +240,26 @@ constexpr int EP_HALF = 32 * EP_PITCH;        // 4608 B per wave half-tile
 
 // gelu_erf'(u) of a bf16 u is a function of 16 bits: the dGELU epilogue looks it up instead of
 // evaluating erf/exp (~20 exposed VALU instructions per element).  The table covers |u| in
-// [2^-15, 8) (exponents -15..2 x 128 mantissas = 2304 fp32 entries, 9 KB of LDS), holds exactly what
-// gelu_erf_grad_f returns for that bf16 value, gelu'(-u) = 1 - gelu'(u); below 2^-15 the linear
-// term 0.5 + 0.79788 u is exact to 1e-13, from 8 up the derivative is 1 to 1e-14.
+// [2^-15, 8) (exponents -15..2 x 128 mantissas = 2304 fp32 entries, 9 KB of LDS), built from what
+// gelu_erf_grad_f returns for that bf16 value; gelu'(-u) = 1 - gelu'(u).
 #ifndef M3P_DGELU_LUT
 #define M3P_DGELU_LUT 1
 #endif
 constexpr int GELU_TAB_LO = 0x3800, GELU_TAB_HI = 0x4100, GELU_TAB_N = GELU_TAB_HI - GELU_TAB_LO;
+// The table holds gelu'(|u|) - 1/2, an odd function of u: gelu'(u) = 1/2 + copysign(tab[|u|], u).  Seven VALU
+// instructions and one LDS read per element (and, sub, med3, lshl_add, bfi, add, + the multiply); the first table
+// entry serves every |u| < 2^-15 (error 2.4e-5, a tenth of a bf16 ulp of 1/2), the last every |u| >= 8 (gelu' = 1).
 __device__ __forceinline__ void gelu_grad_table_fill(float* tab, int tid, int nthreads) {
   for (int i = tid; i < GELU_TAB_N; i += nthreads) {
     const uint16_t bits = (uint16_t)(GELU_TAB_LO + i);
-    tab[i] = gelu_erf_grad_f((float)__builtin_bit_cast(bf16, bits));
+    tab[i] = gelu_erf_grad_f((float)__builtin_bit_cast(bf16, bits)) - 0.5f;
   }
 }
 __device__ __forceinline__ float gelu_grad_lookup(const float* tab, bf16 u) {
   const uint32_t b = __builtin_bit_cast(uint16_t, u);
-  const int a = (int)(b & 0x7FFFu);
-  float t = tab[min(max(a - GELU_TAB_LO, 0), GELU_TAB_N - 1)];
-  if (a < GELU_TAB_LO) t = 0.5f + 0.79788456f * fabsf((float)u);
-  if (a >= GELU_TAB_HI) t = 1.0f;
-  return (b & 0x8000u) ? 1.0f - t : t;
+  const int idx = min(max((int)(b & 0x7FFFu) - GELU_TAB_LO, 0), GELU_TAB_N - 1);   // (compiles to v_med3_i32)
+  const uint32_t t = __builtin_bit_cast(uint32_t, tab[idx]);
+  return 0.5f + __builtin_bit_cast(float, (t & 0x7FFFFFFFu) | ((b << 16) & 0x80000000u));
 }
 
 // bias values of the four 16-column tiles starting at column nw for this lane (columns nw + 16 j + 4 (lane >> 4) ..+3)
@@ -289,23 +289,35 @@ __device__ __forceinline__ void load_aux(const M3PEpilogue& ep, int mrow0, int n
 // instead of 8) and transposed into the accumulator layout through the wave-private staging rows `r1`; load_aux's
 // direct form touches sixteen 32-byte row pieces per instruction.  Measured: dGELU 0.349 -> 0.340 ms, the
 // residual epilogues unchanged (the aux tile costs ~60 us per 41984 x 3072 GEMM either way - see DESIGN.md).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // (HIP's uint4 is a struct: arrays of it passed by reference end up in scratch)
 template <int EPI>
-__device__ __forceinline__ void load_aux_rows(const M3PEpilogue& ep, int mrow0, int nw, int lane, char* r1, bf16x4 (&auxv)[2][4]) {
+__device__ __forceinline__ void load_aux_rows_issue(const M3PEpilogue& ep, int mrow0, int nw, int lane, u32x4 (&t)[4]) {
   constexpr bool kAux = (EPI == M3P_EPI_BIAS_DROP_RES || EPI == M3P_EPI_RES || EPI == M3P_EPI_DGELU || EPI == M3P_EPI_MUL);
   if (!kAux) return;
   const int srow = lane >> 3, sch = lane & 7;
   const bf16* X = reinterpret_cast<const bf16*>(ep.aux) + (size_t)(mrow0 + srow) * ep.ld_aux + nw + sch * 8;
-  uint4 t[4];
 #pragma unroll
-  for (int it = 0; it < 4; ++it) t[it] = *reinterpret_cast<const uint4*>(X + (size_t)(it * 8) * ep.ld_aux);
+  for (int it = 0; it < 4; ++it) t[it] = *reinterpret_cast<const u32x4*>(X + (size_t)(it * 8) * ep.ld_aux);
+}
+template <int EPI>
+__device__ __forceinline__ void load_aux_rows_finish(int lane, char* r1, const u32x4 (&t)[4], bf16x4 (&auxv)[2][4]) {
+  constexpr bool kAux = (EPI == M3P_EPI_BIAS_DROP_RES || EPI == M3P_EPI_RES || EPI == M3P_EPI_DGELU || EPI == M3P_EPI_MUL);
+  if (!kAux) return;
+  const int srow = lane >> 3, sch = lane & 7;
 #pragma unroll
-  for (int it = 0; it < 4; ++it) *reinterpret_cast<uint4*>(r1 + (it * 8 + srow) * EP_PITCH + sch * 16) = t[it];
+  for (int it = 0; it < 4; ++it) *reinterpret_cast<u32x4*>(r1 + (it * 8 + srow) * EP_PITCH + sch * 16) = t[it];
   const int fr = lane & 15, fg = lane >> 4;
 #pragma unroll
   for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       auxv[ii][j] = *reinterpret_cast<const bf16x4*>(r1 + (ii * 16 + fr) * EP_PITCH + (j * 16 + fg * 4) * 2);
+}
+template <int EPI>
+__device__ __forceinline__ void load_aux_rows(const M3PEpilogue& ep, int mrow0, int nw, int lane, char* r1, bf16x4 (&auxv)[2][4]) {
+  u32x4 t[4];
+  load_aux_rows_issue<EPI>(ep, mrow0, nw, lane, t);
+  load_aux_rows_finish<EPI>(lane, r1, t, auxv);
 }
 
 template <int EPI>
@@ -338,7 +350,7 @@ __device__ __forceinline__ void epilogue_half(const M3PEpilogue& ep, bf16* __res
       const int lo = rl * EP_PITCH + (j * 16 + fg * 4) * 2;
       f32x4 v = rows[ii][j];
       if (EPI == M3P_EPI_NONE || EPI == M3P_EPI_BIAS || EPI == M3P_EPI_RES) v = v * mulc + bias4;
-      else v += bias4;
+      else if (EPI != M3P_EPI_DGELU && EPI != M3P_EPI_MUL) v += bias4;      // (those two have no bias: 32 exposed adds per half)
       if (EPI == M3P_EPI_BIAS_GELU) {
         ukeep[ii][j] = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
 #pragma unroll
@@ -613,8 +625,11 @@ void gemm_nt_ring_kernel(const bf16* __restrict__ A, int lda, const bf16* __rest
       const bool fast = io_aligned && (m0 + BM <= M) && (n0 + BN <= N);
       if (fast) {
         char* r1 = smem + cur * STAGE + wid * 6144;
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
+        // both halves' aux rows are requested up front: the second half's round trip hides behind the first half's work
+        u32x4 auxt0[4], auxt1[4];
+        load_aux_rows_issue<EPI>(ep, mw, nw, lane, auxt0);
+        load_aux_rows_issue<EPI>(ep, mw + 32, nw, lane, auxt1);
+        auto do_half = [&](const int hf, const u32x4 (&auxt)[4]) {
           f32x4 rows[2][4];
 #pragma unroll
           for (int ii = 0; ii < 2; ++ii)
@@ -624,14 +639,16 @@ void gemm_nt_ring_kernel(const bf16* __restrict__ A, int lda, const bf16* __rest
           bf16x4 auxv[2][4];
           load_bias4<EPI>(ep, nw, lane, biasv);
           RING_TSEG(1);
-          load_aux_rows<EPI>(ep, mw + 32 * hf, nw, lane, r1, auxv);
+          load_aux_rows_finish<EPI>(lane, r1, auxt, auxv);
 #ifdef M3P_RING_TL
-          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
           RING_TSEG(2);
           epilogue_half<EPI>(ep, C, ldc, N, mw + 32 * hf, nw, r1, rows, biasv, auxv, lane, csum, gtab);
           RING_TSEG(3);
-        }
+        };
+        do_half(0, auxt0);
+        do_half(1, auxt1);
       } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
