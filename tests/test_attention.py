@@ -24,7 +24,8 @@ def _ref_attention(qkv, keylen, B, S, H, dh, keep=None, p=0.0):
     return ctx, lse
 
 
-CASES = [(2, 74, 4, 32), (3, 164, 12, 64), (2, 16, 2, 64), (1, 116, 12, 64), (2, 200, 2, 64), (1, 356, 16, 64), (2, 33, 1, 32)]
+CASES = [(2, 74, 4, 32), (3, 164, 12, 64), (2, 16, 2, 64), (1, 116, 12, 64), (2, 200, 2, 64), (1, 356, 16, 64), (2, 33, 1, 32),
+         (1, 512, 2, 64), (2, 1, 2, 64), (1, 500, 3, 32)]     # the maximum sequence, a single position, long with dh = 32
 
 
 @pytest.mark.parametrize('B,S,H,dh', CASES)
@@ -45,8 +46,6 @@ def test_attention_fwd_bwd(B, S, H, dh, p):
     ctx_ref, lse_ref = _ref_attention(x, keylen.long(), B, S, H, dh, keep, p)
     assert rel_l2(ctx.float(), ctx_ref) < 6e-3
     assert max_abs(lse, lse_ref) < 2e-3
-    if S > 384:
-        return
     dctx, dctxc = randn_bf16((B * S, d), 7)
     dbias = torch.zeros(3 * d, device='cuda')
     dqkv = ops.attn_bwd(qkv, keylen.cuda(), ctx, dctx, lse, B, S, H, dh, dbias_qkv=dbias, seed=seed, p_drop=p)
@@ -62,14 +61,19 @@ def test_attention_fwd_bwd(B, S, H, dh, p):
     ctx_ref.backward(dctxc)
     g = x.grad.clone()
     g[:, :d] *= 1.0 / math.sqrt(dh)       # kernel returns the gradient of the unscaled q projection
+    gall = float(g.norm())
     for name, sl in (('dq', slice(0, d)), ('dk', slice(d, 2 * d)), ('dv', slice(2 * d, 3 * d))):
+        if float(g[:, sl].norm()) < 1e-6 * gall:      # a single key: softmax is constant, dq = dk = 0 exactly
+            # (ours: D = rowsum(dO * O) uses the bf16-rounded O, so with dropout's 1/(1-p) scale a 2^-9 residue remains)
+            assert float(dqkv[:, sl].float().norm()) < 1e-2 * gall, name
+            continue
         assert rel_l2(dqkv[:, sl].float(), g[:, sl]) < 1.5e-2, name
     cs = dqkv.float().sum(0)
     assert rel_l2(dbias[:d], cs[:d]) < 1e-4 and rel_l2(dbias[2 * d:], cs[2 * d:]) < 1e-4   # column sums of the rows it wrote
     # k-bias: softmax shift invariance makes the true gradient 0 (the fp32 reference gives ~1e-7 noise);
     # the kernel writes exact zeros rather than the bf16 rounding noise of its dK rows
     assert bool((dbias[d:2 * d] == 0).all())
-    assert float(g[:, d:2 * d].sum(0).abs().max()) < 1e-3 * float(g[:, d:2 * d].abs().sum(0).max())
+    assert float(g[:, d:2 * d].sum(0).abs().max()) <= 1e-3 * float(g[:, d:2 * d].abs().sum(0).max())
 
 
 def test_attention_perf_smoke():
