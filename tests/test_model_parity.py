@@ -69,14 +69,16 @@ def test_cfg1_forward_losses_vs_golden(golden_dir):
         assert float(out[int(tot[b]):, b].abs().max()) == 0.0 if int(tot[b]) < out.shape[0] else True
 
 
-@pytest.mark.parametrize('cfg_name', ['cfg1', 'mid', 'large'])
+@pytest.mark.parametrize('cfg_name', ['cfg1', 'mid', 'large', 'tiny'])
 def test_gradients_vs_oracle(cfg_name):
     from oracle import ref_cpu as O
     # 'mid': the cfg2 width at a short ragged sequence; 'large': the geometry of BASELINE configs[3] (M3P-large: d=1024,
     # 16 heads, 100 regions + 256 tokens = 356 keys -> the 12-step attention instantiation) at 2 layers / small V
     cfg = {'cfg1': synth.CONFIGS['cfg1'],
            'mid': dict(emb_dim=768, n_heads=12, n_layers=2, n_words=5000, T=40, R=36, B=6, n_pred=6),
-           'large': dict(emb_dim=1024, n_heads=16, n_layers=2, n_words=5000, T=256, R=100, B=4, n_pred=38)}[cfg_name]
+           'large': dict(emb_dim=1024, n_heads=16, n_layers=2, n_words=5000, T=256, R=100, B=4, n_pred=38),
+           # smallest shapes: one region, six tokens, two sequences, head dim 32, one layer, one MLM target each
+           'tiny': dict(emb_dim=128, n_heads=4, n_layers=1, n_words=300, T=6, R=1, B=2, n_pred=1)}[cfg_name]
     m, P, sd = _build(cfg)
     m.train()
     batch = synth.make_batch(cfg['T'], cfg['R'], cfg['B'], cfg['n_words'], cfg['n_pred'], seed=7)
