@@ -6,6 +6,10 @@
 #include "../../include/m3p_hip.h"
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
+#ifndef M3P_LN_BWD_BLOCKS
+#define M3P_LN_BWD_BLOCKS 512
+#endif
+
 namespace {
 
 // NI = ceil(d / 256): 4-element chunks per lane
@@ -285,7 +289,7 @@ int m3p_layernorm_bwd(const void* dy_a, const void* dy_b, const void* x, const f
   if (((uintptr_t)x & 7) || ((uintptr_t)dy_a & 7) || ((uintptr_t)dx & 7) || ((uintptr_t)gamma & 15)) return M3P_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   if ((d == 768 || d == 1024) && !(((uintptr_t)x | (uintptr_t)dy_a | (uintptr_t)dx | (uintptr_t)dy_b | (uintptr_t)dx_drop) & 15)) {
-    const int blocks_hw = min((rows + 7) / 8, 512);   // fewer blocks: the 3*d end-of-block atomics hit the same 2304 addresses
+    const int blocks_hw = min((rows + 7) / 8, M3P_LN_BWD_BLOCKS);   // fewer blocks: the 3*d end-of-block atomics hit the same 2304 addresses
     if (d == 768)
       hipLaunchKernelGGL(ln_bwd_hw_kernel<3>, dim3(blocks_hw), dim3(256), 0, st, (const bf16*)dy_a, (const bf16*)dy_b,
                          (const bf16*)x, gamma, mean, rstd, rowmask, (bf16*)dx, (bf16*)dx_drop, dgamma, dbeta, dbias_drop,
