@@ -39,3 +39,10 @@ def test_w4_gemm_accumulators_are_ours(tmp_path):
                 bad.append(l.strip())
         assert not bad, '%s: compiler-generated AGPR / scratch traffic: %s' % (name, bad[:3])
         assert n_mfma >= 3 * 64, name     # phase 1 (first / accumulate) + phase 2
+    # the persistent eight-wave kernels (one workgroup per CU, every stall exposed) must not spill either: a
+    # 16-byte-struct temporary array once put 144 bytes of them into scratch and cost 15 % of the dGELU launch
+    body = '\n'.join(text)
+    for m in re.finditer(r'^(_ZN\S*gemm_(?:nt|wgrad)_ring_kernel\S*):', body, re.M):
+        k = body.index('; Kernel info:', body.index('.Lfunc_end', m.end()))
+        info = dict(re.findall(r'; (\w+): (\d+)', body[k:k + 600]))
+        assert info['ScratchSize'] == '0' and info['NumAgprs'] == '0', (m.group(1), info['ScratchSize'], info['NumAgprs'])
