@@ -645,12 +645,13 @@ int launch_fwd(const bf16* qkv, const int* keylen, bf16* ctx, float* lse, unsign
   const bool wide = 2 * lds > 160 * 1024;   // a second workgroup would not fit: run eight waves in the one that does
 #define M3P_ATTN_FWD(KT)                                                                                        \
   do {                                                                                                          \
-    auto kern = thresh24 ? attn_fwd_kernel<DH, KT, true, 0> : attn_fwd_kernel<DH, KT, false, 0>;                 \
+    constexpr int NW0 = (KT == 16) ? 8 : 4;   /* S > 384 is always `wide`: no four-wave instantiation (it spills) */ \
+    auto kern = thresh24 ? attn_fwd_kernel<DH, KT, true, 0, NW0> : attn_fwd_kernel<DH, KT, false, 0, NW0>;       \
     if (nt == 11 && KT == 6) kern = thresh24 ? attn_fwd_kernel<DH, 6, true, 11> : attn_fwd_kernel<DH, 6, false, 11>; \
     if (wide) kern = thresh24 ? attn_fwd_kernel<DH, KT, true, 0, 8> : attn_fwd_kernel<DH, KT, false, 0, 8>;       \
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     if (e != hipSuccess) return (int)e;                                                                         \
-    hipLaunchKernelGGL(kern, dim3(B* H), dim3(wide ? 512 : 256), lds, st, qkv, keylen, ctx, lse, keepmask, S, H, dmodel, seed, \
+    hipLaunchKernelGGL(kern, dim3(B* H), dim3((wide || NW0 == 8) ? 512 : 256), lds, st, qkv, keylen, ctx, lse, keepmask, S, H, dmodel, seed, \
                        thresh24, inv_keep);                                                                     \
   } while (0)
   if (nk <= 6) M3P_ATTN_FWD(6);

@@ -46,3 +46,28 @@ def test_w4_gemm_accumulators_are_ours(tmp_path):
         k = body.index('; Kernel info:', body.index('.Lfunc_end', m.end()))
         info = dict(re.findall(r'; (\w+): (\d+)', body[k:k + 600]))
         assert info['ScratchSize'] == '0' and info['NumAgprs'] == '0', (m.group(1), info['ScratchSize'], info['NumAgprs'])
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason='hipcc not installed')
+def test_attention_kernels_keep_their_occupancy(tmp_path):
+    """No production instantiation of the attention kernels spills to scratch, the M3P-sequence instantiations (S = 164: six
+    32-row steps, eleven 16-row tiles) fit three waves per SIMD (three ~48-KB workgroups per CU) and the long-sequence
+    ones (eight waves per workgroup) two."""
+    out = tmp_path / 'attention.s'
+    cmd = [HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-munsafe-fp-atomics', '-ffp-contract=fast',
+           '-Wno-unused-result', '--cuda-device-only', '-S', os.path.join(ROOT, 'm3p_amd', 'csrc', 'attention.hip'), '-o', str(out)]
+    subprocess.run(cmd, check=True, capture_output=True, timeout=600)
+    body = out.read_text()
+    seen = 0
+    for m in re.finditer(r'^(_ZN\S*attn_(fwd|bwd)_kernelI(\S*?)EEv\S*):', body, re.M):
+        k = body.index('; Kernel info:', body.index('.Lfunc_end', m.end()))
+        info = dict(re.findall(r'; (\w+): (\d+)', body[k:k + 600]))
+        args = m.group(3).rstrip('E')
+        rehash = m.group(2) == 'bwd' and 'Lb1ELb0E' in args    # dropout without the forward's keep bits: legacy path
+        assert info['ScratchSize'] == '0' or rehash, (m.group(1), info['ScratchSize'])
+        if m.group(2) == 'fwd' and args.endswith('Li11ELi4') or m.group(2) == 'bwd' and args.endswith('Li6ELi11ELi4'):
+            assert int(info['Occupancy']) >= 3, (m.group(1), info['Occupancy'], info['NumVgprs'])
+            seen += 1
+        if args.endswith('Li8'):
+            assert int(info['Occupancy']) >= 2, (m.group(1), info['Occupancy'])
+    assert seen >= 3
