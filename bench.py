@@ -37,7 +37,7 @@ def flops_train_per_seq(d, L, T, R, V, n_pred):
     return 6.0 * macs
 
 
-def build(cfg, dropout, world, rank, local_rank, refine_layers=0):
+def build(cfg, dropout, world, rank, local_rank, refine_layers=0, ragged=False):
     from m3p_amd import synth
     from m3p_amd.model.transformer import TransformerModel
     from m3p_amd.trainer import XTrainer
@@ -52,7 +52,7 @@ def build(cfg, dropout, world, rank, local_rank, refine_layers=0):
     torch.manual_seed(1234)   # identical random-init weights on every rank (then broadcast anyway)
     model = TransformerModel(P, is_encoder=True, with_output=True, is_crossModal=True).cuda()
     trainer = XTrainer(model, {}, P)
-    batch = synth.make_batch(cfg['T'], cfg['R'], cfg['B'], cfg['n_words'], cfg['n_pred'], seed=1000 + rank, ragged=False)
+    batch = synth.make_batch(cfg['T'], cfg['R'], cfg['B'], cfg['n_words'], cfg['n_pred'], seed=1000 + rank, ragged=ragged)
     B, R = cfg['B'], cfg['R']
     dev = torch.device('cuda', local_rank)
     img = batch['x_img'].transpose(0, 1).contiguous().to(dev)           # (n, R, 2048) as the collate emits it
@@ -101,6 +101,8 @@ def main():
     ap.add_argument('--config', default='cfg2')
     ap.add_argument('--dropout', type=float, default=0.1)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--ragged', action='store_true',
+                    help='text lengths ~ U[T/2, T] with padding (the second throughput run of SURVEY 8d) instead of all = T')
     ap.add_argument('--refine-layers', type=int, default=0,
                     help='AoA refiner layers on the image rows (jointfwd refine_image=True; the reference default is 6). '
                          '0 = the README configuration the headline metric is quoted on')
@@ -114,7 +116,7 @@ def main():
     torch.cuda.set_device(local_rank)
     cfg = dict(synth.CONFIGS[args.config])
     cfg['B'] = args.batch
-    trainer, tup = build(cfg, args.dropout, world, rank, local_rank, args.refine_layers)
+    trainer, tup = build(cfg, args.dropout, world, rank, local_rank, args.refine_layers, args.ragged)
 
     def step():
         trainer.pretrain_under_step(tup, 'google', 't2i', 'en', 1.0, 1.0, 1.0, 1.0)
@@ -184,8 +186,8 @@ def main():
                                         'dropout %.2f, adam_inverse_sqrt + clip 5%s'
                                         % (args.config, cfg['n_layers'], cfg['emb_dim'], cfg['n_heads'], cfg['R'], cfg['T'],
                                            cfg['n_words'], cfg['n_pred'], args.dropout,
-                                           ' + %d AoA refiner layers (not in flops_train_per_seq)' % args.refine_layers
-                                           if args.refine_layers else ''),
+                                           (' + %d AoA refiner layers (not in flops_train_per_seq)' % args.refine_layers
+                                            if args.refine_layers else '') + (', ragged text lengths U[T/2, T]' if args.ragged else '')),
                                per_gpu_batch=cfg['B'], global_batch=cfg['B'] * world, seq_len=cfg['T'] + cfg['R'],
                                parallelism='dp%d' % world, flops_train_per_seq=fl),
                    roofline=roof)
