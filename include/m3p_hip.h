@@ -190,6 +190,10 @@ M3P_API int m3p_embed_image_rows_fwd(const void* img_proj, const float* loc, con
  * nn.Embedding(padding_idx)), d_g_img,d_be_img,d_b_img,d_b_loc [d], d_w_loc [d,5]; writes
  * de [R*B,d] (bf16, gradient of img_proj, rows s*B+b) for the W_img weight-gradient GEMM.
  * dz_scratch: bf16 [B*S,d] workspace.
+ * d_tok_rows (optional, bf16 [T*B,d]): when set, the token rows' gradients are WRITTEN there (row t*B+b, zero rows
+ * for pad / masked tokens) instead of being scatter-added into d_emb - data parallelism exchanges these rows between
+ * ranks and applies them with m3p_scatter_add_token_rows (the 768-MB dense matrix is then reduced early, see
+ * m3p_amd/distributed.py).
  * phase: 0 = everything.  With the AoA refiner between the image rows and the assembly the two halves run
  * separately: 1 = LN_emb / position / token part only - leaves the gradient of the image rows in
  * dz_scratch[b*S + r]; the caller takes it through the refiner's backward, writes the result back to the same
@@ -199,7 +203,7 @@ M3P_API int m3p_embed_assemble_bwd(const void* dh, const void* z, const float* m
                                    const float* rstd_img, const float* g_img, const int64_t* tok,
                                    const int32_t* totlen, const float* loc, void* dz_scratch, void* de,
                                    float* d_g_emb, float* d_be_emb, float* d_pos, float* d_emb,
-                                   float* d_g_img, float* d_be_img, float* d_b_img, float* d_b_loc,
+                                   void* d_tok_rows, float* d_g_img, float* d_be_img, float* d_b_img, float* d_b_loc,
                                    float* d_w_loc, int B, int T, int R, int d, int pad_index,
                                    uint32_t seed_img, uint32_t seed_emb, uint32_t thresh24, float inv_keep,
                                    int phase, void* stream);
@@ -212,6 +216,11 @@ M3P_API int m3p_embed_assemble_bwd(const void* dh, const void* z, const float* m
 M3P_API int m3p_gather_rows(const void* src, const int32_t* idx, void* dst, int n, int d, void* stream);
 /* dst[idx[i],:] += src[i,:] (idx unique) — its backward */
 M3P_API int m3p_scatter_add_rows(const void* src, const int32_t* idx, void* dst, int n, int d, void* stream);
+/* dst[ids[i],:] (fp32 [V,d]) += rows[i,:] (bf16 [n,d]); ids may repeat (atomics), rows with ids[i] == pad_index are
+ * skipped (nn.Embedding(padding_idx), transformer.py:21-26).  The embedding-lookup gradient of token rows gathered
+ * from the data-parallel ranks (m3p_embed_assemble_bwd with d_tok_rows). */
+M3P_API int m3p_scatter_add_token_rows(const void* rows, const int64_t* ids, float* dst, int n, int d, int pad_index,
+                                       void* stream);
 
 /* ----------------------------------------------------------------------------------
  * ITM head: transformer.py:546-558 (BertPooler: tanh(dense(hidden[:, 0]))) followed by

@@ -168,7 +168,9 @@ struct EmbedBwdArgs {
   bf16* dz;                 // [B*S,d] scratch: gradient wrt z (post-mask)
   bf16* de;                 // [R*B,d] gradient wrt the image projection (rows r*B+b)
   float* d_g_emb; float* d_be_emb; float* d_pos;   // accumulated (atomics)
-  float* d_emb;             // [V,d] embeddings.weight gradient (scatter-add)
+  float* d_emb;             // [V,d] embeddings.weight gradient (scatter-add); unused when d_tok_rows is set
+  bf16* d_tok_rows;         // optional [T*B,d]: the token rows' gradients (row t*B+b; zero rows for pad / masked
+                            // tokens) INSTEAD of the scatter-add - the data-parallel sparse exchange applies them
   float* d_g_img; float* d_be_img; float* d_b_img; float* d_b_loc; float* d_w_loc;   // [d],[d],[d],[d],[d,5]
   int B, T, R, d, pad_index, bsplit;
   uint32_t seed_img, seed_emb, thresh24; float inv_keep;
@@ -245,7 +247,19 @@ __global__ __launch_bounds__(256) void embed_bwd_rows_kernel(EmbedBwdArgs a) {
         }
       }
     }
-    if (s >= a.R && id != a.pad_index && mk != 0.f) {
+    if (s >= a.R && a.d_tok_rows) {
+      const bool live = id != a.pad_index && mk != 0.f;
+      bf16* dr = a.d_tok_rows + ((size_t)(s - a.R) * a.B + b) * d;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nchunk) {
+          f32x4 o = *reinterpret_cast<const f32x4*>(&red[wib][4 * c]);
+          if (!live) o = f32x4{0.f, 0.f, 0.f, 0.f};
+          Vec4<bf16>::store(dr + 4 * c, o);
+        }
+      }
+    } else if (s >= a.R && id != a.pad_index && mk != 0.f) {
       // scatter-add into the embedding gradient: one atomic instruction = 64 CONSECUTIVE floats (two
       // full 128-B lines) instead of 64 float4-strided ones (eight partial lines)
       float* de = a.d_emb + (size_t)id * d;
@@ -420,7 +434,7 @@ int m3p_embed_assemble_bwd(const void* dh, const void* z, const float* mean_emb,
                            const float* g_emb, const void* e, const float* mean_img, const float* rstd_img,
                            const float* g_img, const int64_t* tok, const int32_t* totlen, const float* loc,
                            void* dz_scratch, void* de, float* d_g_emb, float* d_be_emb, float* d_pos, float* d_emb,
-                           float* d_g_img, float* d_be_img, float* d_b_img, float* d_b_loc, float* d_w_loc,
+                           void* d_tok_rows, float* d_g_img, float* d_be_img, float* d_b_img, float* d_b_loc, float* d_w_loc,
                            int B, int T, int R, int d, int pad_index, uint32_t seed_img, uint32_t seed_emb,
                            uint32_t thresh24, float inv_keep, int phase, void* stream) {
   if (B <= 0 || T < 0 || R < 0 || d <= 0 || (d % 4) != 0 || d > 1024 || phase < 0 || phase > 2) return M3P_EINVAL;
@@ -428,7 +442,7 @@ int m3p_embed_assemble_bwd(const void* dh, const void* z, const float* mean_emb,
   while (bsplit < 16 && (R + T) * bsplit < M3P_EMB_BWD_BLOCKS && B / (4 * bsplit) >= 8) bsplit *= 2;
   EmbedBwdArgs a = {(const bf16*)dh, (const bf16*)z, mean_emb, rstd_emb, g_emb, (const bf16*)e, mean_img, rstd_img, g_img,
                     tok, totlen, loc, (bf16*)dz_scratch, (bf16*)de, d_g_emb, d_be_emb, d_pos, d_emb,
-                    d_g_img, d_be_img, d_b_img, d_b_loc, d_w_loc, B, T, R, d, pad_index, bsplit,
+                    (bf16*)d_tok_rows, d_g_img, d_be_img, d_b_img, d_b_loc, d_w_loc, B, T, R, d, pad_index, bsplit,
                     seed_img, seed_emb, thresh24, inv_keep};
   hipStream_t st = (hipStream_t)stream;
   const int S = R + T;

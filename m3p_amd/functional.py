@@ -175,12 +175,16 @@ class Arena:
             self.grad.zero_()
             self.grads_known_zero = True
         self.touched.clear()
+        if self.model.ddp_hook is not None:
+            self.model.ddp_hook.step_done()
 
     def after_fused_step(self):
         """The fused Adam kernel updated master + w16 and zeroed every touched gradient range."""
         self.mark_updated_by_fused_optimizer()
         self.touched.clear()
         self.grads_known_zero = True
+        if self.model.ddp_hook is not None:
+            self.model.ddp_hook.step_done()
 
 
 def _site(kind, layer=0):
@@ -284,6 +288,9 @@ def refiner_bwd(model, dout, saved, keylen, B, R, seed_step, p):
     return dx
 
 
+N_ENC_ARGS = 13     # positional arguments of EncoderFn.forward (backward returns one None per argument)
+
+
 class EncoderFn(torch.autograd.Function):
     """Embedding assembly + n_layers post-LN transformer layers
     (TransformerModel.jointfwd, M3P/src/model/transformer.py:901-958; with x_img=None the
@@ -291,7 +298,8 @@ class EncoderFn(torch.autograd.Function):
     output require grad; parameter gradients are written to the arena (module docstring)."""
 
     @staticmethod
-    def forward(ctx, anchor, model, x, lengths, x_img, lengths_img, image_loc, p_drop, p_attn, seed_step, p_refine=None):
+    def forward(ctx, anchor, model, x, lengths, x_img, lengths_img, image_loc, p_drop, p_attn, seed_step, p_refine=None,
+                track=False, text_embed=None):
         ar = model.arena()
         ar.refresh()
         dev = ar.device
@@ -304,6 +312,15 @@ class EncoderFn(torch.autograd.Function):
         seed = lambda kind, i=0: rng.stream_seed(model.base_seed, seed_step, _site(kind, i))   # noqa: E731
 
         x = x.to(dev).contiguous()
+        # text_embed (transformer.py:910-913, the FreeLB steps' perturbed embeddings, (B, T, d)): the assembly kernel
+        # gathers "token" b*T + t from the rows of text_embed instead of id x[t, b] from the vocabulary matrix
+        table, tok = ar.w('embeddings.weight'), x
+        if text_embed is not None:
+            assert tuple(text_embed.shape) == (B, T, d), (tuple(text_embed.shape), (B, T, d))
+            table = text_embed.detach().to(device=dev, dtype=BF16).contiguous().view(B * T, d)
+            tok = (torch.arange(B, device=dev, dtype=torch.int64) * T)[None, :] + \
+                torch.arange(T, device=dev, dtype=torch.int64)[:, None]
+            tok = tok.contiguous()
         totlen = lengths if R == 0 else (lengths + lengths_img)
         totlen = totlen.to(device=dev, dtype=torch.int32).contiguous()
         rowmask = (torch.arange(S, device=dev, dtype=torch.int32)[None, :] < totlen[:, None]).to(torch.uint8).contiguous().view(-1)
@@ -324,7 +341,7 @@ class EncoderFn(torch.autograd.Function):
             keylen_img = lengths_img.to(device=dev, dtype=torch.int32).contiguous()
             img_rows, ref_saved = refiner_fwd(model, rows, keylen_img, B, R, seed_step, p_refine)
         h, emb_saved = ops.embed_assemble_fwd(
-            x, ar.w('embeddings.weight'), ar.p('position_embeddings.weight'), img_proj, loc,
+            tok, table, ar.p('position_embeddings.weight'), img_proj, loc,
             ar.p('image_embeddings.image_location_embeddings.weight'),
             ar.p('image_embeddings.image_location_embeddings.bias'),
             ar.p('image_embeddings.LayerNorm.weight'), ar.p('image_embeddings.LayerNorm.bias'),
@@ -361,8 +378,14 @@ class EncoderFn(torch.autograd.Function):
         ctx.model = model
         ctx.dims = (B, T, R, S, d, H, dh, nL)
         ctx.drop = (p_drop, p_attn, seed_step)
-        ctx.saved = (x, totlen, rowmask, ximg16, loc, emb_saved, saved_layers)
+        ctx.saved = (tok, totlen, rowmask, ximg16, loc, emb_saved, saved_layers)
         ctx.refine = (ref_saved, keylen_img, p_refine)
+        ctx.input_grads = (R > 0 and x_img.requires_grad and track, text_embed is not None)
+        # data parallelism: count the encoder passes that will be differentiated (only the last backward of a
+        # step launches gradient buckets) and learn the token-row count the ranks pad to
+        hook = model.ddp_hook
+        ctx.track = bool(track) and hook is not None
+        ctx.tok_rows_max = hook.encoder_forward(T * B) if ctx.track else None
         ctx.set_materialize_grads(False)
         return h
 
@@ -378,12 +401,15 @@ class EncoderFn(torch.autograd.Function):
         seed = lambda kind, i=0: rng.stream_seed(model.base_seed, seed_step, _site(kind, i))   # noqa: E731
         ref_saved, keylen_img, p_refine = ctx.refine
         ctx.refine = None
+        hook = model.ddp_hook if ctx.track else None
         if dout is None:
-            return (None,) * 11
+            if hook is not None:
+                hook.encoder_backward_end()
+            return (None,) * N_ENC_ARGS
         dh_ = dout.contiguous()
         if dh_.dtype != BF16:
             dh_ = dh_.to(BF16)
-        hook = model.ddp_hook
+        last = hook.encoder_backward_begin() if hook is not None else True
         for i in reversed(range(nL)):
             a, f = 'attentions.%d.' % i, 'ffns.%d.' % i
             (h_in, qkv, ctxt, lse, pre1, mean1, rstd1, x1, u, hact, pre2, mean2, rstd2) = saved_layers[i]
@@ -418,7 +444,12 @@ class EncoderFn(torch.autograd.Function):
             del dqkv, dctx, dAO, dpre1, dx1
             ar.touch_layer(i)
             if hook is not None:
-                hook.layer_done(i)
+                hook.layer_done(i, last)
+        # under data parallelism the token rows' gradients are exchanged as rows, not scattered here
+        want_dximg, has_text_embed = ctx.input_grads
+        tok_rows = None
+        if has_text_embed or (hook is not None and hook.active):
+            tok_rows = torch.empty((T * B, d), dtype=BF16, device=dh_.device)
         grads = dict(
             d_g_emb=ar.g('layer_norm_emb.weight'), d_be_emb=ar.g('layer_norm_emb.bias'),
             d_pos=ar.g('position_embeddings.weight'), d_emb=ar.g('embeddings.weight'),
@@ -428,16 +459,26 @@ class EncoderFn(torch.autograd.Function):
             d_w_loc=ar.g('image_embeddings.image_location_embeddings.weight'))
         de = ops.embed_assemble_bwd(dh_, emb_saved, ar.p('layer_norm_emb.weight'),
                                     ar.p('image_embeddings.LayerNorm.weight'), x, totlen, loc, grads, B, T, R, d,
-                                    model.pad_index, seed_img=seed('img'), seed_emb=seed('emb'), p_drop=p_drop,
+                                    -1 if has_text_embed else model.pad_index, seed_img=seed('img'), seed_emb=seed('emb'), p_drop=p_drop,
                                     img_rows_bwd=None if ref_saved is None else
-                                    (lambda g: refiner_bwd(model, g, ref_saved, keylen_img, B, R, seed_step, p_refine)))
-        ar.touch('layer_norm_emb.weight', 'layer_norm_emb.bias', 'position_embeddings.weight', 'embeddings.weight')
+                                    (lambda g: refiner_bwd(model, g, ref_saved, keylen_img, B, R, seed_step, p_refine)),
+                                    tok_rows=tok_rows)
+        ar.touch('layer_norm_emb.weight', 'layer_norm_emb.bias', 'position_embeddings.weight')
+        if not has_text_embed:
+            ar.touch('embeddings.weight')
+        d_ximg = d_text = None
         if R > 0:
             ops.gemm_wgrad(de, ximg16, ar.g('image_embeddings.image_embeddings.weight'))
             ar.touch(*[n for n in ar.names if n.startswith('image_embeddings.')])
+            if want_dximg:      # gradient wrt the region features (FreeLB's image_delta): de [R*B, d] @ W_img [d, 2048]
+                d_ximg = ops.gemm_nt(de, _transposed(ar.w('image_embeddings.image_embeddings.weight')), L.EPI_NONE)
+                d_ximg = d_ximg.view(R, B, 2048).float()
+        if has_text_embed:
+            d_text = tok_rows.view(T, B, d).transpose(0, 1).float()
+            tok_rows = None
         if hook is not None:
-            hook.embed_done()
-        return (None,) * 11
+            hook.embed_done(last, ids=x if tok_rows is not None else None, rows=tok_rows, n_max=ctx.tok_rows_max)
+        return (None, None, None, None, d_ximg, None, None, None, None, None, None, None, d_text)
 
 
 class MLMHeadFn(torch.autograd.Function):
@@ -482,6 +523,8 @@ class MLMHeadFn(torch.autograd.Function):
         dbase = torch.zeros_like(base)
         ops.scatter_add_rows(dH, row_idx, dbase, n, d)
         dtensor = torch.as_strided(dbase, shape, stride, soff)
+        if model.ddp_hook is not None:
+            model.ddp_hook.mlm_head_done()     # the dense part of the tied matrix is final: reduce it now
         return dtensor, None, None, None, None, None
 
 
@@ -590,6 +633,42 @@ class MrfrHeadFn(torch.autograd.Function):
         dH = torch.zeros((n, d), dtype=torch.float32, device=hsel.device)
         ops.gemm_nn_streamk(dreg, ar.w('mrfr_dense.weight'), dH)
         return _scatter_rows_grad((dH * g).to(BF16), row_idx, base, shape, stride, soff), None, None, None, None
+
+
+class DenseRowsFn(torch.autograd.Function):
+    """y = x W^T + b for one of the arena's Linear layers on arbitrary bf16 rows [n, d_in] (predict(is_mrfr=True),
+    transformer.py:1202-1204).  GEMM forward, column-sum / weight-gradient / data-gradient GEMMs backward."""
+
+    @staticmethod
+    def forward(ctx, x, model, wname, bname):
+        ar = model.arena()
+        ar.refresh()
+        ctx.model, ctx.names = model, (wname, bname)
+        ctx.save_for_backward(x)
+        return ops.gemm_nt(x, ar.w(wname), L.EPI_BIAS, bias=ar.p(bname))
+
+    @staticmethod
+    def backward(ctx, dy):
+        model = ctx.model
+        ar = model.arena()
+        wname, bname = ctx.names
+        x, = ctx.saved_tensors
+        dy = dy.contiguous()
+        if dy.dtype != BF16:
+            dy = dy.to(BF16)
+        ar.touch(wname, bname)
+        ops.colsum(dy, dy.shape[1], ar.g(bname))
+        ops.gemm_wgrad(dy, x, ar.g(wname))
+        dx = ops.gemm_nt(dy, _transposed(ar.w(wname)), L.EPI_NONE)
+        return dx, None, None, None
+
+
+def mrfr_dense_rows(model, tensor):
+    """predict(is_mrfr=True): mrfr_dense on every row of tensor (..., d) -> (..., 2048) bf16."""
+    d = model.dim
+    assert tensor.shape[-1] == d
+    x = tensor.to(BF16).contiguous().view(-1, d)
+    return DenseRowsFn.apply(x, model, 'mrfr_dense.weight', 'mrfr_dense.bias').view(*tensor.shape[:-1], -1)
 
 
 def _masked_region_rows(tensor, labels, d):

@@ -45,12 +45,13 @@ SIGNATURES = {
     'm3p_cast_f32_bf16': (_i, [_p, _p, C.c_longlong, _p]),
     'm3p_embed_assemble_fwd': (_i, [_p] * 19 + [_i, _i, _i, _i, _u32, _u32, _u32, _f, _p, _p]),
     'm3p_embed_image_rows_fwd': (_i, [_p] * 10 + [_i, _i, _i, _u32, _u32, _f, _p]),
-    'm3p_embed_assemble_bwd': (_i, [_p] * 23 + [_i, _i, _i, _i, _i, _u32, _u32, _u32, _f, _i, _p]),
+    'm3p_embed_assemble_bwd': (_i, [_p] * 24 + [_i, _i, _i, _i, _i, _u32, _u32, _u32, _f, _i, _p]),
     'm3p_dropout_rows': (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _u32, _u32, _u32, _u32, _f, _p]),
     'm3p_glu_fwd': (_i, [_p, _i, _p, _i, _i, _p]),
     'm3p_glu_bwd': (_i, [_p, _i, _p, _p, _i, _i, _p]),
     'm3p_gather_rows': (_i, [_p, _p, _p, _i, _i, _p]),
     'm3p_scatter_add_rows': (_i, [_p, _p, _p, _i, _i, _p]),
+    'm3p_scatter_add_token_rows': (_i, [_p, _p, _p, _i, _i, _i, _p]),
     'm3p_ce_fwd_bwd': (_i, [_p, _i, _i, _i, _p, _p, _p, _f, _f, _p]),
     'm3p_colsum_bf16': (_i, [_p, _i, _i, _i, _p, _p, _p]),
     'm3p_sumsq_f32': (_i, [_p, C.c_longlong, _p, _p]),

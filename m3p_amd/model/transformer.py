@@ -352,8 +352,7 @@ class TransformerModel(nn.Module):
                  image_loc=None, refine_image=False, is_latent=False, text_embed=None):
         """transformer.py:878-968.  x (T,B) int64, x_img (R,B,2048), image_loc (R,B,5) ->
         (S=R+T, B, d) (a transposed view of the batch-major activation, like the reference)."""
-        assert not causal and not is_latent and text_embed is None, \
-            'causal / is_latent / text_embed are outside the MI355X hot path'
+        assert not causal and not is_latent, 'causal / is_latent are outside the MI355X hot path'
         T, B = x.size()
         assert lengths.size(0) == B
         R = x_img.size(0)
@@ -364,7 +363,7 @@ class TransformerModel(nn.Module):
             assert self.n_refine_layers > 0, 'refine_image=True needs params.refine_layers > 0'
             p_ref = self.refine_dropout if self.training else 0.0
         out = Fn.EncoderFn.apply(self.layer_norm_emb.weight, self, x, lengths, x_img, lengths_img, image_loc, p, pa,
-                                 self._next_seed_step(), p_ref)
+                                 self._next_seed_step(), p_ref, torch.is_grad_enabled(), text_embed)
         return out.view(B, R + T, self.dim).transpose(0, 1)
 
     def crossfwd(self, x, lengths, causal, stream_='text', src_enc=None, src_len=None, positions=None, langs=None,
@@ -376,7 +375,7 @@ class TransformerModel(nn.Module):
         p = self.dropout if self.training else 0.0
         pa = self.attention_dropout if self.training else 0.0
         out = Fn.EncoderFn.apply(self.layer_norm_emb.weight, self, x, lengths, None, None, None, p, pa,
-                                 self._next_seed_step())
+                                 self._next_seed_step(), None, torch.is_grad_enabled(), None)
         return out.view(B, T, self.dim).transpose(0, 1)
 
     def predict(self, tensor, pred_mask=None, y=None, get_scores=None, is_obj=False, is_relation=False,
@@ -398,7 +397,8 @@ class TransformerModel(nn.Module):
             # not materialised for all B*R rows (only the masked rows enter the ignore_index mean)
             return None, Fn.mrm_head(self, tensor, y)
         if is_mrfr:
-            raise NotImplementedError('predict(is_mrfr=True) returns the regression of every region in the reference; '
-                                      'the fused masked loss is m3p_amd.functional.mrfr_head (used by XTrainer)')
+            # transformer.py:1202-1204: the bare regression mrfr_dense(tensor) of every row handed in (the fused
+            # masked loss XTrainer uses is m3p_amd.functional.mrfr_head)
+            return Fn.mrfr_dense_rows(self, tensor)
         loss, scores = Fn.mlm_head(self, tensor, pred_mask, y, bool(get_scores))
         return scores, loss

@@ -235,36 +235,43 @@ def embed_image_rows_fwd(img_proj, loc, w_loc, b_loc, g_img, be_img, B, R, d, se
 
 
 def embed_assemble_bwd(dh, saved, g_emb, g_img, tok, totlen, loc, grads, B, T, R, d, pad_index,
-                       seed_img=0, seed_emb=0, p_drop=0.0, img_rows_bwd=None):
+                       seed_img=0, seed_emb=0, p_drop=0.0, img_rows_bwd=None, tok_rows=None):
     """grads: dict of fp32 gradient views (d_g_emb, d_be_emb, d_pos, d_emb, d_g_img, d_be_img, d_b_img,
     d_b_loc, d_w_loc).  Returns de (bf16 [R*B, d]).
     img_rows_bwd (refine_image): callable taking the gradient of the refined image rows (bf16 [B*R, d]) and
-    returning the gradient of the refiner's input; run between the two halves of the backward."""
+    returning the gradient of the refiner's input; run between the two halves of the backward.
+    tok_rows (data parallelism): bf16 [T*B, d] buffer that receives the token rows' gradients instead of the
+    scatter-add into d_emb."""
     z, mean_e, rstd_e, e, mean_i, rstd_i = saved
     dz = torch.empty_like(z)
     de = torch.empty_like(e)
     th, ik = _drop_args(p_drop)
+    if tok_rows is not None:
+        assert tok_rows.dtype == BF16 and tok_rows.is_contiguous() and tok_rows.shape == (T * B, d)
+    args = (dh.data_ptr(), z.data_ptr(), mean_e.data_ptr(), rstd_e.data_ptr(), g_emb.data_ptr(), e.data_ptr(),
+            mean_i.data_ptr(), rstd_i.data_ptr(), g_img.data_ptr(), tok.data_ptr(), totlen.data_ptr(), L.ptr(loc),
+            dz.data_ptr(), de.data_ptr(), grads['d_g_emb'].data_ptr(), grads['d_be_emb'].data_ptr(),
+            grads['d_pos'].data_ptr(), grads['d_emb'].data_ptr(), L.ptr(tok_rows), grads['d_g_img'].data_ptr(),
+            grads['d_be_img'].data_ptr(), grads['d_b_img'].data_ptr(), grads['d_b_loc'].data_ptr(),
+            grads['d_w_loc'].data_ptr(), B, T, R, d, pad_index, seed_img, seed_emb, th, ik)
     if img_rows_bwd is not None:
-        args = (dh.data_ptr(), z.data_ptr(), mean_e.data_ptr(), rstd_e.data_ptr(), g_emb.data_ptr(), e.data_ptr(),
-                mean_i.data_ptr(), rstd_i.data_ptr(), g_img.data_ptr(), tok.data_ptr(), totlen.data_ptr(), L.ptr(loc),
-                dz.data_ptr(), de.data_ptr(), grads['d_g_emb'].data_ptr(), grads['d_be_emb'].data_ptr(),
-                grads['d_pos'].data_ptr(), grads['d_emb'].data_ptr(), grads['d_g_img'].data_ptr(),
-                grads['d_be_img'].data_ptr(), grads['d_b_img'].data_ptr(), grads['d_b_loc'].data_ptr(),
-                grads['d_w_loc'].data_ptr(), B, T, R, d, pad_index, seed_img, seed_emb, th, ik)
         L.check(L.load().m3p_embed_assemble_bwd(*args, 1, L.stream()), 'm3p_embed_assemble_bwd')
         dz_img = dz.view(B, R + T, d)[:, :R, :]
         dz_img.copy_(img_rows_bwd(dz_img.contiguous().view(B * R, d)).view(B, R, d))
         L.check(L.load().m3p_embed_assemble_bwd(*args, 2, L.stream()), 'm3p_embed_assemble_bwd')
         return de
-    rc = L.load().m3p_embed_assemble_bwd(
-        dh.data_ptr(), z.data_ptr(), mean_e.data_ptr(), rstd_e.data_ptr(), g_emb.data_ptr(), e.data_ptr(),
-        mean_i.data_ptr(), rstd_i.data_ptr(), g_img.data_ptr(), tok.data_ptr(), totlen.data_ptr(), L.ptr(loc),
-        dz.data_ptr(), de.data_ptr(), grads['d_g_emb'].data_ptr(), grads['d_be_emb'].data_ptr(),
-        grads['d_pos'].data_ptr(), grads['d_emb'].data_ptr(), grads['d_g_img'].data_ptr(),
-        grads['d_be_img'].data_ptr(), grads['d_b_img'].data_ptr(), grads['d_b_loc'].data_ptr(),
-        grads['d_w_loc'].data_ptr(), B, T, R, d, pad_index, seed_img, seed_emb, th, ik, 0, L.stream())
-    L.check(rc, 'm3p_embed_assemble_bwd')
+    L.check(L.load().m3p_embed_assemble_bwd(*args, 0, L.stream()), 'm3p_embed_assemble_bwd')
     return de
+
+
+def scatter_add_token_rows(rows, ids, dst, pad_index):
+    """dst[ids[i], :] (fp32 [V, d]) += rows[i, :] (bf16 [n, d]); pad rows skipped."""
+    _chk_bf16(rows)
+    assert ids.dtype == torch.int64 and dst.dtype == torch.float32 and rows.is_contiguous() and ids.is_contiguous()
+    n, d = rows.shape
+    assert ids.numel() == n and dst.shape[1] == d and dst.stride(0) == d
+    L.check(L.load().m3p_scatter_add_token_rows(rows.data_ptr(), ids.data_ptr(), dst.data_ptr(), n, d, int(pad_index),
+                                                L.stream()), 'm3p_scatter_add_token_rows')
 
 
 def gather_rows(src_base, idx, n, d):

@@ -190,45 +190,50 @@ def clip_grad_norm_(parameters, max_norm, optimizer):
     optimizer.clip_grad_norm(max_norm)
 
 
+# optimizer spec names -> (class, whether the "beta1=..,beta2=.." pair folds into betas=(b1, b2))
+_METHODS = {
+    'adam': (Adam, True),
+    'adam_inverse_sqrt': (AdamInverseSqrtWithWarmup, True),
+    'adadelta': (optim.Adadelta, False),
+    'adagrad': (optim.Adagrad, False),
+    'adamax': (optim.Adamax, False),
+    'asgd': (optim.ASGD, False),
+    'rmsprop': (optim.RMSprop, False),
+    'rprop': (optim.Rprop, False),
+    'sgd': (optim.SGD, False),
+}
+_NUMBER = re.compile(r'^[+-]?(\d+(\.\d*)?|\.\d+)$')
+
+
+def parse_optimizer_spec(spec):
+    """'adam_inverse_sqrt,beta1=0.9,beta2=0.98,lr=0.0001' -> ('adam_inverse_sqrt', {'beta1': 0.9, ...}).
+    The string format is the contract of ``--optimizer`` (optim.py:211-229): a method name followed by
+    comma-separated ``key=<plain decimal>`` pairs."""
+    method, *pairs = spec.split(',')
+    kwargs = {}
+    for pair in pairs:
+        key, eq, val = pair.partition('=')
+        if not eq or '=' in val or _NUMBER.match(val) is None:
+            raise AssertionError('optimizer option %r is not key=<number>' % pair)
+        kwargs[key] = float(val)
+    return method, kwargs
+
+
 def get_optimizer(parameters, s):
-    """optim.py:211-270: "adam_inverse_sqrt,beta1=0.9,beta2=0.98,lr=0.0001" style specs.
-    adam / adam_inverse_sqrt run on the fused kernels; torch.optim pass-throughs are kept
-    for completeness (they then see ordinary fp32 parameters)."""
-    if ',' in s:
-        method = s[:s.find(',')]
-        optim_params = {}
-        for x in s[s.find(',') + 1:].split(','):
-            split = x.split('=')
-            assert len(split) == 2
-            assert re.match(r'^[+-]?(\d+(\.\d*)?|\.\d+)$', split[1]) is not None
-            optim_params[split[0]] = float(split[1])
-    else:
-        method = s
-        optim_params = {}
-    if method in ('adam', 'adam_inverse_sqrt'):
-        optim_fn = Adam if method == 'adam' else AdamInverseSqrtWithWarmup
-        optim_params['betas'] = (optim_params.get('beta1', 0.9), optim_params.get('beta2', 0.999))
-        optim_params.pop('beta1', None)
-        optim_params.pop('beta2', None)
-    elif method == 'adadelta':
-        optim_fn = optim.Adadelta
-    elif method == 'adagrad':
-        optim_fn = optim.Adagrad
-    elif method == 'adamax':
-        optim_fn = optim.Adamax
-    elif method == 'asgd':
-        optim_fn = optim.ASGD
-    elif method == 'rmsprop':
-        optim_fn = optim.RMSprop
-    elif method == 'rprop':
-        optim_fn = optim.Rprop
-    elif method == 'sgd':
-        optim_fn = optim.SGD
-        assert 'lr' in optim_params
-    else:
+    """Drop-in for optim.py:211-270.  adam / adam_inverse_sqrt run on the fused kernels; the torch.optim names the
+    reference also accepts pass through (they then see ordinary fp32 parameters).  Unknown methods and options
+    the optimizer's constructor does not take raise, like the reference."""
+    method, kwargs = parse_optimizer_spec(s)
+    if method not in _METHODS:
         raise Exception('Unknown optimization method: "%s"' % method)
-    expected_args = list(inspect.signature(optim_fn.__init__).parameters.keys())
-    assert expected_args[:2] == ['self', 'params']
-    if not all(k in expected_args[2:] for k in optim_params.keys()):
-        raise Exception('Unexpected parameters: expected "%s", got "%s"' % (str(expected_args[2:]), str(optim_params.keys())))
-    return optim_fn(parameters, **optim_params)
+    cls, fold_betas = _METHODS[method]
+    if fold_betas:
+        kwargs['betas'] = (kwargs.pop('beta1', 0.9), kwargs.pop('beta2', 0.999))
+    if method == 'sgd':
+        assert 'lr' in kwargs
+    accepted = list(inspect.signature(cls.__init__).parameters)
+    assert accepted[:2] == ['self', 'params']
+    unknown = [k for k in kwargs if k not in accepted[2:]]
+    if unknown:
+        raise Exception('Unexpected parameters: expected "%s", got "%s"' % (str(accepted[2:]), str(list(kwargs))))
+    return cls(parameters, **kwargs)

@@ -1,17 +1,20 @@
 """Trainer surface of the hot path: the parts of ``Trainer`` / ``XTrainer``
-(M3P/src/xtrainer.py:35-826, 1128-2961) that the MLM + ITM pre-training step and the ITM
-fine-tune step execute, driving the MI355X model.
+(M3P/src/xtrainer.py:35-826, 1128-2402) that ``train_x.py``'s main loop (:432-508) reaches on
+the understanding / retrieval tasks, driving the MI355X model.
 
-Kept: constructor wiring (parameters, optimizer, DDP), ``optimize`` (:205-243), ``iter`` /
-``print_stats`` (:245-289, the reference's own sent/s meter), ``get_mask_`` (:2226-2232),
-``pretrain_under_step`` (:2234-2402), ``t2i_step`` / ``i2t_step`` loss arithmetic
-(:1888-2018), ``mlm_step`` (:734-770) on a caller-supplied batch, checkpoint save/reload of
-model + optimizer (:511-599).
+Entry points kept with the reference's signatures and batch tuples:
+``mlm_step(lang1, lang2, lambda)`` (:734-770, with ``generate_batch`` / ``round_batch`` /
+``mask_out``), ``pretrain_rel_step`` (:1879-1886), ``rel_step`` (:1867-1877),
+``pretrain_under_step`` (:2234-2402), ``t2i_step`` / ``i2t_step`` (:1888-2018), ``optimize``
+(:205-243), ``iter`` / ``print_stats`` (:245-289, the reference's own sent/s meter),
+``save_model`` / ``save_checkpoint`` / ``reload_checkpoint`` / ``save_periodic`` /
+``save_best_model`` / ``end_epoch`` (:511-650), ``get_iterator`` / ``get_batch`` (:1148-1206).
 
-Changed on purpose (SURVEY.md §7 "host side clean"): no per-step host syncs — the NaN check
-(:210), the ``.cpu()`` ITM loss (:2367-2370) and the ``loss.item()`` statistics
-(:2317, :2374) stay on the device and are only read when ``print_stats`` prints;
-clip + Adam + zero_grad are one fused kernel pass; DDP is our bucketed reducer.
+Changed on purpose (SURVEY.md §7 "host side clean"): no per-step host syncs - the NaN check
+(:210), the ``.cpu()`` ITM loss (:2367-2370) and the ``loss.item()`` statistics (:2317, :2374)
+stay on the device and are only read when ``print_stats`` prints; clip + Adam + zero_grad are
+one fused kernel pass; DDP is our bucketed reducer (m3p_amd/distributed.py).  Not built:
+the generation / captioning / FreeLB / sliding-window steps (SURVEY §8 f4 and out of scope).
 """
 import os
 import time
@@ -22,46 +25,57 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+from . import masking
+from .collate import batch_sentences, batch_sentences_v2, retrieval_collate, retrieval_pretrain_collate  # noqa: F401
 from .distributed import DataParallel
 from .optim import get_optimizer
+from .utils import parse_lambda_config, to_cuda, update_lambdas
 
 logger = getLogger()
 
+_REGION_HEADS = {
+    'mlm': ('embeddings.weight', 'pred_layer.proj.bias'),
+    'mrm': ('transformer_obj.dense.weight', 'transformer_obj.dense.bias', 'transformer_obj.LayerNorm.weight',
+            'transformer_obj.LayerNorm.bias', 'pred_obj_layer.proj.weight', 'pred_obj_layer.proj.bias'),
+    'mrfr': ('mrfr_dense.weight', 'mrfr_dense.bias'),
+}
 
-def to_cuda(*args):
-    """M3P/src/utils.py:233-237."""
-    return [None if x is None else x.cuda(non_blocking=True) for x in args]
+
+def _unwrap(model):
+    return model.module if isinstance(model, DataParallel) else model
 
 
-def batch_sentences_v2(sentences, lm_labels=None, pad_index=1, bos_index=0, eos_index=2):
-    """Collate of xtrainer.py:855-880: (slen, n) int64 with BOS first, EOS last, PAD after;
-    labels -1 where nothing is predicted."""
-    lengths = torch.LongTensor([len(s) + 2 for s in sentences])
-    slen, n = int(lengths.max()), len(sentences)
-    sent = torch.full((slen, n), pad_index, dtype=torch.long)
-    labels = torch.full((slen, n), -1, dtype=torch.long) if lm_labels is not None else None
-    sent[0] = bos_index
-    for i, s in enumerate(sentences):
-        li = int(lengths[i])
-        if li > 2:
-            sent[1:li - 1, i] = torch.from_numpy(np.asarray(s).astype(np.int64))
-            if lm_labels is not None:
-                labels[1:li - 1, i] = torch.from_numpy(np.asarray(lm_labels[i]).astype(np.int64))
-        sent[li - 1, i] = eos_index
-    if lm_labels is not None:
-        return sent, lengths, labels
-    return sent, lengths
+def _stat_names(params):
+    """Loss statistics of the steps this build runs (xtrainer.py:101-130 lists them for every task)."""
+    g = lambda k: getattr(params, k, [])   # noqa: E731
+    names = ['MLM-%s' % l for l in g('langs')]
+    for key, steps in (('CMLM', g('cross_mlm_steps')), ('MRM', g('cross_mrm_steps')), ('MRFR', g('cross_mrfr_steps')),
+                       ('t2i', g('cross_rel_steps')), ('i2t', g('cross_rel_steps'))):
+        names += ['%s-%s' % (key, l1) for l1, _ in steps]
+    return names
 
 
 class Trainer(object):
     MODEL_NAMES = ['model']
 
     def __init__(self, data, params):
-        self.epoch_size = params.epoch_size
+        """xtrainer.py:37-136."""
         self.params = params
         self.data = data
-        self.stopping_criterion = None
-        self.best_stopping_criterion = None
+        self.epoch_size = params.epoch_size
+        if self.epoch_size == -1:
+            self.epoch_size = self.data
+            assert self.epoch_size > 0
+        # early stopping: "metric,patience", a leading underscore = lower is better
+        self.stopping_criterion = self.best_stopping_criterion = None
+        crit = getattr(params, 'stopping_criterion', '')
+        if crit != '':
+            metric, _, patience = crit.partition(',')
+            assert patience.isdigit(), 'stopping_criterion is "<metric>,<patience>"'
+            self.decrease_counts_max, self.decrease_counts = int(patience), 0
+            biggest = not metric.startswith('_')
+            self.stopping_criterion = (metric if biggest else metric[1:], biggest)
+            self.best_stopping_criterion = -1e12 if biggest else 1e12
         self.iterators = {}
         self.set_parameters()
         assert params.amp >= 1 or not params.fp16
@@ -75,15 +89,23 @@ class Trainer(object):
                 setattr(self, name, wrapped)
                 for opt in self.optimizers.values():
                     opt.grad_scale = 1.0 / wrapped.world
+        # probability of masking out / keeping / randomising the words to predict
+        params.pred_probs = torch.FloatTensor([getattr(params, 'word_mask', 0.8), getattr(params, 'word_keep', 0.1),
+                                               getattr(params, 'word_rand', 0.1)])
         self.metrics = []
-        self.best_metrics = {}
+        for m in getattr(params, 'validation_metrics', '').split(','):
+            if m != '':
+                self.metrics.append((m[1:], False) if m[0] == '_' else (m, True))
+        self.best_metrics = {metric: (-1e12 if biggest else 1e12) for metric, biggest in self.metrics}
         self.epoch = 0
         self.n_iter = 0
         self.n_total_iter = 0
         self.n_sentences = 0
-        self.stats = OrderedDict([('processed_s', 0), ('processed_w', 0)])
+        self.stats = OrderedDict([('processed_s', 0), ('processed_w', 0)] + [(k, []) for k in _stat_names(params)])
         self.last_time = time.time()
         self._pending_w = []
+        self.reload_checkpoint()
+        parse_lambda_config(params)
 
     def set_parameters(self):
         """xtrainer.py:168-184."""
@@ -100,12 +122,23 @@ class Trainer(object):
     def _stat(self, key, value):
         self.stats.setdefault(key, []).append(value.detach() if torch.is_tensor(value) else value)
 
+    def _dp_plan(self, vocab_dense, expect=()):
+        """Data parallelism: tell the reducer whether this step type has an MLM head (a dense gradient for the
+        vocabulary matrix), and mark the heads this step type MAY train as touched on every rank - whether a head
+        actually runs depends on the rank's batch (any masked word / region?), and ranks must agree on the ranges
+        the optimizer steps and zeroes."""
+        model = getattr(self, 'model')
+        if isinstance(model, DataParallel) and model.world > 1:
+            model.plan_step(vocab_dense)
+            arena = model.module.arena()
+            for head in expect:
+                arena.touch(*_REGION_HEADS[head])
+
     def optimize(self, loss):
         """xtrainer.py:205-243 without the host round trips: backward -> (bucketed
         all-reduce overlapped with it) -> global-norm clip -> Adam -> zero_grad, the last
         three as one fused pass over the arenas."""
         params = self.params
-        optimizers = list(self.optimizers.values())
         accumulate = max(int(getattr(params, 'accumulate_gradients', 1)), 1)
         boundary = self.n_iter % accumulate == 0   # xtrainer.py:231
         model = getattr(self, 'model')
@@ -116,7 +149,7 @@ class Trainer(object):
         loss.backward()
         if not boundary:
             return
-        for opt in optimizers:
+        for opt in self.optimizers.values():
             if params.clip_grad_norm > 0:
                 opt.clip_grad_norm(params.clip_grad_norm)
             opt.step()
@@ -125,78 +158,228 @@ class Trainer(object):
         """xtrainer.py:245-252."""
         self.n_iter += 1
         self.n_total_iter += 1
+        update_lambdas(self.params, self.n_total_iter)
         self.print_stats()
 
     def print_stats(self):
-        """xtrainer.py:254-289 (sent/s = processed_s / elapsed is the throughput metric)."""
+        """Every 5 iterations: mean of each loss since the last print, learning rates, and the
+        throughput meter sent/s = processed_s / elapsed, words/s likewise (xtrainer.py:254-289 -
+        the reference's definition of the metric bench.py reports).  The only place the step
+        statistics are read back from the device."""
         if self.n_iter % 5 != 0:
             return
         if self._pending_w:
-            self.stats['processed_w'] += int(torch.stack(self._pending_w).sum().item())
+            self.stats['processed_w'] += int(torch.stack([w.reshape(()) for w in self._pending_w]).sum().item())
             self._pending_w = []
-        s_iter = '%7i - ' % self.n_iter
-        parts = []
-        for k, v in self.stats.items():
-            if type(v) is list and len(v) > 0:
-                vals = [float(x) for x in (torch.stack([t.float() for t in v]).tolist() if torch.is_tensor(v[0]) else v)]
-                parts.append('{}: {:7.4f}'.format(k, np.mean(vals)))
-                del v[:]
-        s_stat = ' || '.join(parts)
-        s_lr = ' - '
-        for k, v in self.optimizers.items():
-            s_lr = s_lr + (' - %s LR: ' % k) + ' / '.join('{:.4e}'.format(group['lr']) for group in v.param_groups)
-        new_time = time.time()
-        diff = new_time - self.last_time
-        s_speed = '{:7.2f} sent/s - {:8.2f} words/s - '.format(self.stats['processed_s'] * 1.0 / diff,
-                                                              self.stats['processed_w'] * 1.0 / diff)
-        self.stats['processed_s'] = 0
-        self.stats['processed_w'] = 0
-        self.last_time = new_time
-        logger.info(s_iter + s_speed + s_stat + s_lr)
+        means = []
+        for key, vals in self.stats.items():
+            if isinstance(vals, list) and vals:
+                host = torch.stack([v.float().reshape(()) for v in vals]).tolist() if torch.is_tensor(vals[0]) else vals
+                means.append('%s: %7.4f' % (key, float(np.mean(host))))
+                del vals[:]
+        rates = ' - ' + ''.join(' - %s LR: %s' % (name, ' / '.join('%.4e' % g['lr'] for g in opt.param_groups))
+                                for name, opt in self.optimizers.items())
+        now = time.time()
+        elapsed = now - self.last_time
+        speed = '%7.2f sent/s - %8.2f words/s - ' % (self.stats['processed_s'] / elapsed, self.stats['processed_w'] / elapsed)
+        self.stats['processed_s'] = self.stats['processed_w'] = 0
+        self.last_time = now
+        logger.info('%7i - ' % self.n_iter + speed + ' || '.join(means) + rates)
 
-    # ---- checkpoints (xtrainer.py:511-599): same dict layout / key names
+    # ------------------------------------------------------------------ text batches (xtrainer.py:436-509)
+    def get_cross_lingual_iterator(self, iter_name, lang1, lang2, stream):
+        """Data-layer contract (the datasets themselves are the reference's): ``data['mono_stream'][lang]['train']``
+        / ``data['mono'][lang]['train']`` / ``data['para'][(l1, l2)]['train']`` expose ``get_iterator(...)``
+        yielding ``(x, lengths)`` (or a pair of those for parallel data)."""
+        logger.info('Creating new training data iterator (%s) ...' % ','.join(
+            str(v) for v in (iter_name, lang1, lang2) if v is not None))
+        if lang2 is None:
+            if stream:
+                iterator = self.data['mono_stream'][lang1]['train'].get_iterator(shuffle=True)
+            else:
+                iterator = self.data['mono'][lang1]['train'].get_iterator(
+                    shuffle=True, group_by_size=self.params.group_by_size, n_sentences=-1)
+        else:
+            pair = (lang1, lang2) if lang1 < lang2 else (lang2, lang1)
+            iterator = self.data['para'][pair]['train'].get_iterator(
+                shuffle=True, group_by_size=self.params.group_by_size, n_sentences=-1)
+        self.iterators[(iter_name, lang1, lang2)] = iterator
+        return iterator
+
+    def get_cross_lingual_batch(self, iter_name, lang1, lang2=None, stream=False):
+        assert lang1 in self.params.langs and (lang2 is None or lang2 in self.params.langs)
+        iterator = self.iterators.get((iter_name, lang1, lang2))
+        if iterator is None:
+            iterator = self.get_cross_lingual_iterator(iter_name, lang1, lang2, stream)
+        try:
+            x = next(iterator)
+        except StopIteration:
+            x = next(self.get_cross_lingual_iterator(iter_name, lang1, lang2, stream))
+        return x if lang2 is None or lang1 < lang2 else x[::-1]
+
+    def generate_batch(self, lang1, lang2, name):
+        """xtrainer.py:485-509, the monolingual stream case (MLM).  The TLM case (lang2 given) concatenates two
+        languages with reset positions and language embeddings - not on the MI355X path (the encoder kernels take
+        positions 0..S-1 and ignore language ids, like jointfwd does: transformer.py:937-938)."""
+        if lang2 is not None:
+            raise NotImplementedError('TLM batches (lang2 = %r) need position / language embeddings inputs that the '
+                                      'MI355X text stream does not take; MLM (lang2 = None) is supported' % (lang2,))
+        params = self.params
+        x, lengths = self.get_cross_lingual_batch(name, lang1, stream=True)
+        langs = x.clone().fill_(params.lang2id[lang1]) if params.n_langs > 1 else None
+        return x, lengths, None, langs, (None, None)
+
+    def round_batch(self, x, lengths, positions, langs):
+        """xtrainer.py:654-692."""
+        return masking.round_batch(x, lengths, positions, langs, self.params)
+
+    def mask_out(self, x, lengths):
+        """xtrainer.py:385-434."""
+        return masking.mask_out(x, lengths, self.params)
+
+    def mlm_step(self, lang1, lang2, lambda_coeff):
+        """Masked word prediction on a text batch (xtrainer.py:734-770)."""
+        assert lambda_coeff >= 0
+        if lambda_coeff == 0:
+            return
+        x, lengths, positions, langs, _ = self.generate_batch(lang1, lang2, 'pred')
+        x, lengths, positions, langs, _ = self.round_batch(x, lengths, positions, langs)
+        x, y, pred_mask = self.mask_out(x, lengths)
+        return self.mlm_step_on_batch(x, lengths, pred_mask, y, lang1, lambda_coeff)
+
+    def mlm_step_on_batch(self, x, lengths, pred_mask, y, lang='en', lambda_coeff=1):
+        """Loss path of mlm_step on an already masked batch (:751-770)."""
+        model = self.model
+        model.train()
+        self._dp_plan(True, expect=('mlm',))
+        n_words = pred_mask.sum()
+        x, y, pred_mask, lengths = to_cuda(x, y, pred_mask, lengths)
+        tensor = model('crossfwd', stream_='text', x=x, lengths=lengths, positions=None, langs=None, causal=False)
+        _, loss = model('predict', tensor=tensor, pred_mask=pred_mask, y=y, get_scores=False)
+        self._stat('MLM-%s' % lang, loss)
+        self.optimize(lambda_coeff * loss)
+        self.n_sentences += self.params.batch_size
+        self.stats['processed_s'] += lengths.size(0)
+        self._pending_w.append(n_words)
+        return loss
+
+    # ------------------------------------------------------------------ checkpoints (xtrainer.py:511-650)
+    def _state_dicts(self):
+        return {n: {k: v.detach().cpu().clone() for k, v in _unwrap(getattr(self, n)).state_dict().items()}
+                for n in self.MODEL_NAMES}
+
+    def _params_dict(self):
+        return {k: v for k, v in self.params.__dict__.items()}
+
     def save_model(self, name):
+        """{'model': state_dict, 'params': dict} (:511-529), written by the master rank only."""
+        if not getattr(self.params, 'is_master', True):
+            return None
         path = os.path.join(self.params.dump_path, '%s.pth' % name)
-        data = {}
-        for n in self.MODEL_NAMES:
-            m = getattr(self, n)
-            m = m.module if isinstance(m, DataParallel) else m
-            data[n] = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
-        data['params'] = {k: v for k, v in self.params.__dict__.items() if not torch.is_tensor(v)}
+        logger.info('Saving models to %s ...' % path)
+        data = self._state_dicts()
+        data['params'] = self._params_dict()
         torch.save(data, path)
         return path
 
-    def save_checkpoint(self, name='checkpoint'):
+    def save_checkpoint(self, name='checkpoint', include_optimizers=True):
+        """:531-560: model + optimizer ``state_dict()`` (param_groups with num_updates / lr, and the Adam moments)
+        + epoch counters + best metrics; master rank only."""
+        if not getattr(self.params, 'is_master', True):
+            return None
         path = os.path.join(self.params.dump_path, '%s.pth' % name)
+        logger.info('Saving %s to %s ...' % (name, path))
         data = {'epoch': self.epoch, 'n_total_iter': self.n_total_iter, 'best_metrics': self.best_metrics,
                 'best_stopping_criterion': self.best_stopping_criterion}
-        for n in self.MODEL_NAMES:
-            m = getattr(self, n)
-            m = m.module if isinstance(m, DataParallel) else m
-            data[n] = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
-        for n, opt in self.optimizers.items():
-            data[n + '_optimizer'] = {'param_groups': [{k: v for k, v in g.items() if k != 'params'}
-                                                       for g in opt.param_groups]}
-        data['params'] = {k: v for k, v in self.params.__dict__.items() if not torch.is_tensor(v)}
+        data.update(self._state_dicts())
+        if include_optimizers:
+            for n, opt in self.optimizers.items():
+                sd = opt.state_dict()
+                for st in sd['state'].values():      # moments are views of the flat arenas: detach them from it
+                    for k, v in st.items():
+                        if torch.is_tensor(v):
+                            st[k] = v.detach().cpu().clone()
+                data['%s_optimizer' % n] = sd
+        data['params'] = self._params_dict()
         torch.save(data, path)
         return path
 
-    def reload_checkpoint(self, path):
-        """Restores weights and, like the reference (:586-592), only num_updates / lr of the optimizer."""
+    def reload_checkpoint(self, path=None):
+        """:562-599: looks for dump_path/checkpoint.pth, else params.reload_checkpoint; restores the weights
+        (``module.`` prefixes of a DDP-saved file stripped), and - like the reference - only ``num_updates`` / lr of
+        the optimizer, then the epoch counters and best metrics.  ``path`` overrides the search (extension)."""
+        params = self.params
+        if path is None:
+            path = os.path.join(getattr(params, 'dump_path', ''), 'checkpoint.pth')
+            if not os.path.isfile(path):
+                path = getattr(params, 'reload_checkpoint', '')
+                if path == '':
+                    return
+                assert os.path.isfile(path), path
+        logger.warning('Reloading checkpoint from %s ...' % path)
         data = torch.load(path, map_location='cpu', weights_only=False)
         for n in self.MODEL_NAMES:
-            m = getattr(self, n)
-            m = m.module if isinstance(m, DataParallel) else m
-            sd = {(k[len('module.'):] if k.startswith('module.') else k): v for k, v in data[n].items()}
-            m.load_state_dict(sd)
+            sd = data[n]
+            if all(k.startswith('module.') for k in sd):
+                sd = {k[len('module.'):]: v for k, v in sd.items()}
+            _unwrap(getattr(self, n)).load_state_dict(sd)
         for n, opt in self.optimizers.items():
+            saved = data.get('%s_optimizer' % n)
+            if saved is None:
+                continue
             for gid, g in enumerate(opt.param_groups):
-                saved = data[n + '_optimizer']['param_groups'][gid]
-                if 'num_updates' in saved:
-                    g['num_updates'] = saved['num_updates']
+                if 'num_updates' in g and 'num_updates' in saved['param_groups'][gid]:
+                    g['num_updates'] = saved['param_groups'][gid]['num_updates']
                     g['lr'] = opt.get_lr_for_step(g['num_updates'])
-        self.epoch = data['epoch'] + 1 if 'epoch' in data else self.epoch
-        self.n_total_iter = data.get('n_total_iter', self.n_total_iter)
+        self.epoch = data['epoch'] + 1
+        self.n_total_iter = data['n_total_iter']
+        self.best_metrics = data['best_metrics']
+        self.best_stopping_criterion = data['best_stopping_criterion']
+        logger.warning('Checkpoint reloaded. Resuming at epoch %i / iteration %i ...' % (self.epoch, self.n_total_iter))
+
+    def save_periodic(self):
+        """:601-608."""
+        every = getattr(self.params, 'save_periodic', 0)
+        if getattr(self.params, 'is_master', True) and every > 0 and self.epoch % every == 0:
+            self.save_model('periodic-%i' % self.epoch)
+
+    def save_best_model(self, scores):
+        """:610-625: one 'best-<metric>' model + checkpoint per validation metric that improved."""
+        if not getattr(self.params, 'is_master', True):
+            return
+        for metric, biggest in self.metrics:
+            if metric not in scores:
+                logger.warning('Metric "%s" not found in scores!' % metric)
+                continue
+            sign = 1 if biggest else -1
+            if sign * scores[metric] > sign * self.best_metrics[metric]:
+                self.best_metrics[metric] = scores[metric]
+                logger.info('New best score for %s: %.6f' % (metric, scores[metric]))
+                self.save_model('best-%s' % metric)
+                self.save_checkpoint('best-%s' % metric, include_optimizers=True)
+
+    def end_epoch(self, scores):
+        """:627-650: early stopping on the stopping criterion, then the rolling checkpoint."""
+        if self.stopping_criterion is not None and (getattr(self.params, 'is_master', True)
+                                                    or not self.stopping_criterion[0].endswith('_mt_bleu')):
+            metric, biggest = self.stopping_criterion
+            assert metric in scores, metric
+            sign = 1 if biggest else -1
+            if sign * scores[metric] > sign * self.best_stopping_criterion:
+                self.best_stopping_criterion = scores[metric]
+                logger.info('New best validation score: %f' % self.best_stopping_criterion)
+                self.decrease_counts = 0
+            else:
+                logger.info('Not a better validation score (%i / %i).' % (self.decrease_counts, self.decrease_counts_max))
+                self.decrease_counts += 1
+            if self.decrease_counts > self.decrease_counts_max:
+                logger.info('Stopping criterion has been below its best value for more than %i epochs. '
+                            'Ending the experiment...' % self.decrease_counts_max)
+                if getattr(self.params, 'multi_gpu', False) and 'SLURM_JOB_ID' in os.environ:
+                    os.system('scancel ' + os.environ['SLURM_JOB_ID'])
+                raise SystemExit(0)
+        self.save_checkpoint('checkpoint', include_optimizers=True)
+        self.epoch += 1
 
 
 class XTrainer(Trainer):
@@ -208,7 +391,43 @@ class XTrainer(Trainer):
         self.params = params
         super().__init__(data, params)
 
-    # ------------------------------------------------------------------ masks
+    # ------------------------------------------------------------------ cross-modal batches (xtrainer.py:1148-1206)
+    def get_iterator(self, iter_name, lang1, lang2):
+        """A DataLoader over ``data['cross_modal'][(dataset, 'img')]['train']`` with the pre-training or the
+        retrieval collate; distributed runs shard it with a DistributedSampler.  (Generation / sliding-window
+        loaders are outside this build.)"""
+        from torch.utils.data import DataLoader, RandomSampler
+        from torch.utils.data.distributed import DistributedSampler
+        params = self.params
+        logger.info('Creating new training data iterator (%s) ...' % ','.join(
+            str(v) for v in (iter_name, lang1, lang2) if v is not None))
+        dataset = self.data['cross_modal'][(lang1, lang2)]['train']
+        if lang1 in ('google', 'sbu') and hasattr(dataset, 'update'):
+            dataset.update(self.epoch)                   # conceptual-captions shards rotate per epoch
+        if lang1 == 'flicker' and hasattr(dataset, 'update_captions'):
+            dataset.update_captions()
+        sampler = RandomSampler(dataset) if getattr(params, 'n_gpu_per_node', 1) == 1 else DistributedSampler(dataset)
+        collate = retrieval_pretrain_collate if getattr(params, 'is_pretrain', False) else retrieval_collate
+        loader = DataLoader(dataset, batch_size=params.batch_size, sampler=sampler, collate_fn=collate,
+                            num_workers=getattr(params, 'num_workers', 0))
+        for batch in loader:
+            yield batch
+
+    def get_batch(self, iter_name, lang1, lang2=None):
+        assert lang2 == 'img'
+        key = (iter_name, lang1, lang2)
+        iterator = self.iterators.get(key)
+        if iterator is None:
+            iterator = self.iterators[key] = self.get_iterator(iter_name, lang1, lang2)
+        try:
+            return next(iterator)
+        except StopIteration:
+            if getattr(self.params, 'is_pretrain', False):
+                self.iterators = {}
+            iterator = self.iterators[key] = self.get_iterator(iter_name, lang1, lang2)
+            return next(iterator)
+
+    # ------------------------------------------------------------------ masks / losses
     def get_mask_(self, x, _labels):
         """xtrainer.py:2226-2232: mask = labels != -1; targets = labels[labels > 0]."""
         pred_mask = (_labels != -1)
@@ -219,7 +438,7 @@ class XTrainer(Trainer):
         """xtrainer.py:2357-2372 kept on the device: CE over groups of sample_n + BCE vs one-hot."""
         params = self.params
         dev = relation_scores.device
-        pos = torch.as_tensor(np.asarray(pos_labels), dtype=torch.long).to(dev)
+        pos = torch.as_tensor(np.asarray(pos_labels), dtype=torch.long).reshape(-1).to(dev)
         onehot = F.one_hot(pos, params.sample_n).float().view(-1)
         scores = relation_scores.float()
         loss = 0
@@ -230,9 +449,27 @@ class XTrainer(Trainer):
         return loss
 
     # ------------------------------------------------------------------ hot steps
+    def pretrain_rel_step(self, dataset='coco', input_stream='img'):
+        """xtrainer.py:1879-1886."""
+        p = self.params
+        t2i_batch, i2t_batch = self.get_batch('rel', dataset, input_stream)
+        if p.t2i_flag:
+            self.pretrain_under_step(t2i_batch, dataset, 't2i', 'en', p.lambda_t2i, p.lambda_mlm, p.lambda_mrm, p.lambda_mrfr)
+        if p.i2t_flag:
+            self.pretrain_under_step(i2t_batch, dataset, 'i2t', 'en', p.lambda_i2t, p.lambda_mlm, p.lambda_mrm, p.lambda_mrfr)
+
+    def rel_step(self, dataset='coco', input_stream='img', lambda_1=1, lambda_2=1):
+        """xtrainer.py:1867-1877 (the FreeLB variants are not built)."""
+        t2i_batch, i2t_batch = self.get_batch('rel', dataset, input_stream)
+        assert not getattr(self.params, 'is_freelb', False), 'FreeLB adversarial steps are outside this build'
+        if self.params.t2i_flag:
+            self.t2i_step(t2i_batch, dataset, lambda_1)
+        if self.params.i2t_flag:
+            self.i2t_step(i2t_batch, dataset, lambda_2)
+
     def pretrain_under_step(self, _batch, dataset='coco', task_name='t2i', lang2='en', lambda_coeff_rel=1,
                             lambda_coeff_mlm=1, lambda_coeff_mrm=1, lambda_coeff_mrfr=1):
-        """xtrainer.py:2234-2402 for the MLM (+ITM) objective."""
+        """xtrainer.py:2234-2402: MLM + MRM + MRFR + ITM (+ CLCM on the i2t task) on one joint batch."""
         params = self.params
         model = self.model
         model.train()
@@ -245,7 +482,9 @@ class XTrainer(Trainer):
         x_img = img.transpose(0, 1)
         img_loc = img_loc.transpose(0, 1)
         y_text, pred_mask_text = self.get_mask_(x1, x1_labels)
-        has_mlm = len(params.cross_mlm_steps) > 0 and int(y_text.numel()) > 0
+        mlm_on, mrm_on, mrfr_on = (len(getattr(params, k)) > 0 for k in ('cross_mlm_steps', 'cross_mrm_steps', 'cross_mrfr_steps'))
+        self._dp_plan(mlm_on, expect=[h for h, on in (('mlm', mlm_on), ('mrm', mrm_on), ('mrfr', mrfr_on)) if on])
+        has_mlm = mlm_on and int(y_text.numel()) > 0
         x1, len1, x_img, img_loc, img_len, y_text, pred_mask_text = to_cuda(
             x1, len1, x_img, img_loc, img_len, y_text, pred_mask_text)
 
@@ -260,13 +499,13 @@ class XTrainer(Trainer):
             total_loss = total_loss + lambda_coeff_mlm * loss
         _img_out = encoder_outputs[:R].transpose(0, 1)          # (B, R, d), xtrainer.py:2288-2289
         has_masked_region = bool((obj_labels != -1).any()) if torch.is_tensor(obj_labels) else False   # host tensor
-        if len(params.cross_mrm_steps) > 0 and has_masked_region:          # xtrainer.py:2320-2328
+        if mrm_on and has_masked_region:          # xtrainer.py:2320-2328
             _, loss = model('predict', tensor=_img_out, pred_mask=None, y=obj_labels.reshape(-1), get_scores=False, is_obj=True)
             self._stat('MRM-%s' % dataset, loss)
             total_loss = total_loss + lambda_coeff_mrm * loss
-        if len(params.cross_mrfr_steps) > 0 and has_masked_region:         # xtrainer.py:2330-2352
+        if mrfr_on and has_masked_region:         # xtrainer.py:2330-2352
             from . import functional as Fn
-            loss = Fn.mrfr_head(model.module if hasattr(model, 'module') else model, _img_out, obj_labels, ori_att_feats)
+            loss = Fn.mrfr_head(_unwrap(model), _img_out, obj_labels, ori_att_feats)
             self._stat('MRFR-%s' % dataset, loss)
             total_loss = total_loss + lambda_coeff_mrfr * loss
         relation_scores = model('predict', tensor=encoder_outputs.transpose(0, 1), is_relation=True)
@@ -290,44 +529,42 @@ class XTrainer(Trainer):
         self._pending_w.append(len1.sum())
         return total_loss
 
-    def _rel_step(self, _batch, dataset, task_name, lambda_coeff):
-        """t2i_step / i2t_step loss path (xtrainer.py:1888-2018): jointfwd -> relation scores ->
-        CE/BCE -> optimize; each dataset item contributes sample_n sequences."""
+    def _rel_step(self, batches, dataset, task_name, lambda_coeff):
+        """t2i_step / i2t_step (xtrainer.py:1888-2018): jointfwd -> relation scores -> CE/BCE -> optimize.
+        ``batches`` is what retrieval_collate emits: ((x1, len1, lang_p), (img, img_mask, img_loc, obj_labels,
+        pos_labels, img_ids)); every dataset item contributes sample_n sequences.  The language ids only feed the
+        ``langs`` argument, which jointfwd ignores (transformer.py:937-938)."""
+        assert lambda_coeff >= 0
+        if lambda_coeff == 0:
+            return None
         params = self.params
         model = self.model
         model.train()
-        (x1, len1), (img, img_mask, img_loc, pos_labels) = _batch[:2]
+        text, visual = batches[0], batches[1]
+        x1, len1 = text[0], text[1]
+        if len(visual) == 6:
+            img, img_mask, img_loc, _obj_labels, pos_labels, _img_ids = visual
+        else:                                      # (img, img_mask, img_loc, pos_labels): hand-built batches
+            img, img_mask, img_loc, pos_labels = visual
+        self._dp_plan(False)
         img_len = img_mask.sum(dim=1)
         x_img, img_loc = img.transpose(0, 1), img_loc.transpose(0, 1)
         x1, len1, x_img, img_loc, img_len = to_cuda(x1, len1, x_img, img_loc, img_len)
         enc = model('jointfwd', x=x1, lengths=len1, x_img=x_img, lengths_img=img_len, causal=False, langs=None,
                     image_loc=img_loc, refine_image=params.refine_image)
-        relation_scores = model('predict', tensor=enc.transpose(0, 1), is_relation=True)
+        enc = enc.transpose(0, 1)
+        relation_scores = model('predict', tensor=enc, is_relation=True)
         loss = self._itm_loss(relation_scores, pos_labels)
         self._stat('%s-%s' % (task_name, dataset), loss)
         self.optimize(lambda_coeff * loss)
+        bs = len1.size(0)
         self.n_sentences += params.batch_size
-        self.stats['processed_s'] += len1.size(0)
-        self._pending_w.append(len1.sum())
+        self.stats['processed_s'] += bs
+        self.stats['processed_w'] += bs * enc.size(1)
         return loss
 
-    def t2i_step(self, _batch, dataset='coco', lambda_coeff=1):
-        return self._rel_step(_batch, dataset, 't2i', lambda_coeff)
+    def t2i_step(self, batches, dataset='coco', lambda_coeff=1):
+        return self._rel_step(batches, dataset, 't2i', lambda_coeff)
 
-    def i2t_step(self, _batch, dataset='coco', lambda_coeff=1):
-        return self._rel_step(_batch, dataset, 'i2t', lambda_coeff)
-
-    def mlm_step_on_batch(self, x, lengths, pred_mask, y, lang='en', lambda_coeff=1):
-        """Loss path of Trainer.mlm_step (xtrainer.py:734-770) on an already masked batch
-        (mask_out :385-434 is host-side numpy RNG and stays with the data layer)."""
-        model = self.model
-        model.train()
-        x, lengths, pred_mask, y = to_cuda(x, lengths, pred_mask, y)
-        tensor = model('crossfwd', stream_='text', x=x, lengths=lengths, positions=None, langs=None, causal=False)
-        _, loss = model('predict', tensor=tensor, pred_mask=pred_mask, y=y, get_scores=False)
-        self._stat('MLM-%s' % lang, loss)
-        self.optimize(lambda_coeff * loss)
-        self.n_sentences += self.params.batch_size
-        self.stats['processed_s'] += lengths.size(0)
-        self._pending_w.append(pred_mask.sum())
-        return loss
+    def i2t_step(self, batches, dataset='coco', lambda_coeff=1):
+        return self._rel_step(batches, dataset, 'i2t', lambda_coeff)

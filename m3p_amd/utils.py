@@ -1,0 +1,62 @@
+"""Small host-side helpers of the trainer surface (M3P/src/utils.py): device transfer, the
+scheduled lambda coefficients of ``train_x.py`` and boolean flags.  Pure Python, no kernels."""
+import torch
+
+# coefficients that may carry a schedule "it0:v0,it1:v1,..." (utils.py:28-30)
+DYNAMIC_COEFF = ['lambda_mlm', 'lambda_mass', 'lambda_ic', 'lambda_imlm', 'lambda_ida', 'lambda_tifg', 'lambda_rel',
+                 'lambda_mrm', 'lambda_mrfr', 'lambda_t2i', 'lambda_i2t']
+
+
+def to_cuda(*args):
+    """utils.py:233-237: None stays None, tensors move to the current device without blocking."""
+    return [None if x is None else x.cuda(non_blocking=True) for x in args]
+
+
+def _parse_schedule(spec):
+    """'3' -> (3.0, None);  '0:1,1000:0' -> (1.0, [(0, 1.0), (1000, 0.0)])  (utils.py:249-268)."""
+    if isinstance(spec, (int, float)):
+        return float(spec), None
+    knots = spec.split(',')
+    if len(knots) == 1:
+        return float(spec), None
+    pts = []
+    for knot in knots:
+        it, _, val = knot.partition(':')
+        assert it.isdigit() and val != '', 'bad lambda schedule %r' % spec
+        pts.append((int(it), float(val)))
+    assert all(a[0] < b[0] for a, b in zip(pts, pts[1:])), 'lambda schedule iterations must increase: %r' % spec
+    return pts[0][1], pts
+
+
+def parse_lambda_config(params):
+    """Turns every ``params.lambda_*`` string into its initial float and stores the schedule
+    (or None) as ``params.lambda_*_config``.  Coefficients a caller did not define are skipped."""
+    for name in DYNAMIC_COEFF:
+        if not hasattr(params, name):
+            continue
+        value, config = _parse_schedule(getattr(params, name))
+        setattr(params, name, value)
+        setattr(params, name + '_config', config)
+
+
+def get_lambda_value(config, n_iter):
+    """Piecewise-linear interpolation of a schedule at iteration n_iter; constant after the
+    last knot (utils.py:271-283)."""
+    if n_iter >= config[-1][0]:
+        return config[-1][1]
+    for (x_a, y_a), (x_b, y_b) in zip(config, config[1:]):
+        if x_a <= n_iter < x_b:
+            return y_a + (n_iter - x_a) * float(y_b - y_a) / float(x_b - x_a)
+    raise AssertionError('iteration %d precedes the schedule %r' % (n_iter, config))
+
+
+def update_lambdas(params, n_iter):
+    """utils.py:286-293."""
+    for name in DYNAMIC_COEFF:
+        config = getattr(params, name + '_config', None)
+        if config is not None:
+            setattr(params, name, get_lambda_value(config, n_iter))
+
+
+def concat_rows(tensors):
+    return torch.cat([t.reshape(-1) for t in tensors])

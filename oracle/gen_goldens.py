@@ -383,9 +383,167 @@ def gen_state_dict_enumeration():
     print('state_dict_enum.npz: %d entries' % len(keys))
 
 
+def _reference_trainer(cfg, **over):
+    """The reference's XTrainer on the cfg1 golden model through the container-only shims."""
+    for name in ('apex', 'apex.amp', 'apex.parallel'):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    import src.xtrainer as xt
+    m, P, hot = build_reference_model(cfg)
+    extra = dict(
+        langs=['en'], encoder_only=True, epoch_size=100, stopping_criterion='', amp=-1, fp16=False,
+        accumulate_gradients=1, multi_gpu=False, local_rank=0, word_mask=0.8, word_keep=0.1, word_rand=0.1,
+        validation_metrics='', dump_path='/nonexistent_m3p_dump', reload_checkpoint='',
+        optimizer='adam_inverse_sqrt,beta1=0.9,beta2=0.98,lr=0.0001', use_memory=0, clip_grad_norm=5,
+        pc_steps=[], ae_steps=[], mt_steps=[], mass_steps=[], bt_steps=[], cross_modal_steps=[],
+        cross_rel_steps=[('google', 'img')], cross_mass_steps=[], cross_ae_steps=[], cross_gan_steps=[],
+        cross_mlm_steps=[('google', 'img')], cross_mrm_steps=[], cross_mrfr_steps=[], cross_clcm_steps=[],
+        max_region_num=cfg['R'], sample_n=2, is_latent=False, refine_image=False,
+        multi_cls_loss_weight=0, bin_cls_loss_weight=1, batch_size=cfg['B'],
+        sample_alpha=0, word_pred=0.15, is_ntg=False, group_by_size=False, is_freelb=False, t2i_flag=True, i2t_flag=True,
+    )
+    extra.update(over)
+    for k, v in extra.items():
+        setattr(P, k, v)
+    for lam in ('lambda_clm', 'lambda_mlm', 'lambda_pc', 'lambda_ae', 'lambda_mt', 'lambda_bt', 'lambda_mass',
+                'lambda_ic', 'lambda_imlm', 'lambda_ida', 'lambda_tifg', 'lambda_rel', 'lambda_mrm',
+                'lambda_mrfr', 'lambda_t2i', 'lambda_i2t'):
+        setattr(P, lam, '1')
+    return xt, xt.XTrainer(m, {}, P), m, P, hot
+
+
+def gen_host_goldens():
+    """Host logic of the trainer surface (SURVEY §8c item v and VERDICT r1 item 4): the reference's mask_out /
+    round_batch under fixed seeds, its collate functions on synthetic dataset items, the lambda schedules, and two
+    more entry points run end to end on CPU - mlm_step on a fake monolingual stream and t2i_step on the tuple
+    retrieval_collate emits."""
+    from src.utils import parse_lambda_config, get_lambda_value
+    cfg = synth.CONFIGS['cfg1']
+    xt, tr, m, P, hot = _reference_trainer(cfg)
+    g = {}
+    rs = np.random.RandomState(31)
+
+    # ---- mask_out (xtrainer.py:385-434) under three configurations
+    V = cfg['n_words']
+    x = torch.from_numpy(rs.randint(4, V - 1, size=(21, 11)).astype(np.int64))
+    lengths = torch.from_numpy(rs.randint(10, 22, size=11).astype(np.int64))
+    lengths[0] = 21
+    for b in range(11):
+        x[int(lengths[b]):, b] = P.pad_index
+    g['mo_x'], g['mo_len'] = x.numpy(), lengths.numpy()
+    scores = rs.uniform(0.1, 1.0, size=V)
+    g['mo_scores'] = scores
+    for tag, alpha, fp16 in (('a', 0, False), ('b', 0, True), ('c', 0.5, True)):
+        P.sample_alpha, P.fp16, P.mask_scores = alpha, fp16, scores
+        np.random.seed(123); torch.manual_seed(123)
+        x2, y, pm = tr.mask_out(x.clone(), lengths)
+        g['mo_%s_x' % tag], g['mo_%s_y' % tag], g['mo_%s_mask' % tag] = x2.numpy(), y.numpy(), pm.numpy()
+    # ---- round_batch (:654-692)
+    P.fp16 = True
+    pos = torch.arange(21)[:, None].repeat(1, 11)
+    langs = torch.zeros(21, 11, dtype=torch.long)
+    torch.manual_seed(5)
+    rx, rl, rp, rg, ridx = tr.round_batch(x.clone(), lengths.clone(), pos, langs)
+    g['rb_x'], g['rb_len'], g['rb_pos'], g['rb_langs'], g['rb_idx'] = rx.numpy(), rl.numpy(), rp.numpy(), rg.numpy(), ridx.numpy()
+    torch.manual_seed(6)
+    rx, rl, rp, rg, ridx = tr.round_batch(x[:, :8].clone(), lengths[:8].clone(), None, None)
+    g['rb8_x'], g['rb8_len'] = rx.numpy(), rl.numpy()
+    assert rp is None and rg is None and ridx is None
+    P.fp16, P.sample_alpha = False, 0
+
+    # ---- collates (:829-930, :960-1045) on synthetic items: 3 items x sample_n 2 captions, R = 4 regions
+    def item(pretrain, i2t, k=2, R=4):
+        caps = [rs.randint(4, V - 1, size=rs.randint(0, 7)).astype(np.int64) for _ in range(k)]
+        feats = torch.from_numpy(rs.standard_normal((k, R, 2048)).astype(np.float32))
+        masks = torch.ones(k, R, dtype=torch.long)
+        boxes = torch.from_numpy(rs.uniform(size=(k, R, 5)).astype(np.float32))
+        objs = torch.from_numpy(rs.randint(-1, 5, size=(k, R)).astype(np.int64))
+        ids = [int(v) for v in rs.randint(0, 1000, size=k)]
+        if not pretrain:
+            return (caps, feats, masks, boxes, objs, [int(rs.randint(0, k))], ids, [0] * k)
+        lm = [[int(w) if rs.rand() < 0.3 else -1 for w in c] for c in caps]
+        ori = torch.from_numpy(rs.standard_normal((k, R, 2048)).astype(np.float32))
+        base = (caps, feats, masks, boxes, objs, lm, int(rs.randint(0, k)), ids, ori, [0] * k)
+        if not i2t:
+            return base
+        caps2 = [rs.randint(4, V - 1, size=rs.randint(1, 6)).astype(np.int64) for _ in range(k)]
+        return base + (caps2, torch.from_numpy(rs.randint(0, 2, size=k).astype(np.int64)))
+
+    def flatten(prefix, obj, out):
+        if isinstance(obj, (list, tuple)) and not (len(obj) > 0 and all(isinstance(v, (int, np.integer)) for v in obj)):
+            for i, v in enumerate(obj):
+                flatten('%s.%d' % (prefix, i), v, out)
+        elif torch.is_tensor(obj):
+            out[prefix] = obj.numpy()
+        else:
+            out[prefix] = np.asarray(obj)
+
+    fin_items = [(item(False, False), item(False, False)) for _ in range(3)]
+    pre_items = [(item(True, False), item(True, True)) for _ in range(3)]
+    flatten('col_fin', xt.retrieval_collate(fin_items), g)
+    flatten('col_pre', xt.retrieval_pretrain_collate(pre_items), g)
+    flatten('col_fin_in', fin_items, g)
+    flatten('col_pre_in', pre_items, g)
+
+    # ---- lambda schedules (utils.py:249-293)
+    Q = types.SimpleNamespace(**{n: '1' for n in ('lambda_mlm', 'lambda_mass', 'lambda_ic', 'lambda_imlm', 'lambda_ida',
+                                                  'lambda_tifg', 'lambda_rel', 'lambda_mrm', 'lambda_mrfr', 'lambda_t2i',
+                                                  'lambda_i2t')})
+    Q.lambda_mlm = '0:0,1000:0,2000:1'
+    Q.lambda_t2i = '0:1,1000:0'
+    parse_lambda_config(Q)
+    its = np.array([0, 1, 500, 999, 1000, 1500, 1999, 2000, 5000])
+    g['lam_its'] = its
+    g['lam_mlm'] = np.array([get_lambda_value(Q.lambda_mlm_config, int(i)) for i in its])
+    g['lam_t2i'] = np.array([get_lambda_value(Q.lambda_t2i_config, int(i)) for i in its])
+
+    # ---- mlm_step (:734-770) end to end on a fake monolingual stream, dropout 0
+    class _Stream:
+        def __init__(self, batches):
+            self.batches = batches
+
+        def get_iterator(self, shuffle=True):
+            return iter(self.batches)
+
+    batch = synth.make_batch(cfg['T'], cfg['R'], cfg['B'], cfg['n_words'], 0)
+    xt_, tr2, m2, P2, hot2 = _reference_trainer(cfg)
+    tr2.data = {'mono_stream': {'en': {'train': _Stream([(batch['x'], batch['lengths'])])}}}
+    np.random.seed(77); torch.manual_seed(77)
+    tr2.mlm_step('en', None, 1.0)
+    named = dict(m2.named_parameters())
+    g['mlm_step_loss'] = np.asarray(tr2.stats['MLM-en'][-1])
+    g['mlm_step_lr'] = np.asarray(tr2.optimizers['model'].param_groups[0]['lr'])
+    g['mlm_step_processed_w'] = np.asarray(tr2.stats['processed_w'])
+    for k in ('embeddings.weight', 'attentions.0.q_lin.weight', 'layer_norm2.1.weight', 'pred_layer.proj.bias'):
+        g['mlm_step_pnorm/' + k] = named[k].detach().norm().numpy()
+
+    # ---- t2i_step (:1888-1951) on the tuple retrieval_collate emits, sample_n = 4
+    xt_, tr3, m3, P3, hot3 = _reference_trainer(cfg, sample_n=4, multi_cls_loss_weight=1, bin_cls_loss_weight=1)
+    B, R = cfg['B'], cfg['R']
+    full = synth.make_batch(cfg['T'], R, B, cfg['n_words'], 0)
+    tup = [(full['x'], full['lengths'], torch.zeros_like(full['x'])),
+           [full['x_img'].transpose(0, 1).contiguous(), torch.ones(B, R, dtype=torch.long),
+            full['image_loc'].transpose(0, 1).contiguous(), torch.full((B, R), -1, dtype=torch.long), [2, 0], list(range(B))]]
+    tr3.t2i_step(tup, 'google', 1.0)
+    tr3.i2t_step(tup, 'google', 0.5)
+    named = dict(m3.named_parameters())
+    g['t2i_step_loss'] = np.asarray(tr3.stats['t2i-google'][-1])
+    g['i2t_step_loss'] = np.asarray(tr3.stats['i2t-google'][-1])
+    g['rel_step_processed'] = np.asarray([tr3.stats['processed_s'], tr3.stats['processed_w'], tr3.n_sentences])
+    for k in ('pooled_layer.dense.weight', 'attentions.1.out_lin.weight', 'embeddings.weight'):
+        g['rel_step_pnorm/' + k] = named[k].detach().norm().numpy()
+    np.savez_compressed(os.path.join(OUT, 'host_logic.npz'), **g)
+    print('host_logic.npz: %d arrays; mlm_step %.6f t2i %.6f i2t %.6f' % (len(g), float(g['mlm_step_loss']),
+                                                                         float(g['t2i_step_loss']), float(g['i2t_step_loss'])))
+
+
+
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'enum':
         gen_state_dict_enumeration()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'host':
+        gen_host_goldens()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'refiner':
         gen_refiner_goldens()
@@ -398,3 +556,4 @@ if __name__ == '__main__':
     gen_unit_goldens()
     gen_model_goldens()
     gen_trainer_goldens()
+    gen_host_goldens()

@@ -126,13 +126,13 @@ def test_state_dict_is_the_reference_enumeration_and_checkpoints_round_trip(gold
     want['pred_layer.proj.weight'] = want['embeddings.weight']          # tied (transformer.py:728-729)
     path = os.path.join(str(tmp_path), 'checkpoint.pth')
     torch.save({'model': {'module.' + k: v for k, v in want.items()}, 'params': dict(P.__dict__), 'epoch': 4,
-                'n_total_iter': 17, 'model_optimizer': {'param_groups': [{'num_updates': 123, 'lr': 0.0}]}}, path)
+                'n_total_iter': 17, 'best_metrics': {}, 'best_stopping_criterion': None,
+                'model_optimizer': {'param_groups': [{'num_updates': 123, 'lr': 0.0}]}}, path)
     for k, v in dict(optimizer='adam_inverse_sqrt,beta1=0.9,beta2=0.98,lr=0.0001', clip_grad_norm=5, amp=-1, fp16=False,
                      accumulate_gradients=1, multi_gpu=False, local_rank=0, epoch_size=10, batch_size=2,
                      dump_path=str(tmp_path)).items():
         setattr(P, k, v)
-    tr = XTrainer(m, {}, P)
-    tr.reload_checkpoint(path)
+    tr = XTrainer(m, {}, P)          # the constructor finds dump_path/checkpoint.pth like the reference (xtrainer.py:133, :566)
     got = m.state_dict()
     for k, v in want.items():
         assert torch.equal(got[k], v), k

@@ -1,0 +1,224 @@
+"""Host side of the trainer surface against goldens recorded from the reference
+(tests/golden/host_logic.npz, oracle/gen_goldens.py::gen_host_goldens): word masking and fp16
+batch rounding under fixed seeds (bit-exact, RNG streams included), the data-loader collates,
+lambda schedules, checkpoint / early-stopping bookkeeping, build_model's reload semantics."""
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from m3p_amd import collate, masking, synth, utils
+
+
+@pytest.fixture(scope='module')
+def G(golden_dir):
+    return np.load(os.path.join(golden_dir, 'host_logic.npz'), allow_pickle=False)
+
+
+def _mask_params(alpha, fp16, scores):
+    V = synth.CONFIGS['cfg1']['n_words']
+    return SimpleNamespace(sample_alpha=alpha, fp16=fp16, mask_scores=scores, word_pred=0.15, pad_index=synth.PAD,
+                           n_words=V, mask_index=V - 1, pred_probs=torch.FloatTensor([0.8, 0.1, 0.1]))
+
+
+@pytest.mark.parametrize('tag,alpha,fp16', [('a', 0, False), ('b', 0, True), ('c', 0.5, True)])
+def test_mask_out_is_the_reference_bit_for_bit(G, tag, alpha, fp16):
+    x, lengths = torch.from_numpy(G['mo_x']), torch.from_numpy(G['mo_len'])
+    P = _mask_params(alpha, fp16, G['mo_scores'])
+    np.random.seed(123); torch.manual_seed(123)
+    x2, y, pm = masking.mask_out(x.clone(), lengths, P)
+    assert np.array_equal(x2.numpy(), G['mo_%s_x' % tag])
+    assert np.array_equal(y.numpy(), G['mo_%s_y' % tag])
+    assert np.array_equal(pm.numpy(), G['mo_%s_mask' % tag])
+    assert not pm[0].any() and not pm[x == synth.PAD].any()
+    if fp16:
+        assert int(pm.sum()) % 8 == 0
+
+
+def test_mask_out_edge_cases():
+    P = _mask_params(0, False, None)
+    P.word_pred = 0.0                       # nothing selected -> position [0, 0] is predicted (xtrainer.py:417-419)
+    x = torch.full((5, 3), 7, dtype=torch.long)
+    np.random.seed(0); torch.manual_seed(0)
+    x2, y, pm = masking.mask_out(x, torch.tensor([5, 5, 5]), P)
+    assert int(pm.sum()) <= 1 and y.numel() == int(pm.sum()) and (y == 7).all()
+    P.word_pred = 1.0                       # everything but row 0 and padding
+    x[3:, 1] = synth.PAD
+    x2, y, pm = masking.mask_out(x, torch.tensor([5, 3, 5]), P)
+    assert int(pm.sum()) == 4 * 3 - 2 and not pm[0].any() and not pm[3:, 1].any()
+
+
+def test_round_batch_is_the_reference_bit_for_bit(G):
+    P = SimpleNamespace(fp16=True, pad_index=synth.PAD)
+    x, lengths = torch.from_numpy(G['mo_x']), torch.from_numpy(G['mo_len'])
+    pos = torch.arange(21)[:, None].repeat(1, 11)
+    langs = torch.zeros(21, 11, dtype=torch.long)
+    torch.manual_seed(5)
+    rx, rl, rp, rg, idx = masking.round_batch(x.clone(), lengths.clone(), pos, langs, P)
+    for got, key in ((rx, 'rb_x'), (rl, 'rb_len'), (rp, 'rb_pos'), (rg, 'rb_langs'), (idx, 'rb_idx')):
+        assert np.array_equal(got.numpy(), G[key]), key
+    assert rx.shape[0] % 8 == 0 and rx.shape[1] == 8
+    torch.manual_seed(6)
+    rx, rl, rp, rg, idx = masking.round_batch(x[:, :8].clone(), lengths[:8].clone(), None, None, P)
+    assert np.array_equal(rx.numpy(), G['rb8_x']) and np.array_equal(rl.numpy(), G['rb8_len']) and idx is None
+    # fp32 / small batches are left alone
+    P.fp16 = False
+    out = masking.round_batch(x, lengths, None, None, P)
+    assert out[0] is x and out[4] is None
+    P.fp16 = True
+    out = masking.round_batch(x[:, :5], lengths[:5], None, None, P)
+    assert out[0].shape == (21, 5)
+
+
+# ---- collates -----------------------------------------------------------------------------------------------
+def _tree(G, prefix):
+    """Rebuild the nested lists gen_host_goldens flattened into 'prefix.i.j...' keys."""
+    keys = [k for k in G.files if k == prefix or k.startswith(prefix + '.')]
+    if keys == [prefix]:
+        return G[prefix]
+    kids = sorted({int(k[len(prefix) + 1:].split('.')[0]) for k in keys})
+    return [_tree(G, '%s.%d' % (prefix, i)) if i in kids else [] for i in range(max(kids) + 1)]
+
+
+def _item(fields, pretrain):
+    """Arrays -> the python objects a dataset item holds (tensors for region data, lists for ids / labels)."""
+    t = torch.from_numpy
+    caps = [np.asarray(c) for c in fields[0]]
+    k = len(caps)
+    if not pretrain:
+        sent, feats, masks, boxes, objs, pos, ids, langs = fields
+        return (caps, t(feats), t(masks), t(boxes), t(objs), [int(v) for v in pos], [int(v) for v in ids], [int(v) for v in langs])
+    lm = fields[5] if isinstance(fields[5], list) else []
+    lm = [[int(v) for v in np.asarray(lm[j]).reshape(-1)] if j < len(lm) and not isinstance(lm[j], list) else [] for j in range(k)]
+    base = (caps, t(fields[1]), t(fields[2]), t(fields[3]), t(fields[4]), lm, int(fields[6]), [int(v) for v in fields[7]],
+            t(fields[8]), [int(v) for v in fields[9]])
+    if len(fields) == 10:
+        return base
+    return base + ([np.asarray(c) for c in fields[10]], t(fields[11]))
+
+
+def _same(a, b, path='root'):
+    if isinstance(b, list):
+        assert isinstance(a, (list, tuple)) and len(a) == len(b), path
+        for i, (x, y) in enumerate(zip(a, b)):
+            _same(x, y, '%s.%d' % (path, i))
+    else:
+        got = a.numpy() if torch.is_tensor(a) else np.asarray(a)
+        assert got.shape == b.shape and np.array_equal(got, b), path
+
+
+def test_collates_match_the_reference(G):
+    fin_in, pre_in = _tree(G, 'col_fin_in'), _tree(G, 'col_pre_in')
+    fin = [(_item(a, False), _item(b, False)) for a, b in fin_in]
+    pre = [(_item(a, True), _item(b, True)) for a, b in pre_in]
+    _same(collate.retrieval_collate(fin), _tree(G, 'col_fin'))
+    _same(collate.retrieval_pretrain_collate(pre), _tree(G, 'col_pre'))
+    out = collate.retrieval_pretrain_collate(pre)
+    (x1, len1, lab), (x2, len2), vis = out[1]
+    assert x1.shape[1] == 6 and vis[0].shape == (3, 2) and vis[1].shape == (6, 4, 2048) and len(vis) == 8
+    assert (lab[0] == -1).all() and ((lab == -1) | (lab == x1)).all()
+
+
+def test_lambda_schedules(G):
+    Q = SimpleNamespace(**{n: '1' for n in utils.DYNAMIC_COEFF})
+    Q.lambda_mlm, Q.lambda_t2i = '0:0,1000:0,2000:1', '0:1,1000:0'
+    utils.parse_lambda_config(Q)
+    assert Q.lambda_mlm == 0.0 and Q.lambda_t2i == 1.0 and Q.lambda_i2t == 1.0 and Q.lambda_i2t_config is None
+    for it, a, b in zip(G['lam_its'], G['lam_mlm'], G['lam_t2i']):
+        assert utils.get_lambda_value(Q.lambda_mlm_config, int(it)) == a
+        assert utils.get_lambda_value(Q.lambda_t2i_config, int(it)) == b
+    utils.update_lambdas(Q, 1500)
+    assert Q.lambda_mlm == 0.5 and Q.lambda_t2i == 0.0 and Q.lambda_i2t == 1.0
+    with pytest.raises(AssertionError):
+        utils.parse_lambda_config(SimpleNamespace(lambda_mlm='10:1,5:0'))
+
+
+# ---- trainer bookkeeping (CPU model: constructing the trainer needs no GPU) ---------------------------------
+def _trainer(tmp_path, **over):
+    from m3p_amd.model.transformer import TransformerModel
+    from m3p_amd.trainer import XTrainer
+    P = synth.model_params(64, 2, 2, 120)
+    for k, v in dict(optimizer='adam_inverse_sqrt,beta1=0.9,beta2=0.98,lr=0.0001', clip_grad_norm=5, amp=-1, fp16=False,
+                     accumulate_gradients=1, multi_gpu=False, local_rank=0, epoch_size=10, batch_size=2, is_master=True,
+                     dump_path=str(tmp_path), reload_checkpoint='', validation_metrics='valid_t2i_R1,_valid_loss',
+                     stopping_criterion='_valid_loss,1', save_periodic=2, langs=['en'], lambda_mlm='0:1,10:0',
+                     cross_rel_steps=[('coco', 'img')], cross_mlm_steps=[]).items():
+        setattr(P, k, v)
+    for k, v in over.items():
+        setattr(P, k, v)
+    m = TransformerModel(P, is_encoder=True, with_output=True, is_crossModal=True)
+    return XTrainer(m, {}, P), m, P
+
+
+def test_epoch_bookkeeping_checkpoints_and_early_stopping(tmp_path):
+    tr, m, P = _trainer(tmp_path)
+    assert tr.metrics == [('valid_t2i_R1', True), ('valid_loss', False)]
+    assert tr.best_metrics == {'valid_t2i_R1': -1e12, 'valid_loss': 1e12}
+    assert tr.stopping_criterion == ('valid_loss', False) and tr.decrease_counts_max == 1
+    assert P.lambda_mlm == 1.0 and P.lambda_mlm_config == [(0, 1.0), (10, 0.0)]
+    assert list(tr.stats)[:2] == ['processed_s', 'processed_w'] and 't2i-coco' in tr.stats and 'MLM-en' in tr.stats
+    tr.iter()
+    assert P.lambda_mlm == 0.9 and tr.n_iter == tr.n_total_iter == 1
+    # best-model saving: only metrics that improved
+    tr.save_best_model({'valid_t2i_R1': 10.0, 'valid_loss': 3.0})
+    files = sorted(os.listdir(str(tmp_path)))
+    assert files == ['best-valid_loss.pth', 'best-valid_t2i_R1.pth'] or set(files) >= {'best-valid_loss.pth', 'best-valid_t2i_R1.pth'}
+    t0 = os.path.getmtime(os.path.join(str(tmp_path), 'best-valid_t2i_R1.pth'))
+    tr.save_best_model({'valid_t2i_R1': 9.0, 'valid_loss': 2.0})
+    assert tr.best_metrics == {'valid_t2i_R1': 10.0, 'valid_loss': 2.0}
+    assert os.path.getmtime(os.path.join(str(tmp_path), 'best-valid_t2i_R1.pth')) == t0
+    ck = torch.load(os.path.join(str(tmp_path), 'best-valid_loss.pth'), map_location='cpu', weights_only=False)
+    assert {'model', 'model_optimizer', 'epoch', 'n_total_iter', 'best_metrics', 'best_stopping_criterion', 'params'} <= set(ck)
+    assert set(ck['model_optimizer']) == {'state', 'param_groups'} and ck['model_optimizer']['param_groups'][0]['num_updates'] == 0
+    assert len(ck['model_optimizer']['state']) == len(list(m.parameters()))
+    # periodic: epoch 0 % 2 == 0 -> saved
+    tr.save_periodic()
+    assert os.path.isfile(os.path.join(str(tmp_path), 'periodic-0.pth'))
+    # end_epoch: improvement, then two non-improvements -> SystemExit (patience 1)
+    tr.end_epoch({'valid_loss': 2.0})
+    assert tr.epoch == 1 and tr.best_stopping_criterion == 2.0 and os.path.isfile(os.path.join(str(tmp_path), 'checkpoint.pth'))
+    tr.end_epoch({'valid_loss': 2.5})
+    assert tr.epoch == 2 and tr.decrease_counts == 1
+    with pytest.raises(SystemExit):
+        tr.end_epoch({'valid_loss': 2.6})
+    # a new trainer on the same dump_path resumes (reload_checkpoint() in the constructor, xtrainer.py:133)
+    tr2, m2, _ = _trainer(tmp_path)
+    assert tr2.epoch == 2 and tr2.best_stopping_criterion == 2.0 and tr2.best_metrics['valid_loss'] == 2.0
+    # non-master ranks never write
+    tr3, _, P3 = _trainer(tmp_path / 'r1', is_master=False)
+    os.makedirs(str(tmp_path / 'r1'), exist_ok=True)
+    tr3.save_checkpoint('x'); tr3.save_periodic(); tr3.save_best_model({'valid_t2i_R1': 1.0, 'valid_loss': 0.1}); tr3.save_model('m')
+    assert os.listdir(str(tmp_path / 'r1')) == []
+
+
+def test_build_model_reload_backfills_and_strips_prefix(tmp_path):
+    from m3p_amd.model import build_model
+    from m3p_amd.model.transformer import TransformerModel
+    P = synth.model_params(64, 2, 2, 120)
+    src = TransformerModel(P, is_encoder=True, with_output=True, is_crossModal=True)
+    sd = {k: torch.randn_like(v) for k, v in src.state_dict().items()}
+    sd['pred_layer.proj.weight'] = sd['embeddings.weight']
+    dropped = [k for k in sd if k.startswith(('pooled_layer2.', 'seq_relationship2.'))]
+    assert dropped
+    saved = {'module.' + k: v for k, v in sd.items() if k not in dropped}
+    path = os.path.join(str(tmp_path), 'ckpt.pth')
+    torch.save({'model': saved, 'params': {}}, path)
+    P.encoder_only, P.is_cross_modal, P.reload_model, P.multi_reload_model, P.local_rank = True, True, path, '', 0
+    m = build_model(P)
+    got = {k: v.cpu() for k, v in m.state_dict().items()}
+    for k, v in sd.items():
+        if k not in dropped:
+            assert torch.equal(got[k], v), k
+    assert all(torch.isfinite(got[k]).all() for k in dropped)
+    # ensemble blend (model/__init__.py:106-122): 0.6 * main + 0.4 * mean(others)
+    other = {k: torch.randn_like(v) for k, v in sd.items()}
+    other['pred_layer.proj.weight'] = other['embeddings.weight']
+    p2 = os.path.join(str(tmp_path), 'other.pth')
+    torch.save({'model': other}, p2)
+    torch.save({'model': sd}, path)
+    P.multi_reload_model = p2
+    m = build_model(P)
+    k = 'attentions.0.q_lin.weight'
+    assert torch.allclose(m.state_dict()[k].cpu(), sd[k] * 0.6 + other[k] * 0.4, atol=1e-6)
