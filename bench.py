@@ -47,7 +47,7 @@ def build(cfg, dropout, world, rank, local_rank, refine_layers=0, ragged=False):
                      accumulate_gradients=1, multi_gpu=world > 1, local_rank=local_rank, epoch_size=100000,
                      cross_mlm_steps=[('google', 'img')], cross_mrm_steps=[], cross_mrfr_steps=[], cross_clcm_steps=[],
                      sample_n=2, refine_image=refine_layers > 0, multi_cls_loss_weight=0, bin_cls_loss_weight=1,
-                     batch_size=cfg['B'], dump_path='/tmp').items():
+                     batch_size=cfg['B'], dump_path='/nonexistent_m3p_dump').items():
         setattr(P, k, v)
     torch.manual_seed(1234)   # identical random-init weights on every rank (then broadcast anyway)
     model = TransformerModel(P, is_encoder=True, with_output=True, is_crossModal=True).cuda()

@@ -1,16 +1,23 @@
-"""Retrieval scoring on the MI355X model — the arithmetic of
-``evaluate_image_retrieval`` (M3P/src/evaluation/xevaluator.py:1528-1657): every image is
-scored against every caption with the cross-encoder (``jointfwd`` + ``predict(is_relation)``
-under ``no_grad``), Recall@{1,5,10} is read off the score matrix by top-k (:1621-1657).
-Differences from the reference, on purpose: the image is broadcast over a chunk of captions
-by indexing instead of ``repeat`` (:1563-1564), scores stay on the device, images can be
-sharded over ranks (the reference slices by ``local_rank``, dataset_finetune.py:1218-1219)."""
+"""Retrieval scoring on the MI355X model - the arithmetic of ``evaluate_image_retrieval``
+(M3P/src/evaluation/xevaluator.py:1528-1657): every image is scored against every caption with
+the cross-encoder (``jointfwd`` + ``predict(is_relation)`` under ``no_grad``), then
+Recall@{1,5,10} is read off the (n_img, n_cap) score matrix in both directions (:1621-1657).
+
+Differences from the reference, on purpose:
+  * the image broadcast is an index gather on the device: one encoder call covers a tile of
+    ``img_block`` images x ``chunk`` captions (the reference ``repeat``s one retrieval batch of
+    images over a caption split, :1563-1564, and loops in Python);
+  * scores stay on the device until the metric is read;
+  * images are sharded over ranks by stride (the reference slices the image list by
+    ``local_rank``, dataset_finetune.py:1218-1219) and the shards can be all-gathered.
+"""
 import torch
+import torch.distributed as dist
 
 
 @torch.no_grad()
-def relation_score_matrix(model, x, lengths, x_img, image_loc, chunk=64, rank=0, world=1):
-    """x (T, n_cap) int64, lengths (n_cap,), x_img (R, n_img, 2048), image_loc (R, n_img, 5).
+def relation_score_matrix(model, x, lengths, x_img, image_loc, chunk=256, img_block=4, rank=0, world=1, refine_image=False):
+    """x (T, n_cap) int64, lengths (n_cap,), x_img (R, n_img, 2048), image_loc (R, n_img, 5), all on the device.
     Returns (scores [n_img_local, n_cap] fp32, image indices of this rank)."""
     was_training = model.training
     model.eval()
@@ -19,24 +26,49 @@ def relation_score_matrix(model, x, lengths, x_img, image_loc, chunk=64, rank=0,
     R = x_img.shape[0]
     mine = torch.arange(rank, n_img, world, device=dev)
     out = torch.empty((mine.numel(), n_cap), dtype=torch.float32, device=dev)
-    img_len = torch.full((1,), R, dtype=torch.long, device=dev)
-    for row, i in enumerate(mine.tolist()):
+    for r0 in range(0, mine.numel(), img_block):
+        imgs = mine[r0:r0 + img_block]
+        ni = imgs.numel()
         for c0 in range(0, n_cap, chunk):
-            c1 = min(n_cap, c0 + chunk)
-            nb = c1 - c0
-            xi = x_img[:, i:i + 1].expand(R, nb, x_img.shape[2]).contiguous()
-            li = image_loc[:, i:i + 1].expand(R, nb, 5).contiguous()
-            enc = model('jointfwd', x=x[:, c0:c1].contiguous(), lengths=lengths[c0:c1], x_img=xi,
-                        lengths_img=img_len.expand(nb), causal=False, langs=None, image_loc=li, refine_image=False)
-            out[row, c0:c1] = model('predict', tensor=enc.transpose(0, 1), is_relation=True).view(-1).float()
+            nc = min(n_cap, c0 + chunk) - c0
+            # sequence j of the tile = (image j // nc, caption c0 + j % nc)
+            img_of = imgs.repeat_interleave(nc)
+            xi = x_img.index_select(1, img_of)
+            li = image_loc.index_select(1, img_of)
+            xt = x[:, c0:c0 + nc].repeat(1, ni)
+            lt = lengths[c0:c0 + nc].repeat(ni)
+            enc = model('jointfwd', x=xt, lengths=lt, x_img=xi, lengths_img=torch.full((ni * nc,), R, dtype=torch.long, device=dev),
+                        causal=False, langs=None, image_loc=li, refine_image=refine_image)
+            s = model('predict', tensor=enc.transpose(0, 1), is_relation=True)
+            out[r0:r0 + ni, c0:c0 + nc] = s.view(ni, nc).float()
     if was_training:
         model.train()
     return out, mine
 
 
+def gather_score_matrix(local_scores, mine, n_img, group=None):
+    """All ranks' shards -> the full (n_img, n_cap) matrix on every rank (shards are strided: image i lives on rank
+    i % world; short shards are padded to the longest for the collective)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return local_scores
+    n_cap = local_scores.shape[1]
+    per = (n_img + world - 1) // world
+    buf = torch.zeros((per, n_cap), dtype=local_scores.dtype, device=local_scores.device)
+    buf[:local_scores.shape[0]] = local_scores
+    parts = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(parts, buf, group=group)
+    full = torch.empty((n_img, n_cap), dtype=local_scores.dtype, device=local_scores.device)
+    for r in range(world):
+        idx = torch.arange(r, n_img, world, device=local_scores.device)
+        full[idx] = parts[r][:idx.numel()]
+    return full
+
+
 def recall_at_k(scores, gt, ks=(1, 5, 10)):
     """scores [n_query, n_cand]; gt[q] = index of the ground-truth candidate (or a bool mask
-    [n_query, n_cand] when several candidates are correct, e.g. 5 captions per image)."""
+    [n_query, n_cand] when several candidates are correct, e.g. 5 captions per image):
+    fraction of queries with a correct candidate among the K best."""
     order = torch.argsort(scores, dim=1, descending=True)
     if gt.dim() == 1:
         rank = (order == gt[:, None]).float().argmax(dim=1)
@@ -44,3 +76,23 @@ def recall_at_k(scores, gt, ks=(1, 5, 10)):
         hit = torch.gather(gt, 1, order)
         rank = hit.float().argmax(dim=1)
     return {k: float((rank < k).float().mean()) for k in ks}
+
+
+def retrieval_recalls(scores, labels):
+    """xevaluator.py:1621-1657 on an (n_img, n_cap) score matrix and its 0/1 label matrix, vectorised:
+    -> (t2i_r1, t2i_r5, t2i_r10, i2t_r1, i2t_r5, i2t_r10).  image -> sentence counts, per image, the first positive
+    among its 10 best captions; sentence -> image counts, per caption, every positive among its 10 best images (the
+    reference loop has no early exit there) and divides by the number of captions."""
+    n_img, n_cap = scores.shape
+    lab = labels.to(scores.device) == 1
+    out = []
+    # sentence -> image
+    top = scores.t().topk(min(10, n_img), dim=-1).indices            # (n_cap, 10) image ids
+    hit = torch.gather(lab.t(), 1, top)
+    out += [float(hit[:, :k].sum()) / n_cap for k in (1, 5, 10)]
+    # image -> sentence
+    top = scores.topk(min(10, n_cap), dim=-1).indices                # (n_img, 10) caption ids
+    hit = torch.gather(lab, 1, top)
+    first = torch.where(hit.any(dim=1), hit.float().argmax(dim=1), torch.full((n_img,), 10**6, device=scores.device))
+    out += [float((first < k).sum()) / n_img for k in (1, 5, 10)]
+    return tuple(out)

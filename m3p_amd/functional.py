@@ -372,7 +372,8 @@ class EncoderFn(torch.autograd.Function):
                                aux=x1, seed=seed('ffn', i), p_drop=p_drop)
             h_next, mean2, rstd2 = ops.layernorm_fwd(pre2, ar.p('layer_norm2.%d.weight' % i),
                                                      ar.p('layer_norm2.%d.bias' % i), rowmask)
-            saved_layers.append((h, qkv, ctxt, lse, pre1, mean1, rstd1, x1, u, hact, pre2, mean2, rstd2))
+            if track:      # (inference keeps nothing: retrieval evaluation runs thousands of sequences per call)
+                saved_layers.append((h, qkv, ctxt, lse, pre1, mean1, rstd1, x1, u, hact, pre2, mean2, rstd2))
             h = h_next
 
         ctx.model = model

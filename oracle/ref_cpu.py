@@ -423,3 +423,31 @@ def recall_at_k(score_matrix, gt_index, ks=(1, 5, 10)):
     order = torch.argsort(score_matrix, dim=1, descending=True)
     rank = (order == gt_index[:, None]).float().argmax(dim=1)
     return {k: float((rank < k).float().mean()) for k in ks}
+
+
+def retrieval_recalls(scores, labels):
+    """The metric arithmetic of evaluate_image_retrieval, xevaluator.py:1621-1657, as plain loops.
+    scores, labels: (n_img, n_cap); labels[i, c] == 1 where caption c describes image i.
+    image -> sentence: per image, the FIRST positive among its 10 best captions counts once at every K it falls under;
+    sentence -> image: per caption, every positive among its 10 best images counts (no early exit in the reference).
+    Returns (t2i_r1, t2i_r5, t2i_r10, i2t_r1, i2t_r5, i2t_r10): t2i divided by n_cap, i2t by n_img."""
+    n_img, n_cap = scores.shape
+    i2t = [0, 0, 0]
+    _, pred = scores.topk(min(10, n_cap), dim=-1)
+    for i in range(n_img):
+        for j, c in enumerate(pred[i].tolist()):
+            if labels[i][c] == 1:
+                for slot, k in enumerate((1, 5, 10)):
+                    if j < k:
+                        i2t[slot] += 1
+                break
+    t2i = [0, 0, 0]
+    st, lt = scores.t(), labels.t()
+    _, pred = st.topk(min(10, n_img), dim=-1)
+    for c in range(n_cap):
+        for j, i in enumerate(pred[c].tolist()):
+            if lt[c][i] == 1:
+                for slot, k in enumerate((1, 5, 10)):
+                    if j < k:
+                        t2i[slot] += 1
+    return tuple(v / n_cap for v in t2i) + tuple(v / n_img for v in i2t)

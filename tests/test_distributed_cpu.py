@@ -96,3 +96,189 @@ def test_reducer_single_process_is_noop():
     red.reduce_range(0, 10)
     red.finish()
     assert torch.equal(t, torch.arange(10, dtype=torch.float32))
+
+
+# ---- the DataParallel step protocol on a fake arena (gloo, CPU): what functional.py / optim.py call, in order ----
+class _FakeArena:
+    """Just the bookkeeping m3p_amd.distributed.DataParallel reads from functional.Arena."""
+
+    def __init__(self, V=50, d=8, n_layers=2):
+        from collections import OrderedDict
+        sizes = OrderedDict([('embeddings.weight', V * d), ('pred_layer.proj.bias', 64), ('position_embeddings.weight', 128)])
+        for i in range(n_layers):
+            sizes['layer%d' % i] = 192
+        sizes['pooled_layer.dense.weight'] = 64
+        self.offsets, off = OrderedDict(), 0
+        for k, n in sizes.items():
+            self.offsets[k] = (off, n, (n,))
+            off += n
+        self.total = off
+        self.device = torch.device('cpu')
+        self.master = torch.zeros(off)
+        self.grad = torch.zeros(off)
+        self.layer_ranges = [(self.offsets['layer%d' % i][0], self.offsets['layer%d' % i][0] + 192) for i in range(n_layers)]
+        self.embed_range = (0, self.layer_ranges[0][0])
+        self.head_range = (self.offsets['pooled_layer.dense.weight'][0], off)
+        self.V, self.d = V, d
+
+    def g(self, name):
+        o, n, _ = self.offsets[name]
+        return self.grad[o:o + n].view(self.V, self.d) if name == 'embeddings.weight' else self.grad[o:o + n]
+
+    def touch(self, *names):
+        pass
+
+    def mark_master_changed(self):
+        pass
+
+
+class _FakeModel(torch.nn.Module):
+    pad_index = 1
+
+    def __init__(self):
+        super().__init__()
+        self._arena = _FakeArena()
+        self.ddp_hook = None
+
+    def arena(self):
+        return self._arena
+
+
+def _cpu_scatter(rows, ids, dst, pad_index):
+    keep = ids != pad_index
+    dst.index_add_(0, ids[keep], rows[keep].float())
+
+
+def _protocol_worker(rank, world, port, q):
+    try:
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        torch.set_num_threads(1)
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        from m3p_amd import ops
+        from m3p_amd.distributed import DataParallel
+        ops.scatter_add_token_rows = _cpu_scatter
+        model = _FakeModel()
+        ar = model.arena()
+        ar.master.fill_(float(rank + 1))
+        dp = DataParallel(model)
+        assert float(ar.master[0]) == 1.0                       # broadcast from rank 0
+        results = {}
+
+        def fill(val):
+            ar.grad.fill_(val)
+
+        def tokens(n, seed):
+            g = torch.Generator().manual_seed(seed)
+            ids = torch.randint(0, ar.V, (n,), generator=g)
+            ids[0] = model.pad_index                            # a pad token: its row must be ignored
+            rows = torch.randn(n, ar.d, generator=g).to(torch.bfloat16)
+            return ids, rows
+
+        def expected_tokens(specs):
+            out = torch.zeros(ar.V, ar.d)
+            for n, seed in specs:
+                ids, rows = tokens(n, seed)
+                _cpu_scatter(rows, ids, out, model.pad_index)
+            return out
+
+        # --- step A: one encoder pass + MLM head, finish() called twice (clip, then step); ragged token counts
+        dp.plan_step(True)
+        n_loc = 5 + 2 * rank
+        n_max = dp.encoder_forward(n_loc)
+        assert n_max == 5 + 2 * (world - 1)
+        fill(1.0 + rank)
+        dp.mlm_head_done()
+        last = dp.encoder_backward_begin()
+        assert last
+        for i in (1, 0):
+            dp.layer_done(i, last)
+        ids, rows = tokens(n_loc, 100 + rank)
+        dp.embed_done(last, ids=ids, rows=rows, n_max=n_max)
+        dp.finish()
+        dp.finish()                                             # idempotent: nothing is reduced twice
+        tot = sum(1.0 + r for r in range(world))
+        want = torch.full_like(ar.grad, tot)
+        want[:ar.V * ar.d] += expected_tokens([(5 + 2 * r, 100 + r) for r in range(world)]).view(-1)
+        results['A'] = float((ar.grad - want).abs().max())
+        dp.step_done()
+
+        # --- step B: two encoder passes (CLCM): the first backward must not launch layer buckets
+        dp.plan_step(True)
+        nm1, nm2 = dp.encoder_forward(4), dp.encoder_forward(6)
+        fill(0.0)
+        assert not dp.encoder_backward_begin()                  # pass 2's backward comes first and is not the last
+        ar.grad[ar.layer_ranges[1][0]:ar.layer_ranges[1][1]] += 1.0 + rank
+        dp.layer_done(1, False)
+        assert not dp._launched, 'a non-final backward launched a bucket'
+        i2, r2 = tokens(6, 300 + rank)
+        dp.embed_done(False, ids=i2, rows=r2, n_max=nm2)
+        dp.mlm_head_done()
+        assert dp.encoder_backward_begin()
+        ar.grad[ar.layer_ranges[1][0]:ar.layer_ranges[1][1]] += 10.0
+        dp.layer_done(1, True)
+        dp.layer_done(0, True)
+        i1, r1 = tokens(4, 200 + rank)
+        dp.embed_done(True, ids=i1, rows=r1, n_max=nm1)
+        dp.finish()
+        want = torch.zeros_like(ar.grad)
+        want[ar.layer_ranges[1][0]:ar.layer_ranges[1][1]] = tot + 10.0 * world
+        want[:ar.V * ar.d] += expected_tokens([(6, 300 + r) for r in range(world)] + [(4, 200 + r) for r in range(world)]).view(-1)
+        results['B'] = float((ar.grad - want).abs().max())
+        dp.step_done()
+
+        # --- step C: gradient accumulation: a no_sync micro-step keeps its token rows for the boundary; no MLM head
+        dp.plan_step(False)
+        fill(0.0)
+        with dp.no_sync():
+            nm = dp.encoder_forward(3)
+            assert dp.encoder_backward_begin()
+            ar.grad[ar.layer_ranges[0][0]:ar.layer_ranges[0][1]] += 1.0
+            dp.layer_done(0, True)
+            ia, ra = tokens(3, 400 + rank)
+            dp.embed_done(True, ids=ia, rows=ra, n_max=nm)
+            dp.finish()                                         # disabled: must not mark the step finished
+        assert not dp._launched and len(dp._tokens) == 1
+        nm = dp.encoder_forward(3)
+        assert dp.encoder_backward_begin()
+        ar.grad[ar.layer_ranges[0][0]:ar.layer_ranges[0][1]] += 1.0
+        dp.layer_done(0, True)
+        ib, rb = tokens(3, 500 + rank)
+        dp.embed_done(True, ids=ib, rows=rb, n_max=nm)
+        dp.finish()
+        assert 'vocab' not in dp._launched                      # ITM-only step: the 768-MB bucket is never reduced
+        want = torch.zeros_like(ar.grad)
+        want[ar.layer_ranges[0][0]:ar.layer_ranges[0][1]] = 2.0 * world
+        want[:ar.V * ar.d] += expected_tokens([(3, 400 + r) for r in range(world)] + [(3, 500 + r) for r in range(world)]).view(-1)
+        results['C'] = float((ar.grad - want).abs().max())
+        dp.step_done()
+
+        # --- step D: no encoder backward at all (finish() owes every bucket)
+        dp.plan_step(True)
+        fill(2.0)
+        dp.finish()
+        results['D'] = float((ar.grad - 2.0 * world).abs().max())
+        if rank == 0:
+            q.put(('ok', results))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:
+        import traceback
+        if rank == 0:
+            q.put(('err', traceback.format_exc()))
+        raise
+
+
+def test_data_parallel_step_protocol_two_ranks():
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_protocol_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    status, res = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+    assert status == 'ok', res
+    for k, err in res.items():
+        assert err < 1e-5, (k, err)

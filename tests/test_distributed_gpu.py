@@ -1,9 +1,18 @@
-"""Data-parallel wrapper on the real model: two ranks (gloo, both on cuda:0 — one MI355X is
-all a test box has; RCCL itself is exercised by the driver's multi-GPU bench) each take half
-of a batch; the bucketed all-reduce scheduled from inside backward + 1/world in the optimizer
-must reproduce the single-process gradient of the whole batch, and parameters stay identical."""
+"""Data-parallel wrapper on the real model, driven through XTrainer like a training run: two
+ranks each take half of a batch and go through ``pretrain_under_step`` / ``t2i_step`` /
+``mlm_step_on_batch`` -> ``optimize`` (clip 5 + fused Adam).  Compared with ONE process running
+the whole batch:
+  * the reduced, averaged gradient arena the optimizer consumes (captured right before Adam -
+    Adam's normalisation would hide a gradient that is a constant factor too large),
+  * the clip norm, and the parameters after the steps;
+  * ranks end bit-identical.
+Scenarios: MLM + ITM; i2t with MRM + MRFR + CLCM (two encoder passes per step); gradient
+accumulation over 2 micro-steps; ITM fine-tuning (no dense vocabulary gradient); text MLM.
+Both ranks share cuda:0 over gloo (one MI355X is all a test box has); the same scenarios run
+over RCCL ('nccl') when at least two devices are visible."""
 import os
 import socket
+import traceback
 
 import pytest
 import torch
@@ -14,97 +23,177 @@ from m3p_amd import synth
 
 pytestmark = pytest.mark.gpu
 
+CFG = dict(emb_dim=128, n_heads=4, n_layers=2, n_words=1000, T=24, R=10, B=8, n_pred=4)
+
 
 def _free_port():
     s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close()
     return p
 
 
-def _half(batch, r, world):
-    B = batch['x'].shape[1]
-    per = B // world
-    sl = slice(r * per, (r + 1) * per)
-    out = {k: (v[:, sl].contiguous() if k in ('x', 'x_labels', 'pred_mask', 'x_img', 'image_loc') else v)
-           for k, v in batch.items()}
-    out['lengths'] = batch['lengths'][sl].contiguous()
-    out['lengths_img'] = batch['lengths_img'][sl].contiguous()
-    out['y'] = out['x_labels'][out['pred_mask']]
-    ng = per // 2
-    out['pos_labels'] = batch['pos_labels'][r * ng:(r + 1) * ng]
-    return out
+def _params(scenario, multi_gpu):
+    P = synth.model_params(CFG['emb_dim'], CFG['n_heads'], CFG['n_layers'], CFG['n_words'])
+    for k, v in dict(optimizer='adam_inverse_sqrt,beta1=0.9,beta2=0.98,lr=0.0001', clip_grad_norm=5, amp=1, fp16=True,
+                     accumulate_gradients=2 if scenario == 'accumulate' else 1, multi_gpu=multi_gpu, local_rank=0,
+                     epoch_size=1000, batch_size=CFG['B'], dump_path='/nonexistent_m3p_dump', is_master=True,
+                     cross_mlm_steps=[('google', 'img')], cross_rel_steps=[('google', 'img')],
+                     cross_mrm_steps=[('google', 'img')] if scenario == 'clcm' else [],
+                     cross_mrfr_steps=[('google', 'img')] if scenario == 'clcm' else [],
+                     cross_clcm_steps=[('google', 'img')] if scenario == 'clcm' else [],
+                     sample_n=2, refine_image=False, multi_cls_loss_weight=1 if scenario == 'finetune' else 0,
+                     bin_cls_loss_weight=1, langs=['en']).items():
+        setattr(P, k, v)
+    return P
 
 
-def _loss(m, batch, R):
-    dev = 'cuda'
-    out = m('jointfwd', x=batch['x'].to(dev), lengths=batch['lengths'].to(dev), x_img=batch['x_img'].to(dev),
-            lengths_img=batch['lengths_img'].to(dev), causal=False, langs=None, image_loc=batch['image_loc'].to(dev),
-            refine_image=False)
-    _, mlm = m('predict', tensor=out[R:], pred_mask=batch['pred_mask'].to(dev), y=batch['y'].to(dev), get_scores=False)
-    rel = m('predict', tensor=out.transpose(0, 1), is_relation=True)
-    onehot = torch.eye(2, device=dev)[batch['pos_labels'].to(dev)].reshape(-1)
-    return mlm + torch.nn.functional.binary_cross_entropy_with_logits(rel.view(-1).float(), onehot)
-
-
-def _build(cfg):
+def _build(scenario, multi_gpu):
     from m3p_amd.model.transformer import TransformerModel
-    P = synth.model_params(cfg['emb_dim'], cfg['n_heads'], cfg['n_layers'], cfg['n_words'])
+    from m3p_amd.trainer import XTrainer
+    P = _params(scenario, multi_gpu)
     m = TransformerModel(P, is_encoder=True, with_output=True, is_crossModal=True)
-    m.load_state_dict(synth.golden_state_dict(synth.hot_param_shapes(P)), strict=False)
-    return m.cuda().train()
+    sd = synth.golden_state_dict(synth.hot_param_shapes(P))
+    sd.update(synth.golden_state_dict(synth.region_head_param_shapes(P), seed=4321, pad_index=None))
+    sd.update(synth.golden_state_dict(synth.clcm_head_param_shapes(P), seed=9753, pad_index=None))
+    m.load_state_dict(sd, strict=False)
+    m = m.cuda()
+    return XTrainer(m, {}, P), m
 
 
-def _worker(rank, world, port, q):
+def _slice(full, extra, sl, ng):
+    """Columns ``sl`` of the synthetic batch as the tuples the collates emit."""
+    x, lab = full['x'][:, sl].contiguous(), full['x_labels'][:, sl].contiguous()
+    lens = full['lengths'][sl].contiguous()
+    img = full['x_img'][:, sl].transpose(0, 1).contiguous()
+    loc = full['image_loc'][:, sl].transpose(0, 1).contiguous()
+    n = x.shape[1]
+    mask = torch.ones(n, CFG['R'], dtype=torch.long)
+    pos = full['pos_labels'][ng].tolist()
+    obj = extra['obj_labels'][sl].contiguous()
+    ori = extra['ori_att_feats'][sl].contiguous()
+    t2i = ((x, lens, lab), (img, mask, loc, obj, pos, ori, list(range(n))))
+    x2, len2 = extra['x2'][:, sl].contiguous(), extra['len2'][sl].contiguous()
+    i2t = ((x, lens, lab), (x2, len2), (extra['clcm'][sl].contiguous(), img, mask, loc, obj, pos, ori, list(range(n))))
+    fin = ((x, lens, torch.zeros_like(x)), (img, mask, loc, obj, pos, list(range(n))))
+    text = (x, lens, full['pred_mask'][:, sl].contiguous(), lab[full['pred_mask'][:, sl]])
+    return dict(t2i=t2i, i2t=i2t, fin=fin, text=text)
+
+
+def _batches(step):
+    B = CFG['B']
+    full = synth.make_batch(CFG['T'], CFG['R'], B, CFG['n_words'], CFG['n_pred'], seed=11 + step, ragged=True)
+    other = synth.make_batch(CFG['T'], CFG['R'], B, CFG['n_words'], 0, seed=50 + step, ragged=True)
+    extra = synth.make_region_targets(CFG['R'], B, seed=77 + step)
+    extra['obj_labels'][B // 2, 1] = 3                       # a masked region on both halves
+    extra.update(x2=other['x'], len2=other['lengths'], clcm=torch.tensor([1, 0, 0, 1, 1, 0, 1, 0])[:B])
+    return full, extra
+
+
+def _run_step(tr, scenario, tup):
+    if scenario in ('pretrain', 'accumulate'):
+        tr.pretrain_under_step(tup['t2i'], 'google', 't2i', 'en', 1.0, 1.0, 1.0, 1.0)
+    elif scenario == 'clcm':
+        tr.pretrain_under_step(tup['i2t'], 'google', 'i2t', 'en', 1.0, 1.0, 1.0, 1.0)
+    elif scenario == 'finetune':
+        tr.t2i_step(tup['fin'], 'google', 1.0)
+    elif scenario == 'text':
+        tr.mlm_step_on_batch(*tup['text'], 'en', 1.0)
+    tr.n_iter += 1
+
+
+def _capture_grads(tr, m):
+    """Snapshot (averaged gradient arena, clip norm) every time the optimizer is about to step."""
+    opt = tr.optimizers['model']
+    snaps = []
+    inner = opt.step
+
+    def step(closure=None):
+        hook = m.ddp_hook
+        if hook is not None:
+            hook.finish()
+        torch.cuda.synchronize()
+        snaps.append(((m.arena().grad * opt.grad_scale).cpu(), opt.grad_norm()))
+        return inner(closure)
+    opt.step = step
+    return snaps
+
+
+N_STEPS = 2
+
+
+def _drive(scenario, world, rank):
+    tr, m = _build(scenario, world > 1)
+    snaps = _capture_grads(tr, m)
+    micro = 2 if scenario == 'accumulate' else 1
+    tr.n_iter = 1 if micro == 2 else 0                        # so that micro-steps go (non-boundary, boundary)
+    for step in range(N_STEPS * micro):
+        full, extra = _batches(step)
+        per = CFG['B'] // world
+        sl = slice(rank * per, (rank + 1) * per)
+        ng = slice(rank * per // 2, (rank + 1) * per // 2)
+        _run_step(tr, scenario, _slice(full, extra, sl, ng))
+    torch.cuda.synchronize()
+    return tr, m, snaps
+
+
+def _worker(rank, world, port, q, scenario, backend):
     try:
-        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-        torch.cuda.set_device(0)
-        dist.init_process_group('gloo', rank=rank, world_size=world)
-        from m3p_amd.distributed import DataParallel
-        from m3p_amd.optim import get_optimizer
-        cfg = dict(emb_dim=128, n_heads=4, n_layers=2, n_words=1000, T=24, R=10, B=8, n_pred=4)
-        full = synth.make_batch(cfg['T'], cfg['R'], cfg['B'], cfg['n_words'], cfg['n_pred'], seed=11, ragged=False)
-        m = _build(cfg)
-        ddp = DataParallel(m)
-        opt = get_optimizer([p for p in m.parameters()], 'adam_inverse_sqrt,beta1=0.9,beta2=0.98,lr=0.0001')
-        opt.grad_scale = 1.0 / world
-        loss = _loss(ddp, _half(full, rank, world), cfg['R'])
-        loss.backward()
-        ddp.finish()
-        torch.cuda.synchronize()
-        g = (m.arena().grad / world).cpu()
-        opt.clip_grad_norm(5.0)
-        opt.step()
-        torch.cuda.synchronize()
-        pm = m.arena().master.cpu()
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                          HSA_ENABLE_IPC_MODE_LEGACY='0')
+        torch.cuda.set_device(rank if backend == 'nccl' else 0)
+        dist.init_process_group(backend, rank=rank, world_size=world)
+        tr, m, snaps = _drive(scenario, world, rank)
+        pm = m.arena().master.clone()
         gathered = [torch.zeros_like(pm) for _ in range(world)]
         dist.all_gather(gathered, pm)
         same = all(torch.equal(gathered[0], t) for t in gathered)
+        leftover = float(m.arena().grad.abs().max())
+        launched_vocab = 'vocab' in tr.model._launched or scenario != 'finetune'
         if rank == 0:
-            ref = _build(cfg)
-            _loss(ref, full, cfg['R']).backward()
-            torch.cuda.synchronize()
-            gr = ref.arena().grad.cpu()
-            err = float((g - gr).norm() / gr.norm())
-            q.put(('ok', err, same, float(m.arena().grad.abs().max())))
+            q.put(('ok', [(g, n) for g, n in snaps], pm.cpu(), same, leftover, launched_vocab))
         dist.barrier()
         dist.destroy_process_group()
-    except Exception as e:   # surface the reason to the parent
+    except Exception:
         if rank == 0:
-            q.put(('err', repr(e), False, 0.0))
+            q.put(('err', traceback.format_exc(), None, False, 0.0, False))
         raise
 
 
-def test_dp_two_ranks_match_single_process():
+def _check(scenario, backend):
     world = 2
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, scenario, backend)) for r in range(world)]
     for p in procs:
         p.start()
-    status, err, same, gmax = q.get(timeout=300)
+    status, snaps, pm, same, leftover, _ = q.get(timeout=600)
     for p in procs:
         p.join(timeout=120)
-    assert status == 'ok', err
-    assert err < 2e-2, err
+    assert status == 'ok', snaps
     assert same, 'parameters diverged across ranks'
-    assert gmax == 0.0      # fused zero_grad
+    assert leftover == 0.0, 'gradient arena not zeroed by the fused step'
+    tr, m, ref = _drive(scenario, 1, 0)
+    assert len(snaps) == len(ref) == N_STEPS
+    off = m.arena().offsets
+    v0, v1 = off['embeddings.weight'][0], off['embeddings.weight'][0] + off['embeddings.weight'][1]
+    for i, ((g, n), (gr, nr)) in enumerate(zip(snaps, ref)):
+        err = float((g - gr).norm() / gr.norm())
+        err_vocab = float((g[v0:v1] - gr[v0:v1]).norm() / gr[v0:v1].norm())
+        assert err < 2e-2, (scenario, i, err)
+        assert err_vocab < 2e-2, (scenario, i, err_vocab)     # the tied matrix: dense head part + exchanged token rows
+        assert abs(n - nr) / nr < 1e-2, (scenario, i, n, nr)
+    lr_sum = sum(tr.optimizers['model'].get_lr_for_step(k) for k in range(N_STEPS))
+    diff = float((pm - m.arena().master.cpu()).abs().max())
+    assert diff <= 2.5 * lr_sum, (scenario, diff, lr_sum)    # Adam moves every weight by <= ~lr per step
+
+
+@pytest.mark.parametrize('scenario', ['pretrain', 'clcm', 'accumulate', 'finetune', 'text'])
+def test_dp_two_ranks_match_single_process(scenario):
+    _check(scenario, 'gloo')
+
+
+@pytest.mark.parametrize('scenario', ['pretrain', 'clcm'])
+def test_dp_two_ranks_over_rccl(scenario):
+    if torch.cuda.device_count() < 2:
+        pytest.skip('RCCL needs two devices (the driver\'s multi-GPU bench exercises it)')
+    _check(scenario, 'nccl')

@@ -32,9 +32,12 @@ def _losses(m, batch, R, sl, sample_n=2):
     return out, mlm, bce
 
 
-def test_cfg2_full_size_batch_split_identity():
+@pytest.mark.parametrize('B', [256, 1024])
+def test_cfg2_full_size_batch_split_identity(B):
+    """B = 256: BASELINE configs[1].  B = 1024: the per-GPU share of configs[2] (global batch 8192 over 8 MI355X)."""
     from m3p_amd.model.transformer import TransformerModel
-    cfg = synth.CONFIGS['cfg2']
+    cfg = dict(synth.CONFIGS['cfg2'])
+    cfg['B'] = B
     P = synth.model_params(cfg['emb_dim'], cfg['n_heads'], cfg['n_layers'], cfg['n_words'], dropout=0.0, attention_dropout=0.0)
     torch.manual_seed(1234)
     m = TransformerModel(P, is_encoder=True, with_output=True, is_crossModal=True).cuda()

@@ -214,3 +214,50 @@ def test_gemm_nn_streamk(M, N, K, kv):
         ref = 1.0 + 0.5 * (ac[:, :kv].double() @ wc[:, :N].double())
         assert rel_l2(out, ref) < 1e-5
 
+
+
+def _ref_on_gpu(a, w):
+    """fp32 product of the bf16 operands with PyTorch on the device (the checker at sizes a CPU product takes minutes)."""
+    return a.float() @ w.float().t()
+
+
+@pytest.mark.parametrize('M', [41984, 167936])       # B = 256 (configs[1]) and B = 1024 (per-GPU share of configs[2]) x S = 164
+@pytest.mark.parametrize('N,K', [(2304, 768), (768, 768), (3072, 768), (768, 3072)])
+def test_gemm_nt_at_the_benchmarked_sizes(M, N, K):
+    """The persistent four-wave / ring kernels at the exact (M, N, K) the cfg2 step launches them with, every epilogue
+    the layer uses, against a plain fp32 product: the per-kernel parity shapes above stop at M = 4100."""
+    from m3p_amd import ops, lib as L
+    if M > 41984 and (N, K) != (3072, 768):
+        pytest.skip('one shape at the 1024-sequence row count')
+    g = torch.Generator(device='cuda').manual_seed(M + N)
+    a = (torch.randn((M, K), device='cuda', generator=g)).to(torch.bfloat16)
+    w = (torch.randn((N, K), device='cuda', generator=g) * 0.05).to(torch.bfloat16)
+    r = (torch.randn((M, N), device='cuda', generator=g)).to(torch.bfloat16)
+    bias = torch.randn((N,), device='cuda', generator=g)
+    ref = _ref_on_gpu(a, w)
+    c = ops.gemm_nt(a, w, L.EPI_BIAS, bias=bias)
+    assert rel_l2(c.float(), ref + bias) < 4e-3
+    c = ops.gemm_nt(a, w, L.EPI_RES, aux=r)
+    assert rel_l2(c.float(), ref + r.float()) < 4e-3
+    c = ops.gemm_nt(a, w, L.EPI_BIAS_DROP_RES, bias=bias, aux=r, seed=5, p_drop=0.0)
+    assert rel_l2(c.float(), ref + bias + r.float()) < 4e-3
+    cs = torch.zeros(N, device='cuda')
+    c = ops.gemm_nt(a, w, L.EPI_DGELU, aux=r, colsum=cs)
+    x = r.float()
+    dg = 0.5 * (1 + torch.erf(x / math.sqrt(2))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi)
+    assert rel_l2(c.float(), ref * dg) < 6e-3
+    assert rel_l2(cs, (ref * dg).sum(0)) < 2e-2
+    del c, ref
+
+
+@pytest.mark.parametrize('N,K', [(2304, 768), (768, 768), (3072, 768), (768, 3072)])
+def test_gemm_wgrad_at_the_benchmarked_sizes(N, K):
+    from m3p_amd import ops
+    M = 41984
+    g = torch.Generator(device='cuda').manual_seed(N + K)
+    dy = (torch.randn((M, N), device='cuda', generator=g) * 0.1).to(torch.bfloat16)
+    x = torch.randn((M, K), device='cuda', generator=g).to(torch.bfloat16)
+    dw = torch.ones((N, K), device='cuda')
+    ops.gemm_wgrad(dy, x, dw)
+    ref = dy.float().t() @ x.float() + 1.0
+    assert rel_l2(dw, ref) < 2e-3

@@ -9,7 +9,7 @@ import pytest
 import torch
 
 from m3p_amd import synth
-from tests.util import rel_l2, max_abs
+from tests.util import encoder_keep_masks, rel_l2, max_abs
 
 pytestmark = pytest.mark.gpu
 
@@ -118,7 +118,7 @@ def test_three_training_steps_track_golden(golden_dir):
     for k, v in dict(optimizer='adam_inverse_sqrt,beta1=0.9,beta2=0.98,lr=0.0001', clip_grad_norm=5, amp=-1, fp16=False,
                      accumulate_gradients=1, multi_gpu=False, epoch_size=100, cross_mlm_steps=[('google', 'img')],
                      cross_mrm_steps=[], cross_mrfr_steps=[], cross_clcm_steps=[], sample_n=2, refine_image=False,
-                     multi_cls_loss_weight=0, bin_cls_loss_weight=1, batch_size=cfg['B'], dump_path='/tmp').items():
+                     multi_cls_loss_weight=0, bin_cls_loss_weight=1, batch_size=cfg['B'], dump_path='/nonexistent_m3p_dump').items():
         setattr(P, k, v)
     tr = XTrainer(m, {}, P)
     batch = synth.make_batch(cfg['T'], cfg['R'], cfg['B'], cfg['n_words'], cfg['n_pred'])
@@ -142,6 +142,50 @@ def test_three_training_steps_track_golden(golden_dir):
     assert float(m.arena().grad.abs().max()) == 0.0
     # bf16 working copies follow the master weights
     assert torch.equal(m.arena().w('ffns.0.lin1.weight'), after['ffns.0.lin1.weight'].to(torch.bfloat16))
+
+
+@pytest.mark.parametrize('cfg_name', ['cfg1', 'mid'])
+def test_dropout_on_training_step_vs_oracle_fed_the_same_masks(cfg_name):
+    """The benchmarked configuration (dropout = attention_dropout = 0.1) end to end: every dropout site of the
+    encoder (image rows, embedding, attention probabilities, attention output, FFN output, per layer) draws its keep
+    mask from the counter-based hash keyed by functional._site(); the oracle is handed those very masks (NumPy twin of
+    the device RNG), so output, losses and every gradient are compared element-wise with dropout switched on -
+    same bars as the dropout-free parity tests."""
+    from oracle import ref_cpu as O
+    cfg = {'cfg1': synth.CONFIGS['cfg1'],
+           'mid': dict(emb_dim=768, n_heads=12, n_layers=2, n_words=5000, T=40, R=36, B=6, n_pred=6)}[cfg_name]
+    p = 0.1
+    m, P, sd = _build(cfg, dropout=p)
+    m.train()
+    batch = synth.make_batch(cfg['T'], cfg['R'], cfg['B'], cfg['n_words'], cfg['n_pred'], seed=7)
+    m.arena().zero_grad()
+    out, mlm, rel, bce = _losses(m, batch, cfg['R'])
+    (mlm + bce).backward()
+    torch.cuda.synchronize()
+    keeps = encoder_keep_masks(m, m._fwd_counter, cfg['B'], cfg['T'], cfg['R'], p, p)
+    frac = float(keeps['emb'].float().mean())
+    assert abs(frac - (1 - p)) < 2e-2
+    names = list(sd.keys())
+    leaves = {n: sd[n].clone().requires_grad_(True) for n in names}
+    res = O.pretrain_losses(leaves, cfg['n_layers'], cfg['n_heads'], batch, cfg['R'], dropout=p, attention_dropout=p, keeps=keeps)
+    grads = dict(zip(names, torch.autograd.grad(res['total'], [leaves[n] for n in names])))
+    assert rel_l2(out.float(), res['out']) < 1e-2
+    assert abs(float(mlm) - float(res['mlm'])) < 5e-3 and abs(float(bce) - float(res['itm'])) < 5e-3
+    # and it is not the dropout-free result
+    res0 = O.pretrain_losses(sd, cfg['n_layers'], cfg['n_heads'], batch, cfg['R'])
+    assert rel_l2(out.float(), res0['out']) > 5e-2
+    own = dict(m.named_parameters())
+    qb = float(grads['attentions.0.q_lin.bias'].norm())
+    bad = []
+    for n in names:
+        gm = own[n].grad
+        if '.k_lin.bias' in n:
+            assert float(gm.norm()) < 5e-2 * qb + 1e-6, n
+            continue
+        err = rel_l2(gm, grads[n])
+        if err > 5e-2:
+            bad.append((n, err))
+    assert not bad, bad
 
 
 def test_dropout_training_step_runs_and_is_reproducible():
@@ -173,7 +217,7 @@ def test_gradient_accumulation_equals_the_full_batch_step():
         for k, v in dict(optimizer='adam_inverse_sqrt,beta1=0.9,beta2=0.98,lr=0.0001', clip_grad_norm=5, amp=1, fp16=True,
                          accumulate_gradients=accumulate, multi_gpu=False, epoch_size=100, cross_mlm_steps=[('google', 'img')],
                          cross_mrm_steps=[], cross_mrfr_steps=[], cross_clcm_steps=[], sample_n=2, refine_image=False,
-                         multi_cls_loss_weight=0, bin_cls_loss_weight=1, batch_size=cfg['B'], dump_path='/tmp').items():
+                         multi_cls_loss_weight=0, bin_cls_loss_weight=1, batch_size=cfg['B'], dump_path='/nonexistent_m3p_dump').items():
             setattr(P, k, v)
         return XTrainer(m, {}, P), m
 

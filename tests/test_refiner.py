@@ -202,7 +202,7 @@ def test_pretrain_under_step_with_refine_image_trains_the_refiner():
                          accumulate_gradients=1, multi_gpu=False, local_rank=0, epoch_size=100000,
                          cross_mlm_steps=[('google', 'img')], cross_mrm_steps=[], cross_mrfr_steps=[], cross_clcm_steps=[],
                          sample_n=2, refine_image=True, multi_cls_loss_weight=0, bin_cls_loss_weight=1,
-                         batch_size=cfg['B'], dump_path='/tmp').items():
+                         batch_size=cfg['B'], dump_path='/nonexistent_m3p_dump').items():
             setattr(P, k, v)
         torch.manual_seed(1234)
         model = TransformerModel(P, is_encoder=True, with_output=True, is_crossModal=True).cuda()

@@ -62,7 +62,7 @@ def test_pretrain_step_with_mrm_and_mrfr_matches_oracle():
                      accumulate_gradients=1, multi_gpu=False, epoch_size=100, cross_mlm_steps=[('google', 'img')],
                      cross_mrm_steps=[('google', 'img')], cross_mrfr_steps=[('google', 'img')], cross_clcm_steps=[], sample_n=2,
                      refine_image=False, multi_cls_loss_weight=0, bin_cls_loss_weight=1, batch_size=cfg['B'],
-                     dump_path='/tmp').items():
+                     dump_path='/nonexistent_m3p_dump').items():
         setattr(P, k, v)
     trainer = XTrainer(m, {}, P)
     B, R = cfg['B'], cfg['R']
@@ -135,7 +135,7 @@ def test_i2t_pretrain_step_with_clcm_matches_oracle():
                      accumulate_gradients=1, multi_gpu=False, epoch_size=100, cross_mlm_steps=[('google', 'img')],
                      cross_mrm_steps=[], cross_mrfr_steps=[], cross_clcm_steps=[('google', 'img')], sample_n=2,
                      refine_image=False, multi_cls_loss_weight=0, bin_cls_loss_weight=1, batch_size=cfg['B'],
-                     dump_path='/tmp').items():
+                     dump_path='/nonexistent_m3p_dump').items():
         setattr(P, k, v)
     trainer = XTrainer(m, {}, P)
     B, R = cfg['B'], cfg['R']

@@ -46,7 +46,7 @@ def test_mlm_step_on_batch_and_rel_steps(golden_dir):
     extra = dict(optimizer='adam_inverse_sqrt,beta1=0.9,beta2=0.98,lr=0.0001', clip_grad_norm=5, amp=-1, fp16=False,
                  accumulate_gradients=1, multi_gpu=False, epoch_size=100, cross_mlm_steps=[], cross_mrm_steps=[],
                  cross_mrfr_steps=[], cross_clcm_steps=[], sample_n=4, refine_image=False, multi_cls_loss_weight=1,
-                 bin_cls_loss_weight=1, batch_size=cfg['B'], dump_path='/tmp')
+                 bin_cls_loss_weight=1, batch_size=cfg['B'], dump_path='/nonexistent_m3p_dump')
     m, P, sd = _build(cfg, extra)
     tr = XTrainer(m, {}, P)
     batch = synth.make_batch(cfg['T'], cfg['R'], cfg['B'], cfg['n_words'], cfg['n_pred'])
@@ -61,7 +61,9 @@ def test_mlm_step_on_batch_and_rel_steps(golden_dir):
     img = batch['x_img'].transpose(0, 1).contiguous()
     loc = batch['image_loc'].transpose(0, 1).contiguous()
     pos = g['rel4_pos'].tolist()
-    tup = ((batch['x'], batch['lengths']), (img, torch.ones(B, R, dtype=torch.long), loc, pos))
+    # the tuple retrieval_collate emits (xtrainer.py:1897): (sent, lengths, langs), (img, mask, loc, obj, pos, ids)
+    tup = ((batch['x'], batch['lengths'], torch.zeros_like(batch['x'])),
+           (img, torch.ones(B, R, dtype=torch.long), loc, torch.full((B, R), -1), pos, list(range(B))))
     loss = tr2.t2i_step(tup, 'coco', 1.0)
     assert abs(float(loss) - (float(g['rel4_ce']) + float(g['rel4_bce']))) < 1e-2
     assert tr2.stats['processed_s'] == B
@@ -82,7 +84,8 @@ def test_retrieval_scores_and_recall_vs_oracle():
     n_cap = n_img * per
     b = synth.make_batch(cfg['T'], cfg['R'], n_cap, cfg['n_words'], 0, seed=21)
     bi = synth.make_batch(cfg['T'], cfg['R'], n_img, cfg['n_words'], 0, seed=22)
-    scores, mine = E.relation_score_matrix(m, b['x'].cuda(), b['lengths'].cuda(), bi['x_img'].cuda(), bi['image_loc'].cuda(), chunk=5)
+    scores, mine = E.relation_score_matrix(m, b['x'].cuda(), b['lengths'].cuda(), bi['x_img'].cuda(), bi['image_loc'].cuda(),
+                                           chunk=5, img_block=4)
     assert scores.shape == (n_img, n_cap) and mine.tolist() == list(range(n_img))
     ref = torch.empty(n_img, n_cap)
     for i in range(n_img):
@@ -103,4 +106,191 @@ def test_retrieval_scores_and_recall_vs_oracle():
     assert top1_same >= 0.8 and abs(r_hip[5] - r_ref[5]) <= 1.0 / n_img + 1e-9
     # sharded scoring (rank 1 of 2) covers the complementary images
     s1, mine1 = E.relation_score_matrix(m, b['x'].cuda(), b['lengths'].cuda(), bi['x_img'].cuda(), bi['image_loc'].cuda(), chunk=12, rank=1, world=2)
-    assert mine1.tolist() == [1, 3, 5] and max_abs(s1, scores[mine1]) < 1e-6
+    assert mine1.tolist() == [1, 3, 5] and max_abs(s1, scores[mine1]) < 2e-2     # other tiling: bf16 noise only
+    # both-direction metric of the evaluator (xevaluator.py:1621-1657): vectorised == the oracle's loops, exactly
+    assert E.retrieval_recalls(scores, gt.float()) == O.retrieval_recalls(scores.cpu(), gt.float())
+    assert E.retrieval_recalls(ref.cuda(), gt.float()) == O.retrieval_recalls(ref, gt.float())
+
+
+def _rel_params(cfg, sample_n):
+    return dict(optimizer='adam_inverse_sqrt,beta1=0.9,beta2=0.98,lr=0.0001', clip_grad_norm=5, amp=1, fp16=True,
+                accumulate_gradients=1, multi_gpu=False, epoch_size=100, cross_mlm_steps=[], cross_mrm_steps=[],
+                cross_mrfr_steps=[], cross_clcm_steps=[], sample_n=sample_n, refine_image=False, multi_cls_loss_weight=1,
+                bin_cls_loss_weight=1, batch_size=cfg['B'] // sample_n, dump_path='/nonexistent_m3p_dump')
+
+
+def _rel_tuple(batch, sl, R, pos):
+    n = sl.stop - sl.start
+    x = batch['x'][:, sl].contiguous()
+    return ((x, batch['lengths'][sl].contiguous(), torch.zeros_like(x)),
+            (batch['x_img'][:, sl].transpose(0, 1).contiguous(), torch.ones(n, R, dtype=torch.long),
+             batch['image_loc'][:, sl].transpose(0, 1).contiguous(), torch.full((n, R), -1), pos, list(range(n))))
+
+
+def test_cfg5_geometry_finetune_steps_vs_oracle():
+    """BASELINE configs[4] geometry (768d / 12 heads, 80 tokens + 36 regions, groups of sample_n = 4) at two layers and a
+    small vocabulary, where the oracle runs in seconds: t2i_step / i2t_step losses (CE over groups + BCE) and the
+    gradients the step feeds the optimizer, against the oracle."""
+    from m3p_amd.trainer import XTrainer
+    from oracle import ref_cpu as O
+    cfg = dict(emb_dim=768, n_heads=12, n_layers=2, n_words=5000, T=80, R=36, B=8, n_pred=0)
+    m, P, sd = _build(cfg, _rel_params(cfg, 4))
+    tr = XTrainer(m, {}, P)
+    batch = synth.make_batch(cfg['T'], cfg['R'], cfg['B'], cfg['n_words'], 0, seed=5, ragged=True)
+    pos = [3, 1]
+    grads = {}
+    opt = tr.optimizers['model']
+    inner = opt.step
+
+    def step(closure=None):
+        torch.cuda.synchronize()
+        grads.update({n: p.grad.detach().float().cpu().clone() for n, p in m.named_parameters() if getattr(p, '_m3p_arena', None)})
+        return inner(closure)
+    opt.step = step
+    loss = tr.i2t_step(_rel_tuple(batch, slice(0, cfg['B']), cfg['R'], pos), 'flicker', 1.0)
+    names = list(sd.keys())
+    leaves = {n: sd[n].clone().requires_grad_(True) for n in names}
+    batch['pos_labels'] = torch.tensor(pos)
+    batch['pred_mask'] = torch.zeros_like(batch['x'], dtype=torch.bool)
+    res = O.pretrain_losses(leaves, cfg['n_layers'], cfg['n_heads'], batch, cfg['R'], sample_n=4, multi_w=1.0, bin_w=1.0)
+    assert abs(float(loss) - float(res['itm'])) < 5e-3
+    used = [n for n in names if n not in ('pred_layer.proj.bias',)]
+    gref = dict(zip(used, torch.autograd.grad(res['total'], [leaves[n] for n in used], allow_unused=True)))
+    qb = float(gref['attentions.0.q_lin.bias'].norm())
+    bad = []
+    for n in used:
+        if gref[n] is None:
+            continue
+        if '.k_lin.bias' in n:
+            assert float(grads[n].norm()) < 5e-2 * qb + 1e-6, n
+        elif rel_l2(grads[n], gref[n]) > 5e-2:
+            bad.append((n, rel_l2(grads[n], gref[n])))
+    assert not bad, bad
+    assert tr.stats['processed_s'] == cfg['B'] and tr.stats['processed_w'] == cfg['B'] * (cfg['T'] + cfg['R'])
+
+
+def test_cfg5_full_size_finetune_step_properties():
+    """configs[4] at its workload: 12L / 768d / V = 250 002, 80 + 36, 24 items x sample_n 4 = 96 sequences per step.
+    The oracle cannot run this in seconds; size-independent properties instead: the 96-sequence relation loss and its
+    gradients are the average of the two 48-sequence halves (12 groups each); the first step's loss is the loss of a
+    near-uniform guess, ln 4 + ln 2-ish; three optimizer steps stay finite and lower the loss on the same batch."""
+    import math
+    from m3p_amd.model.transformer import TransformerModel
+    from m3p_amd.trainer import XTrainer
+    cfg = synth.CONFIGS['cfg5']
+    P = synth.model_params(cfg['emb_dim'], cfg['n_heads'], cfg['n_layers'], cfg['n_words'])
+    for k, v in _rel_params(cfg, 4).items():
+        setattr(P, k, v)
+    torch.manual_seed(1234)
+    m = TransformerModel(P, is_encoder=True, with_output=True, is_crossModal=True).cuda()
+    tr = XTrainer(m, {}, P)
+    B, R = cfg['B'], cfg['R']
+    batch = synth.make_batch(cfg['T'], R, B, cfg['n_words'], 0, seed=9, ragged=True)
+    pos = [int(v) for v in np.random.RandomState(3).randint(0, 4, size=B // 4)]
+    names = ['attentions.0.q_lin.weight', 'attentions.11.out_lin.weight', 'ffns.5.lin1.weight', 'ffns.11.lin2.bias',
+             'layer_norm2.7.weight', 'image_embeddings.image_embeddings.weight', 'pooled_layer.dense.weight',
+             'seq_relationship.weight', 'position_embeddings.weight']
+    own = dict(m.named_parameters())
+    tr.params.clip_grad_norm = 0
+
+    def grads_of(sl, pos_sl):
+        m.arena().zero_grad()
+        tr.n_iter = 1
+        tr.params.accumulate_gradients = 2           # non-boundary micro-step: backward only, nothing moves
+        loss = tr.t2i_step(_rel_tuple(batch, sl, R, pos_sl), 'flicker', 1.0)
+        torch.cuda.synchronize()
+        return float(loss), {n: own[n].grad.detach().float().clone() for n in names}
+
+    full, g = grads_of(slice(0, B), pos)
+    la, ga = grads_of(slice(0, B // 2), pos[:B // 8])
+    lb, gb = grads_of(slice(B // 2, B), pos[B // 8:])
+    assert abs(0.5 * (la + lb) - full) < 2e-3
+    assert 0.8 * (math.log(4) + math.log(2)) < full < 1.6 * (math.log(4) + math.log(2)), full
+    bad = [(n, rel_l2(0.5 * (ga[n] + gb[n]), g[n])) for n in names]
+    bad = [(n, e) for n, e in bad if e > 2e-2]
+    assert not bad, bad
+    # real steps
+    m.arena().zero_grad()
+    tr.params.accumulate_gradients, tr.params.clip_grad_norm, tr.n_iter = 1, 5, 0
+    for g_ in tr.optimizers['model'].param_groups:
+        g_['lr'] = 2e-5
+    losses = []
+    for _ in range(4):
+        losses.append(float(tr.i2t_step(_rel_tuple(batch, slice(0, B), R, pos), 'flicker', 1.0)))
+        for g_ in tr.optimizers['model'].param_groups:
+            g_['lr'] = 2e-5
+        tr.n_iter += 1
+    assert all(math.isfinite(v) for v in losses) and losses[-1] < losses[0], losses
+    assert torch.isfinite(m.arena().master).all()
+
+
+def test_cfg5_retrieval_1000x5_shard_and_oracle_subset():
+    """Retrieval evaluation at configs[4] scale (xevaluator.py:1528-1657): a synthetic Multi30K-shaped test set of 1000
+    images x 5 captions, T = 80, R = 36, on the 12L / 768d / V = 250 002 model.  One image shard of the exhaustive
+    1000 x 5000 scoring (stride sharding, as 25 ranks would split it: 40 images x 5000 captions = 200 000 encoder
+    passes) is scored on the MI355X; the metric read off it equals the oracle's metric loops on the same matrix
+    exactly, in both directions; and on a sub-block the CPU oracle can score (the full 12 layers), scores agree within
+    the bf16 bar, every query whose oracle margin exceeds twice that bar has the identical top-1, and Recall@1 of
+    the two sub-blocks differs by no more than the near-tie queries."""
+    from m3p_amd import evaluation as E
+    from m3p_amd.model.transformer import TransformerModel
+    from oracle import ref_cpu as O
+    cfg = synth.CONFIGS['cfg5']
+    n_img, per = 1000, 5
+    n_cap = n_img * per
+    P = synth.model_params(cfg['emb_dim'], cfg['n_heads'], cfg['n_layers'], cfg['n_words'])
+    m = TransformerModel(P, is_encoder=True, with_output=True, is_crossModal=True)
+    sd = synth.golden_state_dict(synth.hot_param_shapes(P), scale=0.05)
+    m.load_state_dict(sd, strict=False)
+    m = m.cuda()
+    rs = np.random.RandomState(2024)
+    T, R = cfg['T'], cfg['R']
+    lengths = torch.from_numpy(rs.randint(8, T + 1, size=n_cap).astype(np.int64))
+    lengths[0] = T
+    x = torch.full((T, n_cap), synth.PAD, dtype=torch.long)
+    toks = torch.from_numpy(rs.randint(4, cfg['n_words'] - 1, size=(T, n_cap)).astype(np.int64))
+    alive = torch.arange(T)[:, None] < lengths[None, :]
+    x[alive] = toks[alive]
+    x[0] = synth.BOS
+    x[lengths - 1, torch.arange(n_cap)] = synth.EOS
+    feats = rs.standard_normal((R, n_img, 2048)).astype(np.float32)
+    feats /= np.linalg.norm(feats, axis=-1, keepdims=True)
+    loc = rs.uniform(size=(R, n_img, 5)).astype(np.float32)
+    loc /= np.linalg.norm(loc, axis=-1, keepdims=True)
+    x_img, image_loc = torch.from_numpy(feats), torch.from_numpy(loc)
+    labels = torch.zeros(n_img, n_cap)
+    for i in range(n_img):
+        labels[i, i * per:(i + 1) * per] = 1
+    world, rank = 25, 3
+    scores, mine = E.relation_score_matrix(m, x.cuda(), lengths.cuda(), x_img.cuda(), image_loc.cuda(), chunk=500, img_block=4,
+                                           rank=rank, world=world)
+    torch.cuda.synchronize()
+    assert scores.shape == (n_img // world, n_cap) and mine.tolist() == list(range(rank, n_img, world))
+    assert torch.isfinite(scores).all()
+    lab_shard = labels[mine.cpu()]
+    got = E.retrieval_recalls(scores, lab_shard)
+    assert got == O.retrieval_recalls(scores.cpu(), lab_shard)
+    assert all(0.0 <= v <= 1.0 for v in got)
+    # the oracle on a 3-image x 40-caption block of that shard (all 12 layers, fp32 CPU)
+    ii = mine.cpu()[:3]
+    cc = torch.cat([torch.arange(int(i) * per, int(i) * per + per) for i in ii] + [torch.arange(2000, 2025)])
+    ref = torch.empty(len(ii), len(cc))
+    with torch.no_grad():
+        for r, i in enumerate(ii.tolist()):
+            xi = x_img[:, i:i + 1].expand(R, len(cc), 2048)
+            li = image_loc[:, i:i + 1].expand(R, len(cc), 5)
+            out = O.jointfwd(sd, cfg['n_layers'], cfg['n_heads'], x[:, cc], lengths[cc], xi, torch.full((len(cc),), R), li)
+            ref[r] = O.predict_relation(sd, out.transpose(0, 1)).view(-1)
+    sub = scores[:3].cpu()[:, cc]
+    tol = 3e-2
+    assert max_abs(sub, ref) < tol, max_abs(sub, ref)
+    top2 = ref.topk(2, dim=1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 2 * tol
+    assert bool((sub.argmax(1)[clear] == ref.argmax(1)[clear]).all())
+    sub_lab = labels[ii][:, cc]
+    r_hip, r_ref = E.retrieval_recalls(sub, sub_lab), O.retrieval_recalls(ref, sub_lab)
+    assert abs(r_hip[3] - r_ref[3]) <= float((~clear).sum()) / len(ii) + 1e-9
+    # every HIP top-1 is within the bar of the oracle's best score for that query (ranking equal up to the noise floor)
+    best_ref = ref.max(dim=1).values
+    picked = ref[torch.arange(len(ii)), sub.argmax(1)]
+    assert bool(((best_ref - picked) <= 2 * tol).all())
