@@ -4,6 +4,7 @@
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...        (no launcher: re-executes itself under torch.distributed.run, N ranks)
 
 One step = XTrainer.pretrain_under_step on a synthetic, device-resident batch of
 BASELINE.json configs[1] (12L/768d/12h, 36 regions + 128 tokens, V=250002, 19 masked
@@ -62,11 +63,26 @@ def build(cfg, dropout, world, rank, local_rank, refine_layers=0, ragged=False):
     return trainer, tup
 
 
-def cpu_baseline(cfg, seconds=20.0):
-    """The oracle's full training step on the host cores: same model shape, B=8 sample."""
+def _host_info():
+    """(physical cores, logical CPUs, CPU model) of this host."""
+    import subprocess
+    logical = os.cpu_count() or 1
+    model, phys = 'unknown', None
+    try:
+        txt = subprocess.run(['lscpu'], capture_output=True, text=True, timeout=10).stdout
+        kv = {l.split(':', 1)[0].strip(): l.split(':', 1)[1].strip() for l in txt.splitlines() if ':' in l}
+        model = kv.get('Model name', model)
+        phys = int(kv['Core(s) per socket']) * int(kv['Socket(s)'])
+    except Exception:
+        pass
+    return phys or max(logical // 2, 1), logical, model
+
+
+def _oracle_steps(cfg, Bs, dropout, threads, warm, timed, budget_s):
+    """warm + up to `timed` full training steps of the oracle (fwd + bwd + clip 5 + Adam-inv-sqrt) -> seconds per step."""
     from m3p_amd import synth
     from oracle import ref_cpu as O
-    Bs = 8
+    torch.set_num_threads(threads)
     P = synth.model_params(cfg['emb_dim'], cfg['n_heads'], cfg['n_layers'], cfg['n_words'])
     shapes = synth.hot_param_shapes(P)
     gen = torch.Generator().manual_seed(0)
@@ -77,26 +93,71 @@ def cpu_baseline(cfg, seconds=20.0):
     names = list(sd.keys())
     batch = synth.make_batch(cfg['T'], cfg['R'], Bs, cfg['n_words'], cfg['n_pred'], seed=1000, ragged=False)
     opt = O.AdamInvSqrt([sd[n] for n in names])
-    cores = torch.get_num_threads()
-    O.train_step(sd, names, opt, cfg['n_layers'], cfg['n_heads'], batch, cfg['R'], clip=5.0)   # warm-up
+    kw = {}
+    if dropout > 0:      # same keep probability at every site as the GPU run; masks drawn once (the oracle takes explicit masks)
+        S, d, H, L = cfg['T'] + cfg['R'], cfg['emb_dim'], cfg['n_heads'], cfg['n_layers']
+        g = torch.Generator().manual_seed(1)
+        bern = lambda *shape: torch.rand(shape, generator=g) >= dropout    # noqa: E731
+        keeps = {'img': bern(Bs, cfg['R'], d), 'emb': bern(Bs, S, d)}
+        for i in range(L):
+            keeps[('attn_p', i)] = bern(Bs, H, S, S)
+            keeps[('attn_out', i)] = bern(Bs, S, d)
+            keeps[('ffn', i)] = bern(Bs, S, d)
+        kw = dict(dropout=dropout, attention_dropout=dropout, keeps=keeps)
+    for _ in range(warm):
+        O.train_step(sd, names, opt, cfg['n_layers'], cfg['n_heads'], batch, cfg['R'], clip=5.0, **kw)
     t0 = time.time()
     n = 0
-    while True:
-        O.train_step(sd, names, opt, cfg['n_layers'], cfg['n_heads'], batch, cfg['R'], clip=5.0)
+    while n < timed:
+        O.train_step(sd, names, opt, cfg['n_layers'], cfg['n_heads'], batch, cfg['R'], clip=5.0, **kw)
         n += 1
-        if time.time() - t0 > seconds or n >= 20:
+        if time.time() - t0 > budget_s:
             break
-    dt = time.time() - t0
-    return dict(value=round(Bs * n / dt, 3), unit='sequences/s', cores=cores, kind='port',
-                sample='%d full train steps (fwd+bwd+clip+Adam) of the same 12L/768d V=250002 model at B=%d, fp32, '
-                       'dropout 0 (oracle/ref_cpu.py)' % (n, Bs))
+    return (time.time() - t0) / n, n
+
+
+def cpu_baseline(cfg, dropout):
+    """The reference path restated (oracle/ref_cpu.py, pinned to the reference by the golden vectors) timed on this
+    host's cores, BASELINE.md section 4: the cfg1 step exactly (B = 8) and the cfg2 model at B = 8, dropout as in the
+    GPU run, Adam-inv-sqrt + clip 5; threads = the better of {32, all physical cores} on a one-step probe; 3 warm-up
+    steps, then 10 timed steps (the big model stops early after ~25 s)."""
+    from m3p_amd import synth
+    phys, logical, model = _host_info()
+    Bs = 8
+    probes = {}
+    for n in sorted({min(32, phys), phys}):
+        probes[n] = _oracle_steps(cfg, Bs, dropout, n, 1, 1, 60.0)[0]
+    threads = min(probes, key=probes.get)
+    sec, n = _oracle_steps(cfg, Bs, dropout, threads, 2, 10, 25.0)
+    c1 = dict(synth.CONFIGS['cfg1'])
+    sec1, n1 = _oracle_steps(c1, c1['B'], dropout, min(threads, 16), 3, 10, 10.0)
+    return dict(value=round(Bs / sec, 3), unit='sequences/s', cores=threads, kind='port',
+                sample='%d timed full train steps (fwd+bwd+clip+Adam, 3 warm-up incl. probe) of the same %dL/%dd V=%d model '
+                       'at B=%d, fp32, dropout %.2f (oracle/ref_cpu.py)' % (n, cfg['n_layers'], cfg['emb_dim'], cfg['n_words'], Bs, dropout),
+                cfg1=dict(value=round(c1['B'] / sec1, 2), unit='sequences/s', cores=min(threads, 16),
+                          sample='%d timed steps of BASELINE configs[0] (2L/128d, 64+10, B=8, V=1000)' % n1),
+                host=dict(physical_cores=phys, logical_cpus=logical, cpu_model=model,
+                          thread_probe_s_per_step={str(k): round(v, 3) for k, v in probes.items()}))
+
+
+def _self_launch(args):
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd))
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=30)
-    ap.add_argument('--warmup', type=int, default=10)   # (the engine clock needs a few hundred ms of load to ramp up from idle)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--batch', type=int, default=256, help='sequences per GPU')
     ap.add_argument('--config', default='cfg2')
     ap.add_argument('--dropout', type=float, default=0.1)
@@ -107,20 +168,48 @@ def main():
                     help='AoA refiner layers on the image rows (jointfwd refine_image=True; the reference default is 6). '
                          '0 = the README configuration the headline metric is quoted on')
     args = ap.parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        _self_launch(args)
 
     from m3p_amd import synth, ops
     from m3p_amd.distributed import init_distributed_mode
     import torch.distributed as dist
     rank, local_rank, world = init_distributed_mode()
-    assert world == args.gpus or world == 1, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+    assert world == args.gpus, 'WORLD_SIZE=%d but --gpus %d' % (world, args.gpus)
+    if world > 1:
+        assert dist.get_world_size() == world
     torch.cuda.set_device(local_rank)
     cfg = dict(synth.CONFIGS[args.config])
     cfg['B'] = args.batch
     trainer, tup = build(cfg, args.dropout, world, rank, local_rank, args.refine_layers, args.ragged)
+    dp = trainer.model if world > 1 else None
 
     def step():
         trainer.pretrain_under_step(tup, 'google', 't2i', 'en', 1.0, 1.0, 1.0, 1.0)
         trainer.n_iter += 1
+
+    # Pre-warm OUTSIDE the counted warm-up until the step time is stable (the engine clock ramps up from idle over a
+    # few hundred ms, lazy allocations settle): two consecutive 3-step groups within 2 %, at most 12 groups - so the
+    # result does not depend on the caller's --warmup.
+    def timed_group(n=3):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(n):
+            step()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / n
+    prev, groups = timed_group(), 1
+    while groups < 12:
+        cur = timed_group()
+        groups += 1
+        stable = abs(cur - prev) <= 0.02 * prev
+        if world > 1:      # ranks must leave the loop together
+            flag = torch.tensor([1.0 if stable else 0.0], device='cuda')
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            stable = bool(flag.item())
+        prev = cur
+        if stable:
+            break
 
     # Warm-up steps time EVERY GEMM launch with HIP events (on the launch stream) to find the dominant
     # instance; the timed region then brackets only that instance's launches (the events of all ~100
@@ -133,6 +222,8 @@ def main():
     warm_agg = {k: sum(a.elapsed_time(b) for a, b in evs) for k, evs in warm_prof.items()}
     gemm_ms_per_step = sum(warm_agg.values()) / max(args.warmup, 1)
     ops.PROFILE_ONLY = max(warm_agg.items(), key=lambda kv: kv[1])[0] if warm_agg else None
+    if dp is not None:
+        dp.exposed_events = []
     if world > 1:
         dist.barrier()
         torch.cuda.synchronize()
@@ -146,10 +237,21 @@ def main():
         torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     prof, ops.PROFILE = ops.PROFILE, None
+    comm = None
     if world > 1:
         t = torch.tensor([dt], device='cuda', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        evs = dp.exposed_events or []
+        exposed = [a.elapsed_time(b) for a, b, _ in evs]
+        payload = [n for _, _, n in evs]
+        e = torch.tensor([sum(exposed) / max(len(exposed), 1)], device='cuda', dtype=torch.float64)
+        dist.all_reduce(e, op=dist.ReduceOp.MAX)
+        comm = dict(exposed_ms_per_step=round(float(e.item()), 3),
+                    payload_MB_per_step=round(sum(payload) / max(len(payload), 1) / 1e6, 1),
+                    note='exposed = compute-stream wait for the gradient collectives + token-row scatter before clip/Adam '
+                         '(max over ranks); payload = bytes handed to RCCL per rank and step (layer / head / vocabulary '
+                         'buckets fp32, token rows bf16)')
 
     if rank == 0:
         seqs = args.steps * cfg['B'] * world
@@ -168,12 +270,16 @@ def main():
             flops = 2.0 * M * N * K
             ach = flops / (avg_ms * 1e-3) / 1e12
             kname = '%s M=%d N=%d K=%d' % (kind, M, N, K)
-            traffic = None
-            tpath = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
-            if os.path.exists(tpath):   # HBM bytes/launch from the committed rocprofv3 --pmc passes of this command
-                traffic = json.load(open(tpath)).get('bench_keys', {}).get(kname)
+            traffic, tsrc = None, None
+            for rel in ('profiles/r02_traffic.json', 'profiles/r01_traffic.json'):
+                tpath = os.path.join(ROOT, rel)
+                if os.path.exists(tpath):   # HBM bytes/launch from the committed rocprofv3 --pmc passes of this command
+                    traffic = json.load(open(tpath)).get('bench_keys', {}).get(kname)
+                    if traffic is not None:
+                        tsrc = rel + ' (committed rocprofv3 --pmc passes of this command; not measured in this run)'
+                        break
             roof = dict(bound='mfma', achieved=round(ach, 1), peak=PEAK_BF16_TFLOPS, unit='TFLOP/s',
-                        frac=round(ach / PEAK_BF16_TFLOPS, 4), traffic=traffic,
+                        frac=round(ach / PEAK_BF16_TFLOPS, 4), traffic=traffic, traffic_source=tsrc,
                         kernel=kname, launches=cnt, avg_ms=round(avg_ms, 4),
                         gemm_time_share=round((gemm_ms_per_step * args.steps if ops.PROFILE_ONLY is not None else
                                                sum(v[0] for v in agg.values())) / (dt * 1e3), 3),
@@ -189,12 +295,14 @@ def main():
                                            (' + %d AoA refiner layers (not in flops_train_per_seq)' % args.refine_layers
                                             if args.refine_layers else '') + (', ragged text lengths U[T/2, T]' if args.ragged else '')),
                                per_gpu_batch=cfg['B'], global_batch=cfg['B'] * world, seq_len=cfg['T'] + cfg['R'],
-                               parallelism='dp%d' % world, flops_train_per_seq=fl),
+                               parallelism='dp%d' % world, flops_train_per_seq=fl, prewarm_steps=3 * groups),
                    roofline=roof)
+        if comm is not None:
+            out['comm'] = comm
         if world == 1 and not args.no_cpu_baseline:
             del trainer
             torch.cuda.empty_cache()
-            out['cpu_baseline'] = cpu_baseline(cfg)
+            out['cpu_baseline'] = cpu_baseline(cfg, args.dropout)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
