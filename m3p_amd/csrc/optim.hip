@@ -22,6 +22,9 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
   if (threadIdx.x == 0) unsafeAtomicAdd(out, (red[0] + red[1]) + (red[2] + red[3]));
 }
 
+#ifndef M3P_ADAM_STREAM
+#define M3P_ADAM_STREAM 1
+#endif
 struct AdamArgs {
   float* p; float* g; float* m; float* v; bf16* w16;
   size_t n4;
@@ -41,6 +44,48 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
     coef *= (c < 1.f) ? c : 1.f;
   }
   const float ob1 = 1.f - a.beta1, ob2 = 1.f - a.beta2, wdl = a.weight_decay * a.lr;
+#if M3P_ADAM_STREAM
+  // Nine streams (4 read, 5 written) of data touched once per step: non-temporal accesses keep them out of the way
+  // of the bf16 weights / activations the next forward re-reads, and two 16-byte quads per thread and iteration put
+  // eight loads in flight before the first use.
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < a.n4; i0 += 2 * stride) {
+    const size_t i1 = i0 + stride;
+    const bool two = i1 < a.n4;
+    f32x4 p[2], g[2], m[2], v[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const size_t i = u ? i1 : i0;
+      if (u == 0 || two) {
+        p[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.p + 4 * i));
+        g[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.g + 4 * i));
+        m[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.m + 4 * i));
+        v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.v + 4 * i));
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const size_t i = u ? i1 : i0;
+      if (u == 0 || two) {
+        const f32x4 gc = g[u] * coef;
+        const f32x4 mn = m[u] * a.beta1 + gc * ob1;
+        const f32x4 vn = v[u] * a.beta2 + gc * gc * ob2;
+        f32x4 pn = p[u];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float denom = sqrtf(vn[j]) + a.eps;
+          if (wdl != 0.f) pn[j] -= wdl * pn[j];
+          pn[j] -= a.step_size * (mn[j] / denom);
+        }
+        __builtin_nontemporal_store(pn, reinterpret_cast<f32x4*>(a.p + 4 * i));
+        __builtin_nontemporal_store(mn, reinterpret_cast<f32x4*>(a.m + 4 * i));
+        __builtin_nontemporal_store(vn, reinterpret_cast<f32x4*>(a.v + 4 * i));
+        if (a.w16) Vec4<bf16>::store(a.w16 + 4 * i, pn);       // (re-read by the very next forward: default policy)
+        if (a.zero_grad) __builtin_nontemporal_store(f32x4{0.f, 0.f, 0.f, 0.f}, reinterpret_cast<f32x4*>(a.g + 4 * i));
+      }
+    }
+  }
+#else
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n4; i += (size_t)gridDim.x * blockDim.x) {
     f32x4 p = Vec4<float>::load(a.p + 4 * i);
     const f32x4 g = Vec4<float>::load(a.g + 4 * i) * coef;
@@ -58,6 +103,7 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
     if (a.w16) Vec4<bf16>::store(a.w16 + 4 * i, p);
     if (a.zero_grad) Vec4<float>::store(a.g + 4 * i, f32x4{0.f, 0.f, 0.f, 0.f});
   }
+#endif
 }
 
 // dst[c][r] = src[r][c], 64x64 tiles through LDS; ld_dst >= rows (pad columns untouched)

@@ -145,7 +145,7 @@ class DataParallel(torch.nn.Module):
         self._tokens_out = None
         self._finished = False
         self.exposed_events = None   # set to [] to record (start, end) events around finish()'s waits
-        module.ddp_hook = self
+        object.__setattr__(module, 'ddp_hook', self)    # plain attribute: as a registered submodule it would close a cycle
         if broadcast and self.world > 1:
             dist.broadcast(arena.master, src=0, group=process_group)
             for p in module.parameters():

@@ -83,7 +83,8 @@ def _batches(step):
     full = synth.make_batch(CFG['T'], CFG['R'], B, CFG['n_words'], CFG['n_pred'], seed=11 + step, ragged=True)
     other = synth.make_batch(CFG['T'], CFG['R'], B, CFG['n_words'], 0, seed=50 + step, ragged=True)
     extra = synth.make_region_targets(CFG['R'], B, seed=77 + step)
-    extra['obj_labels'][B // 2, 1] = 3                       # a masked region on both halves
+    lab = extra['obj_labels']                                # the same number of masked regions on both halves: a rank's
+    lab[B // 2:] = torch.where(lab[:B // 2] != -1, (lab[:B // 2] + 7) % 1600, lab[:B // 2])   # mean is then the global mean
     extra.update(x2=other['x'], len2=other['lengths'], clcm=torch.tensor([1, 0, 0, 1, 1, 0, 1, 0])[:B])
     return full, extra
 
@@ -149,7 +150,8 @@ def _worker(rank, world, port, q, scenario, backend):
         leftover = float(m.arena().grad.abs().max())
         launched_vocab = 'vocab' in tr.model._launched or scenario != 'finetune'
         if rank == 0:
-            q.put(('ok', [(g, n) for g, n in snaps], pm.cpu(), same, leftover, launched_vocab))
+            # numpy, not tensors: a tensor crosses the queue as a shared-memory handle that dies with this process
+            q.put(('ok', [(g.numpy(), n) for g, n in snaps], pm.cpu().numpy(), same, leftover, launched_vocab))
         dist.barrier()
         dist.destroy_process_group()
     except Exception:
@@ -176,7 +178,9 @@ def _check(scenario, backend):
     assert len(snaps) == len(ref) == N_STEPS
     off = m.arena().offsets
     v0, v1 = off['embeddings.weight'][0], off['embeddings.weight'][0] + off['embeddings.weight'][1]
+    pm = torch.from_numpy(pm)
     for i, ((g, n), (gr, nr)) in enumerate(zip(snaps, ref)):
+        g = torch.from_numpy(g)
         err = float((g - gr).norm() / gr.norm())
         err_vocab = float((g[v0:v1] - gr[v0:v1]).norm() / gr[v0:v1].norm())
         assert err < 2e-2, (scenario, i, err)
