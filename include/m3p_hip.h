@@ -15,7 +15,10 @@
  *   - `stream` is a hipStream_t passed as void*; kernels are enqueued asynchronously;
  *   - return value: 0 = enqueued OK; <0 = M3P_E* (bad shape / alignment, nothing was
  *     launched); >0 = a hipError_t.  Nothing throws across the ABI;
- *   - no global mutable state, re-entrant (the autograd engine calls from its own thread).
+ *   - the library never allocates and keeps no per-call state: re-entrant (the autograd engine calls from its
+ *     own thread).  What IS process-global: idempotent one-time initialisation (the CU count, the dynamic-LDS
+ *     attribute of each kernel) and the developer switch m3p_debug_set_variant (A/B runs of kernel generations;
+ *     not in this header, never called by the product).
  */
 #ifndef M3P_HIP_H
 #define M3P_HIP_H
@@ -92,9 +95,15 @@ M3P_API int m3p_gemm_nn_streamk_f32(const void* A, int lda, const void* W, int l
  * (dY bf16 [M,N] pitch lddy, X bf16 [M,K] pitch ldx).  Accumulates with fp32 atomics
  * (split over M to fill 256 CUs), so dW must hold the running gradient (zero after
  * zero_grad).  Replaces autograd's addmm-backward for every nn.Linear weight above.
- * Requires N % 16 == 0 ... see source; lddy/ldx % 8 == 0. */
+ * Requires N % 16 == 0 ... see source; lddy/ldx % 8 == 0.
+ * workspace (optional, device memory, 16-byte aligned, >= m3p_gemm_wgrad_workspace_bytes()): scratch for the
+ * four-wave kernel's partial tiles (one 256-KB slot per CU, folded into dW by a reduce kernel, no atomics).  It
+ * belongs to the caller - the library never allocates - and must not be shared by launches that can run
+ * concurrently (different streams).  NULL: partial tiles are added to dW with atomics instead. */
+M3P_API size_t m3p_gemm_wgrad_workspace_bytes(void);
 M3P_API int m3p_gemm_wgrad_bf16(const void* dY, int lddy, const void* X, int ldx, float* dW, int lddw,
-                                int M, int N, int K, float alpha, void* stream);
+                                int M, int N, int K, float alpha, void* workspace, size_t workspace_bytes,
+                                void* stream);
 
 /* ------------------------------------------------------------------------------------
  * LayerNorm (eps = 1e-12 in the reference: transformer.py:244,660,694,709)

@@ -2277,8 +2277,13 @@ int m3p_gemm_nn_streamk_f32(const void* A, int lda, const void* W, int ldw, int 
   return launch_streamk(A, lda, W, ldw, C, ldc, M, N, K, alpha, true, k_valid, stream);
 }
 
+size_t m3p_gemm_wgrad_workspace_bytes(void) {
+  const size_t grid = (size_t)num_cus();
+  return grid * (65536 + 272) * sizeof(float) + grid * sizeof(int);
+}
+
 int m3p_gemm_wgrad_bf16(const void* dY, int lddy, const void* X, int ldx, float* dW, int lddw, int M, int N, int K,
-                        float alpha, void* stream) {
+                        float alpha, void* workspace, size_t workspace_bytes, void* stream) {
   if (M <= 0 || N <= 0 || K <= 0 || (lddy % 8) != 0 || (ldx % 8) != 0) return M3P_EINVAL;
   if (lddy < ((N + 7) / 8) * 8 || ldx < ((K + 7) / 8) * 8) return M3P_EINVAL;
   if (((uintptr_t)dY & 15) || ((uintptr_t)X & 15)) return M3P_EINVAL;
@@ -2298,21 +2303,13 @@ int m3p_gemm_wgrad_bf16(const void* dY, int lddy, const void* X, int ldx, float*
     long long share = ((long long)ti * tj * nmt + grid - 1) / grid;
     int chunk = (int)(share < nmt ? (share < 1 ? 1 : share) : nmt);
     if ((long long)ti * tj >= 4LL * grid) chunk = 0;   // many tiles: round-robin whole tiles
-    // workspace for first-segment partials: one 256-KB slot per workgroup + a tile-id word each,
-    // allocated once per device on first use.  It serialises nothing on one stream; weight-gradient
-    // GEMMs issued concurrently on DIFFERENT streams of one device would share it (we never do).
-    static float* ws_dev[16] = {};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
+    // workspace for first-segment partials: one 256-KB slot per workgroup + a tile-id word each, owned by the
+    // CALLER (m3p_gemm_wgrad_workspace_bytes): launches that may overlap on different streams need one each.
+    // Without it the partial tiles go to dW with fp32 atomics (slower: DESIGN.md section 4).
     float* ws = nullptr;
-    if (dev >= 0 && dev < 16 && chunk != 0 && (lddw % 4) == 0 && (((uintptr_t)dW & 15) == 0)) {
-      if (!ws_dev[dev]) {
-        void* pws = nullptr;
-        if (hipMalloc(&pws, (size_t)grid * (65536 + 272) * sizeof(float) + (size_t)grid * sizeof(int)) != hipSuccess) return M3P_ENOMEM;
-        ws_dev[dev] = (float*)pws;
-      }
-      ws = ws_dev[dev];
-    }
+    if (workspace && workspace_bytes >= m3p_gemm_wgrad_workspace_bytes() && (((uintptr_t)workspace & 15) == 0) && chunk != 0 &&
+        (lddw % 4) == 0 && (((uintptr_t)dW & 15) == 0))
+      ws = (float*)workspace;
     int* ws_tile = ws ? (int*)(ws + (size_t)grid * (65536 + 272)) : nullptr;
     hipLaunchKernelGGL(gemm_wgrad_w4_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, (const bf16*)dY, lddy,
                        (const bf16*)X, ldx, dW, lddw, M, N, K, alpha, ti, tj, chunk, ws, ws_tile, g_ablate);

@@ -104,6 +104,18 @@ def gemm_nn_streamk(a, w_kn, out_f32, alpha=1.0):
     return out_f32
 
 
+_WGRAD_WS = {}     # (device index, stream) -> workspace tensor of the four-wave weight-gradient kernel
+
+
+def _wgrad_workspace(device):
+    """One scratch buffer per (device, stream): launches on one stream are ordered, so they can share it."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _WGRAD_WS.get(key)
+    if ws is None:
+        ws = _WGRAD_WS[key] = torch.empty(int(L.load().m3p_gemm_wgrad_workspace_bytes()), dtype=torch.uint8, device=device)
+    return ws
+
+
 def gemm_wgrad(dy, x, dw, alpha=1.0, n=None, k=None):
     """dw[N,K] (fp32) += alpha * dy[M,N]^T @ x[M,K]."""
     _chk_bf16(dy, x)
@@ -113,8 +125,9 @@ def gemm_wgrad(dy, x, dw, alpha=1.0, n=None, k=None):
     K = x.shape[1] if k is None else k
     assert x.shape[0] == M and dw.shape[0] >= N and dw.shape[1] >= K
     e0 = _prof_begin(('gemm_wgrad', M, N, K))
+    ws = _wgrad_workspace(dy.device)
     rc = L.load().m3p_gemm_wgrad_bf16(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), dw.data_ptr(),
-                                      dw.stride(0), M, N, K, alpha, L.stream())
+                                      dw.stride(0), M, N, K, alpha, ws.data_ptr(), ws.numel(), L.stream())
     L.check(rc, 'm3p_gemm_wgrad_bf16')
     _prof_end(e0, ('gemm_wgrad', M, N, K))
     return dw

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Turns gpurun_out/counters/ (tools/collect_counters.sh) into profiles/r01_traffic.json and
-profiles/r01_counters.md: per kernel, launches per step, average duration, HBM bytes per launch
+"""Turns gpurun_out/counters/ (tools/collect_counters.sh) into profiles/<ROUND>_traffic.json and
+profiles/<ROUND>_counters.md (ROUND defaults to r02): per kernel, launches per step, average duration, HBM bytes per launch
 (2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md, calibrated on the GELU
 pass), achieved HBM GB/s, and MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES)."""
 import collections, csv, glob, json, os, sys
@@ -19,7 +19,8 @@ for f in glob.glob(os.path.join(src, 'stats', '*', '*kernel_stats.csv')):
     for r in csv.DictReader(open(f)):
         stats[r['Name']] = (int(r['Calls']), float(r['AverageNs']))
 fetch, write, sq = counters('fetch'), counters('write'), counters('sq')
-steps = 4.0          # bench.py --steps 3 --warmup 1
+TAG = os.environ.get('ROUND', 'r02')
+steps = float(max([c for n, (c, _) in stats.items() if 'adam_kernel' in n] + [1]))     # optimizer steps in the profiled run
 rows, kernels = [], {}
 for name, (calls, avg_ns) in sorted(stats.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
     fk = fetch.get(name, {}).get('FETCH_SIZE')
@@ -42,9 +43,9 @@ note = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, tools
         "--warmup 1 --no-cpu-baseline`; values are KB per launch averaged over all launches of the kernel. hbm_bytes = (2*FETCH_SIZE + "
         "WRITE_SIZE)*1024: the x2 on FETCH_SIZE is the gfx950 correction of MI355X_MICROARCH.md (HBM section), calibrated here on "
         "gelu_fwd_kernel (streams 258 MB in, 258 MB out).")
-json.dump(dict(_note=note, kernels=kernels, bench_keys=bench_keys), open(os.path.join(ROOT, 'profiles', 'r01_traffic.json'), 'w'), indent=1)
-with open(os.path.join(ROOT, 'profiles', 'r01_counters.md'), 'w') as o:
-    o.write('# Round 1 - per-kernel counters of one cfg2 training step (MI355X, rocprofv3, separate --pmc passes)\n\n')
+json.dump(dict(_note=note, kernels=kernels, bench_keys=bench_keys), open(os.path.join(ROOT, 'profiles', TAG + '_traffic.json'), 'w'), indent=1)
+with open(os.path.join(ROOT, 'profiles', TAG + '_counters.md'), 'w') as o:
+    o.write('# ' + TAG + ' - per-kernel counters of one cfg2 training step (MI355X, rocprofv3, separate --pmc passes)\n\n')
     o.write('Collected by `tools/collect_counters.sh`, summarised by `tools/summarize_counters.py`.  Durations come from the plain\n'
             '`--kernel-trace --stats` pass (counter passes serialise kernels).  HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE (gfx950\n'
             'correction, MI355X_MICROARCH.md); HBM GB/s = bytes / duration against the 8 TB/s peak (about 6.3 TB/s achievable).\n'
@@ -56,4 +57,4 @@ with open(os.path.join(ROOT, 'profiles', 'r01_counters.md'), 'w') as o:
         short = short.split('(')[0][:60]
         o.write('| `%s` | %.1f | %.1f | %.1f | %.0f | %s | %s |\n' % (short, lps, us, hbm / 1e6, gbs, '%.1f %%' % (100 * util) if util is not None else '-',
                                                                       '%.0f %%' % (100 * wait) if wait is not None else '-'))
-print('wrote profiles/r01_traffic.json, profiles/r01_counters.md;', len(rows), 'kernels')
+print('wrote profiles/%s_traffic.json, profiles/%s_counters.md;' % (TAG, TAG), len(rows), 'kernels')
