@@ -294,3 +294,110 @@ def test_cfg5_retrieval_1000x5_shard_and_oracle_subset():
     best_ref = ref.max(dim=1).values
     picked = ref[torch.arange(len(ii)), sub.argmax(1)]
     assert bool(((best_ref - picked) <= 2 * tol).all())
+
+
+def test_trainer_entry_points_track_the_reference_run(golden_dir):
+    """mlm_step('en', None, 1) on a monolingual stream (generate_batch -> round_batch -> mask_out -> crossfwd -> predict ->
+    optimize) and t2i_step / i2t_step on the tuple retrieval_collate emits, against the same calls made on the
+    reference's own XTrainer on CPU (tests/golden/host_logic.npz): losses, learning rate, word / sentence counters and
+    parameter norms after the steps.  Same seeds => the very same masked batch (tests/test_host_surface.py pins that)."""
+    from m3p_amd.trainer import XTrainer
+    G = np.load(os.path.join(golden_dir, 'host_logic.npz'))
+    cfg = synth.CONFIGS['cfg1']
+    common = dict(optimizer='adam_inverse_sqrt,beta1=0.9,beta2=0.98,lr=0.0001', clip_grad_norm=5, amp=-1, fp16=False,
+                  accumulate_gradients=1, multi_gpu=False, epoch_size=100, cross_mlm_steps=[], cross_mrm_steps=[],
+                  cross_mrfr_steps=[], cross_clcm_steps=[], cross_rel_steps=[('google', 'img')], refine_image=False,
+                  batch_size=cfg['B'], dump_path='/nonexistent_m3p_dump', langs=['en'], sample_alpha=0, word_pred=0.15,
+                  word_mask=0.8, word_keep=0.1, word_rand=0.1, t2i_flag=True, i2t_flag=True)
+
+    class _Stream:
+        def __init__(self, batches):
+            self.batches = batches
+
+        def get_iterator(self, shuffle=True):
+            return iter(self.batches)
+
+    batch = synth.make_batch(cfg['T'], cfg['R'], cfg['B'], cfg['n_words'], 0)
+    m, P, sd = _build(cfg, dict(common, sample_n=2, multi_cls_loss_weight=0, bin_cls_loss_weight=1))
+    tr = XTrainer(m, {'mono_stream': {'en': {'train': _Stream([(batch['x'], batch['lengths'])])}}}, P)
+    np.random.seed(77); torch.manual_seed(77)
+    loss = tr.mlm_step('en', None, 1.0)
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(G['mlm_step_loss'])) < 5e-3
+    assert abs(tr.optimizers['model'].param_groups[0]['lr'] - float(G['mlm_step_lr'])) < 1e-15
+    assert int(torch.stack(tr._pending_w).sum()) == int(G['mlm_step_processed_w'])      # the same number of masked words
+    assert tr.stats['processed_s'] == cfg['B'] and tr.n_sentences == cfg['B']
+    own = dict(m.named_parameters())
+    for k in ('embeddings.weight', 'attentions.0.q_lin.weight', 'layer_norm2.1.weight', 'pred_layer.proj.bias'):
+        assert abs(float(own[k].detach().norm()) - float(G['mlm_step_pnorm/' + k])) < 1e-4 * float(G['mlm_step_pnorm/' + k]), k
+    with pytest.raises(NotImplementedError):
+        tr.mlm_step('en', 'en', 1.0)            # TLM batches are outside the MI355X text stream
+    assert tr.mlm_step('en', None, 0) is None   # lambda 0: nothing happens (xtrainer.py:740-741)
+
+    m3, P3, _ = _build(cfg, dict(common, sample_n=4, multi_cls_loss_weight=1, bin_cls_loss_weight=1))
+    tr3 = XTrainer(m3, {}, P3)
+    B, R = cfg['B'], cfg['R']
+    tup = [(batch['x'], batch['lengths'], torch.zeros_like(batch['x'])),
+           [batch['x_img'].transpose(0, 1).contiguous(), torch.ones(B, R, dtype=torch.long),
+            batch['image_loc'].transpose(0, 1).contiguous(), torch.full((B, R), -1, dtype=torch.long), [2, 0], list(range(B))]]
+    l1 = tr3.t2i_step(tup, 'google', 1.0)
+    l2 = tr3.i2t_step(tup, 'google', 0.5)
+    torch.cuda.synchronize()
+    assert abs(float(l1) - float(G['t2i_step_loss'])) < 1e-2 and abs(float(l2) - float(G['i2t_step_loss'])) < 1e-2
+    ps, pw, ns = (int(v) for v in G['rel_step_processed'])
+    assert (tr3.stats['processed_s'], tr3.stats['processed_w'], tr3.n_sentences) == (ps, pw, ns)
+    own = dict(m3.named_parameters())
+    for k in ('pooled_layer.dense.weight', 'attentions.1.out_lin.weight', 'embeddings.weight'):
+        assert abs(float(own[k].detach().norm()) - float(G['rel_step_pnorm/' + k])) < 1e-4 * float(G['rel_step_pnorm/' + k]), k
+    assert tr3.t2i_step(tup, 'google', 0) is None
+
+
+def test_pretrain_rel_step_and_rel_step_through_a_dataloader():
+    """pretrain_rel_step / rel_step (xtrainer.py:1867-1886): get_batch -> DataLoader(dataset, collate) -> the two task
+    steps.  A synthetic dataset of per-item tuples stands in for the reference's HDF5 readers."""
+    from m3p_amd.trainer import XTrainer
+    cfg = dict(emb_dim=128, n_heads=4, n_layers=2, n_words=1000, T=16, R=10, B=4, n_pred=0)
+    k, R, V = 2, cfg['R'], cfg['n_words']
+    rs = np.random.RandomState(4)
+
+    def item(pretrain, i2t):
+        caps = [rs.randint(4, V - 1, size=rs.randint(3, 12)).astype(np.int64) for _ in range(k)]
+        feats = torch.from_numpy(rs.standard_normal((k, R, 2048)).astype(np.float32))
+        feats = feats / feats.norm(dim=-1, keepdim=True)
+        masks = torch.ones(k, R, dtype=torch.long)
+        boxes = torch.from_numpy(rs.uniform(size=(k, R, 5)).astype(np.float32))
+        objs = torch.from_numpy(np.where(rs.rand(k, R) < 0.3, rs.randint(0, 1600, size=(k, R)), -1).astype(np.int64))
+        objs[0, 0] = 5
+        ids = [int(v) for v in rs.randint(0, 1000, size=k)]
+        if not pretrain:
+            return (caps, feats, masks, boxes, objs, [int(rs.randint(0, k))], ids, [0] * k)
+        lm = [[int(w) if j == 1 else -1 for j, w in enumerate(c)] for c in caps]
+        base = (caps, feats, masks, boxes, objs, lm, int(rs.randint(0, k)), ids, feats.clone(), [0] * k)
+        if not i2t:
+            return base
+        caps2 = [rs.randint(4, V - 1, size=rs.randint(3, 9)).astype(np.int64) for _ in range(k)]
+        return base + (caps2, torch.from_numpy(rs.randint(0, 2, size=k).astype(np.int64)))
+
+    for pretrain in (True, False):
+        data = [(item(pretrain, False), item(pretrain, True)) for _ in range(6)]
+        extra = dict(optimizer='adam_inverse_sqrt,beta1=0.9,beta2=0.98,lr=0.0001', clip_grad_norm=5, amp=1, fp16=True,
+                     accumulate_gradients=1, multi_gpu=False, epoch_size=100, batch_size=2, dump_path='/nonexistent_m3p_dump',
+                     cross_rel_steps=[('coco', 'img')], cross_mlm_steps=[('coco', 'img')] if pretrain else [],
+                     cross_mrm_steps=[('coco', 'img')] if pretrain else [], cross_mrfr_steps=[('coco', 'img')] if pretrain else [],
+                     cross_clcm_steps=[('coco', 'img')] if pretrain else [], sample_n=k, refine_image=False,
+                     multi_cls_loss_weight=1, bin_cls_loss_weight=1, is_pretrain=pretrain, n_gpu_per_node=1, num_workers=0,
+                     t2i_flag=True, i2t_flag=True, lambda_t2i='1', lambda_i2t='1', lambda_mlm='1', lambda_mrm='1', lambda_mrfr='1')
+        m, P, sd = _build(cfg, extra)
+        tr = XTrainer(m, {'cross_modal': {('coco', 'img'): {'train': data}}}, P)
+        before = m.arena().master.clone()
+        for _ in range(4):                      # 3 batches per epoch: the fourth call re-creates the iterator
+            if pretrain:
+                tr.pretrain_rel_step('coco', 'img')
+            else:
+                tr.rel_step('coco', 'img', 1.0, 1.0)
+            tr.iter()
+        torch.cuda.synchronize()
+        assert tr.n_sentences == 4 * 2 * P.batch_size and tr.stats['processed_s'] == 4 * 2 * 2 * k
+        assert torch.isfinite(m.arena().master).all() and not torch.equal(before, m.arena().master)
+        keys = {'t2i-coco', 'i2t-coco'} | ({'CMLM-coco', 'MRM-coco', 'MRFR-coco', 'CLCM-coco'} if pretrain else set())
+        assert all(len(tr.stats[s]) > 0 for s in keys), {s: len(tr.stats.get(s, [])) for s in keys}
