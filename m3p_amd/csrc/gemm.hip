@@ -683,6 +683,286 @@ void gemm_nt_ring_kernel(const bf16* __restrict__ A, int lda, const bf16* __rest
 #undef M3P_LGKM0
 }
 
+
+// ---------------------------------------------------------------------------------
+// NT kernel, "w8" version: 256x256 output tile, EIGHT waves (2 x 4), 128x64 per wave, two 64-KB LDS stages.
+// tools/gemm_timeline.py on the four-wave kernel: a wave alone on its SIMD loses ~32 clocks of matrix pipe to each of its
+// 16 LDS-DMA instructions per K-tile and issues 16x16x32 MFMAs every ~18 clocks instead of 16 - 29 % of the K loop - and
+// pays the whole epilogue (20 % of a K = 768 launch) with the pipe idle; neither depends on the MFMA shape.  With two
+// waves per SIMD the partner's MFMAs fill those holes.  What made the earlier eight-wave kernels LDS-bound was 64x64 per
+// wave (256 KB of fragment reads per K-tile and CU); 128x64 per wave reads 192 KB (94 B/clk/CU over the 2048 clocks of a
+// K-tile) and halves the LDS-DMAs per wave (8 per K-tile).  This is the geometry the CDNA4 guide's 256^2 template runs.
+// Pipeline per K-tile (one barrier): read k-step 1 | 32 MFMAs on k-step 0 | lgkm, vmcnt(0) (K-tile +1 was requested one
+// full K-tile ago), s_barrier | request K-tile +2 into the stage just vacated | read k-step 0 of K-tile +1 | 32 MFMAs on
+// k-step 1.  The epilogue stages through the vacated stage (the request for K-tile +2 waits for it on an output tile's
+// last K-tile).  128 accumulator + 96 fragment registers per lane: the compiler's allocation (no literal AGPR numbers).
+// ---------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(512)
+void gemm_nt_w8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ W, int ldw,
+                       bf16* __restrict__ C, int ldc, int M, int N, int K, M3PEpilogue ep,
+                       int tiles_m, int tiles_n) {
+  constexpr int BM = 256, BN = 256, NWAVES = 8;
+  constexpr int A_BYTES = BM * ROWB, STAGE = (BM + BN) * ROWB;      // 32 KB, 64 KB
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntiles = tiles_m * tiles_n;
+  const int n_strips = (tiles_n >= 12) ? (tiles_n + 3) / 4 : 1;
+  const int strip_w = (tiles_n + n_strips - 1) / n_strips;
+  auto split_tile = [&](int t, int& tm, int& tn) {
+    const int strip = t / (tiles_m * strip_w);
+    const int rem = t - strip * tiles_m * strip_w;
+    const int bn = min(strip_w, tiles_n - strip * strip_w);
+    tm = rem / bn;
+    tn = strip * strip_w + (rem - tm * bn);
+  };
+  const int nwg = gridDim.x;
+  const int per_xcd = nwg >> 3;
+  const int slot = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  auto tile_of = [&](int q) { return q * nwg + slot; };
+  const int my_tiles = (ntiles > slot) ? (ntiles - slot + nwg - 1) / nwg : 0;
+  if (my_tiles == 0) return;
+  float* gtab = (EPI == M3P_EPI_DGELU && M3P_DGELU_LUT) ? reinterpret_cast<float*>(smem + 2 * STAGE) : nullptr;
+  if (EPI == M3P_EPI_DGELU && M3P_DGELU_LUT) gelu_grad_table_fill(gtab, tid, 512);
+  const int nk = K / BK;
+  const int total = my_tiles * nk;
+
+  // ---- load cursor: one LDS-DMA = 8 rows x 128 B; piece i of wave w covers row group w + 8 i of an operand
+  //      (lane -> row l >> 3, LDS slot l & 7, source chunk slot ^ (row & 7)); groups are 64 rows apart
+  const int sr = lane >> 3, sc = (lane & 7) ^ sr;
+  const bf16* a_src;
+  const bf16* w_src;
+  const size_t a_step = (size_t)64 * lda, w_step = (size_t)64 * ldw;
+  int l_q = 0, l_kt = 0;
+  auto set_load_tile = [&](int q) {
+    int tm, tn;
+    split_tile(tile_of(q), tm, tn);
+    a_src = A + (size_t)(tm * BM + wid * 8 + sr) * lda + sc * 8;
+    w_src = W + (size_t)(tn * BN + wid * 8 + sr) * ldw + sc * 8;
+  };
+  auto issue_load = [&](int s, int piece) {
+    char* sa = smem + s * STAGE;
+    const int k0 = l_kt * BK;
+    if (piece < 4)
+      __builtin_amdgcn_global_load_lds(GLB_PTR(a_src + piece * a_step + k0), LDS_PTR(sa + (wid + piece * NWAVES) * 1024), 16, 0, 0);
+    else
+      __builtin_amdgcn_global_load_lds(GLB_PTR(w_src + (piece - 4) * w_step + k0), LDS_PTR(sa + A_BYTES + (wid + (piece - 4) * NWAVES) * 1024), 16, 0, 0);
+  };
+  auto load_done = [&]() {
+    if (++l_kt == nk) { l_kt = 0; ++l_q; if (l_q < my_tiles) set_load_tile(l_q); }
+  };
+  auto stage_next = [&](int s) {
+#pragma unroll
+    for (int pc = 0; pc < 8; ++pc) issue_load(s, pc);
+    load_done();
+  };
+
+  // ---- fragment addressing (128-B rows, chunk ^= row & 7): A fragment i at + i * 2048, W fragment j at + j * 2048
+  const int wm = wid >> 2, wn = wid & 3;
+  const int fr = lane & 15, fg = lane >> 4;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  uint32_t a_addr[2], b_addr[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int ch = ((fg + 4 * ks) ^ (fr & 7)) * 16;
+    a_addr[ks] = lds0 + (wm * 128 + fr) * ROWB + ch;
+    b_addr[ks] = lds0 + A_BYTES + (wn * 64 + fr) * ROWB + ch;
+  }
+#define W8_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
+  // fragments are fetched a QUARTER K-tile (16 MFMAs) ahead: four W fragments per k-step, four A fragments per half
+  // (64 fragment registers instead of the 96 of a whole k-step ahead - with 128 accumulators that is the difference
+  // between fitting the 256 registers two waves per SIMD leave and spilling inside the K loop)
+  auto read_w = [&](uint32_t ba, bf16x8 (&wf)[4]) {
+    W8_DSR(wf[0], ba, 0); W8_DSR(wf[1], ba, 2048); W8_DSR(wf[2], ba, 4096); W8_DSR(wf[3], ba, 6144);
+  };
+  auto read_a_lo = [&](uint32_t aa, bf16x8 (&af)[4]) {
+    W8_DSR(af[0], aa, 0); W8_DSR(af[1], aa, 2048); W8_DSR(af[2], aa, 4096); W8_DSR(af[3], aa, 6144);
+  };
+  auto read_a_hi = [&](uint32_t aa, bf16x8 (&af)[4]) {
+    W8_DSR(af[0], aa, 8192); W8_DSR(af[1], aa, 10240); W8_DSR(af[2], aa, 12288); W8_DSR(af[3], aa, 14336);
+  };
+#define W8_LGKM0() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#ifndef M3P_W8_SETPRIO
+#define M3P_W8_SETPRIO 1
+#endif
+#ifndef M3P_W8_SPREAD
+#define M3P_W8_SPREAD 1
+#endif
+#ifndef M3P_W8_INTERLEAVE
+#define M3P_W8_INTERLEAVE 0
+#endif
+  // (ld_s, ld_p0, ld_n): with M3P_W8_INTERLEAVE the quarter's LDS-DMA pieces ld_p0 .. ld_p0 + ld_n - 1 (stage ld_s) are
+  //  issued one after every fourth MFMA instead of in front of the cluster
+  auto mfma_q = [&](auto half_c, const bf16x8 (&af)[4], const bf16x8 (&wf)[4], int ld_s = 0, int ld_p0 = 0, int ld_n = 0) {
+    constexpr int I0 = 4 * decltype(half_c)::value;
+    if (M3P_W8_SETPRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[I0 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[I0 + i][j], 0, 0, 0);
+      if (M3P_W8_INTERLEAVE && i < ld_n) {
+        __builtin_amdgcn_sched_barrier(0);
+        issue_load(ld_s, ld_p0 + i);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (M3P_W8_SETPRIO) __builtin_amdgcn_s_setprio(0);
+  };
+  using H0 = std::integral_constant<int, 0>;
+  using H1 = std::integral_constant<int, 1>;
+
+  // ---- prologue: K-tiles 0 and 1 into stages 0 and 1
+  set_load_tile(0);
+  stage_next(0);
+  if (total > 1) {
+    stage_next(1);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  bf16x8 fa0[4], fa1[4], fw0[4], fw1[4];
+  read_w(b_addr[0], fw0);
+  read_a_lo(a_addr[0], fa0);
+  W8_LGKM0();
+  int c_q = 0, c_kt = 0;
+  const bool io_aligned = ((ldc & 7) == 0) && (((uintptr_t)C & 15) == 0) &&
+                          (!(EPI == M3P_EPI_BIAS_GELU) || (((ep.ld_out2 & 7) == 0) && (((uintptr_t)ep.out2 & 15) == 0))) &&
+                          (!ep.bias || (((uintptr_t)ep.bias & 15) == 0)) &&
+                          (!ep.aux || (((ep.ld_aux & 7) == 0) && (((uintptr_t)ep.aux & 15) == 0)));
+  f32x4 csum[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) csum[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int csum_nw = -1;
+  auto flush_csum = [&]() {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float sfl = csum[j][r];
+        sfl += __shfl_xor(sfl, 1, 64); sfl += __shfl_xor(sfl, 2, 64);
+        sfl += __shfl_xor(sfl, 4, 64); sfl += __shfl_xor(sfl, 8, 64);
+        const int n = csum_nw + j * 16 + fg * 4 + r;
+        if (fr == 0 && n < N) unsafeAtomicAdd(ep.colsum + n, sfl);
+        csum[j][r] = 0.f;
+      }
+  };
+  bool spread_pending = false;
+  for (int step = 0; step < total; ++step) {
+    const int cur = step & 1, nxt = cur ^ 1;
+    const bool last_kt = (c_kt + 1 == nk);
+    const bool more2 = (step + 2 < total);
+    const uint32_t so = cur * STAGE;
+    const bool pend = M3P_W8_SPREAD && spread_pending;      // the request for K-tile +1 started in the previous quarter 3
+    // quarter 0: k-step 0, rows 0-63 | fetch k-step 0, rows 64-127
+    if (pend && !M3P_W8_INTERLEAVE) { issue_load(nxt, 3); issue_load(nxt, 4); issue_load(nxt, 5); }
+    read_a_hi(a_addr[0] + so, fa1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_q(H0{}, fa0, fw0, nxt, 3, pend ? 3 : 0);
+    W8_LGKM0();
+    // quarter 1: k-step 0, rows 64-127 | fetch k-step 1: W and rows 0-63
+    if (pend && !M3P_W8_INTERLEAVE) { issue_load(nxt, 6); issue_load(nxt, 7); }
+    read_w(b_addr[1] + so, fw1);
+    read_a_lo(a_addr[1] + so, fa0);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_q(H1{}, fa1, fw0, nxt, 6, pend ? 2 : 0);
+    if (pend) { load_done(); spread_pending = false; }
+    W8_LGKM0();
+    // quarter 2: k-step 1, rows 0-63 | fetch k-step 1, rows 64-127 (the last LDS read of this K-tile)
+    read_a_hi(a_addr[1] + so, fa1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_q(H0{}, fa0, fw1);
+    // every LDS read of this K-tile is complete and K-tile +1, requested one K-tile ago, has landed for this wave
+    W8_LGKM0();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    // quarter 3: k-step 1, rows 64-127 | request K-tile +2 into the vacated stage | fetch K-tile +1's first fragments
+    // (on an output tile's last K-tile both wait for the epilogue, which stages through that stage and wants the registers)
+    const bool req = more2 && !last_kt;
+    if (req) {
+      if (!M3P_W8_SPREAD) stage_next(cur);
+      else if (!M3P_W8_INTERLEAVE) { issue_load(cur, 0); issue_load(cur, 1); issue_load(cur, 2); }
+      if (M3P_W8_SPREAD) spread_pending = true;
+    }
+    if (step + 1 < total && !last_kt) {
+      read_w(b_addr[0] + nxt * STAGE, fw0);
+      read_a_lo(a_addr[0] + nxt * STAGE, fa0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_q(H1{}, fa1, fw1, cur, 0, (req && M3P_W8_SPREAD) ? 3 : 0);
+    W8_LGKM0();
+
+    if (++c_kt == nk) {
+      // ---- epilogue of output tile c_q through the vacated stage `cur`
+      c_kt = 0;
+      const int t = tile_of(c_q);
+      ++c_q;
+      int tm, tn;
+      split_tile(t, tm, tn);
+      const int m0 = tm * BM, n0 = tn * BN;
+      const int mw = m0 + wm * 128, nw = n0 + wn * 64;
+      if ((EPI == M3P_EPI_DGELU || EPI == M3P_EPI_MUL) && ep.colsum && csum_nw != nw) {
+        if (csum_nw >= 0) flush_csum();
+        csum_nw = nw;
+      }
+      const bool fast = io_aligned && (m0 + BM <= M) && (n0 + BN <= N);
+      if (fast) {
+        char* r1 = smem + cur * STAGE + wid * 6144;
+        f32x4 biasv[4];
+        load_bias4<EPI>(ep, nw, lane, biasv);
+#pragma unroll
+        for (int hf = 0; hf < 4; ++hf) {
+          f32x4 rows[2][4];
+#pragma unroll
+          for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rows[ii][j] = acc[2 * hf + ii][j];
+          bf16x4 auxv[2][4];
+          load_aux_rows<EPI>(ep, mw + 32 * hf, nw, lane, r1, auxv);
+          epilogue_half<EPI>(ep, C, ldc, N, mw + 32 * hf, nw, r1, rows, biasv, auxv, lane, csum, gtab);
+          __builtin_amdgcn_sched_barrier(0);      // one piece at a time: hoisted loads of the next piece cost registers
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            epilogue_store<EPI>(ep, C, ldc, M, N, mw + i * 16 + fr, nw + j * 16 + fg * 4, acc[i][j], csum[j]);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (step + 1 < total) {
+        // the staging rows are where K-tile +2 goes: nobody requests it before every wave is done with its round trip
+        W8_LGKM0();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (more2) stage_next(cur);
+        read_w(b_addr[0] + nxt * STAGE, fw0);
+        read_a_lo(a_addr[0] + nxt * STAGE, fa0);
+        W8_LGKM0();
+      }
+    }
+  }
+  if ((EPI == M3P_EPI_DGELU || EPI == M3P_EPI_MUL) && ep.colsum && csum_nw >= 0) flush_csum();
+#undef W8_DSR
+#undef W8_LGKM0
+}
+
 struct WgCursor {
   int c, t, mt, len;   // chunk, tile, K-tile inside the chunk, K-tiles in this chunk
 };
@@ -1329,7 +1609,25 @@ int launch_nt(const bf16* A, int lda, const bf16* W, int ldw, bf16* C, int ldc, 
   // kernel: K=3072,N=768 1000 vs 855 TF; N=3072,K=768 910 vs 815; 768x768 980 vs 925); ragged
   // shapes and the vocabulary projection's m-fast order stay on the ring kernel
   const bool deep = (N >= 512) && (2LL * N * K <= (64LL << 20)) && EPI != M3P_EPI_DGELU;   // (dGELU epilogue: 240 VGPRs there, measured slower in the step)
-  if (M >= 1024 && (g_variant == 2 || (g_variant == 1 && deep)) && (K % 64) == 0 && (lda % 8) == 0 && (ldw % 8) == 0 &&
+  if (M >= 1024 && (g_variant == 1 || g_variant == 6) && (N >= 512) && (2LL * N * K <= (64LL << 20)) && (K % 64) == 0 && (lda % 8) == 0 &&
+      (ldw % 8) == 0 && (M % 256) == 0 && (N % 256) == 0) {
+    const int tiles_m = M / 256, tiles_n = N / 256;
+    const size_t lds = 2 * 512 * ROWB + (EPI == M3P_EPI_DGELU && M3P_DGELU_LUT ? GELU_TAB_N * sizeof(float) : 0);
+    auto kern = gemm_nt_w8_kernel<EPI>;
+    static bool attr_set8 = false;
+    if (!attr_set8) {
+      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return (int)e;
+      attr_set8 = true;
+    }
+    int grid = num_cus();
+    const int ntiles = tiles_m * tiles_n;
+    if (ntiles < grid) grid = (ntiles + 7) / 8 * 8;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_m, tiles_n);
+    M3P_CHECK_LAUNCH();
+    return M3P_OK;
+  }
+  if (M >= 1024 && (g_variant == 2 || ((g_variant == 1 || g_variant == 7) && deep)) && (K % 64) == 0 && (lda % 8) == 0 && (ldw % 8) == 0 &&
       (M % 256) == 0 && (N % 256) == 0) {
     constexpr int BM = 256, BN = 256;
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;

@@ -150,10 +150,13 @@ def test_gemm_nt_streamk(M, N, K):
     assert rel_l2(out, ref) < 1e-5
 
 
-@pytest.mark.parametrize('M,N,K', [(1024, 768, 3072), (1024 + 40, 1000, 128), (2560, 512, 2304), (1300, 2304 + 8, 1536)])
-def test_gemm_nt_four_wave_kernel(M, N, K):
-    """The 256x256 four-wave kernel (deep-K shapes pick it automatically) against the fp32 product,
-    every epilogue, full and ragged tiles; forced through the developer switch so shallow K runs it too."""
+@pytest.mark.parametrize('variant', [2, 6])
+@pytest.mark.parametrize('M,N,K', [(1024, 768, 3072), (1024 + 40, 1000, 128), (2560, 512, 2304), (1300, 2304 + 8, 1536),
+                                   (1280, 2304, 768), (4096, 768, 768), (8192, 3072, 768)])
+def test_gemm_nt_256x256_kernels(M, N, K, variant):
+    """The 256x256-tile kernels (variant 2: four waves of 128x128; variant 6: eight waves of 128x64) against the fp32
+    product, every epilogue, full and ragged tiles; forced through the developer switch so every shape runs them
+    (shapes a kernel does not take fall through to the next one, as in production)."""
     from m3p_amd import ops, rng, lib as L
     lib = L.load()
     a, ac = randn_bf16((M, K), 1)
@@ -161,7 +164,7 @@ def test_gemm_nt_four_wave_kernel(M, N, K):
     bias, bc = randn_f32((N,), 3)
     r, rc = randn_bf16((M, N), 4)
     prod = ac @ wc.t()
-    lib.m3p_debug_set_variant(2)
+    lib.m3p_debug_set_variant(variant)
     try:
         c = ops.gemm_nt(a, w, L.EPI_NONE)
         assert rel_l2(c.float(), prod) < 4e-3
