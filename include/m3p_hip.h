@@ -67,6 +67,8 @@ typedef struct M3PEpilogue {
   uint32_t seed;      /* dropout stream key (DROP_RES)                                 */
   uint32_t thresh24;  /* drop iff (hash >> 8) < thresh24; 0 = no dropout               */
   float inv_keep;     /* 1 / (1 - p)                                                   */
+  const float* descale_a;  /* m3p_gemm_nt_fp8 only: device scalars, the accumulators are multiplied by    */
+  const float* descale_b;  /* (*descale_a) * (*descale_b) (NULL = 1) before the epilogue                  */
 } M3PEpilogue;
 
 /* C[M,N] (bf16, row pitch ldc) = epilogue( A[M,K] (bf16, pitch lda) x W[N,K]^T (bf16, pitch ldw) ).
@@ -78,6 +80,21 @@ typedef struct M3PEpilogue {
  * Requires K % 64 == 0, lda/ldw % 8 == 0, ldc % 4 == 0, 16-byte aligned bases. */
 M3P_API int m3p_gemm_nt_bf16(const void* A, int lda, const void* W, int ldw, void* C, int ldc,
                              int M, int N, int K, int epilogue, const M3PEpilogue* ep, void* stream);
+
+/* The same contraction with 8-bit operands on the K = 128 MFMA (BASELINE configs[3], "fp8 MFMA GEMMs"):
+ * C[M,N] (bf16) = epilogue( (*ep->descale_a) * (*ep->descale_b) * A8[M,K] x W8[N,K]^T ), fp32 accumulate.
+ * A8: OCP fp8 e4m3, or bf8 e5m2 when a_is_bf8 (gradients); W8: fp8 e4m3; row pitches lda / ldw in BYTES.
+ * Operands come from m3p_quant_fp8 (per-tensor scale, delayed: m3p_amd/fp8.py).  Epilogues NONE, BIAS, BIAS_DROP_RES,
+ * RES, DGELU.  Requires M % 256 == 0, N % 256 == 0, K % 128 == 0, lda/ldw % 16 == 0, ldc % 8 == 0, 16-byte bases. */
+M3P_API int m3p_gemm_nt_fp8(const void* A8, int lda, int a_is_bf8, const void* W8, int ldw, void* C, int ldc,
+                            int M, int N, int K, int epilogue, const M3PEpilogue* ep, void* stream);
+
+/* Per-tensor quantisation for the above: dst[r, c] (8-bit, pitch ld_dst bytes) = sat(src[r, c] * (*scale)) for a bf16
+ * matrix [rows, cols] (pitch ld_src elements), format e4m3 (bf8 = 0, saturates at +-448) or e5m2 (bf8 = 1, +-57344),
+ * round to nearest even; *amax (fp32, device) is raised to max |src| (atomic max over the launch; the caller zeroes it).
+ * scale NULL = 1.  cols % 8 == 0, ld_src % 8 == 0, ld_dst % 8 == 0. */
+M3P_API int m3p_quant_fp8(const void* src, int ld_src, void* dst, int ld_dst, int rows, int cols, const float* scale,
+                          float* amax, int bf8, void* stream);
 
 /* Stream-K variant with fp32 accumulate output: Cf[M,N] (fp32, pitch ldc) += alpha * A Wᵀ.
  * For few-tile / very-long-K problems — the data gradient of the tied vocabulary
@@ -323,6 +340,10 @@ M3P_API int m3p_transpose_bf16(const void* src, void* dst, int rows, int cols, i
  * ---------------------------------------------------------------------------------- */
 M3P_API int m3p_probe_mfma_16x16x32(const void* a_rowmajor_16x32, const void* b_colmajor_32x16,
                                     float* d_16x16, int* d_rowcol, void* stream);
+/* v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales: a, w row-major 8-bit [16,128] (a: fp8 e4m3, or bf8 e5m2
+ * when a_is_bf8; w: fp8 e4m3), d fp32 [16,16] = a w^T written through the 16x16 result map */
+M3P_API int m3p_probe_mfma_fp8_16x16x128(const void* a_16x128, const void* w_16x128, float* d_16x16, int a_is_bf8,
+                                         void* stream);
 M3P_API int m3p_probe_tr16(const void* tile_bf16_64x16, void* out_64x4, void* stream);
 
 #ifdef __cplusplus

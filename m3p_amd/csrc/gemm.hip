@@ -963,6 +963,281 @@ void gemm_nt_w8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
 #undef W8_LGKM0
 }
 
+// ---------------------------------------------------------------------------------
+// fp8 NT kernel (BASELINE configs[3]: fp8 MFMA GEMMs): the eight-wave 256x256 kernel above with 8-bit operands on
+// v_mfma_scale_f32_16x16x128_f8f6f4 (block scales fixed at 1: gfx950 has no unscaled K = 128 form; per-tensor scales are
+// applied to the accumulators).  C (bf16) = epilogue(descale_a * descale_b * A8[M,K] x W8[N,K]^T).
+// An LDS row is again 128 bytes - now 128 contraction elements - so staging, swizzle and fragment addresses are the
+// bf16 kernel's; what was two 16-byte k-steps there is ONE MFMA operand here: lane group g = lane >> 4 holds the 16-byte
+// chunks g and g + 4 of its row (the contraction order is permuted identically for both operands, which a sum does not
+// see).  32 MFMAs of 32 clocks per K-tile and wave; quarters of 8 MFMAs (two A tiles x four W tiles) with the next
+// quarter's A fragments - and, in the last quarter, the next K-tile's W fragments - fetched underneath: 96 fragment registers.
+// A_BF8: the A operand is bf8 (e5m2, gradients); W is fp8 (e4m3) always.
+// ---------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+template <int EPI, bool A_BF8>
+__global__ __launch_bounds__(512)
+void gemm_nt_w8f8_kernel(const uint8_t* __restrict__ A, int lda, const uint8_t* __restrict__ W, int ldw,
+                         bf16* __restrict__ C, int ldc, int M, int N, int K, M3PEpilogue ep,
+                         int tiles_m, int tiles_n) {
+  constexpr int BM = 256, BN = 256, NWAVES = 8, BK8 = 128;
+  constexpr int A_BYTES = BM * ROWB, STAGE = (BM + BN) * ROWB;      // 32 KB, 64 KB
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntiles = tiles_m * tiles_n;
+  const int n_strips = (tiles_n >= 12) ? (tiles_n + 3) / 4 : 1;
+  const int strip_w = (tiles_n + n_strips - 1) / n_strips;
+  auto split_tile = [&](int t, int& tm, int& tn) {
+    const int strip = t / (tiles_m * strip_w);
+    const int rem = t - strip * tiles_m * strip_w;
+    const int bn = min(strip_w, tiles_n - strip * strip_w);
+    tm = rem / bn;
+    tn = strip * strip_w + (rem - tm * bn);
+  };
+  const int nwg = gridDim.x;
+  const int per_xcd = nwg >> 3;
+  const int slot = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  auto tile_of = [&](int q) { return q * nwg + slot; };
+  const int my_tiles = (ntiles > slot) ? (ntiles - slot + nwg - 1) / nwg : 0;
+  if (my_tiles == 0) return;
+  float* gtab = (EPI == M3P_EPI_DGELU && M3P_DGELU_LUT) ? reinterpret_cast<float*>(smem + 2 * STAGE) : nullptr;
+  if (EPI == M3P_EPI_DGELU && M3P_DGELU_LUT) gelu_grad_table_fill(gtab, tid, 512);
+  const int nk = K / BK8;
+  const int total = my_tiles * nk;
+  // per-tensor scales of the two operands (device scalars: delayed scaling keeps them on the device)
+  const float dsc = (ep.descale_a ? *ep.descale_a : 1.f) * (ep.descale_b ? *ep.descale_b : 1.f);
+
+  const int sr = lane >> 3, sc = (lane & 7) ^ sr;
+  const uint8_t* a_src;
+  const uint8_t* w_src;
+  const size_t a_step = (size_t)64 * lda, w_step = (size_t)64 * ldw;
+  int l_q = 0, l_kt = 0;
+  auto set_load_tile = [&](int q) {
+    int tm, tn;
+    split_tile(tile_of(q), tm, tn);
+    a_src = A + (size_t)(tm * BM + wid * 8 + sr) * lda + sc * 16;
+    w_src = W + (size_t)(tn * BN + wid * 8 + sr) * ldw + sc * 16;
+  };
+  auto issue_load = [&](int s, int piece) {
+    char* sa = smem + s * STAGE;
+    const int k0 = l_kt * BK8;
+    if (piece < 4)
+      __builtin_amdgcn_global_load_lds(GLB_PTR(a_src + piece * a_step + k0), LDS_PTR(sa + (wid + piece * NWAVES) * 1024), 16, 0, 0);
+    else
+      __builtin_amdgcn_global_load_lds(GLB_PTR(w_src + (piece - 4) * w_step + k0), LDS_PTR(sa + A_BYTES + (wid + (piece - 4) * NWAVES) * 1024), 16, 0, 0);
+  };
+  auto load_done = [&]() {
+    if (++l_kt == nk) { l_kt = 0; ++l_q; if (l_q < my_tiles) set_load_tile(l_q); }
+  };
+  auto stage_next = [&](int s) {
+#pragma unroll
+    for (int pc = 0; pc < 8; ++pc) issue_load(s, pc);
+    load_done();
+  };
+
+  const int wm = wid >> 2, wn = wid & 3;
+  const int fr = lane & 15, fg = lane >> 4;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  uint32_t a_addr[2], b_addr[2];        // the two 16-byte chunks (fg, fg + 4) of this lane's row
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int ch = ((fg + 4 * ks) ^ (fr & 7)) * 16;
+    a_addr[ks] = lds0 + (wm * 128 + fr) * ROWB + ch;
+    b_addr[ks] = lds0 + A_BYTES + (wn * 64 + fr) * ROWB + ch;
+  }
+  // an 8-register MFMA operand = two 16-byte LDS reads into the halves of one register tuple (plain loads: the
+  // register allocator then places the halves adjacently; inline-asm reads into two 4-register values cost a copy each)
+  typedef i32x8 Frag;
+  auto frag = [&](uint32_t o0, uint32_t o1) {
+    const i32x4 lo = *reinterpret_cast<const i32x4*>(smem + o0), hi = *reinterpret_cast<const i32x4*>(smem + o1);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+  auto read_w = [&](uint32_t so, Frag (&wf)[4]) {
+    const uint32_t b0 = b_addr[0] - lds0 + so, b1 = b_addr[1] - lds0 + so;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wf[j] = frag(b0 + j * 2048, b1 + j * 2048);
+  };
+  auto read_a = [&](auto q_c, uint32_t so, Frag (&af)[2]) {       // A tiles 2q, 2q + 1
+    constexpr int Q = decltype(q_c)::value;
+    const uint32_t a0 = a_addr[0] - lds0 + so + Q * 4096, a1 = a_addr[1] - lds0 + so + Q * 4096;
+    af[0] = frag(a0, a1);
+    af[1] = frag(a0 + 2048, a1 + 2048);
+  };
+#define F8_LGKM0() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // (ld_s, ld_p0, ld_n): LDS-DMA pieces issued in front of the cluster (spread over the quarters like the bf16 kernel)
+  auto mfma_q = [&](auto q_c, const Frag (&af)[2], const Frag (&wf)[4]) {
+    constexpr int I0 = 2 * decltype(q_c)::value;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[I0 + i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[j], af[i], acc[I0 + i][j], 0, A_BF8 ? 1 : 0,
+                                                                          0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  using Q0 = std::integral_constant<int, 0>;
+  using Q1 = std::integral_constant<int, 1>;
+  using Q2 = std::integral_constant<int, 2>;
+  using Q3 = std::integral_constant<int, 3>;
+
+  set_load_tile(0);
+  stage_next(0);
+  if (total > 1) {
+    stage_next(1);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  Frag fa0[2], fa1[2], fw[4];
+  read_w(0, fw);
+  read_a(Q0{}, 0, fa0);
+  F8_LGKM0();
+  int c_q = 0;
+  const bool io_aligned = ((ldc & 7) == 0) && (((uintptr_t)C & 15) == 0) &&
+                          (!ep.bias || (((uintptr_t)ep.bias & 15) == 0)) &&
+                          (!ep.aux || (((ep.ld_aux & 7) == 0) && (((uintptr_t)ep.aux & 15) == 0)));
+  f32x4 csum[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) csum[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int csum_nw = -1;
+  auto flush_csum = [&]() {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float sfl = csum[j][r];
+        sfl += __shfl_xor(sfl, 1, 64); sfl += __shfl_xor(sfl, 2, 64);
+        sfl += __shfl_xor(sfl, 4, 64); sfl += __shfl_xor(sfl, 8, 64);
+        const int n = csum_nw + j * 16 + fg * 4 + r;
+        if (fr == 0 && n < N) unsafeAtomicAdd(ep.colsum + n, sfl);
+        csum[j][r] = 0.f;
+      }
+  };
+  bool spread_pending = false;
+  int step = 0;
+  // One K-tile.  LAST (compile time): the output tile's last K-tile - no request for K-tile +2 and no fragment prefetch
+  // (the epilogue stages through the vacated stage and wants the registers); peeling it keeps both bodies straight-line
+  // code (a run-time condition around the prefetch makes phi copies of 48 fragment registers and lets MFMAs sink).
+  auto ktile = [&](auto last_c) __attribute__((always_inline)) {
+    constexpr bool LAST = decltype(last_c)::value;
+    const int cur = step & 1, nxt = cur ^ 1;
+    const bool more2 = (step + 2 < total);
+    const uint32_t so = cur * STAGE;
+    const bool pend = spread_pending;
+    if (pend) { issue_load(nxt, 3); issue_load(nxt, 4); issue_load(nxt, 5); }
+    read_a(Q1{}, so, fa1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_q(Q0{}, fa0, fw);
+    F8_LGKM0();
+    if (pend) { issue_load(nxt, 6); issue_load(nxt, 7); load_done(); spread_pending = false; }
+    read_a(Q2{}, so, fa0);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_q(Q1{}, fa1, fw);
+    F8_LGKM0();
+    read_a(Q3{}, so, fa1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_q(Q2{}, fa0, fw);
+    F8_LGKM0();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (!LAST) {
+      if (more2) { issue_load(cur, 0); issue_load(cur, 1); issue_load(cur, 2); spread_pending = true; }
+      read_a(Q0{}, nxt * STAGE, fa0);           // (stale bytes after the very last K-tile: never used)
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // last quarter W-tile-major: the W fragments are single-buffered (a second set of 32 registers does not exist
+    // beside 128 accumulators), so W tile j of the next K-tile is fetched as soon as the two MFMAs that read tile j
+    // have been issued
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      acc[6][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fw[j], fa1[0], acc[6][j], 0, A_BF8 ? 1 : 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+      acc[7][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fw[j], fa1[1], acc[7][j], 0, A_BF8 ? 1 : 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+      if (!LAST) {
+        const uint32_t b0 = b_addr[0] - lds0 + nxt * STAGE + j * 2048, b1 = b_addr[1] - lds0 + nxt * STAGE + j * 2048;
+        fw[j] = frag(b0, b1);
+      }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    F8_LGKM0();
+    ++step;
+  };
+  for (int tq = 0; tq < my_tiles; ++tq) {
+    for (int kt = 0; kt + 1 < nk; ++kt) ktile(std::false_type{});
+    ktile(std::true_type{});
+    {
+      const int cur = (step - 1) & 1, nxt = cur ^ 1;
+      const bool more2 = (step + 1 < total);       // (step was advanced past the tile's last K-tile)
+      const bool more1 = (step < total);
+      const int t = tile_of(c_q);
+      ++c_q;
+      int tm, tn;
+      split_tile(t, tm, tn);
+      const int m0 = tm * BM, n0 = tn * BN;
+      const int mw = m0 + wm * 128, nw = n0 + wn * 64;
+      if ((EPI == M3P_EPI_DGELU || EPI == M3P_EPI_MUL) && ep.colsum && csum_nw != nw) {
+        if (csum_nw >= 0) flush_csum();
+        csum_nw = nw;
+      }
+      const bool fast = io_aligned && (m0 + BM <= M) && (n0 + BN <= N);
+      if (fast) {
+        char* r1 = smem + cur * STAGE + wid * 6144;
+        f32x4 biasv[4];
+        load_bias4<EPI>(ep, nw, lane, biasv);
+#pragma unroll
+        for (int hf = 0; hf < 4; ++hf) {
+          f32x4 rows[2][4];
+#pragma unroll
+          for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rows[ii][j] = acc[2 * hf + ii][j] * dsc;
+          bf16x4 auxv[2][4];
+          load_aux_rows<EPI>(ep, mw + 32 * hf, nw, lane, r1, auxv);
+          epilogue_half<EPI>(ep, C, ldc, N, mw + 32 * hf, nw, r1, rows, biasv, auxv, lane, csum, gtab);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            epilogue_store<EPI>(ep, C, ldc, M, N, mw + i * 16 + fr, nw + j * 16 + fg * 4, acc[i][j] * dsc, csum[j]);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (more1) {
+        F8_LGKM0();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (more2) stage_next(cur);
+        read_w(nxt * STAGE, fw);
+        read_a(Q0{}, nxt * STAGE, fa0);
+        F8_LGKM0();
+      }
+    }
+  }
+  if ((EPI == M3P_EPI_DGELU || EPI == M3P_EPI_MUL) && ep.colsum && csum_nw >= 0) flush_csum();
+#undef F8_LGKM0
+}
+
+
 struct WgCursor {
   int c, t, mt, len;   // chunk, tile, K-tile inside the chunk, K-tiles in this chunk
 };
@@ -2485,6 +2760,29 @@ void gemm_wgrad_ring_kernel(const bf16* __restrict__ dY, int lddy, const bf16* _
 
 }  // namespace
 
+namespace {
+template <int EPI, bool A_BF8>
+int launch_nt_fp8(const uint8_t* A, int lda, const uint8_t* W, int ldw, bf16* C, int ldc, int M, int N, int K,
+                         const M3PEpilogue& ep, hipStream_t st) {
+  const int tiles_m = M / 256, tiles_n = N / 256;
+  const size_t lds = 2 * 512 * ROWB + (EPI == M3P_EPI_DGELU && M3P_DGELU_LUT ? GELU_TAB_N * sizeof(float) : 0);
+  auto kern = gemm_nt_w8f8_kernel<EPI, A_BF8>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  int grid = num_cus();
+  const int ntiles = tiles_m * tiles_n;
+  if (ntiles < grid) grid = (ntiles + 7) / 8 * 8;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_m, tiles_n);
+  M3P_CHECK_LAUNCH();
+  return M3P_OK;
+}
+
+}  // namespace
+
 extern "C" {
 
 int m3p_gemm_nt_bf16(const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K,
@@ -2510,6 +2808,32 @@ int m3p_gemm_nt_bf16(const void* A, int lda, const void* W, int ldw, void* C, in
     case M3P_EPI_MUL: return launch_nt<M3P_EPI_MUL>(a, lda, w, ldw, c, ldc, M, N, K, ep, st);
     default: return M3P_EINVAL;
   }
+}
+
+int m3p_gemm_nt_fp8(const void* A, int lda, int a_is_bf8, const void* W, int ldw, void* C, int ldc, int M, int N, int K,
+                    int epilogue, const M3PEpilogue* ep_in, void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || (K % 128) != 0 || (lda % 16) != 0 || (ldw % 16) != 0 || (ldc % 8) != 0) return M3P_EINVAL;
+  if ((M % 256) != 0 || (N % 256) != 0) return M3P_EINVAL;       // full 256x256 tiles only (the encoder layers' shapes)
+  if (((uintptr_t)A & 15) || ((uintptr_t)W & 15) || ((uintptr_t)C & 15)) return M3P_EINVAL;
+  M3PEpilogue ep = {};
+  if (ep_in) ep = *ep_in;
+  if ((epilogue == M3P_EPI_BIAS_DROP_RES || epilogue == M3P_EPI_RES || epilogue == M3P_EPI_DGELU || epilogue == M3P_EPI_MUL) &&
+      (!ep.aux || (ep.ld_aux % 8) != 0))
+    return M3P_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const uint8_t* a = (const uint8_t*)A; const uint8_t* w = (const uint8_t*)W; bf16* c = (bf16*)C;
+#define M3P_F8_CASE(E)                                                                                        \
+  case E: return a_is_bf8 ? launch_nt_fp8<E, true>(a, lda, w, ldw, c, ldc, M, N, K, ep, st)                    \
+                          : launch_nt_fp8<E, false>(a, lda, w, ldw, c, ldc, M, N, K, ep, st)
+  switch (epilogue) {
+    M3P_F8_CASE(M3P_EPI_NONE);
+    M3P_F8_CASE(M3P_EPI_BIAS);
+    M3P_F8_CASE(M3P_EPI_BIAS_DROP_RES);
+    M3P_F8_CASE(M3P_EPI_RES);
+    M3P_F8_CASE(M3P_EPI_DGELU);
+    default: return M3P_ENOTIMPL;
+  }
+#undef M3P_F8_CASE
 }
 
 // debug (only with -DM3P_RING_TL): per-wave cycle sums of the last dGELU launch of the eight-wave kernel

@@ -106,6 +106,42 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
 #endif
 }
 
+// bf16 -> fp8 (e4m3) / bf8 (e5m2) with a per-tensor scale, saturating, + running max |x| for the next step's scale
+// (delayed scaling, m3p_amd/fp8.py).  8 elements (16 B in, 8 B out) per thread and iteration.
+template <bool BF8>
+__global__ __launch_bounds__(256) void quant_fp8_kernel(const bf16* __restrict__ src, int ld_src, uint8_t* __restrict__ dst, int ld_dst,
+                                                        int rows, int cols8, const float* __restrict__ scale, float* __restrict__ amax) {
+  const float s = scale ? *scale : 1.f;
+  constexpr float kMax = BF8 ? 57344.f : 448.f;
+  float mx = 0.f;
+  const size_t total = (size_t)rows * cols8;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / cols8), c = (int)(i - (size_t)r * cols8) * 8;
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + (size_t)r * ld_src + c);
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float x = (float)v[e];
+      mx = fmaxf(mx, fabsf(x));
+      f[e] = fminf(fmaxf(x * s, -kMax), kMax);
+    }
+    int w0 = 0, w1 = 0;
+    if (BF8) {
+      w0 = __builtin_amdgcn_cvt_pk_bf8_f32(f[0], f[1], w0, false); w0 = __builtin_amdgcn_cvt_pk_bf8_f32(f[2], f[3], w0, true);
+      w1 = __builtin_amdgcn_cvt_pk_bf8_f32(f[4], f[5], w1, false); w1 = __builtin_amdgcn_cvt_pk_bf8_f32(f[6], f[7], w1, true);
+    } else {
+      w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], w0, false); w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], w0, true);
+      w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], w1, false); w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], w1, true);
+    }
+    *reinterpret_cast<int2*>(dst + (size_t)r * ld_dst + c) = int2{w0, w1};
+  }
+  if (amax) {
+    mx = wave_max(mx);
+    // non-negative floats order like their bit patterns: an integer atomic max is a float max
+    if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(reinterpret_cast<unsigned int*>(amax), __float_as_uint(mx));
+  }
+}
+
 // dst[c][r] = src[r][c], 64x64 tiles through LDS; ld_dst >= rows (pad columns untouched)
 __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16* __restrict__ src, bf16* __restrict__ dst,
                                                              int rows, int cols, int ld_src, int ld_dst) {
@@ -244,6 +280,23 @@ int m3p_transpose_batch_bf16(const long long* desc, int n_desc, int max_tiles, v
   return M3P_OK;
 }
 
+
+int m3p_quant_fp8(const void* src, int ld_src, void* dst, int ld_dst, int rows, int cols, const float* scale, float* amax,
+                  int bf8, void* stream) {
+  if (rows <= 0 || cols <= 0 || (cols % 8) != 0 || (ld_src % 8) != 0 || (ld_dst % 8) != 0 || ld_src < cols || ld_dst < cols)
+    return M3P_EINVAL;
+  if (((uintptr_t)src & 15) || ((uintptr_t)dst & 7)) return M3P_EINVAL;
+  const size_t total = (size_t)rows * (cols / 8);
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  if (bf8)
+    hipLaunchKernelGGL(quant_fp8_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)src, ld_src,
+                       (uint8_t*)dst, ld_dst, rows, cols / 8, scale, amax);
+  else
+    hipLaunchKernelGGL(quant_fp8_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)src, ld_src,
+                       (uint8_t*)dst, ld_dst, rows, cols / 8, scale, amax);
+  M3P_CHECK_LAUNCH();
+  return M3P_OK;
+}
 
 int m3p_sumsq_f32(const float* g, long long n, double* out, void* stream) {
   if (n <= 0 || (n % 4) != 0 || ((uintptr_t)g & 15)) return M3P_EINVAL;

@@ -23,6 +23,20 @@ __global__ void probe_mfma_kernel(const bf16* __restrict__ a, const bf16* __rest
   }
 }
 
+// v_mfma_scale_f32_16x16x128_f8f6f4 (the fp8 GEMM's instruction; gfx950 has no unscaled K = 128 form): operand lane l
+// holds the 32 consecutive bytes X[l & 15][32 * (l >> 4) .. +32]; both block scales E8M0 = 127 (x 1.0); the result map
+// is the 16x16 one of the bf16 instruction.  FA / FW: 0 = fp8 e4m3, 1 = bf8 e5m2 (OCP encodings).
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+template <int FA, int FW>
+__global__ void probe_mfma_fp8_kernel(const unsigned char* __restrict__ a, const unsigned char* __restrict__ w, float* __restrict__ d) {
+  const int l = threadIdx.x;
+  const i32x8 af = *reinterpret_cast<const i32x8*>(a + (l & 15) * 128 + 32 * (l >> 4));
+  const i32x8 wf = *reinterpret_cast<const i32x8*>(w + (l & 15) * 128 + 32 * (l >> 4));
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(af, wf, acc, FA, FW, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+  for (int r = 0; r < 4; ++r) d[(4 * (l >> 4) + r) * 16 + (l & 15)] = acc[r];
+}
+
 __global__ void probe_tr16_kernel(const short* __restrict__ tile, short* __restrict__ out) {
   __shared__ __attribute__((aligned(16))) short lds[64 * 16];
   const int l = threadIdx.x;
@@ -44,6 +58,15 @@ const char* m3p_version(void) { return "m3p_hip 0.1 gfx950"; }
 
 int m3p_probe_mfma_16x16x32(const void* a, const void* w, float* d, int* rowcol, void* stream) {
   hipLaunchKernelGGL(probe_mfma_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const bf16*)a, (const bf16*)w, d, rowcol);
+  M3P_CHECK_LAUNCH();
+  return M3P_OK;
+}
+
+int m3p_probe_mfma_fp8_16x16x128(const void* a, const void* w, float* d, int a_is_bf8, void* stream) {
+  if (a_is_bf8)
+    hipLaunchKernelGGL((probe_mfma_fp8_kernel<1, 0>), dim3(1), dim3(64), 0, (hipStream_t)stream, (const unsigned char*)a, (const unsigned char*)w, d);
+  else
+    hipLaunchKernelGGL((probe_mfma_fp8_kernel<0, 0>), dim3(1), dim3(64), 0, (hipStream_t)stream, (const unsigned char*)a, (const unsigned char*)w, d);
   M3P_CHECK_LAUNCH();
   return M3P_OK;
 }

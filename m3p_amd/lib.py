@@ -26,6 +26,7 @@ class Epilogue(C.Structure):
         ('bias', C.c_void_p), ('aux', C.c_void_p), ('out2', C.c_void_p), ('colsum', C.c_void_p),
         ('ld_aux', C.c_int32), ('ld_out2', C.c_int32), ('scale_cols', C.c_int32), ('scale', C.c_float),
         ('alpha', C.c_float), ('seed', C.c_uint32), ('thresh24', C.c_uint32), ('inv_keep', C.c_float),
+        ('descale_a', C.c_void_p), ('descale_b', C.c_void_p),
     ]
 
 
@@ -35,6 +36,8 @@ _p, _i, _f, _u32 = C.c_void_p, C.c_int, C.c_float, C.c_uint32
 SIGNATURES = {
     'm3p_version': (C.c_char_p, []),
     'm3p_gemm_nt_bf16': (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, C.POINTER(Epilogue), _p]),
+    'm3p_gemm_nt_fp8': (_i, [_p, _i, _i, _p, _i, _p, _i, _i, _i, _i, _i, C.POINTER(Epilogue), _p]),
+    'm3p_quant_fp8': (_i, [_p, _i, _p, _i, _i, _i, _p, _p, _i, _p]),
     'm3p_gemm_nt_streamk_f32': (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _f, _p]),
     'm3p_gemm_nn_streamk_f32': (_i, [_p, _i, _p, _i, _i, _p, _i, _i, _i, _i, _f, _p]),
     'm3p_gemm_wgrad_workspace_bytes': (C.c_size_t, []),
@@ -65,6 +68,7 @@ SIGNATURES = {
     'm3p_transpose_batch_bf16': (_i, [_p, _i, _i, _p]),
     'm3p_transpose_bf16': (_i, [_p, _p, _i, _i, _i, _i, _p]),
     'm3p_probe_mfma_16x16x32': (_i, [_p, _p, _p, _p, _p]),
+    'm3p_probe_mfma_fp8_16x16x128': (_i, [_p, _p, _p, _i, _p]),
     'm3p_probe_tr16': (_i, [_p, _p, _p]),
 }
 

@@ -75,6 +75,52 @@ def gemm_nt(a, w, epilogue=L.EPI_NONE, bias=None, aux=None, out=None, out2=None,
     return out
 
 
+def quant_fp8(x, scale=None, amax=None, bf8=False, out=None):
+    """x bf16 [rows, cols] -> 8-bit [rows, cols] (uint8 storage): fp8 e4m3, or bf8 e5m2 when ``bf8``; multiplied by the
+    device scalar ``scale`` first, saturating; ``amax`` (device fp32 scalar, zeroed by the caller) is raised to max |x|."""
+    _chk_bf16(x)
+    rows, cols = x.shape
+    assert x.stride(1) == 1
+    if out is None:
+        out = torch.empty((rows, cols), dtype=torch.uint8, device=x.device)
+    rc = L.load().m3p_quant_fp8(x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), rows, cols, L.ptr(scale), L.ptr(amax),
+                                1 if bf8 else 0, L.stream())
+    L.check(rc, 'm3p_quant_fp8')
+    return out
+
+
+def gemm_nt_fp8(a8, w8, epilogue=L.EPI_NONE, a_is_bf8=False, descale_a=None, descale_b=None, bias=None, aux=None, out=None,
+                colsum=None, scale_cols=0, scale=1.0, seed=0, p_drop=0.0):
+    """C[M,N] (bf16) = epi(descale_a * descale_b * a8[M,K] @ w8[N,K]^T): 8-bit operands (uint8 storage) from quant_fp8,
+    descale_* device fp32 scalars (1 / the quantisation scales)."""
+    assert a8.dtype == torch.uint8 and w8.dtype == torch.uint8 and a8.is_cuda and w8.is_cuda
+    M, K = a8.shape
+    N = w8.shape[0]
+    assert w8.shape[1] == K and a8.stride(1) == 1 and w8.stride(1) == 1
+    _chk_bf16(aux, out)
+    if out is None:
+        out = torch.empty((M, N), dtype=BF16, device=a8.device)
+    ep = L.Epilogue()
+    ep.bias = L.ptr(bias)
+    ep.aux = L.ptr(aux)
+    ep.colsum = L.ptr(colsum)
+    ep.ld_aux = aux.stride(0) if aux is not None else 0
+    ep.scale_cols = scale_cols
+    ep.scale = scale
+    ep.alpha = 1.0
+    ep.seed = seed
+    ep.thresh24 = L.thresh24(p_drop)
+    ep.inv_keep = 1.0 / (1.0 - p_drop) if p_drop > 0 else 1.0
+    ep.descale_a = L.ptr(descale_a)
+    ep.descale_b = L.ptr(descale_b)
+    e0 = _prof_begin(('gemm_fp8/' + _EPI_NAMES[epilogue].split('/')[1], M, N, K))
+    rc = L.load().m3p_gemm_nt_fp8(a8.data_ptr(), a8.stride(0), 1 if a_is_bf8 else 0, w8.data_ptr(), w8.stride(0), out.data_ptr(),
+                                  out.stride(0), M, N, K, epilogue, C.byref(ep), L.stream())
+    L.check(rc, 'm3p_gemm_nt_fp8')
+    _prof_end(e0, ('gemm_fp8/' + _EPI_NAMES[epilogue].split('/')[1], M, N, K))
+    return out
+
+
 def gemm_nt_streamk(a, w, out_f32, alpha=1.0):
     """out_f32[M,N] (fp32) += alpha * a[M,K] @ w[N,K]^T  (stream-K, fp32 atomics)."""
     _chk_bf16(a, w)

@@ -23,6 +23,21 @@ def test_mfma_16x16x32_lane_maps():
     assert torch.equal(d.cpu(), ref), 'MFMA lane map differs from the documented one:\n%s\n%s' % (d.cpu(), ref)
 
 
+@pytest.mark.parametrize('a_is_bf8', [0, 1])
+def test_mfma_fp8_16x16x128_lane_maps(a_is_bf8):
+    from m3p_amd import lib as L
+    lib = L.load()
+    rs = np.random.RandomState(2 + a_is_bf8)
+    a = torch.from_numpy(rs.randint(-4, 5, size=(16, 128)).astype(np.float32))     # small integers: exact in e4m3 and e5m2
+    w = torch.from_numpy(rs.randint(-4, 5, size=(16, 128)).astype(np.float32))
+    ad = a.to(torch.float8_e5m2 if a_is_bf8 else torch.float8_e4m3fn).cuda()      # (named: a temporary would be freed and reused)
+    wd = w.to(torch.float8_e4m3fn).cuda()
+    d = torch.zeros(16, 16, dtype=torch.float32, device='cuda')
+    L.check(lib.m3p_probe_mfma_fp8_16x16x128(ad.data_ptr(), wd.data_ptr(), d.data_ptr(), a_is_bf8, L.stream()), 'probe')
+    torch.cuda.synchronize()
+    assert torch.equal(d.cpu(), a @ w.t()), 'fp8 MFMA lane map / format selector differs from the documented one'
+
+
 def test_ds_read_tr16_gather():
     from m3p_amd import lib as L
     lib = L.load()
