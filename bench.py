@@ -28,6 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md; 2:1-sparse figure excluded)
+PEAK_FP8_TFLOPS = 5000.0    # dense fp8 MFMA peak (same source)
 
 
 def flops_train_per_seq(d, L, T, R, V, n_pred):
@@ -38,17 +39,17 @@ def flops_train_per_seq(d, L, T, R, V, n_pred):
     return 6.0 * macs
 
 
-def build(cfg, dropout, world, rank, local_rank, refine_layers=0, ragged=False):
+def build(cfg, dropout, world, rank, local_rank, refine_layers=0, ragged=False, fp8=False, lr='0.0001'):
     from m3p_amd import synth
     from m3p_amd.model.transformer import TransformerModel
     from m3p_amd.trainer import XTrainer
     P = synth.model_params(cfg['emb_dim'], cfg['n_heads'], cfg['n_layers'], cfg['n_words'], dropout=dropout,
                            attention_dropout=dropout, refine_layers=refine_layers)
-    for k, v in dict(optimizer='adam_inverse_sqrt,beta1=0.9,beta2=0.98,lr=0.0001', clip_grad_norm=5, amp=1, fp16=True,
+    for k, v in dict(optimizer='adam_inverse_sqrt,beta1=0.9,beta2=0.98,lr=%s' % lr, clip_grad_norm=5, amp=1, fp16=True,
                      accumulate_gradients=1, multi_gpu=world > 1, local_rank=local_rank, epoch_size=100000,
                      cross_mlm_steps=[('google', 'img')], cross_mrm_steps=[], cross_mrfr_steps=[], cross_clcm_steps=[],
                      sample_n=2, refine_image=refine_layers > 0, multi_cls_loss_weight=0, bin_cls_loss_weight=1,
-                     batch_size=cfg['B'], dump_path='/nonexistent_m3p_dump').items():
+                     batch_size=cfg['B'], dump_path='/nonexistent_m3p_dump', fp8_gemm=fp8).items():
         setattr(P, k, v)
     torch.manual_seed(1234)   # identical random-init weights on every rank (then broadcast anyway)
     model = TransformerModel(P, is_encoder=True, with_output=True, is_crossModal=True).cuda()
@@ -167,6 +168,9 @@ def main():
     ap.add_argument('--refine-layers', type=int, default=0,
                     help='AoA refiner layers on the image rows (jointfwd refine_image=True; the reference default is 6). '
                          '0 = the README configuration the headline metric is quoted on')
+    ap.add_argument('--fp8', action='store_true',
+                    help='encoder-layer projections and their data gradients on the fp8 MFMA GEMM (BASELINE configs[3]; '
+                         'needs per-GPU batch x (T + R) to be a multiple of 256, e.g. --config cfg4 --batch 64)')
     args = ap.parse_args()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         _self_launch(args)
@@ -181,7 +185,7 @@ def main():
     torch.cuda.set_device(local_rank)
     cfg = dict(synth.CONFIGS[args.config])
     cfg['B'] = args.batch
-    trainer, tup = build(cfg, args.dropout, world, rank, local_rank, args.refine_layers, args.ragged)
+    trainer, tup = build(cfg, args.dropout, world, rank, local_rank, args.refine_layers, args.ragged, args.fp8)
     dp = trainer.model if world > 1 else None
 
     def step():
@@ -278,22 +282,25 @@ def main():
                     if traffic is not None:
                         tsrc = rel + ' (committed rocprofv3 --pmc passes of this command; not measured in this run)'
                         break
-            roof = dict(bound='mfma', achieved=round(ach, 1), peak=PEAK_BF16_TFLOPS, unit='TFLOP/s',
-                        frac=round(ach / PEAK_BF16_TFLOPS, 4), traffic=traffic, traffic_source=tsrc,
+            peak = PEAK_FP8_TFLOPS if kind.startswith('gemm_fp8') else PEAK_BF16_TFLOPS
+            roof = dict(bound='mfma', achieved=round(ach, 1), peak=peak, unit='TFLOP/s',
+                        frac=round(ach / peak, 4), traffic=traffic, traffic_source=tsrc,
                         kernel=kname, launches=cnt, avg_ms=round(avg_ms, 4),
                         gemm_time_share=round((gemm_ms_per_step * args.steps if ops.PROFILE_ONLY is not None else
                                                sum(v[0] for v in agg.values())) / (dt * 1e3), 3),
                         step_frac=round(value / world * fl / 1e12 / PEAK_BF16_TFLOPS, 4))
-        out = dict(metric='pre-train samples/sec (whole node), 12L/768d seq=128+36', value=round(value, 2),
+        metric = 'pre-train samples/sec (whole node), %dL/%dd seq=%d+%d' % (cfg['n_layers'], cfg['emb_dim'], cfg['T'], cfg['R'])
+        out = dict(metric=metric, value=round(value, 2),
                    unit='sequences/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
                    ms_per_step=round(dt / args.steps * 1e3, 3), higher_is_better=True, scaling='weak',
-                   vs_baseline=None, dtype='bf16', data='synthetic',
+                   vs_baseline=None, dtype='fp8 e4m3/e5m2 layer GEMMs, bf16 elsewhere' if args.fp8 else 'bf16', data='synthetic',
                    config=dict(workload='%s: %dL/%dd/%dh, %d regions + %d tokens, V=%d, %d MLM targets/seq + ITM BCE, '
                                         'dropout %.2f, adam_inverse_sqrt + clip 5%s'
                                         % (args.config, cfg['n_layers'], cfg['emb_dim'], cfg['n_heads'], cfg['R'], cfg['T'],
                                            cfg['n_words'], cfg['n_pred'], args.dropout,
                                            (' + %d AoA refiner layers (not in flops_train_per_seq)' % args.refine_layers
-                                            if args.refine_layers else '') + (', ragged text lengths U[T/2, T]' if args.ragged else '')),
+                                            if args.refine_layers else '') + (', ragged text lengths U[T/2, T]' if args.ragged else '')
+                                           + (', fp8 layer projections + data gradients' if args.fp8 else '')),
                                per_gpu_batch=cfg['B'], global_batch=cfg['B'] * world, seq_len=cfg['T'] + cfg['R'],
                                parallelism='dp%d' % world, flops_train_per_seq=fl, prewarm_steps=3 * groups),
                    roofline=roof)

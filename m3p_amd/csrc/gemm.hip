@@ -2831,6 +2831,7 @@ int m3p_gemm_nt_fp8(const void* A, int lda, int a_is_bf8, const void* W, int ldw
     M3P_F8_CASE(M3P_EPI_BIAS_DROP_RES);
     M3P_F8_CASE(M3P_EPI_RES);
     M3P_F8_CASE(M3P_EPI_DGELU);
+    M3P_F8_CASE(M3P_EPI_MUL);
     default: return M3P_ENOTIMPL;
   }
 #undef M3P_F8_CASE

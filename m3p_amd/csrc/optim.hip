@@ -136,9 +136,19 @@ __global__ __launch_bounds__(256) void quant_fp8_kernel(const bf16* __restrict__
     *reinterpret_cast<int2*>(dst + (size_t)r * ld_dst + c) = int2{w0, w1};
   }
   if (amax) {
+    // One candidate per workgroup, and only if it beats the value already there: thousands of same-address atomics
+    // from every wave cost ~200 us per launch (they serialise at the memory side), the filtered ones a few.
+    __shared__ float wmax[4];
     mx = wave_max(mx);
-    // non-negative floats order like their bit patterns: an integer atomic max is a float max
-    if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(reinterpret_cast<unsigned int*>(amax), __float_as_uint(mx));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      mx = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+      unsigned int* slot = reinterpret_cast<unsigned int*>(amax);
+      // non-negative floats order like their bit patterns: an integer atomic max is a float max.  The plain read may be
+      // stale (another XCD's L2) - then it is too small and the atomic merely runs without effect.
+      if (__float_as_uint(mx) > __builtin_nontemporal_load(slot)) atomicMax(slot, __float_as_uint(mx));
+    }
   }
 }
 

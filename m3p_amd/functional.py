@@ -77,6 +77,7 @@ class Arena:
         self._cast_version = -1
         self._transposes_stale = True
         self._tdesc = None
+        self.epoch = 0          # bumped whenever the weights change (load / cast / optimizer step): 8-bit copies key on it
         self.grads_known_zero = True
         self.touched = set()   # names of parameters that received gradient since the last zero_grad
         self._layer_names = [[n for n in self.names if n.startswith(('attentions.%d.' % i, 'layer_norm1.%d.' % i,
@@ -141,11 +142,13 @@ class Arena:
     def mark_master_changed(self):
         self._cast_version = -1
         self._transposes_stale = True
+        self.epoch += 1
 
     def mark_updated_by_fused_optimizer(self):
         """Adam wrote master and w16 together through raw pointers: only transposes are stale."""
         self._cast_version = self.master._version
         self._transposes_stale = True
+        self.epoch += 1
 
     def refresh(self):
         if self._cast_version != self.master._version:
@@ -350,26 +353,42 @@ class EncoderFn(torch.autograd.Function):
 
         saved_layers = []
         qscale = 1.0 / math.sqrt(dh)
+        # fp8 GEMMs (BASELINE configs[3]; m3p_amd/fp8.py): the layer projections run on 8-bit operands
+        st8 = model.fp8_state() if model.fp8 else None
+        if st8 is not None:
+            assert M % 256 == 0, 'the fp8 GEMM takes whole 256-row tiles (B * S %% 256 == 0): M = %d' % M
+            if model.training:
+                st8.roll()
+            st8.quant_weights(ar)
+
+        def lin(xin, i, xsite, wsite, w16, epi, **kw):
+            if st8 is None:
+                return ops.gemm_nt(xin, w16, epi, **kw)
+            x8, dxs = st8.quant(xin, i, xsite)
+            w8, _, dws = st8.weights[(i, wsite)]
+            return ops.gemm_nt_fp8(x8, w8, epi, descale_a=dxs, descale_b=dws, **kw)
+
         for i in range(nL):
             a, f = 'attentions.%d.' % i, 'ffns.%d.' % i
-            qkv = ops.gemm_nt(h, ar.qkv_w16(i), L.EPI_BIAS, bias=ar.qkv_bias(i), scale_cols=d, scale=qscale)
+            qkv = lin(h, i, 'x', 'wqkv', ar.qkv_w16(i), L.EPI_BIAS, bias=ar.qkv_bias(i), scale_cols=d, scale=qscale)
             ctxt, lse, kmask = ops.attn_fwd(qkv, totlen, B, S, H, dh, seed=seed('attn_p', i), p_drop=p_attn,
                                             want_mask=True)
             lse = (lse, kmask)      # the dropout keep bits travel with the log-sum-exp to backward
-            pre1 = ops.gemm_nt(ctxt, ar.w(a + 'out_lin.weight'), L.EPI_BIAS_DROP_RES, bias=ar.p(a + 'out_lin.bias'),
-                               aux=h, seed=seed('attn_out', i), p_drop=p_drop)
+            pre1 = lin(ctxt, i, 'ctx', 'wout', ar.w(a + 'out_lin.weight'), L.EPI_BIAS_DROP_RES, bias=ar.p(a + 'out_lin.bias'),
+                       aux=h, seed=seed('attn_out', i), p_drop=p_drop)
             x1, mean1, rstd1 = ops.layernorm_fwd(pre1, ar.p('layer_norm1.%d.weight' % i), ar.p('layer_norm1.%d.bias' % i))
-            if M >= 1024:
+            if M >= 1024 or st8 is not None:
                 # persistent GEMM: bias in the epilogue, GELU as its own HBM-speed pass
                 # The same pass leaves gelu'(u) in u's buffer: the backward dgrad then only multiplies
                 # (EPI_MUL, runs on the four-wave GEMM) instead of evaluating erf/exp in its epilogue.
-                u = ops.gemm_nt(x1, ar.w(f + 'lin1.weight'), L.EPI_BIAS, bias=ar.p(f + 'lin1.bias'))
-                hact = ops.gelu_fwd(u, grad_inplace=_GELU_GRAD_IN_FWD)
+                u = lin(x1, i, 'x1', 'w1', ar.w(f + 'lin1.weight'), L.EPI_BIAS, bias=ar.p(f + 'lin1.bias'))
+                # (fp8: the K loop is half as long, so the erf / exp of EPI_DGELU would dominate the dgrad - always multiply)
+                hact = ops.gelu_fwd(u, grad_inplace=_GELU_GRAD_IN_FWD or st8 is not None)
             else:
                 u = torch.empty((M, 4 * d), dtype=BF16, device=dev)
                 hact = ops.gemm_nt(x1, ar.w(f + 'lin1.weight'), L.EPI_BIAS_GELU, bias=ar.p(f + 'lin1.bias'), out2=u)
-            pre2 = ops.gemm_nt(hact, ar.w(f + 'lin2.weight'), L.EPI_BIAS_DROP_RES, bias=ar.p(f + 'lin2.bias'),
-                               aux=x1, seed=seed('ffn', i), p_drop=p_drop)
+            pre2 = lin(hact, i, 'hact', 'w2', ar.w(f + 'lin2.weight'), L.EPI_BIAS_DROP_RES, bias=ar.p(f + 'lin2.bias'),
+                       aux=x1, seed=seed('ffn', i), p_drop=p_drop)
             h_next, mean2, rstd2 = ops.layernorm_fwd(pre2, ar.p('layer_norm2.%d.weight' % i),
                                                      ar.p('layer_norm2.%d.bias' % i), rowmask)
             if track:      # (inference keeps nothing: retrieval evaluation runs thousands of sequences per call)
@@ -411,6 +430,16 @@ class EncoderFn(torch.autograd.Function):
         if dh_.dtype != BF16:
             dh_ = dh_.to(BF16)
         last = hook.encoder_backward_begin() if hook is not None else True
+        st8 = model.fp8_state() if model.fp8 else None
+
+        def dgrad(g, i, gsite, wsite, wt16, epi, **kw):
+            """data gradient g [M, n] x W -> [M, k] on the transposed weight copy (bf8 gradient x fp8 weight when fp8 is on)"""
+            if st8 is None:
+                return ops.gemm_nt(g, wt16, epi, **kw)
+            g8, dgs = st8.quant(g, i, gsite)
+            _, wt8, dws = st8.weights[(i, wsite)]
+            return ops.gemm_nt_fp8(g8, wt8, epi, a_is_bf8=True, descale_a=dgs, descale_b=dws, **kw)
+
         for i in reversed(range(nL)):
             a, f = 'attentions.%d.' % i, 'ffns.%d.' % i
             (h_in, qkv, ctxt, lse, pre1, mean1, rstd1, x1, u, hact, pre2, mean2, rstd2) = saved_layers[i]
@@ -423,11 +452,12 @@ class EncoderFn(torch.autograd.Function):
             if dY2 is None:
                 dY2 = dpre2
             ops.gemm_wgrad(dY2, hact, ar.g(f + 'lin2.weight'))
-            dU = ops.gemm_nt(dY2, ar.wt[('lin2', i)], L.EPI_MUL if (M >= 1024 and _GELU_GRAD_IN_FWD) else L.EPI_DGELU, aux=u,
-                             colsum=ar.g(f + 'lin1.bias'))      # u holds gelu'(u) on the persistent path
+            dU = dgrad(dY2, i, 'dy2', 'w2', ar.wt[('lin2', i)],
+                       L.EPI_MUL if ((M >= 1024 and _GELU_GRAD_IN_FWD) or st8 is not None) else L.EPI_DGELU, aux=u,
+                       colsum=ar.g(f + 'lin1.bias'))      # u holds gelu'(u) on the persistent path
             del hact, u, pre2
             ops.gemm_wgrad(dU, x1, ar.g(f + 'lin1.weight'))
-            dx1 = ops.gemm_nt(dU, ar.wt[('lin1', i)], L.EPI_RES, aux=dpre2)
+            dx1 = dgrad(dU, i, 'du', 'w1', ar.wt[('lin1', i)], L.EPI_RES, aux=dpre2)
             del dU, dpre2, dY2
             # LayerNorm1 and the attention-output dropout
             dpre1, dAO = ops.layernorm_bwd(dx1, None, pre1, ar.p('layer_norm1.%d.weight' % i), mean1, rstd1, None,
@@ -437,11 +467,11 @@ class EncoderFn(torch.autograd.Function):
             if dAO is None:
                 dAO = dpre1
             ops.gemm_wgrad(dAO, ctxt, ar.g(a + 'out_lin.weight'))
-            dctx = ops.gemm_nt(dAO, ar.wt[('out', i)], L.EPI_NONE)
+            dctx = dgrad(dAO, i, 'dao', 'wout', ar.wt[('out', i)], L.EPI_NONE)
             dqkv = ops.attn_bwd(qkv, totlen, ctxt, dctx, lse[0], B, S, H, dh, dbias_qkv=ar.qkv_bias(i, grad=True),
                                 seed=seed('attn_p', i), p_drop=p_attn, keepmask=lse[1])
             ops.gemm_wgrad(dqkv, h_in, ar.qkv_wgrad(i))
-            dh_ = ops.gemm_nt(dqkv, ar.wt[('qkv', i)], L.EPI_RES, aux=dpre1)
+            dh_ = dgrad(dqkv, i, 'dqkv', 'wqkv', ar.wt[('qkv', i)], L.EPI_RES, aux=dpre1)
             del dqkv, dctx, dAO, dpre1, dx1
             ar.touch_layer(i)
             if hook is not None:

@@ -244,6 +244,9 @@ class TransformerModel(nn.Module):
         self.share_inout_emb = bool(params.share_inout_emb)
         assert self.share_inout_emb, 'the fused MLM head assumes the tied projection (share_inout_emb)'
 
+        # fp8 GEMMs for the encoder layers' projections (BASELINE.json configs[3]; not a reference flag: m3p_amd/fp8.py)
+        self.fp8 = bool(getattr(params, 'fp8_gemm', False))
+        self._fp8_state = None
         self._arena = None
         self.base_seed = 0x5EED
         self._fwd_counter = 0
@@ -314,6 +317,12 @@ class TransformerModel(nn.Module):
         if self.embeddings.weight.is_cuda:
             self._arena = Fn.Arena(self)
         return self
+
+    def fp8_state(self):
+        if self._fp8_state is None or self._fp8_state.scale.device != self.arena().device:
+            from ..fp8 import Fp8State
+            self._fp8_state = Fp8State(self.n_layers, self.arena().device)
+        return self._fp8_state
 
     def arena(self):
         if self._arena is None:
