@@ -404,7 +404,7 @@ __device__ __forceinline__ void epilogue_half(const M3PEpilogue& ep, bf16* __res
   }
 }
 
-#ifdef M3P_RING_TL
+#if defined(M3P_RING_TL) || defined(M3P_W8_TL)
 __device__ unsigned long long g_ring_tl[256 * 8 * 8];   // debug build: per-wave cycle sums of the eight-wave kernel's segments
 #endif
 
@@ -820,6 +820,16 @@ void gemm_nt_w8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
   using H0 = std::integral_constant<int, 0>;
   using H1 = std::integral_constant<int, 1>;
 
+#ifdef M3P_W8_TL
+  // debug build: s_memtime sums per segment (0 K loop, 1 bias + aux fetch / wait, 2 epilogue pieces, 3 restart after the
+  // epilogue, 4 prologue) and the absolute start / end stamps (5, 6) of every wave  (tools/w8_timeline.py)
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tl0 = __builtin_amdgcn_s_memtime(), tl1;
+  tacc[5] = tl0;
+#define W8_TSEG(k) do { tl1 = __builtin_amdgcn_s_memtime(); tacc[k] += tl1 - tl0; tl0 = tl1; } while (0)
+#else
+#define W8_TSEG(k) do { } while (0)
+#endif
   // ---- prologue: K-tiles 0 and 1 into stages 0 and 1
   set_load_tile(0);
   stage_next(0);
@@ -859,6 +869,9 @@ void gemm_nt_w8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
       }
   };
   bool spread_pending = false;
+#ifdef M3P_W8_TL
+  W8_TSEG(4);
+#endif
   for (int step = 0; step < total; ++step) {
     const int cur = step & 1, nxt = cur ^ 1;
     const bool last_kt = (c_kt + 1 == nk);
@@ -907,6 +920,7 @@ void gemm_nt_w8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
 
     if (++c_kt == nk) {
       // ---- epilogue of output tile c_q through the vacated stage `cur`
+      W8_TSEG(0);
       c_kt = 0;
       const int t = tile_of(c_q);
       ++c_q;
@@ -932,7 +946,12 @@ void gemm_nt_w8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
             for (int j = 0; j < 4; ++j) rows[ii][j] = acc[2 * hf + ii][j];
           bf16x4 auxv[2][4];
           load_aux_rows<EPI>(ep, mw + 32 * hf, nw, lane, r1, auxv);
+#ifdef M3P_W8_TL
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          W8_TSEG(1);
+#endif
           epilogue_half<EPI>(ep, C, ldc, N, mw + 32 * hf, nw, r1, rows, biasv, auxv, lane, csum, gtab);
+          W8_TSEG(2);
           __builtin_amdgcn_sched_barrier(0);      // one piece at a time: hoisted loads of the next piece cost registers
         }
       } else {
@@ -956,9 +975,16 @@ void gemm_nt_w8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
         read_a_lo(a_addr[0] + nxt * STAGE, fa0);
         W8_LGKM0();
       }
+      W8_TSEG(3);
     }
   }
   if ((EPI == M3P_EPI_DGELU || EPI == M3P_EPI_MUL) && ep.colsum && csum_nw >= 0) flush_csum();
+#ifdef M3P_W8_TL
+  tacc[6] = __builtin_amdgcn_s_memtime();
+  if (lane == 0)
+    for (int k = 0; k < 8; ++k) g_ring_tl[(blockIdx.x * 8 + wid) * 8 + k] = tacc[k];
+#endif
+#undef W8_TSEG
 #undef W8_DSR
 #undef W8_LGKM0
 }
@@ -2841,7 +2867,7 @@ int m3p_gemm_nt_fp8(const void* A, int lda, int a_is_bf8, const void* W, int ldw
 // [256 workgroups][8 waves][8 segments]: 0 K loop, 1 bias / row copies, 2 aux fetch + wait, 3 epilogue half (compute,
 // staging, stores), 4 column sums, 5 zeroing + end barrier  (tools/ring_timeline.py)
 __attribute__((visibility("default"))) int m3p_debug_ring_timeline(void* out, size_t bytes) {
-#ifdef M3P_RING_TL
+#if defined(M3P_RING_TL) || defined(M3P_W8_TL)
   if (bytes > sizeof(g_ring_tl)) return M3P_EINVAL;
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ring_tl), bytes);
 #else

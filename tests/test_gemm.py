@@ -152,7 +152,7 @@ def test_gemm_nt_streamk(M, N, K):
 
 @pytest.mark.parametrize('variant', [2, 6])
 @pytest.mark.parametrize('M,N,K', [(1024, 768, 3072), (1024 + 40, 1000, 128), (2560, 512, 2304), (1300, 2304 + 8, 1536),
-                                   (1280, 2304, 768), (4096, 768, 768), (8192, 3072, 768)])
+                                   (1280, 2304, 768), (4096, 768, 768), (8192, 3072, 768), (1280, 640, 64), (33024, 384, 192)])
 def test_gemm_nt_256x256_kernels(M, N, K, variant):
     """The 256x256-tile kernels (variant 2: four waves of 128x128; variant 6: eight waves of 128x64) against the fp32
     product, every epilogue, full and ragged tiles; forced through the developer switch so every shape runs them

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Where the eight-wave 256x256 NT kernel spends its cycles, per epilogue and shape (needs tools/build_alt.sh -DM3P_W8_TL and
+M3P_HIP_LIB=m3p_amd/libm3p_hip_alt.so): per-wave s_memtime sums per segment + the spread of the waves' start / end stamps."""
+import ctypes as C, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from m3p_amd import lib as L, ops
+lib = L.load()
+f = lib.m3p_debug_ring_timeline
+f.restype = C.c_int; f.argtypes = [C.c_void_p, C.c_size_t]
+M = int(os.environ.get('AB_M', '41984'))
+names = ['K loop', 'bias + aux fetch / wait', 'epilogue pieces (compute, staging, stores)', 'restart (zero, barrier, request, fragments)', 'prologue']
+for nm, N, K, epi in (('FFN1 fwd (bias)', 3072, 768, L.EPI_BIAS), ('dU (dGELU)', 3072, 768, L.EPI_DGELU), ('FFN2 fwd (bias+drop+res)', 768, 3072, L.EPI_BIAS_DROP_RES),
+                      ('dctx (none)', 768, 768, L.EPI_NONE)):
+    a = torch.randn(M, K, device='cuda').to(torch.bfloat16); w = (torch.randn(N, K, device='cuda') * 0.05).to(torch.bfloat16)
+    aux = torch.randn(M, N, device='cuda').to(torch.bfloat16)
+    bias = torch.randn(N, device='cuda')
+    out = torch.empty(M, N, dtype=torch.bfloat16, device='cuda')
+    kw = {}
+    if epi in (L.EPI_BIAS, L.EPI_BIAS_DROP_RES): kw['bias'] = bias
+    if epi in (L.EPI_DGELU, L.EPI_BIAS_DROP_RES): kw['aux'] = aux
+    if epi == L.EPI_BIAS_DROP_RES: kw.update(seed=5, p_drop=0.1)
+    for _ in range(3):
+        ops.gemm_nt(a, w, epi, out=out, **kw)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); ops.gemm_nt(a, w, epi, out=out, **kw); e1.record(); torch.cuda.synchronize()
+    buf = np.zeros((256, 8, 8), dtype=np.uint64)
+    rc = f(buf.ctypes.data, buf.nbytes); assert rc == 0, rc
+    d = buf.astype(np.float64)
+    span = d[..., 6] - d[..., 5]
+    t0 = d[..., 5].min()
+    print('%s M=%d N=%d K=%d: %.1f us; wave span mean %.0f ticks (min %.0f max %.0f); first start..last end %.0f ticks; start spread %.0f, end spread %.0f'
+          % (nm, M, N, K, e0.elapsed_time(e1) * 1e3, span.mean(), span.min(), span.max(), d[..., 6].max() - t0,
+             d[..., 5].max() - t0, d[..., 6].max() - d[..., 6].min()))
+    tiles = (M // 256) * (N // 256)
+    for k, s in enumerate(names):
+        print('  %-46s %9.0f (%.1f%% of the span; %.0f per tile)' % (s, d[..., k].mean(), 100 * d[..., k].mean() / span.mean(),
+                                                                     d[..., k].mean() / (tiles / 256.0)))
