@@ -175,6 +175,16 @@ M3P_API int m3p_attn_bwd(const void* qkv, const int32_t* keylen, const void* ctx
                          int H, int dh, float qscale, uint32_t seed, uint32_t thresh24, float inv_keep,
                          void* stream);
 
+/* Decoder inference (transformer.py:149-210 with the key / value cache of :187-195): every query row
+ * attends a prefix of a cached key / value sequence.  q bf16 [B*Tq, ld_q] (scaled and biased by the projection's
+ * epilogue); key j of sequence b, head h at kv + b*kv_bstride + j*ld_kv + h*dh, its value H*dh elements further
+ * (bf16; element strides, multiples of 8); klen int32 [B] or NULL (= Lk keys everywhere); causal != 0: query t sees keys
+ * 0 .. pos0 + t only (pos0 = tokens cached before this call).  fp32 softmax, no dropout (inference), ctx bf16
+ * [B*Tq, H*dh].  dh in {32, 64}, Lk <= 1024. */
+M3P_API int m3p_attn_query_fwd(const void* q, int ld_q, const void* kv, long long kv_bstride, int ld_kv,
+                               const int32_t* klen, void* ctx, int B, int Tq, int H, int dh, int Lk, int causal,
+                               int pos0, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Input assembly of jointfwd (transformer.py:901-943) and its backward
  * ---------------------------------------------------------------------------------- */

@@ -236,6 +236,18 @@ def attn_bwd(qkv, keylen, ctx, dctx, lse, B, S, H, dh, dbias_qkv=None, seed=0, p
     return dqkv
 
 
+def attn_query_fwd(q, kv, klen, B, Tq, H, dh, Lk, causal=False, pos0=0):
+    """Decoder-inference attention: q bf16 [B*Tq, >= H*dh] (scaled), kv bf16 [B, >= Lk, >= 2*H*dh] (keys | values per
+    cached position), klen int32 [B] or None -> ctx bf16 [B*Tq, H*dh]  (csrc/decode.hip)."""
+    _chk_bf16(q, kv)
+    assert q.stride(1) == 1 and kv.dim() == 3 and kv.stride(2) == 1 and kv.shape[0] == B and kv.shape[1] >= Lk
+    ctx = torch.empty((B * Tq, H * dh), dtype=BF16, device=q.device)
+    rc = L.load().m3p_attn_query_fwd(q.data_ptr(), q.stride(0), kv.data_ptr(), kv.stride(0), kv.stride(1), L.ptr(klen),
+                                     ctx.data_ptr(), B, Tq, H, dh, Lk, 1 if causal else 0, pos0, L.stream())
+    L.check(rc, 'm3p_attn_query_fwd')
+    return ctx
+
+
 def cast_bf16(x):
     """fp32 -> bf16 through the HIP cast kernel (bf16 input is returned unchanged)."""
     if x.dtype == BF16:

@@ -37,7 +37,9 @@ for name, (calls, avg_ns) in sorted(stats.items(), key=lambda kv: -kv[1][0] * kv
     kernels[name[:90]] = dict(launches=calls, fetch_kb=round(f_kb, 1), write_kb=round(w_kb, 1), hbm_bytes_per_launch=int(hbm))
     rows.append((name, calls / steps, avg_ns / 1e3, hbm, hbm / avg_ns, util, wait))
 
-dg = [k for k in kernels if 'gemm_nt_ring_kernel<5>' in k]
+# the dominant instance of bench.py's roofline block: the dGELU data gradient (epilogue 5 runs only on this shape in the
+# step), on whichever NT kernel the dispatch picked
+dg = [k for k in kernels if 'gemm_nt_w8_kernel<5>' in k] or [k for k in kernels if 'gemm_nt_ring_kernel<5>' in k]
 bench_keys = {'gemm_nt/dgelu M=41984 N=3072 K=768': kernels[dg[0]]['hbm_bytes_per_launch']} if dg else {}
 note = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, tools/collect_counters.sh) of `python bench.py --steps 3 "
         "--warmup 1 --no-cpu-baseline`; values are KB per launch averaged over all launches of the kernel. hbm_bytes = (2*FETCH_SIZE + "
