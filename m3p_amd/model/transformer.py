@@ -127,6 +127,12 @@ class PredLayer(nn.Module):
         self.pad_index = params.pad_index
         self.proj = nn.Linear(params.emb_dim, params.n_words, bias=True)
 
+    def get_scores(self, x):
+        """transformer.py:120-124: word scores of (n, d) hidden states, fp32 (inference; the vocabulary GEMM of the
+        training path).  Needs the owning model for the tied bf16 matrix: set by TransformerModel."""
+        from ..decoder import word_scores
+        return word_scores(self._owner, x)
+
 
 class BertImageEmbeddings(nn.Module):
     """transformer.py:231-269 parameter holder (forward is fused into the assembly kernel)."""
@@ -175,9 +181,10 @@ class TransformerModel(nn.Module):
         self.is_decoder = not is_encoder
         self.with_output = with_output
         self.is_crossModal = is_crossModal
-        assert is_encoder and is_crossModal, \
-            'the MI355X hot path is the cross-modal encoder (the reference itself requires is_crossModal=True: ' \
-            'transformer.py:673-698)'
+        assert is_crossModal, 'the reference itself requires is_crossModal=True (transformer.py:673-698)'
+        # is_encoder=False: the causal decoder of the captioning / translation tasks (same parameter set, n_dec_layers
+        # layers, transformer.py:657).  Its inference path (crossfwd(causal=True, src_enc=...), generate, generate_beam)
+        # is m3p_amd/decoder.py; its training step is not built.
 
         self.n_langs = params.n_langs
         self.n_words = params.n_words
@@ -191,7 +198,8 @@ class TransformerModel(nn.Module):
         self.dim = params.emb_dim
         self.hidden_dim = self.dim * 4
         self.n_heads = params.n_heads
-        self.n_layers = params.n_layers
+        self.n_layers = params.n_layers if is_encoder else params.n_dec_layers
+        assert self.n_layers >= 1
         self.dropout = params.dropout
         self.attention_dropout = params.attention_dropout
         assert self.dim % self.n_heads == 0, 'transformer dim must be a multiple of n_heads'
@@ -239,6 +247,7 @@ class TransformerModel(nn.Module):
 
         if self.with_output:
             self.pred_layer = PredLayer(params)
+            object.__setattr__(self.pred_layer, '_owner', self)      # (a plain attribute: no cycle in the module tree)
             if params.share_inout_emb:
                 self.pred_layer.proj.weight = self.embeddings.weight   # transformer.py:728-729
         self.share_inout_emb = bool(params.share_inout_emb)
@@ -248,6 +257,7 @@ class TransformerModel(nn.Module):
         self.fp8 = bool(getattr(params, 'fp8_gemm', False))
         self._fp8_state = None
         self._arena = None
+        self._cold_w16 = None
         self.base_seed = 0x5EED
         self._fwd_counter = 0
         self.ddp_hook = None   # set by m3p_amd.distributed.DataParallel
@@ -318,6 +328,13 @@ class TransformerModel(nn.Module):
             self._arena = Fn.Arena(self)
         return self
 
+    def decoder_cold_weights(self):
+        """bf16 copies of the encoder-attention sub-layer's weights (decoder inference, m3p_amd/decoder.py)."""
+        if self._cold_w16 is None:
+            from ..decoder import _ColdWeights
+            self._cold_w16 = _ColdWeights(self)
+        return self._cold_w16.refresh()
+
     def fp8_state(self):
         if self._fp8_state is None or self._fp8_state.scale.device != self.arena().device:
             from ..fp8 import Fp8State
@@ -378,8 +395,13 @@ class TransformerModel(nn.Module):
     def crossfwd(self, x, lengths, causal, stream_='text', src_enc=None, src_len=None, positions=None, langs=None,
                  cache=None, enc_mask=None, image_loc=None, **kw):
         """Text-only stream of transformer.py:970-1114 (the mlm_step caller, xtrainer.py:757)."""
-        assert stream_ == 'text' and not causal and src_enc is None and cache is None and positions is None, \
-            'only the text MLM stream of crossfwd is on the MI355X hot path'
+        assert stream_ == 'text', "crossfwd(stream_='img') is outside the MI355X build"
+        if causal:       # the decoder: causal self-attention (+ attention over src_enc), key / value cache (:1011-1091)
+            from .. import decoder
+            return decoder.decoder_forward(self, x, lengths, src_enc=src_enc, src_len=src_len, positions=positions,
+                                           langs=langs, cache=cache, enc_mask=enc_mask)
+        assert src_enc is None and cache is None and positions is None, \
+            'the non-causal text stream takes no source encoding, cache or explicit positions (the mlm_step caller)'
         T, B = x.size()
         p = self.dropout if self.training else 0.0
         pa = self.attention_dropout if self.training else 0.0
@@ -411,3 +433,14 @@ class TransformerModel(nn.Module):
             return Fn.mrfr_dense_rows(self, tensor)
         loss, scores = Fn.mlm_head(self, tensor, pred_mask, y, bool(get_scores))
         return scores, loss
+
+    def generate(self, src_enc, src_len, tgt_lang_id, max_len=200, sample_temperature=None, cross_modal=True):
+        """transformer.py:1216-1317 (greedy / sampled decoding)."""
+        from .. import decoder
+        return decoder.generate(self, src_enc, src_len, tgt_lang_id, max_len=max_len, sample_temperature=sample_temperature)
+
+    def generate_beam(self, src_enc, src_len, tgt_lang_id, beam_size, length_penalty, early_stopping, max_len=200):
+        """transformer.py:1319-1515 (beam search)."""
+        from .. import decoder
+        return decoder.generate_beam(self, src_enc, src_len, tgt_lang_id, beam_size, length_penalty, early_stopping,
+                                     max_len=max_len)

@@ -89,6 +89,72 @@ def hot_param_shapes(p):
     return out
 
 
+def decoder_param_shapes(p):
+    """(name, shape) of the parameters the causal decoder (is_encoder=False) executes in
+    crossfwd(causal=True, src_enc=...) / generate / generate_beam (transformer.py:1050-1102): the text embeddings, per
+    layer the self-attention, the encoder attention + layer_norm15, the FFN, and the tied output bias."""
+    d, V, L = p.emb_dim, p.n_words, p.n_dec_layers
+    out = OrderedDict()
+    out['position_embeddings.weight'] = (N_MAX_POSITIONS, d)
+    out['embeddings.weight'] = (V, d)
+    if p.n_langs > 1:
+        out['cross_lang_embeddings.weight'] = (p.n_langs, d)
+    out['layer_norm_emb.weight'] = (d,)
+    out['layer_norm_emb.bias'] = (d,)
+    for i in range(L):
+        for blk in ('attentions', 'encoder_attn'):
+            for lin in ('q_lin', 'k_lin', 'v_lin', 'out_lin'):
+                out['%s.%d.%s.weight' % (blk, i, lin)] = (d, d)
+                out['%s.%d.%s.bias' % (blk, i, lin)] = (d,)
+        for ln in ('layer_norm1', 'layer_norm15', 'layer_norm2'):
+            out['%s.%d.weight' % (ln, i)] = (d,)
+            out['%s.%d.bias' % (ln, i)] = (d,)
+        out['ffns.%d.lin1.weight' % i] = (4 * d, d)
+        out['ffns.%d.lin1.bias' % i] = (4 * d,)
+        out['ffns.%d.lin2.weight' % i] = (d, 4 * d)
+        out['ffns.%d.lin2.bias' % i] = (d,)
+    out['pred_layer.proj.bias'] = (V,)
+    return out
+
+
+DECODER_CASES = {
+    # tag: model geometry and search settings of the decoder golden vectors (oracle/gen_goldens.py decoder)
+    'mono': dict(emb_dim=128, n_heads=4, n_dec_layers=2, n_words=1000, n_langs=1, bs=5, S=12, T=10, max_len=18,
+                 tgt_lang_id=None, beam_size=0, eos_bias=-3.0, eos_ramp=1.0, seed=31),
+    'multi': dict(emb_dim=128, n_heads=4, n_dec_layers=2, n_words=1000, n_langs=2, bs=4, S=9, T=8, max_len=14,
+                  tgt_lang_id=1, beam_size=3, eos_bias=-2.0, eos_ramp=0.3, seed=47),
+    'wide': dict(emb_dim=256, n_heads=4, n_dec_layers=3, n_words=2000, n_langs=2, bs=3, S=20, T=12, max_len=16,
+                 tgt_lang_id=0, beam_size=4, eos_bias=1.0, eos_ramp=0.3, seed=59),
+}
+
+
+def decoder_case(tag):
+    """params, deterministic weights and inputs of one decoder golden case."""
+    c = DECODER_CASES[tag]
+    langs = {0: 'en', 1: 'zh'} if c['n_langs'] > 1 else {0: 'en'}
+    p = model_params(c['emb_dim'], c['n_heads'], 1, c['n_words'], n_dec_layers=c['n_dec_layers'], n_langs=c['n_langs'],
+                     id2lang=langs, lang2id={v: k for k, v in langs.items()})
+    sd = golden_state_dict(decoder_param_shapes(p), seed=c['seed'], scale=0.05)
+    # so that hypotheses end at different, input-dependent steps: <EOS> starts below the other words and every position
+    # embedding leans a little further towards the <EOS> embedding (which is also its output vector: tied matrix)
+    sd['pred_layer.proj.bias'][EOS] += c['eos_bias']
+    e_hat = sd['embeddings.weight'][EOS] / sd['embeddings.weight'][EOS].norm()
+    ramp = torch.arange(64, dtype=torch.float32)[:, None] * c.get('eos_ramp', 0.0)
+    sd['position_embeddings.weight'][:64] += ramp * e_hat[None, :]
+    rs = np.random.RandomState(c['seed'] + 1)
+    src_enc = torch.from_numpy(rs.standard_normal((c['bs'], c['S'], c['emb_dim'])).astype(np.float32))
+    src_len = torch.from_numpy(rs.randint(c['S'] // 2, c['S'] + 1, size=c['bs'])).long()
+    src_len[0] = c['S']
+    x = torch.from_numpy(rs.randint(3, c['n_words'], size=(c['T'], c['bs']))).long()
+    lengths = torch.from_numpy(rs.randint(c['T'] // 2, c['T'] + 1, size=c['bs'])).long()
+    lengths[-1] = c['T']
+    x[0] = EOS
+    for b in range(c['bs']):
+        x[int(lengths[b]) - 1, b] = EOS
+        x[int(lengths[b]):, b] = PAD
+    return c, p, sd, src_enc, src_len, x, lengths
+
+
 def region_head_param_shapes(p):
     """Parameters of the two masked-region objectives: MRM = BertPredictionHeadTransform
     (transformer.py:595-606) + ObjPredLayer (:562-584); MRFR = mrfr_dense (:718).  Kept apart from

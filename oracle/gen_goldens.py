@@ -538,12 +538,81 @@ def gen_host_goldens():
 
 
 
+def gen_decoder_goldens():
+    """decoder.npz: the reference's causal decoder (TransformerModel(is_encoder=False)) on the deterministic cases of
+    m3p_amd.synth.DECODER_CASES - teacher-forced crossfwd(causal=True, src_enc) hidden states, the same computed
+    incrementally through the key / value cache, word scores of the last position, greedy generate() and
+    generate_beam() outputs.  Weights and inputs are regenerated from the seeds by the tests (synth.decoder_case)."""
+    from src.model.transformer import TransformerModel
+    from oracle import ref_cpu
+    out = {}
+    for tag in synth.DECODER_CASES:
+        c, P, sd, src_enc, src_len, x, lengths = synth.decoder_case(tag)
+        torch.manual_seed(0)
+        m = TransformerModel(P, is_encoder=False, with_output=True, is_crossModal=True)
+        own = dict(m.named_parameters())
+        with torch.no_grad():
+            for k, v in sd.items():
+                assert tuple(own[k].shape) == tuple(v.shape), (k, own[k].shape, v.shape)
+                own[k].copy_(v)
+        assert m.pred_layer.proj.weight is m.embeddings.weight
+        m.eval()
+        T, bs = x.shape
+        lid = c['tgt_lang_id']
+        langs = None if lid is None else torch.full((T, bs), lid, dtype=torch.long)
+        with torch.no_grad():
+            full = m('crossfwd', x=x, lengths=lengths, causal=True, src_enc=src_enc, src_len=src_len, langs=langs)
+            # the same through the cache: a 4-token prefix, then one token at a time
+            cache = {'slen': 0}
+            pieces = [m('crossfwd', x=x[:4], lengths=lengths.clamp(max=4), causal=True, src_enc=src_enc, src_len=src_len,
+                        langs=None if langs is None else langs[:4], cache=cache)]
+            for t in range(5, T + 1):
+                pieces.append(m('crossfwd', x=x[:t], lengths=lengths.clamp(max=t), causal=True, src_enc=src_enc, src_len=src_len,
+                                langs=None if langs is None else langs[:t], cache=cache))
+            inc = torch.cat(pieces, 0)
+            scores = m.pred_layer.get_scores(full[-1])
+            # container-only shim: transformer.py:1315 masks with a uint8 tensor, which this torch rejects (bool is the same mask)
+            _byte = torch.Tensor.byte
+            torch.Tensor.byte = lambda self: self.bool()
+            try:
+                gen, gen_len = m.generate(src_enc, src_len, lid, max_len=c['max_len'])
+            finally:
+                torch.Tensor.byte = _byte
+            out[tag + '.full'] = full.numpy()
+            out[tag + '.incremental'] = inc.numpy()
+            out[tag + '.scores_last'] = scores.numpy()
+            out[tag + '.greedy'] = gen.numpy()
+            out[tag + '.greedy_len'] = gen_len.numpy()
+            if c['beam_size']:
+                for lp, es in ((1.0, False), (0.6, True)):
+                    dec, tl = m.generate_beam(src_enc, src_len, lid, c['beam_size'], lp, es, max_len=c['max_len'])
+                    out['%s.beam_lp%.1f_es%d' % (tag, lp, es)] = dec.numpy()
+                    out['%s.beam_lp%.1f_es%d_len' % (tag, lp, es)] = tl.numpy()
+        # the restatement agrees with the reference it restates
+        o_full = ref_cpu.decoder_crossfwd(sd, c['n_dec_layers'], c['n_heads'], x, lengths, src_enc, src_len, langs=langs)
+        err = float((o_full - full).abs().max())
+        o_gen, o_len, margins = ref_cpu.greedy_decode(sd, c['n_dec_layers'], c['n_heads'], src_enc, src_len, lid, c['max_len'])
+        print('%s: crossfwd oracle-vs-reference max|d| %.2e; cache-vs-full max|d| %.2e; greedy equal: %s; lens %s; min margin %.3f'
+              % (tag, err, float((inc - full).abs().max()), bool(torch.equal(o_gen, gen) and torch.equal(o_len, gen_len)),
+                 gen_len.tolist(), float(margins[torch.isfinite(margins)].min())))
+        for k in out:
+            if k.startswith(tag + '.beam') and not k.endswith('_len'):
+                print('   ', k, out[k + '_len'].tolist())
+        assert err < 1e-4 and torch.equal(o_gen, gen)
+        out[tag + '.greedy_margin'] = margins.numpy()
+    np.savez_compressed(os.path.join(OUT, 'decoder.npz'), **out)
+    print('wrote decoder.npz', {k: v.shape for k, v in out.items() if k.endswith('full')})
+
+
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'enum':
         gen_state_dict_enumeration()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'host':
         gen_host_goldens()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'decoder':
+        gen_decoder_goldens()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'refiner':
         gen_refiner_goldens()
@@ -557,3 +626,4 @@ if __name__ == '__main__':
     gen_model_goldens()
     gen_trainer_goldens()
     gen_host_goldens()
+    gen_decoder_goldens()

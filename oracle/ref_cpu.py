@@ -221,6 +221,91 @@ def crossfwd_text(sd, n_layers, n_heads, x, lengths, dropout=0.0, attention_drop
 
 
 # ----------------------------------------------------------------------------
+# causal decoder: crossfwd(causal=True, src_enc=...), greedy decoding
+# ----------------------------------------------------------------------------
+def attention_kv(x, kv, mask, sd, prefix, n_heads):
+    """transformer.py:149-210 with a separate key / value source: x (bs, Tq, d) queries, kv (bs, Tk, d), mask (bs, Tk) or
+    (bs, Tq, Tk) bool (True = attend).  Without a cache (recomputing every position each step gives what the cached
+    run gives: a cached key / value is the projection of the same hidden state)."""
+    bs, Tq, d = x.shape
+    Tk = kv.shape[1]
+    dh = d // n_heads
+    q = F.linear(x, sd[prefix + 'q_lin.weight'], sd[prefix + 'q_lin.bias']).view(bs, Tq, n_heads, dh).transpose(1, 2)
+    k = F.linear(kv, sd[prefix + 'k_lin.weight'], sd[prefix + 'k_lin.bias']).view(bs, Tk, n_heads, dh).transpose(1, 2)
+    v = F.linear(kv, sd[prefix + 'v_lin.weight'], sd[prefix + 'v_lin.bias']).view(bs, Tk, n_heads, dh).transpose(1, 2)
+    scores = torch.matmul(q / math.sqrt(dh), k.transpose(2, 3))
+    m4 = mask[:, None, :, :] if mask.dim() == 3 else mask[:, None, None, :]
+    scores = scores.masked_fill(~m4, float('-inf'))
+    w = torch.softmax(scores.float(), dim=-1).to(scores.dtype)
+    ctx = torch.matmul(w, v).transpose(1, 2).contiguous().view(bs, Tq, d)
+    return F.linear(ctx, sd[prefix + 'out_lin.weight'], sd[prefix + 'out_lin.bias'])
+
+
+def decoder_crossfwd(sd, n_layers, n_heads, x, lengths, src_enc=None, src_len=None, positions=None, langs=None):
+    """TransformerModel.crossfwd(stream_='text', causal=True, src_enc, src_len) in eval mode, transformer.py:1005-1102:
+    mask[b, s] = s < lengths[b]; the causal attention mask is position-only (:70-71: key <= query, padded keys inside
+    the window ARE attended); Emb[x] + Pos (+ Lang) -> LN_emb -> * mask; per layer self-attention -> LN1 ->
+    encoder attention over src_enc[:, :src_len] -> LN1.5 -> FFN -> LN2 -> * mask.  x (T, B) -> (T, B, d)."""
+    T, B = x.shape
+    alen = torch.arange(T)
+    mask = alen[None, :] < lengths[:, None]
+    attn_mask = (alen[None, None, :] <= alen[None, :, None]).expand(B, T, T)
+    pos = alen[None, :].expand(B, T) if positions is None else positions.t()
+    h = F.embedding(x.t(), sd['embeddings.weight']) + F.embedding(pos, sd['position_embeddings.weight'])
+    if langs is not None:
+        h = h + F.embedding(langs.t(), sd['cross_lang_embeddings.weight'])
+    h = layer_norm(h, sd['layer_norm_emb.weight'], sd['layer_norm_emb.bias'])
+    h = h * mask[..., None].to(h.dtype)
+    if src_enc is not None:
+        src_mask = torch.arange(int(src_len.max()))[None, :] < src_len[:, None]
+    for i in range(n_layers):
+        h = layer_norm(h + attention_kv(h, h, attn_mask, sd, 'attentions.%d.' % i, n_heads),
+                       sd['layer_norm1.%d.weight' % i], sd['layer_norm1.%d.bias' % i])
+        if src_enc is not None:
+            h = layer_norm(h + attention_kv(h, src_enc[:, :src_mask.shape[1]], src_mask, sd, 'encoder_attn.%d.' % i, n_heads),
+                           sd['layer_norm15.%d.weight' % i], sd['layer_norm15.%d.bias' % i])
+        f = 'ffns.%d.' % i
+        h = h + transformer_ffn(h, sd[f + 'lin1.weight'], sd[f + 'lin1.bias'], sd[f + 'lin2.weight'], sd[f + 'lin2.bias'])
+        h = layer_norm(h, sd['layer_norm2.%d.weight' % i], sd['layer_norm2.%d.bias' % i])
+        h = h * mask[..., None].to(h.dtype)
+    return h.transpose(0, 1)
+
+
+def word_scores(sd, h):
+    """PredLayer.get_scores with the tied matrix (transformer.py:120-124, :728-729)."""
+    return F.linear(h, sd['embeddings.weight'], sd['pred_layer.proj.bias'])
+
+
+def greedy_decode(sd, n_layers, n_heads, src_enc, src_len, tgt_lang_id, max_len, pad_index=1, eos_index=2):
+    """TransformerModel.generate, greedy branch (transformer.py:1216-1317), every step recomputed from scratch over the
+    prefix (no cache).  Also returns, per step, the margin between the two best scores of every unfinished sentence -
+    tests use it to tell a real mismatch from a near-tie flipped by bf16 arithmetic."""
+    bs = len(src_len)
+    generated = torch.full((max_len, bs), pad_index, dtype=torch.long)
+    generated[0] = eos_index
+    gen_len = torch.ones(bs, dtype=torch.long)
+    unfinished = torch.ones(bs, dtype=torch.long)
+    cur_len, margins = 1, []
+    while cur_len < max_len:
+        langs = None if tgt_lang_id is None else torch.full((cur_len, bs), int(tgt_lang_id), dtype=torch.long)
+        h = decoder_crossfwd(sd, n_layers, n_heads, generated[:cur_len], gen_len, src_enc, src_len, langs=langs)
+        # (the cached run evaluates position cur_len - 1 when gen_len has just reached cur_len for unfinished sentences)
+        scores = word_scores(sd, h[-1])
+        top2 = scores.topk(2, dim=1)[0]
+        margins.append(torch.where(unfinished.bool(), top2[:, 0] - top2[:, 1], torch.full((bs,), float('inf'))))
+        nxt = scores.argmax(dim=1)
+        generated[cur_len] = nxt * unfinished + pad_index * (1 - unfinished)
+        gen_len += unfinished
+        unfinished = unfinished * nxt.ne(eos_index).long()
+        cur_len += 1
+        if int(unfinished.max()) == 0:
+            break
+    if cur_len == max_len:
+        generated[-1].masked_fill_(unfinished.bool(), eos_index)
+    return generated[:cur_len], gen_len, torch.stack(margins)
+
+
+# ----------------------------------------------------------------------------
 # heads: TransformerModel.predict
 # ----------------------------------------------------------------------------
 

@@ -1,0 +1,216 @@
+"""Causal decoder at inference time: crossfwd(causal=True, src_enc=...) with and without the key / value
+cache, word scores, generate() and generate_beam() - transformer.py:970-1114, :149-210, :1216-1561.
+
+Golden vectors (tests/golden/decoder.npz) come from the reference's own TransformerModel(is_encoder=False) on the
+deterministic cases of m3p_amd.synth.DECODER_CASES (oracle/gen_goldens.py decoder).  CPU tests pin the oracle restatement
+and the search loops (driven by the oracle's step function) on them; the GPU tests run the HIP path."""
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from m3p_amd import synth
+from oracle import ref_cpu
+from tests.util import rel_l2
+
+G = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'decoder.npz'))
+TAGS = list(synth.DECODER_CASES)
+
+
+def _langs(c, T, bs):
+    return None if c['tgt_lang_id'] is None else torch.full((T, bs), c['tgt_lang_id'], dtype=torch.long)
+
+
+# ------------------------------------------------------------------------------------------------ CPU: oracle + host logic
+@pytest.mark.parametrize('tag', TAGS)
+def test_oracle_decoder_matches_the_reference(tag):
+    c, P, sd, src_enc, src_len, x, lengths = synth.decoder_case(tag)
+    T, bs = x.shape
+    out = ref_cpu.decoder_crossfwd(sd, c['n_dec_layers'], c['n_heads'], x, lengths, src_enc, src_len, langs=_langs(c, T, bs))
+    assert np.abs(out.numpy() - G[tag + '.full']).max() < 2e-5
+    # the reference's cached run (4-token prefix, then token by token) gives the same hidden states
+    assert np.abs(G[tag + '.incremental'] - G[tag + '.full']).max() < 2e-5
+    assert np.abs(ref_cpu.word_scores(sd, out[-1]).numpy() - G[tag + '.scores_last']).max() < 2e-5
+    gen, gen_len, margins = ref_cpu.greedy_decode(sd, c['n_dec_layers'], c['n_heads'], src_enc, src_len, c['tgt_lang_id'], c['max_len'])
+    assert np.array_equal(gen.numpy(), G[tag + '.greedy']) and np.array_equal(gen_len.numpy(), G[tag + '.greedy_len'])
+    assert np.allclose(margins.numpy(), G[tag + '.greedy_margin'], atol=1e-4)
+    # the fixtures exercise both ways a sentence ends
+    assert (G[tag + '.greedy_len'] < c['max_len']).any()
+
+
+def _oracle_backed(monkeypatch, c, sd):
+    """m3p_amd.decoder's search loops with the oracle as the step function (full recomputation instead of the HIP path)."""
+    from m3p_amd import decoder
+
+    def fwd(model, x, lengths, src_enc, src_len, positions, langs, cache):
+        cache['slen'] = x.shape[0]
+        return ref_cpu.decoder_crossfwd(sd, c['n_dec_layers'], c['n_heads'], x, lengths, src_enc, src_len, positions, langs)[-1:]
+
+    monkeypatch.setattr(decoder, 'decoder_forward', fwd)
+    monkeypatch.setattr(decoder, 'word_scores', lambda model, h: ref_cpu.word_scores(sd, h))
+    return SimpleNamespace(n_words=c['n_words'], pad_index=synth.PAD, eos_index=synth.EOS, dim=c['emb_dim'],
+                           embeddings=SimpleNamespace(weight=torch.zeros(1)))
+
+
+@pytest.mark.parametrize('tag', TAGS)
+def test_search_loops_on_the_oracle_step_reproduce_the_reference(tag, monkeypatch):
+    from m3p_amd import decoder
+    c, P, sd, src_enc, src_len, x, lengths = synth.decoder_case(tag)
+    stub = _oracle_backed(monkeypatch, c, sd)
+    gen, gen_len = decoder.generate(stub, src_enc, src_len, c['tgt_lang_id'], max_len=c['max_len'])
+    assert np.array_equal(gen.numpy(), G[tag + '.greedy']) and np.array_equal(gen_len.numpy(), G[tag + '.greedy_len'])
+    if c['beam_size']:
+        for lp, es in ((1.0, False), (0.6, True)):
+            dec, tl = decoder.generate_beam(stub, src_enc, src_len, c['tgt_lang_id'], c['beam_size'], lp, es, max_len=c['max_len'])
+            key = '%s.beam_lp%.1f_es%d' % (tag, lp, es)
+            assert np.array_equal(tl.numpy(), G[key + '_len']), (key, tl.tolist(), G[key + '_len'].tolist())
+            assert np.array_equal(dec.numpy(), G[key]), key
+
+
+def test_beam_hypotheses_keep_the_n_best():
+    from m3p_amd.decoder import BeamHypotheses
+    h = BeamHypotheses(2, 11, 1.0, False)
+    assert not h.is_done(0.0)
+    h.add(torch.arange(4), -4.0)            # score -1.0
+    h.add(torch.arange(2), -1.0)            # score -0.5
+    assert len(h) == 2 and h.worst_score == -1.0
+    h.add(torch.arange(5), -10.0)           # -2.0: worse than the worst, ignored
+    assert len(h) == 2
+    h.add(torch.arange(4), -1.0)            # -0.25: replaces the -1.0
+    assert sorted(s for s, _ in h.hyp) == [-0.5, -0.25] and h.worst_score == -0.5
+    assert h.is_done(-6.0) and not h.is_done(-4.0)          # -6 / 10 = -0.6 < -0.5 <= -4 / 10
+    assert BeamHypotheses(1, 5, 1.0, True).is_done(0.0) is False
+
+
+def test_decoder_refuses_training_mode():
+    from m3p_amd import decoder
+    m = SimpleNamespace(training=True)
+    with torch.enable_grad(), pytest.raises(NotImplementedError):
+        decoder.decoder_forward(m, torch.zeros(2, 1, dtype=torch.long), torch.ones(1, dtype=torch.long))
+
+
+# ------------------------------------------------------------------------------------------------ GPU: the HIP path
+def _hip_model(tag):
+    from m3p_amd.model.transformer import TransformerModel
+    c, P, sd, src_enc, src_len, x, lengths = synth.decoder_case(tag)
+    torch.manual_seed(0)
+    m = TransformerModel(P, is_encoder=False, with_output=True, is_crossModal=True).cuda()
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and not [k for k in missing if k.split('.')[0] in
+                                   ('attentions', 'encoder_attn', 'ffns', 'layer_norm1', 'layer_norm15', 'layer_norm2')]
+    m.eval()
+    return m, c, sd, src_enc.cuda(), src_len.cuda(), x.cuda(), lengths.cuda()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('tag', TAGS)
+def test_decoder_forward_and_cache_vs_reference(tag):
+    m, c, sd, src_enc, src_len, x, lengths = _hip_model(tag)
+    T, bs = x.shape
+    langs = _langs(c, T, bs)
+    langs = None if langs is None else langs.cuda()
+    with torch.no_grad():
+        full = m('crossfwd', x=x, lengths=lengths, causal=True, src_enc=src_enc, src_len=src_len, langs=langs)
+        assert full.shape == (T, bs, c['emb_dim'])
+        assert rel_l2(full.float().cpu(), torch.from_numpy(G[tag + '.full'])) < 2e-2
+        # incrementally through the cache, as the golden run: the same numbers as the one-shot run (same kernels, same
+        # operands - only the GEMM row counts differ)
+        cache = {'slen': 0}
+        pieces = [m('crossfwd', x=x[:4], lengths=lengths.clamp(max=4), causal=True, src_enc=src_enc, src_len=src_len,
+                    langs=None if langs is None else langs[:4], cache=cache)]
+        for t in range(5, T + 1):
+            pieces.append(m('crossfwd', x=x[:t], lengths=lengths.clamp(max=t), causal=True, src_enc=src_enc, src_len=src_len,
+                            langs=None if langs is None else langs[:t], cache=cache))
+            assert pieces[-1].shape == (1, bs, c['emb_dim']) and cache['slen'] == t
+        inc = torch.cat(pieces, 0)
+        assert rel_l2(inc.float().cpu(), torch.from_numpy(G[tag + '.incremental'])) < 2e-2
+        assert rel_l2(inc.float(), full.float()) < 5e-3
+        scores = m.pred_layer.get_scores(full[-1])
+        assert scores.dtype == torch.float32 and scores.shape == (bs, c['n_words'])
+        assert rel_l2(scores.cpu(), torch.from_numpy(G[tag + '.scores_last'])) < 2e-2
+        # without a source: the plain causal language-model stack (no encoder attention)
+        lm = m('crossfwd', x=x, lengths=lengths, causal=True, langs=langs)
+        o = ref_cpu.decoder_crossfwd(sd, c['n_dec_layers'], c['n_heads'], x.cpu(), lengths.cpu(), langs=None if langs is None else langs.cpu())
+        assert rel_l2(lm.float().cpu(), o) < 2e-2
+
+
+def _agree_until_near_tie(ours, ref, margins, tol):
+    """Token sequences (len, bs) must agree up to (excluding) the first step at which the reference's own top-2 margin
+    is below `tol` - from there on bf16 arithmetic may legitimately pick the other word and the continuations differ."""
+    n = min(ours.shape[0], ref.shape[0])
+    for b in range(ref.shape[1]):
+        for t in range(1, n):
+            if margins[t - 1, b] < tol:
+                break
+            assert ours[t, b] == ref[t, b], (b, t, ours[:, b].tolist(), ref[:, b].tolist(), float(margins[t - 1, b]))
+    return True
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('tag', TAGS)
+def test_generate_greedy_vs_reference(tag):
+    m, c, sd, src_enc, src_len, x, lengths = _hip_model(tag)
+    with torch.no_grad():
+        gen, gen_len = m.generate(src_enc, src_len, c['tgt_lang_id'], max_len=c['max_len'])
+    ref, ref_len, margins = G[tag + '.greedy'], G[tag + '.greedy_len'], G[tag + '.greedy_margin']
+    gen, gen_len = gen.cpu().numpy(), gen_len.cpu().numpy()
+    assert gen.shape[1] == ref.shape[1] and (gen[0] == synth.EOS).all()
+    assert ((gen == synth.EOS).sum(0) == 2).all()
+    _agree_until_near_tie(gen, ref, margins, tol=0.02)
+    exact = [b for b in range(ref.shape[1]) if margins[:, b].min() >= 0.02]      # (score differences seen: ~2e-3)
+    assert exact, 'the fixture should hold at least one sentence without a near-tie'
+    for b in exact:
+        assert gen_len[b] == ref_len[b] and np.array_equal(gen[:gen_len[b], b], ref[:ref_len[b], b])
+    # sampling: same shapes and invariants, reproducible under a seed
+    torch.manual_seed(5)
+    with torch.no_grad():
+        s1, l1 = m.generate(src_enc, src_len, c['tgt_lang_id'], max_len=c['max_len'], sample_temperature=0.7)
+        torch.manual_seed(5)
+        s2, l2 = m.generate(src_enc, src_len, c['tgt_lang_id'], max_len=c['max_len'], sample_temperature=0.7)
+    assert torch.equal(s1, s2) and torch.equal(l1, l2) and int((s1 == synth.EOS).sum()) == 2 * s1.shape[1]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('tag', [t for t in TAGS if synth.DECODER_CASES[t]['beam_size']])
+def test_generate_beam_vs_reference(tag):
+    m, c, sd, src_enc, src_len, x, lengths = _hip_model(tag)
+    n_equal = n_total = 0
+    for lp, es in ((1.0, False), (0.6, True)):
+        with torch.no_grad():
+            dec, tl = m.generate_beam(src_enc, src_len, c['tgt_lang_id'], c['beam_size'], lp, es, max_len=c['max_len'])
+        key = '%s.beam_lp%.1f_es%d' % (tag, lp, es)
+        ref, ref_len = G[key], G[key + '_len']
+        dec, tl = dec.cpu().numpy(), tl.cpu().numpy()
+        assert dec.shape[1] == ref.shape[1] and ((dec == synth.EOS).sum(0) == 2).all() and (dec[0] == synth.EOS).all()
+        for b in range(ref.shape[1]):
+            n_total += 1
+            n_equal += int(tl[b] == ref_len[b] and np.array_equal(dec[:tl[b], b], ref[:ref_len[b], b]))
+    # hypotheses whose cumulated log-probabilities are closer than bf16 resolution may swap; most must be identical
+    assert n_equal >= n_total - 1, (n_equal, n_total)
+
+
+@pytest.mark.gpu
+def test_attn_query_kernel_vs_torch():
+    from m3p_amd import ops
+    g = torch.Generator(device='cuda').manual_seed(3)
+    for B, Tq, H, dh, Lk, causal, pos0 in ((3, 1, 4, 32, 37, True, 36), (2, 5, 12, 64, 9, True, 4), (4, 3, 2, 64, 200, False, 0),
+                                            (1, 1, 16, 64, 700, False, 0)):
+        d = H * dh
+        q = torch.randn(B * Tq, d, device='cuda', generator=g).to(torch.bfloat16)
+        kv = torch.randn(B, Lk + 3, 2 * d, device='cuda', generator=g).to(torch.bfloat16)
+        klen = None if causal else torch.randint(1, Lk + 1, (B,), device='cuda', generator=g).to(torch.int32)
+        ctx = ops.attn_query_fwd(q, kv, klen, B, Tq, H, dh, Lk, causal=causal, pos0=pos0)
+        qf = q.float().view(B, Tq, H, dh).transpose(1, 2)
+        kf = kv[:, :Lk, :d].float().reshape(B, Lk, H, dh).transpose(1, 2)
+        vf = kv[:, :Lk, d:].float().reshape(B, Lk, H, dh).transpose(1, 2)
+        s = qf @ kf.transpose(2, 3)
+        j = torch.arange(Lk, device='cuda')
+        if causal:
+            ok = j[None, :] <= (pos0 + torch.arange(Tq, device='cuda'))[:, None]
+            s = s.masked_fill(~ok[None, None], float('-inf'))
+        else:
+            s = s.masked_fill(~(j[None, :] < klen[:, None])[:, None, None, :], float('-inf'))
+        ref = (torch.softmax(s, -1) @ vf).transpose(1, 2).reshape(B * Tq, d)
+        assert rel_l2(ctx.float(), ref) < 5e-3, (B, Tq, H, dh, Lk)
