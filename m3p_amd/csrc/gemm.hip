@@ -1890,6 +1890,68 @@ void gemm_nt_w4_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
 }
 
 // W4-END
+
+// ---------------------------------------------------------------------------------
+// NT kernel for a handful of rows (M <= 128: one decoding step of the causal decoder, heads on a batch of [CLS] rows):
+// latency / HBM work - every weight row is read once, straight from global memory into the MFMA operand registers (a
+// lane's 16-byte fragment is 8 consecutive contraction elements of one W row), no LDS staging, no persistent schedule.
+// SPLITK: a workgroup owns 16 output columns and its four waves a quarter of the contraction each (small N: 48
+// workgroups x 4 waves for N = 768 instead of 12), partial sums folded through LDS.  Otherwise a workgroup owns 64
+// columns, one wave per 16 (the vocabulary projection: N = 250 002).  Epilogues as everywhere (epilogue_store).
+// ---------------------------------------------------------------------------------
+template <int EPI, int MT, bool SPLITK>
+__global__ __launch_bounds__(256)
+void gemm_nt_skinny_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ W, int ldw,
+                           bf16* __restrict__ C, int ldc, int M, int N, int K, M3PEpilogue ep) {
+  __shared__ f32x4 red[SPLITK ? 3 : 1][MT][64];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int n0 = SPLITK ? blockIdx.x * 16 : (blockIdx.x * 4 + wid) * 16;
+  const int klen = SPLITK ? K / 4 : K;
+  const int kbeg = SPLITK ? wid * klen : 0;
+  if (!SPLITK && n0 >= N) return;
+  const bf16* wp = W + (size_t)min(n0 + fr, N - 1) * ldw + kbeg + fg * 8;
+  const bf16* ap[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) ap[i] = A + (size_t)min(i * 16 + fr, M - 1) * lda + kbeg + fg * 8;
+  f32x4 acc[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+  for (int k = 0; k < klen; k += 32) {
+    const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wp + k);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const bf16x8 af = *reinterpret_cast<const bf16x8*>(ap[i] + k);
+      acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af, acc[i], 0, 0, 0);
+    }
+  }
+  if (SPLITK) {
+    if (wid > 0) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) red[wid - 1][i][lane] = acc[i];
+    }
+    __syncthreads();
+    if (wid > 0) return;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) acc[i] += red[0][i][lane] + red[1][i][lane] + red[2][i][lane];
+  }
+  f32x4 unused = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < MT; ++i) epilogue_store<EPI>(ep, C, ldc, M, N, i * 16 + fr, n0 + fg * 4, acc[i], unused);
+}
+
+template <int EPI, int MT>
+int launch_nt_skinny(const bf16* A, int lda, const bf16* W, int ldw, bf16* C, int ldc, int M, int N, int K,
+                     const M3PEpilogue& ep, hipStream_t st) {
+  if (N <= 8192)
+    hipLaunchKernelGGL((gemm_nt_skinny_kernel<EPI, MT, true>), dim3((N + 15) / 16), dim3(256), 0, st, A, lda, W, ldw, C, ldc, M, N, K, ep);
+  else
+    hipLaunchKernelGGL((gemm_nt_skinny_kernel<EPI, MT, false>), dim3((N + 63) / 64), dim3(256), 0, st, A, lda, W, ldw, C, ldc, M, N, K, ep);
+  M3P_CHECK_LAUNCH();
+  return M3P_OK;
+}
+
 static int num_cus() {
   static int n = 0;
   if (n == 0) {
@@ -1909,6 +1971,13 @@ int launch_nt(const bf16* A, int lda, const bf16* W, int ldw, bf16* C, int ldc, 
   // full-tile shapes go to the 4-wave 256x256 kernel (measured on M=41984 against the 8-wave ring
   // kernel: K=3072,N=768 1000 vs 855 TF; N=3072,K=768 910 vs 815; 768x768 980 vs 925); ragged
   // shapes and the vocabulary projection's m-fast order stay on the ring kernel
+  if (M <= 128 && g_variant >= 1 && g_variant != 9 && (K % 128) == 0 && (lda % 8) == 0 && (ldw % 8) == 0 &&
+      (((uintptr_t)A | (uintptr_t)W) & 15) == 0 && EPI != M3P_EPI_DGELU && EPI != M3P_EPI_MUL) {
+    if (M <= 16) return launch_nt_skinny<EPI, 1>(A, lda, W, ldw, C, ldc, M, N, K, ep, st);
+    if (M <= 32) return launch_nt_skinny<EPI, 2>(A, lda, W, ldw, C, ldc, M, N, K, ep, st);
+    if (M <= 64) return launch_nt_skinny<EPI, 4>(A, lda, W, ldw, C, ldc, M, N, K, ep, st);
+    return launch_nt_skinny<EPI, 8>(A, lda, W, ldw, C, ldc, M, N, K, ep, st);
+  }
   const bool deep = (N >= 512) && (2LL * N * K <= (64LL << 20)) && EPI != M3P_EPI_DGELU;   // (dGELU epilogue: 240 VGPRs there, measured slower in the step)
   if (M >= 1024 && (g_variant == 1 || g_variant == 6) && (N >= 512) && (2LL * N * K <= (64LL << 20)) && (K % 64) == 0 && (lda % 8) == 0 &&
       (ldw % 8) == 0 && (M % 256) == 0 && (N % 256) == 0) {

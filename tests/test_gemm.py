@@ -196,6 +196,48 @@ def test_gemm_nt_256x256_kernels(M, N, K, variant):
         lib.m3p_debug_set_variant(1)
 
 
+@pytest.mark.parametrize('M,N,K', [(1, 768, 768), (5, 256, 128), (16, 2304, 768), (33, 1000, 3072), (64, 768, 3072),
+                                   (100, 3072, 768), (128, 1536, 1024), (32, 250002, 768), (128, 20003, 256)])
+def test_gemm_nt_skinny_rows(M, N, K):
+    """M <= 128 rows (a decoding step, head GEMMs on [CLS] rows): the fragment-from-global kernel, split-K for small N and
+    one wave per 16 columns for the vocabulary width; every epilogue it takes, ragged N, against the fp32 product."""
+    from m3p_amd import ops, rng, lib as L
+    a, ac = randn_bf16((M, K), 11)
+    w, wc = randn_bf16((N, K), 12, 0.05)
+    bias, bc = randn_f32((N,), 13)
+    r, rc = randn_bf16((M, N), 14)
+    prod = ac @ wc.t()
+    if N % 8:       # a row pitch must be a multiple of 4 elements: odd widths (the vocabulary) live in padded buffers
+        NP = (N + 63) // 64 * 64
+        buf = torch.zeros((M, NP), dtype=torch.bfloat16, device='cuda')
+        ops.gemm_nt(a, w, L.EPI_BIAS, bias=bias, out=buf, n=N)
+        assert rel_l2(buf[:, :N].float(), prod + bc) < 4e-3 and float(buf[:, N:].abs().max()) == 0.0
+        return
+    c = ops.gemm_nt(a, w, L.EPI_NONE)
+    assert rel_l2(c.float(), prod) < 4e-3
+    c = ops.gemm_nt(a, w, L.EPI_BIAS, bias=bias, scale_cols=N // 3, scale=0.125)
+    ref = prod + bc
+    ref[:, :N // 3] *= 0.125
+    assert rel_l2(c.float(), ref) < 4e-3
+    u = torch.empty((M, N), dtype=torch.bfloat16, device='cuda')
+    h = ops.gemm_nt(a, w, L.EPI_BIAS_GELU, bias=bias, out2=u)
+    assert rel_l2(u.float(), prod + bc) < 4e-3
+    uf = u.float().cpu().double()
+    assert rel_l2(h.float(), (0.5 * uf * (1 + torch.erf(uf / math.sqrt(2)))).float()) < 4e-3
+    c = ops.gemm_nt(a, w, L.EPI_BIAS_DROP_RES, bias=bias, aux=r, seed=99, p_drop=0.1)
+    keep = torch.from_numpy(rng.keep_mask(M * N, 99, 0.1, (M, N)))
+    assert rel_l2(c.float(), (prod + bc) * keep / 0.9 + rc) < 4e-3
+    c = ops.gemm_nt(a, w, L.EPI_RES, aux=r, alpha=0.5)
+    assert rel_l2(c.float(), 0.5 * prod + rc) < 4e-3
+    # a strided output (the vocabulary logits live in a padded buffer) and a row-sliced weight (k | v rows of the fused matrix)
+    if N >= 512:
+        buf = torch.zeros((M, N + 64), dtype=torch.bfloat16, device='cuda')
+        ops.gemm_nt(a, w, L.EPI_BIAS, bias=bias, out=buf, n=N)
+        assert rel_l2(buf[:, :N].float(), prod + bc) < 4e-3 and float(buf[:, N:].abs().max()) == 0.0
+        c = ops.gemm_nt(a, w[256:], L.EPI_NONE)
+        assert rel_l2(c.float(), prod[:, 256:]) < 4e-3
+
+
 @pytest.mark.parametrize('M,N,K,kv', [(300, 768, 4096, 4096), (4864, 768, 25024, 25002), (1000, 130, 640, 601)])
 def test_gemm_nn_streamk(M, N, K, kv):
     """Cf += alpha * A[M,K] W[K,N] with W row-major in the contraction index (the vocabulary data gradient reads the
