@@ -402,6 +402,12 @@ class TransformerModel(nn.Module):
                                            langs=langs, cache=cache, enc_mask=enc_mask)
         assert src_enc is None and cache is None and positions is None, \
             'the non-causal text stream takes no source encoding, cache or explicit positions (the mlm_step caller)'
+        if langs is not None:
+            # transformer.py:1059-1060 adds cross_lang_embeddings(langs) to the text rows of a multilingual model; the
+            # fused assembly kernel has no such term (and the training arena does not hold that table): refuse rather
+            # than train a different model silently
+            raise NotImplementedError('language embeddings in the non-causal text stream are not built: run the MLM '
+                                      'stream with params.n_langs == 1 (langs=None)')
         T, B = x.size()
         p = self.dropout if self.training else 0.0
         pa = self.attention_dropout if self.training else 0.0

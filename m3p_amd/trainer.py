@@ -245,16 +245,17 @@ class Trainer(object):
         x, lengths, positions, langs, _ = self.generate_batch(lang1, lang2, 'pred')
         x, lengths, positions, langs, _ = self.round_batch(x, lengths, positions, langs)
         x, y, pred_mask = self.mask_out(x, lengths)
-        return self.mlm_step_on_batch(x, lengths, pred_mask, y, lang1, lambda_coeff)
+        return self.mlm_step_on_batch(x, lengths, pred_mask, y, lang1, lambda_coeff, langs=langs)
 
-    def mlm_step_on_batch(self, x, lengths, pred_mask, y, lang='en', lambda_coeff=1):
+    def mlm_step_on_batch(self, x, lengths, pred_mask, y, lang='en', lambda_coeff=1, langs=None):
         """Loss path of mlm_step on an already masked batch (:751-770)."""
         model = self.model
         model.train()
         self._dp_plan(True, expect=('mlm',))
         n_words = pred_mask.sum()
         x, y, pred_mask, lengths = to_cuda(x, y, pred_mask, lengths)
-        tensor = model('crossfwd', stream_='text', x=x, lengths=lengths, positions=None, langs=None, causal=False)
+        # (langs is None unless params.n_langs > 1: the model refuses language ids on this stream instead of dropping them)
+        tensor = model('crossfwd', stream_='text', x=x, lengths=lengths, positions=None, langs=langs, causal=False)
         _, loss = model('predict', tensor=tensor, pred_mask=pred_mask, y=y, get_scores=False)
         self._stat('MLM-%s' % lang, loss)
         self.optimize(lambda_coeff * loss)
