@@ -291,7 +291,7 @@ def refiner_bwd(model, dout, saved, keylen, B, R, seed_step, p):
     return dx
 
 
-N_ENC_ARGS = 13     # positional arguments of EncoderFn.forward (backward returns one None per argument)
+N_ENC_ARGS = 14     # positional arguments of EncoderFn.forward (backward returns one None per argument)
 
 
 class EncoderFn(torch.autograd.Function):
@@ -302,7 +302,7 @@ class EncoderFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, anchor, model, x, lengths, x_img, lengths_img, image_loc, p_drop, p_attn, seed_step, p_refine=None,
-                track=False, text_embed=None):
+                track=False, text_embed=None, langs=None):
         ar = model.arena()
         ar.refresh()
         dev = ar.device
@@ -324,6 +324,16 @@ class EncoderFn(torch.autograd.Function):
             tok = (torch.arange(B, device=dev, dtype=torch.int64) * T)[None, :] + \
                 torch.arange(T, device=dev, dtype=torch.int64)[:, None]
             tok = tok.contiguous()
+        if langs is not None:
+            # language embeddings of the text stream (transformer.py:1059-1060): the assembly kernel again gathers "token"
+            # b*T + t, now from the rows  Emb[x] + Lang[langs]  built here (one extra bf16 rounding of the sum); backward
+            # gets the rows' gradients back and scatters them into both tables
+            assert text_embed is None and R == 0
+            langs = langs.to(dev).contiguous()
+            rows = table[x.t()].float() + ar.p('cross_lang_embeddings.weight')[langs.t()]
+            table = rows.to(BF16).reshape(B * T, d).contiguous()
+            tok = ((torch.arange(B, device=dev, dtype=torch.int64) * T)[None, :] +
+                   torch.arange(T, device=dev, dtype=torch.int64)[:, None]).contiguous()
         totlen = lengths if R == 0 else (lengths + lengths_img)
         totlen = totlen.to(device=dev, dtype=torch.int32).contiguous()
         rowmask = (torch.arange(S, device=dev, dtype=torch.int32)[None, :] < totlen[:, None]).to(torch.uint8).contiguous().view(-1)
@@ -398,9 +408,12 @@ class EncoderFn(torch.autograd.Function):
         ctx.model = model
         ctx.dims = (B, T, R, S, d, H, dh, nL)
         ctx.drop = (p_drop, p_attn, seed_step)
-        ctx.saved = (tok, totlen, rowmask, ximg16, loc, emb_saved, saved_layers)
+        # (backward wants the REAL token ids where they exist - pad rows, the scatter into the vocabulary matrix; with
+        #  text_embed there are none and it gets the row numbers)
+        ctx.saved = (tok if text_embed is not None else x, totlen, rowmask, ximg16, loc, emb_saved, saved_layers)
         ctx.refine = (ref_saved, keylen_img, p_refine)
         ctx.input_grads = (R > 0 and x_img.requires_grad and track, text_embed is not None)
+        ctx.langs = langs
         # data parallelism: count the encoder passes that will be differentiated (only the last backward of a
         # step launches gradient buckets) and learn the token-row count the ranks pad to
         hook = model.ddp_hook
@@ -478,8 +491,9 @@ class EncoderFn(torch.autograd.Function):
                 hook.layer_done(i, last)
         # under data parallelism the token rows' gradients are exchanged as rows, not scattered here
         want_dximg, has_text_embed = ctx.input_grads
+        langs = ctx.langs
         tok_rows = None
-        if has_text_embed or (hook is not None and hook.active):
+        if has_text_embed or langs is not None or (hook is not None and hook.active):
             tok_rows = torch.empty((T * B, d), dtype=BF16, device=dh_.device)
         grads = dict(
             d_g_emb=ar.g('layer_norm_emb.weight'), d_be_emb=ar.g('layer_norm_emb.bias'),
@@ -507,9 +521,23 @@ class EncoderFn(torch.autograd.Function):
         if has_text_embed:
             d_text = tok_rows.view(T, B, d).transpose(0, 1).float()
             tok_rows = None
+        if langs is not None:
+            # the rows' gradients go to both tables: Lang[l] += sum of the rows with language l - a one-hot [T*B, n_langs]
+            # matrix against the rows on the weight-gradient GEMM - and Emb[x] += row (below, or by the data-parallel
+            # row exchange)
+            npad = (model.n_langs + 7) // 8 * 8
+            onehot = torch.zeros((T * B, npad), dtype=BF16, device=tok_rows.device)
+            onehot.scatter_(1, langs.view(-1, 1), 1.0)
+            dl = torch.zeros((npad, d), dtype=torch.float32, device=tok_rows.device)
+            ops.gemm_wgrad(onehot, tok_rows, dl)
+            ar.g('cross_lang_embeddings.weight').add_(dl[:model.n_langs])
+            ar.touch('cross_lang_embeddings.weight')
+            if hook is None or not hook.active:
+                ops.scatter_add_token_rows(tok_rows, x.contiguous().view(-1), ar.g('embeddings.weight'), model.pad_index)
+                tok_rows = None
         if hook is not None:
             hook.embed_done(last, ids=x if tok_rows is not None else None, rows=tok_rows, n_max=ctx.tok_rows_max)
-        return (None, None, None, None, d_ximg, None, None, None, None, None, None, None, d_text)
+        return (None, None, None, None, d_ximg, None, None, None, None, None, None, None, d_text, None)
 
 
 class MLMHeadFn(torch.autograd.Function):

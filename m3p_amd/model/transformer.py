@@ -269,6 +269,8 @@ class TransformerModel(nn.Module):
         out['embeddings.weight'] = self.embeddings.weight
         out['pred_layer.proj.bias'] = self.pred_layer.proj.bias
         out['position_embeddings.weight'] = self.position_embeddings.weight
+        if self.n_langs > 1:      # language embeddings of the text streams (transformer.py:657, :1059-1060)
+            out['cross_lang_embeddings.weight'] = self.cross_lang_embeddings.weight
         out['layer_norm_emb.weight'] = self.layer_norm_emb.weight
         out['layer_norm_emb.bias'] = self.layer_norm_emb.bias
         ie = self.image_embeddings
@@ -402,17 +404,13 @@ class TransformerModel(nn.Module):
                                            langs=langs, cache=cache, enc_mask=enc_mask)
         assert src_enc is None and cache is None and positions is None, \
             'the non-causal text stream takes no source encoding, cache or explicit positions (the mlm_step caller)'
-        if langs is not None:
-            # transformer.py:1059-1060 adds cross_lang_embeddings(langs) to the text rows of a multilingual model; the
-            # fused assembly kernel has no such term (and the training arena does not hold that table): refuse rather
-            # than train a different model silently
-            raise NotImplementedError('language embeddings in the non-causal text stream are not built: run the MLM '
-                                      'stream with params.n_langs == 1 (langs=None)')
         T, B = x.size()
+        if langs is not None:      # transformer.py:1059-1060: + cross_lang_embeddings(langs) on the text rows
+            assert self.n_langs > 1 and langs.size() == (T, B), 'language ids need a model with n_langs > 1'
         p = self.dropout if self.training else 0.0
         pa = self.attention_dropout if self.training else 0.0
         out = Fn.EncoderFn.apply(self.layer_norm_emb.weight, self, x, lengths, None, None, None, p, pa,
-                                 self._next_seed_step(), None, torch.is_grad_enabled(), None)
+                                 self._next_seed_step(), None, torch.is_grad_enabled(), None, langs)
         return out.view(B, T, self.dim).transpose(0, 1)
 
     def predict(self, tensor, pred_mask=None, y=None, get_scores=None, is_obj=False, is_relation=False,

@@ -61,6 +61,8 @@ def hot_param_shapes(p):
     out = OrderedDict()
     out['position_embeddings.weight'] = (N_MAX_POSITIONS, d)
     out['embeddings.weight'] = (V, d)
+    if p.n_langs > 1:
+        out['cross_lang_embeddings.weight'] = (p.n_langs, d)
     out['layer_norm_emb.weight'] = (d,)
     out['layer_norm_emb.bias'] = (d,)
     out['image_embeddings.image_embeddings.weight'] = (d, 2048)
@@ -293,3 +295,14 @@ def make_batch(T, R, B, n_words, n_pred, seed=5678, ragged=True, sample_n=2):
         lengths_img=torch.from_numpy(lengths_img),
         pos_labels=torch.from_numpy(pos_labels), itm_targets=torch.from_numpy(itm),
     )
+
+
+def text_langs_case():
+    """Two-language cfg1 model + batch of the language-embedding golden (sentence b is in language b % 2)."""
+    cfg = CONFIGS['cfg1']
+    P = model_params(cfg['emb_dim'], cfg['n_heads'], cfg['n_layers'], cfg['n_words'], n_langs=2,
+                           id2lang={0: 'en', 1: 'zh'}, lang2id={'en': 0, 'zh': 1})
+    sd = golden_state_dict(hot_param_shapes(P), seed=4321)
+    batch = make_batch(cfg['T'], cfg['R'], cfg['B'], cfg['n_words'], cfg['n_pred'], seed=99)
+    langs = (torch.arange(cfg['B']) % 2)[None, :].expand(cfg['T'], cfg['B']).contiguous()
+    return cfg, P, sd, batch, langs

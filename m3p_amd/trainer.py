@@ -254,7 +254,7 @@ class Trainer(object):
         self._dp_plan(True, expect=('mlm',))
         n_words = pred_mask.sum()
         x, y, pred_mask, lengths = to_cuda(x, y, pred_mask, lengths)
-        # (langs is None unless params.n_langs > 1: the model refuses language ids on this stream instead of dropping them)
+        # (langs is None unless params.n_langs > 1: then the stream adds the language embeddings, transformer.py:1059-1060)
         tensor = model('crossfwd', stream_='text', x=x, lengths=lengths, positions=None, langs=langs, causal=False)
         _, loss = model('predict', tensor=tensor, pred_mask=pred_mask, y=y, get_scores=False)
         self._stat('MLM-%s' % lang, loss)

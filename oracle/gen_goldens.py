@@ -538,6 +538,38 @@ def gen_host_goldens():
 
 
 
+def gen_text_langs_goldens():
+    """text_langs.npz: the text MLM stream of a multilingual model (crossfwd adds cross_lang_embeddings(langs),
+    transformer.py:1059-1060): output, MLM loss and gradients from the reference."""
+    from src.model.transformer import TransformerModel
+    from oracle import ref_cpu
+    cfg, P, sd, batch, langs = synth.text_langs_case()
+    torch.manual_seed(0)
+    m = TransformerModel(P, is_encoder=True, with_output=True, is_crossModal=True)
+    own = dict(m.named_parameters())
+    with torch.no_grad():
+        for k, v in sd.items():
+            own[k].copy_(v)
+    m.train()       # dropout 0: same numbers as eval, with gradients
+    out = m('crossfwd', stream_='text', x=batch['x'], lengths=batch['lengths'], positions=None, langs=langs, causal=False)
+    _, loss = m('predict', tensor=out, pred_mask=batch['pred_mask'], y=batch['y'], get_scores=False)
+    loss.backward()
+    g = {'text_out': out.detach().numpy(), 'mlm_loss': loss.detach().numpy()}
+    for k in ('cross_lang_embeddings.weight', 'position_embeddings.weight', 'layer_norm_emb.weight', 'attentions.0.q_lin.weight',
+              'ffns.1.lin2.weight', 'pred_layer.proj.bias'):
+        g['grad.' + k] = own[k].grad.numpy()
+    ge = own['embeddings.weight'].grad
+    rows = torch.unique(batch['x'])[:64]
+    g['grad_rows.ids'] = rows.numpy()
+    g['grad_rows.embeddings.weight'] = ge[rows].numpy()
+    g['grad_norm.embeddings.weight'] = ge.norm().numpy()
+    o = ref_cpu.crossfwd_text(sd, cfg['n_layers'], cfg['n_heads'], batch['x'], batch['lengths'], langs=langs)
+    print('text_langs.npz: loss %.6f; oracle-vs-reference max|d| %.2e; |d lang| %.4f' %
+          (float(loss), float((o - out.detach()).abs().max()), float(own['cross_lang_embeddings.weight'].grad.norm())))
+    assert float((o - out.detach()).abs().max()) < 1e-4
+    np.savez_compressed(os.path.join(OUT, 'text_langs.npz'), **g)
+
+
 def gen_decoder_goldens():
     """decoder.npz: the reference's causal decoder (TransformerModel(is_encoder=False)) on the deterministic cases of
     m3p_amd.synth.DECODER_CASES - teacher-forced crossfwd(causal=True, src_enc) hidden states, the same computed
@@ -611,6 +643,9 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'host':
         gen_host_goldens()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'langs':
+        gen_text_langs_goldens()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'decoder':
         gen_decoder_goldens()
         sys.exit(0)
@@ -627,3 +662,4 @@ if __name__ == '__main__':
     gen_trainer_goldens()
     gen_host_goldens()
     gen_decoder_goldens()
+    gen_text_langs_goldens()

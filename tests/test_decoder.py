@@ -216,12 +216,10 @@ def test_attn_query_kernel_vs_torch():
         assert rel_l2(ctx.float(), ref) < 5e-3, (B, Tq, H, dh, Lk)
 
 
-def test_noncausal_text_stream_refuses_language_ids():
-    """transformer.py:1059-1060 adds cross_lang_embeddings(langs) on the text stream of a multilingual model; this build's
-    fused assembly has no such term, so it must refuse instead of silently training a different model."""
+def test_language_ids_need_a_multilingual_model():
     from m3p_amd.model.transformer import TransformerModel
-    P = synth.model_params(128, 4, 1, 100, n_langs=2, id2lang={0: 'en', 1: 'zh'}, lang2id={'en': 0, 'zh': 1})
+    P = synth.model_params(128, 4, 1, 100)
     m = TransformerModel(P, is_encoder=True, with_output=True, is_crossModal=True)
     x = torch.full((6, 2), 5, dtype=torch.long)
-    with pytest.raises(NotImplementedError, match='language embeddings'):
+    with pytest.raises(AssertionError, match='n_langs'):
         m('crossfwd', stream_='text', x=x, lengths=torch.tensor([6, 4]), langs=torch.zeros_like(x), causal=False)
