@@ -185,6 +185,20 @@ M3P_API int m3p_attn_query_fwd(const void* q, int ld_q, const void* kv, long lon
                                const int32_t* klen, void* ctx, int B, int Tq, int H, int dh, int Lk, int causal,
                                int pos0, void* stream);
 
+/* The same attention for the TRAINING of the causal / cross-attention sub-layers (teacher forcing: Tq = the whole target
+ * sequence, pos0 = 0): dropout on the probabilities (stream (seed, thresh24) indexed ((b*H + h)*Tq + t)*Lk + key) and the
+ * log-sum-exp lse fp32 [B, H, Tq] kept for backward.  B*H*Tq*Lk < 2^32. */
+M3P_API int m3p_attn_rows_fwd(const void* q, int ld_q, const void* kv, long long kv_bstride, int ld_kv, const int32_t* klen,
+                              void* ctx, float* lse, int B, int Tq, int H, int dh, int Lk, int causal, int pos0,
+                              uint32_t seed, uint32_t thresh24, float inv_keep, void* stream);
+/* Backward: dq bf16 [B*Tq, ld_dq] = gradient of the UNSCALED query projection (the scaled gradient x qscale, like
+ * m3p_attn_bwd); the key / value gradients are ADDED (fp32 atomics) into dkv [B, Lk, 2*H*dh] (keys | values per position),
+ * which the caller zeroes. */
+M3P_API int m3p_attn_rows_bwd(const void* q, int ld_q, const void* kv, long long kv_bstride, int ld_kv, const int32_t* klen,
+                              const void* dctx, const float* lse, void* dq, int ld_dq, float* dkv, int B, int Tq, int H,
+                              int dh, int Lk, int causal, int pos0, float qscale, uint32_t seed, uint32_t thresh24,
+                              float inv_keep, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Input assembly of jointfwd (transformer.py:901-943) and its backward
  * ---------------------------------------------------------------------------------- */

@@ -47,6 +47,8 @@ SIGNATURES = {
     'm3p_attn_fwd': (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _u32, _u32, _f, _p]),
     'm3p_attn_bwd': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _u32, _u32, _f, _p]),
     'm3p_attn_query_fwd': (_i, [_p, _i, _p, C.c_longlong, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    'm3p_attn_rows_fwd': (_i, [_p, _i, _p, C.c_longlong, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _u32, _u32, _f, _p]),
+    'm3p_attn_rows_bwd': (_i, [_p, _i, _p, C.c_longlong, _i, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _f, _u32, _u32, _f, _p]),
     'm3p_cast_f32_bf16': (_i, [_p, _p, C.c_longlong, _p]),
     'm3p_embed_assemble_fwd': (_i, [_p] * 19 + [_i, _i, _i, _i, _u32, _u32, _u32, _f, _p, _p]),
     'm3p_embed_image_rows_fwd': (_i, [_p] * 10 + [_i, _i, _i, _u32, _u32, _f, _p]),

@@ -248,6 +248,34 @@ def attn_query_fwd(q, kv, klen, B, Tq, H, dh, Lk, causal=False, pos0=0):
     return ctx
 
 
+def attn_rows_fwd(q, kv, klen, B, Tq, H, dh, Lk, causal=False, seed=0, p_drop=0.0):
+    """Training form of attn_query_fwd: dropout on the probabilities, returns (ctx bf16 [B*Tq, H*dh], lse fp32 [B, H, Tq])."""
+    _chk_bf16(q, kv)
+    assert q.stride(1) == 1 and kv.dim() == 3 and kv.stride(2) == 1 and kv.shape[0] == B and kv.shape[1] >= Lk
+    ctx = torch.empty((B * Tq, H * dh), dtype=BF16, device=q.device)
+    lse = torch.empty((B, H, Tq), dtype=torch.float32, device=q.device)
+    rc = L.load().m3p_attn_rows_fwd(q.data_ptr(), q.stride(0), kv.data_ptr(), kv.stride(0), kv.stride(1), L.ptr(klen),
+                                    ctx.data_ptr(), lse.data_ptr(), B, Tq, H, dh, Lk, 1 if causal else 0, 0, seed,
+                                    L.thresh24(p_drop), 1.0 / (1.0 - p_drop) if p_drop > 0 else 1.0, L.stream())
+    L.check(rc, 'm3p_attn_rows_fwd')
+    return ctx, lse
+
+
+def attn_rows_bwd(q, kv, klen, dctx, lse, B, Tq, H, dh, Lk, qscale, causal=False, seed=0, p_drop=0.0, dq_out=None):
+    """-> (dq bf16 [B*Tq, H*dh] (or written into dq_out, row pitch dq_out.stride(0)), dkv fp32 [B, Lk, 2*H*dh])."""
+    _chk_bf16(q, kv, dctx)
+    assert dctx.is_contiguous()
+    d = H * dh
+    dq = dq_out if dq_out is not None else torch.empty((B * Tq, d), dtype=BF16, device=q.device)
+    dkv = torch.zeros((B, Lk, 2 * d), dtype=torch.float32, device=q.device)
+    rc = L.load().m3p_attn_rows_bwd(q.data_ptr(), q.stride(0), kv.data_ptr(), kv.stride(0), kv.stride(1), L.ptr(klen),
+                                    dctx.data_ptr(), lse.data_ptr(), dq.data_ptr(), dq.stride(0), dkv.data_ptr(), B, Tq, H, dh, Lk,
+                                    1 if causal else 0, 0, qscale, seed, L.thresh24(p_drop),
+                                    1.0 / (1.0 - p_drop) if p_drop > 0 else 1.0, L.stream())
+    L.check(rc, 'm3p_attn_rows_bwd')
+    return dq, dkv
+
+
 def cast_bf16(x):
     """fp32 -> bf16 through the HIP cast kernel (bf16 input is returned unchanged)."""
     if x.dtype == BF16:

@@ -223,3 +223,42 @@ def test_language_ids_need_a_multilingual_model():
     x = torch.full((6, 2), 5, dtype=torch.long)
     with pytest.raises(AssertionError, match='n_langs'):
         m('crossfwd', stream_='text', x=x, lengths=torch.tensor([6, 4]), langs=torch.zeros_like(x), causal=False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,Tq,H,dh,Lk,causal,p', [(3, 9, 4, 32, 9, True, 0.0), (2, 17, 12, 64, 17, True, 0.1),
+                                                   (4, 6, 2, 64, 50, False, 0.1), (2, 33, 4, 32, 137, False, 0.0)])
+def test_attn_rows_training_kernels_vs_autograd(B, Tq, H, dh, Lk, causal, p):
+    """Forward with dropout (keep mask regenerated by the RNG twin) + log-sum-exp, and the backward (dq of the unscaled
+    projection, dk / dv accumulated in fp32) against torch autograd on the same bf16 operands."""
+    from m3p_amd import ops, rng
+    d = H * dh
+    g = torch.Generator(device='cuda').manual_seed(7)
+    qscale = 1.0 / np.sqrt(dh)
+    q = (torch.randn(B * Tq, d, device='cuda', generator=g) * qscale).to(torch.bfloat16)       # the scaled projection output
+    kv = torch.randn(B, Lk, 2 * d, device='cuda', generator=g).to(torch.bfloat16)
+    klen = None if causal else torch.randint(1, Lk + 1, (B,), device='cuda', generator=g).to(torch.int32)
+    dctx = torch.randn(B * Tq, d, device='cuda', generator=g).to(torch.bfloat16)
+    seed = 4242
+    ctx, lse = ops.attn_rows_fwd(q, kv, klen, B, Tq, H, dh, Lk, causal=causal, seed=seed, p_drop=p)
+    keep = torch.from_numpy(rng.keep_mask(B * H * Tq * Lk, seed, p, (B, H, Tq, Lk))).cuda() if p > 0 else None
+    qf = q.float().view(B, Tq, H, dh).transpose(1, 2).requires_grad_(True)
+    kf = kv[:, :, :d].float().reshape(B, Lk, H, dh).transpose(1, 2).requires_grad_(True)
+    vf = kv[:, :, d:].float().reshape(B, Lk, H, dh).transpose(1, 2).requires_grad_(True)
+    s = qf @ kf.transpose(2, 3)
+    j = torch.arange(Lk, device='cuda')
+    if causal:
+        s = s.masked_fill(~(j[None, :] <= torch.arange(Tq, device='cuda')[:, None])[None, None], float('-inf'))
+    else:
+        s = s.masked_fill(~(j[None, :] < klen[:, None])[:, None, None, :], float('-inf'))
+    pr = torch.softmax(s, -1)
+    if keep is not None:
+        pr = pr * keep / (1 - p)
+    ref = (pr @ vf).transpose(1, 2).reshape(B * Tq, d)
+    assert rel_l2(ctx.float(), ref) < 5e-3
+    assert rel_l2(lse, torch.logsumexp(s, -1)) < 1e-4
+    ref.backward(dctx.float())
+    dq, dkv = ops.attn_rows_bwd(q, kv, klen, dctx, lse, B, Tq, H, dh, Lk, qscale, causal=causal, seed=seed, p_drop=p)
+    assert rel_l2(dq.float(), (qf.grad * qscale).transpose(1, 2).reshape(B * Tq, d)) < 1e-2
+    assert rel_l2(dkv[:, :, :d], kf.grad.transpose(1, 2).reshape(B, Lk, d)) < 1e-2
+    assert rel_l2(dkv[:, :, d:], vf.grad.transpose(1, 2).reshape(B, Lk, d)) < 1e-2
