@@ -10,8 +10,9 @@ holds, per layer, ONE token-major bf16 tensor [bs, capacity, 2 d] (keys | values
 [bs, S_src, 2 d] for the encoder attention (projected once, at the first step); the reference keeps (k, v) head-major
 tuples under the module ids and concatenates per step.  ``cache['slen']`` has the reference's meaning.
 
-Forward only: the teacher-forced training of the decoder (backward through causal / cross attention) is not built -
-calling this with autograd enabled on a model in training mode raises.
+This module is forward only; the teacher-forced training pass of the same stream is ``functional.DecoderFn``
+(``TransformerModel.crossfwd`` picks it in training mode), and calling ``decoder_forward`` itself with autograd enabled on
+a model in training mode raises.
 """
 import math
 

@@ -66,6 +66,10 @@ class Arena:
             self.wt[('out', i)] = torch.zeros((d, d), dtype=BF16, device=dev)
             self.wt[('lin1', i)] = torch.zeros((d, 4 * d), dtype=BF16, device=dev)
             self.wt[('lin2', i)] = torch.zeros((4 * d, d), dtype=BF16, device=dev)
+            if model.cross_attention_hot:
+                self.wt[('xq', i)] = torch.zeros((d, d), dtype=BF16, device=dev)
+                self.wt[('xkv', i)] = torch.zeros((d, 2 * d), dtype=BF16, device=dev)
+                self.wt[('xout', i)] = torch.zeros((d, d), dtype=BF16, device=dev)
         # contiguous arena ranges used as gradient buckets (reverse-backward order) and by the optimizer
         self.layer_ranges = []
         for i in range(L_):
@@ -83,13 +87,17 @@ class Arena:
         self._layer_names = [[n for n in self.names if n.startswith(('attentions.%d.' % i, 'layer_norm1.%d.' % i,
                                                                      'ffns.%d.' % i, 'layer_norm2.%d.' % i))]
                              for i in range(L_)]
+        self._cross_names = [[n for n in self.names if n.startswith(('encoder_attn.%d.' % i, 'layer_norm15.%d.' % i))]
+                             for i in range(L_)]
 
     def touch(self, *names):
         self.touched.update(names)
         self.grads_known_zero = False
 
-    def touch_layer(self, i):
+    def touch_layer(self, i, cross=False):
         self.touched.update(self._layer_names[i])
+        if cross:
+            self.touched.update(self._cross_names[i])
         self.grads_known_zero = False
 
     # ---- views
@@ -114,6 +122,17 @@ class Arena:
         o = self.offsets['attentions.%d.q_lin.weight' % i][0]
         d = self.model.dim
         return self.grad[o:o + 3 * d * d].view(3 * d, d)
+
+    # encoder-attention sub-layer of layer i (cross_attention_hot): q | k | v adjacent like the self-attention
+    def xattn(self, i, what, grad=False):
+        """what: 'q' [d, d], 'kv' [2d, d] (weights; bf16 working copy or fp32 gradient), 'bq' [d], 'bkv' [2d] (fp32)."""
+        d = self.model.dim
+        if what in ('q', 'kv'):
+            o = self.offsets['encoder_attn.%d.%s_lin.weight' % (i, 'q' if what == 'q' else 'k')][0]
+            n = d if what == 'q' else 2 * d
+            return (self.grad if grad else self.w16)[o:o + n * d].view(n, d)
+        o = self.offsets['encoder_attn.%d.%s_lin.bias' % (i, 'q' if what == 'bq' else 'k')][0]
+        return (self.grad if grad else self.master)[o:o + (d if what == 'bq' else 2 * d)]
 
     # AoA refiner layer i: the three input projections are adjacent in the arena like q/k/v of an encoder layer
     def ref_qkv_w16(self, i):
@@ -164,7 +183,10 @@ class Arena:
                     for src, dst in ((self.qkv_w16(i), self.wt[('qkv', i)]),
                                      (self.w('attentions.%d.out_lin.weight' % i), self.wt[('out', i)]),
                                      (self.w('ffns.%d.lin1.weight' % i), self.wt[('lin1', i)]),
-                                     (self.w('ffns.%d.lin2.weight' % i), self.wt[('lin2', i)])):
+                                     (self.w('ffns.%d.lin2.weight' % i), self.wt[('lin2', i)])) + \
+                                    (((self.xattn(i, 'q'), self.wt[('xq', i)]), (self.xattn(i, 'kv'), self.wt[('xkv', i)]),
+                                      (self.w('encoder_attn.%d.out_lin.weight' % i), self.wt[('xout', i)]))
+                                     if self.model.cross_attention_hot else ()):
                         r, c = src.shape
                         rows.append([src.data_ptr(), dst.data_ptr(), r, c, src.stride(0), dst.stride(0)])
                         mt = max(mt, ((r + 63) // 64) * ((c + 63) // 64))
@@ -192,6 +214,23 @@ class Arena:
 
 def _site(kind, layer=0):
     return {'img': 0, 'emb': 1}.get(kind, 8 + 4 * layer + {'attn_p': 0, 'attn_out': 1, 'ffn': 2}.get(kind, 3))
+
+
+_DEC_SITE0 = 1 << 21   # dropout sites of the causal stream: _DEC_SITE0 + 8 * layer + {0 self-attention probabilities,
+                        # 1 self-attention output, 2 encoder-attention probabilities, 3 encoder-attention output, 4 FFN}, + 7 = embeddings
+
+
+class ArenaCrossWeights:
+    """The encoder-attention weights as the decoder path wants them (q, kv, out, bq, bkv, bo per layer), read from the arena."""
+
+    def __init__(self, ar):
+        n = ar.model.n_layers
+        self.q = [ar.xattn(i, 'q') for i in range(n)]
+        self.kv = [ar.xattn(i, 'kv') for i in range(n)]
+        self.out = [ar.w('encoder_attn.%d.out_lin.weight' % i) for i in range(n)]
+        self.bq = [ar.xattn(i, 'bq') for i in range(n)]
+        self.bkv = [ar.xattn(i, 'bkv') for i in range(n)]
+        self.bo = [ar.p('encoder_attn.%d.out_lin.bias' % i) for i in range(n)]
 
 
 _REF_SITE0 = 1 << 20   # dropout sites of the refiner: _REF_SITE0 + 8 * layer + {0 attention probabilities, 1 AoA
@@ -538,6 +577,192 @@ class EncoderFn(torch.autograd.Function):
         if hook is not None:
             hook.embed_done(last, ids=x if tok_rows is not None else None, rows=tok_rows, n_max=ctx.tok_rows_max)
         return (None, None, None, None, d_ximg, None, None, None, None, None, None, None, d_text, None)
+
+
+class DecoderFn(torch.autograd.Function):
+    """crossfwd(stream_='text', causal=True, src_enc=..., src_len=...) with gradients: the teacher-forced pass of the
+    translation / auto-encoding steps (transformer.py:1005-1102; caller xtrainer.py:1383-1441).  Text embedding assembly as
+    in the non-causal stream, then per layer causal self-attention -> LN1 -> attention over the source encoding -> LN1.5
+    -> FFN -> LN2.  Target sequences are short, so both attentions run on the rows kernels (csrc/decode.hip: a wave per
+    (sequence, head, query)); every projection, LayerNorm and the embedding assembly are the encoder's kernels.  The
+    gradient wrt src_enc is returned to autograd (it flows on into the encoder pass that produced it); parameter
+    gradients go to the arena."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, x, lengths, src_enc, src_len, langs, p_drop, p_attn, seed_step):
+        ar = model.arena()
+        ar.refresh()
+        dev = ar.device
+        d, H, nL = model.dim, model.n_heads, model.n_layers
+        dh = d // H
+        T, B = x.shape
+        M = B * T
+        dseed = lambda k, i=0: rng.stream_seed(model.base_seed, seed_step, _DEC_SITE0 + 8 * i + k)   # noqa: E731
+        x = x.to(dev).contiguous()
+        table, tok = ar.w('embeddings.weight'), x
+        if langs is not None:
+            langs = langs.to(dev).contiguous()
+            rows = table[x.t()].float() + ar.p('cross_lang_embeddings.weight')[langs.t()]
+            table = rows.to(BF16).reshape(B * T, d).contiguous()
+            tok = ((torch.arange(B, device=dev, dtype=torch.int64) * T)[None, :] +
+                   torch.arange(T, device=dev, dtype=torch.int64)[:, None]).contiguous()
+        totlen = lengths.to(device=dev, dtype=torch.int32).contiguous()
+        rowmask = (torch.arange(T, device=dev, dtype=torch.int32)[None, :] < totlen[:, None]).to(torch.uint8).contiguous().view(-1)
+        h, emb_saved = ops.embed_assemble_fwd(
+            tok, table, ar.p('position_embeddings.weight'), None, None,
+            ar.p('image_embeddings.image_location_embeddings.weight'), ar.p('image_embeddings.image_location_embeddings.bias'),
+            ar.p('image_embeddings.LayerNorm.weight'), ar.p('image_embeddings.LayerNorm.bias'),
+            ar.p('layer_norm_emb.weight'), ar.p('layer_norm_emb.bias'), totlen, B, T, 0, d,
+            seed_img=0, seed_emb=dseed(7), p_drop=p_drop)
+        has_src = src_enc is not None
+        S = src16 = src_klen = None
+        if has_src:
+            assert model.cross_attention_hot, 'the encoder-attention sub-layer is not in the training arena (params.mt_steps)'
+            S = src_enc.shape[1]
+            src16 = src_enc.detach().to(device=dev, dtype=BF16).contiguous().view(B * S, d)
+            src_klen = src_len.to(device=dev, dtype=torch.int32).clamp(max=S).contiguous()
+        qscale = 1.0 / math.sqrt(dh)
+        saved = []
+        for i in range(nL):
+            a, f, e = 'attentions.%d.' % i, 'ffns.%d.' % i, 'encoder_attn.%d.' % i
+            qkv = ops.gemm_nt(h, ar.qkv_w16(i), L.EPI_BIAS, bias=ar.qkv_bias(i), scale_cols=d, scale=qscale)
+            ctxt, lse = ops.attn_rows_fwd(qkv, qkv.view(B, T, 3 * d)[:, :, d:], None, B, T, H, dh, T, causal=True,
+                                          seed=dseed(0, i), p_drop=p_attn)
+            pre1 = ops.gemm_nt(ctxt, ar.w(a + 'out_lin.weight'), L.EPI_BIAS_DROP_RES, bias=ar.p(a + 'out_lin.bias'), aux=h,
+                               seed=dseed(1, i), p_drop=p_drop)
+            x1, mean1, rstd1 = ops.layernorm_fwd(pre1, ar.p('layer_norm1.%d.weight' % i), ar.p('layer_norm1.%d.bias' % i))
+            cross = None
+            xf = x1
+            if has_src:
+                q2 = ops.gemm_nt(x1, ar.xattn(i, 'q'), L.EPI_BIAS, bias=ar.xattn(i, 'bq'), scale_cols=d, scale=qscale)
+                kvc = ops.gemm_nt(src16, ar.xattn(i, 'kv'), L.EPI_BIAS, bias=ar.xattn(i, 'bkv')).view(B, S, 2 * d)
+                ctx2, lse2 = ops.attn_rows_fwd(q2, kvc, src_klen, B, T, H, dh, S, seed=dseed(2, i), p_drop=p_attn)
+                pre15 = ops.gemm_nt(ctx2, ar.w(e + 'out_lin.weight'), L.EPI_BIAS_DROP_RES, bias=ar.p(e + 'out_lin.bias'),
+                                    aux=x1, seed=dseed(3, i), p_drop=p_drop)
+                xf, mean15, rstd15 = ops.layernorm_fwd(pre15, ar.p('layer_norm15.%d.weight' % i), ar.p('layer_norm15.%d.bias' % i))
+                cross = (q2, kvc, ctx2, lse2, pre15, mean15, rstd15)
+            u = torch.empty((M, 4 * d), dtype=BF16, device=dev)
+            hact = ops.gemm_nt(xf, ar.w(f + 'lin1.weight'), L.EPI_BIAS_GELU, bias=ar.p(f + 'lin1.bias'), out2=u)
+            pre2 = ops.gemm_nt(hact, ar.w(f + 'lin2.weight'), L.EPI_BIAS_DROP_RES, bias=ar.p(f + 'lin2.bias'), aux=xf,
+                               seed=dseed(4, i), p_drop=p_drop)
+            h_next, mean2, rstd2 = ops.layernorm_fwd(pre2, ar.p('layer_norm2.%d.weight' % i), ar.p('layer_norm2.%d.bias' % i),
+                                                     rowmask)
+            saved.append((h, qkv, ctxt, lse, pre1, mean1, rstd1, x1, cross, xf, u, hact, pre2, mean2, rstd2))
+            h = h_next
+        ctx.model = model
+        ctx.dims = (B, T, S, d, H, dh, nL)
+        ctx.drop = (p_drop, p_attn, seed_step)
+        ctx.saved = (x, totlen, rowmask, emb_saved, saved, src16, src_klen, langs)
+        ctx.src_meta = (src_enc.dtype, src_enc.requires_grad) if has_src else None
+        hook = model.ddp_hook
+        ctx.track = hook is not None
+        ctx.tok_rows_max = hook.encoder_forward(T * B) if ctx.track else None
+        ctx.set_materialize_grads(False)
+        return h
+
+    @staticmethod
+    def backward(ctx, dout):
+        model = ctx.model
+        ar = model.arena()
+        B, T, S, d, H, dh, nL = ctx.dims
+        p_drop, p_attn, seed_step = ctx.drop
+        x, totlen, rowmask, emb_saved, saved, src16, src_klen, langs = ctx.saved
+        ctx.saved = None
+        dseed = lambda k, i=0: rng.stream_seed(model.base_seed, seed_step, _DEC_SITE0 + 8 * i + k)   # noqa: E731
+        hook = model.ddp_hook if ctx.track else None
+        n_args = 10
+        if dout is None:
+            if hook is not None:
+                hook.encoder_backward_end()
+            return (None,) * n_args
+        dh_ = dout.contiguous()
+        if dh_.dtype != BF16:
+            dh_ = dh_.to(BF16)
+        last = hook.encoder_backward_begin() if hook is not None else True
+        qscale = 1.0 / math.sqrt(dh)
+        has_src = src16 is not None
+        d_src = None
+        for i in reversed(range(nL)):
+            a, f, e = 'attentions.%d.' % i, 'ffns.%d.' % i, 'encoder_attn.%d.' % i
+            (h_in, qkv, ctxt, lse, pre1, mean1, rstd1, x1, cross, xf, u, hact, pre2, mean2, rstd2) = saved[i]
+            saved[i] = None
+            dpre2, dY2 = ops.layernorm_bwd(dh_, None, pre2, ar.p('layer_norm2.%d.weight' % i), mean2, rstd2, rowmask,
+                                           ar.g('layer_norm2.%d.weight' % i), ar.g('layer_norm2.%d.bias' % i),
+                                           dbias_drop=ar.g(f + 'lin2.bias'), want_drop=p_drop > 0, seed=dseed(4, i), p_drop=p_drop)
+            if dY2 is None:
+                dY2 = dpre2
+            ops.gemm_wgrad(dY2, hact, ar.g(f + 'lin2.weight'))
+            dU = ops.gemm_nt(dY2, ar.wt[('lin2', i)], L.EPI_DGELU, aux=u, colsum=ar.g(f + 'lin1.bias'))
+            ops.gemm_wgrad(dU, xf, ar.g(f + 'lin1.weight'))
+            dxf = ops.gemm_nt(dU, ar.wt[('lin1', i)], L.EPI_RES, aux=dpre2)
+            if has_src:
+                q2, kvc, ctx2, lse2, pre15, mean15, rstd15 = cross
+                dpre15, dAO2 = ops.layernorm_bwd(dxf, None, pre15, ar.p('layer_norm15.%d.weight' % i), mean15, rstd15, None,
+                                                 ar.g('layer_norm15.%d.weight' % i), ar.g('layer_norm15.%d.bias' % i),
+                                                 dbias_drop=ar.g(e + 'out_lin.bias'), want_drop=p_drop > 0, seed=dseed(3, i),
+                                                 p_drop=p_drop)
+                if dAO2 is None:
+                    dAO2 = dpre15
+                ops.gemm_wgrad(dAO2, ctx2, ar.g(e + 'out_lin.weight'))
+                dctx2 = ops.gemm_nt(dAO2, ar.wt[('xout', i)], L.EPI_NONE)
+                dq2, dkvc = ops.attn_rows_bwd(q2, kvc, src_klen, dctx2, lse2, B, T, H, dh, S, qscale, seed=dseed(2, i), p_drop=p_attn)
+                dkvc = dkvc.to(BF16).view(B * S, 2 * d)
+                ops.gemm_wgrad(dq2, x1, ar.xattn(i, 'q', grad=True))
+                ops.colsum(dq2, d, ar.xattn(i, 'bq', grad=True))
+                ops.gemm_wgrad(dkvc, src16, ar.xattn(i, 'kv', grad=True))
+                ops.colsum(dkvc, 2 * d, ar.xattn(i, 'bkv', grad=True))
+                d_src = ops.gemm_nt(dkvc, ar.wt[('xkv', i)], L.EPI_NONE if d_src is None else L.EPI_RES, aux=d_src)
+                dx1 = ops.gemm_nt(dq2, ar.wt[('xq', i)], L.EPI_RES, aux=dpre15)
+            else:
+                dx1 = dxf
+            dpre1, dAO = ops.layernorm_bwd(dx1, None, pre1, ar.p('layer_norm1.%d.weight' % i), mean1, rstd1, None,
+                                           ar.g('layer_norm1.%d.weight' % i), ar.g('layer_norm1.%d.bias' % i),
+                                           dbias_drop=ar.g(a + 'out_lin.bias'), want_drop=p_drop > 0, seed=dseed(1, i), p_drop=p_drop)
+            if dAO is None:
+                dAO = dpre1
+            ops.gemm_wgrad(dAO, ctxt, ar.g(a + 'out_lin.weight'))
+            dctx = ops.gemm_nt(dAO, ar.wt[('out', i)], L.EPI_NONE)
+            dqkv = torch.empty_like(qkv)
+            _, dkv = ops.attn_rows_bwd(qkv, qkv.view(B, T, 3 * d)[:, :, d:], None, dctx, lse, B, T, H, dh, T, qscale, causal=True,
+                                       seed=dseed(0, i), p_drop=p_attn, dq_out=dqkv)
+            dqkv.view(B, T, 3 * d)[:, :, d:] = dkv
+            ops.colsum(dqkv, 3 * d, ar.qkv_bias(i, grad=True))
+            ops.gemm_wgrad(dqkv, h_in, ar.qkv_wgrad(i))
+            dh_ = ops.gemm_nt(dqkv, ar.wt[('qkv', i)], L.EPI_RES, aux=dpre1)
+            ar.touch_layer(i, cross=has_src)
+            if hook is not None:
+                hook.layer_done(i, last)
+        tok_rows = None
+        if langs is not None or (hook is not None and hook.active):
+            tok_rows = torch.empty((T * B, d), dtype=BF16, device=dh_.device)
+        grads = dict(
+            d_g_emb=ar.g('layer_norm_emb.weight'), d_be_emb=ar.g('layer_norm_emb.bias'),
+            d_pos=ar.g('position_embeddings.weight'), d_emb=ar.g('embeddings.weight'),
+            d_g_img=ar.g('image_embeddings.LayerNorm.weight'), d_be_img=ar.g('image_embeddings.LayerNorm.bias'),
+            d_b_img=ar.g('image_embeddings.image_embeddings.bias'),
+            d_b_loc=ar.g('image_embeddings.image_location_embeddings.bias'),
+            d_w_loc=ar.g('image_embeddings.image_location_embeddings.weight'))
+        ops.embed_assemble_bwd(dh_, emb_saved, ar.p('layer_norm_emb.weight'), ar.p('image_embeddings.LayerNorm.weight'), x,
+                               totlen, None, grads, B, T, 0, d, model.pad_index, seed_img=0, seed_emb=dseed(7), p_drop=p_drop,
+                               tok_rows=tok_rows)
+        ar.touch('layer_norm_emb.weight', 'layer_norm_emb.bias', 'position_embeddings.weight', 'embeddings.weight')
+        if langs is not None:
+            npad = (model.n_langs + 7) // 8 * 8
+            onehot = torch.zeros((T * B, npad), dtype=BF16, device=tok_rows.device)
+            onehot.scatter_(1, langs.view(-1, 1), 1.0)
+            dl = torch.zeros((npad, d), dtype=torch.float32, device=tok_rows.device)
+            ops.gemm_wgrad(onehot, tok_rows, dl)
+            ar.g('cross_lang_embeddings.weight').add_(dl[:model.n_langs])
+            ar.touch('cross_lang_embeddings.weight')
+            if hook is None or not hook.active:
+                ops.scatter_add_token_rows(tok_rows, x.contiguous().view(-1), ar.g('embeddings.weight'), model.pad_index)
+                tok_rows = None
+        if hook is not None:
+            hook.embed_done(last, ids=x if tok_rows is not None else None, rows=tok_rows, n_max=ctx.tok_rows_max)
+        g_src = None
+        if has_src and ctx.src_meta[1]:
+            g_src = d_src.view(B, S, d).to(ctx.src_meta[0])
+        return (None, None, None, None, g_src, None, None, None, None, None)
 
 
 class MLMHeadFn(torch.autograd.Function):

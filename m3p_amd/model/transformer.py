@@ -256,6 +256,12 @@ class TransformerModel(nn.Module):
         # fp8 GEMMs for the encoder layers' projections (BASELINE.json configs[3]; not a reference flag: m3p_amd/fp8.py)
         self.fp8 = bool(getattr(params, 'fp8_gemm', False))
         self._fp8_state = None
+        # the encoder-attention sub-layer (encoder_attn / layer_norm15, transformer.py:673-698, executed only by
+        # crossfwd(causal=True, src_enc=...)) is trained - i.e. lives in the arena - when the model is a decoder or the
+        # run lists translation / auto-encoding steps (train_x.py:215-218); otherwise its parameters stay outside, as
+        # never-executed state, and cost the gradient buckets nothing
+        self.cross_attention_hot = bool(self.is_decoder or getattr(params, 'mt_steps', None) or getattr(params, 'ae_steps', None)
+                                        or getattr(params, 'train_cross_attention', False))
         self._arena = None
         self._cold_w16 = None
         self.base_seed = 0x5EED
@@ -304,6 +310,13 @@ class TransformerModel(nn.Module):
             out['attentions.%d.out_lin.bias' % i] = a.out_lin.bias
             out['layer_norm1.%d.weight' % i] = self.layer_norm1[i].weight
             out['layer_norm1.%d.bias' % i] = self.layer_norm1[i].bias
+            if self.cross_attention_hot:       # q / k / v adjacent again (one [2d, d] view is the fused key-value projection)
+                pre = 'encoder_attn.%d.' % i
+                for suffix in ('weight', 'bias'):
+                    for lin in ('q_lin', 'k_lin', 'v_lin'):
+                        out[pre + lin + '.' + suffix] = own[pre + lin + '.' + suffix]
+                for n in (pre + 'out_lin.weight', pre + 'out_lin.bias', 'layer_norm15.%d.weight' % i, 'layer_norm15.%d.bias' % i):
+                    out[n] = own[n]
             out['ffns.%d.lin1.weight' % i] = f.lin1.weight
             out['ffns.%d.lin1.bias' % i] = f.lin1.bias
             out['ffns.%d.lin2.weight' % i] = f.lin2.weight
@@ -331,7 +344,10 @@ class TransformerModel(nn.Module):
         return self
 
     def decoder_cold_weights(self):
-        """bf16 copies of the encoder-attention sub-layer's weights (decoder inference, m3p_amd/decoder.py)."""
+        """bf16 copies of the encoder-attention sub-layer's weights (decoder inference, m3p_amd/decoder.py): views of the
+        arena's working copy when the sub-layer is trained, copies made on demand otherwise."""
+        if self.cross_attention_hot:
+            return Fn.ArenaCrossWeights(self.arena())
         if self._cold_w16 is None:
             from ..decoder import _ColdWeights
             self._cold_w16 = _ColdWeights(self)
@@ -399,6 +415,13 @@ class TransformerModel(nn.Module):
         """Text-only stream of transformer.py:970-1114 (the mlm_step caller, xtrainer.py:757)."""
         assert stream_ == 'text', "crossfwd(stream_='img') is outside the MI355X build"
         if causal:       # the decoder: causal self-attention (+ attention over src_enc), key / value cache (:1011-1091)
+            if torch.is_grad_enabled() and self.training:
+                # teacher-forced training pass (mt_step / ae_step, xtrainer.py:1383-1441): the whole target at once
+                assert cache is None and positions is None and enc_mask is None
+                T, B = x.size()
+                out = Fn.DecoderFn.apply(self.layer_norm_emb.weight, self, x, lengths, src_enc, src_len, langs, self.dropout,
+                                         self.attention_dropout, self._next_seed_step())
+                return out.view(B, T, self.dim).transpose(0, 1)
             from .. import decoder
             return decoder.decoder_forward(self, x, lengths, src_enc=src_enc, src_len=src_len, positions=positions,
                                            langs=langs, cache=cache, enc_mask=enc_mask)

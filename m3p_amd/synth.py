@@ -306,3 +306,42 @@ def text_langs_case():
     batch = make_batch(cfg['T'], cfg['R'], cfg['B'], cfg['n_words'], cfg['n_pred'], seed=99)
     langs = (torch.arange(cfg['B']) % 2)[None, :].expand(cfg['T'], cfg['B']).contiguous()
     return cfg, P, sd, batch, langs
+
+
+def mt_case():
+    """Two-language encoder_only model (cfg1 width, 2 layers) with a trained encoder-attention sub-layer, and a translation
+    batch (source sentences x1 in language 0, targets x2 in language 1) for the mt_step golden."""
+    P = model_params(128, 4, 2, 1000, n_langs=2, id2lang={0: 'en', 1: 'zh'}, lang2id={'en': 0, 'zh': 1},
+                     mt_steps=[('en', 'zh')], encoder_only=True)
+    shapes = hot_param_shapes(P)
+    d = P.emb_dim
+    for i in range(P.n_layers):
+        for lin in ('q_lin', 'k_lin', 'v_lin', 'out_lin'):
+            shapes['encoder_attn.%d.%s.weight' % (i, lin)] = (d, d)
+            shapes['encoder_attn.%d.%s.bias' % (i, lin)] = (d,)
+        shapes['layer_norm15.%d.weight' % i] = (d,)
+        shapes['layer_norm15.%d.bias' % i] = (d,)
+    sd = golden_state_dict(shapes, seed=777)
+    rs = np.random.RandomState(778)
+
+    def sentences(T, B):
+        x = torch.from_numpy(rs.randint(3, P.n_words, size=(T, B))).long()
+        lengths = torch.from_numpy(rs.randint(T // 2, T + 1, size=B)).long()
+        lengths[0] = T
+        x[0] = EOS
+        for b in range(B):
+            x[int(lengths[b]) - 1, b] = EOS
+            x[int(lengths[b]):, b] = PAD
+        return x, lengths
+
+    x1, len1 = sentences(14, 6)
+    x2, len2 = sentences(11, 6)
+    return P, sd, x1, len1, x2, len2
+
+
+def mt_targets(x2, len2):
+    """xtrainer.py:1410-1413: predict word t + 1 from position t for every position but a sentence's last."""
+    alen = torch.arange(int(len2.max()), dtype=torch.long)
+    pred_mask = alen[:, None] < len2[None] - 1
+    y = x2[1:].masked_select(pred_mask[:-1])
+    return pred_mask, y

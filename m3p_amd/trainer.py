@@ -13,8 +13,9 @@ Entry points kept with the reference's signatures and batch tuples:
 Changed on purpose (SURVEY.md §7 "host side clean"): no per-step host syncs - the NaN check
 (:210), the ``.cpu()`` ITM loss (:2367-2370) and the ``loss.item()`` statistics (:2317, :2374)
 stay on the device and are only read when ``print_stats`` prints; clip + Adam + zero_grad are
-one fused kernel pass; DDP is our bucketed reducer (m3p_amd/distributed.py).  Not built:
-the generation / captioning / FreeLB / sliding-window steps (SURVEY §8 f4 and out of scope).
+one fused kernel pass; DDP is our bucketed reducer (m3p_amd/distributed.py).  ``mt_step`` (:1383-1441) is the
+translation step on the causal stream.  Not built: the captioning / FreeLB / sliding-window steps (SURVEY §8 f4 and
+out of scope).
 """
 import os
 import time
@@ -48,7 +49,7 @@ def _unwrap(model):
 def _stat_names(params):
     """Loss statistics of the steps this build runs (xtrainer.py:101-130 lists them for every task)."""
     g = lambda k: getattr(params, k, [])   # noqa: E731
-    names = ['MLM-%s' % l for l in g('langs')]
+    names = ['MLM-%s' % l for l in g('langs')] + ['MT-%s-%s' % (l1, l2) for l1, l2 in (g('mt_steps') or [])]
     for key, steps in (('CMLM', g('cross_mlm_steps')), ('MRM', g('cross_mrm_steps')), ('MRFR', g('cross_mrfr_steps')),
                        ('t2i', g('cross_rel_steps')), ('i2t', g('cross_rel_steps'))):
         names += ['%s-%s' % (key, l1) for l1, _ in steps]
@@ -265,6 +266,43 @@ class Trainer(object):
         return loss
 
     # ------------------------------------------------------------------ checkpoints (xtrainer.py:511-650)
+
+    def mt_step(self, lang1, lang2, lambda_coeff):
+        """Machine translation step (xtrainer.py:1383-1441; lang1 == lang2: denoising auto-encoding is not built - its
+        add_noise lives in the data layer)."""
+        assert lambda_coeff >= 0
+        if lambda_coeff == 0:
+            return
+        assert lang1 != lang2, 'the auto-encoding variant (add_noise) is not part of this build'
+        (x1, len1), (x2, len2) = self.get_cross_lingual_batch('mt', lang1, lang2)
+        return self.mt_step_on_batch(x1, len1, x2, len2, lang1, lang2, lambda_coeff)
+
+    def mt_step_on_batch(self, x1, len1, x2, len2, lang1, lang2, lambda_coeff=1):
+        """Loss path of mt_step on a parallel batch (:1410-1441): the model encodes the source sentence (non-causal text
+        stream with its language embedding) and decodes the target with teacher forcing (causal stream + attention over
+        the encoding); word t + 1 is predicted from position t."""
+        params = self.params
+        model = self.model
+        model.train()
+        self._dp_plan(True, expect=('mlm',))
+        langs1 = x1.clone().fill_(params.lang2id[lang1])
+        langs2 = x2.clone().fill_(params.lang2id[lang2])
+        alen = torch.arange(int(len2.max()), dtype=torch.long, device=len2.device)
+        pred_mask = alen[:, None] < len2[None] - 1           # nothing is predicted from a sentence's last word
+        y = x2[1:].masked_select(pred_mask[:-1])
+        n_words = int((len2 - 1).sum())
+        assert len(y) == n_words
+        x1, len1, langs1, x2, len2, langs2, y, pred_mask = to_cuda(x1, len1, langs1, x2, len2, langs2, y, pred_mask)
+        enc1 = model('crossfwd', stream_='text', x=x1, lengths=len1, langs=langs1, causal=False)
+        enc1 = enc1.transpose(0, 1)
+        dec2 = model('crossfwd', stream_='text', x=x2, lengths=len2, langs=langs2, causal=True, src_enc=enc1, src_len=len1)
+        _, loss = model('predict', tensor=dec2, pred_mask=pred_mask, y=y, get_scores=False)
+        self._stat('MT-%s-%s' % (lang1, lang2), loss)
+        self.optimize(lambda_coeff * loss)
+        self.n_sentences += params.batch_size
+        self.stats['processed_s'] += len2.size(0)
+        self.stats['processed_w'] += n_words
+        return loss.detach()
     def _state_dicts(self):
         return {n: {k: v.detach().cpu().clone() for k, v in _unwrap(getattr(self, n)).state_dict().items()}
                 for n in self.MODEL_NAMES}

@@ -570,6 +570,47 @@ def gen_text_langs_goldens():
     np.savez_compressed(os.path.join(OUT, 'text_langs.npz'), **g)
 
 
+def gen_mt_goldens():
+    """mt_step.npz: the translation step of xtrainer.py:1383-1441 on the reference (dropout 0): encoder pass on the source
+    (crossfwd text, langs), teacher-forced causal pass over it, loss, gradients."""
+    from src.model.transformer import TransformerModel
+    from oracle import ref_cpu
+    P, sd, x1, len1, x2, len2 = synth.mt_case()
+    torch.manual_seed(0)
+    m = TransformerModel(P, is_encoder=True, with_output=True, is_crossModal=True)
+    own = dict(m.named_parameters())
+    with torch.no_grad():
+        for k, v in sd.items():
+            own[k].copy_(v)
+    m.train()
+    langs1, langs2 = x1.clone().fill_(0), x2.clone().fill_(1)
+    pred_mask, y = synth.mt_targets(x2, len2)
+    enc1 = m('crossfwd', stream_='text', x=x1, lengths=len1, langs=langs1, causal=False).transpose(0, 1)
+    dec2 = m('crossfwd', stream_='text', x=x2, lengths=len2, langs=langs2, causal=True, src_enc=enc1, src_len=len1)
+    _, loss = m('predict', tensor=dec2, pred_mask=pred_mask, y=y, get_scores=False)
+    loss.backward()
+    g = {'enc1': enc1.detach().numpy(), 'dec2': dec2.detach().numpy(), 'loss': loss.detach().numpy()}
+    names = ['cross_lang_embeddings.weight', 'position_embeddings.weight', 'layer_norm_emb.weight', 'pred_layer.proj.bias']
+    for i in range(P.n_layers):
+        names += ['attentions.%d.q_lin.weight' % i, 'attentions.%d.k_lin.weight' % i, 'attentions.%d.v_lin.bias' % i,
+                  'attentions.%d.out_lin.weight' % i, 'layer_norm1.%d.weight' % i,
+                  'encoder_attn.%d.q_lin.weight' % i, 'encoder_attn.%d.q_lin.bias' % i, 'encoder_attn.%d.k_lin.weight' % i,
+                  'encoder_attn.%d.v_lin.weight' % i, 'encoder_attn.%d.v_lin.bias' % i, 'encoder_attn.%d.out_lin.weight' % i,
+                  'encoder_attn.%d.out_lin.bias' % i, 'layer_norm15.%d.weight' % i, 'layer_norm15.%d.bias' % i,
+                  'ffns.%d.lin1.weight' % i, 'ffns.%d.lin2.bias' % i, 'layer_norm2.%d.bias' % i]
+    for k in names:
+        g['grad.' + k] = own[k].grad.numpy()
+    g['grad_norm.embeddings.weight'] = own['embeddings.weight'].grad.norm().numpy()
+    # the restatement
+    o_enc = ref_cpu.crossfwd_text(sd, P.n_layers, P.n_heads, x1, len1, langs=langs1).transpose(0, 1)
+    o_dec = ref_cpu.decoder_crossfwd(sd, P.n_layers, P.n_heads, x2, len2, o_enc, len1, langs=langs2)
+    o_loss = ref_cpu.predict_mlm(sd, o_dec, pred_mask, y)
+    o_loss = o_loss[1] if isinstance(o_loss, tuple) else o_loss
+    print('mt_step.npz: loss %.6f (oracle %.6f); dec max|d| %.2e' % (float(loss), float(o_loss), float((o_dec - dec2.detach()).abs().max())))
+    assert abs(float(loss) - float(o_loss)) < 1e-4
+    np.savez_compressed(os.path.join(OUT, 'mt_step.npz'), **g)
+
+
 def gen_decoder_goldens():
     """decoder.npz: the reference's causal decoder (TransformerModel(is_encoder=False)) on the deterministic cases of
     m3p_amd.synth.DECODER_CASES - teacher-forced crossfwd(causal=True, src_enc) hidden states, the same computed
@@ -637,29 +678,12 @@ def gen_decoder_goldens():
 
 
 if __name__ == '__main__':
-    if len(sys.argv) > 1 and sys.argv[1] == 'enum':
-        gen_state_dict_enumeration()
+    single = {'enum': gen_state_dict_enumeration, 'host': gen_host_goldens, 'mt': gen_mt_goldens, 'langs': gen_text_langs_goldens,
+              'decoder': gen_decoder_goldens, 'refiner': gen_refiner_goldens}
+    if len(sys.argv) > 1:
+        single[sys.argv[1]]()
         sys.exit(0)
-    if len(sys.argv) > 1 and sys.argv[1] == 'host':
-        gen_host_goldens()
-        sys.exit(0)
-    if len(sys.argv) > 1 and sys.argv[1] == 'langs':
-        gen_text_langs_goldens()
-        sys.exit(0)
-    if len(sys.argv) > 1 and sys.argv[1] == 'decoder':
-        gen_decoder_goldens()
-        sys.exit(0)
-    if len(sys.argv) > 1 and sys.argv[1] == 'refiner':
-        gen_refiner_goldens()
-        sys.exit(0)
-    gen_state_dict_enumeration()
-    gen_refiner_goldens()
-    gen_clcm_goldens()
-    gen_region_head_goldens()
-    gen_text_and_itm_goldens()
-    gen_unit_goldens()
-    gen_model_goldens()
-    gen_trainer_goldens()
-    gen_host_goldens()
-    gen_decoder_goldens()
-    gen_text_langs_goldens()
+    for fn in (gen_state_dict_enumeration, gen_refiner_goldens, gen_clcm_goldens, gen_region_head_goldens,
+               gen_text_and_itm_goldens, gen_unit_goldens, gen_model_goldens, gen_trainer_goldens, gen_host_goldens,
+               gen_decoder_goldens, gen_text_langs_goldens, gen_mt_goldens):
+        fn()

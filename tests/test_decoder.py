@@ -262,3 +262,97 @@ def test_attn_rows_training_kernels_vs_autograd(B, Tq, H, dh, Lk, causal, p):
     assert rel_l2(dq.float(), (qf.grad * qscale).transpose(1, 2).reshape(B * Tq, d)) < 1e-2
     assert rel_l2(dkv[:, :, :d], kf.grad.transpose(1, 2).reshape(B, Lk, d)) < 1e-2
     assert rel_l2(dkv[:, :, d:], vf.grad.transpose(1, 2).reshape(B, Lk, d)) < 1e-2
+
+
+def _mt_model(extra=None):
+    from m3p_amd.model.transformer import TransformerModel
+    P, sd, x1, len1, x2, len2 = synth.mt_case()
+    for k, v in (extra or {}).items():
+        setattr(P, k, v)
+    torch.manual_seed(0)
+    m = TransformerModel(P, is_encoder=True, with_output=True, is_crossModal=True).cuda()
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and not [k for k in missing if k.startswith(('encoder_attn', 'layer_norm15', 'cross_lang'))]
+    return m, P, sd, x1, len1, x2, len2
+
+
+def test_oracle_mt_step_matches_the_reference():
+    """CPU: the restatement of the translation step (encoder pass with language ids, teacher-forced causal pass with
+    attention over it, next-word loss) against the reference's recorded outputs."""
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'mt_step.npz'))
+    P, sd, x1, len1, x2, len2 = synth.mt_case()
+    pred_mask, y = synth.mt_targets(x2, len2)
+    enc = ref_cpu.crossfwd_text(sd, P.n_layers, P.n_heads, x1, len1, langs=x1.clone().fill_(0)).transpose(0, 1)
+    dec = ref_cpu.decoder_crossfwd(sd, P.n_layers, P.n_heads, x2, len2, enc, len1, langs=x2.clone().fill_(1))
+    assert np.abs(enc.numpy() - g['enc1']).max() < 2e-5 and np.abs(dec.numpy() - g['dec2']).max() < 2e-5
+    loss = ref_cpu.predict_mlm(sd, dec, pred_mask, y)
+    loss = loss[1] if isinstance(loss, tuple) else loss
+    assert abs(float(loss) - float(g['loss'])) < 1e-5
+
+
+@pytest.mark.gpu
+def test_mt_step_forward_backward_vs_reference():
+    """The translation step on the HIP path (DecoderFn: causal self-attention, attention over the encoder pass of the same
+    model, gradients through both passes) against the reference's loss and gradients (tests/golden/mt_step.npz)."""
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'mt_step.npz'))
+    m, P, sd, x1, len1, x2, len2 = _mt_model()
+    assert m.cross_attention_hot and 'encoder_attn.0.q_lin.weight' in m.arena().offsets
+    m.train()
+    m.arena().zero_grad()
+    pred_mask, y = synth.mt_targets(x2, len2)
+    enc1 = m('crossfwd', stream_='text', x=x1.cuda(), lengths=len1.cuda(), langs=x1.clone().fill_(0).cuda(), causal=False).transpose(0, 1)
+    dec2 = m('crossfwd', stream_='text', x=x2.cuda(), lengths=len2.cuda(), langs=x2.clone().fill_(1).cuda(), causal=True,
+             src_enc=enc1, src_len=len1.cuda())
+    assert rel_l2(enc1.float(), g['enc1']) < 1e-2 and rel_l2(dec2.float(), g['dec2']) < 1.5e-2
+    _, loss = m('predict', tensor=dec2, pred_mask=pred_mask.cuda(), y=y.cuda(), get_scores=False)
+    assert abs(float(loss.detach()) - float(g['loss'])) < 5e-3
+    loss.backward()
+    own = dict(m.named_parameters())
+    bad = []
+    for k in [k[5:] for k in g.files if k.startswith('grad.')]:
+        ref = g['grad.' + k]
+        if np.abs(ref).max() < 1e-7:            # (the key biases: exactly zero up to fp32 noise)
+            continue
+        e = rel_l2(own[k].grad.float(), ref)
+        if e > 4e-2:
+            bad.append((k, e))
+    assert not bad, bad
+    ge = own['embeddings.weight'].grad.float()
+    assert abs(float(ge.norm()) - float(g['grad_norm.embeddings.weight'])) < 3e-2 * float(g['grad_norm.embeddings.weight'])
+    touched = m.arena().touched
+    assert {'encoder_attn.1.out_lin.weight', 'layer_norm15.0.bias', 'cross_lang_embeddings.weight'} <= touched
+
+
+@pytest.mark.gpu
+def test_mt_step_trains_and_inference_follows_the_updated_weights():
+    """Trainer.mt_step_on_batch: the loss goes down over a few Adam steps with dropout on; generate() afterwards reads the
+    UPDATED encoder-attention weights (arena views, not stale copies)."""
+    from m3p_amd.trainer import XTrainer
+    extra = dict(optimizer='adam_inverse_sqrt,beta1=0.9,beta2=0.98,lr=0.002,warmup_updates=4', clip_grad_norm=5, amp=-1, fp16=False,
+                 accumulate_gradients=1, multi_gpu=False, epoch_size=100, cross_mlm_steps=[], cross_mrm_steps=[], langs=['en', 'zh'],
+                 cross_mrfr_steps=[], cross_clcm_steps=[], sample_n=2, refine_image=False, batch_size=6, dropout=0.1,
+                 attention_dropout=0.1, dump_path='/nonexistent_m3p_dump')
+    m, P, sd, x1, len1, x2, len2 = _mt_model(extra)
+    m.dropout = m.attention_dropout = 0.1
+    tr = XTrainer(m, {}, P)
+    losses = []
+    for _ in range(12):
+        losses.append(float(tr.mt_step_on_batch(x1, len1, x2, len2, 'en', 'zh', 1.0)))
+        tr.iter()
+    assert np.isfinite(losses).all() and losses[-1] < losses[0] - 0.5, losses
+    assert tr.stats['processed_w'] % int((len2 - 1).sum()) == 0       # (print_stats resets the counters every few iterations)
+    m.eval()
+    with torch.no_grad():
+        enc = m('crossfwd', stream_='text', x=x1.cuda(), lengths=len1.cuda(), langs=x1.clone().fill_(0).cuda(), causal=False).transpose(0, 1)
+        dec_inf = m('crossfwd', stream_='text', x=x2.cuda(), lengths=len2.cuda(), langs=x2.clone().fill_(1).cuda(), causal=True,
+                    src_enc=enc, src_len=len1.cuda())
+    # the same forward through the training kernels with dropout off
+    m.train()
+    m.dropout = m.attention_dropout = 0.0
+    dec_tr = m('crossfwd', stream_='text', x=x2.cuda(), lengths=len2.cuda(), langs=x2.clone().fill_(1).cuda(), causal=True,
+               src_enc=enc, src_len=len1.cuda())
+    assert rel_l2(dec_inf.float(), dec_tr.float().detach()) < 5e-3
+    m.eval()
+    with torch.no_grad():
+        gen, gen_len = m.generate(enc, len1.cuda(), 1, max_len=12)
+    assert gen.shape[1] == 6 and int((gen == synth.EOS).sum()) == 12
