@@ -308,19 +308,25 @@ def text_langs_case():
     return cfg, P, sd, batch, langs
 
 
+def cross_attention_param_shapes(p):
+    """(name, shape) of the encoder-attention sub-layer (transformer.py:673-698) of every layer."""
+    d, out = p.emb_dim, OrderedDict()
+    for i in range(p.n_layers):
+        for lin in ('q_lin', 'k_lin', 'v_lin', 'out_lin'):
+            out['encoder_attn.%d.%s.weight' % (i, lin)] = (d, d)
+            out['encoder_attn.%d.%s.bias' % (i, lin)] = (d,)
+        out['layer_norm15.%d.weight' % i] = (d,)
+        out['layer_norm15.%d.bias' % i] = (d,)
+    return out
+
+
 def mt_case():
     """Two-language encoder_only model (cfg1 width, 2 layers) with a trained encoder-attention sub-layer, and a translation
     batch (source sentences x1 in language 0, targets x2 in language 1) for the mt_step golden."""
     P = model_params(128, 4, 2, 1000, n_langs=2, id2lang={0: 'en', 1: 'zh'}, lang2id={'en': 0, 'zh': 1},
                      mt_steps=[('en', 'zh')], encoder_only=True)
     shapes = hot_param_shapes(P)
-    d = P.emb_dim
-    for i in range(P.n_layers):
-        for lin in ('q_lin', 'k_lin', 'v_lin', 'out_lin'):
-            shapes['encoder_attn.%d.%s.weight' % (i, lin)] = (d, d)
-            shapes['encoder_attn.%d.%s.bias' % (i, lin)] = (d,)
-        shapes['layer_norm15.%d.weight' % i] = (d,)
-        shapes['layer_norm15.%d.bias' % i] = (d,)
+    shapes.update(cross_attention_param_shapes(P))
     sd = golden_state_dict(shapes, seed=777)
     rs = np.random.RandomState(778)
 

@@ -32,7 +32,8 @@ def _free_port():
 
 
 def _params(scenario, multi_gpu):
-    P = synth.model_params(CFG['emb_dim'], CFG['n_heads'], CFG['n_layers'], CFG['n_words'])
+    two = dict(n_langs=2, id2lang={0: 'en', 1: 'zh'}, lang2id={'en': 0, 'zh': 1}, mt_steps=[('en', 'zh')]) if scenario == 'mt' else {}
+    P = synth.model_params(CFG['emb_dim'], CFG['n_heads'], CFG['n_layers'], CFG['n_words'], **two)
     for k, v in dict(optimizer='adam_inverse_sqrt,beta1=0.9,beta2=0.98,lr=0.0001', clip_grad_norm=5, amp=1, fp16=True,
                      accumulate_gradients=2 if scenario == 'accumulate' else 1, multi_gpu=multi_gpu, local_rank=0,
                      epoch_size=1000, batch_size=CFG['B'], dump_path='/nonexistent_m3p_dump', is_master=True,
@@ -41,7 +42,7 @@ def _params(scenario, multi_gpu):
                      cross_mrfr_steps=[('google', 'img')] if scenario == 'clcm' else [],
                      cross_clcm_steps=[('google', 'img')] if scenario == 'clcm' else [],
                      sample_n=2, refine_image=False, multi_cls_loss_weight=1 if scenario == 'finetune' else 0,
-                     bin_cls_loss_weight=1, langs=['en']).items():
+                     bin_cls_loss_weight=1, langs=['en', 'zh'] if scenario == 'mt' else ['en']).items():
         setattr(P, k, v)
     return P
 
@@ -54,6 +55,8 @@ def _build(scenario, multi_gpu):
     sd = synth.golden_state_dict(synth.hot_param_shapes(P))
     sd.update(synth.golden_state_dict(synth.region_head_param_shapes(P), seed=4321, pad_index=None))
     sd.update(synth.golden_state_dict(synth.clcm_head_param_shapes(P), seed=9753, pad_index=None))
+    if scenario == 'mt':
+        sd.update(synth.golden_state_dict(synth.cross_attention_param_shapes(P), seed=2468, pad_index=None))
     m.load_state_dict(sd, strict=False)
     m = m.cuda()
     return XTrainer(m, {}, P), m
@@ -75,7 +78,7 @@ def _slice(full, extra, sl, ng):
     i2t = ((x, lens, lab), (x2, len2), (extra['clcm'][sl].contiguous(), img, mask, loc, obj, pos, ori, list(range(n))))
     fin = ((x, lens, torch.zeros_like(x)), (img, mask, loc, obj, pos, list(range(n))))
     text = (x, lens, full['pred_mask'][:, sl].contiguous(), lab[full['pred_mask'][:, sl]])
-    return dict(t2i=t2i, i2t=i2t, fin=fin, text=text)
+    return dict(t2i=t2i, i2t=i2t, fin=fin, text=text, mt=(x, lens, x2, len2))
 
 
 def _batches(step):
@@ -85,7 +88,9 @@ def _batches(step):
     extra = synth.make_region_targets(CFG['R'], B, seed=77 + step)
     lab = extra['obj_labels']                                # the same number of masked regions on both halves: a rank's
     lab[B // 2:] = torch.where(lab[:B // 2] != -1, (lab[:B // 2] + 7) % 1600, lab[:B // 2])   # mean is then the global mean
-    extra.update(x2=other['x'], len2=other['lengths'], clcm=torch.tensor([1, 0, 0, 1, 1, 0, 1, 0])[:B])
+    len2 = other['lengths'].clone()
+    len2[B // 2:] = len2[:B // 2]           # the same number of target words on both halves (translation scenario)
+    extra.update(x2=other['x'], len2=len2, clcm=torch.tensor([1, 0, 0, 1, 1, 0, 1, 0])[:B])
     return full, extra
 
 
@@ -98,6 +103,8 @@ def _run_step(tr, scenario, tup):
         tr.t2i_step(tup['fin'], 'google', 1.0)
     elif scenario == 'text':
         tr.mlm_step_on_batch(*tup['text'], 'en', 1.0)
+    elif scenario == 'mt':          # two differentiated passes per step: encoder stream, then the causal stream over it
+        tr.mt_step_on_batch(*tup['mt'], 'en', 'zh', 1.0)
     tr.n_iter += 1
 
 
@@ -191,7 +198,7 @@ def _check(scenario, backend):
     assert diff <= 2.5 * lr_sum, (scenario, diff, lr_sum)    # Adam moves every weight by <= ~lr per step
 
 
-@pytest.mark.parametrize('scenario', ['pretrain', 'clcm', 'accumulate', 'finetune', 'text'])
+@pytest.mark.parametrize('scenario', ['pretrain', 'clcm', 'accumulate', 'finetune', 'text', 'mt'])
 def test_dp_two_ranks_match_single_process(scenario):
     _check(scenario, 'gloo')
 
