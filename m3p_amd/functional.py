@@ -330,7 +330,7 @@ def refiner_bwd(model, dout, saved, keylen, B, R, seed_step, p):
     return dx
 
 
-N_ENC_ARGS = 14     # positional arguments of EncoderFn.forward (backward returns one None per argument)
+N_ENC_ARGS = 15     # positional arguments of EncoderFn.forward (backward returns one None per argument)
 
 
 class EncoderFn(torch.autograd.Function):
@@ -341,64 +341,77 @@ class EncoderFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, anchor, model, x, lengths, x_img, lengths_img, image_loc, p_drop, p_attn, seed_step, p_refine=None,
-                track=False, text_embed=None, langs=None):
+                track=False, text_embed=None, langs=None, h0=None):
         ar = model.arena()
         ar.refresh()
         dev = ar.device
         d, H, nL = model.dim, model.n_heads, model.n_layers
         dh = d // H
-        T, B = x.shape
-        R = 0 if x_img is None else x_img.shape[0]
-        S = R + T
-        M = B * S
         seed = lambda kind, i=0: rng.stream_seed(model.base_seed, seed_step, _site(kind, i))   # noqa: E731
+        if h0 is not None:
+            # the layers alone on rows assembled elsewhere (the image-only stream, ImageStreamFn): h0 bf16 [B*S, d],
+            # rows b*S + s, already masked; its gradient goes back to autograd
+            assert x is None and x_img is None and text_embed is None and langs is None
+            B = lengths.shape[0]
+            S = h0.shape[0] // B
+            T, R, M = S, 0, B * S
+            totlen = lengths.to(device=dev, dtype=torch.int32).contiguous()
+            rowmask = (torch.arange(S, device=dev, dtype=torch.int32)[None, :] < totlen[:, None]).to(torch.uint8).contiguous().view(-1)
+            h = h0.detach().to(BF16).contiguous()
+            ximg16 = loc = emb_saved = img_rows = img_saved = ref_saved = keylen_img = tok = None
+        else:
+            h = None
+            T, B = x.shape
+            R = 0 if x_img is None else x_img.shape[0]
+            S = R + T
+            M = B * S
+            x = x.to(dev).contiguous()
+        if h is None:
+            # text_embed (transformer.py:910-913, the FreeLB steps' perturbed embeddings, (B, T, d)): the assembly kernel
+            # gathers "token" b*T + t from the rows of text_embed instead of id x[t, b] from the vocabulary matrix
+            table, tok = ar.w('embeddings.weight'), x
+            if text_embed is not None:
+                assert tuple(text_embed.shape) == (B, T, d), (tuple(text_embed.shape), (B, T, d))
+                table = text_embed.detach().to(device=dev, dtype=BF16).contiguous().view(B * T, d)
+                tok = (torch.arange(B, device=dev, dtype=torch.int64) * T)[None, :] + \
+                    torch.arange(T, device=dev, dtype=torch.int64)[:, None]
+                tok = tok.contiguous()
+            if langs is not None:
+                # language embeddings of the text stream (transformer.py:1059-1060): the assembly kernel again gathers "token"
+                # b*T + t, now from the rows  Emb[x] + Lang[langs]  built here (one extra bf16 rounding of the sum); backward
+                # gets the rows' gradients back and scatters them into both tables
+                assert text_embed is None and R == 0
+                langs = langs.to(dev).contiguous()
+                rows = table[x.t()].float() + ar.p('cross_lang_embeddings.weight')[langs.t()]
+                table = rows.to(BF16).reshape(B * T, d).contiguous()
+                tok = ((torch.arange(B, device=dev, dtype=torch.int64) * T)[None, :] +
+                       torch.arange(T, device=dev, dtype=torch.int64)[:, None]).contiguous()
+            totlen = lengths if R == 0 else (lengths + lengths_img)
+            totlen = totlen.to(device=dev, dtype=torch.int32).contiguous()
+            rowmask = (torch.arange(S, device=dev, dtype=torch.int32)[None, :] < totlen[:, None]).to(torch.uint8).contiguous().view(-1)
 
-        x = x.to(dev).contiguous()
-        # text_embed (transformer.py:910-913, the FreeLB steps' perturbed embeddings, (B, T, d)): the assembly kernel
-        # gathers "token" b*T + t from the rows of text_embed instead of id x[t, b] from the vocabulary matrix
-        table, tok = ar.w('embeddings.weight'), x
-        if text_embed is not None:
-            assert tuple(text_embed.shape) == (B, T, d), (tuple(text_embed.shape), (B, T, d))
-            table = text_embed.detach().to(device=dev, dtype=BF16).contiguous().view(B * T, d)
-            tok = (torch.arange(B, device=dev, dtype=torch.int64) * T)[None, :] + \
-                torch.arange(T, device=dev, dtype=torch.int64)[:, None]
-            tok = tok.contiguous()
-        if langs is not None:
-            # language embeddings of the text stream (transformer.py:1059-1060): the assembly kernel again gathers "token"
-            # b*T + t, now from the rows  Emb[x] + Lang[langs]  built here (one extra bf16 rounding of the sum); backward
-            # gets the rows' gradients back and scatters them into both tables
-            assert text_embed is None and R == 0
-            langs = langs.to(dev).contiguous()
-            rows = table[x.t()].float() + ar.p('cross_lang_embeddings.weight')[langs.t()]
-            table = rows.to(BF16).reshape(B * T, d).contiguous()
-            tok = ((torch.arange(B, device=dev, dtype=torch.int64) * T)[None, :] +
-                   torch.arange(T, device=dev, dtype=torch.int64)[:, None]).contiguous()
-        totlen = lengths if R == 0 else (lengths + lengths_img)
-        totlen = totlen.to(device=dev, dtype=torch.int32).contiguous()
-        rowmask = (torch.arange(S, device=dev, dtype=torch.int32)[None, :] < totlen[:, None]).to(torch.uint8).contiguous().view(-1)
-
-        ximg16 = img_proj = loc = None
-        if R > 0:
-            ximg16 = ops.cast_bf16(x_img.contiguous().view(R * B, 2048))
-            loc = image_loc.contiguous().float()
-            img_proj = ops.gemm_nt(ximg16, ar.w('image_embeddings.image_embeddings.weight'), L.EPI_BIAS,
-                                   bias=ar.p('image_embeddings.image_embeddings.bias'))
-        # refine_image (transformer.py:905-906): the image rows take a detour through the AoA refiner
-        img_rows = img_saved = ref_saved = keylen_img = None
-        if p_refine is not None and R > 0:
-            rows, img_saved = ops.embed_image_rows_fwd(
-                img_proj, loc, ar.p('image_embeddings.image_location_embeddings.weight'),
-                ar.p('image_embeddings.image_location_embeddings.bias'), ar.p('image_embeddings.LayerNorm.weight'),
-                ar.p('image_embeddings.LayerNorm.bias'), B, R, d, seed_img=seed('img'), p_drop=p_drop)
-            keylen_img = lengths_img.to(device=dev, dtype=torch.int32).contiguous()
-            img_rows, ref_saved = refiner_fwd(model, rows, keylen_img, B, R, seed_step, p_refine)
-        h, emb_saved = ops.embed_assemble_fwd(
-            tok, table, ar.p('position_embeddings.weight'), img_proj, loc,
-            ar.p('image_embeddings.image_location_embeddings.weight'),
-            ar.p('image_embeddings.image_location_embeddings.bias'),
-            ar.p('image_embeddings.LayerNorm.weight'), ar.p('image_embeddings.LayerNorm.bias'),
-            ar.p('layer_norm_emb.weight'), ar.p('layer_norm_emb.bias'), totlen, B, T, R, d,
-            seed_img=seed('img'), seed_emb=seed('emb'), p_drop=p_drop, img_rows=img_rows, img_saved=img_saved)
+            ximg16 = img_proj = loc = None
+            if R > 0:
+                ximg16 = ops.cast_bf16(x_img.contiguous().view(R * B, 2048))
+                loc = image_loc.contiguous().float()
+                img_proj = ops.gemm_nt(ximg16, ar.w('image_embeddings.image_embeddings.weight'), L.EPI_BIAS,
+                                       bias=ar.p('image_embeddings.image_embeddings.bias'))
+            # refine_image (transformer.py:905-906): the image rows take a detour through the AoA refiner
+            img_rows = img_saved = ref_saved = keylen_img = None
+            if p_refine is not None and R > 0:
+                rows, img_saved = ops.embed_image_rows_fwd(
+                    img_proj, loc, ar.p('image_embeddings.image_location_embeddings.weight'),
+                    ar.p('image_embeddings.image_location_embeddings.bias'), ar.p('image_embeddings.LayerNorm.weight'),
+                    ar.p('image_embeddings.LayerNorm.bias'), B, R, d, seed_img=seed('img'), p_drop=p_drop)
+                keylen_img = lengths_img.to(device=dev, dtype=torch.int32).contiguous()
+                img_rows, ref_saved = refiner_fwd(model, rows, keylen_img, B, R, seed_step, p_refine)
+            h, emb_saved = ops.embed_assemble_fwd(
+                tok, table, ar.p('position_embeddings.weight'), img_proj, loc,
+                ar.p('image_embeddings.image_location_embeddings.weight'),
+                ar.p('image_embeddings.image_location_embeddings.bias'),
+                ar.p('image_embeddings.LayerNorm.weight'), ar.p('image_embeddings.LayerNorm.bias'),
+                ar.p('layer_norm_emb.weight'), ar.p('layer_norm_emb.bias'), totlen, B, T, R, d,
+                seed_img=seed('img'), seed_emb=seed('emb'), p_drop=p_drop, img_rows=img_rows, img_saved=img_saved)
 
         saved_layers = []
         qscale = 1.0 / math.sqrt(dh)
@@ -453,11 +466,12 @@ class EncoderFn(torch.autograd.Function):
         ctx.refine = (ref_saved, keylen_img, p_refine)
         ctx.input_grads = (R > 0 and x_img.requires_grad and track, text_embed is not None)
         ctx.langs = langs
+        ctx.h0_mode = None if h0 is None else h0.dtype
         # data parallelism: count the encoder passes that will be differentiated (only the last backward of a
         # step launches gradient buckets) and learn the token-row count the ranks pad to
         hook = model.ddp_hook
         ctx.track = bool(track) and hook is not None
-        ctx.tok_rows_max = hook.encoder_forward(T * B) if ctx.track else None
+        ctx.tok_rows_max = hook.encoder_forward(0 if h0 is not None else T * B) if ctx.track else None
         ctx.set_materialize_grads(False)
         return h
 
@@ -528,6 +542,10 @@ class EncoderFn(torch.autograd.Function):
             ar.touch_layer(i)
             if hook is not None:
                 hook.layer_done(i, last)
+        if ctx.h0_mode is not None:       # no embedding assembly in this pass: the rows' gradient goes back to whoever made them
+            if hook is not None:
+                hook.embed_done(last, ids=None, rows=None, n_max=ctx.tok_rows_max)
+            return (None,) * (N_ENC_ARGS - 1) + (dh_.to(ctx.h0_mode),)
         # under data parallelism the token rows' gradients are exchanged as rows, not scattered here
         want_dximg, has_text_embed = ctx.input_grads
         langs = ctx.langs
@@ -576,7 +594,69 @@ class EncoderFn(torch.autograd.Function):
                 tok_rows = None
         if hook is not None:
             hook.embed_done(last, ids=x if tok_rows is not None else None, rows=tok_rows, n_max=ctx.tok_rows_max)
-        return (None, None, None, None, d_ximg, None, None, None, None, None, None, None, d_text, None)
+        return (None, None, None, None, d_ximg, None, None, None, None, None, None, None, d_text, None, None)
+
+
+class ImageStreamFn(torch.autograd.Function):
+    """Input rows of crossfwd(stream_='img') (transformer.py:1044-1052, the encoder pass of the captioning step):
+    BertImageEmbeddings (region projection + location projection -> LayerNorm -> its dropout, :247-269), + the language
+    embedding, the stream's dropout, the length mask - no positions and no layer_norm_emb on this stream.
+    x_img (R, B, 2048), image_loc (R, B, 5) -> bf16 [B*R, d] (rows b*R + r) for EncoderFn's layers-only mode."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, x_img, lengths, image_loc, langs, p_drop, seed_step):
+        ar = model.arena()
+        ar.refresh()
+        dev = ar.device
+        d = model.dim
+        R, B = x_img.shape[0], x_img.shape[1]
+        seed = lambda kind: rng.stream_seed(model.base_seed, seed_step, _site(kind))   # noqa: E731
+        ximg16 = ops.cast_bf16(x_img.to(dev).contiguous().view(R * B, 2048))
+        loc = image_loc.to(dev).contiguous().float()
+        img_proj = ops.gemm_nt(ximg16, ar.w('image_embeddings.image_embeddings.weight'), L.EPI_BIAS,
+                               bias=ar.p('image_embeddings.image_embeddings.bias'))
+        rows, img_saved = ops.embed_image_rows_fwd(
+            img_proj, loc, ar.p('image_embeddings.image_location_embeddings.weight'),
+            ar.p('image_embeddings.image_location_embeddings.bias'), ar.p('image_embeddings.LayerNorm.weight'),
+            ar.p('image_embeddings.LayerNorm.bias'), B, R, d, seed_img=seed('img'), p_drop=p_drop)
+        if langs is not None:
+            langs = langs.to(dev).contiguous()                                   # (R, B)
+            rows = (rows.float() + ar.p('cross_lang_embeddings.weight')[langs.t()].reshape(B * R, d)).to(BF16)
+        totlen = lengths.to(device=dev, dtype=torch.int32).contiguous()
+        mask = (torch.arange(R, device=dev, dtype=torch.int32)[None, :] < totlen[:, None]).reshape(B * R, 1)
+        h0 = ops.dropout_rows(rows, p_drop, seed('emb')) * mask.to(BF16)
+        ctx.model = model
+        ctx.saved = (ximg16, loc, img_saved, totlen, mask, langs)
+        ctx.meta = (B, R, d, p_drop, seed_step)
+        return h0
+
+    @staticmethod
+    def backward(ctx, dh0):
+        model = ctx.model
+        ar = model.arena()
+        ximg16, loc, img_saved, totlen, mask, langs = ctx.saved
+        ctx.saved = None
+        B, R, d, p_drop, seed_step = ctx.meta
+        seed = lambda kind: rng.stream_seed(model.base_seed, seed_step, _site(kind))   # noqa: E731
+        g = (dh0.to(BF16) * mask.to(BF16)).contiguous()
+        d_rows = ops.dropout_rows(g, p_drop, seed('emb'))
+        if langs is not None:
+            npad = (model.n_langs + 7) // 8 * 8
+            onehot = torch.zeros((B * R, npad), dtype=BF16, device=g.device)
+            onehot.scatter_(1, langs.t().reshape(-1, 1), 1.0)
+            dl = torch.zeros((npad, d), dtype=torch.float32, device=g.device)
+            ops.gemm_wgrad(onehot, d_rows, dl)
+            ar.g('cross_lang_embeddings.weight').add_(dl[:model.n_langs])
+            ar.touch('cross_lang_embeddings.weight')
+        grads = dict(d_g_img=ar.g('image_embeddings.LayerNorm.weight'), d_be_img=ar.g('image_embeddings.LayerNorm.bias'),
+                     d_b_img=ar.g('image_embeddings.image_embeddings.bias'),
+                     d_b_loc=ar.g('image_embeddings.image_location_embeddings.bias'),
+                     d_w_loc=ar.g('image_embeddings.image_location_embeddings.weight'))
+        de = ops.embed_image_rows_bwd(d_rows, img_saved, ar.p('image_embeddings.LayerNorm.weight'), loc, totlen, grads, B, R, d,
+                                      seed_img=seed('img'), p_drop=p_drop)
+        ops.gemm_wgrad(de, ximg16, ar.g('image_embeddings.image_embeddings.weight'))
+        ar.touch(*[n for n in ar.names if n.startswith('image_embeddings.')])
+        return (None,) * 8
 
 
 class DecoderFn(torch.autograd.Function):

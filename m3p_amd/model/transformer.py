@@ -261,6 +261,7 @@ class TransformerModel(nn.Module):
         # run lists translation / auto-encoding steps (train_x.py:215-218); otherwise its parameters stay outside, as
         # never-executed state, and cost the gradient buckets nothing
         self.cross_attention_hot = bool(self.is_decoder or getattr(params, 'mt_steps', None) or getattr(params, 'ae_steps', None)
+                                        or getattr(params, 'cross_modal_steps', None)
                                         or getattr(params, 'train_cross_attention', False))
         self._arena = None
         self._cold_w16 = None
@@ -413,7 +414,22 @@ class TransformerModel(nn.Module):
     def crossfwd(self, x, lengths, causal, stream_='text', src_enc=None, src_len=None, positions=None, langs=None,
                  cache=None, enc_mask=None, image_loc=None, **kw):
         """Text-only stream of transformer.py:970-1114 (the mlm_step caller, xtrainer.py:757)."""
-        assert stream_ == 'text', "crossfwd(stream_='img') is outside the MI355X build"
+        if stream_ == 'img':
+            # the image-only encoder pass of the captioning step (:1044-1052): x (R, B, 2048) region features
+            assert not causal and src_enc is None and cache is None and positions is None
+            assert image_loc is not None and not kw.get('refine_image', False) and kw.get('image_dist') is None, \
+                'the image stream runs without the refiner and without the class-distribution embedding'
+            R, B = x.size(0), x.size(1)
+            if langs is not None:
+                assert self.n_langs > 1 and langs.size() == (R, B)
+            p = self.dropout if self.training else 0.0
+            pa = self.attention_dropout if self.training else 0.0
+            step = self._next_seed_step()
+            h0 = Fn.ImageStreamFn.apply(self.layer_norm_emb.weight, self, x, lengths, image_loc, langs, p, step)
+            out = Fn.EncoderFn.apply(self.layer_norm_emb.weight, self, None, lengths, None, None, None, p, pa, step, None,
+                                     torch.is_grad_enabled(), None, None, h0)
+            return out.view(B, R, self.dim).transpose(0, 1)
+        assert stream_ == 'text'
         if causal:       # the decoder: causal self-attention (+ attention over src_enc), key / value cache (:1011-1091)
             if torch.is_grad_enabled() and self.training:
                 # teacher-forced training pass (mt_step / ae_step, xtrainer.py:1383-1441): the whole target at once

@@ -333,6 +333,25 @@ def embed_image_rows_fwd(img_proj, loc, w_loc, b_loc, g_img, be_img, B, R, d, se
     return rows, (e, mean_i, rstd_i)
 
 
+def embed_image_rows_bwd(d_rows, img_saved, g_img, loc, totlen, grads, B, R, d, seed_img=0, p_drop=0.0):
+    """Backward of embed_image_rows_fwd alone (the image-only stream): d_rows bf16 [B*R, d] = gradient wrt the rows it
+    returned -> its dropout, LayerNorm and location-projection backward (the image half of m3p_embed_assemble_bwd with no
+    token rows).  grads: d_g_img, d_be_img, d_b_img, d_b_loc, d_w_loc.  Returns de (bf16 [R*B, d], rows r*B + b): the
+    gradient wrt the image projection's output."""
+    e, mean_i, rstd_i = img_saved
+    assert d_rows.dtype == BF16 and d_rows.is_contiguous() and d_rows.shape == (B * R, d)
+    de = torch.empty_like(e)
+    th, ik = _drop_args(p_drop)
+    dummy = d_rows.data_ptr()       # the token-row arguments are not read by the image half
+    args = (dummy, dummy, mean_i.data_ptr(), rstd_i.data_ptr(), g_img.data_ptr(), e.data_ptr(), mean_i.data_ptr(),
+            rstd_i.data_ptr(), g_img.data_ptr(), dummy, totlen.data_ptr(), loc.data_ptr(), d_rows.data_ptr(), de.data_ptr(),
+            grads['d_g_img'].data_ptr(), grads['d_be_img'].data_ptr(), grads['d_g_img'].data_ptr(), grads['d_g_img'].data_ptr(),
+            None, grads['d_g_img'].data_ptr(), grads['d_be_img'].data_ptr(), grads['d_b_img'].data_ptr(),
+            grads['d_b_loc'].data_ptr(), grads['d_w_loc'].data_ptr(), B, 0, R, d, -1, seed_img, 0, th, ik)
+    L.check(L.load().m3p_embed_assemble_bwd(*args, 2, L.stream()), 'm3p_embed_assemble_bwd')
+    return de
+
+
 def embed_assemble_bwd(dh, saved, g_emb, g_img, tok, totlen, loc, grads, B, T, R, d, pad_index,
                        seed_img=0, seed_emb=0, p_drop=0.0, img_rows_bwd=None, tok_rows=None):
     """grads: dict of fp32 gradient views (d_g_emb, d_be_emb, d_pos, d_emb, d_g_img, d_be_img, d_b_img,

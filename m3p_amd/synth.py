@@ -351,3 +351,15 @@ def mt_targets(x2, len2):
     pred_mask = alen[:, None] < len2[None] - 1
     y = x2[1:].masked_select(pred_mask[:-1])
     return pred_mask, y
+
+
+def ic_case():
+    """The translation model of mt_case with an image source: R = 10 regions per image (ragged), captions x2."""
+    P, sd, _, _, x2, len2 = mt_case()
+    rs = np.random.RandomState(779)
+    R, B = 10, x2.shape[1]
+    x_img = torch.from_numpy(rs.standard_normal((R, B, 2048)).astype(np.float32))
+    loc = torch.from_numpy(rs.uniform(0, 1, size=(R, B, 5)).astype(np.float32))
+    img_len = torch.from_numpy(rs.randint(R // 2, R + 1, size=B)).long()
+    img_len[0] = R
+    return P, sd, x_img, loc, img_len, x2, len2

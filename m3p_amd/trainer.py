@@ -13,9 +13,8 @@ Entry points kept with the reference's signatures and batch tuples:
 Changed on purpose (SURVEY.md §7 "host side clean"): no per-step host syncs - the NaN check
 (:210), the ``.cpu()`` ITM loss (:2367-2370) and the ``loss.item()`` statistics (:2317, :2374)
 stay on the device and are only read when ``print_stats`` prints; clip + Adam + zero_grad are
-one fused kernel pass; DDP is our bucketed reducer (m3p_amd/distributed.py).  ``mt_step`` (:1383-1441) is the
-translation step on the causal stream.  Not built: the captioning / FreeLB / sliding-window steps (SURVEY §8 f4 and
-out of scope).
+one fused kernel pass; DDP is our bucketed reducer (m3p_amd/distributed.py).  ``mt_step`` (:1383-1441) and ``ic_step`` (:1443-1515) are the
+translation / captioning steps on the causal stream.  Not built: the FreeLB / sliding-window steps (out of scope).
 """
 import os
 import time
@@ -298,6 +297,61 @@ class Trainer(object):
         dec2 = model('crossfwd', stream_='text', x=x2, lengths=len2, langs=langs2, causal=True, src_enc=enc1, src_len=len1)
         _, loss = model('predict', tensor=dec2, pred_mask=pred_mask, y=y, get_scores=False)
         self._stat('MT-%s-%s' % (lang1, lang2), loss)
+        self.optimize(lambda_coeff * loss)
+        self.n_sentences += params.batch_size
+        self.stats['processed_s'] += len2.size(0)
+        self.stats['processed_w'] += n_words
+        return loss.detach()
+
+    def ic_step(self, dataset='coco', input_stream='img', lambda_coeff=1):
+        """Captioning step (xtrainer.py:1443-1515) on a ``('txt2img', dataset, 'img')`` batch:
+        ``(x2, len2), (x1, x1_mask, img_loc, img_id)``."""
+        assert lambda_coeff >= 0
+        if lambda_coeff == 0:
+            return
+        # the caption collate belongs to the reference's data layer (not part of this build): the dataset hands out
+        # ready batches through its own iterator
+        key = ('txt2img', dataset, input_stream)
+        ds = self.data['cross_modal'][(dataset, input_stream)]['train']
+        if not hasattr(ds, 'get_iterator'):
+            raise NotImplementedError("ic_step needs data['cross_modal'][(%r, %r)]['train'].get_iterator() yielding "
+                                      "((x2, len2), (x1, x1_mask, img_loc, img_id)) batches" % (dataset, input_stream))
+        if key not in self.iterators:
+            self.iterators[key] = iter(ds.get_iterator())
+        try:
+            batch = next(self.iterators[key])
+        except StopIteration:
+            self.iterators[key] = iter(ds.get_iterator())
+            batch = next(self.iterators[key])
+        (x2, len2), (x1, x1_mask, img_loc, _img_id) = batch
+        return self.ic_step_on_batch(x2, len2, x1, x1_mask, img_loc, dataset, input_stream, lambda_coeff)
+
+    def ic_step_on_batch(self, x2, len2, x1, x1_mask, img_loc, dataset='coco', input_stream='img', lambda_coeff=1):
+        """Loss path of ic_step (:1466-1515): the model encodes the regions (image-only stream) and decodes the caption with
+        teacher forcing over that encoding.  x1 (B, R, 2048), x1_mask (B, R), img_loc (B, R, 5) as the collate emits them."""
+        params = self.params
+        model = self.model
+        model.train()
+        self._dp_plan(True, expect=('mlm',))
+        ft = getattr(params, 'ft_lgs', None) or []
+        lang_id = params.lang2id[ft[0]] if len(ft) > 0 else params.lang2id['en']
+        langs = x2.clone().fill_(lang_id)
+        alen = torch.arange(int(len2.max()), dtype=torch.long, device=len2.device)
+        pred_mask = alen[:, None] < len2[None] - 1
+        y = x2[1:].masked_select(pred_mask[:-1])
+        n_words = int((len2 - 1).sum())
+        assert len(y) == n_words
+        len1 = x1_mask.sum(dim=1)
+        x1 = x1.transpose(0, 1)
+        img_loc = img_loc.transpose(0, 1)
+        langs_img = x1_mask.transpose(0, 1).clone().long().fill_(lang_id)
+        x1, len1, img_loc, x2, len2, y, langs, langs_img, pred_mask = to_cuda(x1, len1, img_loc, x2, len2, y, langs, langs_img, pred_mask)
+        enc1 = model('crossfwd', stream_='img', x=x1, lengths=len1, langs=langs_img, causal=False, image_loc=img_loc,
+                     refine_image=False)
+        enc1 = enc1.transpose(0, 1)
+        dec2 = model('crossfwd', stream_='text', x=x2, lengths=len2, langs=langs, causal=True, src_enc=enc1, src_len=len1)
+        _, loss = model('predict', tensor=dec2, pred_mask=pred_mask, y=y, get_scores=False)
+        self._stat('IC-%s-%s' % (dataset, input_stream), loss)
         self.optimize(lambda_coeff * loss)
         self.n_sentences += params.batch_size
         self.stats['processed_s'] += len2.size(0)

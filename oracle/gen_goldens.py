@@ -611,6 +611,44 @@ def gen_mt_goldens():
     np.savez_compressed(os.path.join(OUT, 'mt_step.npz'), **g)
 
 
+def gen_ic_goldens():
+    """ic_step.npz: the captioning step of xtrainer.py:1443-1515 on the reference (dropout 0): image-only encoder pass
+    (crossfwd stream_='img' with language ids), teacher-forced causal pass over it, loss, gradients."""
+    from src.model.transformer import TransformerModel
+    from oracle import ref_cpu
+    P, sd, x_img, loc, img_len, x2, len2 = synth.ic_case()
+    torch.manual_seed(0)
+    m = TransformerModel(P, is_encoder=True, with_output=True, is_crossModal=True)
+    own = dict(m.named_parameters())
+    with torch.no_grad():
+        for k, v in sd.items():
+            own[k].copy_(v)
+    m.train()
+    R, B = x_img.shape[0], x_img.shape[1]
+    langs_img = torch.zeros((R, B), dtype=torch.long)          # xtrainer.py:1481-1483: the 'en' id on both streams
+    langs = x2.clone().fill_(0)
+    pred_mask, y = synth.mt_targets(x2, len2)
+    enc1 = m('crossfwd', stream_='img', x=x_img, lengths=img_len, langs=langs_img, causal=False, cross_modal=True,
+             image_loc=loc, refine_image=False, refine_encoder=False, image_dist=None).transpose(0, 1)
+    dec2 = m('crossfwd', stream_='text', x=x2, lengths=len2, langs=langs, causal=True, src_enc=enc1, src_len=img_len)
+    _, loss = m('predict', tensor=dec2, pred_mask=pred_mask, y=y, get_scores=False)
+    loss.backward()
+    g = {'enc1': enc1.detach().numpy(), 'dec2': dec2.detach().numpy(), 'loss': loss.detach().numpy()}
+    names = ['cross_lang_embeddings.weight', 'image_embeddings.image_embeddings.weight', 'image_embeddings.image_embeddings.bias',
+             'image_embeddings.image_location_embeddings.weight', 'image_embeddings.image_location_embeddings.bias',
+             'image_embeddings.LayerNorm.weight', 'image_embeddings.LayerNorm.bias', 'position_embeddings.weight',
+             'attentions.0.q_lin.weight', 'attentions.1.out_lin.weight', 'encoder_attn.0.k_lin.weight',
+             'encoder_attn.1.v_lin.weight', 'layer_norm15.1.weight', 'ffns.0.lin1.weight', 'layer_norm2.1.bias']
+    for k in names:
+        g['grad.' + k] = own[k].grad.numpy()
+    o_enc = ref_cpu.crossfwd_img(sd, P.n_layers, P.n_heads, x_img, img_len, loc, langs=langs_img).transpose(0, 1)
+    o_dec = ref_cpu.decoder_crossfwd(sd, P.n_layers, P.n_heads, x2, len2, o_enc, img_len, langs=langs)
+    print('ic_step.npz: loss %.6f; enc max|d| %.2e dec max|d| %.2e' % (float(loss), float((o_enc - enc1.detach()).abs().max()),
+                                                                       float((o_dec - dec2.detach()).abs().max())))
+    assert float((o_dec - dec2.detach()).abs().max()) < 1e-4
+    np.savez_compressed(os.path.join(OUT, 'ic_step.npz'), **g)
+
+
 def gen_decoder_goldens():
     """decoder.npz: the reference's causal decoder (TransformerModel(is_encoder=False)) on the deterministic cases of
     m3p_amd.synth.DECODER_CASES - teacher-forced crossfwd(causal=True, src_enc) hidden states, the same computed
@@ -678,12 +716,12 @@ def gen_decoder_goldens():
 
 
 if __name__ == '__main__':
-    single = {'enum': gen_state_dict_enumeration, 'host': gen_host_goldens, 'mt': gen_mt_goldens, 'langs': gen_text_langs_goldens,
+    single = {'enum': gen_state_dict_enumeration, 'host': gen_host_goldens, 'mt': gen_mt_goldens, 'ic': gen_ic_goldens, 'langs': gen_text_langs_goldens,
               'decoder': gen_decoder_goldens, 'refiner': gen_refiner_goldens}
     if len(sys.argv) > 1:
         single[sys.argv[1]]()
         sys.exit(0)
     for fn in (gen_state_dict_enumeration, gen_refiner_goldens, gen_clcm_goldens, gen_region_head_goldens,
                gen_text_and_itm_goldens, gen_unit_goldens, gen_model_goldens, gen_trainer_goldens, gen_host_goldens,
-               gen_decoder_goldens, gen_text_langs_goldens, gen_mt_goldens):
+               gen_decoder_goldens, gen_text_langs_goldens, gen_mt_goldens, gen_ic_goldens):
         fn()

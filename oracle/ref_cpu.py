@@ -273,6 +273,30 @@ def decoder_crossfwd(sd, n_layers, n_heads, x, lengths, src_enc=None, src_len=No
     return h.transpose(0, 1)
 
 
+def crossfwd_img(sd, n_layers, n_heads, x_img, lengths, image_loc, langs=None):
+    """TransformerModel.crossfwd(stream_='img', causal=False) in eval mode, transformer.py:1044-1102: BertImageEmbeddings on the
+    region features (+ the language embedding), * mask - no positions and no layer_norm_emb on this stream - then the
+    post-LN layers.  x_img (R, B, 2048), image_loc (R, B, 5) -> (R, B, d)."""
+    R, B = x_img.shape[0], x_img.shape[1]
+    mask, attn_mask = get_masks(R, lengths)
+    h = image_embeddings(sd, x_img.transpose(0, 1), image_loc.transpose(0, 1))
+    if langs is not None:
+        h = h + F.embedding(langs.t(), sd['cross_lang_embeddings.weight'])
+    h = h * mask[..., None].to(h.dtype)
+    for i in range(n_layers):
+        a = 'attentions.%d.' % i
+        attn = multi_head_attention(
+            h, attn_mask,
+            sd[a + 'q_lin.weight'], sd[a + 'q_lin.bias'], sd[a + 'k_lin.weight'], sd[a + 'k_lin.bias'],
+            sd[a + 'v_lin.weight'], sd[a + 'v_lin.bias'], sd[a + 'out_lin.weight'], sd[a + 'out_lin.bias'], n_heads)
+        h = layer_norm(h + attn, sd['layer_norm1.%d.weight' % i], sd['layer_norm1.%d.bias' % i])
+        f = 'ffns.%d.' % i
+        h = h + transformer_ffn(h, sd[f + 'lin1.weight'], sd[f + 'lin1.bias'], sd[f + 'lin2.weight'], sd[f + 'lin2.bias'])
+        h = layer_norm(h, sd['layer_norm2.%d.weight' % i], sd['layer_norm2.%d.bias' % i])
+        h = h * mask[..., None].to(h.dtype)
+    return h.transpose(0, 1)
+
+
 def word_scores(sd, h):
     """PredLayer.get_scores with the tied matrix (transformer.py:120-124, :728-729)."""
     return F.linear(h, sd['embeddings.weight'], sd['pred_layer.proj.bias'])

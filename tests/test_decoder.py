@@ -356,3 +356,60 @@ def test_mt_step_trains_and_inference_follows_the_updated_weights():
     with torch.no_grad():
         gen, gen_len = m.generate(enc, len1.cuda(), 1, max_len=12)
     assert gen.shape[1] == 6 and int((gen == synth.EOS).sum()) == 12
+
+
+def test_oracle_ic_step_matches_the_reference():
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'ic_step.npz'))
+    P, sd, x_img, loc, img_len, x2, len2 = synth.ic_case()
+    R, B = x_img.shape[0], x_img.shape[1]
+    enc = ref_cpu.crossfwd_img(sd, P.n_layers, P.n_heads, x_img, img_len, loc, langs=torch.zeros((R, B), dtype=torch.long)).transpose(0, 1)
+    dec = ref_cpu.decoder_crossfwd(sd, P.n_layers, P.n_heads, x2, len2, enc, img_len, langs=x2.clone().fill_(0))
+    assert np.abs(enc.numpy() - g['enc1']).max() < 2e-5 and np.abs(dec.numpy() - g['dec2']).max() < 2e-5
+    pred_mask, y = synth.mt_targets(x2, len2)
+    loss = ref_cpu.predict_mlm(sd, dec, pred_mask, y)
+    loss = loss[1] if isinstance(loss, tuple) else loss
+    assert abs(float(loss) - float(g['loss'])) < 1e-5
+
+
+@pytest.mark.gpu
+def test_ic_step_vs_reference():
+    """The captioning step: image-only encoder stream (crossfwd stream_='img': BertImageEmbeddings + language embedding, no
+    positions / layer_norm_emb), teacher-forced caption decoding over it - loss and gradients against the reference's
+    (tests/golden/ic_step.npz), through Trainer.ic_step_on_batch on the tuple layout the reference's collate emits."""
+    from m3p_amd.model.transformer import TransformerModel
+    from m3p_amd.trainer import XTrainer
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'ic_step.npz'))
+    P, sd, x_img, loc, img_len, x2, len2 = synth.ic_case()
+    for k, v in dict(optimizer='adam_inverse_sqrt,beta1=0.9,beta2=0.98,lr=0.0001', clip_grad_norm=5, amp=-1, fp16=False,
+                     accumulate_gradients=1, multi_gpu=False, epoch_size=100, cross_mlm_steps=[], cross_mrm_steps=[], langs=['en', 'zh'],
+                     cross_mrfr_steps=[], cross_clcm_steps=[], sample_n=2, refine_image=False, batch_size=6, ft_lgs=[],
+                     dump_path='/nonexistent_m3p_dump').items():
+        setattr(P, k, v)
+    torch.manual_seed(0)
+    m = TransformerModel(P, is_encoder=True, with_output=True, is_crossModal=True).cuda()
+    m.load_state_dict(sd, strict=False)
+    m.train()
+    R, B = x_img.shape[0], x_img.shape[1]
+    enc1 = m('crossfwd', stream_='img', x=x_img.cuda(), lengths=img_len.cuda(), langs=torch.zeros((R, B), dtype=torch.long).cuda(),
+             causal=False, image_loc=loc.cuda(), refine_image=False).transpose(0, 1)
+    assert rel_l2(enc1.float(), g['enc1']) < 1e-2
+    m.arena().zero_grad()
+    tr = XTrainer(m, {}, P)
+    grads = {}
+    opt = tr.optimizers['model']
+    inner = opt.step
+
+    def step(closure=None):          # look at the gradients the optimizer is about to consume
+        torch.cuda.synchronize()
+        for k in [k[5:] for k in g.files if k.startswith('grad.')]:
+            grads[k] = dict(m.named_parameters())[k].grad.float().cpu().clone()
+        return inner(closure)
+    opt.step = step
+    x1_mask = (torch.arange(R)[None, :] < img_len[:, None]).long()
+    loss = tr.ic_step_on_batch(x2, len2, x_img.transpose(0, 1).contiguous(), x1_mask, loc.transpose(0, 1).contiguous(), 'coco', 'img', 1.0)
+    assert abs(float(loss) - float(g['loss'])) < 5e-3
+    bad = [(k, rel_l2(v, g['grad.' + k])) for k, v in grads.items()]
+    bad = [(k, e) for k, e in bad if e > 4e-2]
+    assert grads and not bad, bad
+    # the clip norm of this step is far below 5: the gradients above are the unclipped ones
+    assert opt.grad_norm() < 5
