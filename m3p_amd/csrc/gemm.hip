@@ -24,7 +24,8 @@
 #include "../../include/m3p_hip.h"
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
-static int g_variant = 1;  // debug: 0 = force the 128x128 2-stage kernel, 1 = auto (ring / w4 by shape), 2 = force w4, 3 = force ring
+static int g_variant = 1;  // debug: 0 = force the 128x128 2-stage kernel, 1 = auto (skinny for M <= 128, eight-wave 256x256 for full tiles, ring otherwise),
+                           // 2 = force the four-wave 256x256 kernel, 3 = force ring, 6 = force eight-wave 256x256, 7 = the round-1 auto choice (w4 / ring), 9 = auto without the skinny kernel
 static int g_ablate = 0;  // debug: timeline kernels only (bit0 = no fragment reads, bit1 = no LDS-DMA)
 extern "C" __attribute__((visibility("default"))) void m3p_debug_set_variant(int v) { g_variant = v & 0xff; g_ablate = v >> 8; }
 

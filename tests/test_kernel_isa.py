@@ -49,6 +49,32 @@ def test_w4_gemm_accumulators_are_ours(tmp_path):
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason='hipcc not installed')
+def test_eight_wave_gemm_fits_two_waves_per_simd(tmp_path):
+    """The eight-wave 256x256 NT kernel lives on 256 registers per wave (two waves per SIMD): 128 accumulators + a
+    quarter K-tile of fragments.  A whole k-step of fragments ahead spilled inside the K loop - this pins the budget: no
+    scratch at all in the plain / bias / residual instantiations, a few dwords at most (epilogue only) in the
+    dGELU / multiply ones, occupancy 2 everywhere; the fp8 body may keep its small epilogue spill."""
+    out = tmp_path / 'gemm.s'
+    cmd = [HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-munsafe-fp-atomics', '-ffp-contract=fast',
+           '-Wno-unused-result', '--cuda-device-only', '-S', os.path.join(ROOT, 'm3p_amd', 'csrc', 'gemm.hip'), '-o', str(out)]
+    subprocess.run(cmd, check=True, capture_output=True, timeout=900)
+    body = out.read_text()
+    seen = 0
+    for m in re.finditer(r'^(_ZN\S*gemm_nt_w8_kernelILi(\d)E\S*):', body, re.M):
+        k = body.index('; Kernel info:', body.index('.Lfunc_end', m.end()))
+        info = dict(re.findall(r'; (\w+): (\d+)', body[k:k + 700]))
+        epi = int(m.group(2))
+        assert int(info['Occupancy']) >= 2 and int(info['NumVgprs']) <= 256, (m.group(1), info)
+        assert int(info['ScratchSize']) <= (0 if epi <= 4 else 32), (m.group(1), info['ScratchSize'])
+        seen += 1
+    assert seen == 7
+    for m in re.finditer(r'^(_ZN\S*gemm_nt_w8f8_kernel\S*):', body, re.M):
+        k = body.index('; Kernel info:', body.index('.Lfunc_end', m.end()))
+        info = dict(re.findall(r'; (\w+): (\d+)', body[k:k + 700]))
+        assert int(info['Occupancy']) >= 2 and int(info['ScratchSize']) <= 320, (m.group(1), info)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason='hipcc not installed')
 def test_attention_kernels_keep_their_occupancy(tmp_path):
     """No production instantiation of the attention kernels spills to scratch, the M3P-sequence instantiations (S = 164: six
     32-row steps, eleven 16-row tiles) fit three waves per SIMD (three ~48-KB workgroups per CU) and the long-sequence
