@@ -74,3 +74,59 @@ def test_cfg2_full_size_batch_split_identity(B):
     bad = [(n, rel_l2(0.5 * (ga[n] + gb[n]), g[n])) for n in names]
     bad = [(n, e) for n, e in bad if e > 2e-2]
     assert not bad, bad
+
+
+def test_translation_step_full_size_batch_split_identity():
+    """The translation step (encoder pass + teacher-forced causal pass over it) at M3P-base size - 12 layers / 768 wide /
+    12 heads (head dim 64), V = 250 002, 64 sentence pairs of up to 48 source / 32 target words: the loss of near-uniform
+    guessing, finite gradients on every encoder-attention tensor, and loss / gradients of the whole batch equal to the
+    average of its two halves (equal target-word counts per half)."""
+    from m3p_amd.model.transformer import TransformerModel
+    P = synth.model_params(768, 12, 12, 250002, n_langs=2, id2lang={0: 'en', 1: 'zh'}, lang2id={'en': 0, 'zh': 1},
+                           mt_steps=[('en', 'zh')])
+    torch.manual_seed(4321)
+    m = TransformerModel(P, is_encoder=True, with_output=True, is_crossModal=True).cuda()
+    m.train()
+    g = torch.Generator().manual_seed(5)
+    B, T1, T2 = 64, 48, 32
+
+    def sentences(T, lens):
+        x = torch.randint(3, P.n_words, (T, B), generator=g)
+        x[0] = synth.EOS
+        for b in range(B):
+            x[int(lens[b]) - 1, b] = synth.EOS
+            x[int(lens[b]):, b] = synth.PAD
+        return x
+    len1 = torch.randint(T1 // 2, T1 + 1, (B,), generator=g)
+    len1[0] = len1[B // 2] = T1
+    len2 = torch.randint(T2 // 2, T2 + 1, (B // 2,), generator=g)
+    len2[0] = T2
+    len2 = torch.cat([len2, len2])                       # the same number of target words in both halves
+    x1, x2 = sentences(T1, len1), sentences(T2, len2)
+    names = ['encoder_attn.0.q_lin.weight', 'encoder_attn.11.k_lin.weight', 'encoder_attn.5.v_lin.bias', 'encoder_attn.7.out_lin.weight',
+             'layer_norm15.3.weight', 'attentions.11.q_lin.weight', 'ffns.0.lin2.weight', 'cross_lang_embeddings.weight',
+             'position_embeddings.weight', 'pred_layer.proj.bias']
+    own = dict(m.named_parameters())
+
+    def run(sl):
+        m.arena().zero_grad()
+        a, la, b_, lb = x1[:, sl].cuda(), len1[sl].cuda(), x2[:, sl].cuda(), len2[sl].cuda()
+        Tb = int(lb.max())
+        b_ = b_[:Tb]
+        pred_mask, y = synth.mt_targets(x2[:Tb, sl], len2[sl])
+        enc = m('crossfwd', stream_='text', x=a, lengths=la, langs=torch.zeros_like(a), causal=False).transpose(0, 1)
+        dec = m('crossfwd', stream_='text', x=b_, lengths=lb, langs=torch.ones_like(b_), causal=True, src_enc=enc, src_len=la)
+        _, loss = m('predict', tensor=dec, pred_mask=pred_mask.cuda(), y=y.cuda(), get_scores=False)
+        loss.backward()
+        torch.cuda.synchronize()
+        return float(loss.detach()), {n: own[n].grad.detach().float().clone() for n in names}
+
+    loss, gr = run(slice(0, B))
+    assert 0.0 < loss - math.log(P.n_words) < 3.0, loss
+    assert all(torch.isfinite(v).all() and float(v.abs().max()) > 0 for v in gr.values())
+    la_, ga = run(slice(0, B // 2))
+    lb_, gb = run(slice(B // 2, B))
+    assert abs(0.5 * (la_ + lb_) - loss) < 2e-3
+    bad = [(n, rel_l2(0.5 * (ga[n] + gb[n]), gr[n])) for n in names]
+    bad = [(n, e) for n, e in bad if e > 3e-2]
+    assert not bad, bad
