@@ -178,7 +178,12 @@ def main():
     from m3p_amd import synth, ops
     from m3p_amd.distributed import init_distributed_mode
     import torch.distributed as dist
-    rank, local_rank, world = init_distributed_mode()
+    # M3P_BENCH_SHARED_GPU=1 (development dry run of the multi-rank path on a one-GPU box): every rank on cuda:0 over gloo;
+    # the line it prints says so and is not a measurement
+    shared = os.environ.get('M3P_BENCH_SHARED_GPU', '0') != '0'
+    if shared:
+        os.environ['LOCAL_RANK'] = '0'
+    rank, local_rank, world = init_distributed_mode(backend='gloo' if shared else None)
     assert world == args.gpus, 'WORLD_SIZE=%d but --gpus %d' % (world, args.gpus)
     if world > 1:
         assert dist.get_world_size() == world
@@ -306,6 +311,8 @@ def main():
                    roofline=roof)
         if comm is not None:
             out['comm'] = comm
+        if shared:
+            out['data'] = 'synthetic; DRY RUN: %d ranks sharing one GPU over gloo - not a measurement' % world
         if world == 1 and not args.no_cpu_baseline:
             del trainer
             torch.cuda.empty_cache()
