@@ -80,3 +80,49 @@ def round_batch(x, lengths, positions, langs, params):
             langs = torch.cat([langs, langs[-1][None].expand(extra, n_out)], 0)
     assert x.size(0) % 8 == 0 and x.size(1) % 8 == 0
     return x, lengths, positions, langs, idx
+
+
+def word_shuffle(x, lengths, k):
+    """Local word shuffle of the denoising auto-encoder input (xtrainer.py:291-310): word j of a sentence moves to the rank
+    of j + U(0, k) among its sentence (the first symbol gets -1 and stays; the last symbol is not part of the window).
+    One np.random.uniform draw of shape (slen - 1, bs), like the reference."""
+    if k == 0:
+        return x, lengths
+    assert k > 1
+    noise = np.random.uniform(0, k, size=(x.size(0) - 1, x.size(1)))
+    noise[0] = -1
+    out = x.clone()
+    for b, n in enumerate(lengths.tolist()):
+        order = (np.arange(n - 1) + noise[:n - 1, b]).argsort()
+        out[:n - 1, b] = x[:n - 1, b][torch.from_numpy(order)]
+    return out, lengths
+
+
+def word_dropout(x, lengths, p, pad_index):
+    """Random word removal (xtrainer.py:312-345): every word but the first is dropped with probability p; the window is
+    the sentence WITHOUT its final symbol, which the reference does not put back (its re-append is commented out), so
+    every sentence comes back at least one symbol shorter; a sentence reduced to its first symbol gets one random word
+    of its own back.  RNG order: one np.random.rand of shape (slen - 1, bs), then one randint per emptied sentence."""
+    if p == 0:
+        return x, lengths
+    assert 0 < p < 1
+    keep = np.random.rand(x.size(0) - 1, x.size(1)) >= p
+    keep[0] = True
+    kept = []
+    for b, n in enumerate(lengths.tolist()):
+        words = x[:n - 1, b].tolist()
+        s = [w for j, w in enumerate(words) if keep[j, b]]
+        if len(s) == 1:
+            s.append(words[np.random.randint(1, len(words))])
+        kept.append(s)
+    new_len = torch.LongTensor([len(s) for s in kept])
+    out = torch.full((int(new_len.max()), len(kept)), pad_index, dtype=torch.long)
+    for b, s in enumerate(kept):
+        out[:len(s), b] = torch.LongTensor(s)
+    return out, new_len
+
+
+def add_noise(x, lengths, params):
+    """xtrainer.py:376-383: shuffle, then dropout (the blanking pass is disabled in the reference)."""
+    x, lengths = word_shuffle(x, lengths, getattr(params, 'word_shuffle', 0))
+    return word_dropout(x, lengths, getattr(params, 'word_dropout', 0), params.pad_index)

@@ -48,7 +48,8 @@ def _unwrap(model):
 def _stat_names(params):
     """Loss statistics of the steps this build runs (xtrainer.py:101-130 lists them for every task)."""
     g = lambda k: getattr(params, k, [])   # noqa: E731
-    names = ['MLM-%s' % l for l in g('langs')] + ['MT-%s-%s' % (l1, l2) for l1, l2 in (g('mt_steps') or [])]
+    names = ['MLM-%s' % l for l in g('langs')] + ['MT-%s-%s' % (l1, l2) for l1, l2 in (g('mt_steps') or [])] + \
+        ['AE-%s' % l for l in (g('ae_steps') or [])]
     for key, steps in (('CMLM', g('cross_mlm_steps')), ('MRM', g('cross_mrm_steps')), ('MRFR', g('cross_mrfr_steps')),
                        ('t2i', g('cross_rel_steps')), ('i2t', g('cross_rel_steps'))):
         names += ['%s-%s' % (key, l1) for l1, _ in steps]
@@ -266,14 +267,22 @@ class Trainer(object):
 
     # ------------------------------------------------------------------ checkpoints (xtrainer.py:511-650)
 
+    def add_noise(self, words, lengths):
+        """xtrainer.py:376-383 (word_shuffle + word_dropout under np.random, bit-identical: m3p_amd/masking.py)."""
+        return masking.add_noise(words, lengths, self.params)
+
     def mt_step(self, lang1, lang2, lambda_coeff):
-        """Machine translation step (xtrainer.py:1383-1441; lang1 == lang2: denoising auto-encoding is not built - its
-        add_noise lives in the data layer)."""
+        """Machine translation step, or - lang1 == lang2 - denoising auto-encoding of a monolingual batch
+        (xtrainer.py:1383-1441)."""
         assert lambda_coeff >= 0
         if lambda_coeff == 0:
             return
-        assert lang1 != lang2, 'the auto-encoding variant (add_noise) is not part of this build'
-        (x1, len1), (x2, len2) = self.get_cross_lingual_batch('mt', lang1, lang2)
+        if lang1 == lang2:
+            (x1, len1) = self.get_cross_lingual_batch('ae', lang1)
+            (x2, len2) = (x1, len1)
+            (x1, len1) = self.add_noise(x1, len1)
+        else:
+            (x1, len1), (x2, len2) = self.get_cross_lingual_batch('mt', lang1, lang2)
         return self.mt_step_on_batch(x1, len1, x2, len2, lang1, lang2, lambda_coeff)
 
     def mt_step_on_batch(self, x1, len1, x2, len2, lang1, lang2, lambda_coeff=1):
@@ -296,7 +305,7 @@ class Trainer(object):
         enc1 = enc1.transpose(0, 1)
         dec2 = model('crossfwd', stream_='text', x=x2, lengths=len2, langs=langs2, causal=True, src_enc=enc1, src_len=len1)
         _, loss = model('predict', tensor=dec2, pred_mask=pred_mask, y=y, get_scores=False)
-        self._stat('MT-%s-%s' % (lang1, lang2), loss)
+        self._stat(('AE-%s' % lang1) if lang1 == lang2 else ('MT-%s-%s' % (lang1, lang2)), loss)
         self.optimize(lambda_coeff * loss)
         self.n_sentences += params.batch_size
         self.stats['processed_s'] += len2.size(0)

@@ -649,6 +649,30 @@ def gen_ic_goldens():
     np.savez_compressed(os.path.join(OUT, 'ic_step.npz'), **g)
 
 
+def gen_noise_goldens():
+    """host_noise.npz: Trainer.add_noise (word_shuffle + word_dropout, xtrainer.py:291-383) of the reference under fixed
+    numpy seeds on synthetic sentences."""
+    xt, tr, m, P, hot = _reference_trainer(synth.CONFIGS['cfg1'], word_shuffle=3, word_dropout=0.1, word_blank=0.0)
+    rs = np.random.RandomState(31)
+    out = {}
+    for case, (T, B) in enumerate(((12, 5), (30, 16), (6, 3))):
+        lengths = torch.from_numpy(rs.randint(4, T + 1, size=B)).long()
+        lengths[0] = T
+        x = torch.from_numpy(rs.randint(3, 990, size=(T, B))).long()
+        x[0] = synth.EOS
+        for b in range(B):
+            x[int(lengths[b]) - 1, b] = synth.EOS
+            x[int(lengths[b]):, b] = synth.PAD
+        out['%d.x' % case], out['%d.len' % case] = x.numpy(), lengths.numpy()
+        for name, (ws, wd) in (('both', (3, 0.1)), ('shuffle', (3, 0.0)), ('drop', (0, 0.45))):
+            P.word_shuffle, P.word_dropout = ws, wd
+            np.random.seed(100 + case)
+            x2, l2 = tr.add_noise(x.clone(), lengths.clone())
+            out['%d.%s.x' % (case, name)], out['%d.%s.len' % (case, name)] = x2.numpy(), l2.numpy()
+    np.savez_compressed(os.path.join(OUT, 'host_noise.npz'), **out)
+    print('host_noise.npz', len(out), 'arrays')
+
+
 def gen_decoder_goldens():
     """decoder.npz: the reference's causal decoder (TransformerModel(is_encoder=False)) on the deterministic cases of
     m3p_amd.synth.DECODER_CASES - teacher-forced crossfwd(causal=True, src_enc) hidden states, the same computed
@@ -716,12 +740,12 @@ def gen_decoder_goldens():
 
 
 if __name__ == '__main__':
-    single = {'enum': gen_state_dict_enumeration, 'host': gen_host_goldens, 'mt': gen_mt_goldens, 'ic': gen_ic_goldens, 'langs': gen_text_langs_goldens,
+    single = {'enum': gen_state_dict_enumeration, 'host': gen_host_goldens, 'mt': gen_mt_goldens, 'noise': gen_noise_goldens, 'ic': gen_ic_goldens, 'langs': gen_text_langs_goldens,
               'decoder': gen_decoder_goldens, 'refiner': gen_refiner_goldens}
     if len(sys.argv) > 1:
         single[sys.argv[1]]()
         sys.exit(0)
     for fn in (gen_state_dict_enumeration, gen_refiner_goldens, gen_clcm_goldens, gen_region_head_goldens,
                gen_text_and_itm_goldens, gen_unit_goldens, gen_model_goldens, gen_trainer_goldens, gen_host_goldens,
-               gen_decoder_goldens, gen_text_langs_goldens, gen_mt_goldens, gen_ic_goldens):
+               gen_decoder_goldens, gen_text_langs_goldens, gen_mt_goldens, gen_ic_goldens, gen_noise_goldens):
         fn()

@@ -222,3 +222,23 @@ def test_build_model_reload_backfills_and_strips_prefix(tmp_path):
     m = build_model(P)
     k = 'attentions.0.q_lin.weight'
     assert torch.allclose(m.state_dict()[k].cpu(), sd[k] * 0.6 + other[k] * 0.4, atol=1e-6)
+
+
+def test_add_noise_matches_the_reference_bit_for_bit():
+    """word_shuffle + word_dropout of the denoising auto-encoder input (xtrainer.py:291-383) under the same numpy seeds:
+    identical tokens and lengths, random streams included (tests/golden/host_noise.npz, recorded from the reference)."""
+    import os
+    from types import SimpleNamespace
+    from m3p_amd import masking, synth
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'host_noise.npz'))
+    for case in range(3):
+        x, lengths = torch.from_numpy(g['%d.x' % case]), torch.from_numpy(g['%d.len' % case])
+        for name, (ws, wd) in (('both', (3, 0.1)), ('shuffle', (3, 0.0)), ('drop', (0, 0.45))):
+            P = SimpleNamespace(word_shuffle=ws, word_dropout=wd, pad_index=synth.PAD)
+            np.random.seed(100 + case)
+            x2, l2 = masking.add_noise(x.clone(), lengths.clone(), P)
+            assert np.array_equal(l2.numpy(), g['%d.%s.len' % (case, name)]), (case, name)
+            assert np.array_equal(x2.numpy(), g['%d.%s.x' % (case, name)]), (case, name)
+    # nothing to do: the very tensors come back
+    x2, l2 = masking.add_noise(x, lengths, SimpleNamespace(word_shuffle=0, word_dropout=0, pad_index=synth.PAD))
+    assert x2 is x and l2 is lengths
