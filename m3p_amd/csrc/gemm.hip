@@ -238,11 +238,21 @@ void gemm_nt_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict_
 // ---------------------------------------------------------------------------------
 constexpr int EP_PITCH = 144;                 // bytes per staged row: 128 + 16 (16-B aligned, rotates banks)
 constexpr int EP_HALF = 32 * EP_PITCH;        // 4608 B per wave half-tile
+// byte offset of (row, byte column) inside a wave's staging rows.  SW: 128-byte pitch with the 16-byte chunk index XORed
+// with row & 7 instead of the padded pitch - 32 rows are exactly 4 KB, so eight waves' staging fits the 32 KB a CU has left
+// beside two 64-KB stages (the eight-wave kernel then never touches a stage in its epilogue)
+template <bool SW>
+__device__ __forceinline__ int ep_off(int row, int bcol) {
+  return SW ? row * 128 + ((((bcol >> 4) ^ (row & 7)) << 4) | (bcol & 15)) : row * EP_PITCH + bcol;
+}
 
 // gelu_erf'(u) of a bf16 u is a function of 16 bits: the dGELU epilogue looks it up instead of
 // evaluating erf/exp (~20 exposed VALU instructions per element).  The table covers |u| in
 // [2^-15, 8) (exponents -15..2 x 128 mantissas = 2304 fp32 entries, 9 KB of LDS), built from what
 // gelu_erf_grad_f returns for that bf16 value; gelu'(-u) = 1 - gelu'(u).
+#ifndef M3P_W8_SPARE_EPILOGUE
+#define M3P_W8_SPARE_EPILOGUE 1
+#endif
 #ifndef M3P_DGELU_LUT
 #define M3P_DGELU_LUT 1
 #endif
@@ -300,28 +310,28 @@ __device__ __forceinline__ void load_aux_rows_issue(const M3PEpilogue& ep, int m
 #pragma unroll
   for (int it = 0; it < 4; ++it) t[it] = *reinterpret_cast<const u32x4*>(X + (size_t)(it * 8) * ep.ld_aux);
 }
-template <int EPI>
+template <int EPI, bool SW = false>
 __device__ __forceinline__ void load_aux_rows_finish(int lane, char* r1, const u32x4 (&t)[4], bf16x4 (&auxv)[2][4]) {
   constexpr bool kAux = (EPI == M3P_EPI_BIAS_DROP_RES || EPI == M3P_EPI_RES || EPI == M3P_EPI_DGELU || EPI == M3P_EPI_MUL);
   if (!kAux) return;
   const int srow = lane >> 3, sch = lane & 7;
 #pragma unroll
-  for (int it = 0; it < 4; ++it) *reinterpret_cast<u32x4*>(r1 + (it * 8 + srow) * EP_PITCH + sch * 16) = t[it];
+  for (int it = 0; it < 4; ++it) *reinterpret_cast<u32x4*>(r1 + ep_off<SW>(it * 8 + srow, sch * 16)) = t[it];
   const int fr = lane & 15, fg = lane >> 4;
 #pragma unroll
   for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      auxv[ii][j] = *reinterpret_cast<const bf16x4*>(r1 + (ii * 16 + fr) * EP_PITCH + (j * 16 + fg * 4) * 2);
+      auxv[ii][j] = *reinterpret_cast<const bf16x4*>(r1 + ep_off<SW>(ii * 16 + fr, (j * 16 + fg * 4) * 2));
 }
-template <int EPI>
+template <int EPI, bool SW = false>
 __device__ __forceinline__ void load_aux_rows(const M3PEpilogue& ep, int mrow0, int nw, int lane, char* r1, bf16x4 (&auxv)[2][4]) {
   u32x4 t[4];
   load_aux_rows_issue<EPI>(ep, mrow0, nw, lane, t);
-  load_aux_rows_finish<EPI>(lane, r1, t, auxv);
+  load_aux_rows_finish<EPI, SW>(lane, r1, t, auxv);
 }
 
-template <int EPI>
+template <int EPI, bool SW = false>
 __device__ __forceinline__ void epilogue_half(const M3PEpilogue& ep, bf16* __restrict__ C, int ldc, int N,
                                               int mrow0, int nw, char* r1, const f32x4 (&rows)[2][4],
                                               const f32x4 (&biasv)[4], const bf16x4 (&auxv)[2][4], int lane, f32x4 (&csum)[4],
@@ -348,7 +358,7 @@ __device__ __forceinline__ void epilogue_half(const M3PEpilogue& ep, bf16* __res
     for (int ii = 0; ii < 2; ++ii) {
       const int rl = ii * 16 + fr;                  // row inside the staged half
       const int mrow = mrow0 + rl;                  // global row
-      const int lo = rl * EP_PITCH + (j * 16 + fg * 4) * 2;
+      const int lo = ep_off<SW>(rl, (j * 16 + fg * 4) * 2);
       f32x4 v = rows[ii][j];
       if (EPI == M3P_EPI_NONE || EPI == M3P_EPI_BIAS || EPI == M3P_EPI_RES) v = v * mulc + bias4;
       else if (EPI != M3P_EPI_DGELU && EPI != M3P_EPI_MUL) v += bias4;      // (those two have no bias: 32 exposed adds per half)
@@ -388,20 +398,69 @@ __device__ __forceinline__ void epilogue_half(const M3PEpilogue& ep, bf16* __res
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
     const int row = it * 8 + srow;
-    *reinterpret_cast<uint4*>(Cp + (size_t)row * ldc) = *reinterpret_cast<const uint4*>(r1 + row * EP_PITCH + sch * 16);
+    *reinterpret_cast<uint4*>(Cp + (size_t)row * ldc) = *reinterpret_cast<const uint4*>(r1 + ep_off<SW>(row, sch * 16));
   }
   if (EPI == M3P_EPI_BIAS_GELU) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int ii = 0; ii < 2; ++ii)
-        *reinterpret_cast<bf16x4*>(r1 + (ii * 16 + fr) * EP_PITCH + (j * 16 + fg * 4) * 2) = ukeep[ii][j];
+        *reinterpret_cast<bf16x4*>(r1 + ep_off<SW>(ii * 16 + fr, (j * 16 + fg * 4) * 2)) = ukeep[ii][j];
     bf16* Up = reinterpret_cast<bf16*>(ep.out2) + (size_t)mrow0 * ep.ld_out2 + nw + sch * 8;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int row = it * 8 + srow;
-      *reinterpret_cast<uint4*>(Up + (size_t)row * ep.ld_out2) = *reinterpret_cast<const uint4*>(r1 + row * EP_PITCH + sch * 16);
+      *reinterpret_cast<uint4*>(Up + (size_t)row * ep.ld_out2) = *reinterpret_cast<const uint4*>(r1 + ep_off<SW>(row, sch * 16));
     }
+  }
+}
+
+
+// 16-row pieces of the multiply epilogues (dGELU / MUL: out = acc * f(aux), column sums) for the eight-wave kernel: the
+// aux rows of piece h + 1 are requested while piece h is computed (8 registers per piece), staging is 2 KB per wave in
+// the swizzled layout - eight waves' staging and the 9-KB derivative table fit the 32 KB beside the two stages.
+__device__ __forceinline__ void aux16_issue(const M3PEpilogue& ep, int mrow0, int nw, int lane, u32x4 (&t)[2]) {
+  const int srow = lane >> 3, sch = lane & 7;
+  const bf16* X = reinterpret_cast<const bf16*>(ep.aux) + (size_t)(mrow0 + srow) * ep.ld_aux + nw + sch * 8;
+  t[0] = *reinterpret_cast<const u32x4*>(X);
+  t[1] = *reinterpret_cast<const u32x4*>(X + (size_t)8 * ep.ld_aux);
+}
+template <int EPI>
+__device__ __forceinline__ void epilogue_piece16(const M3PEpilogue& ep, bf16* __restrict__ C, int ldc, int mrow0, int nw, char* r1,
+                                                 const f32x4 (&rows)[4], const u32x4 (&t)[2], int lane, f32x4 (&csum)[4],
+                                                 const float* gtab) {
+  const int fr = lane & 15, fg = lane >> 4;
+  const int srow = lane >> 3, sch = lane & 7;
+  // aux rows -> accumulator layout through the staging rows
+  *reinterpret_cast<u32x4*>(r1 + ep_off<true>(srow, sch * 16)) = t[0];
+  *reinterpret_cast<u32x4*>(r1 + ep_off<true>(8 + srow, sch * 16)) = t[1];
+  bf16x4 auxv[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) auxv[j] = *reinterpret_cast<const bf16x4*>(r1 + ep_off<true>(fr, (j * 16 + fg * 4) * 2));
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    f32x4 v = rows[j];
+    const bf16x4 a = auxv[j];
+    if (EPI == M3P_EPI_DGELU) {
+      if (gtab) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= gelu_grad_lookup(gtab, a[r]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_grad_f((float)a[r]);
+      }
+    } else {
+      v *= f32x4{(float)a[0], (float)a[1], (float)a[2], (float)a[3]};
+    }
+    const bf16x4 ob = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+    *reinterpret_cast<bf16x4*>(r1 + ep_off<true>(fr, (j * 16 + fg * 4) * 2)) = ob;
+    csum[j] += f32x4{(float)ob[0], (float)ob[1], (float)ob[2], (float)ob[3]};
+  }
+  bf16* Cp = C + (size_t)mrow0 * ldc + nw + sch * 8;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int row = it * 8 + srow;
+    *reinterpret_cast<uint4*>(Cp + (size_t)row * ldc) = *reinterpret_cast<const uint4*>(r1 + ep_off<true>(row, sch * 16));
   }
 }
 
@@ -725,6 +784,14 @@ void gemm_nt_w8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
   auto tile_of = [&](int q) { return q * nwg + slot; };
   const int my_tiles = (ntiles > slot) ? (ntiles - slot + nwg - 1) / nwg : 0;
   if (my_tiles == 0) return;
+  // kSpare: the epilogue stages through the 32 KB beside the two stages (swizzled 128-byte rows: 4 KB per wave, or 2 KB
+  // for the 16-row pieces of the multiply epilogues, whose derivative table lives there too) instead of the stage the
+  // output tile's last K-tile vacated: the next tile's K-tile 1 is then requested on schedule and nobody has to meet at a
+  // barrier after the epilogue.
+  constexpr bool kSpare = M3P_W8_SPARE_EPILOGUE;
+  constexpr bool kMulE = (EPI == M3P_EPI_DGELU || EPI == M3P_EPI_MUL);
+  constexpr bool kAuxE = (EPI == M3P_EPI_BIAS_DROP_RES || EPI == M3P_EPI_RES || kMulE);
+  constexpr int kTabBytes = (EPI == M3P_EPI_DGELU && M3P_DGELU_LUT) ? GELU_TAB_N * (int)sizeof(float) : 0;
   float* gtab = (EPI == M3P_EPI_DGELU && M3P_DGELU_LUT) ? reinterpret_cast<float*>(smem + 2 * STAGE) : nullptr;
   if (EPI == M3P_EPI_DGELU && M3P_DGELU_LUT) gelu_grad_table_fill(gtab, tid, 512);
   const int nk = K / BK;
@@ -905,7 +972,9 @@ void gemm_nt_w8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
     __builtin_amdgcn_sched_barrier(0);
     // quarter 3: k-step 1, rows 64-127 | request K-tile +2 into the vacated stage | fetch K-tile +1's first fragments
     // (on an output tile's last K-tile both wait for the epilogue, which stages through that stage and wants the registers)
-    const bool req = more2 && !last_kt;
+    // (epilogues with an aux tile ask for it FIRST: vmcnt retires in order, so a load issued behind the three LDS-DMAs
+    //  would wait for them too - on an output tile's last K-tile the request moves into the epilogue, behind the aux loads)
+    const bool req = more2 && (!last_kt || (kSpare && !kAuxE));
     if (req) {
       if (!M3P_W8_SPREAD) stage_next(cur);
       else if (!M3P_W8_INTERLEAVE) { issue_load(cur, 0); issue_load(cur, 1); issue_load(cur, 2); }
@@ -934,10 +1003,35 @@ void gemm_nt_w8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
         csum_nw = nw;
       }
       const bool fast = io_aligned && (m0 + BM <= M) && (n0 + BN <= N);
-      if (fast) {
-        char* r1 = smem + cur * STAGE + wid * 6144;
+      if (fast && kSpare && kMulE) {
+        // 16-row pieces, the aux rows of the next piece in flight while this one is computed
+        char* r1 = smem + 2 * STAGE + kTabBytes + wid * 2048;
+        u32x4 ta[2], tb[2];
+        aux16_issue(ep, mw, nw, lane, ta);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more2) { issue_load(cur, 0); issue_load(cur, 1); issue_load(cur, 2); spread_pending = true; }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int hp = 0; hp < 8; hp += 2) {
+          aux16_issue(ep, mw + 16 * (hp + 1), nw, lane, tb);
+          epilogue_piece16<EPI>(ep, C, ldc, mw + 16 * hp, nw, r1, acc[hp], ta, lane, csum, gtab);
+          __builtin_amdgcn_sched_barrier(0);
+          if (hp + 2 < 8) aux16_issue(ep, mw + 16 * (hp + 2), nw, lane, ta);
+          epilogue_piece16<EPI>(ep, C, ldc, mw + 16 * (hp + 1), nw, r1, acc[hp + 1], tb, lane, csum, gtab);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        W8_TSEG(2);
+      } else if (fast) {
+        char* r1 = kSpare ? smem + 2 * STAGE + wid * 4096 : smem + cur * STAGE + wid * 6144;
         f32x4 biasv[4];
         load_bias4<EPI>(ep, nw, lane, biasv);
+        u32x4 aux0[4];
+        if (kSpare && kAuxE) {
+          load_aux_rows_issue<EPI>(ep, mw, nw, lane, aux0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (more2) { issue_load(cur, 0); issue_load(cur, 1); issue_load(cur, 2); spread_pending = true; }
+          __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int hf = 0; hf < 4; ++hf) {
           f32x4 rows[2][4];
@@ -946,16 +1040,18 @@ void gemm_nt_w8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
 #pragma unroll
             for (int j = 0; j < 4; ++j) rows[ii][j] = acc[2 * hf + ii][j];
           bf16x4 auxv[2][4];
-          load_aux_rows<EPI>(ep, mw + 32 * hf, nw, lane, r1, auxv);
+          if (kSpare && kAuxE && hf == 0) load_aux_rows_finish<EPI, kSpare>(lane, r1, aux0, auxv);
+          else load_aux_rows<EPI, kSpare>(ep, mw + 32 * hf, nw, lane, r1, auxv);
 #ifdef M3P_W8_TL
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           W8_TSEG(1);
 #endif
-          epilogue_half<EPI>(ep, C, ldc, N, mw + 32 * hf, nw, r1, rows, biasv, auxv, lane, csum, gtab);
+          epilogue_half<EPI, kSpare>(ep, C, ldc, N, mw + 32 * hf, nw, r1, rows, biasv, auxv, lane, csum, gtab);
           W8_TSEG(2);
           __builtin_amdgcn_sched_barrier(0);      // one piece at a time: hoisted loads of the next piece cost registers
         }
       } else {
+        if (kSpare && kAuxE && more2) { issue_load(cur, 0); issue_load(cur, 1); issue_load(cur, 2); spread_pending = true; }
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -967,11 +1063,13 @@ void gemm_nt_w8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (step + 1 < total) {
-        // the staging rows are where K-tile +2 goes: nobody requests it before every wave is done with its round trip
-        W8_LGKM0();
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (more2) stage_next(cur);
+        if (!kSpare) {
+          // the staging rows are where K-tile +2 goes: nobody requests it before every wave is done with its round trip
+          W8_LGKM0();
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+          if (more2) stage_next(cur);
+        }
         read_w(b_addr[0] + nxt * STAGE, fw0);
         read_a_lo(a_addr[0] + nxt * STAGE, fa0);
         W8_LGKM0();
@@ -1983,7 +2081,8 @@ int launch_nt(const bf16* A, int lda, const bf16* W, int ldw, bf16* C, int ldc, 
   if (M >= 1024 && (g_variant == 1 || g_variant == 6) && (N >= 512) && (2LL * N * K <= (64LL << 20)) && (K % 64) == 0 && (lda % 8) == 0 &&
       (ldw % 8) == 0 && (M % 256) == 0 && (N % 256) == 0) {
     const int tiles_m = M / 256, tiles_n = N / 256;
-    const size_t lds = 2 * 512 * ROWB + (EPI == M3P_EPI_DGELU && M3P_DGELU_LUT ? GELU_TAB_N * sizeof(float) : 0);
+    const size_t lds = 2 * 512 * ROWB + (EPI == M3P_EPI_DGELU && M3P_DGELU_LUT ? GELU_TAB_N * sizeof(float) : 0) +
+                       (M3P_W8_SPARE_EPILOGUE ? ((EPI == M3P_EPI_DGELU || EPI == M3P_EPI_MUL) ? 8 * 2048 : 8 * 4096) : 0);
     auto kern = gemm_nt_w8_kernel<EPI>;
     static bool attr_set8 = false;
     if (!attr_set8) {
