@@ -437,14 +437,42 @@ __device__ __forceinline__ void epilogue_piece16(const M3PEpilogue& ep, bf16* __
   bf16x4 auxv[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) auxv[j] = *reinterpret_cast<const bf16x4*>(r1 + ep_off<true>(fr, (j * 16 + fg * 4) * 2));
+  // the sixteen table reads of a piece are independent: all addresses first, all reads in flight together, one wait (left
+  // inside the per-element expression the compiler chains address -> read -> wait -> multiply sixteen times: ~130 clocks each)
+  float tv[4][4];
+  if (EPI == M3P_EPI_DGELU && gtab) {
+    int idx[4][4];
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const u32x2 raw = __builtin_bit_cast(u32x2, auxv[j]);      // four bf16 bit patterns in two dwords
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const uint32_t b = (raw[r >> 1] >> (16 * (r & 1))) & 0x7FFFu;
+        idx[j][r] = min(max((int)b - GELU_TAB_LO, 0), GELU_TAB_N - 1);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tv[j][r] = gtab[idx[j][r]];
+  }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     f32x4 v = rows[j];
     const bf16x4 a = auxv[j];
     if (EPI == M3P_EPI_DGELU) {
       if (gtab) {
+        {
+          typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+          const u32x2 raw = __builtin_bit_cast(u32x2, a);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] *= gelu_grad_lookup(gtab, a[r]);
+          for (int r = 0; r < 4; ++r) {
+            const uint32_t sign = (raw[r >> 1] << (16 * (1 - (r & 1)))) & 0x80000000u;
+            const uint32_t tb = __builtin_bit_cast(uint32_t, tv[j][r]);
+            v[r] *= 0.5f + __builtin_bit_cast(float, (tb & 0x7FFFFFFFu) | sign);
+          }
+        }
       } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_grad_f((float)a[r]);
@@ -1128,6 +1156,11 @@ void gemm_nt_w8f8_kernel(const uint8_t* __restrict__ A, int lda, const uint8_t* 
   auto tile_of = [&](int q) { return q * nwg + slot; };
   const int my_tiles = (ntiles > slot) ? (ntiles - slot + nwg - 1) / nwg : 0;
   if (my_tiles == 0) return;
+  // the epilogue stages through the 32 KB beside the two stages, like the bf16 kernel (see there)
+  constexpr bool kSpare = M3P_W8_SPARE_EPILOGUE;
+  constexpr bool kMulE = (EPI == M3P_EPI_DGELU || EPI == M3P_EPI_MUL);
+  constexpr bool kAuxE = (EPI == M3P_EPI_BIAS_DROP_RES || EPI == M3P_EPI_RES || kMulE);
+  constexpr int kTabBytes = (EPI == M3P_EPI_DGELU && M3P_DGELU_LUT) ? GELU_TAB_N * (int)sizeof(float) : 0;
   float* gtab = (EPI == M3P_EPI_DGELU && M3P_DGELU_LUT) ? reinterpret_cast<float*>(smem + 2 * STAGE) : nullptr;
   if (EPI == M3P_EPI_DGELU && M3P_DGELU_LUT) gelu_grad_table_fill(gtab, tid, 512);
   const int nk = K / BK8;
@@ -1280,10 +1313,10 @@ void gemm_nt_w8f8_kernel(const uint8_t* __restrict__ A, int lda, const uint8_t* 
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    if (!LAST) {
+    if (!LAST || (kSpare && !kAuxE)) {
       if (more2) { issue_load(cur, 0); issue_load(cur, 1); issue_load(cur, 2); spread_pending = true; }
-      read_a(Q0{}, nxt * STAGE, fa0);           // (stale bytes after the very last K-tile: never used)
     }
+    if (!LAST) read_a(Q0{}, nxt * STAGE, fa0);           // (stale bytes after the very last K-tile: never used)
     __builtin_amdgcn_sched_barrier(0);
     // last quarter W-tile-major: the W fragments are single-buffered (a second set of 32 registers does not exist
     // beside 128 accumulators), so W tile j of the next K-tile is fetched as soon as the two MFMAs that read tile j
@@ -1320,10 +1353,38 @@ void gemm_nt_w8f8_kernel(const uint8_t* __restrict__ A, int lda, const uint8_t* 
         csum_nw = nw;
       }
       const bool fast = io_aligned && (m0 + BM <= M) && (n0 + BN <= N);
-      if (fast) {
-        char* r1 = smem + cur * STAGE + wid * 6144;
+      if (fast && kSpare && kMulE) {
+        char* r1 = smem + 2 * STAGE + kTabBytes + wid * 2048;
+        u32x4 ta[2], tb[2];
+        aux16_issue(ep, mw, nw, lane, ta);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more2) { issue_load(cur, 0); issue_load(cur, 1); issue_load(cur, 2); spread_pending = true; }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int hp = 0; hp < 8; hp += 2) {
+          f32x4 rows[4];
+          aux16_issue(ep, mw + 16 * (hp + 1), nw, lane, tb);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) rows[j] = acc[hp][j] * dsc;
+          epilogue_piece16<EPI>(ep, C, ldc, mw + 16 * hp, nw, r1, rows, ta, lane, csum, gtab);
+          __builtin_amdgcn_sched_barrier(0);
+          if (hp + 2 < 8) aux16_issue(ep, mw + 16 * (hp + 2), nw, lane, ta);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) rows[j] = acc[hp + 1][j] * dsc;
+          epilogue_piece16<EPI>(ep, C, ldc, mw + 16 * (hp + 1), nw, r1, rows, tb, lane, csum, gtab);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else if (fast) {
+        char* r1 = kSpare ? smem + 2 * STAGE + wid * 4096 : smem + cur * STAGE + wid * 6144;
         f32x4 biasv[4];
         load_bias4<EPI>(ep, nw, lane, biasv);
+        u32x4 aux0[4];
+        if (kSpare && kAuxE) {
+          load_aux_rows_issue<EPI>(ep, mw, nw, lane, aux0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (more2) { issue_load(cur, 0); issue_load(cur, 1); issue_load(cur, 2); spread_pending = true; }
+          __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int hf = 0; hf < 4; ++hf) {
           f32x4 rows[2][4];
@@ -1332,11 +1393,13 @@ void gemm_nt_w8f8_kernel(const uint8_t* __restrict__ A, int lda, const uint8_t* 
 #pragma unroll
             for (int j = 0; j < 4; ++j) rows[ii][j] = acc[2 * hf + ii][j] * dsc;
           bf16x4 auxv[2][4];
-          load_aux_rows<EPI>(ep, mw + 32 * hf, nw, lane, r1, auxv);
-          epilogue_half<EPI>(ep, C, ldc, N, mw + 32 * hf, nw, r1, rows, biasv, auxv, lane, csum, gtab);
+          if (kSpare && kAuxE && hf == 0) load_aux_rows_finish<EPI, kSpare>(lane, r1, aux0, auxv);
+          else load_aux_rows<EPI, kSpare>(ep, mw + 32 * hf, nw, lane, r1, auxv);
+          epilogue_half<EPI, kSpare>(ep, C, ldc, N, mw + 32 * hf, nw, r1, rows, biasv, auxv, lane, csum, gtab);
           __builtin_amdgcn_sched_barrier(0);
         }
       } else {
+        if (kSpare && kAuxE && more2) { issue_load(cur, 0); issue_load(cur, 1); issue_load(cur, 2); spread_pending = true; }
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -1348,10 +1411,12 @@ void gemm_nt_w8f8_kernel(const uint8_t* __restrict__ A, int lda, const uint8_t* 
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (more1) {
-        F8_LGKM0();
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (more2) stage_next(cur);
+        if (!kSpare) {
+          F8_LGKM0();
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+          if (more2) stage_next(cur);
+        }
         read_w(nxt * STAGE, fw);
         read_a(Q0{}, nxt * STAGE, fa0);
         F8_LGKM0();
@@ -2960,7 +3025,8 @@ template <int EPI, bool A_BF8>
 int launch_nt_fp8(const uint8_t* A, int lda, const uint8_t* W, int ldw, bf16* C, int ldc, int M, int N, int K,
                          const M3PEpilogue& ep, hipStream_t st) {
   const int tiles_m = M / 256, tiles_n = N / 256;
-  const size_t lds = 2 * 512 * ROWB + (EPI == M3P_EPI_DGELU && M3P_DGELU_LUT ? GELU_TAB_N * sizeof(float) : 0);
+  const size_t lds = 2 * 512 * ROWB + (EPI == M3P_EPI_DGELU && M3P_DGELU_LUT ? GELU_TAB_N * sizeof(float) : 0) +
+                     (M3P_W8_SPARE_EPILOGUE ? ((EPI == M3P_EPI_DGELU || EPI == M3P_EPI_MUL) ? 8 * 2048 : 8 * 4096) : 0);
   auto kern = gemm_nt_w8f8_kernel<EPI, A_BF8>;
   static bool attr_set = false;
   if (!attr_set) {
