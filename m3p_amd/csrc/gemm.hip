@@ -2143,7 +2143,10 @@ int launch_nt(const bf16* A, int lda, const bf16* W, int ldw, bf16* C, int ldc, 
     return launch_nt_skinny<EPI, 8>(A, lda, W, ldw, C, ldc, M, N, K, ep, st);
   }
   const bool deep = (N >= 512) && (2LL * N * K <= (64LL << 20)) && EPI != M3P_EPI_DGELU;   // (dGELU epilogue: 240 VGPRs there, measured slower in the step)
-  if (M >= 1024 && (g_variant == 1 || g_variant == 6) && (N >= 512) && (2LL * N * K <= (64LL << 20)) && (K % 64) == 0 && (lda % 8) == 0 &&
+#ifndef M3P_W8_MAX_W_BYTES
+#define M3P_W8_MAX_W_BYTES (1LL << 40)      // (no limit: the vocabulary projection - W = 384 MB - measured 2.18 -> 1.85 ms on this kernel)
+#endif
+  if (M >= 1024 && (g_variant == 1 || g_variant == 6) && (N >= 512) && (2LL * N * K <= M3P_W8_MAX_W_BYTES) && (K % 64) == 0 && (lda % 8) == 0 &&
       (ldw % 8) == 0 && (M % 256) == 0 && (N % 256) == 0) {
     const int tiles_m = M / 256, tiles_n = N / 256;
     const size_t lds = 2 * 512 * ROWB + (EPI == M3P_EPI_DGELU && M3P_DGELU_LUT ? GELU_TAB_N * sizeof(float) : 0) +

@@ -29,6 +29,7 @@ def _round_up(n, a):
 
 # developer switch for A/B runs: 1 = gelu_fwd also leaves gelu'(u) in u's buffer and the dgrad uses EPI_MUL;
 # 0 (default) = the dgrad epilogue recomputes gelu'(u) (EPI_DGELU).  -40 us per dgrad, +40 us per gelu pass.
+_VOCAB_FULL_TILES = os.environ.get('M3P_VOCAB_FULL_TILES', '1') != '0'    # developer switch for A/B runs (Arena.V_pad)
 _GELU_GRAD_IN_FWD = os.environ.get('M3P_GELU_GRAD_IN_FWD', '0') != '0'   # measured equal in the step (47.97 vs 47.97 ms): off
 
 class Arena:
@@ -58,7 +59,12 @@ class Arena:
             p._m3p_arena = (self, n)
         self.params = named
         d, L_, V = model.dim, model.n_layers, model.n_words
-        self.V_pad = _round_up(V, 64)
+        # pitch of the logits rows: whole 256-column tiles, so that the vocabulary projection of a 256-multiple of rows
+        # runs on the eight-wave 256x256 kernel (it then reads rows V .. V_pad - 1 of "the matrix" - the bf16 bytes of
+        # the parameters that follow embeddings.weight in the arena - and their logits land in the pad columns, which
+        # the cross-entropy kernel zeroes again)
+        self.V_pad = _round_up(V, 256)
+        assert self.total >= self.V_pad * d, 'the arena ends before the padded vocabulary matrix does'
         # transposed bf16 copies for the data-gradient GEMMs
         self.wt = {}
         for i in range(L_):
@@ -858,7 +864,8 @@ class MLMHeadFn(torch.autograd.Function):
         n = int(y.shape[0])
         hsel = ops.gather_rows(base, row_idx, n, d)
         logits = torch.empty((n, ar.V_pad), dtype=BF16, device=hsel.device)
-        ops.gemm_nt(hsel, ar.w('embeddings.weight'), L.EPI_BIAS, bias=ar.p('pred_layer.proj.bias'), out=logits, n=V)
+        n_cols = ar.V_pad if (_VOCAB_FULL_TILES and n >= 1024 and n % 256 == 0) else V   # whole tiles: the eight-wave kernel
+        ops.gemm_nt(hsel, ar.w('embeddings.weight'), L.EPI_BIAS, bias=ar.p('pred_layer.proj.bias'), out=logits, n=n_cols)
         if scores_out is not None:
             scores_out.append(logits[:, :V].float())
         loss_sum, _ = ops.ce_fwd_bwd(logits, V, y, 1.0 / n, 1.0 / n)
@@ -877,7 +884,14 @@ class MLMHeadFn(torch.autograd.Function):
         n = hsel.shape[0]
         g = gloss.reshape(1).float()
         hs = (hsel.float() * g).to(BF16)
-        ops.gemm_wgrad(dlogits, hs, ar.g('embeddings.weight'), n=V, k=d)
+        if _VOCAB_FULL_TILES and n >= 4096 and n % 64 == 0:
+            # whole 256-row tiles of the vocabulary: the four-wave weight-gradient kernel.  The pad columns of dlogits are
+            # exact zeros (the CE kernel wrote them), so rows V .. V_pad - 1 of "the matrix" - the head of the bias
+            # gradient that follows it in the arena - receive += 0
+            o = ar.offsets['embeddings.weight'][0]
+            ops.gemm_wgrad(dlogits, hs, ar.grad[o:o + ar.V_pad * d].view(ar.V_pad, d), n=ar.V_pad, k=d)
+        else:
+            ops.gemm_wgrad(dlogits, hs, ar.g('embeddings.weight'), n=V, k=d)
         ops.colsum(dlogits, V, ar.g('pred_layer.proj.bias'), scale=g)
         dH32 = torch.zeros((n, d), dtype=torch.float32, device=dlogits.device)
         ops.gemm_nn_streamk(dlogits, ar.w('embeddings.weight'), dH32)     # E [V, d] read in place: no transposed copy
