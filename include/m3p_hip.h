@@ -294,6 +294,15 @@ M3P_API int m3p_itm_score_bwd(const float* dscores, const float* pooled, const f
 M3P_API int m3p_ce_fwd_bwd(void* logits, int ld, int n_rows, int V, const int64_t* target, float* row_loss,
                            float* loss_sum, float loss_scale, float grad_scale, void* stream);
 
+/* The same cross-entropy with the column sums of the gradient - the gradient of the output bias (PredLayer.proj.bias,
+ * transformer.py:111) - produced by the pass that writes the gradient, instead of a second pass over it: colsum[c]
+ * (fp32 [ld], OVERWRITTEN) = sum over rows of the rounded bf16 gradient; row_lse [n_rows] receives the log-sum-exp.
+ * workspace: m3p_ce_colsum_workspace_bytes(ld, n_rows) bytes owned by the caller (16-byte aligned). */
+M3P_API size_t m3p_ce_colsum_workspace_bytes(int ld, int n_rows);
+M3P_API int m3p_ce_fwd_bwd_colsum(void* logits, int ld, int n_rows, int V, const int64_t* target, float* row_loss,
+                                  float* row_lse, float grad_scale, float* colsum, void* workspace,
+                                  size_t workspace_bytes, void* stream);
+
 /* out[c] += scale * sum_r x[r,c] for c < ncols (x bf16 [n, ld]); scale read from the
  * device scalar *scale_ptr (NULL = 1): the vocabulary-bias gradient colsum(dlogits). */
 M3P_API int m3p_colsum_bf16(const void* x, int ld, int n, int ncols, float* out, const float* scale_ptr,

@@ -123,6 +123,94 @@ __global__ __launch_bounds__(1024) void ce_fwd_bwd_kernel(bf16* __restrict__ log
   }
 }
 
+// ---- cross-entropy with the vocabulary-bias gradient folded in (the MLM head at V = 250 002: the separate column-sum
+// pass over the 2.4-GB gradient costs 0.42 ms).  Three launches:
+//   ce_stats_kernel      one 1024-thread block per row: log-sum-exp + loss (pass 1 of ce_fwd_bwd_kernel)
+//   ce_grad_tile_kernel  one 256-thread block per (32 rows x 2048 columns): the gradient in place AND the column sums of
+//                        its 32 rows in registers -> part[row group][column] (fp32)
+//   ce_colsum_reduce     colsum[c] = sum over row groups
+__global__ __launch_bounds__(1024) void ce_stats_kernel(const bf16* __restrict__ logits, int ld, int V, const int64_t* __restrict__ target,
+                                                        float* __restrict__ row_loss, float* __restrict__ row_lse) {
+  __shared__ float s_m[16], s_s[16];
+  constexpr float kLog2e = 1.4426950408889634f;
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wib = tid >> 6;
+  const bf16* lr = logits + (size_t)row * ld;
+  const int nchunk = ld >> 3;
+  float m = -INFINITY, s = 0.f;
+  for (int c = tid; c < nchunk; c += 1024) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(lr + 8 * c);
+    float x[8];
+    float gm = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      x[j] = (8 * c + j < V) ? (float)v[j] : -INFINITY;
+      gm = fmaxf(gm, x[j]);
+    }
+    if (gm > m) {
+      s *= __builtin_amdgcn_exp2f((m - gm) * kLog2e);
+      m = gm;
+    }
+    const float mb = m * kLog2e;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += __builtin_amdgcn_exp2f(__builtin_fmaf(x[j], kLog2e, -mb));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s, o, 64);
+    const float mm = fmaxf(m, m2);
+    s = (m == -INFINITY ? 0.f : s * __expf(m - mm)) + (m2 == -INFINITY ? 0.f : s2 * __expf(m2 - mm));
+    m = mm;
+  }
+  if (lane == 0) { s_m[wib] = m; s_s[wib] = s; }
+  __syncthreads();
+  if (tid == 0) {
+    float M = -INFINITY;
+    for (int w = 0; w < 16; ++w) M = fmaxf(M, s_m[w]);
+    float Ssum = 0.f;
+    for (int w = 0; w < 16; ++w) Ssum += (s_m[w] == -INFINITY) ? 0.f : s_s[w] * __expf(s_m[w] - M);
+    const float lse = M + __logf(Ssum);
+    row_lse[row] = lse;
+    row_loss[row] = lse - (float)lr[target[row]];
+  }
+}
+
+constexpr int CE_RB = 32, CE_CB = 2048;      // rows / columns of a gradient tile
+__global__ __launch_bounds__(256) void ce_grad_tile_kernel(bf16* __restrict__ logits, int ld, int n_rows, int V,
+                                                           const int64_t* __restrict__ target, const float* __restrict__ row_lse,
+                                                           float gscale, float* __restrict__ part) {
+  constexpr float kLog2e = 1.4426950408889634f;
+  const int col0 = blockIdx.x * CE_CB + threadIdx.x * 8;
+  if (col0 >= ld) return;
+  const int r0 = blockIdx.y * CE_RB, r1 = min(n_rows, r0 + CE_RB);
+  float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int r = r0; r < r1; ++r) {
+    bf16* p = logits + (size_t)r * ld + col0;
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+    const float lb = row_lse[r] * kLog2e;
+    const int tc = (int)(target[r] - col0);          // the target's position inside this thread's eight columns (or outside)
+    bf16x8 g;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float q = (col0 + j < V) ? __builtin_amdgcn_exp2f(__builtin_fmaf((float)v[j], kLog2e, -lb)) : 0.f;
+      if (j == tc) q -= 1.f;
+      g[j] = (bf16)(q * gscale);
+      cs[j] += (float)g[j];                          // the sum of the ROUNDED gradient: what summing the bf16 tensor gives
+    }
+    *reinterpret_cast<bf16x8*>(p) = g;
+  }
+  float* out = part + (size_t)blockIdx.y * ld + col0;
+  *reinterpret_cast<f32x4*>(out) = f32x4{cs[0], cs[1], cs[2], cs[3]};
+  *reinterpret_cast<f32x4*>(out + 4) = f32x4{cs[4], cs[5], cs[6], cs[7]};
+}
+
+__global__ __launch_bounds__(256) void ce_colsum_reduce_kernel(const float* __restrict__ part, int ld, int n_groups, float* __restrict__ out) {
+  const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (c >= ld) return;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int g = 0; g < n_groups; ++g) acc += *reinterpret_cast<const f32x4*>(part + (size_t)g * ld + c);
+  *reinterpret_cast<f32x4*>(out + c) = acc;
+}
+
 // out[c] += scale * sum_r x[r, c]   (x bf16 [n, ld], c < ncols); rows split over gridDim.y
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ x, int ld, int n, int ncols,
                                                      float* __restrict__ out, const float* __restrict__ scale_ptr) {
@@ -141,6 +229,27 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ x,
 }  // namespace
 
 extern "C" {
+
+size_t m3p_ce_colsum_workspace_bytes(int ld, int n_rows) {
+  return (size_t)((n_rows + CE_RB - 1) / CE_RB) * (size_t)ld * sizeof(float);
+}
+
+int m3p_ce_fwd_bwd_colsum(void* logits, int ld, int n_rows, int V, const int64_t* target, float* row_loss, float* row_lse,
+                          float grad_scale, float* colsum, void* workspace, size_t workspace_bytes, void* stream) {
+  if (n_rows <= 0 || V <= 0 || ld < V || (ld % 8) != 0 || ((uintptr_t)logits & 15) || ((uintptr_t)colsum & 15) ||
+      ((uintptr_t)workspace & 15))
+    return M3P_EINVAL;
+  if (workspace_bytes < m3p_ce_colsum_workspace_bytes(ld, n_rows)) return M3P_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int groups = (n_rows + CE_RB - 1) / CE_RB;
+  hipLaunchKernelGGL(ce_stats_kernel, dim3(n_rows), dim3(1024), 0, st, (const bf16*)logits, ld, V, target, row_loss, row_lse);
+  hipLaunchKernelGGL(ce_grad_tile_kernel, dim3((ld + CE_CB - 1) / CE_CB, groups), dim3(256), 0, st, (bf16*)logits, ld, n_rows, V,
+                     target, (const float*)row_lse, grad_scale, (float*)workspace);
+  hipLaunchKernelGGL(ce_colsum_reduce_kernel, dim3((ld / 4 + 255) / 256), dim3(256), 0, st, (const float*)workspace, ld, groups,
+                     colsum);
+  M3P_CHECK_LAUNCH();
+  return M3P_OK;
+}
 
 int m3p_colsum_bf16(const void* x, int ld, int n, int ncols, float* out, const float* scale_ptr, void* stream) {
   if (n <= 0 || ncols <= 0 || (ld % 4) != 0 || ld < ((ncols + 3) / 4) * 4) return M3P_EINVAL;

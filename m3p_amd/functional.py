@@ -868,9 +868,15 @@ class MLMHeadFn(torch.autograd.Function):
         ops.gemm_nt(hsel, ar.w('embeddings.weight'), L.EPI_BIAS, bias=ar.p('pred_layer.proj.bias'), out=logits, n=n_cols)
         if scores_out is not None:
             scores_out.append(logits[:, :V].float())
-        loss_sum, _ = ops.ce_fwd_bwd(logits, V, y, 1.0 / n, 1.0 / n)
+        dbias = None
+        if _VOCAB_FULL_TILES and n >= 1024:
+            # the pass that writes the gradient also sums its columns (the output-bias gradient up to the upstream scale):
+            # no second pass over 2.4 GB in backward
+            loss_sum, _, dbias = ops.ce_fwd_bwd_colsum(logits, V, y, 1.0 / n, 1.0 / n)
+        else:
+            loss_sum, _ = ops.ce_fwd_bwd(logits, V, y, 1.0 / n, 1.0 / n)
         ctx.model = model
-        ctx.saved = (hsel, logits, row_idx, tuple(tensor.shape), tuple(tensor.stride()), tensor.storage_offset(), base)
+        ctx.saved = (hsel, logits, row_idx, tuple(tensor.shape), tuple(tensor.stride()), tensor.storage_offset(), base, dbias)
         return loss_sum[0].clone()
 
     @staticmethod
@@ -879,7 +885,7 @@ class MLMHeadFn(torch.autograd.Function):
         ar = model.arena()
         ar.touch('embeddings.weight', 'pred_layer.proj.bias')
         d, V = model.dim, model.n_words
-        hsel, dlogits, row_idx, shape, stride, soff, base = ctx.saved
+        hsel, dlogits, row_idx, shape, stride, soff, base, dbias = ctx.saved
         ctx.saved = None
         n = hsel.shape[0]
         g = gloss.reshape(1).float()
@@ -892,7 +898,10 @@ class MLMHeadFn(torch.autograd.Function):
             ops.gemm_wgrad(dlogits, hs, ar.grad[o:o + ar.V_pad * d].view(ar.V_pad, d), n=ar.V_pad, k=d)
         else:
             ops.gemm_wgrad(dlogits, hs, ar.g('embeddings.weight'), n=V, k=d)
-        ops.colsum(dlogits, V, ar.g('pred_layer.proj.bias'), scale=g)
+        if dbias is not None:
+            ar.g('pred_layer.proj.bias').add_(dbias[:V] * g)
+        else:
+            ops.colsum(dlogits, V, ar.g('pred_layer.proj.bias'), scale=g)
         dH32 = torch.zeros((n, d), dtype=torch.float32, device=dlogits.device)
         ops.gemm_nn_streamk(dlogits, ar.w('embeddings.weight'), dH32)     # E [V, d] read in place: no transposed copy
         dH = (dH32 * g).to(BF16)

@@ -415,6 +415,28 @@ def ce_fwd_bwd(logits, V, target, loss_scale, grad_scale):
     return loss_sum, row_loss
 
 
+_CE_WS = {}
+
+
+def ce_fwd_bwd_colsum(logits, V, target, loss_scale, grad_scale):
+    """ce_fwd_bwd + the column sums of the gradient from the same pass.  In place: logits <- dlogits.
+    Returns (loss_sum [1], row_loss [n], colsum fp32 [ld] of the rounded gradient)."""
+    n, ld = logits.shape[0], logits.stride(0)
+    dev = logits.device
+    row_loss = torch.empty(n, dtype=torch.float32, device=dev)
+    row_lse = torch.empty(n, dtype=torch.float32, device=dev)
+    cs = torch.empty(ld, dtype=torch.float32, device=dev)
+    need = L.load().m3p_ce_colsum_workspace_bytes(ld, n)
+    ws = _CE_WS.get(dev)
+    if ws is None or ws.numel() < need:
+        ws = _CE_WS[dev] = torch.empty(need, dtype=torch.uint8, device=dev)
+    assert target.dtype == torch.int64
+    rc = L.load().m3p_ce_fwd_bwd_colsum(logits.data_ptr(), ld, n, V, target.data_ptr(), row_loss.data_ptr(), row_lse.data_ptr(),
+                                        grad_scale, cs.data_ptr(), ws.data_ptr(), ws.numel(), L.stream())
+    L.check(rc, 'm3p_ce_fwd_bwd_colsum')
+    return (row_loss.sum() * loss_scale).reshape(1), row_loss, cs
+
+
 def colsum(x, ncols, out, scale=None):
     rc = L.load().m3p_colsum_bf16(x.data_ptr(), x.stride(0), x.shape[0], ncols, out.data_ptr(), L.ptr(scale), L.stream())
     L.check(rc, 'm3p_colsum_bf16')

@@ -56,6 +56,26 @@ def test_cross_entropy_fwd_bwd(n, V):
     assert bool((logits[:, V:] == 0).all())
 
 
+@pytest.mark.parametrize('n,V', [(9, 1000), (70, 250002), (33, 4100), (1, 64)])
+def test_cross_entropy_with_fused_bias_gradient(n, V):
+    """The three-launch form (row statistics; gradient tiles that also sum their columns; reduction of the partial sums):
+    same loss and gradient as the one-kernel form, and column sums equal to the sum of the rounded gradient rows."""
+    from m3p_amd import ops
+    ld = (V + 255) // 256 * 256
+    logits, lc = randn_bf16((n, ld), 1, 3.0)
+    twin = logits.clone()
+    y = torch.from_numpy(np.random.RandomState(2).randint(0, V, size=n)).long()
+    loss_sum, row_loss, cs = ops.ce_fwd_bwd_colsum(logits, V, y.cuda(), 1.0 / n, 1.0 / n)
+    loss_ref, row_ref = ops.ce_fwd_bwd(twin, V, y.cuda(), 1.0 / n, 1.0 / n)
+    assert abs(float(loss_sum) - float(loss_ref)) < 1e-5 * max(1.0, float(loss_ref))
+    assert rel_l2(row_loss, row_ref) < 1e-6
+    assert torch.equal(logits, twin)                      # the same gradient bits, pad columns zero
+    assert bool((logits[:, V:] == 0).all())
+    ref = F.cross_entropy(lc[:, :V], y, reduction='mean')
+    assert abs(float(loss_sum) - float(ref)) < 2e-4 * max(1.0, float(ref))
+    assert cs.shape == (ld,) and rel_l2(cs, logits.float().sum(0)) < 1e-5 and float(cs[V:].abs().max()) == 0.0
+
+
 def test_adam_step_matches_oracle():
     from m3p_amd import ops
     from oracle import ref_cpu as O
