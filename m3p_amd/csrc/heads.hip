@@ -126,8 +126,8 @@ __global__ __launch_bounds__(1024) void ce_fwd_bwd_kernel(bf16* __restrict__ log
 // ---- cross-entropy with the vocabulary-bias gradient folded in (the MLM head at V = 250 002: the separate column-sum
 // pass over the 2.4-GB gradient costs 0.42 ms).  Three launches:
 //   ce_stats_kernel      one 1024-thread block per row: log-sum-exp + loss (pass 1 of ce_fwd_bwd_kernel)
-//   ce_grad_tile_kernel  one 256-thread block per (32 rows x 2048 columns): the gradient in place AND the column sums of
-//                        its 32 rows in registers -> part[row group][column] (fp32)
+//   ce_grad_tile_kernel  one 256-thread block per (64 rows x 2048 columns): the gradient in place AND the column sums of
+//                        its 64 rows in registers -> part[row group][column] (fp32)
 //   ce_colsum_reduce     colsum[c] = sum over row groups
 __global__ __launch_bounds__(1024) void ce_stats_kernel(const bf16* __restrict__ logits, int ld, int V, const int64_t* __restrict__ target,
                                                         float* __restrict__ row_loss, float* __restrict__ row_lse) {
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(1024) void ce_stats_kernel(const bf16* __restrict__
   }
 }
 
-constexpr int CE_RB = 32, CE_CB = 2048;      // rows / columns of a gradient tile
+constexpr int CE_RB = 64, CE_CB = 2048;      // rows / columns of a gradient tile
 __global__ __launch_bounds__(256) void ce_grad_tile_kernel(bf16* __restrict__ logits, int ld, int n_rows, int V,
                                                            const int64_t* __restrict__ target, const float* __restrict__ row_lse,
                                                            float gscale, float* __restrict__ part) {
@@ -203,12 +203,17 @@ __global__ __launch_bounds__(256) void ce_grad_tile_kernel(bf16* __restrict__ lo
   *reinterpret_cast<f32x4*>(out + 4) = f32x4{cs[4], cs[5], cs[6], cs[7]};
 }
 
+// (row groups split over gridDim.y, folded with atomics into the zeroed output: 245 column blocks alone leave most of
+//  the chip idle and every thread 152 dependent loads deep - 95 us for 152 MB)
 __global__ __launch_bounds__(256) void ce_colsum_reduce_kernel(const float* __restrict__ part, int ld, int n_groups, float* __restrict__ out) {
   const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
   if (c >= ld) return;
+  const int per = (n_groups + gridDim.y - 1) / gridDim.y;
+  const int g0 = blockIdx.y * per, g1 = min(n_groups, g0 + per);
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int g = 0; g < n_groups; ++g) acc += *reinterpret_cast<const f32x4*>(part + (size_t)g * ld + c);
-  *reinterpret_cast<f32x4*>(out + c) = acc;
+  for (int g = g0; g < g1; ++g) acc += *reinterpret_cast<const f32x4*>(part + (size_t)g * ld + c);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) unsafeAtomicAdd(out + c + j, acc[j]);
 }
 
 // out[c] += scale * sum_r x[r, c]   (x bf16 [n, ld], c < ncols); rows split over gridDim.y
@@ -245,8 +250,9 @@ int m3p_ce_fwd_bwd_colsum(void* logits, int ld, int n_rows, int V, const int64_t
   hipLaunchKernelGGL(ce_stats_kernel, dim3(n_rows), dim3(1024), 0, st, (const bf16*)logits, ld, V, target, row_loss, row_lse);
   hipLaunchKernelGGL(ce_grad_tile_kernel, dim3((ld + CE_CB - 1) / CE_CB, groups), dim3(256), 0, st, (bf16*)logits, ld, n_rows, V,
                      target, (const float*)row_lse, grad_scale, (float*)workspace);
-  hipLaunchKernelGGL(ce_colsum_reduce_kernel, dim3((ld / 4 + 255) / 256), dim3(256), 0, st, (const float*)workspace, ld, groups,
-                     colsum);
+  if (hipMemsetAsync(colsum, 0, (size_t)ld * sizeof(float), st) != hipSuccess) return M3P_EINVAL;
+  hipLaunchKernelGGL(ce_colsum_reduce_kernel, dim3((ld / 4 + 255) / 256, groups >= 16 ? 8 : 1), dim3(256), 0, st,
+                     (const float*)workspace, ld, groups, colsum);
   M3P_CHECK_LAUNCH();
   return M3P_OK;
 }
