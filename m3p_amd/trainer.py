@@ -540,7 +540,8 @@ class XTrainer(Trainer):
         """xtrainer.py:2357-2372 kept on the device: CE over groups of sample_n + BCE vs one-hot."""
         params = self.params
         dev = relation_scores.device
-        pos = torch.as_tensor(np.asarray(pos_labels), dtype=torch.long).reshape(-1).to(dev)
+        pos = to_cuda(torch.as_tensor(np.asarray(pos_labels), dtype=torch.long).reshape(-1))[0] if dev.type == 'cuda' else \
+            torch.as_tensor(np.asarray(pos_labels), dtype=torch.long).reshape(-1)
         onehot = F.one_hot(pos, params.sample_n).float().view(-1)
         scores = relation_scores.float()
         loss = 0

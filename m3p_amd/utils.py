@@ -1,5 +1,7 @@
 """Small host-side helpers of the trainer surface (M3P/src/utils.py): device transfer, the
 scheduled lambda coefficients of ``train_x.py`` and boolean flags.  Pure Python, no kernels."""
+import os
+
 import torch
 
 # coefficients that may carry a schedule "it0:v0,it1:v1,..." (utils.py:28-30)
@@ -7,9 +9,24 @@ DYNAMIC_COEFF = ['lambda_mlm', 'lambda_mass', 'lambda_ic', 'lambda_imlm', 'lambd
                  'lambda_mrm', 'lambda_mrfr', 'lambda_t2i', 'lambda_i2t']
 
 
+_PIN_H2D = os.environ.get('M3P_PIN_H2D', '1') != '0'      # developer switch for A/B runs
+
+
+def _h2d(x):
+    """Host tensor -> current device through page-locked memory: a copy from pageable memory blocks the host until every
+    kernel queued before it has run (one full pipeline drain per training step: the GPU then idles ~0.2 ms while the
+    host starts enqueueing the next step); from pinned memory (PyTorch's caching host allocator) it is just another
+    stream-ordered operation."""
+    if x.is_cuda:
+        return x
+    if _PIN_H2D and torch.cuda.is_available() and not x.is_pinned() and x.numel() > 0:
+        x = x.pin_memory()
+    return x.cuda(non_blocking=True)
+
+
 def to_cuda(*args):
     """utils.py:233-237: None stays None, tensors move to the current device without blocking."""
-    return [None if x is None else x.cuda(non_blocking=True) for x in args]
+    return [None if x is None else _h2d(x) for x in args]
 
 
 def _parse_schedule(spec):
