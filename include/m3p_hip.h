@@ -96,6 +96,10 @@ M3P_API int m3p_gemm_nt_fp8(const void* A8, int lda, int a_is_bf8, const void* W
 M3P_API int m3p_quant_fp8(const void* src, int ld_src, void* dst, int ld_dst, int rows, int cols, const float* scale,
                           float* amax, int bf8, void* stream);
 
+/* The same for many contiguous matrices in one launch (the layers' weights, once per optimizer step): desc = n_desc rows
+ * of five int64 {src bf16*, dst uint8*, const float* scale, float* amax or 0, elements / 8}, device memory; e4m3. */
+M3P_API int m3p_quant_fp8_batch(const long long* desc, int n_desc, int blocks_per_matrix, void* stream);
+
 /* Stream-K variant with fp32 accumulate output: Cf[M,N] (fp32, pitch ldc) += alpha * A Wᵀ.
  * For few-tile / very-long-K problems — the data gradient of the tied vocabulary
  * projection (autograd of transformer.py:111: M = n_pred, N = d, K = V_pad). */
@@ -329,6 +333,9 @@ M3P_API int m3p_adam_step(float* p, float* g, float* m, float* v, void* w16, lon
  * dh (nullable, may alias u): also writes gelu_erf'(u) in bf16, which the backward FFN dgrad
  * then applies with M3P_EPI_MUL instead of recomputing the derivative in the GEMM epilogue. */
 M3P_API int m3p_gelu_fwd(const void* u, void* h, void* dh, long long n, void* stream);
+/* The same pass also writing h8 = e4m3(scale * h) (uint8 [n]) and raising *amax to max |h| (nullable): the operand of the
+ * fp8 lin2 product without a second pass over h (m3p_quant_fp8 of h gives the same bytes). */
+M3P_API int m3p_gelu_fwd_q8(const void* u, void* h, void* h8, long long n, const float* scale, float* amax, void* stream);
 
 /* du = dy * gelu_erf'(u) elementwise (backward of the GELU inside BertPredictionHeadTransform,
  * transformer.py:595-606, for the masked-region classification head), bf16, n % 8 == 0. */

@@ -152,6 +152,43 @@ __global__ __launch_bounds__(256) void quant_fp8_kernel(const bf16* __restrict__
   }
 }
 
+// Batched form for the weights (fp8 path: ~120 matrices per optimizer step, 8-10 us of launch each on their own): one
+// grid.y slice per matrix.  desc[i] = {src, dst, scale ptr, amax ptr or 0, elements / 8} (int64 each); e4m3 only.
+__global__ __launch_bounds__(256) void quant_fp8_batch_kernel(const long long* __restrict__ desc) {
+  const long long* dsc = desc + 5 * blockIdx.y;
+  const bf16* src = reinterpret_cast<const bf16*>(dsc[0]);
+  uint8_t* dst = reinterpret_cast<uint8_t*>(dsc[1]);
+  const float s = *reinterpret_cast<const float*>(dsc[2]);
+  float* amax = reinterpret_cast<float*>(dsc[3]);
+  const size_t total = (size_t)dsc[4];
+  float mx = 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + 8 * i);
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float x = (float)v[e];
+      mx = fmaxf(mx, fabsf(x));
+      f[e] = fminf(fmaxf(x * s, -448.f), 448.f);
+    }
+    int w0 = 0, w1 = 0;
+    w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], w0, false); w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], w0, true);
+    w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], w1, false); w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], w1, true);
+    *reinterpret_cast<int2*>(dst + 8 * i) = int2{w0, w1};
+  }
+  if (amax) {
+    __shared__ float wmax[4];
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      mx = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+      unsigned int* slot = reinterpret_cast<unsigned int*>(amax);
+      if (__float_as_uint(mx) > __builtin_nontemporal_load(slot)) atomicMax(slot, __float_as_uint(mx));
+    }
+  }
+}
+
 // dst[c][r] = src[r][c], 64x64 tiles through LDS; ld_dst >= rows (pad columns untouched)
 __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16* __restrict__ src, bf16* __restrict__ dst,
                                                              int rows, int cols, int ld_src, int ld_dst) {
@@ -208,6 +245,45 @@ __global__ __launch_bounds__(256) void gelu_fwd_kernel(const bf16* u, bf16* __re
     }
     *reinterpret_cast<bf16x8*>(h + 8 * i) = o;
     if (GRAD) *reinterpret_cast<bf16x8*>(dh + 8 * i) = d;     // may overwrite u: each thread has read its 8 values
+  }
+}
+
+// The same pass also emitting the e4m3 copy of h the fp8 lin2 product reads (fp8 path: a separate quantisation pass would
+// read the 280-MB activation again) + the running max |h| for the next step's scale.  The 8-bit value is the
+// quantisation of the ROUNDED bf16 h, i.e. exactly what m3p_quant_fp8 would produce from h.
+__global__ __launch_bounds__(256) void gelu_fwd_q8_kernel(const bf16* __restrict__ u, bf16* __restrict__ h, uint8_t* __restrict__ h8,
+                                                          size_t n8, const float* __restrict__ scale, float* __restrict__ amax) {
+  const float s = *scale;
+  float mx = 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(u + 8 * i);
+    bf16x8 o;
+    float f[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float x = (float)v[j];
+      const GeluParts g = gelu_parts(x);
+      o[j] = (bf16)(x * g.cdf);
+      const float hr = (float)o[j];
+      mx = fmaxf(mx, fabsf(hr));
+      f[j] = fminf(fmaxf(hr * s, -448.f), 448.f);
+    }
+    *reinterpret_cast<bf16x8*>(h + 8 * i) = o;
+    int w0 = 0, w1 = 0;
+    w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], w0, false); w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], w0, true);
+    w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], w1, false); w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], w1, true);
+    *reinterpret_cast<int2*>(h8 + 8 * i) = int2{w0, w1};
+  }
+  if (amax) {
+    __shared__ float wmax[4];
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      mx = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+      unsigned int* slot = reinterpret_cast<unsigned int*>(amax);
+      if (__float_as_uint(mx) > __builtin_nontemporal_load(slot)) atomicMax(slot, __float_as_uint(mx));
+    }
   }
 }
 
@@ -283,6 +359,16 @@ int m3p_gelu_fwd(const void* u, void* h, void* dh, long long n, void* stream) {
   return M3P_OK;
 }
 
+int m3p_gelu_fwd_q8(const void* u, void* h, void* h8, long long n, const float* scale, float* amax, void* stream) {
+  if (n <= 0 || (n % 8) != 0 || ((uintptr_t)u & 15) || ((uintptr_t)h & 15) || ((uintptr_t)h8 & 7) || !scale) return M3P_EINVAL;
+  const size_t n8 = (size_t)n / 8;
+  const int blocks = (int)((n8 + 255) / 256 < 8192 ? (n8 + 255) / 256 : 8192);
+  hipLaunchKernelGGL(gelu_fwd_q8_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)u, (bf16*)h, (uint8_t*)h8, n8,
+                     scale, amax);
+  M3P_CHECK_LAUNCH();
+  return M3P_OK;
+}
+
 int m3p_transpose_batch_bf16(const long long* desc, int n_desc, int max_tiles, void* stream) {
   if (n_desc <= 0 || max_tiles <= 0) return M3P_EINVAL;
   hipLaunchKernelGGL(transpose_batch_kernel, dim3(max_tiles, n_desc), dim3(256), 0, (hipStream_t)stream, desc);
@@ -304,6 +390,13 @@ int m3p_quant_fp8(const void* src, int ld_src, void* dst, int ld_dst, int rows, 
   else
     hipLaunchKernelGGL(quant_fp8_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)src, ld_src,
                        (uint8_t*)dst, ld_dst, rows, cols / 8, scale, amax);
+  M3P_CHECK_LAUNCH();
+  return M3P_OK;
+}
+
+int m3p_quant_fp8_batch(const long long* desc, int n_desc, int blocks_per_matrix, void* stream) {
+  if (!desc || n_desc <= 0 || blocks_per_matrix <= 0 || blocks_per_matrix > 4096) return M3P_EINVAL;
+  hipLaunchKernelGGL(quant_fp8_batch_kernel, dim3(blocks_per_matrix, n_desc), dim3(256), 0, (hipStream_t)stream, desc);
   M3P_CHECK_LAUNCH();
   return M3P_OK;
 }

@@ -18,6 +18,16 @@ import torch
 from . import ops
 
 SITES = ('x', 'ctx', 'x1', 'hact', 'wqkv', 'wout', 'w1', 'w2', 'dy2', 'du', 'dao', 'dqkv')
+# Which of a layer's eight products actually run in 8 bits, named by their weight.  A product pays for itself only if the
+# GEMM saves more than the quantisation pass of its activation / gradient operand costs (both measured on the cfg4 shapes,
+# profiles/r02_fp8_gemm_shapes.txt): the three wide or deep forward products and the two data gradients with a 4096- /
+# 3072-deep contraction do (+11 .. +43 us each); the two 1024 x 1024 products break even, and the dU product would need
+# the derivative pre-computed by the forward GELU pass (+40 us there) to save 18 us.  M3P_FP8_ALL=1: all eight (A/B runs).
+import os as _os
+if _os.environ.get('M3P_FP8_ALL', '0') != '0':
+    FWD_SITES, BWD_SITES = {'wqkv', 'wout', 'w1', 'w2'}, {'wqkv', 'wout', 'w1', 'w2'}
+else:
+    FWD_SITES, BWD_SITES = {'wqkv', 'w1', 'w2'}, {'wqkv', 'w1'}
 _BF8 = {'dy2', 'du', 'dao', 'dqkv'}
 E4M3_MAX, E5M2_MAX = 448.0, 57344.0
 
@@ -34,6 +44,7 @@ class Fp8State:
         self.seen = [False] * n
         self.weights = {}           # (layer, site) -> (w8, 8-bit transposed copy, descale [1])
         self.weights_version = None
+        self._wdesc = None
 
     def index(self, layer, site):
         return layer * len(SITES) + SITES.index(site)
@@ -60,18 +71,49 @@ class Fp8State:
         x8 = ops.quant_fp8(x, scale=self.scale[i:i + 1], amax=self.amax[i:i + 1] if record else None, bf8=site in _BF8)
         return x8, self.descale[i:i + 1]
 
+    def gelu_quant(self, u, layer):
+        """hact = gelu(u) together with its 8-bit copy for the lin2 product (one pass instead of GELU + quantisation); the
+        site's first use - no scale history yet - takes the two-pass route.  -> (hact, (hact8, descale) or None)"""
+        i = self.index(layer, 'hact')
+        if not self.seen[i]:
+            return ops.gelu_fwd(u), None
+        h, h8 = ops.gelu_fwd_q8(u, self.scale[i:i + 1], self.amax[i:i + 1])
+        return h, (h8, self.descale[i:i + 1])
+
     def quant_weights(self, arena):
-        """8-bit copies of every layer's four weight matrices and of their transposes (the data-gradient operands),
-        re-made when the bf16 working copy changed (once per optimizer step)."""
+        """8-bit copies of the layers' weight matrices that run in fp8 and of the transposes their data gradients need,
+        re-made when the bf16 working copy changed (once per optimizer step) - ONE batched launch (a descriptor row per
+        matrix; 120 separate launches cost more than the 1.3 GB they move)."""
         version = (arena.epoch, arena.master._version)
         if self.weights_version == version and self.weights:
             return
-        for i in range(self.n_layers):
-            for site, w, wt in (('wqkv', arena.qkv_w16(i), arena.wt[('qkv', i)]),
-                                ('wout', arena.w('attentions.%d.out_lin.weight' % i), arena.wt[('out', i)]),
-                                ('w1', arena.w('ffns.%d.lin1.weight' % i), arena.wt[('lin1', i)]),
-                                ('w2', arena.w('ffns.%d.lin2.weight' % i), arena.wt[('lin2', i)])):
-                w8, dsc = self.quant(w, i, site)
-                wt8, _ = self.quant(wt, i, site, record=False)        # same values, same scale
-                self.weights[(i, site)] = (w8, wt8, dsc.clone())     # roll() rewrites descale in place; these copies keep theirs
+        first = not self.weights
+        used = [(i, site) for i in range(self.n_layers) for site in ('wqkv', 'wout', 'w1', 'w2')
+                if site in FWD_SITES or site in BWD_SITES]
+        if first:
+            self._wk = torch.tensor([self.index(i, s) for i, s in used], dtype=torch.long, device=arena.device)
+            self._wdsc = torch.empty(len(used), dtype=torch.float32, device=arena.device)
+        rows = []
+        for j, (i, site) in enumerate(used):
+            w, wt = {'wqkv': (arena.qkv_w16(i), arena.wt[('qkv', i)]),
+                     'wout': (arena.w('attentions.%d.out_lin.weight' % i), arena.wt[('out', i)]),
+                     'w1': (arena.w('ffns.%d.lin1.weight' % i), arena.wt[('lin1', i)]),
+                     'w2': (arena.w('ffns.%d.lin2.weight' % i), arena.wt[('lin2', i)])}[site]
+            k = self.index(i, site)
+            if not self.seen[k]:
+                self._first_use(w, k)
+            if first:
+                w8 = torch.empty(w.shape, dtype=torch.uint8, device=w.device)
+                wt8 = torch.empty(wt.shape, dtype=torch.uint8, device=w.device) if site in BWD_SITES else None
+                self.weights[(i, site)] = (w8, wt8, self._wdsc[j:j + 1])
+            w8, wt8, _ = self.weights[(i, site)]
+            assert w.is_contiguous() and wt.is_contiguous() and w.numel() % 8 == 0
+            rows.append([w.data_ptr(), w8.data_ptr(), self.scale[k:k + 1].data_ptr(), self.amax[k:k + 1].data_ptr(), w.numel() // 8])
+            if wt8 is not None:
+                rows.append([wt.data_ptr(), wt8.data_ptr(), self.scale[k:k + 1].data_ptr(), 0, wt.numel() // 8])
+        # (roll() rewrites descale in place; the copies made now stay valid for the 8-bit weights quantised now)
+        torch.index_select(self.descale, 0, self._wk, out=self._wdsc)
+        if self._wdesc is None or self._wdesc[1] != rows:
+            self._wdesc = (torch.tensor(rows, dtype=torch.int64, device=arena.device), rows)
+        ops.quant_fp8_batch(self._wdesc[0], len(rows))
         self.weights_version = version

@@ -16,6 +16,7 @@ from collections import OrderedDict
 import torch
 
 from . import lib as L
+from . import fp8 as fp8mod
 from . import ops
 from . import rng
 
@@ -429,10 +430,10 @@ class EncoderFn(torch.autograd.Function):
                 st8.roll()
             st8.quant_weights(ar)
 
-        def lin(xin, i, xsite, wsite, w16, epi, **kw):
-            if st8 is None:
+        def lin(xin, i, xsite, wsite, w16, epi, pre8=None, **kw):
+            if st8 is None or wsite not in fp8mod.FWD_SITES:
                 return ops.gemm_nt(xin, w16, epi, **kw)
-            x8, dxs = st8.quant(xin, i, xsite)
+            x8, dxs = pre8 if pre8 is not None else st8.quant(xin, i, xsite)
             w8, _, dws = st8.weights[(i, wsite)]
             return ops.gemm_nt_fp8(x8, w8, epi, descale_a=dxs, descale_b=dws, **kw)
 
@@ -445,18 +446,21 @@ class EncoderFn(torch.autograd.Function):
             pre1 = lin(ctxt, i, 'ctx', 'wout', ar.w(a + 'out_lin.weight'), L.EPI_BIAS_DROP_RES, bias=ar.p(a + 'out_lin.bias'),
                        aux=h, seed=seed('attn_out', i), p_drop=p_drop)
             x1, mean1, rstd1 = ops.layernorm_fwd(pre1, ar.p('layer_norm1.%d.weight' % i), ar.p('layer_norm1.%d.bias' % i))
+            hact8 = None
             if M >= 1024 or st8 is not None:
                 # persistent GEMM: bias in the epilogue, GELU as its own HBM-speed pass
                 # The same pass leaves gelu'(u) in u's buffer: the backward dgrad then only multiplies
                 # (EPI_MUL, runs on the four-wave GEMM) instead of evaluating erf/exp in its epilogue.
                 u = lin(x1, i, 'x1', 'w1', ar.w(f + 'lin1.weight'), L.EPI_BIAS, bias=ar.p(f + 'lin1.bias'))
-                # (fp8: the K loop is half as long, so the erf / exp of EPI_DGELU would dominate the dgrad - always multiply)
-                hact = ops.gelu_fwd(u, grad_inplace=_GELU_GRAD_IN_FWD or st8 is not None)
+                if st8 is not None and 'w2' in fp8mod.FWD_SITES and 'w2' not in fp8mod.BWD_SITES and not _GELU_GRAD_IN_FWD:
+                    hact, hact8 = st8.gelu_quant(u, i)           # GELU and the 8-bit copy for lin2 in one pass
+                else:
+                    hact = ops.gelu_fwd(u, grad_inplace=_GELU_GRAD_IN_FWD or (st8 is not None and 'w2' in fp8mod.BWD_SITES))
             else:
                 u = torch.empty((M, 4 * d), dtype=BF16, device=dev)
                 hact = ops.gemm_nt(x1, ar.w(f + 'lin1.weight'), L.EPI_BIAS_GELU, bias=ar.p(f + 'lin1.bias'), out2=u)
             pre2 = lin(hact, i, 'hact', 'w2', ar.w(f + 'lin2.weight'), L.EPI_BIAS_DROP_RES, bias=ar.p(f + 'lin2.bias'),
-                       aux=x1, seed=seed('ffn', i), p_drop=p_drop)
+                       aux=x1, seed=seed('ffn', i), p_drop=p_drop, pre8=hact8)
             h_next, mean2, rstd2 = ops.layernorm_fwd(pre2, ar.p('layer_norm2.%d.weight' % i),
                                                      ar.p('layer_norm2.%d.bias' % i), rowmask)
             if track:      # (inference keeps nothing: retrieval evaluation runs thousands of sequences per call)
@@ -506,7 +510,7 @@ class EncoderFn(torch.autograd.Function):
 
         def dgrad(g, i, gsite, wsite, wt16, epi, **kw):
             """data gradient g [M, n] x W -> [M, k] on the transposed weight copy (bf8 gradient x fp8 weight when fp8 is on)"""
-            if st8 is None:
+            if st8 is None or wsite not in fp8mod.BWD_SITES:
                 return ops.gemm_nt(g, wt16, epi, **kw)
             g8, dgs = st8.quant(g, i, gsite)
             _, wt8, dws = st8.weights[(i, wsite)]
@@ -525,7 +529,8 @@ class EncoderFn(torch.autograd.Function):
                 dY2 = dpre2
             ops.gemm_wgrad(dY2, hact, ar.g(f + 'lin2.weight'))
             dU = dgrad(dY2, i, 'dy2', 'w2', ar.wt[('lin2', i)],
-                       L.EPI_MUL if ((M >= 1024 and _GELU_GRAD_IN_FWD) or st8 is not None) else L.EPI_DGELU, aux=u,
+                       L.EPI_MUL if ((M >= 1024 and _GELU_GRAD_IN_FWD) or (st8 is not None and 'w2' in fp8mod.BWD_SITES))
+                       else L.EPI_DGELU, aux=u,
                        colsum=ar.g(f + 'lin1.bias'))      # u holds gelu'(u) on the persistent path
             del hact, u, pre2
             ops.gemm_wgrad(dU, x1, ar.g(f + 'lin1.weight'))

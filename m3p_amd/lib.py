@@ -38,6 +38,7 @@ SIGNATURES = {
     'm3p_gemm_nt_bf16': (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, C.POINTER(Epilogue), _p]),
     'm3p_gemm_nt_fp8': (_i, [_p, _i, _i, _p, _i, _p, _i, _i, _i, _i, _i, C.POINTER(Epilogue), _p]),
     'm3p_quant_fp8': (_i, [_p, _i, _p, _i, _i, _i, _p, _p, _i, _p]),
+    'm3p_quant_fp8_batch': (_i, [_p, _i, _i, _p]),
     'm3p_gemm_nt_streamk_f32': (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _f, _p]),
     'm3p_gemm_nn_streamk_f32': (_i, [_p, _i, _p, _i, _i, _p, _i, _i, _i, _i, _f, _p]),
     'm3p_gemm_wgrad_workspace_bytes': (C.c_size_t, []),
@@ -70,6 +71,7 @@ SIGNATURES = {
     'm3p_gelu_bwd': (_i, [_p, _p, _p, C.c_longlong, _p]),
     'm3p_mse_fwd_bwd': (_i, [_p, _i, _p, _i, _p, _p, _i, _i, _f, _p]),
     'm3p_gelu_fwd': (_i, [_p, _p, _p, C.c_longlong, _p]),
+    'm3p_gelu_fwd_q8': (_i, [_p, _p, _p, C.c_longlong, _p, _p, _p]),
     'm3p_transpose_batch_bf16': (_i, [_p, _i, _i, _p]),
     'm3p_transpose_bf16': (_i, [_p, _p, _i, _i, _i, _i, _p]),
     'm3p_probe_mfma_16x16x32': (_i, [_p, _p, _p, _p, _p]),

@@ -89,6 +89,11 @@ def quant_fp8(x, scale=None, amax=None, bf8=False, out=None):
     return out
 
 
+def quant_fp8_batch(desc, n_desc, blocks_per_matrix=512):
+    """Many contiguous bf16 matrices -> e4m3 in one launch; desc int64 [n_desc, 5] on the device (csrc/optim.hip)."""
+    L.check(L.load().m3p_quant_fp8_batch(desc.data_ptr(), n_desc, blocks_per_matrix, L.stream()), 'm3p_quant_fp8_batch')
+
+
 def gemm_nt_fp8(a8, w8, epilogue=L.EPI_NONE, a_is_bf8=False, descale_a=None, descale_b=None, bias=None, aux=None, out=None,
                 colsum=None, scale_cols=0, scale=1.0, seed=0, p_drop=0.0):
     """C[M,N] (bf16) = epi(descale_a * descale_b * a8[M,K] @ w8[N,K]^T): 8-bit operands (uint8 storage) from quant_fp8,
@@ -468,6 +473,15 @@ def gelu_fwd(u, grad_inplace=False):
     L.check(L.load().m3p_gelu_fwd(u.data_ptr(), h.data_ptr(), u.data_ptr() if grad_inplace else None, u.numel(), L.stream()),
             'm3p_gelu_fwd')
     return h
+
+
+def gelu_fwd_q8(u, scale, amax=None):
+    """(h = gelu_erf(u) bf16, h8 = e4m3(scale * h) uint8) in one pass; amax (fp32 [1]) is raised to max |h|."""
+    h = torch.empty_like(u)
+    h8 = torch.empty(u.shape, dtype=torch.uint8, device=u.device)
+    L.check(L.load().m3p_gelu_fwd_q8(u.data_ptr(), h.data_ptr(), h8.data_ptr(), u.numel(), scale.data_ptr(), L.ptr(amax), L.stream()),
+            'm3p_gelu_fwd_q8')
+    return h, h8
 
 
 def transpose_batch(desc, n_desc, max_tiles):

@@ -161,3 +161,14 @@ def test_fp8_needs_whole_row_tiles():
     trainer, tup = bench.build(cfg, 0.0, 1, 0, 0, fp8=True)
     with pytest.raises(AssertionError, match='256-row tiles'):
         trainer.pretrain_under_step(tup, 'google', 't2i', 'en', 1.0, 1.0, 1.0, 1.0)
+
+
+def test_gelu_pass_with_8bit_copy_equals_gelu_then_quant():
+    from m3p_amd import ops
+    u = _bf16((1000, 512), 5, 2.0)
+    scale = torch.tensor([24.0], device='cuda')
+    am1, am2 = torch.zeros(1, device='cuda'), torch.zeros(1, device='cuda')
+    h, h8 = ops.gelu_fwd_q8(u.clone(), scale, am1)
+    h_ref = ops.gelu_fwd(u.clone())
+    q_ref = ops.quant_fp8(h_ref, scale=scale, amax=am2)
+    assert torch.equal(h, h_ref) and torch.equal(h8, q_ref) and float(am1) == float(am2) == float(h_ref.float().abs().max())
