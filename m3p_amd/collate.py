@@ -1,7 +1,9 @@
 """Collate functions of the pre-training / retrieval data loaders: what turns per-item dataset
 tuples into the batch tuples ``pretrain_under_step`` / ``t2i_step`` / ``i2t_step`` consume
 (M3P/src/xtrainer.py:829-880 ``batch_sentences(_v2)``, :883-930 ``retrieval_collate``,
-:960-1045 ``retrieval_pretrain_collate``).  Host-side tensor packing only.
+:960-1045 ``retrieval_pretrain_collate``), and those of the generation loaders that feed ``ic_step`` /
+``mt_ic_step`` / the text-to-text steps (:931-957 ``caption_collate``, :1048-1075 ``mt_caption_collate``,
+:1078-1087 ``ntg_collate``, :1089-1125 ``slide_collate``).  Host-side tensor packing only.
 
 Conventions kept from the reference: sentences become (slen, n) int64 with BOS = 0 in row 0,
 EOS = 2 after the last token and PAD = 1 below; language ids fill a (slen, n) tensor that
@@ -103,3 +105,40 @@ def retrieval_pretrain_collate(data):
 
     t2i, i2t = zip(*data)
     return [t2i_side(t2i) if t2i is not None else None, i2t_side(i2t) if i2t is not None else None]
+
+
+def _regions(feats, masks, boxes):
+    """Per-item (k, R, ...) region tensors -> (n_items * k, R, ...): features, mask, boxes."""
+    return [_merge(feats), _merge(masks), _merge(boxes)]
+
+
+def caption_collate(data):
+    """Captioning loader (xtrainer.py:931-957).  Item = (captions, region feats, region mask, box feats, image ids); the
+    captions of a batch are the per-item entries themselves (one word-id array per item, no chaining) and the image ids
+    stay a tuple of per-item values.  Returns [(sent, lengths), [img, img_mask, img_loc, img_ids]]."""
+    sent, feats, masks, boxes, ids = zip(*data)
+    x_img, x_mask, loc = _regions(feats, masks, boxes)
+    return [batch_sentences(sent), [x_img, x_mask, loc, ids]]
+
+
+def mt_caption_collate(data):
+    """Multimodal-translation loader (xtrainer.py:1048-1075).  Item = (source sentence, target sentence, region feats,
+    region mask, box feats, image ids) -> [(src, src_len), (tgt, tgt_len), [img, img_mask, img_loc, img_ids]]."""
+    src, tgt, feats, masks, boxes, ids = zip(*data)
+    x_img, x_mask, loc = _regions(feats, masks, boxes)
+    return [batch_sentences(src), batch_sentences(tgt), [x_img, x_mask, loc, ids]]
+
+
+def ntg_collate(data):
+    """Text-to-text generation loader (xtrainer.py:1078-1087): items (source, target) -> [(src, len), (tgt, len)]."""
+    src, tgt = zip(*data)
+    return [batch_sentences(src), batch_sentences(tgt)]
+
+
+def slide_collate(data):
+    """Sliding-window retrieval loader (xtrainer.py:1089-1125).  Item = (captions, region feats, region mask, box feats,
+    image ids, labels) with per-item lists that are concatenated -> [(sent, lengths), [img, img_mask, img_loc, img_ids],
+    labels]."""
+    sent, feats, masks, boxes, ids, labels = zip(*data)
+    x_img, x_mask, loc = _regions(feats, masks, boxes)
+    return [batch_sentences(_chain(sent)), [x_img, x_mask, loc, _chain(ids)], _chain(labels)]

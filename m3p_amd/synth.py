@@ -363,3 +363,29 @@ def ic_case():
     img_len = torch.from_numpy(rs.randint(R // 2, R + 1, size=B)).long()
     img_len[0] = R
     return P, sd, x_img, loc, img_len, x2, len2
+
+
+def mt_ic_case():
+    """The translation model of mt_case with an image beside the source sentence (the multimodal-translation step):
+    R = 10 regions per image, all valid - the loaders always hand out full region sets (dataset_pretrain.py:313), which is
+    what makes jointfwd's prefix mask (image length + text length) the right one."""
+    P, sd, x_src, len_src, x2, len2 = mt_case()
+    rs = np.random.RandomState(780)
+    R, B = 10, x2.shape[1]
+    x_img = torch.from_numpy(rs.standard_normal((R, B, 2048)).astype(np.float32))
+    x_img = x_img / x_img.norm(dim=-1, keepdim=True)
+    loc = torch.from_numpy(rs.uniform(0, 1, size=(R, B, 5)).astype(np.float32))
+    img_len = torch.full((B,), R, dtype=torch.long)
+    return P, sd, x_src, len_src, x_img, loc, img_len, x2, len2
+
+
+def token_stream(seed=41, n_sent=23, V=1000):
+    """A monolingual corpus as the reference's binarised files hold it: word ids with an EOS after every sentence, the
+    (start, end) position of each sentence (end = its EOS), and a language id per token (for the StreamDataset golden)."""
+    rs = np.random.RandomState(seed)
+    sents = [rs.randint(4, V - 1, size=rs.randint(1, 12)) for _ in range(n_sent)]
+    sent = np.concatenate([np.concatenate([s, [EOS]]) for s in sents]).astype(np.int32)
+    ends = np.cumsum([len(s) + 1 for s in sents]) - 1
+    pos = np.stack([ends - np.array([len(s) for s in sents]), ends], axis=1).astype(np.int64)
+    langs = rs.randint(0, 2, size=len(sent)).astype(np.int32)
+    return sent, pos, langs

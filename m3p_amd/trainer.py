@@ -26,7 +26,8 @@ import torch
 import torch.nn.functional as F
 
 from . import masking
-from .collate import batch_sentences, batch_sentences_v2, retrieval_collate, retrieval_pretrain_collate  # noqa: F401
+from .collate import (batch_sentences, batch_sentences_v2, caption_collate, mt_caption_collate, ntg_collate,  # noqa: F401
+                      retrieval_collate, retrieval_pretrain_collate, slide_collate)
 from .distributed import DataParallel
 from .optim import get_optimizer
 from .utils import parse_lambda_config, to_cuda, update_lambdas
@@ -318,20 +319,7 @@ class Trainer(object):
         assert lambda_coeff >= 0
         if lambda_coeff == 0:
             return
-        # the caption collate belongs to the reference's data layer (not part of this build): the dataset hands out
-        # ready batches through its own iterator
-        key = ('txt2img', dataset, input_stream)
-        ds = self.data['cross_modal'][(dataset, input_stream)]['train']
-        if not hasattr(ds, 'get_iterator'):
-            raise NotImplementedError("ic_step needs data['cross_modal'][(%r, %r)]['train'].get_iterator() yielding "
-                                      "((x2, len2), (x1, x1_mask, img_loc, img_id)) batches" % (dataset, input_stream))
-        if key not in self.iterators:
-            self.iterators[key] = iter(ds.get_iterator())
-        try:
-            batch = next(self.iterators[key])
-        except StopIteration:
-            self.iterators[key] = iter(ds.get_iterator())
-            batch = next(self.iterators[key])
+        batch = self.get_batch('txt2img', dataset, input_stream)
         (x2, len2), (x1, x1_mask, img_loc, _img_id) = batch
         return self.ic_step_on_batch(x2, len2, x1, x1_mask, img_loc, dataset, input_stream, lambda_coeff)
 
@@ -366,6 +354,54 @@ class Trainer(object):
         self.stats['processed_s'] += len2.size(0)
         self.stats['processed_w'] += n_words
         return loss.detach()
+    def mt_ic_step(self, dataset='coco', input_stream='img', lambda_coeff=1):
+        """Multimodal translation step (xtrainer.py:1517-1593) on a ``mt_caption_collate`` batch
+        ``(x_src, len_src), (x2, len2), (x1, x1_mask, img_loc, img_id)``."""
+        assert lambda_coeff >= 0
+        if lambda_coeff == 0:
+            return
+        (x_src, len_src), (x2, len2), (x1, x1_mask, img_loc, _img_id) = self.get_batch('txt2img', dataset, input_stream)
+        return self.mt_ic_step_on_batch(x_src, len_src, x2, len2, x1, x1_mask, img_loc, dataset, input_stream, lambda_coeff)
+
+    def mt_ic_step_on_batch(self, x_src, len_src, x2, len2, x1, x1_mask, img_loc, dataset='coco', input_stream='img',
+                            lambda_coeff=1):
+        """Loss path of mt_ic_step (:1540-1593): the source sentence is encoded together with the image regions (``jointfwd``,
+        language ids ignored there) - or alone with its language embedding when ``params.mt_only_text`` - and the target is
+        decoded with teacher forcing over that encoding (``src_len`` = source words + regions).  Languages come from
+        ``params.ft_lgs`` = [source, target]."""
+        params = self.params
+        model = self.model
+        model.train()
+        self._dp_plan(True, expect=('mlm',))
+        lang_src = x_src.clone().fill_(params.lang2id[params.ft_lgs[0]])
+        langs = x2.clone().fill_(params.lang2id[params.ft_lgs[1]])
+        alen = torch.arange(int(len2.max()), dtype=torch.long, device=len2.device)
+        pred_mask = alen[:, None] < len2[None] - 1
+        y = x2[1:].masked_select(pred_mask[:-1])
+        n_words = int((len2 - 1).sum())
+        assert len(y) == n_words
+        len1 = x1_mask.sum(dim=1)
+        x1 = x1.transpose(0, 1)
+        img_loc = img_loc.transpose(0, 1)
+        x1, len1, img_loc, x2, len2, y, langs, lang_src, x_src, len_src, pred_mask = to_cuda(
+            x1, len1, img_loc, x2, len2, y, langs, lang_src, x_src, len_src, pred_mask)
+        if getattr(params, 'mt_only_text', False):
+            enc1 = model('crossfwd', stream_='text', x=x_src, lengths=len_src, langs=lang_src, causal=False)
+            len_all = len_src
+        else:
+            enc1 = model('jointfwd', x=x_src, lengths=len_src, x_img=x1, lengths_img=len1, causal=False, langs=None,
+                         image_loc=img_loc, refine_image=getattr(params, 'refine_image', False))
+            len_all = len_src + len1
+        enc1 = enc1.transpose(0, 1)
+        dec2 = model('crossfwd', stream_='text', x=x2, lengths=len2, langs=langs, causal=True, src_enc=enc1, src_len=len_all)
+        _, loss = model('predict', tensor=dec2, pred_mask=pred_mask, y=y, get_scores=False)
+        self._stat('IC-%s-%s' % (dataset, input_stream), loss)
+        self.optimize(lambda_coeff * loss)
+        self.n_sentences += params.batch_size
+        self.stats['processed_s'] += len2.size(0)
+        self.stats['processed_w'] += n_words
+        return loss.detach()
+
     def _state_dicts(self):
         return {n: {k: v.detach().cpu().clone() for k, v in _unwrap(getattr(self, n)).state_dict().items()}
                 for n in self.MODEL_NAMES}
@@ -496,8 +532,8 @@ class XTrainer(Trainer):
     # ------------------------------------------------------------------ cross-modal batches (xtrainer.py:1148-1206)
     def get_iterator(self, iter_name, lang1, lang2):
         """A DataLoader over ``data['cross_modal'][(dataset, 'img')]['train']`` with the pre-training or the
-        retrieval collate; distributed runs shard it with a DistributedSampler.  (Generation / sliding-window
-        loaders are outside this build.)"""
+        retrieval / captioning / multimodal-translation / sliding-window collate the run's flags select; distributed
+        runs shard it with a DistributedSampler."""
         from torch.utils.data import DataLoader, RandomSampler
         from torch.utils.data.distributed import DistributedSampler
         params = self.params
@@ -509,7 +545,12 @@ class XTrainer(Trainer):
         if lang1 == 'flicker' and hasattr(dataset, 'update_captions'):
             dataset.update_captions()
         sampler = RandomSampler(dataset) if getattr(params, 'n_gpu_per_node', 1) == 1 else DistributedSampler(dataset)
-        collate = retrieval_pretrain_collate if getattr(params, 'is_pretrain', False) else retrieval_collate
+        if getattr(params, 'is_generation', False):            # xtrainer.py:1164-1181
+            collate = mt_caption_collate if getattr(params, 'is_mt', False) else caption_collate
+        elif getattr(params, 'is_pretrain', False):
+            collate = retrieval_pretrain_collate
+        else:
+            collate = slide_collate if getattr(params, 'is_slide', False) else retrieval_collate
         loader = DataLoader(dataset, batch_size=params.batch_size, sampler=sampler, collate_fn=collate,
                             num_workers=getattr(params, 'num_workers', 0))
         for batch in loader:

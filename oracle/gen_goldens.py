@@ -649,6 +649,120 @@ def gen_ic_goldens():
     np.savez_compressed(os.path.join(OUT, 'ic_step.npz'), **g)
 
 
+def gen_mt_ic_goldens():
+    """mt_ic_step.npz: the multimodal-translation step of xtrainer.py:1517-1593 on the reference (dropout 0): jointfwd
+    encoder pass on (source sentence, regions), teacher-forced causal pass over it with src_len = words + regions, loss,
+    gradients."""
+    from src.model.transformer import TransformerModel
+    from oracle import ref_cpu
+    P, sd, x_src, len_src, x_img, loc, img_len, x2, len2 = synth.mt_ic_case()
+    torch.manual_seed(0)
+    m = TransformerModel(P, is_encoder=True, with_output=True, is_crossModal=True)
+    own = dict(m.named_parameters())
+    with torch.no_grad():
+        for k, v in sd.items():
+            own[k].copy_(v)
+    m.train()
+    langs = x2.clone().fill_(1)
+    pred_mask, y = synth.mt_targets(x2, len2)
+    enc1 = m('jointfwd', x=x_src, lengths=len_src, x_img=x_img, lengths_img=img_len, causal=False, langs=None,
+             image_loc=loc, refine_image=False).transpose(0, 1)
+    len_all = len_src + img_len
+    dec2 = m('crossfwd', stream_='text', x=x2, lengths=len2, langs=langs, causal=True, src_enc=enc1, src_len=len_all)
+    _, loss = m('predict', tensor=dec2, pred_mask=pred_mask, y=y, get_scores=False)
+    loss.backward()
+    g = {'enc1': enc1.detach().numpy(), 'dec2': dec2.detach().numpy(), 'loss': loss.detach().numpy()}
+    names = ['cross_lang_embeddings.weight', 'image_embeddings.image_embeddings.weight', 'image_embeddings.image_location_embeddings.bias',
+             'image_embeddings.LayerNorm.weight', 'position_embeddings.weight', 'layer_norm_emb.weight', 'layer_norm_emb.bias',
+             'attentions.0.q_lin.weight', 'attentions.1.out_lin.weight', 'encoder_attn.0.k_lin.weight', 'encoder_attn.0.q_lin.bias',
+             'encoder_attn.1.v_lin.weight', 'layer_norm15.1.weight', 'ffns.0.lin1.weight', 'ffns.1.lin2.bias', 'layer_norm2.1.bias',
+             'pred_layer.proj.bias']
+    for k in names:
+        g['grad.' + k] = own[k].grad.numpy()
+    g['grad_norm.embeddings.weight'] = own['embeddings.weight'].grad.norm().numpy()
+    o_enc = ref_cpu.jointfwd(sd, P.n_layers, P.n_heads, x_src, len_src, x_img, img_len, loc).transpose(0, 1)
+    o_dec = ref_cpu.decoder_crossfwd(sd, P.n_layers, P.n_heads, x2, len2, o_enc, len_all, langs=langs)
+    print('mt_ic_step.npz: loss %.6f; enc max|d| %.2e dec max|d| %.2e' % (float(loss), float((o_enc - enc1.detach()).abs().max()),
+                                                                          float((o_dec - dec2.detach()).abs().max())))
+    assert float((o_dec - dec2.detach()).abs().max()) < 1e-4
+    np.savez_compressed(os.path.join(OUT, 'mt_ic_step.npz'), **g)
+
+
+def gen_data_goldens():
+    """host_data.npz: the reference's StreamDataset (dataset_pretrain.py:787-890) on a synthetic token stream - lane matrix,
+    an unshuffled and two seeded shuffled epochs, select_data, the resumed-epoch skip - and its generation collates
+    (xtrainer.py:931-957, :1048-1125) on synthetic dataset items.  h5py / lmdb are absent here and unused by that class:
+    empty stand-in modules let the file import (container-only, like the apex ones of SURVEY App. A)."""
+    for name in ('apex', 'apex.amp', 'apex.parallel', 'h5py', 'lmdb'):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    import src.xtrainer as xt
+    from src.data.dataset_pretrain import StreamDataset
+    g = {}
+    sent, pos, langs = synth.token_stream(seed=41)
+    g['sd_sent'], g['sd_pos'], g['sd_langs'] = sent, pos, langs
+
+    def P(**kw):
+        return types.SimpleNamespace(bptt=8, batch_size=5, eos_index=synth.EOS, n_gpu_per_node=2, local_rank=1,
+                                     lang2id={'en': 0, 'zh': 1}, **kw)
+
+    def epoch(ds, tag, **kw):
+        for i, b in enumerate(ds.get_iterator(**kw)):
+            g['%s.%d.x' % (tag, i)] = b[0].numpy()
+            g['%s.%d.len' % (tag, i)] = b[1].numpy()
+            if len(b) > 2:
+                g['%s.%d.langs' % (tag, i)] = b[2].numpy()
+        g[tag + '.n'] = np.asarray(i + 1)
+
+    ds = StreamDataset(sent, pos, P())
+    g['sd_data'] = ds.data.copy()
+    g['sd_counts'] = np.asarray([ds.n_tokens, ds.n_batches, len(ds)])
+    epoch(ds, 'sd_plain', shuffle=False)
+    epoch(ds, 'sd_shuf1', shuffle=True, seed=17)
+    epoch(ds, 'sd_shuf2', shuffle=True, seed=17)              # second shuffled epoch of the same object: seed + 3
+    g['sd_loaded'] = np.asarray(ds.loaded[1])
+    ds.reload_check({0: [], 1: [int(ds.n_batches), 2]})        # resumed after two batches of its second epoch
+    epoch(ds, 'sd_resume', shuffle=True, seed=17)
+    g['sd_resume_loaded'] = np.asarray(ds.loaded[1])
+    ds.select_data(1, 3)
+    g['sd_sel_data'] = ds.data.copy()
+    g['sd_sel_counts'] = np.asarray([ds.n_batches, len(ds)])
+    dl = StreamDataset(sent, pos, P(), langs=langs)
+    g['sd_lang_matrix'] = dl.langs.copy()
+    epoch(dl, 'sd_lang', shuffle=False, subsample=2)
+
+    rs = np.random.RandomState(43)
+    V = 1000
+
+    def regions(k, R=4):
+        return (torch.from_numpy(rs.standard_normal((k, R, 2048)).astype(np.float32)), torch.ones(k, R, dtype=torch.long),
+                torch.from_numpy(rs.uniform(size=(k, R, 5)).astype(np.float32)))
+
+    def words(lo=0, hi=7):
+        return rs.randint(4, V - 1, size=rs.randint(lo, hi)).astype(np.int64)
+
+    def flatten(prefix, obj, out):
+        if isinstance(obj, (list, tuple)) and not (len(obj) > 0 and all(isinstance(v, (int, np.integer)) for v in obj)):
+            for i, v in enumerate(obj):
+                flatten('%s.%d' % (prefix, i), v, out)
+        elif torch.is_tensor(obj):
+            out[prefix] = obj.numpy()
+        else:
+            out[prefix] = np.asarray(obj)
+
+    cap_items = [(words(),) + regions(1) + (int(rs.randint(0, 1000)),) for _ in range(4)]
+    mt_items = [(words(1), words(1)) + regions(1) + (int(rs.randint(0, 1000)),) for _ in range(4)]
+    ntg_items = [(words(1, 9), words(1, 5)) for _ in range(5)]
+    slide_items = [([words(), words()],) + regions(2) + ([int(v) for v in rs.randint(0, 1000, size=2)], [int(v) for v in rs.randint(0, 2, size=2)])
+                   for _ in range(3)]
+    for tag, fn, items in (('cap', xt.caption_collate, cap_items), ('mtc', xt.mt_caption_collate, mt_items),
+                           ('ntg', xt.ntg_collate, ntg_items), ('sld', xt.slide_collate, slide_items)):
+        flatten('col_%s_in' % tag, items, g)
+        flatten('col_%s' % tag, fn(items), g)
+    np.savez_compressed(os.path.join(OUT, 'host_data.npz'), **g)
+    print('host_data.npz: %d arrays' % len(g))
+
+
 def gen_noise_goldens():
     """host_noise.npz: Trainer.add_noise (word_shuffle + word_dropout, xtrainer.py:291-383) of the reference under fixed
     numpy seeds on synthetic sentences."""
@@ -741,11 +855,12 @@ def gen_decoder_goldens():
 
 if __name__ == '__main__':
     single = {'enum': gen_state_dict_enumeration, 'host': gen_host_goldens, 'mt': gen_mt_goldens, 'noise': gen_noise_goldens, 'ic': gen_ic_goldens, 'langs': gen_text_langs_goldens,
-              'decoder': gen_decoder_goldens, 'refiner': gen_refiner_goldens}
+              'decoder': gen_decoder_goldens, 'refiner': gen_refiner_goldens, 'mt_ic': gen_mt_ic_goldens, 'data': gen_data_goldens}
     if len(sys.argv) > 1:
         single[sys.argv[1]]()
         sys.exit(0)
     for fn in (gen_state_dict_enumeration, gen_refiner_goldens, gen_clcm_goldens, gen_region_head_goldens,
                gen_text_and_itm_goldens, gen_unit_goldens, gen_model_goldens, gen_trainer_goldens, gen_host_goldens,
-               gen_decoder_goldens, gen_text_langs_goldens, gen_mt_goldens, gen_ic_goldens, gen_noise_goldens):
+               gen_decoder_goldens, gen_text_langs_goldens, gen_mt_goldens, gen_ic_goldens, gen_noise_goldens,
+               gen_mt_ic_goldens, gen_data_goldens):
         fn()

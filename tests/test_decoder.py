@@ -413,3 +413,61 @@ def test_ic_step_vs_reference():
     assert grads and not bad, bad
     # the clip norm of this step is far below 5: the gradients above are the unclipped ones
     assert opt.grad_norm() < 5
+
+
+def test_oracle_mt_ic_step_matches_the_reference():
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'mt_ic_step.npz'))
+    P, sd, x_src, len_src, x_img, loc, img_len, x2, len2 = synth.mt_ic_case()
+    enc = ref_cpu.jointfwd(sd, P.n_layers, P.n_heads, x_src, len_src, x_img, img_len, loc).transpose(0, 1)
+    dec = ref_cpu.decoder_crossfwd(sd, P.n_layers, P.n_heads, x2, len2, enc, len_src + img_len, langs=x2.clone().fill_(1))
+    assert np.abs(enc.numpy() - g['enc1']).max() < 2e-5 and np.abs(dec.numpy() - g['dec2']).max() < 2e-5
+    pred_mask, y = synth.mt_targets(x2, len2)
+    loss = ref_cpu.predict_mlm(sd, dec, pred_mask, y)
+    loss = loss[1] if isinstance(loss, tuple) else loss
+    assert abs(float(loss) - float(g['loss'])) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('only_text', [False, True])
+def test_mt_ic_step_vs_reference(only_text):
+    """The multimodal-translation step: jointfwd over (regions | source words) as the encoder pass, the target decoded over all
+    R + len_src positions - loss and gradients against the reference's (tests/golden/mt_ic_step.npz) through
+    Trainer.mt_ic_step_on_batch on the tuple layout of mt_caption_collate.  With params.mt_only_text the encoder pass is the
+    text stream alone, which is mt_step's computation: checked against tests/golden/mt_step.npz."""
+    from m3p_amd.model.transformer import TransformerModel
+    from m3p_amd.trainer import XTrainer
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'mt_step.npz' if only_text else 'mt_ic_step.npz'))
+    P, sd, x_src, len_src, x_img, loc, img_len, x2, len2 = synth.mt_ic_case()
+    for k, v in dict(optimizer='adam_inverse_sqrt,beta1=0.9,beta2=0.98,lr=0.0001', clip_grad_norm=5, amp=-1, fp16=False,
+                     accumulate_gradients=1, multi_gpu=False, epoch_size=100, cross_mlm_steps=[], cross_mrm_steps=[], langs=['en', 'zh'],
+                     cross_mrfr_steps=[], cross_clcm_steps=[], sample_n=2, refine_image=False, batch_size=6, ft_lgs=['en', 'zh'],
+                     mt_only_text=only_text, dump_path='/nonexistent_m3p_dump').items():
+        setattr(P, k, v)
+    torch.manual_seed(0)
+    m = TransformerModel(P, is_encoder=True, with_output=True, is_crossModal=True).cuda()
+    m.load_state_dict(sd, strict=False)
+    m.train()
+    tr = XTrainer(m, {}, P)
+    grads = {}
+    opt = tr.optimizers['model']
+    inner = opt.step
+
+    def step(closure=None):
+        torch.cuda.synchronize()
+        for k in [k[5:] for k in g.files if k.startswith('grad.')]:
+            grads[k] = dict(m.named_parameters())[k].grad.float().cpu().clone()
+        grads['|embeddings.weight|'] = dict(m.named_parameters())['embeddings.weight'].grad.float().norm().cpu()
+        return inner(closure)
+    opt.step = step
+    R, B = x_img.shape[0], x_img.shape[1]
+    x1_mask = torch.ones(B, R, dtype=torch.long)
+    loss = tr.mt_ic_step_on_batch(x_src, len_src, x2, len2, x_img.transpose(0, 1).contiguous(), x1_mask,
+                                  loc.transpose(0, 1).contiguous(), 'coco', 'img', 1.0)
+    assert abs(float(loss) - float(g['loss'])) < 5e-3
+    enorm = grads.pop('|embeddings.weight|')
+    assert abs(float(enorm) - float(g['grad_norm.embeddings.weight'])) < 4e-2 * float(g['grad_norm.embeddings.weight'])
+    bad = [(k, rel_l2(v, g['grad.' + k])) for k, v in grads.items()]
+    bad = [(k, e) for k, e in bad if e > 4e-2]
+    assert grads and not bad, bad
+    assert opt.grad_norm() < 5
+    assert tr.stats['processed_s'] == B and tr.stats['processed_w'] == int((len2 - 1).sum())
