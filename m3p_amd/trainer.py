@@ -191,15 +191,16 @@ class Trainer(object):
     # ------------------------------------------------------------------ text batches (xtrainer.py:436-509)
     def get_cross_lingual_iterator(self, iter_name, lang1, lang2, stream):
         """Data-layer contract (the datasets themselves are the reference's): ``data['mono_stream'][lang]['train']``
-        / ``data['mono'][lang]['train']`` / ``data['para'][(l1, l2)]['train']`` expose ``get_iterator(...)``
+        / ``data['mono'][lang]['train']`` (``data['text']`` under ``is_ntg``) / ``data['para'][(l1, l2)]['train']`` expose ``get_iterator(...)``
         yielding ``(x, lengths)`` (or a pair of those for parallel data)."""
         logger.info('Creating new training data iterator (%s) ...' % ','.join(
             str(v) for v in (iter_name, lang1, lang2) if v is not None))
         if lang2 is None:
             if stream:
                 iterator = self.data['mono_stream'][lang1]['train'].get_iterator(shuffle=True)
-            else:
-                iterator = self.data['mono'][lang1]['train'].get_iterator(
+            else:                                   # text-to-text generation reads its own table (:446-450)
+                table = 'text' if getattr(self.params, 'is_ntg', False) else 'mono'
+                iterator = self.data[table][lang1]['train'].get_iterator(
                     shuffle=True, group_by_size=self.params.group_by_size, n_sentences=-1)
         else:
             pair = (lang1, lang2) if lang1 < lang2 else (lang2, lang1)
@@ -286,7 +287,7 @@ class Trainer(object):
             (x1, len1), (x2, len2) = self.get_cross_lingual_batch('mt', lang1, lang2)
         return self.mt_step_on_batch(x1, len1, x2, len2, lang1, lang2, lambda_coeff)
 
-    def mt_step_on_batch(self, x1, len1, x2, len2, lang1, lang2, lambda_coeff=1):
+    def mt_step_on_batch(self, x1, len1, x2, len2, lang1, lang2, lambda_coeff=1, stat=None):
         """Loss path of mt_step on a parallel batch (:1410-1441): the model encodes the source sentence (non-causal text
         stream with its language embedding) and decodes the target with teacher forcing (causal stream + attention over
         the encoding); word t + 1 is predicted from position t."""
@@ -306,12 +307,22 @@ class Trainer(object):
         enc1 = enc1.transpose(0, 1)
         dec2 = model('crossfwd', stream_='text', x=x2, lengths=len2, langs=langs2, causal=True, src_enc=enc1, src_len=len1)
         _, loss = model('predict', tensor=dec2, pred_mask=pred_mask, y=y, get_scores=False)
-        self._stat(('AE-%s' % lang1) if lang1 == lang2 else ('MT-%s-%s' % (lang1, lang2)), loss)
+        self._stat(stat or (('AE-%s' % lang1) if lang1 == lang2 else ('MT-%s-%s' % (lang1, lang2))), loss)
         self.optimize(lambda_coeff * loss)
         self.n_sentences += params.batch_size
         self.stats['processed_s'] += len2.size(0)
         self.stats['processed_w'] += n_words
         return loss.detach()
+
+    def ntg_step(self, lang1='en', lang2=None, lambda_coeff=1):
+        """Text-to-text generation step (xtrainer.py:2596-2645; train_x.py:443-445 over ``text_steps``): a
+        (source, target) batch of one language from ``ntg_collate`` - the translation step's loss path with the same language
+        id on both sides and no input noise."""
+        assert lambda_coeff >= 0
+        if lambda_coeff == 0:
+            return
+        (x1, len1), (x2, len2) = self.get_cross_lingual_batch('ntg', lang1, None)
+        return self.mt_step_on_batch(x1, len1, x2, len2, lang1, lang1, lambda_coeff, stat='NTG-%s' % lang1)
 
     def ic_step(self, dataset='coco', input_stream='img', lambda_coeff=1):
         """Captioning step (xtrainer.py:1443-1515) on a ``('txt2img', dataset, 'img')`` batch:
@@ -712,3 +723,30 @@ class XTrainer(Trainer):
 
     def i2t_step(self, batches, dataset='coco', lambda_coeff=1):
         return self._rel_step(batches, dataset, 'i2t', lambda_coeff)
+
+    def slide_step(self, dataset='slide', input_stream='img', lambda_coeff=1):
+        """Sliding-window matching step (xtrainer.py:2649-2698) on a ``slide_collate`` batch
+        ``(x2, len2), (x1, x1_mask, img_loc, img_id), labels``: jointfwd -> relation score per sequence -> BCE against the
+        0 / 1 labels (kept on the device here; the reference moves the scores to the host first)."""
+        assert lambda_coeff >= 0
+        if lambda_coeff == 0:
+            return None
+        params = self.params
+        model = self.model
+        model.train()
+        (x2, len2), (x1, x1_mask, img_loc, _img_id), labels = self.get_batch('slide2img', dataset, input_stream)
+        self._dp_plan(False)
+        img_len = x1_mask.sum(dim=1)
+        x_img, img_loc = x1.transpose(0, 1), img_loc.transpose(0, 1)
+        target = torch.as_tensor(np.asarray(labels, dtype='float32')).view(-1)
+        x2, len2, x_img, img_loc, img_len, target = to_cuda(x2, len2, x_img, img_loc, img_len, target)
+        enc = model('jointfwd', x=x2, lengths=len2, x_img=x_img, lengths_img=img_len, causal=False, langs=None,
+                    image_loc=img_loc, refine_image=params.refine_image)
+        relation_scores = model('predict', tensor=enc.transpose(0, 1), is_relation=True)
+        loss = F.binary_cross_entropy_with_logits(relation_scores.float().view(-1), target)
+        self._stat('SLIDE-%s' % input_stream, loss)
+        self.optimize(lambda_coeff * loss)
+        self.n_sentences += params.batch_size
+        self.stats['processed_s'] += len2.size(0)
+        self.stats['processed_w'] += int((len2 - 1).sum())
+        return loss.detach()

@@ -471,3 +471,120 @@ def test_mt_ic_step_vs_reference(only_text):
     assert grads and not bad, bad
     assert opt.grad_norm() < 5
     assert tr.stats['processed_s'] == B and tr.stats['processed_w'] == int((len2 - 1).sum())
+
+
+def _step_params(P, **over):
+    base = dict(optimizer='adam_inverse_sqrt,beta1=0.9,beta2=0.98,lr=0.0001', clip_grad_norm=5, amp=-1, fp16=False,
+                accumulate_gradients=1, multi_gpu=False, epoch_size=100, cross_mlm_steps=[], cross_mrm_steps=[], langs=['en', 'zh'],
+                cross_mrfr_steps=[], cross_clcm_steps=[], sample_n=2, refine_image=False, batch_size=6, ft_lgs=['en', 'zh'],
+                group_by_size=False, dump_path='/nonexistent_m3p_dump')
+    base.update(over)
+    for k, v in base.items():
+        setattr(P, k, v)
+    return P
+
+
+def _grads_at_step(m, opt, names):
+    """Gradients the optimizer is about to consume, captured by wrapping its step()."""
+    got = {}
+    inner = opt.step
+
+    def step(closure=None):
+        torch.cuda.synchronize()
+        named = dict(m.named_parameters())
+        for k in names:
+            got[k] = named[k].grad.float().cpu().clone()
+        return inner(closure)
+    opt.step = step
+    return got
+
+
+@pytest.mark.gpu
+def test_ntg_step_vs_oracle():
+    """Text-to-text generation (xtrainer.py:2596-2645): a (source, target) batch of one language out of data['text'] - the
+    translation computation with the same language id on both sides.  Loss and gradients against the oracle's autograd (the
+    oracle's encoder / decoder passes are pinned to the reference by tests/golden/mt_step.npz)."""
+    from m3p_amd.model.transformer import TransformerModel
+    from m3p_amd.trainer import XTrainer
+    P, sd, x1, len1, x2, len2 = synth.mt_case()
+    _step_params(P, is_ntg=True)
+
+    class Pairs:
+        def get_iterator(self, shuffle, group_by_size=False, n_sentences=-1):
+            assert shuffle and n_sentences == -1
+            return iter([((x1, len1), (x2, len2))])
+
+    torch.manual_seed(0)
+    m = TransformerModel(P, is_encoder=True, with_output=True, is_crossModal=True).cuda()
+    m.load_state_dict(sd, strict=False)
+    tr = XTrainer(m, {'text': {'zh': {'train': Pairs()}}}, P)
+    names = ['cross_lang_embeddings.weight', 'attentions.0.q_lin.weight', 'encoder_attn.1.k_lin.weight', 'encoder_attn.0.out_lin.bias',
+             'ffns.1.lin1.weight', 'layer_norm15.0.weight', 'pred_layer.proj.bias']
+    grads = _grads_at_step(m, tr.optimizers['model'], names)
+    loss = tr.ntg_step('zh', None, 1.0)
+    # oracle: both sides carry language id 1
+    ref = {k: v.clone().requires_grad_(k in names) for k, v in sd.items()}
+    enc = ref_cpu.crossfwd_text(ref, P.n_layers, P.n_heads, x1, len1, langs=x1.clone().fill_(1)).transpose(0, 1)
+    dec = ref_cpu.decoder_crossfwd(ref, P.n_layers, P.n_heads, x2, len2, enc, len1, langs=x2.clone().fill_(1))
+    pred_mask, y = synth.mt_targets(x2, len2)
+    o = ref_cpu.predict_mlm(ref, dec, pred_mask, y)
+    o = o[1] if isinstance(o, tuple) else o
+    o.backward()
+    assert abs(float(loss) - float(o.detach())) < 5e-3
+    bad = [(k, rel_l2(grads[k], ref[k].grad.numpy())) for k in names]
+    assert not [b for b in bad if b[1] > 4e-2], bad
+    assert 'NTG-zh' in tr.stats and tr.stats['processed_w'] == int((len2 - 1).sum())
+    assert tr.ntg_step('zh', None, 0) is None
+
+
+@pytest.mark.gpu
+def test_slide_step_vs_oracle():
+    """Sliding-window matching (xtrainer.py:2649-2698): slide_collate batch -> jointfwd -> relation score -> BCE against 0/1
+    labels; loss and gradients against the oracle's autograd, the batch drawn through the DataLoader the is_slide flag selects."""
+    from m3p_amd.model.transformer import TransformerModel
+    from m3p_amd.trainer import XTrainer
+    P, sd, x_src, len_src, x_img, loc, img_len, _, _ = synth.mt_ic_case()
+    _step_params(P, is_slide=True, is_generation=False, is_pretrain=False, n_gpu_per_node=1, num_workers=0, batch_size=3)
+    R, B = x_img.shape[0], x_img.shape[1]                 # six sequences = three items of two windows each
+    labels = [1, 0, 0, 1, 1, 1]
+
+    class Items(torch.utils.data.Dataset):
+        def __len__(self):
+            return 3
+
+        def __getitem__(self, i):
+            cols = [2 * i, 2 * i + 1]
+            sents = [x_src[1:int(len_src[c]) - 1, c].numpy() for c in cols]
+            return (sents, x_img[:, cols].transpose(0, 1).contiguous(), torch.ones(2, R, dtype=torch.long),
+                    loc[:, cols].transpose(0, 1).contiguous(), [10 * c for c in cols], [labels[c] for c in cols])
+
+    torch.manual_seed(0)
+    m = TransformerModel(P, is_encoder=True, with_output=True, is_crossModal=True).cuda()
+    m.load_state_dict(sd, strict=False)
+    tr = XTrainer(m, {'cross_modal': {('slide', 'img'): {'train': Items()}}}, P)
+    names = ['pooled_layer.dense.weight', 'seq_relationship.weight', 'attentions.1.v_lin.weight', 'ffns.0.lin2.weight',
+             'image_embeddings.image_embeddings.weight', 'layer_norm_emb.bias']
+    grads = _grads_at_step(m, tr.optimizers['model'], names)
+    order = []
+    real_get = tr.get_batch
+
+    def get_batch(*a):                                     # the sampler shuffles items: record which ones came
+        b = real_get(*a)
+        order.extend(b[1][3])
+        return b
+    tr.get_batch = get_batch
+    loss = tr.slide_step('slide', 'img', 1.0)
+    cols = [i // 10 for i in order]
+    assert sorted(cols) == list(range(6))
+    ref = {k: v.clone().requires_grad_(k in names) for k, v in sd.items()}
+    # BOS/EOS framing of batch_sentences: the reference marks both sentence ends with EOS in its streams, the collate uses 0 / 2
+    xs = x_src[:, cols].clone()
+    xs[0] = 0
+    enc = ref_cpu.jointfwd(ref, P.n_layers, P.n_heads, xs, len_src[cols], x_img[:, cols], img_len[cols], loc[:, cols])
+    scores = ref_cpu.predict_relation(ref, enc.transpose(0, 1))
+    o = torch.nn.functional.binary_cross_entropy_with_logits(scores.view(-1), torch.tensor([float(labels[c]) for c in cols]))
+    o.backward()
+    assert abs(float(loss) - float(o.detach())) < 5e-3
+    bad = [(k, rel_l2(grads[k], ref[k].grad.numpy())) for k in names]
+    assert not [b for b in bad if b[1] > 4e-2], bad
+    assert 'SLIDE-img' in tr.stats and tr.stats['processed_s'] == 6
