@@ -493,7 +493,8 @@ __device__ __forceinline__ void epilogue_piece16(const M3PEpilogue& ep, bf16* __
 }
 
 #if defined(M3P_RING_TL) || defined(M3P_W8_TL)
-__device__ unsigned long long g_ring_tl[256 * 8 * 8];   // debug build: per-wave cycle sums of the eight-wave kernel's segments
+__device__ unsigned long long g_ring_tl[256 * 8 * 16];  // debug build: per-wave cycle sums of the eight-wave kernel's segments
+                                                        // ([256][8][8] segments, then [256][8][8] K-tile phases of the w8 kernel)
 #endif
 
 // ---------------------------------------------------------------------------------
@@ -923,8 +924,15 @@ void gemm_nt_w8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
   unsigned long long tl0 = __builtin_amdgcn_s_memtime(), tl1;
   tacc[5] = tl0;
 #define W8_TSEG(k) do { tl1 = __builtin_amdgcn_s_memtime(); tacc[k] += tl1 - tl0; tl0 = tl1; } while (0)
+  // phases of a K-tile: stamps are issued (not waited for) in front of each quarter's closing lgkmcnt wait, behind the vmcnt
+  // wait and behind the barrier; the sums are taken behind quarter 3's wait, when all of them have returned
+  unsigned long long kq[8] = {0, 0, 0, 0, 0, 0, 0, 0}, kst[7];
+#define W8_KSTAMP(i) asm volatile("s_memtime %0" : "=s"(kst[i]))
+#define W8_KSTAMP0() do { W8_KSTAMP(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); } while (0)
 #else
 #define W8_TSEG(k) do { } while (0)
+#define W8_KSTAMP(i) do { } while (0)
+#define W8_KSTAMP0() do { } while (0)
 #endif
   // ---- prologue: K-tiles 0 and 1 into stages 0 and 1
   set_load_tile(0);
@@ -968,6 +976,7 @@ void gemm_nt_w8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
 #ifdef M3P_W8_TL
   W8_TSEG(4);
 #endif
+  W8_KSTAMP0();
   for (int step = 0; step < total; ++step) {
     const int cur = step & 1, nxt = cur ^ 1;
     const bool last_kt = (c_kt + 1 == nk);
@@ -979,6 +988,7 @@ void gemm_nt_w8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
     read_a_hi(a_addr[0] + so, fa1);
     __builtin_amdgcn_sched_barrier(0);
     mfma_q(H0{}, fa0, fw0, nxt, 3, pend ? 3 : 0);
+    W8_KSTAMP(1);
     W8_LGKM0();
     // quarter 1: k-step 0, rows 64-127 | fetch k-step 1: W and rows 0-63
     if (pend && !M3P_W8_INTERLEAVE) { issue_load(nxt, 6); issue_load(nxt, 7); }
@@ -987,16 +997,20 @@ void gemm_nt_w8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
     __builtin_amdgcn_sched_barrier(0);
     mfma_q(H1{}, fa1, fw0, nxt, 6, pend ? 2 : 0);
     if (pend) { load_done(); spread_pending = false; }
+    W8_KSTAMP(2);
     W8_LGKM0();
     // quarter 2: k-step 1, rows 0-63 | fetch k-step 1, rows 64-127 (the last LDS read of this K-tile)
     read_a_hi(a_addr[1] + so, fa1);
     __builtin_amdgcn_sched_barrier(0);
     mfma_q(H0{}, fa0, fw1);
+    W8_KSTAMP(3);
     // every LDS read of this K-tile is complete and K-tile +1, requested one K-tile ago, has landed for this wave
     W8_LGKM0();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    W8_KSTAMP(4);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    W8_KSTAMP(5);
     __builtin_amdgcn_sched_barrier(0);
     // quarter 3: k-step 1, rows 64-127 | request K-tile +2 into the vacated stage | fetch K-tile +1's first fragments
     // (on an output tile's last K-tile both wait for the epilogue, which stages through that stage and wants the registers)
@@ -1014,7 +1028,14 @@ void gemm_nt_w8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
     }
     __builtin_amdgcn_sched_barrier(0);
     mfma_q(H1{}, fa1, fw1, cur, 0, (req && M3P_W8_SPREAD) ? 3 : 0);
+    W8_KSTAMP(6);
     W8_LGKM0();
+#ifdef M3P_W8_TL
+#pragma unroll
+    for (int i = 0; i < 6; ++i) kq[i] += kst[i + 1] - kst[i];
+    kq[6] += 1;
+    kst[0] = kst[6];
+#endif
 
     if (++c_kt == nk) {
       // ---- epilogue of output tile c_q through the vacated stage `cur`
@@ -1103,15 +1124,21 @@ void gemm_nt_w8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
         W8_LGKM0();
       }
       W8_TSEG(3);
+      W8_KSTAMP0();
     }
   }
   if ((EPI == M3P_EPI_DGELU || EPI == M3P_EPI_MUL) && ep.colsum && csum_nw >= 0) flush_csum();
 #ifdef M3P_W8_TL
   tacc[6] = __builtin_amdgcn_s_memtime();
   if (lane == 0)
-    for (int k = 0; k < 8; ++k) g_ring_tl[(blockIdx.x * 8 + wid) * 8 + k] = tacc[k];
+    for (int k = 0; k < 8; ++k) {
+      g_ring_tl[(blockIdx.x * 8 + wid) * 8 + k] = tacc[k];
+      g_ring_tl[256 * 8 * 8 + (blockIdx.x * 8 + wid) * 8 + k] = kq[k];
+    }
 #endif
 #undef W8_TSEG
+#undef W8_KSTAMP
+#undef W8_KSTAMP0
 #undef W8_DSR
 #undef W8_LGKM0
 }

@@ -25,9 +25,10 @@ for nm, N, K, epi in (('FFN1 fwd (bias)', 3072, 768, L.EPI_BIAS), ('dU (dGELU)',
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); ops.gemm_nt(a, w, epi, out=out, **kw); e1.record(); torch.cuda.synchronize()
-    buf = np.zeros((256, 8, 8), dtype=np.uint64)
+    buf = np.zeros((2, 256, 8, 8), dtype=np.uint64)
     rc = f(buf.ctypes.data, buf.nbytes); assert rc == 0, rc
-    d = buf.astype(np.float64)
+    d = buf[0].astype(np.float64)
+    kq = buf[1].astype(np.float64)
     live = d[..., 6] > 0                      # workgroups beyond the tile count return before the first stamp
     span = (d[..., 6] - d[..., 5])[live]
     print('%s M=%d N=%d K=%d: %.1f us; %d waves, span mean %.0f ticks (min %.0f max %.0f)'
@@ -37,3 +38,15 @@ for nm, N, K, epi in (('FFN1 fwd (bias)', 3072, 768, L.EPI_BIAS), ('dU (dGELU)',
     for k, s in enumerate(names):
         print('  %-46s %9.0f (%.1f%% of the span; %.0f per tile)' % (s, d[..., k].mean(), 100 * d[..., k].mean() / span.mean(),
                                                                      d[..., k].mean() / (tiles / 256.0)))
+    # phases of a K-tile (sums over the wave's K-tiles / their count); each quarter = its memory issue + 16 MFMAs, measured up to
+    # the stamp in front of its closing lgkmcnt wait (which therefore counts into the next phase)
+    kq = kq[live]
+    n_kt = kq[..., 6]
+    ph = ['quarter 0', 'quarter 1', 'quarter 2', 'lgkm + vmcnt(0) wait', 's_barrier', 'quarter 3']
+    tot = sum(kq[..., i].sum() for i in range(6)) / n_kt.sum()
+    print('  K-tile phases, ticks per K-tile (mean over waves; %.0f in all):' % tot)
+    for i, nm_ in enumerate(ph):
+        per = kq[..., i] / n_kt
+        print('    %-22s %7.0f   (waves 0-3 %7.0f, waves 4-7 %7.0f; min %.0f max %.0f)'
+              % (nm_, per.mean(), per.reshape(-1, 8)[:, :4].mean() if per.ndim == 1 else per[..., :4].mean(),
+                 per.reshape(-1, 8)[:, 4:].mean() if per.ndim == 1 else per[..., 4:].mean(), per.min(), per.max()))
