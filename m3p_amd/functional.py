@@ -615,7 +615,7 @@ class ImageStreamFn(torch.autograd.Function):
     x_img (R, B, 2048), image_loc (R, B, 5) -> bf16 [B*R, d] (rows b*R + r) for EncoderFn's layers-only mode."""
 
     @staticmethod
-    def forward(ctx, anchor, model, x_img, lengths, image_loc, langs, p_drop, seed_step):
+    def forward(ctx, anchor, model, x_img, lengths, image_loc, langs, p_drop, seed_step, p_refine=None):
         ar = model.arena()
         ar.refresh()
         dev = ar.device
@@ -636,19 +636,25 @@ class ImageStreamFn(torch.autograd.Function):
         totlen = lengths.to(device=dev, dtype=torch.int32).contiguous()
         mask = (torch.arange(R, device=dev, dtype=torch.int32)[None, :] < totlen[:, None]).reshape(B * R, 1)
         h0 = ops.dropout_rows(rows, p_drop, seed('emb')) * mask.to(BF16)
+        ref_saved = None
+        if p_refine is not None:      # refine_image on this stream (transformer.py:1064-1066): the AoA refiner on the masked rows
+            h0, ref_saved = refiner_fwd(model, h0.contiguous(), totlen, B, R, seed_step, p_refine)
         ctx.model = model
-        ctx.saved = (ximg16, loc, img_saved, totlen, mask, langs)
-        ctx.meta = (B, R, d, p_drop, seed_step)
+        ctx.saved = (ximg16, loc, img_saved, totlen, mask, langs, ref_saved)
+        ctx.meta = (B, R, d, p_drop, seed_step, p_refine)
         return h0
 
     @staticmethod
     def backward(ctx, dh0):
         model = ctx.model
         ar = model.arena()
-        ximg16, loc, img_saved, totlen, mask, langs = ctx.saved
+        ximg16, loc, img_saved, totlen, mask, langs, ref_saved = ctx.saved
         ctx.saved = None
-        B, R, d, p_drop, seed_step = ctx.meta
+        B, R, d, p_drop, seed_step, p_refine = ctx.meta
         seed = lambda kind: rng.stream_seed(model.base_seed, seed_step, _site(kind))   # noqa: E731
+        if ref_saved is not None:
+            dh0 = refiner_bwd(model, dh0.to(BF16).contiguous(), ref_saved, totlen, B, R, seed_step, p_refine)
+            ar.touch(*[n for n in ar.names if n.startswith('refine_embeddings.')])
         g = (dh0.to(BF16) * mask.to(BF16)).contiguous()
         d_rows = ops.dropout_rows(g, p_drop, seed('emb'))
         if langs is not None:
@@ -667,7 +673,7 @@ class ImageStreamFn(torch.autograd.Function):
                                       seed_img=seed('img'), p_drop=p_drop)
         ops.gemm_wgrad(de, ximg16, ar.g('image_embeddings.image_embeddings.weight'))
         ar.touch(*[n for n in ar.names if n.startswith('image_embeddings.')])
-        return (None,) * 8
+        return (None,) * 9
 
 
 class DecoderFn(torch.autograd.Function):

@@ -417,15 +417,19 @@ class TransformerModel(nn.Module):
         if stream_ == 'img':
             # the image-only encoder pass of the captioning step (:1044-1052): x (R, B, 2048) region features
             assert not causal and src_enc is None and cache is None and positions is None
-            assert image_loc is not None and not kw.get('refine_image', False) and kw.get('image_dist') is None, \
-                'the image stream runs without the refiner and without the class-distribution embedding'
+            assert image_loc is not None and kw.get('image_dist') is None, \
+                'the image stream runs without the class-distribution embedding'
             R, B = x.size(0), x.size(1)
             if langs is not None:
                 assert self.n_langs > 1 and langs.size() == (R, B)
             p = self.dropout if self.training else 0.0
             pa = self.attention_dropout if self.training else 0.0
+            p_ref = None
+            if kw.get('refine_image', False):       # the AoA refiner on the stream's rows (:1064-1066)
+                assert self.n_refine_layers > 0, 'refine_image=True needs params.refine_layers > 0'
+                p_ref = self.refine_dropout if self.training else 0.0
             step = self._next_seed_step()
-            h0 = Fn.ImageStreamFn.apply(self.layer_norm_emb.weight, self, x, lengths, image_loc, langs, p, step)
+            h0 = Fn.ImageStreamFn.apply(self.layer_norm_emb.weight, self, x, lengths, image_loc, langs, p, step, p_ref)
             out = Fn.EncoderFn.apply(self.layer_norm_emb.weight, self, None, lengths, None, None, None, p, pa, step, None,
                                      torch.is_grad_enabled(), None, None, h0)
             return out.view(B, R, self.dim).transpose(0, 1)

@@ -389,3 +389,14 @@ def token_stream(seed=41, n_sent=23, V=1000):
     pos = np.stack([ends - np.array([len(s) for s in sents]), ends], axis=1).astype(np.int64)
     langs = rs.randint(0, 2, size=len(sent)).astype(np.int32)
     return sent, pos, langs
+
+
+def ic_refine_case():
+    """ic_case with a two-layer AoA refiner on the image stream (crossfwd(stream_='img', refine_image=True)): the captioning
+    runs of the reference keep the parser's default refine_image=True (train_x.py:285)."""
+    P, sd, x_img, loc, img_len, x2, len2 = ic_case()
+    P.refine_layers = 2
+    sd = OrderedDict(sd)
+    sd.update(golden_state_dict(refiner_param_shapes(P), seed=2468, pad_index=None))
+    w = torch.from_numpy(np.random.RandomState(781).standard_normal((x_img.shape[0], x_img.shape[1], P.emb_dim)).astype(np.float32))
+    return P, sd, x_img, loc, img_len, w

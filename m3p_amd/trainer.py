@@ -355,7 +355,7 @@ class Trainer(object):
         langs_img = x1_mask.transpose(0, 1).clone().long().fill_(lang_id)
         x1, len1, img_loc, x2, len2, y, langs, langs_img, pred_mask = to_cuda(x1, len1, img_loc, x2, len2, y, langs, langs_img, pred_mask)
         enc1 = model('crossfwd', stream_='img', x=x1, lengths=len1, langs=langs_img, causal=False, image_loc=img_loc,
-                     refine_image=False)
+                     refine_image=getattr(params, 'refine_image', False))
         enc1 = enc1.transpose(0, 1)
         dec2 = model('crossfwd', stream_='text', x=x2, lengths=len2, langs=langs, causal=True, src_enc=enc1, src_len=len1)
         _, loss = model('predict', tensor=dec2, pred_mask=pred_mask, y=y, get_scores=False)

@@ -763,6 +763,42 @@ def gen_data_goldens():
     print('host_data.npz: %d arrays' % len(g))
 
 
+def gen_ic_refine_goldens():
+    """ic_refine.npz: the image-only encoder pass WITH the AoA refiner (crossfwd(stream_='img', refine_image=True),
+    transformer.py:1044-1066) on the reference in eval mode (the refiner's own dropouts are hard-wired to 0.1 in train mode):
+    the encoding and the gradients of sum(enc * w) for every refiner parameter and parameters up- and downstream of it."""
+    from src.model.transformer import TransformerModel
+    from oracle import ref_cpu
+    P, sd, x_img, loc, img_len, w = synth.ic_refine_case()
+    torch.manual_seed(0)
+    m = TransformerModel(P, is_encoder=True, with_output=True, is_crossModal=True)
+    own = dict(m.named_parameters())
+    with torch.no_grad():
+        for k, v in sd.items():
+            assert tuple(own[k].shape) == tuple(v.shape), k
+            own[k].copy_(v)
+    m.eval()
+    R, B = x_img.shape[0], x_img.shape[1]
+    langs_img = torch.ones((R, B), dtype=torch.long)
+    enc = m('crossfwd', stream_='img', x=x_img, lengths=img_len, langs=langs_img, causal=False, cross_modal=True,
+            image_loc=loc, refine_image=True, refine_encoder=False, image_dist=None)
+    (enc * w).sum().backward()
+    g = {'enc': enc.detach().numpy()}
+    names = [k for k in own if k.startswith('refine_embeddings.')] + [
+        'cross_lang_embeddings.weight', 'image_embeddings.image_embeddings.weight', 'image_embeddings.image_location_embeddings.weight',
+        'image_embeddings.LayerNorm.weight', 'image_embeddings.LayerNorm.bias', 'attentions.0.q_lin.weight', 'layer_norm2.1.weight']
+    for k in names:
+        if k == 'image_embeddings.image_embeddings.weight':      # 1 MB: its first rows and its norm
+            g['grad_rows8.' + k], g['grad_norm.' + k] = own[k].grad[:8].numpy(), own[k].grad.norm().numpy()
+        else:
+            g['grad.' + k] = own[k].grad.numpy()
+    o = ref_cpu.crossfwd_img(sd, P.n_layers, P.n_heads, x_img, img_len, loc, langs=langs_img, n_refine_layers=2)
+    err = float((o - enc.detach()).abs().max())
+    print('ic_refine.npz: %d gradients; oracle max|d| %.2e' % (len(names), err))
+    assert err < 1e-4
+    np.savez_compressed(os.path.join(OUT, 'ic_refine.npz'), **g)
+
+
 def gen_noise_goldens():
     """host_noise.npz: Trainer.add_noise (word_shuffle + word_dropout, xtrainer.py:291-383) of the reference under fixed
     numpy seeds on synthetic sentences."""
@@ -855,12 +891,12 @@ def gen_decoder_goldens():
 
 if __name__ == '__main__':
     single = {'enum': gen_state_dict_enumeration, 'host': gen_host_goldens, 'mt': gen_mt_goldens, 'noise': gen_noise_goldens, 'ic': gen_ic_goldens, 'langs': gen_text_langs_goldens,
-              'decoder': gen_decoder_goldens, 'refiner': gen_refiner_goldens, 'mt_ic': gen_mt_ic_goldens, 'data': gen_data_goldens}
+              'decoder': gen_decoder_goldens, 'refiner': gen_refiner_goldens, 'mt_ic': gen_mt_ic_goldens, 'data': gen_data_goldens, 'ic_refine': gen_ic_refine_goldens}
     if len(sys.argv) > 1:
         single[sys.argv[1]]()
         sys.exit(0)
     for fn in (gen_state_dict_enumeration, gen_refiner_goldens, gen_clcm_goldens, gen_region_head_goldens,
                gen_text_and_itm_goldens, gen_unit_goldens, gen_model_goldens, gen_trainer_goldens, gen_host_goldens,
                gen_decoder_goldens, gen_text_langs_goldens, gen_mt_goldens, gen_ic_goldens, gen_noise_goldens,
-               gen_mt_ic_goldens, gen_data_goldens):
+               gen_mt_ic_goldens, gen_data_goldens, gen_ic_refine_goldens):
         fn()

@@ -273,7 +273,7 @@ def decoder_crossfwd(sd, n_layers, n_heads, x, lengths, src_enc=None, src_len=No
     return h.transpose(0, 1)
 
 
-def crossfwd_img(sd, n_layers, n_heads, x_img, lengths, image_loc, langs=None):
+def crossfwd_img(sd, n_layers, n_heads, x_img, lengths, image_loc, langs=None, n_refine_layers=0):
     """TransformerModel.crossfwd(stream_='img', causal=False) in eval mode, transformer.py:1044-1102: BertImageEmbeddings on the
     region features (+ the language embedding), * mask - no positions and no layer_norm_emb on this stream - then the
     post-LN layers.  x_img (R, B, 2048), image_loc (R, B, 5) -> (R, B, d)."""
@@ -283,6 +283,8 @@ def crossfwd_img(sd, n_layers, n_heads, x_img, lengths, image_loc, langs=None):
     if langs is not None:
         h = h + F.embedding(langs.t(), sd['cross_lang_embeddings.weight'])
     h = h * mask[..., None].to(h.dtype)
+    if n_refine_layers:            # refine_image=True on this stream (:1064-1066)
+        h = aoa_refiner(sd, h, attn_mask, n_refine_layers, n_heads)
     for i in range(n_layers):
         a = 'attentions.%d.' % i
         attn = multi_head_attention(
