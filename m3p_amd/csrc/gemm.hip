@@ -2514,9 +2514,14 @@ void gemm_wgrad_w4_kernel(const bf16* __restrict__ dY, int lddy, const bf16* __r
     y_addr[c] = lds0 + frow * ROWB + ((qy ^ fsw) << 4) + ((ft & 1) << 3);
     x_addr[c] = lds0 + Y_BYTES + frow * ROWB + ((qx ^ fsw) << 4) + ((ft & 1) << 3);
   }
-  // one fragment = two tr16 reads (rows +0 / +4); OFF selects the k-step (0 / 16384)
+  // one fragment = two tr16 reads (rows +0 / +4); OFF selects the k-step (0 / 16384).  The outputs are EARLY-CLOBBER: without
+  // the '&' the compiler may give the first read's destination the address register (it did, in 21 of the kernel's 80 pairs),
+  // and when the wave stalls between the two reads for longer than the LDS latency the first read's data IS the second
+  // read's address - one half-fragment of wrong (finite) data, about once in 300 launches when the operands were freshly
+  // allocated (slow first touches), never with warm ones (tools/wgrad_stress2.py; found by tests/test_gemm.py failing once
+  // in ~20 runs of the suite)
 #define WG_TR2(LO, HI, ADDR, OFF) asm volatile("ds_read_b64_tr_b16 %0, %2 offset:" #OFF "\n\tds_read_b64_tr_b16 %1, %2 offset:" #OFF "+2048" \
-                                               : "=v"(LO), "=v"(HI) : "v"(ADDR))
+                                               : "=&v"(LO), "=&v"(HI) : "v"(ADDR))
 #define WG_LGKM0() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 
   asm volatile("" ::: "a0", "a255");     // reserve all 256 AGPRs (see gemm_nt_w4_kernel)

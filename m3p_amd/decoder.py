@@ -71,13 +71,12 @@ def _self_cache(cache, i, bs, need, d, dev):
     return cur
 
 
-def decoder_forward(model, x, lengths, src_enc=None, src_len=None, positions=None, langs=None, cache=None, enc_mask=None):
+def decoder_forward(model, x, lengths, src_enc=None, src_len=None, positions=None, langs=None, cache=None):
     """crossfwd(stream_='text', causal=True): x (slen, bs) int64 -> (n_new, bs, d) bf16, n_new = slen - cache['slen'] (all of
     them without a cache).  src_enc (bs, S, d) / src_len (bs) switch the encoder-attention sub-layer on."""
     if torch.is_grad_enabled() and model.training:
         raise NotImplementedError('the causal decoder is built for inference (eval mode / torch.no_grad()): its '
                                   'teacher-forced training step is not part of this build (SURVEY 8 f4)')
-    assert enc_mask is None, 'enc_mask is not supported (the reference callers pass None)'
     assert (src_enc is None) == (src_len is None)
     slen, bs = x.size()
     assert lengths.size(0) == bs

@@ -686,7 +686,7 @@ class DecoderFn(torch.autograd.Function):
     gradients go to the arena."""
 
     @staticmethod
-    def forward(ctx, anchor, model, x, lengths, src_enc, src_len, langs, p_drop, p_attn, seed_step):
+    def forward(ctx, anchor, model, x, lengths, src_enc, src_len, langs, p_drop, p_attn, seed_step, positions=None):
         ar = model.arena()
         ar.refresh()
         dev = ar.device
@@ -697,9 +697,18 @@ class DecoderFn(torch.autograd.Function):
         dseed = lambda k, i=0: rng.stream_seed(model.base_seed, seed_step, _DEC_SITE0 + 8 * i + k)   # noqa: E731
         x = x.to(dev).contiguous()
         table, tok = ar.w('embeddings.weight'), x
-        if langs is not None:
-            langs = langs.to(dev).contiguous()
-            rows = table[x.t()].float() + ar.p('cross_lang_embeddings.weight')[langs.t()]
+        if langs is not None or positions is not None:
+            # rows assembled here instead of gathered by the kernel: + the language embedding; explicit positions (the MASS
+            # step decodes a span at its ORIGINAL positions, xtrainer.py:1684) as P[pos] - P[t], the kernel adds P[t] back
+            rows = table[x.t()].float()
+            if langs is not None:
+                langs = langs.to(dev).contiguous()
+                rows = rows + ar.p('cross_lang_embeddings.weight')[langs.t()]
+            if positions is not None:
+                positions = positions.to(dev).contiguous()
+                assert positions.size() == (T, B)
+                ptab = ar.p('position_embeddings.weight')
+                rows = rows + ptab[positions.t()] - ptab[:T][None, :, :]
             table = rows.to(BF16).reshape(B * T, d).contiguous()
             tok = ((torch.arange(B, device=dev, dtype=torch.int64) * T)[None, :] +
                    torch.arange(T, device=dev, dtype=torch.int64)[:, None]).contiguous()
@@ -749,7 +758,7 @@ class DecoderFn(torch.autograd.Function):
         ctx.model = model
         ctx.dims = (B, T, S, d, H, dh, nL)
         ctx.drop = (p_drop, p_attn, seed_step)
-        ctx.saved = (x, totlen, rowmask, emb_saved, saved, src16, src_klen, langs)
+        ctx.saved = (x, totlen, rowmask, emb_saved, saved, src16, src_klen, langs, positions)
         ctx.src_meta = (src_enc.dtype, src_enc.requires_grad) if has_src else None
         hook = model.ddp_hook
         ctx.track = hook is not None
@@ -763,7 +772,7 @@ class DecoderFn(torch.autograd.Function):
         ar = model.arena()
         B, T, S, d, H, dh, nL = ctx.dims
         p_drop, p_attn, seed_step = ctx.drop
-        x, totlen, rowmask, emb_saved, saved, src16, src_klen, langs = ctx.saved
+        x, totlen, rowmask, emb_saved, saved, src16, src_klen, langs, positions = ctx.saved
         ctx.saved = None
         dseed = lambda k, i=0: rng.stream_seed(model.base_seed, seed_step, _DEC_SITE0 + 8 * i + k)   # noqa: E731
         hook = model.ddp_hook if ctx.track else None
@@ -830,7 +839,8 @@ class DecoderFn(torch.autograd.Function):
             if hook is not None:
                 hook.layer_done(i, last)
         tok_rows = None
-        if langs is not None or (hook is not None and hook.active):
+        own_rows = langs is not None or positions is not None
+        if own_rows or (hook is not None and hook.active):
             tok_rows = torch.empty((T * B, d), dtype=BF16, device=dh_.device)
         grads = dict(
             d_g_emb=ar.g('layer_norm_emb.weight'), d_be_emb=ar.g('layer_norm_emb.bias'),
@@ -843,14 +853,20 @@ class DecoderFn(torch.autograd.Function):
                                totlen, None, grads, B, T, 0, d, model.pad_index, seed_img=0, seed_emb=dseed(7), p_drop=p_drop,
                                tok_rows=tok_rows)
         ar.touch('layer_norm_emb.weight', 'layer_norm_emb.bias', 'position_embeddings.weight', 'embeddings.weight')
-        if langs is not None:
-            npad = (model.n_langs + 7) // 8 * 8
-            onehot = torch.zeros((T * B, npad), dtype=BF16, device=tok_rows.device)
-            onehot.scatter_(1, langs.view(-1, 1), 1.0)
-            dl = torch.zeros((npad, d), dtype=torch.float32, device=tok_rows.device)
-            ops.gemm_wgrad(onehot, tok_rows, dl)
-            ar.g('cross_lang_embeddings.weight').add_(dl[:model.n_langs])
-            ar.touch('cross_lang_embeddings.weight')
+        if own_rows:
+            if langs is not None:
+                npad = (model.n_langs + 7) // 8 * 8
+                onehot = torch.zeros((T * B, npad), dtype=BF16, device=tok_rows.device)
+                onehot.scatter_(1, langs.view(-1, 1), 1.0)
+                dl = torch.zeros((npad, d), dtype=torch.float32, device=tok_rows.device)
+                ops.gemm_wgrad(onehot, tok_rows, dl)
+                ar.g('cross_lang_embeddings.weight').add_(dl[:model.n_langs])
+                ar.touch('cross_lang_embeddings.weight')
+            if positions is not None:       # rows held P[pos] - P[t] (rows t * B + b): the kernel's own dP[t] is taken back
+                gpos = ar.g('position_embeddings.weight')
+                rows32 = tok_rows.float()
+                gpos.index_add_(0, positions.reshape(-1), rows32)
+                gpos[:T].sub_(rows32.view(T, B, d).sum(dim=1))
             if hook is None or not hook.active:
                 ops.scatter_add_token_rows(tok_rows, x.contiguous().view(-1), ar.g('embeddings.weight'), model.pad_index)
                 tok_rows = None
@@ -859,7 +875,7 @@ class DecoderFn(torch.autograd.Function):
         g_src = None
         if has_src and ctx.src_meta[1]:
             g_src = d_src.view(B, S, d).to(ctx.src_meta[0])
-        return (None, None, None, None, g_src, None, None, None, None, None)
+        return (None, None, None, None, g_src, None, None, None, None, None, None)
 
 
 class MLMHeadFn(torch.autograd.Function):

@@ -126,3 +126,118 @@ def add_noise(x, lengths, params):
     """xtrainer.py:376-383: shuffle, then dropout (the blanking pass is disabled in the reference)."""
     x, lengths = word_shuffle(x, lengths, getattr(params, 'word_shuffle', 0))
     return word_dropout(x, lengths, getattr(params, 'word_dropout', 0), params.pad_index)
+
+
+# ---- span masking of the sequence-to-sequence denoising steps (xtrainer.py:1207-1381) ---------------------------------------
+# A sentence of n symbols keeps its first one; `mask_len` of the others are chosen as whole spans of at most `min_len`
+# words.  RNG order per sentence, as in the reference: one np.random.random() for the span placement rule, one
+# random.shuffle (Python's generator) of the span / gap list, and - MASS only - np.random.randint + torch.multinomial for
+# the 80 / 10 / 10 replacement of the chosen words.
+
+def span_lengths(mask_len, min_len):
+    """``get_segments`` (:1260-1267): mask_len split into spans of min_len, the remainder last."""
+    spans = [min_len] * (mask_len // min_len)
+    if mask_len % min_len:
+        spans.append(mask_len % min_len)
+    return spans
+
+
+def place_spans(spans, gaps):
+    """``shuffle_segments`` (:1237-1258): the spans and the single-word gaps (zeros) in random order; with probability
+    0.2 the first span is pinned to the sentence start, with 0.2 the last span to its end."""
+    import random
+    p = np.random.random()
+    if p >= 0.8:
+        body = spans[1:] + gaps
+    elif p >= 0.6:
+        body = spans[:-1] + gaps
+    else:
+        body = spans + gaps
+    random.shuffle(body)
+    if p >= 0.8:
+        return spans[0:1] + body
+    if p >= 0.6:
+        return body + spans[-1:]
+    return body
+
+
+def span_positions(layout):
+    """``unfold_segments`` (:1217-1235): positions (from 1: the first symbol is never masked) covered by the spans of a
+    layout in which an entry l >= 1 is a span of l words and 0 a single unmasked word."""
+    pos, cur = [], 1
+    for l in layout:
+        if l >= 1:
+            pos.extend(range(cur, cur + l))
+            cur += l
+        else:
+            cur += 1
+    return np.array(pos)
+
+
+def mask_word(w, params):
+    """``mask_word`` (:1207-1215): each chosen word becomes <mask> / stays / becomes a random word with params.pred_probs."""
+    rand = np.random.randint(params.n_words, size=w.shape)
+    probs = torch.multinomial(params.pred_probs, len(w), replacement=True)
+    return np.full(w.shape, params.mask_index) * (probs == 0).numpy() + w * (probs == 1).numpy() + rand * (probs == 2).numpy()
+
+
+def _columns(rows, length, n, pad):
+    out = torch.LongTensor(length, n).fill_(pad)
+    for i, r in enumerate(rows):
+        out[:len(r), i].copy_(torch.LongTensor(r))
+    return out
+
+
+def restricted_mask_sent(x, lengths, params, min_len=100000):
+    """MASS batch (:1269-1316): round(shortest sentence * params.word_mass) words of every sentence are masked in the
+    encoder input x1 (80 / 10 / 10 rule); the decoder reads the word BEFORE each masked one (x2), at its original position
+    (pos), and predicts the masked word (y).  -> (x1, len1, x2, len2, y, pred_mask, pos)."""
+    min_len = max(min_len, 1)
+    n = lengths.size(0)
+    mask_len = round(lengths[np.argsort(lengths)[0].item()].item() * params.word_mass)
+    gaps = [0] * (lengths.min().item() - mask_len - 1)
+    spans = span_lengths(mask_len, min_len)
+    inputs, targets, outputs, positions = [], [], [], []
+    for i in range(n):
+        words = np.array(x[:lengths[i], i].tolist())
+        pos = span_positions(place_spans(spans, gaps))
+        outputs.append(words[pos].copy())
+        targets.append(words[pos - 1].copy())
+        words[pos] = mask_word(words[pos], params)
+        inputs.append(words)
+        positions.append(pos - 1)
+    pad = params.pad_index
+    x1 = _columns(inputs, int(max(lengths)), n, pad)
+    x2, y, pos = (_columns(v, mask_len, n, pad) for v in (targets, outputs, positions))
+    pred_mask = y != pad
+    return x1, lengths.clone(), x2, torch.LongTensor([mask_len] * n), y.masked_select(pred_mask), pred_mask, pos
+
+
+def bart_token_mask_sent(x, lengths, params, min_len=100000):
+    """BART-style text infilling batch (:1318-1381): ONE span of  Poisson(3) mod round(0.3 * slen)  words (at least one) per
+    sentence collapses into a single <mask> in the encoder input x1; the decoder is teacher-forced on the whole original
+    sentence (x2 = all but the last symbol, y = all but the first).  -> (x1, len1, x2, len2, y, pred_mask, pos)."""
+    min_len = max(min_len, 1)
+    n = lengths.size(0)
+    mask_len = np.random.poisson(lam=3) % round(len(x[:, 0]) * 0.3)
+    if mask_len == 0:
+        mask_len = 1
+    len1 = [lengths[i] - mask_len + 1 for i in range(n)]
+    len2 = [lengths[i] - 1 for i in range(n)]
+    gaps = [0] * (lengths.min().item() - mask_len - 1)
+    spans = span_lengths(mask_len, min_len)
+    inputs, targets, outputs, positions = [], [], [], []
+    for i in range(n):
+        words = np.array(x[:lengths[i], i].tolist())
+        pos = span_positions(place_spans(spans, gaps))
+        kept = np.concatenate([words[:pos[0]], words[pos[-1]:]])       # the span's last word stays, its first slot ...
+        kept[pos[0]] = params.mask_index                               # ... becomes the <mask>
+        inputs.append(kept)
+        targets.append(words[:-1].copy())
+        outputs.append(words[1:].copy())
+        positions.append(np.arange(len(words) - 1))
+    pad = params.pad_index
+    x1 = _columns(inputs, int(max(len1)), n, pad)
+    x2, y, pos = (_columns(v, int(max(len2)), n, pad) for v in (targets, outputs, positions))
+    pred_mask = y != pad
+    return x1, torch.LongTensor(len1), x2, torch.LongTensor(len2), y.masked_select(pred_mask), pred_mask, pos

@@ -411,6 +411,20 @@ class TransformerModel(nn.Module):
                                  self._next_seed_step(), p_ref, torch.is_grad_enabled(), text_embed)
         return out.view(B, R + T, self.dim).transpose(0, 1)
 
+    @staticmethod
+    def _drop_masked_source(src_enc, src_len, enc_mask):
+        """``enc_mask`` of crossfwd (transformer.py:1016-1017: ``src_mask &= enc_mask``, the MASS step's hidden source words):
+        attention over a key set does not depend on the keys' order, so instead of a second mask in the kernels the allowed
+        source rows of every sentence move to the front (a differentiable gather) and ``src_len`` becomes their count."""
+        B, S = src_enc.size(0), src_enc.size(1)
+        dev = src_enc.device
+        ok = enc_mask.to(dev)[:, :S].bool() & (torch.arange(S, device=dev)[None, :] < src_len.to(dev)[:, None])
+        order = torch.sort((~ok).to(torch.int8), dim=1, stable=True).indices          # allowed rows first, in their order
+        n = ok.sum(dim=1)
+        packed = torch.gather(src_enc, 1, order[:, :, None].expand(-1, -1, src_enc.size(2)))
+        packed = packed * (torch.arange(S, device=dev)[None, :] < n[:, None])[:, :, None].to(packed.dtype)
+        return packed, n
+
     def crossfwd(self, x, lengths, causal, stream_='text', src_enc=None, src_len=None, positions=None, langs=None,
                  cache=None, enc_mask=None, image_loc=None, **kw):
         """Text-only stream of transformer.py:970-1114 (the mlm_step caller, xtrainer.py:757)."""
@@ -435,16 +449,18 @@ class TransformerModel(nn.Module):
             return out.view(B, R, self.dim).transpose(0, 1)
         assert stream_ == 'text'
         if causal:       # the decoder: causal self-attention (+ attention over src_enc), key / value cache (:1011-1091)
+            if enc_mask is not None:
+                src_enc, src_len = self._drop_masked_source(src_enc, src_len, enc_mask)
             if torch.is_grad_enabled() and self.training:
                 # teacher-forced training pass (mt_step / ae_step, xtrainer.py:1383-1441): the whole target at once
-                assert cache is None and positions is None and enc_mask is None
+                assert cache is None
                 T, B = x.size()
                 out = Fn.DecoderFn.apply(self.layer_norm_emb.weight, self, x, lengths, src_enc, src_len, langs, self.dropout,
-                                         self.attention_dropout, self._next_seed_step())
+                                         self.attention_dropout, self._next_seed_step(), positions)
                 return out.view(B, T, self.dim).transpose(0, 1)
             from .. import decoder
             return decoder.decoder_forward(self, x, lengths, src_enc=src_enc, src_len=src_len, positions=positions,
-                                           langs=langs, cache=cache, enc_mask=enc_mask)
+                                           langs=langs, cache=cache)
         assert src_enc is None and cache is None and positions is None, \
             'the non-causal text stream takes no source encoding, cache or explicit positions (the mlm_step caller)'
         T, B = x.size()

@@ -314,6 +314,82 @@ class Trainer(object):
         self.stats['processed_w'] += n_words
         return loss.detach()
 
+    def bart_token_mask_sent(self, x, lengths, min_len=100000):
+        """xtrainer.py:1318-1381."""
+        return masking.bart_token_mask_sent(x, lengths, self.params, min_len)
+
+    def restricted_mask_sent(self, x, lengths, min_len=100000):
+        """xtrainer.py:1269-1316 (the MASS batch)."""
+        return masking.restricted_mask_sent(x, lengths, self.params, min_len)
+
+    def bart_mlm_step(self, lang1, lang2, lambda_coeff):
+        """Text-infilling denoising step (xtrainer.py:1595-1646): one span of every sentence of a monolingual stream batch
+        collapses into a <mask> (``bart_token_mask_sent``, optionally followed by ``add_noise``), the model encodes that and
+        decodes the whole original sentence with teacher forcing.  Both sides carry lang1's id (:1608-1609)."""
+        assert lambda_coeff >= 0
+        if lambda_coeff == 0:
+            return
+        params = self.params
+        model = self.model
+        model.train()
+        self._dp_plan(True, expect=('mlm',))
+        x, lengths, positions, langs, _ = self.generate_batch(lang1, lang2, 'pred')
+        x, lengths, positions, langs, _ = self.round_batch(x, lengths, positions, langs)
+        x1, len1, x2, len2, y, pred_mask, _pos = self.bart_token_mask_sent(x, lengths)
+        if getattr(params, 'use_noise', False):
+            x1, len1 = self.add_noise(x1, len1)
+        langs1 = x1.clone().fill_(params.lang2id[lang1])
+        langs2 = x2.clone().fill_(params.lang2id[lang1])
+        n_words = int(pred_mask.sum())
+        x1, x2, len1, len2, y, pred_mask, langs1, langs2 = to_cuda(x1, x2, len1, len2, y, pred_mask, langs1, langs2)
+        enc1 = model('crossfwd', stream_='text', x=x1, lengths=len1, langs=langs1, causal=False).transpose(0, 1)
+        dec2 = model('crossfwd', stream_='text', x=x2, lengths=len2, langs=langs2, causal=True, src_enc=enc1, src_len=len1)
+        _, loss = model('predict', tensor=dec2, pred_mask=pred_mask, y=y, get_scores=False)
+        self._stat(('M-BART-%s' % lang1) if lang2 is None else ('MLM-%s-%s' % (lang1, lang2)), loss)
+        self.optimize(lambda_coeff * loss)
+        self.n_sentences += params.batch_size
+        self.stats['processed_s'] += lengths.size(0)
+        self.stats['processed_w'] += n_words
+        return loss.detach()
+
+    def bart_mass_step(self, lang1, lang2, lambda_coeff):
+        """MASS step (xtrainer.py:1648-1697): a span of every sentence is hidden in the encoder input (80 / 10 / 10 rule,
+        ``restricted_mask_sent``); the decoder reads the words before the hidden ones AT THEIR ORIGINAL POSITIONS, may not
+        look at the source's <mask> positions (``enc_mask``) and predicts the hidden words."""
+        assert lambda_coeff >= 0
+        if lambda_coeff == 0:
+            return
+        params = self.params
+        model = self.model
+        model.train()
+        self._dp_plan(True, expect=('mlm',))
+        x, lengths, positions, langs, _ = self.generate_batch(lang1, lang2, 'pred')
+        x, lengths, positions, langs, _ = self.round_batch(x, lengths, positions, langs)
+        x1, len1, x2, len2, y, pred_mask, positions = self.restricted_mask_sent(x, lengths)
+        return self.mass_step_on_batch(x1, len1, x2, len2, y, pred_mask, positions, lang1, lang2, lambda_coeff, n_sent=lengths.size(0))
+
+    def mass_step_on_batch(self, x1, len1, x2, len2, y, pred_mask, positions, lang1, lang2=None, lambda_coeff=1, n_sent=None):
+        """Loss path of bart_mass_step (:1668-1697) on a batch of ``restricted_mask_sent``."""
+        params = self.params
+        model = self.model
+        model.train()
+        langs1 = x1.clone().fill_(params.lang2id[lang1])
+        langs2 = x2.clone().fill_(params.lang2id[lang1])
+        n_words = int(pred_mask.sum())
+        enc_mask = x1.ne(params.mask_index).transpose(0, 1)
+        x1, x2, len1, len2, y, pred_mask, positions, langs1, langs2, enc_mask = to_cuda(
+            x1, x2, len1, len2, y, pred_mask, positions, langs1, langs2, enc_mask)
+        enc1 = model('crossfwd', stream_='text', x=x1, lengths=len1, langs=langs1, causal=False).transpose(0, 1)
+        dec2 = model('crossfwd', stream_='text', x=x2, lengths=len2, langs=langs2, causal=True, src_enc=enc1, src_len=len1,
+                     positions=positions, enc_mask=enc_mask)
+        _, loss = model('predict', tensor=dec2, pred_mask=pred_mask, y=y, get_scores=False)
+        self._stat(('M-MASS-%s' % lang1) if lang2 is None else ('M-MASS-%s-%s' % (lang1, lang2)), loss)
+        self.optimize(lambda_coeff * loss)
+        self.n_sentences += params.batch_size
+        self.stats['processed_s'] += len1.size(0) if n_sent is None else n_sent
+        self.stats['processed_w'] += n_words
+        return loss.detach()
+
     def ntg_step(self, lang1='en', lang2=None, lambda_coeff=1):
         """Text-to-text generation step (xtrainer.py:2596-2645; train_x.py:443-445 over ``text_steps``): a
         (source, target) batch of one language from ``ntg_collate`` - the translation step's loss path with the same language

@@ -799,6 +799,49 @@ def gen_ic_refine_goldens():
     np.savez_compressed(os.path.join(OUT, 'ic_refine.npz'), **g)
 
 
+def gen_mass_goldens():
+    """mass_step.npz: the MASS step's model calls (xtrainer.py:1648-1697) on the reference (dropout 0): encoder over the sentence
+    with its span hidden, decoder on the span at its ORIGINAL positions with enc_mask = source words that are not <mask>,
+    loss, gradients.  The batch comes from masking.restricted_mask_sent (bit-identical to the reference's builder:
+    host_spans.npz) and is stored with the golden."""
+    import random
+    from src.model.transformer import TransformerModel
+    from oracle import ref_cpu
+    from m3p_amd import masking
+    P, sd, x, lengths, _, _ = synth.mt_case()
+    P.word_mass, P.pred_probs = 0.5, torch.FloatTensor([0.8, 0.1, 0.1])
+    np.random.seed(61); random.seed(61); torch.manual_seed(61)
+    x1, len1, x2, len2, y, pred_mask, pos = masking.restricted_mask_sent(x, lengths, P, min_len=3)
+    torch.manual_seed(0)
+    m = TransformerModel(P, is_encoder=True, with_output=True, is_crossModal=True)
+    own = dict(m.named_parameters())
+    with torch.no_grad():
+        for k, v in sd.items():
+            own[k].copy_(v)
+    m.train()
+    langs1, langs2 = x1.clone().fill_(1), x2.clone().fill_(1)
+    enc1 = m('crossfwd', stream_='text', x=x1, lengths=len1, langs=langs1, causal=False).transpose(0, 1)
+    enc_mask = x1.ne(P.mask_index).transpose(0, 1)
+    dec2 = m('crossfwd', stream_='text', x=x2, lengths=len2, langs=langs2, causal=True, src_enc=enc1, src_len=len1,
+             positions=pos, enc_mask=enc_mask.bool())
+    _, loss = m('predict', tensor=dec2, pred_mask=pred_mask, y=y, get_scores=False)
+    loss.backward()
+    g = {'x1': x1.numpy(), 'len1': len1.numpy(), 'x2': x2.numpy(), 'len2': len2.numpy(), 'y': y.numpy(), 'pred_mask': pred_mask.numpy(),
+         'pos': pos.numpy(), 'enc1': enc1.detach().numpy(), 'dec2': dec2.detach().numpy(), 'loss': loss.detach().numpy()}
+    names = ['cross_lang_embeddings.weight', 'position_embeddings.weight', 'layer_norm_emb.weight', 'attentions.0.q_lin.weight',
+             'attentions.1.v_lin.weight', 'encoder_attn.0.k_lin.weight', 'encoder_attn.0.v_lin.weight', 'encoder_attn.1.q_lin.weight',
+             'encoder_attn.1.out_lin.weight', 'layer_norm15.0.weight', 'ffns.1.lin1.weight', 'layer_norm2.1.bias', 'pred_layer.proj.bias']
+    for k in names:
+        g['grad.' + k] = own[k].grad.numpy()
+    g['grad_norm.embeddings.weight'] = own['embeddings.weight'].grad.norm().numpy()
+    o_enc = ref_cpu.crossfwd_text(sd, P.n_layers, P.n_heads, x1, len1, langs=langs1).transpose(0, 1)
+    o_dec = ref_cpu.decoder_crossfwd(sd, P.n_layers, P.n_heads, x2, len2, o_enc, len1, positions=pos, langs=langs2, enc_mask=enc_mask)
+    err = float((o_dec - dec2.detach()).abs().max())
+    print('mass_step.npz: loss %.6f, %d masked source words; oracle dec max|d| %.2e' % (float(loss), int((~enc_mask).sum()), err))
+    assert err < 1e-4 and int((x1 == P.mask_index).sum()) > 0
+    np.savez_compressed(os.path.join(OUT, 'mass_step.npz'), **g)
+
+
 def gen_noise_goldens():
     """host_noise.npz: Trainer.add_noise (word_shuffle + word_dropout, xtrainer.py:291-383) of the reference under fixed
     numpy seeds on synthetic sentences."""
@@ -821,6 +864,35 @@ def gen_noise_goldens():
             out['%d.%s.x' % (case, name)], out['%d.%s.len' % (case, name)] = x2.numpy(), l2.numpy()
     np.savez_compressed(os.path.join(OUT, 'host_noise.npz'), **out)
     print('host_noise.npz', len(out), 'arrays')
+
+
+def gen_span_mask_goldens():
+    """host_spans.npz: the reference's span-masking batch builders of the denoising steps (restricted_mask_sent = MASS,
+    bart_token_mask_sent = text infilling; xtrainer.py:1207-1381) under fixed numpy / random / torch seeds."""
+    import random
+    xt, tr, m, P, hot = _reference_trainer(synth.CONFIGS['cfg1'], word_mass=0.5)
+    P.pred_probs = torch.FloatTensor([P.word_mask, P.word_keep, P.word_rand])
+    rs = np.random.RandomState(37)
+    out = {}
+    for case, (T, B, min_len) in enumerate(((14, 6, 100000), (25, 9, 3), (9, 4, 1), (40, 5, 100000))):
+        lengths = torch.from_numpy(rs.randint(max(T // 2, 5), T + 1, size=B)).long()
+        lengths[0] = T
+        x = torch.from_numpy(rs.randint(3, 990, size=(T, B))).long()
+        x[0] = synth.EOS
+        for b in range(B):
+            x[int(lengths[b]) - 1, b] = synth.EOS
+            x[int(lengths[b]):, b] = synth.PAD
+        out['%d.x' % case], out['%d.len' % case], out['%d.min_len' % case] = x.numpy(), lengths.numpy(), np.asarray(min_len)
+        for name, fn in (('mass', tr.restricted_mask_sent), ('bart', tr.bart_token_mask_sent)):
+            for rep in range(3):
+                seed = 500 + 10 * case + rep
+                np.random.seed(seed); random.seed(seed); torch.manual_seed(seed)
+                # (text infilling is only defined for ONE span: with several, the reference's own length bookkeeping breaks)
+                res = fn(x.clone(), lengths.clone(), min_len if name == 'mass' else 100000)
+                for tag, v in zip(('x1', 'len1', 'x2', 'len2', 'y', 'pred_mask', 'pos'), res):
+                    out['%d.%s.%d.%s' % (case, name, rep, tag)] = v.numpy()
+    np.savez_compressed(os.path.join(OUT, 'host_spans.npz'), **out)
+    print('host_spans.npz', len(out), 'arrays')
 
 
 def gen_decoder_goldens():
@@ -891,12 +963,13 @@ def gen_decoder_goldens():
 
 if __name__ == '__main__':
     single = {'enum': gen_state_dict_enumeration, 'host': gen_host_goldens, 'mt': gen_mt_goldens, 'noise': gen_noise_goldens, 'ic': gen_ic_goldens, 'langs': gen_text_langs_goldens,
-              'decoder': gen_decoder_goldens, 'refiner': gen_refiner_goldens, 'mt_ic': gen_mt_ic_goldens, 'data': gen_data_goldens, 'ic_refine': gen_ic_refine_goldens}
+              'decoder': gen_decoder_goldens, 'refiner': gen_refiner_goldens, 'mt_ic': gen_mt_ic_goldens, 'data': gen_data_goldens, 'ic_refine': gen_ic_refine_goldens, 'spans': gen_span_mask_goldens, 'mass': gen_mass_goldens}
     if len(sys.argv) > 1:
         single[sys.argv[1]]()
         sys.exit(0)
     for fn in (gen_state_dict_enumeration, gen_refiner_goldens, gen_clcm_goldens, gen_region_head_goldens,
                gen_text_and_itm_goldens, gen_unit_goldens, gen_model_goldens, gen_trainer_goldens, gen_host_goldens,
                gen_decoder_goldens, gen_text_langs_goldens, gen_mt_goldens, gen_ic_goldens, gen_noise_goldens,
-               gen_mt_ic_goldens, gen_data_goldens, gen_ic_refine_goldens):
+               gen_mt_ic_goldens, gen_data_goldens, gen_ic_refine_goldens,
+               gen_span_mask_goldens, gen_mass_goldens):
         fn()

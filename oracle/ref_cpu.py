@@ -243,7 +243,7 @@ def attention_kv(x, kv, mask, sd, prefix, n_heads):
     return F.linear(ctx, sd[prefix + 'out_lin.weight'], sd[prefix + 'out_lin.bias'])
 
 
-def decoder_crossfwd(sd, n_layers, n_heads, x, lengths, src_enc=None, src_len=None, positions=None, langs=None):
+def decoder_crossfwd(sd, n_layers, n_heads, x, lengths, src_enc=None, src_len=None, positions=None, langs=None, enc_mask=None):
     """TransformerModel.crossfwd(stream_='text', causal=True, src_enc, src_len) in eval mode, transformer.py:1005-1102:
     mask[b, s] = s < lengths[b]; the causal attention mask is position-only (:70-71: key <= query, padded keys inside
     the window ARE attended); Emb[x] + Pos (+ Lang) -> LN_emb -> * mask; per layer self-attention -> LN1 ->
@@ -260,6 +260,8 @@ def decoder_crossfwd(sd, n_layers, n_heads, x, lengths, src_enc=None, src_len=No
     h = h * mask[..., None].to(h.dtype)
     if src_enc is not None:
         src_mask = torch.arange(int(src_len.max()))[None, :] < src_len[:, None]
+        if enc_mask is not None:          # :1016-1017: source positions the decoder must not look at (the MASS step's <mask>s)
+            src_mask = src_mask & enc_mask
     for i in range(n_layers):
         h = layer_norm(h + attention_kv(h, h, attn_mask, sd, 'attentions.%d.' % i, n_heads),
                        sd['layer_norm1.%d.weight' % i], sd['layer_norm1.%d.bias' % i])

@@ -645,3 +645,109 @@ def test_image_stream_with_refiner_vs_reference():
     enc0 = m('crossfwd', stream_='img', x=x_img.cuda(), lengths=img_len.cuda(), langs=torch.ones((R, B), dtype=torch.long).cuda(),
              causal=False, image_loc=loc.cuda(), refine_image=False)
     assert rel_l2(enc0.float(), g['enc']) > 5e-2
+
+
+@pytest.mark.gpu
+def test_bart_mlm_step_vs_oracle():
+    """Text infilling (xtrainer.py:1595-1646): the stream batch -> bart_token_mask_sent (bit-exact with the reference:
+    tests/test_host_data.py) -> encoder over the <mask>ed sentence -> the whole sentence decoded with teacher forcing.  Loss and
+    gradients against the oracle's autograd on the batch the step built (re-built here from the same seeds)."""
+    import random
+    from m3p_amd import masking
+    from m3p_amd.model.transformer import TransformerModel
+    from m3p_amd.trainer import XTrainer
+    P, sd, x1_, len1_, _, _ = synth.mt_case()
+    _step_params(P, use_noise=False, word_pred=0.15, sample_alpha=0, word_mask=0.8, word_keep=0.1, word_rand=0.1)
+    x, lengths = x1_, len1_                    # (14, 6) sentences framed by EOS, as a stream / sentence batch holds them
+
+    class Stream:
+        def get_iterator(self, shuffle=True):
+            return iter([(x, lengths)])
+
+    torch.manual_seed(0)
+    m = TransformerModel(P, is_encoder=True, with_output=True, is_crossModal=True).cuda()
+    m.load_state_dict(sd, strict=False)
+    tr = XTrainer(m, {'mono_stream': {'zh': {'train': Stream()}}}, P)
+    names = ['cross_lang_embeddings.weight', 'attentions.1.v_lin.weight', 'encoder_attn.0.q_lin.weight', 'encoder_attn.1.out_lin.weight',
+             'ffns.0.lin2.weight', 'layer_norm15.1.bias', 'layer_norm_emb.weight', 'pred_layer.proj.bias']
+    grads = _grads_at_step(m, tr.optimizers['model'], names)
+    np.random.seed(91); random.seed(91); torch.manual_seed(91)
+    loss = tr.bart_mlm_step('zh', None, 1.0)
+    np.random.seed(91); random.seed(91); torch.manual_seed(91)
+    x1, len1, x2, len2, y, pred_mask, _ = masking.bart_token_mask_sent(x, lengths, P)
+    assert int((x1 == P.mask_index).sum()) == x.size(1)
+    ref = {k: v.clone().requires_grad_(k in names) for k, v in sd.items()}
+    enc = ref_cpu.crossfwd_text(ref, P.n_layers, P.n_heads, x1, len1, langs=x1.clone().fill_(1)).transpose(0, 1)
+    dec = ref_cpu.decoder_crossfwd(ref, P.n_layers, P.n_heads, x2, len2, enc, len1, langs=x2.clone().fill_(1))
+    o = ref_cpu.predict_mlm(ref, dec, pred_mask, y)
+    o = o[1] if isinstance(o, tuple) else o
+    o.backward()
+    assert abs(float(loss) - float(o.detach())) < 5e-3
+    bad = [(k, rel_l2(grads[k], ref[k].grad.numpy())) for k in names]
+    assert not [b for b in bad if b[1] > 4e-2], bad
+    assert 'M-BART-zh' in tr.stats and tr.stats['processed_w'] == int(pred_mask.sum()) == int((lengths - 1).sum())
+
+
+def test_oracle_mass_step_matches_the_reference():
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'mass_step.npz'))
+    P, sd, _, _, _, _ = synth.mt_case()
+    t = lambda k: torch.from_numpy(g[k])      # noqa: E731
+    x1, len1, x2, len2, y, pred_mask, pos = (t(k) for k in ('x1', 'len1', 'x2', 'len2', 'y', 'pred_mask', 'pos'))
+    enc = ref_cpu.crossfwd_text(sd, P.n_layers, P.n_heads, x1, len1, langs=x1.clone().fill_(1)).transpose(0, 1)
+    dec = ref_cpu.decoder_crossfwd(sd, P.n_layers, P.n_heads, x2, len2, enc, len1, positions=pos, langs=x2.clone().fill_(1),
+                                   enc_mask=x1.ne(P.mask_index).t())
+    assert np.abs(enc.numpy() - g['enc1']).max() < 2e-5 and np.abs(dec.numpy() - g['dec2']).max() < 2e-5
+    loss = ref_cpu.predict_mlm(sd, dec, pred_mask, y)
+    loss = loss[1] if isinstance(loss, tuple) else loss
+    assert abs(float(loss) - float(g['loss'])) < 1e-5
+    # the two inputs this step adds do matter: without them the decoder output is a different one
+    plain = ref_cpu.decoder_crossfwd(sd, P.n_layers, P.n_heads, x2, len2, enc, len1, langs=x2.clone().fill_(1))
+    nomask = ref_cpu.decoder_crossfwd(sd, P.n_layers, P.n_heads, x2, len2, enc, len1, positions=pos, langs=x2.clone().fill_(1))
+    assert np.abs(plain.numpy() - g['dec2']).max() > 1e-2 and np.abs(nomask.numpy() - g['dec2']).max() > 1e-4
+
+
+def test_drop_masked_source_packs_the_allowed_rows():
+    from m3p_amd.model.transformer import TransformerModel
+    src = torch.arange(2 * 5 * 3, dtype=torch.float32).view(2, 5, 3).requires_grad_(True)
+    enc_mask = torch.tensor([[1, 0, 1, 1, 0], [0, 1, 1, 1, 1]], dtype=torch.bool)
+    packed, n = TransformerModel._drop_masked_source(src, torch.tensor([4, 5]), enc_mask)
+    assert n.tolist() == [3, 4]
+    assert torch.equal(packed[0, :3], src[0, [0, 2, 3]].detach()) and float(packed[0, 3:].abs().sum()) == 0
+    assert torch.equal(packed[1, :4], src[1, 1:].detach()) and float(packed[1, 4:].abs().sum()) == 0
+    packed.sum().backward()
+    assert src.grad[:, :, 0].tolist() == [[1, 0, 1, 1, 0], [0, 1, 1, 1, 1]]
+
+
+@pytest.mark.gpu
+def test_mass_step_vs_reference():
+    """bart_mass_step's loss path: explicit decoder positions (the span's original positions) and enc_mask (the source's <mask>
+    positions are not attended: the allowed source rows are packed to the front instead of a second mask in the kernels) -
+    encoder / decoder outputs, loss and gradients against the reference's (tests/golden/mass_step.npz), incl. the position table,
+    whose gradient now comes from two passes and the explicit positions."""
+    from m3p_amd.model.transformer import TransformerModel
+    from m3p_amd.trainer import XTrainer
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'mass_step.npz'))
+    P, sd, _, _, _, _ = synth.mt_case()
+    _step_params(P)
+    t = lambda k: torch.from_numpy(g[k])      # noqa: E731
+    x1, len1, x2, len2, y, pred_mask, pos = (t(k) for k in ('x1', 'len1', 'x2', 'len2', 'y', 'pred_mask', 'pos'))
+    torch.manual_seed(0)
+    m = TransformerModel(P, is_encoder=True, with_output=True, is_crossModal=True).cuda()
+    m.load_state_dict(sd, strict=False)
+    m.train()
+    enc = m('crossfwd', stream_='text', x=x1.cuda(), lengths=len1.cuda(), langs=x1.clone().fill_(1).cuda(), causal=False).transpose(0, 1)
+    dec = m('crossfwd', stream_='text', x=x2.cuda(), lengths=len2.cuda(), langs=x2.clone().fill_(1).cuda(), causal=True, src_enc=enc,
+            src_len=len1.cuda(), positions=pos.cuda(), enc_mask=x1.ne(P.mask_index).t().cuda())
+    assert rel_l2(enc.float(), g['enc1']) < 1e-2 and rel_l2(dec.float(), g['dec2']) < 1e-2
+    del enc, dec
+    m.arena().zero_grad()
+    tr = XTrainer(m, {}, P)
+    names = [k[5:] for k in g.files if k.startswith('grad.')]
+    grads = _grads_at_step(m, tr.optimizers['model'], names + ['embeddings.weight'])
+    loss = tr.mass_step_on_batch(x1, len1, x2, len2, y, pred_mask, pos, 'zh', None, 1.0)
+    assert abs(float(loss) - float(g['loss'])) < 5e-3
+    enorm = float(grads.pop('embeddings.weight').norm())
+    assert abs(enorm - float(g['grad_norm.embeddings.weight'])) < 4e-2 * enorm
+    bad = [(k, rel_l2(v, g['grad.' + k])) for k, v in grads.items()]
+    assert not [b for b in bad if b[1] > 4e-2], bad
+    assert 'M-MASS-zh' in tr.stats and tr.stats['processed_w'] == int(pred_mask.sum())

@@ -192,3 +192,33 @@ def test_loader_picks_the_collate_the_flags_name():
     # five items in batches of two: the third batch is the short one, the fourth call starts a new epoch
     sizes = [tr.get_batch('txt2img', 'coco', 'img')[0][0].shape[1] for _ in range(3)]
     assert sorted(sizes) == [1, 2, 2]
+
+
+def test_span_masking_batches_match_the_reference_bit_for_bit(golden_dir):
+    """restricted_mask_sent (MASS) and bart_token_mask_sent (text infilling), xtrainer.py:1207-1381, under the numpy / random /
+    torch seeds the golden was recorded with (tests/golden/host_spans.npz): seven tensors per call, three draws per case."""
+    import random
+    from m3p_amd import masking
+    G = np.load(os.path.join(golden_dir, 'host_spans.npz'))
+    P = SimpleNamespace(word_mass=0.5, pad_index=synth.PAD, mask_index=999, n_words=1000, pred_probs=torch.FloatTensor([0.8, 0.1, 0.1]))
+    n = 0
+    for case in range(4):
+        x, lengths, min_len = torch.from_numpy(G['%d.x' % case]), torch.from_numpy(G['%d.len' % case]), int(G['%d.min_len' % case])
+        for name, fn in (('mass', masking.restricted_mask_sent), ('bart', masking.bart_token_mask_sent)):
+            for rep in range(3):
+                seed = 500 + 10 * case + rep
+                np.random.seed(seed); random.seed(seed); torch.manual_seed(seed)
+                res = fn(x.clone(), lengths.clone(), P, min_len if name == 'mass' else 100000)
+                for tag, v in zip(('x1', 'len1', 'x2', 'len2', 'y', 'pred_mask', 'pos'), res):
+                    want = G['%d.%s.%d.%s' % (case, name, rep, tag)]
+                    assert v.numpy().shape == want.shape and np.array_equal(v.numpy(), want), (case, name, rep, tag)
+                    n += 1
+                x1, len1, x2, len2, y, pred_mask, pos = res
+                if name == 'bart':          # one <mask> per sentence, the decoder sees the whole original sentence
+                    assert ((x1 == P.mask_index).sum(0) == 1).all() and torch.equal(len2, lengths - 1)
+                    assert all(torch.equal(x2[:int(len2[b]), b], x[:int(len2[b]), b]) for b in range(x.size(1)))
+                    assert int(pred_mask.sum()) == int(len2.sum()) == len(y)
+                else:                       # the same number of words masked in every sentence, never the first symbol
+                    assert len(set(len2.tolist())) == 1 and torch.equal(len1, lengths) and (x1[0] == x[0]).all()
+                    assert torch.equal(y, torch.cat([x[pos[:, b] + 1, b] for b in range(x.size(1))]).view(x.size(1), -1).t()[pred_mask])
+    assert n == 4 * 2 * 3 * 7

@@ -97,3 +97,37 @@ def test_attention_kernels_keep_their_occupancy(tmp_path):
         if args.endswith('Li8'):
             assert int(info['Occupancy']) >= 2, (m.group(1), info['Occupancy'])
     assert seen >= 3
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason='hipcc not installed')
+def test_no_lds_read_may_overwrite_the_address_of_the_next_one(tmp_path):
+    """Two LDS reads from one inline-asm statement share their address register; if the first read's destination includes
+    that register (outputs not marked early-clobber) the second read's address is the first read's DATA whenever the wave
+    stalls between the two for longer than the LDS latency.  The weight-gradient kernel had 21 such pairs: one wrong
+    half-fragment in about one launch out of 300 with freshly allocated operands (tools/wgrad_stress2.py), found by
+    tests/test_gemm.py failing once in ~20 runs of the suite.  Checked over every csrc file: consecutive LDS reads that use
+    the same address register must not write it."""
+    pat = re.compile(r'\bds_read\w*\s+(v\[(\d+):(\d+)\]|v(\d+)),\s+v(\d+)\b')
+    n_pairs = 0
+    for src in sorted(os.listdir(os.path.join(ROOT, 'm3p_amd', 'csrc'))):
+        if not src.endswith('.hip'):
+            continue
+        out = tmp_path / (src[:-4] + '.s')
+        cmd = [HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-munsafe-fp-atomics', '-ffp-contract=fast',
+               '-Wno-unused-result', '--cuda-device-only', '-S', os.path.join(ROOT, 'm3p_amd', 'csrc', src), '-o', str(out)]
+        subprocess.run(cmd, check=True, capture_output=True, timeout=900)
+        text = out.read_text().splitlines()
+        prev = None
+        for i, l in enumerate(text):
+            m = pat.search(l)
+            if m is None:
+                if l.strip() and not l.strip().startswith(';'):
+                    prev = None
+                continue
+            lo, hi = (int(m.group(2)), int(m.group(3))) if m.group(2) else (int(m.group(4)), int(m.group(4)))
+            addr = int(m.group(5))
+            if prev is not None and prev[2] == addr:
+                n_pairs += 1
+                assert not (prev[0] <= addr <= prev[1]), '%s:%d: %s  then  %s' % (src, i, text[i - 1].strip(), l.strip())
+            prev = (lo, hi, addr)
+    assert n_pairs >= 80          # the tr16 pairs of the weight-gradient kernel are seen at all
