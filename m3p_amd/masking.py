@@ -241,3 +241,38 @@ def bart_token_mask_sent(x, lengths, params, min_len=100000):
     x2, y, pos = (_columns(v, int(max(len2)), n, pad) for v in (targets, outputs, positions))
     pred_mask = y != pad
     return x1, torch.LongTensor(len1), x2, torch.LongTensor(len2), y.masked_select(pred_mask), pred_mask, pos
+
+
+# ---- region-feature noise of the image denoising step (xtrainer.py:1699-1744) -------------------------------------------------
+
+def mask_object(object_features, mask_len=50):
+    """``_mask_object`` (:1699-1732) on one image's region features (R, 2048) numpy: with probability 0.15 a region is hit;
+    nine times in ten it becomes a zero vector that stands for itself AND the next  Poisson(3) mod mask_len  regions (a span
+    collapses into one blank), otherwise it stays.  The result is cut / zero-padded to R - mask_len regions and every row is
+    L2-normalised again (zero rows stay zero).  RNG order: one np.random.poisson, then one random.random() per visited region."""
+    import random
+    import torch.nn.functional as F
+    rows = []
+    max_len = len(object_features) - mask_len
+    span = np.random.poisson(lam=3) % mask_len
+    i = 0
+    while i < len(object_features):
+        prob = random.random()
+        if prob < 0.15 and prob / 0.15 < 0.9:
+            rows.append(np.zeros((2048), dtype=np.float32))
+            i += span
+        else:
+            rows.append(object_features[i])
+        i += 1
+    rows = rows[:max_len] + [np.zeros((2048), dtype=np.float32)] * max(max_len - len(rows), 0)
+    return F.normalize(torch.FloatTensor(np.stack(rows, 0)), dim=-1).numpy()
+
+
+def bart_img_noise(object_features, loc_features, img_mask):
+    """``bart_img_noise`` (:1734-1744): every image of the batch through ``mask_object`` with one common
+    mask_len = Poisson(3) mod round(R / 2) + 1; boxes and mask are cut to the shortened region count."""
+    feats = object_features.numpy()
+    mask_len = np.random.poisson(lam=3) % (round(len(object_features[0]) * 0.5)) + 1
+    out = torch.FloatTensor(np.stack([mask_object(feats[i], mask_len) for i in range(len(feats))], 0))
+    n = out.shape[1]
+    return out, loc_features[:, :n], img_mask[:, :n]

@@ -410,7 +410,7 @@ class Trainer(object):
         (x2, len2), (x1, x1_mask, img_loc, _img_id) = batch
         return self.ic_step_on_batch(x2, len2, x1, x1_mask, img_loc, dataset, input_stream, lambda_coeff)
 
-    def ic_step_on_batch(self, x2, len2, x1, x1_mask, img_loc, dataset='coco', input_stream='img', lambda_coeff=1):
+    def ic_step_on_batch(self, x2, len2, x1, x1_mask, img_loc, dataset='coco', input_stream='img', lambda_coeff=1, stat=None):
         """Loss path of ic_step (:1466-1515): the model encodes the regions (image-only stream) and decodes the caption with
         teacher forcing over that encoding.  x1 (B, R, 2048), x1_mask (B, R), img_loc (B, R, 5) as the collate emits them."""
         params = self.params
@@ -435,12 +435,27 @@ class Trainer(object):
         enc1 = enc1.transpose(0, 1)
         dec2 = model('crossfwd', stream_='text', x=x2, lengths=len2, langs=langs, causal=True, src_enc=enc1, src_len=len1)
         _, loss = model('predict', tensor=dec2, pred_mask=pred_mask, y=y, get_scores=False)
-        self._stat('IC-%s-%s' % (dataset, input_stream), loss)
+        self._stat(stat or 'IC-%s-%s' % (dataset, input_stream), loss)
         self.optimize(lambda_coeff * loss)
         self.n_sentences += params.batch_size
         self.stats['processed_s'] += len2.size(0)
         self.stats['processed_w'] += n_words
         return loss.detach()
+    def bart_img_noise(self, object_features, loc_features, img_mask):
+        """xtrainer.py:1734-1744."""
+        return masking.bart_img_noise(object_features, loc_features, img_mask)
+
+    def bart_img_step(self, dataset='coco', input_stream='img', token_mask=False, lambda_coeff=1):
+        """Image denoising step (xtrainer.py:1746-1808; train_x.py:462-463 over ``cross_ae_steps``): the captioning pass on a
+        batch whose region features went through ``bart_img_noise`` (spans of regions blanked and collapsed, fewer regions)."""
+        assert lambda_coeff >= 0
+        if lambda_coeff == 0:
+            return
+        (x2, len2), (x_img, x_img_mask, img_loc, _img_id) = self.get_batch('ida', dataset, input_stream)
+        x_img, img_loc, x_img_mask = self.bart_img_noise(x_img, img_loc, x_img_mask)
+        return self.ic_step_on_batch(x2, len2, x_img, x_img_mask, img_loc, dataset, input_stream, lambda_coeff,
+                                     stat='IDA-%s' % dataset)
+
     def mt_ic_step(self, dataset='coco', input_stream='img', lambda_coeff=1):
         """Multimodal translation step (xtrainer.py:1517-1593) on a ``mt_caption_collate`` batch
         ``(x_src, len_src), (x2, len2), (x1, x1_mask, img_loc, img_id)``."""

@@ -895,6 +895,35 @@ def gen_span_mask_goldens():
     print('host_spans.npz', len(out), 'arrays')
 
 
+def gen_img_noise_goldens():
+    """host_img_noise.npz: the reference's bart_img_noise / _mask_object (xtrainer.py:1699-1744) under fixed numpy / random seeds
+    on synthetic region features."""
+    import random
+    xt, tr, m, P, hot = _reference_trainer(synth.CONFIGS['cfg1'])
+    rs = np.random.RandomState(53)
+    out = {}
+    for case, (B, R) in enumerate(((4, 10), (3, 36), (2, 7))):
+        feats = torch.from_numpy(rs.standard_normal((B, R, 2048)).astype(np.float32))
+        feats = feats / feats.norm(dim=-1, keepdim=True)
+        loc = torch.from_numpy(rs.uniform(size=(B, R, 5)).astype(np.float32))
+        mask = torch.ones(B, R, dtype=torch.long)
+        out['%d.seed' % case] = np.asarray(53 + case)
+        out['%d.shape' % case] = np.asarray([B, R])
+        for rep in range(3):
+            seed = 700 + 10 * case + rep
+            np.random.seed(seed); random.seed(seed)
+            f2, l2, m2 = tr.bart_img_noise(feats.clone(), loc.clone(), mask.clone())
+            # the features are large: keep which rows are blank, the row norms and a checksum per image
+            out['%d.%d.n' % (case, rep)] = np.asarray(f2.shape[1])
+            out['%d.%d.blank' % (case, rep)] = (f2.abs().sum(-1) == 0).numpy()
+            out['%d.%d.first8' % (case, rep)] = f2[:, :, :8].numpy()
+            out['%d.%d.sum' % (case, rep)] = f2.double().sum(-1).numpy()
+            out['%d.%d.loc' % (case, rep)] = l2.numpy()
+            out['%d.%d.mask' % (case, rep)] = m2.numpy()
+    np.savez_compressed(os.path.join(OUT, 'host_img_noise.npz'), **out)
+    print('host_img_noise.npz', len(out), 'arrays')
+
+
 def gen_decoder_goldens():
     """decoder.npz: the reference's causal decoder (TransformerModel(is_encoder=False)) on the deterministic cases of
     m3p_amd.synth.DECODER_CASES - teacher-forced crossfwd(causal=True, src_enc) hidden states, the same computed
@@ -963,7 +992,7 @@ def gen_decoder_goldens():
 
 if __name__ == '__main__':
     single = {'enum': gen_state_dict_enumeration, 'host': gen_host_goldens, 'mt': gen_mt_goldens, 'noise': gen_noise_goldens, 'ic': gen_ic_goldens, 'langs': gen_text_langs_goldens,
-              'decoder': gen_decoder_goldens, 'refiner': gen_refiner_goldens, 'mt_ic': gen_mt_ic_goldens, 'data': gen_data_goldens, 'ic_refine': gen_ic_refine_goldens, 'spans': gen_span_mask_goldens, 'mass': gen_mass_goldens}
+              'decoder': gen_decoder_goldens, 'refiner': gen_refiner_goldens, 'mt_ic': gen_mt_ic_goldens, 'data': gen_data_goldens, 'ic_refine': gen_ic_refine_goldens, 'spans': gen_span_mask_goldens, 'mass': gen_mass_goldens, 'img_noise': gen_img_noise_goldens}
     if len(sys.argv) > 1:
         single[sys.argv[1]]()
         sys.exit(0)
@@ -971,5 +1000,5 @@ if __name__ == '__main__':
                gen_text_and_itm_goldens, gen_unit_goldens, gen_model_goldens, gen_trainer_goldens, gen_host_goldens,
                gen_decoder_goldens, gen_text_langs_goldens, gen_mt_goldens, gen_ic_goldens, gen_noise_goldens,
                gen_mt_ic_goldens, gen_data_goldens, gen_ic_refine_goldens,
-               gen_span_mask_goldens, gen_mass_goldens):
+               gen_span_mask_goldens, gen_mass_goldens, gen_img_noise_goldens):
         fn()

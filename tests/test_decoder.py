@@ -751,3 +751,65 @@ def test_mass_step_vs_reference():
     bad = [(k, rel_l2(v, g['grad.' + k])) for k, v in grads.items()]
     assert not [b for b in bad if b[1] > 4e-2], bad
     assert 'M-MASS-zh' in tr.stats and tr.stats['processed_w'] == int(pred_mask.sum())
+
+
+@pytest.mark.gpu
+def test_bart_img_step_vs_oracle():
+    """Image denoising (xtrainer.py:1746-1808): caption_collate batch -> bart_img_noise (bit-exact with the reference:
+    tests/test_host_data.py) -> the captioning pass on the shortened, partly blanked region set.  Loss and gradients against the
+    oracle's autograd on the noised batch (re-built here from the same seeds)."""
+    import random
+    from m3p_amd import masking
+    from m3p_amd.model.transformer import TransformerModel
+    from m3p_amd.trainer import XTrainer
+    P, sd, x_img, loc, _, x2, len2 = synth.ic_case()
+    _step_params(P, is_generation=True, is_mt=False, is_pretrain=False, is_slide=False, n_gpu_per_node=1, num_workers=0, batch_size=6,
+                 ft_lgs=[])
+    R, B = x_img.shape[0], x_img.shape[1]
+    feats = (x_img / x_img.norm(dim=-1, keepdim=True)).transpose(0, 1).contiguous()          # (B, R, 2048), unit rows
+
+    class Items(torch.utils.data.Dataset):
+        def __len__(self):
+            return B
+
+        def __getitem__(self, i):
+            return (x2[1:int(len2[i]) - 1, i].numpy(), feats[i:i + 1], torch.ones(1, R, dtype=torch.long),
+                    loc[:, i].unsqueeze(0).contiguous(), i)
+
+    torch.manual_seed(0)
+    m = TransformerModel(P, is_encoder=True, with_output=True, is_crossModal=True).cuda()
+    m.load_state_dict(sd, strict=False)
+    tr = XTrainer(m, {'cross_modal': {('coco', 'img'): {'train': Items()}}}, P)
+    names = ['image_embeddings.image_embeddings.bias', 'image_embeddings.LayerNorm.weight', 'attentions.0.v_lin.weight',
+             'encoder_attn.1.k_lin.weight', 'ffns.1.lin1.weight', 'pred_layer.proj.bias']
+    grads = _grads_at_step(m, tr.optimizers['model'], names)
+    seen = {}
+    real_get = tr.get_batch
+
+    def get_batch(*a):
+        b = real_get(*a)
+        seen['ids'] = list(b[1][3])
+        return b
+    tr.get_batch = get_batch
+    np.random.seed(17); random.seed(17)
+    loss = tr.bart_img_step('coco', 'img', False, 1.0)
+    order = seen['ids']
+    np.random.seed(17); random.seed(17)
+    f2, l2, m2 = masking.bart_img_noise(feats[order], loc.transpose(0, 1)[order], torch.ones(B, R, dtype=torch.long))
+    n = f2.shape[1]
+    assert 1 <= n < R and bool((f2.abs().sum(-1) == 0).any())           # fewer regions, some of them blank
+    xs = x2[:, order].clone()
+    xs[0] = 0                                                           # the collate frames sentences with BOS = 0
+    ref = {k: v.clone().requires_grad_(k in names) for k, v in sd.items()}
+    img_len = m2.sum(1)
+    enc = ref_cpu.crossfwd_img(ref, P.n_layers, P.n_heads, f2.transpose(0, 1), img_len, l2.transpose(0, 1),
+                               langs=torch.zeros((n, B), dtype=torch.long)).transpose(0, 1)
+    dec = ref_cpu.decoder_crossfwd(ref, P.n_layers, P.n_heads, xs, len2[order], enc, img_len, langs=xs.clone().fill_(0))
+    pred_mask, y = synth.mt_targets(xs, len2[order])
+    o = ref_cpu.predict_mlm(ref, dec, pred_mask, y)
+    o = o[1] if isinstance(o, tuple) else o
+    o.backward()
+    assert abs(float(loss) - float(o.detach())) < 5e-3
+    bad = [(k, rel_l2(grads[k], ref[k].grad.numpy())) for k in names]
+    assert not [b for b in bad if b[1] > 4e-2], bad
+    assert 'IDA-coco' in tr.stats and tr.stats['processed_s'] == B

@@ -222,3 +222,31 @@ def test_span_masking_batches_match_the_reference_bit_for_bit(golden_dir):
                     assert len(set(len2.tolist())) == 1 and torch.equal(len1, lengths) and (x1[0] == x[0]).all()
                     assert torch.equal(y, torch.cat([x[pos[:, b] + 1, b] for b in range(x.size(1))]).view(x.size(1), -1).t()[pred_mask])
     assert n == 4 * 2 * 3 * 7
+
+
+def test_region_feature_noise_matches_the_reference(golden_dir):
+    """bart_img_noise / _mask_object (xtrainer.py:1699-1744) under the reference's numpy / random seeds: how many regions stay,
+    which are blanked, the (re-normalised) features, boxes and mask (tests/golden/host_img_noise.npz)."""
+    import random
+    from m3p_amd import masking
+    G = np.load(os.path.join(golden_dir, 'host_img_noise.npz'))
+    for case in range(3):
+        B, R = G['%d.shape' % case].tolist()
+        rs = np.random.RandomState(53)
+        for c in range(case + 1):               # the generator drew the cases one after another from one stream
+            b_, r_ = [(4, 10), (3, 36), (2, 7)][c]
+            feats = torch.from_numpy(rs.standard_normal((b_, r_, 2048)).astype(np.float32))
+            feats = feats / feats.norm(dim=-1, keepdim=True)
+            loc = torch.from_numpy(rs.uniform(size=(b_, r_, 5)).astype(np.float32))
+        mask = torch.ones(B, R, dtype=torch.long)
+        for rep in range(3):
+            seed = 700 + 10 * case + rep
+            np.random.seed(seed); random.seed(seed)
+            f2, l2, m2 = masking.bart_img_noise(feats.clone(), loc.clone(), mask.clone())
+            assert f2.shape == (B, int(G['%d.%d.n' % (case, rep)]), 2048) and f2.shape[1] < R
+            assert np.array_equal((f2.abs().sum(-1) == 0).numpy(), G['%d.%d.blank' % (case, rep)])
+            assert np.array_equal(f2[:, :, :8].numpy(), G['%d.%d.first8' % (case, rep)])
+            assert np.allclose(f2.double().sum(-1).numpy(), G['%d.%d.sum' % (case, rep)], rtol=0, atol=1e-12)
+            assert np.array_equal(l2.numpy(), G['%d.%d.loc' % (case, rep)]) and np.array_equal(m2.numpy(), G['%d.%d.mask' % (case, rep)])
+            norms = f2.norm(dim=-1)
+            assert (((norms - 1).abs() < 1e-5) | (norms == 0)).all()
