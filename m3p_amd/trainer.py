@@ -16,6 +16,7 @@ stay on the device and are only read when ``print_stats`` prints; clip + Adam + 
 one fused kernel pass; DDP is our bucketed reducer (m3p_amd/distributed.py).  ``mt_step`` (:1383-1441) and ``ic_step`` (:1443-1515) are the
 translation / captioning steps on the causal stream.  Not built: the FreeLB / sliding-window steps (out of scope).
 """
+import math
 import os
 import time
 from collections import OrderedDict
@@ -705,13 +706,138 @@ class XTrainer(Trainer):
             self.pretrain_under_step(i2t_batch, dataset, 'i2t', 'en', p.lambda_i2t, p.lambda_mlm, p.lambda_mrm, p.lambda_mrfr)
 
     def rel_step(self, dataset='coco', input_stream='img', lambda_1=1, lambda_2=1):
-        """xtrainer.py:1867-1877 (the FreeLB variants are not built)."""
+        """xtrainer.py:1867-1877; with ``params.is_freelb`` every task's step is preceded by its adversarial one - the
+        reference hands BOTH of those the t2i batch and lambda_1 (:1871, :1875), kept."""
         t2i_batch, i2t_batch = self.get_batch('rel', dataset, input_stream)
-        assert not getattr(self.params, 'is_freelb', False), 'FreeLB adversarial steps are outside this build'
+        freelb = getattr(self.params, 'is_freelb', False)
         if self.params.t2i_flag:
+            if freelb:
+                self.freelb_t2i_step(t2i_batch, dataset, lambda_1)
             self.t2i_step(t2i_batch, dataset, lambda_1)
         if self.params.i2t_flag:
+            if freelb:
+                self.freelb_i2t_step(t2i_batch, dataset, lambda_1)
             self.i2t_step(i2t_batch, dataset, lambda_2)
+
+    # ---- FreeLB adversarial fine-tuning of the matching steps (xtrainer.py:2021-2224, :2700-2851)
+    @staticmethod
+    def _uniform_like(t):
+        """U(-1, 1) noise of t's shape, drawn on the host from torch's CPU generator (the reference draws on whatever device
+        the embeddings live on; drawn here where a seeded CPU run of the reference draws it, so that the two can be compared)."""
+        return torch.zeros(t.shape, dtype=torch.float32).uniform_(-1, 1).to(t.device)
+
+    def deal_freelb_delta(self, model, input_ids, input_lengths, adv_init_mag=1e-4, norm_type='l2'):
+        """:2700-2722: the word embeddings of the batch and a random perturbation of magnitude adv_init_mag / sqrt(len * d)."""
+        embeds_init = _unwrap(model).embeddings(input_ids)
+        if adv_init_mag > 0:
+            if norm_type == 'l2':
+                dims = input_lengths * embeds_init.size(-1)
+                mag = adv_init_mag / torch.sqrt(dims.float())
+                delta = (self._uniform_like(embeds_init) * mag.view(-1, 1, 1)).detach()
+            else:
+                assert norm_type == 'linf'
+                delta = self._uniform_like(embeds_init) * adv_init_mag
+        else:
+            delta = torch.zeros_like(embeds_init, dtype=torch.float32)
+        return embeds_init, delta
+
+    def deal_image_freelb_delta(self, image_feature, adv_init_mag=1e-4, norm_type='l2'):
+        """:2724-2735 (the magnitude is per FIRST index of the (R, B, 2048) features, as the reference has it)."""
+        if adv_init_mag > 0:
+            if norm_type == 'l2':
+                mag = adv_init_mag / math.sqrt(image_feature.size(-1))
+                return (self._uniform_like(image_feature) * mag).detach()
+            assert norm_type == 'linf'
+            return self._uniform_like(image_feature) * adv_init_mag
+        return torch.zeros_like(image_feature, dtype=torch.float32)
+
+    @staticmethod
+    def _ascend(delta, norm_type, adv_lr, adv_max_norm):
+        """One projected ascent step on a perturbation (:2793-2850): + adv_lr * grad / |grad| per first-index slice, then
+        scaled back into the adv_max_norm ball."""
+        g = delta.grad.clone().detach()
+        n0 = g.size(0)
+        shape = (-1,) + (1,) * (g.dim() - 1)
+        if norm_type == 'l2':
+            denorm = torch.clamp(torch.norm(g.reshape(n0, -1), dim=1), min=1e-8).view(shape)
+            delta = (delta + adv_lr * g / denorm).detach()
+            if adv_max_norm > 0:
+                dn = torch.norm(delta.reshape(n0, -1).float(), p=2, dim=1).detach()
+                exceed = (dn > adv_max_norm).to(delta)
+                delta = (delta * (adv_max_norm / dn * exceed + (1 - exceed)).view(shape)).detach()
+        elif norm_type == 'linf':
+            denorm = torch.clamp(torch.norm(g.reshape(n0, -1), dim=1, p=float('inf')), min=1e-8).view(shape)
+            delta = (delta + adv_lr * g / denorm).detach()
+            if adv_max_norm > 0:
+                delta = torch.clamp(delta, -adv_max_norm, adv_max_norm).detach()
+        else:
+            raise NotImplementedError('Norm type {} not specified.'.format(norm_type))
+        return delta
+
+    def update_freelb_delta(self, model, delta, embeds_init, input_ids, norm_type='l2', adv_lr=1e-3, adv_max_norm=1e-2):
+        """:2793-2827: ascent step on the text perturbation; the embeddings are looked up again (the step before moved them)."""
+        return _unwrap(model).embeddings(input_ids), self._ascend(delta, norm_type, adv_lr, adv_max_norm)
+
+    def update_image_freelb_delta(self, image_embeds, delta, norm_type='l2', adv_lr=1e-3, adv_max_norm=1e-2):
+        """:2829-2851."""
+        return self._ascend(delta, norm_type, adv_lr, adv_max_norm)
+
+    def free_optimize(self, loss):
+        """:2755-2791 - ``optimize`` without the accumulation bookkeeping: every adversarial step is an optimizer step."""
+        self.optimize(loss)
+
+    def _freelb_rel_step(self, batches, dataset, task_name, lambda_coeff):
+        """freelb_t2i_step / freelb_i2t_step (:2021-2224, identical up to the statistics key): three passes over one batch, each
+        with the word embeddings and the region features perturbed (``text_embed=`` / ``x_img +``), the loss / 3 optimised at
+        once, and between passes one normalised ascent step of both perturbations along their gradients."""
+        assert lambda_coeff >= 0
+        if lambda_coeff == 0:
+            return None
+        params = self.params
+        model = self.model
+        model.train()
+        (x1, len1, _lang_p), visual = batches[0], batches[1]
+        img, img_mask, img_loc, _obj_labels, pos_labels, _img_ids = visual
+        assert getattr(_unwrap(model), 'ddp_hook', None) is None or not params.multi_gpu, \
+            'FreeLB steps are single-GPU in this build (the dense word-embedding gradient of text_embed has no reducer bucket)'
+        self._dp_plan(False)
+        img_len = img_mask.sum(dim=1)
+        x_img, img_loc = img.transpose(0, 1), img_loc.transpose(0, 1)
+        x1, len1, x_img, img_loc, img_len = to_cuda(x1, len1, x_img, img_loc, img_len)
+        embeds_init, delta = self.deal_freelb_delta(model, x1.transpose(0, 1), len1)
+        image_delta = self.deal_image_freelb_delta(x_img)
+        adv_steps, tb_loss = 3, 0.0
+        for astep in range(adv_steps):
+            delta.requires_grad_()
+            text_imb = delta + embeds_init
+            image_delta.requires_grad_()
+            img_imb = x_img + image_delta
+            enc = model('jointfwd', x=x1, lengths=len1, x_img=img_imb, lengths_img=img_len, causal=False, langs=None,
+                        image_loc=img_loc, refine_image=params.refine_image, text_embed=text_imb)
+            enc = enc.transpose(0, 1)
+            relation_scores = model('predict', tensor=enc, is_relation=True)
+            loss = self._itm_loss(relation_scores, pos_labels) / (1.0 * adv_steps)
+            # the word-embedding gradient of these passes arrives through autograd (text_embed = delta + Emb[x]), not through
+            # the encoder's own backward: tell the arena that the matrix is part of this step
+            _unwrap(model).arena().touch('embeddings.weight')
+            self.free_optimize(loss)
+            tb_loss = tb_loss + loss.detach()
+            if astep == adv_steps - 1:
+                break
+            embeds_init, delta = self.update_freelb_delta(model, delta, embeds_init, x1.transpose(0, 1))
+            image_delta = self.update_image_freelb_delta(x_img, image_delta)
+        self._stat('FRLB-%s-%s' % (task_name, dataset), tb_loss)
+        bs = len1.size(0)
+        self.n_sentences += params.batch_size
+        self.stats['processed_s'] += bs
+        self.stats['processed_w'] += bs * enc.size(1)
+        return tb_loss
+
+    def freelb_t2i_step(self, batches, dataset='coco', lambda_coeff=1):
+        return self._freelb_rel_step(batches, dataset, 't2i', lambda_coeff)
+
+    def freelb_i2t_step(self, batches, dataset='coco', lambda_coeff=1):
+        return self._freelb_rel_step(batches, dataset, 'i2t', lambda_coeff)
 
     def pretrain_under_step(self, _batch, dataset='coco', task_name='t2i', lang2='en', lambda_coeff_rel=1,
                             lambda_coeff_mlm=1, lambda_coeff_mrm=1, lambda_coeff_mrfr=1):

@@ -387,6 +387,9 @@ def _reference_trainer(cfg, **over):
     """The reference's XTrainer on the cfg1 golden model through the container-only shims."""
     for name in ('apex', 'apex.amp', 'apex.parallel'):
         sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules['apex'].parallel = sys.modules['apex.parallel']            # (the FreeLB helpers name apex.parallel.DistributedDataParallel)
+    if not hasattr(sys.modules['apex.parallel'], 'DistributedDataParallel'):
+        sys.modules['apex.parallel'].DistributedDataParallel = type('DistributedDataParallel', (), {})
     torch.Tensor.cuda = lambda self, *a, **k: self
     import src.xtrainer as xt
     m, P, hot = build_reference_model(cfg)
@@ -924,6 +927,34 @@ def gen_img_noise_goldens():
     print('host_img_noise.npz', len(out), 'arrays')
 
 
+def gen_freelb_goldens():
+    """freelb_step.npz: the reference's freelb_t2i_step (xtrainer.py:2021-2121) on the cfg1 batch through the shimmed trainer,
+    CPU, dropout 0, torch seed fixed (the perturbations are drawn from torch's generator): the summed loss of the three
+    adversarial passes, the learning rate and parameter norms after the three optimizer steps it takes."""
+    cfg = synth.CONFIGS['cfg1']
+    xt, tr, m, P, hot = _reference_trainer(cfg, sample_n=4, multi_cls_loss_weight=1, bin_cls_loss_weight=1)
+    B, R = cfg['B'], cfg['R']
+    full = synth.make_batch(cfg['T'], R, B, cfg['n_words'], 0)
+    tup = [(full['x'], full['lengths'], torch.zeros_like(full['x'])),
+           # (region tensors as transposed VIEWS: the step's own transpose then yields contiguous (R, B, .) tensors, which the
+           #  reference's .view() calls on the perturbation gradients need with this torch - zeros_like keeps strides now)
+           [full['x_img'].transpose(0, 1), torch.ones(B, R, dtype=torch.long),
+            full['image_loc'].transpose(0, 1), torch.full((B, R), -1, dtype=torch.long), [2, 0], list(range(B))]]
+    tr.stats['FRLB-t2i-google'] = []
+    named = dict(m.named_parameters())
+    before = {k: named[k].detach().clone() for k in ('embeddings.weight', 'attentions.0.q_lin.weight', 'pooled_layer.dense.weight')}
+    torch.manual_seed(4242)
+    tr.freelb_t2i_step(tup, 'google', 1.0)
+    g = {'loss': np.asarray(tr.stats['FRLB-t2i-google'][-1]), 'lr': np.asarray(tr.optimizers['model'].param_groups[0]['lr']),
+         'n_updates': np.asarray(tr.optimizers['model'].param_groups[0]['num_updates'])}
+    for k, v in before.items():
+        g['dnorm/' + k] = (named[k].detach() - v).norm().numpy()
+        g['pnorm/' + k] = named[k].detach().norm().numpy()
+    g['emb_rows_moved'] = np.asarray(int(((named['embeddings.weight'].detach() - before['embeddings.weight']).abs().sum(1) > 0).sum()))
+    np.savez_compressed(os.path.join(OUT, 'freelb_step.npz'), **g)
+    print('freelb_step.npz: loss %.6f, %d updates, %d embedding rows moved' % (float(g['loss']), int(g['n_updates']), int(g['emb_rows_moved'])))
+
+
 def gen_decoder_goldens():
     """decoder.npz: the reference's causal decoder (TransformerModel(is_encoder=False)) on the deterministic cases of
     m3p_amd.synth.DECODER_CASES - teacher-forced crossfwd(causal=True, src_enc) hidden states, the same computed
@@ -992,7 +1023,7 @@ def gen_decoder_goldens():
 
 if __name__ == '__main__':
     single = {'enum': gen_state_dict_enumeration, 'host': gen_host_goldens, 'mt': gen_mt_goldens, 'noise': gen_noise_goldens, 'ic': gen_ic_goldens, 'langs': gen_text_langs_goldens,
-              'decoder': gen_decoder_goldens, 'refiner': gen_refiner_goldens, 'mt_ic': gen_mt_ic_goldens, 'data': gen_data_goldens, 'ic_refine': gen_ic_refine_goldens, 'spans': gen_span_mask_goldens, 'mass': gen_mass_goldens, 'img_noise': gen_img_noise_goldens}
+              'decoder': gen_decoder_goldens, 'refiner': gen_refiner_goldens, 'mt_ic': gen_mt_ic_goldens, 'data': gen_data_goldens, 'ic_refine': gen_ic_refine_goldens, 'spans': gen_span_mask_goldens, 'mass': gen_mass_goldens, 'img_noise': gen_img_noise_goldens, 'freelb': gen_freelb_goldens}
     if len(sys.argv) > 1:
         single[sys.argv[1]]()
         sys.exit(0)
@@ -1000,5 +1031,6 @@ if __name__ == '__main__':
                gen_text_and_itm_goldens, gen_unit_goldens, gen_model_goldens, gen_trainer_goldens, gen_host_goldens,
                gen_decoder_goldens, gen_text_langs_goldens, gen_mt_goldens, gen_ic_goldens, gen_noise_goldens,
                gen_mt_ic_goldens, gen_data_goldens, gen_ic_refine_goldens,
-               gen_span_mask_goldens, gen_mass_goldens, gen_img_noise_goldens):
+               gen_span_mask_goldens, gen_mass_goldens, gen_img_noise_goldens,
+               gen_freelb_goldens):
         fn()

@@ -437,3 +437,40 @@ def test_text_stream_with_language_embeddings_vs_reference(golden_dir):
     # without language ids the same model runs the plain stream; ids on a one-language model are refused
     out0 = m('crossfwd', stream_='text', x=batch['x'].cuda(), lengths=batch['lengths'].cuda(), causal=False)
     assert rel_l2(out0.float(), O.crossfwd_text(sd, cfg['n_layers'], cfg['n_heads'], batch['x'], batch['lengths'])) < 1e-2
+
+
+def test_freelb_t2i_step_tracks_the_reference_run(golden_dir):
+    """freelb_t2i_step (xtrainer.py:2021-2121): three adversarial passes over one batch - perturbed word embeddings through
+    jointfwd(text_embed=) and perturbed region features, each pass an optimizer step, a normalised ascent step on both
+    perturbations in between - against the same call on the reference's XTrainer on CPU under the same torch seed
+    (tests/golden/freelb_step.npz): the summed loss, the schedule's state and how far the parameters moved (Adam steps of
+    1e-7-scale learning rates: the displacement, not the norm, is what three steps change)."""
+    from m3p_amd.trainer import XTrainer
+    G = np.load(os.path.join(golden_dir, 'freelb_step.npz'))
+    cfg = synth.CONFIGS['cfg1']
+    common = dict(optimizer='adam_inverse_sqrt,beta1=0.9,beta2=0.98,lr=0.0001', clip_grad_norm=5, amp=-1, fp16=False,
+                  accumulate_gradients=1, multi_gpu=False, epoch_size=100, cross_mlm_steps=[], cross_mrm_steps=[],
+                  cross_mrfr_steps=[], cross_clcm_steps=[], cross_rel_steps=[('google', 'img')], refine_image=False,
+                  batch_size=cfg['B'], dump_path='/nonexistent_m3p_dump', langs=['en'], t2i_flag=True, i2t_flag=True, is_freelb=True)
+    batch = synth.make_batch(cfg['T'], cfg['R'], cfg['B'], cfg['n_words'], 0)
+    m, P, _ = _build(cfg, dict(common, sample_n=4, multi_cls_loss_weight=1, bin_cls_loss_weight=1))
+    tr = XTrainer(m, {}, P)
+    B, R = cfg['B'], cfg['R']
+    tup = [(batch['x'], batch['lengths'], torch.zeros_like(batch['x'])),
+           [batch['x_img'].transpose(0, 1).contiguous(), torch.ones(B, R, dtype=torch.long),
+            batch['image_loc'].transpose(0, 1).contiguous(), torch.full((B, R), -1, dtype=torch.long), [2, 0], list(range(B))]]
+    own = dict(m.named_parameters())
+    before = {k: own[k].detach().clone() for k in ('embeddings.weight', 'attentions.0.q_lin.weight', 'pooled_layer.dense.weight')}
+    torch.manual_seed(4242)
+    loss = tr.freelb_t2i_step(tup, 'google', 1.0)
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(G['loss'])) < 1e-2
+    group = tr.optimizers['model'].param_groups[0]
+    assert group['num_updates'] == int(G['n_updates']) == 3 and abs(group['lr'] - float(G['lr'])) < 1e-15
+    for k, b in before.items():
+        moved = float((own[k].detach() - b).norm())
+        assert abs(moved - float(G['dnorm/' + k])) < 0.1 * float(G['dnorm/' + k]), (k, moved, float(G['dnorm/' + k]))
+    rows = int(((own['embeddings.weight'].detach() - before['embeddings.weight']).abs().sum(1) > 0).sum())
+    assert rows == int(G['emb_rows_moved'])          # the word-embedding gradient of text_embed reached the matrix, for the batch's words only
+    assert 'FRLB-t2i-google' in tr.stats and tr.stats['processed_s'] == B
+    assert tr.freelb_i2t_step(tup, 'google', 0) is None
