@@ -172,6 +172,13 @@ def main():
                     help='encoder-layer projections and their data gradients on the fp8 MFMA GEMM (BASELINE configs[3]; '
                          'needs per-GPU batch x (T + R) to be a multiple of 256, e.g. --config cfg4 --batch 64)')
     args = ap.parse_args()
+    # The timed loop needs ONE host thread (it only enqueues kernels; its few CPU tensor ops are tiny), but torch's intra-op
+    # pool defaults to every physical core (128 here) and its workers spin after each small host op.  The GPU boxes run this
+    # container under a 16-CPU quota (cpu.max 1600000/100000): a pool of 256 turned the 39-ms step into 125-130 ms, and the
+    # default 128 is the likeliest reason for the occasional 42-47 ms runs with unchanged kernel times.  A small pool
+    # removes the exposure (1-2 threads 38.4 ms, 4-16 threads 38.1 ms on a quiet box).  M3P_BENCH_HOST_THREADS overrides; the
+    # CPU baseline sets its own count.
+    torch.set_num_threads(int(os.environ.get('M3P_BENCH_HOST_THREADS', '4')))
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         _self_launch(args)
 
@@ -228,7 +235,12 @@ def main():
         step()
     torch.cuda.synchronize()
     warm_prof = ops.PROFILE
-    warm_agg = {k: sum(a.elapsed_time(b) for a, b in evs) for k, evs in warm_prof.items()}
+    # per instance: median launch time x launches - one outlier among the warm-up launches (a first launch, a clock ramp)
+    # must not decide which instance the timed region brackets
+    def _robust_total(evs):
+        ts = sorted(a.elapsed_time(b) for a, b in evs)
+        return ts[len(ts) // 2] * len(ts)
+    warm_agg = {k: _robust_total(evs) for k, evs in warm_prof.items()}
     gemm_ms_per_step = sum(warm_agg.values()) / max(args.warmup, 1)
     ops.PROFILE_ONLY = max(warm_agg.items(), key=lambda kv: kv[1])[0] if warm_agg else None
     if dp is not None:
