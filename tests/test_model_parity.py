@@ -256,3 +256,31 @@ def test_gradient_accumulation_equals_the_full_batch_step():
         d2 = dict(m2.named_parameters())[n].detach() - before[n]
         touched = d1[n].abs() > 0
         assert rel_l2(d2[touched], d1[n][touched]) < 5e-2, n
+
+
+@pytest.mark.gpu
+def test_jointfwd_text_embed_override_and_its_gradient():
+    """jointfwd(text_embed=...) (transformer.py:910-913): caller-made word rows instead of Emb[x].  Handing in Emb[x] itself
+    must reproduce the plain pass, and the gradient that comes back for the rows must be the one the oracle's autograd gives
+    (the FreeLB steps ascend along it: tests/test_streams_and_retrieval.py::test_freelb_t2i_step_tracks_the_reference_run)."""
+    from oracle import ref_cpu as O
+    cfg = synth.CONFIGS['cfg1']
+    m, P, sd = _build(cfg)
+    m.eval()
+    batch = synth.make_batch(cfg['T'], cfg['R'], cfg['B'], cfg['n_words'], cfg['n_pred'])
+    dev = 'cuda'
+    kw = dict(x=batch['x'].to(dev), lengths=batch['lengths'].to(dev), x_img=batch['x_img'].to(dev), lengths_img=batch['lengths_img'].to(dev),
+              causal=False, langs=None, image_loc=batch['image_loc'].to(dev), refine_image=False)
+    plain = m('jointfwd', **kw)
+    rows = sd['embeddings.weight'][batch['x'].t()].to(dev).requires_grad_(True)                  # (B, T, d)
+    out = m('jointfwd', text_embed=rows, **kw)
+    assert rel_l2(out.float(), plain.float()) < 2e-3
+    w = torch.from_numpy(np.random.RandomState(5).standard_normal(tuple(out.shape)).astype(np.float32))
+    m.arena().zero_grad()
+    (out.float() * w.to(dev)).sum().backward()
+    leaves = {k: v.clone() for k, v in sd.items()}
+    rows_ref = sd['embeddings.weight'][batch['x'].t()].clone().requires_grad_(True)
+    o = O.jointfwd(leaves, cfg['n_layers'], cfg['n_heads'], batch['x'], batch['lengths'], batch['x_img'], batch['lengths_img'],
+                   batch['image_loc'], text_embed=rows_ref)
+    (o * w).sum().backward()
+    assert rel_l2(rows.grad.float(), rows_ref.grad) < 5e-2

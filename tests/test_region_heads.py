@@ -147,3 +147,16 @@ def test_i2t_pretrain_step_with_clcm_matches_oracle():
     assert abs(float(trainer.stats['CLCM-google'][-1]) - float(ref)) < 5e-3
     own = dict(m.named_parameters())
     assert float((own['pooled_layer2.dense.weight'].detach().cpu() - sd['pooled_layer2.dense.weight']).abs().max()) > 0
+
+
+def test_predict_is_mrfr_is_the_bare_regression(golden_dir):
+    """predict(tensor, is_mrfr=True) (transformer.py:1202-1204): mrfr_dense on every row handed in, against the oracle."""
+    from oracle import ref_cpu as O
+    g = dict(np.load(os.path.join(golden_dir, 'cfg1_region_heads.npz')))
+    cfg = synth.CONFIGS['cfg1']
+    m, P, sd, _ = _model(cfg)
+    x = torch.from_numpy(g['img_out']).to(torch.bfloat16)                       # (B, R, d)
+    reg = m('predict', tensor=x.cuda(), is_mrfr=True)
+    ref = O.predict_mrfr(sd, x.float())
+    assert tuple(reg.shape) == tuple(ref.shape) == (cfg['B'], cfg['R'], 2048)
+    assert rel_l2(reg.float(), ref) < 6e-3
