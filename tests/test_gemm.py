@@ -321,3 +321,28 @@ def test_gemm_wgrad_at_the_benchmarked_sizes(N, K):
         ref32 = dy.float().t() @ x.float() + 1.0
         raise AssertionError('rel %.3e against the fp64 product (the same call repeated: %.3e; the fp32 library product: %.3e); '
                              'differs in %s' % (err, rel_l2(dw2.double(), ref64), rel_l2(ref32.double(), ref64), where))
+
+
+def test_gemm_wgrad_with_fresh_operands_of_changing_shapes():
+    """~900 weight-gradient launches, each on freshly allocated operands of another shape, against fp64 products: the pattern
+    under which one launch in ~300 returned a wrong half-fragment's worth of one tile before the fragment asm's outputs were
+    made early-clobber (tools/wgrad_stress2.py) - warm, repeated operands never showed it."""
+    from m3p_amd import ops
+    shapes = [(4288, 2304, 768), (4100, 768, 768), (8192, 768, 768), (4096, 3072, 768), (8192, 768, 3072), (4160, 1024, 1024),
+              (16384, 256, 128), (20992, 2304, 768), (20992, 3072, 768)]
+    bad = []
+    for rnd in range(100):
+        for M, N, K in shapes:
+            g = torch.Generator(device='cuda').manual_seed(N + K + rnd)
+            dy = (torch.randn((M, N), device='cuda', generator=g) * 0.1).to(torch.bfloat16)
+            x = torch.randn((M, K), device='cuda', generator=g).to(torch.bfloat16)
+            dw = torch.ones((N, K), device='cuda')
+            ops.gemm_wgrad(dy, x, dw)
+            ref = torch.ones((N, K), dtype=torch.float64, device='cuda')
+            for m0 in range(0, M, 8192):
+                ref += dy[m0:m0 + 8192].double().t() @ x[m0:m0 + 8192].double()
+            err = float((dw.double() - ref).norm() / ref.norm())
+            if err > 1e-5:
+                bad.append((rnd, M, N, K, err))
+            del dy, x, dw, ref
+    assert not bad, bad
