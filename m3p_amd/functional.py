@@ -642,6 +642,7 @@ class ImageStreamFn(torch.autograd.Function):
         ctx.model = model
         ctx.saved = (ximg16, loc, img_saved, totlen, mask, langs, ref_saved)
         ctx.meta = (B, R, d, p_drop, seed_step, p_refine)
+        ctx.x_img_meta = (x_img.dtype, x_img.device) if x_img.requires_grad else None      # (the FreeLB steps perturb the features)
         return h0
 
     @staticmethod
@@ -673,7 +674,12 @@ class ImageStreamFn(torch.autograd.Function):
                                       seed_img=seed('img'), p_drop=p_drop)
         ops.gemm_wgrad(de, ximg16, ar.g('image_embeddings.image_embeddings.weight'))
         ar.touch(*[n for n in ar.names if n.startswith('image_embeddings.')])
-        return (None,) * 9
+        d_ximg = None
+        if ctx.x_img_meta is not None:
+            # de rows are in the (r, b) order of ximg16, like in EncoderFn
+            d_rows = ops.gemm_nt(de, _transposed(ar.w('image_embeddings.image_embeddings.weight')), L.EPI_NONE)
+            d_ximg = d_rows.view(R, B, 2048).to(device=ctx.x_img_meta[1], dtype=ctx.x_img_meta[0])
+        return (None, None, d_ximg) + (None,) * 6
 
 
 class DecoderFn(torch.autograd.Function):
@@ -686,7 +692,7 @@ class DecoderFn(torch.autograd.Function):
     gradients go to the arena."""
 
     @staticmethod
-    def forward(ctx, anchor, model, x, lengths, src_enc, src_len, langs, p_drop, p_attn, seed_step, positions=None):
+    def forward(ctx, anchor, model, x, lengths, src_enc, src_len, langs, p_drop, p_attn, seed_step, positions=None, text_embed=None):
         ar = model.arena()
         ar.refresh()
         dev = ar.device
@@ -697,10 +703,11 @@ class DecoderFn(torch.autograd.Function):
         dseed = lambda k, i=0: rng.stream_seed(model.base_seed, seed_step, _DEC_SITE0 + 8 * i + k)   # noqa: E731
         x = x.to(dev).contiguous()
         table, tok = ar.w('embeddings.weight'), x
-        if langs is not None or positions is not None:
+        if langs is not None or positions is not None or text_embed is not None:
             # rows assembled here instead of gathered by the kernel: + the language embedding; explicit positions (the MASS
             # step decodes a span at its ORIGINAL positions, xtrainer.py:1684) as P[pos] - P[t], the kernel adds P[t] back
-            rows = table[x.t()].float()
+            # (text_embed: caller-made word rows (B, T, d) instead of Emb[x] - transformer.py:1053-1056, the FreeLB captioning step)
+            rows = table[x.t()].float() if text_embed is None else text_embed.detach().to(dev).float()
             if langs is not None:
                 langs = langs.to(dev).contiguous()
                 rows = rows + ar.p('cross_lang_embeddings.weight')[langs.t()]
@@ -759,6 +766,7 @@ class DecoderFn(torch.autograd.Function):
         ctx.dims = (B, T, S, d, H, dh, nL)
         ctx.drop = (p_drop, p_attn, seed_step)
         ctx.saved = (x, totlen, rowmask, emb_saved, saved, src16, src_klen, langs, positions)
+        ctx.text_meta = (text_embed.dtype, text_embed.device, text_embed.requires_grad) if text_embed is not None else None
         ctx.src_meta = (src_enc.dtype, src_enc.requires_grad) if has_src else None
         hook = model.ddp_hook
         ctx.track = hook is not None
@@ -839,7 +847,8 @@ class DecoderFn(torch.autograd.Function):
             if hook is not None:
                 hook.layer_done(i, last)
         tok_rows = None
-        own_rows = langs is not None or positions is not None
+        own_rows = langs is not None or positions is not None or ctx.text_meta is not None
+        g_text = None
         if own_rows or (hook is not None and hook.active):
             tok_rows = torch.empty((T * B, d), dtype=BF16, device=dh_.device)
         grads = dict(
@@ -867,7 +876,13 @@ class DecoderFn(torch.autograd.Function):
                 rows32 = tok_rows.float()
                 gpos.index_add_(0, positions.reshape(-1), rows32)
                 gpos[:T].sub_(rows32.view(T, B, d).sum(dim=1))
-            if hook is None or not hook.active:
+            if ctx.text_meta is not None:
+                # the word rows were the caller's: their gradient goes back to autograd, nothing to the embedding matrix here
+                assert hook is None or not hook.active, 'text_embed on the decoder is single-GPU (no token-row exchange for it)'
+                if ctx.text_meta[2]:
+                    g_text = tok_rows.view(T, B, d).transpose(0, 1).to(device=ctx.text_meta[1], dtype=ctx.text_meta[0])
+                tok_rows = None
+            elif hook is None or not hook.active:
                 ops.scatter_add_token_rows(tok_rows, x.contiguous().view(-1), ar.g('embeddings.weight'), model.pad_index)
                 tok_rows = None
         if hook is not None:
@@ -875,7 +890,7 @@ class DecoderFn(torch.autograd.Function):
         g_src = None
         if has_src and ctx.src_meta[1]:
             g_src = d_src.view(B, S, d).to(ctx.src_meta[0])
-        return (None, None, None, None, g_src, None, None, None, None, None, None)
+        return (None, None, None, None, g_src, None, None, None, None, None, None, g_text)
 
 
 class MLMHeadFn(torch.autograd.Function):

@@ -456,7 +456,7 @@ class TransformerModel(nn.Module):
                 assert cache is None
                 T, B = x.size()
                 out = Fn.DecoderFn.apply(self.layer_norm_emb.weight, self, x, lengths, src_enc, src_len, langs, self.dropout,
-                                         self.attention_dropout, self._next_seed_step(), positions)
+                                         self.attention_dropout, self._next_seed_step(), positions, kw.get('text_embed'))
                 return out.view(B, T, self.dim).transpose(0, 1)
             from .. import decoder
             return decoder.decoder_forward(self, x, lengths, src_enc=src_enc, src_len=src_len, positions=positions,

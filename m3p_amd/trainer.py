@@ -833,6 +833,73 @@ class XTrainer(Trainer):
         self.stats['processed_w'] += bs * enc.size(1)
         return tb_loss
 
+    def get_ic_output(self, params, model, x2, len2, x1, len1, img_loc, langs, langs_img, pred_mask, y, adv_text_embed):
+        """:2737-2753: the captioning pass with (optionally) caller-made word rows on the decoder side."""
+        enc1 = model('crossfwd', stream_='img', x=x1, lengths=len1, langs=langs_img, causal=False, image_loc=img_loc,
+                     refine_image=getattr(params, 'refine_image', False)).transpose(0, 1)
+        dec2 = model('crossfwd', stream_='text', x=x2, lengths=len2, langs=langs, causal=True, src_enc=enc1, src_len=len1,
+                     text_embed=adv_text_embed)
+        _, loss = model('predict', tensor=dec2, pred_mask=pred_mask, y=y, get_scores=False)
+        return loss, dec2
+
+    def free_lb_ic_step(self, dataset='coco', input_stream='img', lambda_coeff=1):
+        """FreeLB captioning step (xtrainer.py:2853-2962; train_x.py:454-455): three captioning passes over one batch with the
+        caption's word embeddings (``params.free_text``) and / or the region features (``params.free_img``) perturbed, every
+        pass an optimizer step on loss / 3, one normalised ascent step on the perturbations in between."""
+        assert lambda_coeff >= 0
+        if lambda_coeff == 0:
+            return None
+        params = self.params
+        model = self.model
+        model.train()
+        assert getattr(_unwrap(model), 'ddp_hook', None) is None or not params.multi_gpu, 'FreeLB steps are single-GPU in this build'
+        self._dp_plan(True, expect=('mlm',))
+        (x2, len2), (x1, x1_mask, img_loc, _img_id) = self.get_batch('txt2img', dataset, input_stream)
+        ft = getattr(params, 'ft_lgs', None) or []
+        lang_id = params.lang2id[ft[0]] if len(ft) > 0 else params.lang2id['en']
+        langs = x2.clone().fill_(lang_id)
+        alen = torch.arange(int(len2.max()), dtype=torch.long, device=len2.device)
+        pred_mask = alen[:, None] < len2[None] - 1
+        y = x2[1:].masked_select(pred_mask[:-1])
+        n_words = int((len2 - 1).sum())
+        assert len(y) == n_words
+        len1 = x1_mask.sum(dim=1)
+        x1 = x1.transpose(0, 1)
+        img_loc = img_loc.transpose(0, 1)
+        langs_img = x1_mask.transpose(0, 1).clone().long().fill_(lang_id)
+        x1, len1, img_loc, x2, len2, y, langs, langs_img, pred_mask = to_cuda(x1, len1, img_loc, x2, len2, y, langs, langs_img, pred_mask)
+        x1 = x1.contiguous()
+        free_text, free_img = getattr(params, 'free_text', False), getattr(params, 'free_img', False)
+        if free_text:
+            embeds_init, delta = self.deal_freelb_delta(model, x2.transpose(0, 1), len2)
+        if free_img:
+            image_delta = self.deal_image_freelb_delta(x1)
+        adv_steps, tb_loss = 3, 0.0
+        for astep in range(adv_steps):
+            text_imb, img_imb = None, x1
+            if free_text:
+                delta.requires_grad_()
+                text_imb = delta + embeds_init
+                _unwrap(model).arena().touch('embeddings.weight')
+            if free_img:
+                image_delta.requires_grad_()
+                img_imb = x1 + image_delta
+            loss, _dec = self.get_ic_output(params, model, x2, len2, img_imb, len1, img_loc, langs, langs_img, pred_mask, y, text_imb)
+            loss = loss / (1.0 * adv_steps)
+            self.free_optimize(loss)
+            tb_loss = tb_loss + loss.detach()
+            if astep == adv_steps - 1:
+                break
+            if free_text:
+                embeds_init, delta = self.update_freelb_delta(model, delta, embeds_init, x2.transpose(0, 1))
+            if free_img:
+                image_delta = self.update_image_freelb_delta(x1, image_delta)
+        self._stat('FRLB-IC-%s-%s' % (dataset, input_stream), tb_loss)
+        self.n_sentences += params.batch_size
+        self.stats['processed_s'] += len2.size(0)
+        self.stats['processed_w'] += n_words
+        return tb_loss
+
     def freelb_t2i_step(self, batches, dataset='coco', lambda_coeff=1):
         return self._freelb_rel_step(batches, dataset, 't2i', lambda_coeff)
 

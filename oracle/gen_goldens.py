@@ -955,6 +955,49 @@ def gen_freelb_goldens():
     print('freelb_step.npz: loss %.6f, %d updates, %d embedding rows moved' % (float(g['loss']), int(g['n_updates']), int(g['emb_rows_moved'])))
 
 
+def gen_freelb_ic_goldens():
+    """freelb_ic_step.npz: the reference's free_lb_ic_step (xtrainer.py:2853-2962) on the captioning case (synth.ic_case) through
+    the shimmed trainer, CPU, dropout 0, torch seed fixed, both perturbations on: summed loss of the three passes, schedule
+    state, parameter displacements after its three optimizer steps."""
+    from src.model.transformer import TransformerModel
+    xt, tr0, _, P0, _ = _reference_trainer(synth.CONFIGS['cfg1'])
+    P, sd, x_img, loc, img_len, x2, len2 = synth.ic_case()
+    for k, v in vars(P0).items():                    # the trainer fields of the shimmed run, on the captioning model's params
+        if not hasattr(P, k):
+            setattr(P, k, v)
+    P.langs, P.ft_lgs, P.free_text, P.free_img, P.refine_encoder, P.batch_size = ['en', 'zh'], [], True, True, False, x2.size(1)
+    for k in list(vars(P)):                          # the first trainer parsed its lambda strings in place: hand the new one strings again
+        if k.startswith('lambda_'):
+            if k.endswith('_config'):
+                delattr(P, k)
+            else:
+                setattr(P, k, '1')
+    torch.manual_seed(0)
+    m = TransformerModel(P, is_encoder=True, with_output=True, is_crossModal=True)
+    own = dict(m.named_parameters())
+    with torch.no_grad():
+        for k, v in sd.items():
+            own[k].copy_(v)
+    tr = xt.XTrainer(m, {}, P)
+    R, B = x_img.shape[0], x_img.shape[1]
+    # (region tensors as transposed views, all regions valid: see gen_freelb_goldens)
+    batch = ((x2, len2), (x_img.transpose(0, 1), torch.ones(B, R, dtype=torch.long), loc.transpose(0, 1), list(range(B))))
+    tr.get_batch = lambda *a, **k: batch
+    tr.stats['FRLB-IC-coco-img'] = []
+    names = ('embeddings.weight', 'image_embeddings.image_embeddings.weight', 'encoder_attn.0.k_lin.weight', 'attentions.1.q_lin.weight',
+             'cross_lang_embeddings.weight')
+    before = {k: own[k].detach().clone() for k in names}
+    torch.manual_seed(777)
+    tr.free_lb_ic_step('coco', 'img', 1.0)
+    g = {'loss': np.asarray(tr.stats['FRLB-IC-coco-img'][-1]), 'lr': np.asarray(tr.optimizers['model'].param_groups[0]['lr']),
+         'n_updates': np.asarray(tr.optimizers['model'].param_groups[0]['num_updates']),
+         'processed': np.asarray([tr.stats['processed_s'], tr.stats['processed_w']])}
+    for k, v in before.items():
+        g['dnorm/' + k] = (own[k].detach() - v).norm().numpy()
+    np.savez_compressed(os.path.join(OUT, 'freelb_ic_step.npz'), **g)
+    print('freelb_ic_step.npz: loss %.6f, %d updates' % (float(g['loss']), int(g['n_updates'])))
+
+
 def gen_decoder_goldens():
     """decoder.npz: the reference's causal decoder (TransformerModel(is_encoder=False)) on the deterministic cases of
     m3p_amd.synth.DECODER_CASES - teacher-forced crossfwd(causal=True, src_enc) hidden states, the same computed
@@ -1023,7 +1066,7 @@ def gen_decoder_goldens():
 
 if __name__ == '__main__':
     single = {'enum': gen_state_dict_enumeration, 'host': gen_host_goldens, 'mt': gen_mt_goldens, 'noise': gen_noise_goldens, 'ic': gen_ic_goldens, 'langs': gen_text_langs_goldens,
-              'decoder': gen_decoder_goldens, 'refiner': gen_refiner_goldens, 'mt_ic': gen_mt_ic_goldens, 'data': gen_data_goldens, 'ic_refine': gen_ic_refine_goldens, 'spans': gen_span_mask_goldens, 'mass': gen_mass_goldens, 'img_noise': gen_img_noise_goldens, 'freelb': gen_freelb_goldens}
+              'decoder': gen_decoder_goldens, 'refiner': gen_refiner_goldens, 'mt_ic': gen_mt_ic_goldens, 'data': gen_data_goldens, 'ic_refine': gen_ic_refine_goldens, 'spans': gen_span_mask_goldens, 'mass': gen_mass_goldens, 'img_noise': gen_img_noise_goldens, 'freelb': gen_freelb_goldens, 'freelb_ic': gen_freelb_ic_goldens}
     if len(sys.argv) > 1:
         single[sys.argv[1]]()
         sys.exit(0)
@@ -1032,5 +1075,5 @@ if __name__ == '__main__':
                gen_decoder_goldens, gen_text_langs_goldens, gen_mt_goldens, gen_ic_goldens, gen_noise_goldens,
                gen_mt_ic_goldens, gen_data_goldens, gen_ic_refine_goldens,
                gen_span_mask_goldens, gen_mass_goldens, gen_img_noise_goldens,
-               gen_freelb_goldens):
+               gen_freelb_goldens, gen_freelb_ic_goldens):
         fn()

@@ -243,7 +243,8 @@ def attention_kv(x, kv, mask, sd, prefix, n_heads):
     return F.linear(ctx, sd[prefix + 'out_lin.weight'], sd[prefix + 'out_lin.bias'])
 
 
-def decoder_crossfwd(sd, n_layers, n_heads, x, lengths, src_enc=None, src_len=None, positions=None, langs=None, enc_mask=None):
+def decoder_crossfwd(sd, n_layers, n_heads, x, lengths, src_enc=None, src_len=None, positions=None, langs=None, enc_mask=None,
+                     text_embed=None):
     """TransformerModel.crossfwd(stream_='text', causal=True, src_enc, src_len) in eval mode, transformer.py:1005-1102:
     mask[b, s] = s < lengths[b]; the causal attention mask is position-only (:70-71: key <= query, padded keys inside
     the window ARE attended); Emb[x] + Pos (+ Lang) -> LN_emb -> * mask; per layer self-attention -> LN1 ->
@@ -253,7 +254,8 @@ def decoder_crossfwd(sd, n_layers, n_heads, x, lengths, src_enc=None, src_len=No
     mask = alen[None, :] < lengths[:, None]
     attn_mask = (alen[None, None, :] <= alen[None, :, None]).expand(B, T, T)
     pos = alen[None, :].expand(B, T) if positions is None else positions.t()
-    h = F.embedding(x.t(), sd['embeddings.weight']) + F.embedding(pos, sd['position_embeddings.weight'])
+    tok = F.embedding(x.t(), sd['embeddings.weight']) if text_embed is None else text_embed      # (:1053-1056)
+    h = tok + F.embedding(pos, sd['position_embeddings.weight'])
     if langs is not None:
         h = h + F.embedding(langs.t(), sd['cross_lang_embeddings.weight'])
     h = layer_norm(h, sd['layer_norm_emb.weight'], sd['layer_norm_emb.bias'])

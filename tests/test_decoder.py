@@ -813,3 +813,76 @@ def test_bart_img_step_vs_oracle():
     bad = [(k, rel_l2(grads[k], ref[k].grad.numpy())) for k in names]
     assert not [b for b in bad if b[1] > 4e-2], bad
     assert 'IDA-coco' in tr.stats and tr.stats['processed_s'] == B
+
+
+@pytest.mark.gpu
+def test_free_lb_ic_step_tracks_the_reference_run():
+    """free_lb_ic_step (xtrainer.py:2853-2962): three captioning passes with the caption's word rows (decoder text_embed) and the
+    region features perturbed, each an optimizer step, an ascent step on both perturbations in between - against the same
+    call on the reference's XTrainer on CPU under the same torch seed (tests/golden/freelb_ic_step.npz)."""
+    from m3p_amd.model.transformer import TransformerModel
+    from m3p_amd.trainer import XTrainer
+    G = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'freelb_ic_step.npz'))
+    P, sd, x_img, loc, img_len, x2, len2 = synth.ic_case()
+    _step_params(P, ft_lgs=[], free_text=True, free_img=True, cross_modal_steps=[('coco', 'img')], batch_size=x2.size(1))
+    R, B = x_img.shape[0], x_img.shape[1]
+    torch.manual_seed(0)
+    m = TransformerModel(P, is_encoder=True, with_output=True, is_crossModal=True).cuda()
+    m.load_state_dict(sd, strict=False)
+    tr = XTrainer(m, {}, P)
+    batch = ((x2, len2), (x_img.transpose(0, 1).contiguous(), torch.ones(B, R, dtype=torch.long), loc.transpose(0, 1).contiguous(), list(range(B))))
+    tr.get_batch = lambda *a, **k: batch
+    own = dict(m.named_parameters())
+    names = [k[6:] for k in G.files if k.startswith('dnorm/')]
+    before = {k: own[k].detach().clone() for k in names}
+    torch.manual_seed(777)
+    loss = tr.free_lb_ic_step('coco', 'img', 1.0)
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(G['loss'])) < 1e-2
+    group = tr.optimizers['model'].param_groups[0]
+    assert group['num_updates'] == int(G['n_updates']) == 3 and abs(group['lr'] - float(G['lr'])) < 1e-15
+    assert [tr.stats['processed_s'], tr.stats['processed_w']] == G['processed'].tolist()
+    for k in names:
+        moved = float((own[k].detach() - before[k]).norm())
+        assert abs(moved - float(G['dnorm/' + k])) < 0.1 * float(G['dnorm/' + k]), (k, moved, float(G['dnorm/' + k]))
+    assert 'FRLB-IC-coco-img' in tr.stats
+
+
+@pytest.mark.gpu
+def test_decoder_text_embed_and_region_feature_gradients_vs_oracle():
+    """What the FreeLB captioning step ascends along: d loss / d text_embed through DecoderFn and d loss / d x_img through the
+    image stream, against the oracle's autograd (and text_embed = Emb[x] reproduces the plain pass)."""
+    from m3p_amd.model.transformer import TransformerModel
+    P, sd, x_img, loc, img_len, x2, len2 = synth.ic_case()
+    _step_params(P)
+    R, B = x_img.shape[0], x_img.shape[1]
+    torch.manual_seed(0)
+    m = TransformerModel(P, is_encoder=True, with_output=True, is_crossModal=True).cuda()
+    m.load_state_dict(sd, strict=False)
+    m.train()
+    P.dropout = P.attention_dropout = 0
+    langs, langs_img = x2.clone().fill_(0), torch.zeros((R, B), dtype=torch.long)
+    pred_mask, y = synth.mt_targets(x2, len2)
+
+    def run(model_rows, feats):
+        enc = m('crossfwd', stream_='img', x=feats, lengths=img_len.cuda(), langs=langs_img.cuda(), causal=False, image_loc=loc.cuda(),
+                refine_image=False).transpose(0, 1)
+        dec = m('crossfwd', stream_='text', x=x2.cuda(), lengths=len2.cuda(), langs=langs.cuda(), causal=True, src_enc=enc, src_len=img_len.cuda(),
+                text_embed=model_rows)
+        return m('predict', tensor=dec, pred_mask=pred_mask.cuda(), y=y.cuda(), get_scores=False)[1]
+    m.arena().zero_grad()
+    plain = run(None, x_img.cuda())
+    rows = sd['embeddings.weight'][x2.t()].cuda().requires_grad_(True)
+    feats = x_img.cuda().requires_grad_(True)
+    loss = run(rows, feats)
+    assert abs(float(loss) - float(plain)) < 2e-3
+    loss.backward()
+    ref_rows = sd['embeddings.weight'][x2.t()].clone().requires_grad_(True)
+    ref_feats = x_img.clone().requires_grad_(True)
+    enc = ref_cpu.crossfwd_img(sd, P.n_layers, P.n_heads, ref_feats, img_len, loc, langs=langs_img).transpose(0, 1)
+    dec = ref_cpu.decoder_crossfwd(sd, P.n_layers, P.n_heads, x2, len2, enc, img_len, langs=langs, text_embed=ref_rows)
+    o = ref_cpu.predict_mlm(sd, dec, pred_mask, y)
+    o = o[1] if isinstance(o, tuple) else o
+    o.backward()
+    assert abs(float(loss) - float(o.detach())) < 5e-3
+    assert rel_l2(rows.grad.float(), ref_rows.grad) < 5e-2 and rel_l2(feats.grad.float(), ref_feats.grad) < 5e-2
