@@ -375,6 +375,34 @@ M3P_API int m3p_transpose_bf16(const void* src, void* dst, int rows, int cols, i
                                void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * Host-glue kernels (csrc/glue.hip): index / mask / loss arithmetic the reference does with chains of elementwise
+ * tensor ops around the hot path; one launch each, no host reads.
+ * ---------------------------------------------------------------------------------- */
+/* get_masks (transformer.py:59-78) for the prefix mask of jointfwd (:917-919): totlen[b] = lengths[b] (+ lengths_b[b]
+ * when given), rowmask[b*S + s] = s < totlen[b] */
+M3P_API int m3p_seq_masks(const int64_t* lengths, const int64_t* lengths_b, int B, int S, int32_t* totlen,
+                          uint8_t* rowmask, void* stream);
+/* The boolean gather of :1208 as row numbers: the k-th True entry (flat order i = t * inner + b) of mask [n_mask] ->
+ * rows[k] = (soff + t * s0 + b * s1) / d, the row of that position in the [*, d] buffer under a strided (T, B, d) view
+ * (element strides s0, s1, storage offset soff).  n_rows = the caller's count of True entries (host knowledge); a
+ * shorter mask leaves the tail at row 0.  n_mask <= 2^20. */
+M3P_API int m3p_mask_to_rows(const uint8_t* mask, int n_mask, int inner, long long s0, long long s1, long long soff,
+                             int d, int32_t* rows, int n_rows, void* stream);
+/* out[(i0 * n1 + i1), :] (bf16, contiguous) = in[i0 * s0 + i1 * s1 + (0 .. cols)] (fp32): the region features through
+ * the transposed view the model is handed (transformer.py:897-898) without materialising it.  cols, s0, s1 % 4 == 0 */
+M3P_API int m3p_cast_rows_f32_bf16(const float* in, long long s0, long long s1, int n0, int n1, int cols, void* out,
+                                   void* stream);
+/* out (bf16) = g[0] * in (bf16, or fp32 when in_is_f32), g a DEVICE scalar (an upstream gradient); n % 4 == 0 */
+M3P_API int m3p_scale_bf16_dev(const void* in, int in_is_f32, const float* g, void* out, long long n, void* stream);
+/* dst += g[0] * src (fp32), g a device scalar */
+M3P_API int m3p_axpy_dev_f32(float* dst, const float* src, const float* g, long long n, void* stream);
+/* ITM loss of xtrainer.py:2357-2372 on the device: scores fp32 [n_groups * sample_n], pos int64 [n_groups];
+ * loss[0] = w_ce * CE(scores.view(-1, sample_n), pos) + w_bce * BCEWithLogits(scores, one_hot(pos)) (both means);
+ * dscores = d loss / d scores */
+M3P_API int m3p_itm_loss_fwd_bwd(const float* scores, const int64_t* pos, int n_groups, int sample_n, float w_ce,
+                                 float w_bce, float* loss, float* dscores, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Hardware-semantics probes (used by tests/test_hw_probes.py only): each fills `out`
  * with what the instruction delivered so the test can compare with the documented map.
  * ---------------------------------------------------------------------------------- */

@@ -14,6 +14,7 @@ This module is forward only; the teacher-forced training pass of the same stream
 (``TransformerModel.crossfwd`` picks it in training mode), and calling ``decoder_forward`` itself with autograd enabled on
 a model in training mode raises.
 """
+import heapq
 import math
 
 import torch
@@ -195,36 +196,45 @@ def generate(model, src_enc, src_len, tgt_lang_id, max_len=200, sample_temperatu
 
 
 class BeamHypotheses(object):
-    """n-best list of finished hypotheses of one sentence (transformer.py:1518-1561)."""
+    """The n best finished hypotheses of one sentence, ranked by length-normalised log-probability (the bookkeeping of
+    transformer.py:1518-1561).  A bounded min-heap keyed on (score, arrival order): the root is the entry the next better
+    hypothesis evicts, `worst_score` is the root's score; among equal scores the earliest arrival goes first, which is
+    the tie-break of the reference's sort."""
 
     def __init__(self, n_hyp, max_len, length_penalty, early_stopping):
-        self.max_len = max_len - 1              # without <BOS>
+        self.n_hyp, self.early_stopping = n_hyp, early_stopping
         self.length_penalty = length_penalty
-        self.early_stopping = early_stopping
-        self.n_hyp = n_hyp
-        self.hyp = []
-        self.worst_score = 1e9
+        self._norm = float(max_len - 1) ** length_penalty      # longest possible hypothesis (without <BOS>)
+        self._heap, self._arrivals = [], 0
 
     def __len__(self):
-        return len(self.hyp)
+        return len(self._heap)
+
+    @property
+    def hyp(self):
+        """[(score, tokens)] in arrival order."""
+        return [(s, t) for s, _, t in sorted(self._heap, key=lambda e: e[1])]
+
+    @property
+    def worst_score(self):
+        return self._heap[0][0] if self._heap else 1e9
+
+    def best(self):
+        """Tokens of the best hypothesis (the earliest among equals)."""
+        return max(self._heap, key=lambda e: (e[0], -e[1]))[2]
 
     def add(self, hyp, sum_logprobs):
-        score = sum_logprobs / len(hyp) ** self.length_penalty
-        if len(self) < self.n_hyp or score > self.worst_score:
-            self.hyp.append((score, hyp))
-            if len(self) > self.n_hyp:
-                ranked = sorted((s, k) for k, (s, _) in enumerate(self.hyp))
-                del self.hyp[ranked[0][1]]
-                self.worst_score = ranked[1][0]
-            else:
-                self.worst_score = min(score, self.worst_score)
+        entry = (sum_logprobs / len(hyp) ** self.length_penalty, self._arrivals, hyp)
+        self._arrivals += 1
+        if len(self._heap) < self.n_hyp:
+            heapq.heappush(self._heap, entry)
+        elif entry[0] > self._heap[0][0]:
+            heapq.heapreplace(self._heap, entry)
 
     def is_done(self, best_sum_logprobs):
-        if len(self) < self.n_hyp:
-            return False
-        if self.early_stopping:
-            return True
-        return self.worst_score >= best_sum_logprobs / self.max_len ** self.length_penalty
+        """Can no open beam still enter the list?  (always, once it is full, under early stopping)"""
+        full = len(self._heap) >= self.n_hyp
+        return full and (self.early_stopping or self.worst_score >= best_sum_logprobs / self._norm)
 
 
 def generate_beam(model, src_enc, src_len, tgt_lang_id, beam_size, length_penalty, early_stopping, max_len=200):
@@ -294,7 +304,7 @@ def generate_beam(model, src_enc, src_len, tgt_lang_id, beam_size, length_penalt
     tgt_len = torch.zeros(bs, dtype=torch.long, device=dev)
     best = []
     for i, hp in enumerate(hyps):
-        best_hyp = max(hp.hyp, key=lambda v: v[0])[1]
+        best_hyp = hp.best()
         tgt_len[i] = len(best_hyp) + 1                      # + <EOS>
         best.append(best_hyp)
     decoded = torch.full((int(tgt_len.max()), bs), model.pad_index, dtype=torch.long, device=dev)

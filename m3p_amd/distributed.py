@@ -140,6 +140,8 @@ class DataParallel(torch.nn.Module):
             self._ranges[('layer', i)] = r
         self.vocab_dense = True      # plan of the current step: does an MLM head feed the vocabulary matrix?
         self._live = 0               # encoder passes that still owe a backward
+        self._live_streams = 0       # image-stream passes (ImageStreamFn) that still owe a backward: their gradients land
+                                     # in the 'embed' range AFTER the encoder pass they feed has finished its own backward
         self._launched = set()
         self._tokens = []            # [(ids [n] int64, rows [n, d] bf16, n_max over ranks)]
         self._tokens_out = None
@@ -214,9 +216,21 @@ class DataParallel(torch.nn.Module):
         if ids is not None and self.world > 1:
             self._tokens.append((ids, rows, int(n_max)))
         if last:
-            self._launch('embed')
+            if self._live_streams == 0:      # else the image stream's backward still owes gradients inside this range
+                self._launch('embed')
             self._exchange_tokens()
         self.encoder_backward_end()
+
+    def stream_forward(self):
+        """An image-stream pass (functional.ImageStreamFn) that will be differentiated: it feeds an encoder pass in
+        layers-only mode, and its backward - the image projection / location / LayerNorm / language-table / refiner
+        gradients, all inside the 'embed' range - runs after that encoder pass's."""
+        self._live_streams += 1
+
+    def stream_backward_end(self):
+        self._live_streams = max(self._live_streams - 1, 0)
+        if self._live_streams == 0 and self._live == 0:
+            self._launch('embed')
 
     def _exchange_tokens(self):
         if self.world == 1 or not self.reducer.enabled or not self._tokens or self._tokens_out is not None:
@@ -291,5 +305,6 @@ class DataParallel(torch.nn.Module):
         self._launched = set()
         self._finished = False
         self._live = 0
+        self._live_streams = 0
         self._tokens = []
         self._tokens_out = None

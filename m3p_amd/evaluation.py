@@ -10,9 +10,16 @@ Differences from the reference, on purpose:
   * scores stay on the device until the metric is read;
   * images are sharded over ranks by stride (the reference slices the image list by
     ``local_rank``, dataset_finetune.py:1218-1219) and the shards can be all-gathered.
+
+Valid-set matching accuracy (``evaluate_t2i`` / ``evaluate_i2t`` / ``evaluate_understanding_tasks``,
+xevaluator.py:1262-1417): each dataset item contributes ``sample_n`` (text, image) sequences, one of them the true
+pair; a group counts as correct when its highest relation score sits on ``pos_labels``.
 """
+import numpy as np
 import torch
 import torch.distributed as dist
+
+from .utils import to_cuda
 
 
 @torch.no_grad()
@@ -96,3 +103,60 @@ def retrieval_recalls(scores, labels):
     first = torch.where(hit.any(dim=1), hit.float().argmax(dim=1), torch.full((n_img,), 10**6, device=scores.device))
     out += [float((first < k).sum()) / n_img for k in (1, 5, 10)]
     return tuple(out)
+
+
+@torch.no_grad()
+def _matching_accuracy(model, params, batch):
+    """One collate batch -> (#groups whose best-scoring member is the labelled pair, #groups).  Both layouts the
+    reference unpacks: the pre-training tuples (t2i: (x1, len1, labels), (img, mask, loc, obj, pos, ori, ids); i2t with
+    the extra (x2, len2) and CLCM labels) and the fine-tuning one ((x1, len1, lang_p), (img, mask, loc, pos, ids)).
+    The per-position language ids the reference assembles (:1317-1326) feed ``langs``, which jointfwd ignores
+    (transformer.py:937-938) - not built."""
+    model = getattr(model, 'module', model)
+    was_training = model.training
+    model.eval()
+    text, visual = batch[0], batch[-1]
+    x1, len1 = text[0], text[1]
+    if getattr(params, 'is_pretrain', False):
+        if len(batch) == 3:                 # i2t: (clcm_labels, img, img_mask, img_loc, obj_labels, pos_labels, img_ori, img_ids)
+            img, img_mask, img_loc, pos_labels = visual[1], visual[2], visual[3], visual[5]
+        else:                               # t2i: (img, img_mask, img_loc, obj_labels, pos_labels, img_ori, img_ids)
+            img, img_mask, img_loc, pos_labels = visual[0], visual[1], visual[2], visual[4]
+    else:                                   # (img, img_mask, img_loc, pos_labels, img_ids); retrieval_collate adds obj_labels
+        img, img_mask, img_loc = visual[0], visual[1], visual[2]
+        pos_labels = visual[4] if len(visual) == 6 else visual[3]
+    img_len = img_mask.sum(dim=1)
+    x1, len1, x_img, loc, img_len = to_cuda(x1, len1, img.transpose(0, 1), img_loc.transpose(0, 1), img_len)
+    enc = model('jointfwd', x=x1, lengths=len1, x_img=x_img, lengths_img=img_len, causal=False, langs=None,
+                image_loc=loc, refine_image=getattr(params, 'refine_image', False))
+    scores = model('predict', tensor=enc.transpose(0, 1), is_relation=True)
+    pred = scores.view(-1, params.sample_n).float().argmax(dim=1).cpu()         # the step's one device read
+    label = torch.from_numpy(np.asarray(pos_labels)).reshape(-1)
+    if was_training:
+        model.train()
+    return int((pred == label).sum()), int(label.numel())
+
+
+def evaluate_t2i(model, params, batch):
+    """xevaluator.py:1309-1359."""
+    return _matching_accuracy(model, params, batch)
+
+
+def evaluate_i2t(model, params, batch):
+    """xevaluator.py:1361-1417 (the same arithmetic on the i2t tuple)."""
+    return _matching_accuracy(model, params, batch)
+
+
+def evaluate_understanding_tasks(model, params, iterator, scores, data_set, lang1, lang2):
+    """xevaluator.py:1262-1307: accumulates both accuracies over ``iterator`` (pairs of (t2i_batch, i2t_batch), what
+    ``get_iterator(data_set, lang1, lang2)`` yields there) into ``scores`` under the reference's keys."""
+    assert data_set in ('valid', 'test')
+    t2i_acc = t2i_n = i2t_acc = i2t_n = 0
+    for t2i_batch, i2t_batch in iterator:
+        a, n = evaluate_t2i(model, params, t2i_batch)
+        t2i_acc, t2i_n = t2i_acc + a, t2i_n + n
+        a, n = evaluate_i2t(model, params, i2t_batch)
+        i2t_acc, i2t_n = i2t_acc + a, i2t_n + n
+    scores['%s_%s-%s_rel_t2i_acc' % (data_set, lang1, lang2)] = 100. * t2i_acc / t2i_n
+    scores['%s_%s-%s_rel_i2t_acc' % (data_set, lang1, lang2)] = 100. * i2t_acc / i2t_n
+    return scores

@@ -337,7 +337,65 @@ def refiner_bwd(model, dout, saved, keylen, B, R, seed_step, p):
     return dx
 
 
-N_ENC_ARGS = 15     # positional arguments of EncoderFn.forward (backward returns one None per argument)
+class GradSink:
+    """Where the heads of one encoder pass leave the gradient of its output.  The reference slices / transposes the
+    (S, B, d) output before every head (xtrainer.py:2287-2289, :2357), and autograd's backward of each of those views is
+    a zero-filled copy of the whole 64-MB tensor plus an add per extra head; here every head scatter-adds its few rows
+    into ONE zeroed row buffer (allocated by the first head that arrives) and returns no gradient for its input -
+    EncoderFn.backward takes the buffer.  Heads outside the protocol still work: their gradient arrives through
+    autograd and is added to the buffer's."""
+
+    def __init__(self):
+        self.buf = None
+
+    def rows(self, like):
+        if self.buf is None:
+            self.buf = torch.zeros_like(like)
+        assert self.buf.shape == like.shape
+        return self.buf
+
+    def take(self):
+        buf, self.buf = self.buf, None
+        return buf
+
+
+def _sink_of(tensor, base):
+    """The GradSink of the encoder pass ``tensor`` is a view of (None if it is not one, or if ``base`` - the [rows, d]
+    buffer the head indexes - is not exactly that pass's output)."""
+    root = tensor._base if tensor._is_view() else tensor
+    sink = getattr(root, '_m3p_sink', None) if root is not None else None
+    if sink is None or base is None or not torch.is_grad_enabled():
+        return None
+    if root.dim() != 2 or not root.is_contiguous() or root.storage_offset() != 0 or tuple(root.shape) != tuple(base.shape):
+        return None
+    return sink
+
+
+def first_rows_sink(model, tensor):
+    """For predict(is_relation=True) on ``tensor`` (B, S, d): (sink, base, rows) with rows = the row numbers of
+    tensor[:, 0] inside the encoder pass's [M, d] output, when tensor is a view of one; (None, None, None) otherwise."""
+    d = model.dim
+    if tensor.dim() != 3 or tensor.dtype != BF16 or not tensor._is_view():
+        return None, None, None
+    st, soff = tensor.stride(), tensor.storage_offset()
+    if st[2] != 1 or st[0] % d or soff % d:
+        return None, None, None
+    with torch.no_grad():
+        base = torch.as_strided(tensor, (tensor.untyped_storage().nbytes() // 2 // d, d), (d, 1), 0)
+    sink = _sink_of(tensor, base)
+    if sink is None:
+        return None, None, None
+    cache = model.__dict__.setdefault('_first_rows_cache', {})
+    key = (tensor.shape[0], st[0], soff, tensor.device)
+    rows = cache.get(key)
+    if rows is None:
+        rows = ((soff + torch.arange(tensor.shape[0], device=tensor.device, dtype=torch.int64) * st[0]) // d).to(torch.int32)
+        cache.clear()
+        cache[key] = rows
+    return sink, base, rows
+
+
+N_ENC_ARGS = 16     # positional arguments of EncoderFn.forward (backward returns one None per argument)
 
 
 class EncoderFn(torch.autograd.Function):
@@ -348,7 +406,7 @@ class EncoderFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, anchor, model, x, lengths, x_img, lengths_img, image_loc, p_drop, p_attn, seed_step, p_refine=None,
-                track=False, text_embed=None, langs=None, h0=None):
+                track=False, text_embed=None, langs=None, h0=None, positions=None):
         ar = model.arena()
         ar.refresh()
         dev = ar.device
@@ -358,12 +416,11 @@ class EncoderFn(torch.autograd.Function):
         if h0 is not None:
             # the layers alone on rows assembled elsewhere (the image-only stream, ImageStreamFn): h0 bf16 [B*S, d],
             # rows b*S + s, already masked; its gradient goes back to autograd
-            assert x is None and x_img is None and text_embed is None and langs is None
+            assert x is None and x_img is None and text_embed is None and langs is None and positions is None
             B = lengths.shape[0]
             S = h0.shape[0] // B
             T, R, M = S, 0, B * S
-            totlen = lengths.to(device=dev, dtype=torch.int32).contiguous()
-            rowmask = (torch.arange(S, device=dev, dtype=torch.int32)[None, :] < totlen[:, None]).to(torch.uint8).contiguous().view(-1)
+            totlen, rowmask = ops.seq_masks(lengths.to(device=dev, dtype=torch.int64).contiguous(), None, B, S)
             h = h0.detach().to(BF16).contiguous()
             ximg16 = loc = emb_saved = img_rows = img_saved = ref_saved = keylen_img = tok = None
         else:
@@ -383,23 +440,36 @@ class EncoderFn(torch.autograd.Function):
                 tok = (torch.arange(B, device=dev, dtype=torch.int64) * T)[None, :] + \
                     torch.arange(T, device=dev, dtype=torch.int64)[:, None]
                 tok = tok.contiguous()
-            if langs is not None:
+            if langs is not None or positions is not None:
                 # language embeddings of the text stream (transformer.py:1059-1060): the assembly kernel again gathers "token"
                 # b*T + t, now from the rows  Emb[x] + Lang[langs]  built here (one extra bf16 rounding of the sum); backward
-                # gets the rows' gradients back and scatters them into both tables
+                # gets the rows' gradients back and scatters them into both tables.  Explicit positions (TLM batches restart
+                # them at the second sentence, utils.py:324 concat_batches; transformer.py:1057-1058) enter the same rows as
+                # P[pos] - P[t]: the kernel adds P[t] back
                 assert text_embed is None and R == 0
-                langs = langs.to(dev).contiguous()
-                rows = table[x.t()].float() + ar.p('cross_lang_embeddings.weight')[langs.t()]
+                rows = table[x.t()].float()
+                if langs is not None:
+                    langs = langs.to(dev).contiguous()
+                    rows = rows + ar.p('cross_lang_embeddings.weight')[langs.t()]
+                if positions is not None:
+                    positions = positions.to(dev).contiguous()
+                    assert positions.size() == (T, B)
+                    ptab = ar.p('position_embeddings.weight')
+                    rows = rows + ptab[positions.t()] - ptab[:T][None, :, :]
                 table = rows.to(BF16).reshape(B * T, d).contiguous()
                 tok = ((torch.arange(B, device=dev, dtype=torch.int64) * T)[None, :] +
                        torch.arange(T, device=dev, dtype=torch.int64)[:, None]).contiguous()
-            totlen = lengths if R == 0 else (lengths + lengths_img)
-            totlen = totlen.to(device=dev, dtype=torch.int32).contiguous()
-            rowmask = (torch.arange(S, device=dev, dtype=torch.int32)[None, :] < totlen[:, None]).to(torch.uint8).contiguous().view(-1)
+            # prefix validity of [regions | words] (get_masks on lengths + lengths_img, transformer.py:917-919): one launch
+            totlen, rowmask = ops.seq_masks(lengths.to(device=dev, dtype=torch.int64).contiguous(),
+                                            None if R == 0 else lengths_img.to(device=dev, dtype=torch.int64).contiguous(), B, S)
 
             ximg16 = img_proj = loc = None
             if R > 0:
-                ximg16 = ops.cast_bf16(x_img.contiguous().view(R * B, 2048))
+                xi = x_img.detach().to(dev)
+                if xi.dtype == torch.float32 and xi.stride(2) == 1 and xi.stride(0) % 4 == 0 and xi.stride(1) % 4 == 0:
+                    ximg16 = ops.cast_rows_bf16(xi)         # reads the collate's (n, R, 2048) layout through the (R, n) view
+                else:
+                    ximg16 = ops.cast_bf16(xi.contiguous().view(R * B, 2048))
                 loc = image_loc.contiguous().float()
                 img_proj = ops.gemm_nt(ximg16, ar.w('image_embeddings.image_embeddings.weight'), L.EPI_BIAS,
                                        bias=ar.p('image_embeddings.image_embeddings.bias'))
@@ -447,6 +517,7 @@ class EncoderFn(torch.autograd.Function):
                        aux=h, seed=seed('attn_out', i), p_drop=p_drop)
             x1, mean1, rstd1 = ops.layernorm_fwd(pre1, ar.p('layer_norm1.%d.weight' % i), ar.p('layer_norm1.%d.bias' % i))
             hact8 = None
+            u_holds_grad = False     # does the pass below leave gelu'(u) in u's buffer? (backward then only multiplies)
             if M >= 1024 or st8 is not None:
                 # persistent GEMM: bias in the epilogue, GELU as its own HBM-speed pass
                 # The same pass leaves gelu'(u) in u's buffer: the backward dgrad then only multiplies
@@ -455,7 +526,8 @@ class EncoderFn(torch.autograd.Function):
                 if st8 is not None and 'w2' in fp8mod.FWD_SITES and 'w2' not in fp8mod.BWD_SITES and not _GELU_GRAD_IN_FWD:
                     hact, hact8 = st8.gelu_quant(u, i)           # GELU and the 8-bit copy for lin2 in one pass
                 else:
-                    hact = ops.gelu_fwd(u, grad_inplace=_GELU_GRAD_IN_FWD or (st8 is not None and 'w2' in fp8mod.BWD_SITES))
+                    u_holds_grad = _GELU_GRAD_IN_FWD or (st8 is not None and 'w2' in fp8mod.BWD_SITES)
+                    hact = ops.gelu_fwd(u, grad_inplace=u_holds_grad)
             else:
                 u = torch.empty((M, 4 * d), dtype=BF16, device=dev)
                 hact = ops.gemm_nt(x1, ar.w(f + 'lin1.weight'), L.EPI_BIAS_GELU, bias=ar.p(f + 'lin1.bias'), out2=u)
@@ -470,12 +542,14 @@ class EncoderFn(torch.autograd.Function):
         ctx.model = model
         ctx.dims = (B, T, R, S, d, H, dh, nL)
         ctx.drop = (p_drop, p_attn, seed_step)
+        ctx.u_holds_grad = nL > 0 and u_holds_grad
         # (backward wants the REAL token ids where they exist - pad rows, the scatter into the vocabulary matrix; with
         #  text_embed there are none and it gets the row numbers)
         ctx.saved = (tok if text_embed is not None else x, totlen, rowmask, ximg16, loc, emb_saved, saved_layers)
         ctx.refine = (ref_saved, keylen_img, p_refine)
         ctx.input_grads = (R > 0 and x_img.requires_grad and track, text_embed is not None)
         ctx.langs = langs
+        ctx.positions = positions
         ctx.h0_mode = None if h0 is None else h0.dtype
         # data parallelism: count the encoder passes that will be differentiated (only the last backward of a
         # step launches gradient buckets) and learn the token-row count the ranks pad to
@@ -483,6 +557,10 @@ class EncoderFn(torch.autograd.Function):
         ctx.track = bool(track) and hook is not None
         ctx.tok_rows_max = hook.encoder_forward(0 if h0 is not None else T * B) if ctx.track else None
         ctx.set_materialize_grads(False)
+        # gradient sink of this pass's output (see GradSink): the heads add their rows' gradients into one zeroed [M, d]
+        # buffer and hand autograd nothing; backward picks the buffer up here
+        ctx.sink = GradSink()
+        model._pending_sink = ctx.sink
         return h
 
     @staticmethod
@@ -498,13 +576,19 @@ class EncoderFn(torch.autograd.Function):
         ref_saved, keylen_img, p_refine = ctx.refine
         ctx.refine = None
         hook = model.ddp_hook if ctx.track else None
-        if dout is None:
+        sunk = ctx.sink.take()
+        if dout is None and sunk is None:
             if hook is not None:
                 hook.encoder_backward_end()
             return (None,) * N_ENC_ARGS
-        dh_ = dout.contiguous()
-        if dh_.dtype != BF16:
-            dh_ = dh_.to(BF16)
+        if dout is None:
+            dh_ = sunk
+        else:
+            dh_ = dout.contiguous()
+            if dh_.dtype != BF16:
+                dh_ = dh_.to(BF16)
+            if sunk is not None:          # a consumer outside the sink protocol handed autograd a gradient as well
+                dh_ = dh_ + sunk.view_as(dh_)
         last = hook.encoder_backward_begin() if hook is not None else True
         st8 = model.fp8_state() if model.fp8 else None
 
@@ -528,10 +612,8 @@ class EncoderFn(torch.autograd.Function):
             if dY2 is None:
                 dY2 = dpre2
             ops.gemm_wgrad(dY2, hact, ar.g(f + 'lin2.weight'))
-            dU = dgrad(dY2, i, 'dy2', 'w2', ar.wt[('lin2', i)],
-                       L.EPI_MUL if ((M >= 1024 and _GELU_GRAD_IN_FWD) or (st8 is not None and 'w2' in fp8mod.BWD_SITES))
-                       else L.EPI_DGELU, aux=u,
-                       colsum=ar.g(f + 'lin1.bias'))      # u holds gelu'(u) on the persistent path
+            dU = dgrad(dY2, i, 'dy2', 'w2', ar.wt[('lin2', i)], L.EPI_MUL if ctx.u_holds_grad else L.EPI_DGELU, aux=u,
+                       colsum=ar.g(f + 'lin1.bias'))
             del hact, u, pre2
             ops.gemm_wgrad(dU, x1, ar.g(f + 'lin1.weight'))
             dx1 = dgrad(dU, i, 'du', 'w1', ar.wt[('lin1', i)], L.EPI_RES, aux=dpre2)
@@ -559,9 +641,9 @@ class EncoderFn(torch.autograd.Function):
             return (None,) * (N_ENC_ARGS - 1) + (dh_.to(ctx.h0_mode),)
         # under data parallelism the token rows' gradients are exchanged as rows, not scattered here
         want_dximg, has_text_embed = ctx.input_grads
-        langs = ctx.langs
+        langs, positions = ctx.langs, ctx.positions
         tok_rows = None
-        if has_text_embed or langs is not None or (hook is not None and hook.active):
+        if has_text_embed or langs is not None or positions is not None or (hook is not None and hook.active):
             tok_rows = torch.empty((T * B, d), dtype=BF16, device=dh_.device)
         grads = dict(
             d_g_emb=ar.g('layer_norm_emb.weight'), d_be_emb=ar.g('layer_norm_emb.bias'),
@@ -600,12 +682,17 @@ class EncoderFn(torch.autograd.Function):
             ops.gemm_wgrad(onehot, tok_rows, dl)
             ar.g('cross_lang_embeddings.weight').add_(dl[:model.n_langs])
             ar.touch('cross_lang_embeddings.weight')
-            if hook is None or not hook.active:
-                ops.scatter_add_token_rows(tok_rows, x.contiguous().view(-1), ar.g('embeddings.weight'), model.pad_index)
-                tok_rows = None
+        if positions is not None:       # the rows held P[pos] - P[t] (rows t * B + b): the kernel's own dP[t] is taken back
+            gpos = ar.g('position_embeddings.weight')
+            rows32 = tok_rows.float()
+            gpos.index_add_(0, positions.reshape(-1), rows32)
+            gpos[:T].sub_(rows32.view(T, B, d).sum(dim=1))
+        if (langs is not None or positions is not None) and (hook is None or not hook.active):
+            ops.scatter_add_token_rows(tok_rows, x.contiguous().view(-1), ar.g('embeddings.weight'), model.pad_index)
+            tok_rows = None
         if hook is not None:
             hook.embed_done(last, ids=x if tok_rows is not None else None, rows=tok_rows, n_max=ctx.tok_rows_max)
-        return (None, None, None, None, d_ximg, None, None, None, None, None, None, None, d_text, None, None)
+        return (None, None, None, None, d_ximg, None, None, None, None, None, None, None, d_text, None, None, None)
 
 
 class ImageStreamFn(torch.autograd.Function):
@@ -615,7 +702,7 @@ class ImageStreamFn(torch.autograd.Function):
     x_img (R, B, 2048), image_loc (R, B, 5) -> bf16 [B*R, d] (rows b*R + r) for EncoderFn's layers-only mode."""
 
     @staticmethod
-    def forward(ctx, anchor, model, x_img, lengths, image_loc, langs, p_drop, seed_step, p_refine=None):
+    def forward(ctx, anchor, model, x_img, lengths, image_loc, langs, p_drop, seed_step, p_refine=None, track=False):
         ar = model.arena()
         ar.refresh()
         dev = ar.device
@@ -643,6 +730,11 @@ class ImageStreamFn(torch.autograd.Function):
         ctx.saved = (ximg16, loc, img_saved, totlen, mask, langs, ref_saved)
         ctx.meta = (B, R, d, p_drop, seed_step, p_refine)
         ctx.x_img_meta = (x_img.dtype, x_img.device) if x_img.requires_grad else None      # (the FreeLB steps perturb the features)
+        # data parallelism: this pass's gradients land in the 'embed' bucket after the encoder pass it feeds has run its
+        # backward - the reducer must not launch that bucket before stream_backward_end()
+        ctx.hook = model.ddp_hook if track else None
+        if ctx.hook is not None:
+            ctx.hook.stream_forward()
         return h0
 
     @staticmethod
@@ -679,7 +771,12 @@ class ImageStreamFn(torch.autograd.Function):
             # de rows are in the (r, b) order of ximg16, like in EncoderFn
             d_rows = ops.gemm_nt(de, _transposed(ar.w('image_embeddings.image_embeddings.weight')), L.EPI_NONE)
             d_ximg = d_rows.view(R, B, 2048).to(device=ctx.x_img_meta[1], dtype=ctx.x_img_meta[0])
-        return (None, None, d_ximg) + (None,) * 6
+        if ctx.hook is not None:
+            ctx.hook.stream_backward_end()
+        return (None, None, d_ximg) + (None,) * 7
+
+
+N_DEC_ARGS = 12     # positional arguments of DecoderFn.forward
 
 
 class DecoderFn(torch.autograd.Function):
@@ -784,11 +881,10 @@ class DecoderFn(torch.autograd.Function):
         ctx.saved = None
         dseed = lambda k, i=0: rng.stream_seed(model.base_seed, seed_step, _DEC_SITE0 + 8 * i + k)   # noqa: E731
         hook = model.ddp_hook if ctx.track else None
-        n_args = 10
         if dout is None:
             if hook is not None:
                 hook.encoder_backward_end()
-            return (None,) * n_args
+            return (None,) * N_DEC_ARGS
         dh_ = dout.contiguous()
         if dh_.dtype != BF16:
             dh_ = dh_.to(BF16)
@@ -899,11 +995,12 @@ class MLMHeadFn(torch.autograd.Function):
     into their own gradient in place by the CE kernel, so backward is two GEMMs."""
 
     @staticmethod
-    def forward(ctx, tensor, model, base, row_idx, y, scores_out):
+    def forward(ctx, tensor, model, base, row_idx, y, scores_out, sink=None):
         ar = model.arena()
         ar.refresh()
         d, V = model.dim, model.n_words
         n = int(y.shape[0])
+        ctx.sink = sink
         hsel = ops.gather_rows(base, row_idx, n, d)
         logits = torch.empty((n, ar.V_pad), dtype=BF16, device=hsel.device)
         n_cols = ar.V_pad if (_VOCAB_FULL_TILES and n >= 1024 and n % 256 == 0) else V   # whole tiles: the eight-wave kernel
@@ -931,7 +1028,7 @@ class MLMHeadFn(torch.autograd.Function):
         ctx.saved = None
         n = hsel.shape[0]
         g = gloss.reshape(1).float()
-        hs = (hsel.float() * g).to(BF16)
+        hs = ops.scale_bf16_dev(hsel, g)
         if _VOCAB_FULL_TILES and n >= 4096 and n % 64 == 0:
             # whole 256-row tiles of the vocabulary: the four-wave weight-gradient kernel.  The pad columns of dlogits are
             # exact zeros (the CE kernel wrote them), so rows V .. V_pad - 1 of "the matrix" - the head of the bias
@@ -941,20 +1038,18 @@ class MLMHeadFn(torch.autograd.Function):
         else:
             ops.gemm_wgrad(dlogits, hs, ar.g('embeddings.weight'), n=V, k=d)
         if dbias is not None:
-            ar.g('pred_layer.proj.bias').add_(dbias[:V] * g)
+            ops.axpy_dev(ar.g('pred_layer.proj.bias'), dbias[:V], g)
         else:
             ops.colsum(dlogits, V, ar.g('pred_layer.proj.bias'), scale=g)
         dH32 = torch.zeros((n, d), dtype=torch.float32, device=dlogits.device)
         ops.gemm_nn_streamk(dlogits, ar.w('embeddings.weight'), dH32)     # E [V, d] read in place: no transposed copy
-        dH = (dH32 * g).to(BF16)
-        # gradient wrt `tensor` (a strided view of the encoder output): build it on a zeroed
-        # twin of the underlying row buffer and hand autograd the same strided view of it
-        dbase = torch.zeros_like(base)
-        ops.scatter_add_rows(dH, row_idx, dbase, n, d)
-        dtensor = torch.as_strided(dbase, shape, stride, soff)
+        dH = ops.scale_bf16_dev(dH32, g)
+        # gradient wrt `tensor` (a strided view of the encoder output): the rows go to the pass's gradient sink, or - for a
+        # tensor that is not an encoder pass's output - onto a zeroed twin of the underlying row buffer
+        dtensor = _scatter_rows_grad(dH, row_idx, base, shape, stride, soff, ctx.sink)
         if model.ddp_hook is not None:
             model.ddp_hook.mlm_head_done()     # the dense part of the tied matrix is final: reduce it now
-        return dtensor, None, None, None, None, None
+        return dtensor, None, None, None, None, None, None
 
 
 def _as_row_buffer(tensor, d):
@@ -973,8 +1068,12 @@ def _as_row_buffer(tensor, d):
     return tensor, base, strides, soff
 
 
-def _scatter_rows_grad(dH, row_idx, base, shape, stride, soff):
-    """Gradient wrt a strided view of a row buffer: zeroed twin of the buffer + scatter-add of the selected rows."""
+def _scatter_rows_grad(dH, row_idx, base, shape, stride, soff, sink=None):
+    """Gradient wrt a strided view of a row buffer: zeroed twin of the buffer + scatter-add of the selected rows - or,
+    with the pass's GradSink, the rows go there and autograd gets nothing (GradSink)."""
+    if sink is not None:
+        ops.scatter_add_rows(dH, row_idx, sink.rows(base), dH.shape[0], dH.shape[1])
+        return None
     dbase = torch.zeros_like(base)
     ops.scatter_add_rows(dH, row_idx, dbase, dH.shape[0], dH.shape[1])
     return torch.as_strided(dbase, shape, stride, soff)
@@ -988,11 +1087,12 @@ class ObjHeadFn(torch.autograd.Function):
     are the kernels of the encoder / MLM head; GELU backward is m3p_gelu_bwd."""
 
     @staticmethod
-    def forward(ctx, tensor, model, base, row_idx, y):
+    def forward(ctx, tensor, model, base, row_idx, y, sink=None):
         ar = model.arena()
         ar.refresh()
         d = model.dim
         n = int(y.shape[0])
+        ctx.sink = sink
         hsel = ops.gather_rows(base, row_idx, n, d)
         u = torch.empty((n, d), dtype=BF16, device=hsel.device)
         t = ops.gemm_nt(hsel, ar.w('transformer_obj.dense.weight'), L.EPI_BIAS_GELU, bias=ar.p('transformer_obj.dense.bias'), out2=u)
@@ -1028,7 +1128,7 @@ class ObjHeadFn(torch.autograd.Function):
         ops.colsum(du, d, ar.g('transformer_obj.dense.bias'))
         dH = torch.zeros((n, d), dtype=torch.float32, device=dev)
         ops.gemm_nn_streamk(du, ar.w('transformer_obj.dense.weight'), dH)
-        return _scatter_rows_grad(dH.to(BF16), row_idx, base, shape, stride, soff), None, None, None, None
+        return _scatter_rows_grad(dH.to(BF16), row_idx, base, shape, stride, soff, ctx.sink), None, None, None, None, None
 
 
 class MrfrHeadFn(torch.autograd.Function):
@@ -1036,11 +1136,12 @@ class MrfrHeadFn(torch.autograd.Function):
     on the masked regions + F.mse_loss against their original 2048-d features (xtrainer.py:2332-2352)."""
 
     @staticmethod
-    def forward(ctx, tensor, model, base, row_idx, target):
+    def forward(ctx, tensor, model, base, row_idx, target, sink=None):
         ar = model.arena()
         ar.refresh()
         d = model.dim
         n = int(target.shape[0])
+        ctx.sink = sink
         hsel = ops.gather_rows(base, row_idx, n, d)
         reg = ops.gemm_nt(hsel, ar.w('mrfr_dense.weight'), L.EPI_BIAS, bias=ar.p('mrfr_dense.bias'))
         sq, dreg = ops.mse_fwd_bwd(reg, target, 1.0 / (n * reg.shape[1]))
@@ -1057,11 +1158,11 @@ class MrfrHeadFn(torch.autograd.Function):
         n, d = hsel.shape
         g = gloss.reshape(1).float()
         ar.touch('mrfr_dense.weight', 'mrfr_dense.bias')
-        ops.gemm_wgrad(dreg, (hsel.float() * g).to(BF16), ar.g('mrfr_dense.weight'))
+        ops.gemm_wgrad(dreg, ops.scale_bf16_dev(hsel, g), ar.g('mrfr_dense.weight'))
         ops.colsum(dreg, dreg.shape[1], ar.g('mrfr_dense.bias'), scale=g)
         dH = torch.zeros((n, d), dtype=torch.float32, device=hsel.device)
         ops.gemm_nn_streamk(dreg, ar.w('mrfr_dense.weight'), dH)
-        return _scatter_rows_grad((dH * g).to(BF16), row_idx, base, shape, stride, soff), None, None, None, None
+        return _scatter_rows_grad(ops.scale_bf16_dev(dH, g), row_idx, base, shape, stride, soff, ctx.sink), None, None, None, None, None
 
 
 class DenseRowsFn(torch.autograd.Function):
@@ -1118,7 +1219,7 @@ def mrm_head(model, tensor, y_all):
     tensor, base, row_idx, pos = _masked_region_rows(tensor, y_all, model.dim)
     assert pos.numel() > 0, 'no masked region in the batch'
     y = y_all.reshape(-1).cpu()[pos].to(tensor.device)
-    return ObjHeadFn.apply(tensor, model, base, row_idx, y)
+    return ObjHeadFn.apply(tensor, model, base, row_idx, y, _sink_of(tensor, base))
 
 
 def mrfr_head(model, tensor, obj_labels, ori_att_feats):
@@ -1128,7 +1229,7 @@ def mrfr_head(model, tensor, obj_labels, ori_att_feats):
         return torch.zeros((), dtype=torch.float32, device=tensor.device)
     feats = ori_att_feats.reshape(-1, ori_att_feats.shape[-1])
     target = feats[pos.to(feats.device)].to(device=tensor.device, dtype=torch.float32).contiguous()
-    return MrfrHeadFn.apply(tensor, model, base, row_idx, target)
+    return MrfrHeadFn.apply(tensor, model, base, row_idx, target, _sink_of(tensor, base))
 
 
 class ItmHeadFn(torch.autograd.Function):
@@ -1138,9 +1239,10 @@ class ItmHeadFn(torch.autograd.Function):
     gradient arena (main-grad)."""
 
     @staticmethod
-    def forward(ctx, first, model, pooler='pooled_layer', rel='seq_relationship'):
+    def forward(ctx, first, model, pooler='pooled_layer', rel='seq_relationship', sink=None, base=None, row_idx=None):
         ar = model.arena()
         ar.refresh()
+        ctx.sink = (sink, base, row_idx)
         h16, pooled, scores = ops.itm_head_fwd(first, ar.w(pooler + '.dense.weight'), ar.p(pooler + '.dense.bias').detach(),
                                                ar.p(rel + '.weight').detach().view(-1), ar.p(rel + '.bias').detach())
         ctx.model = model
@@ -1152,7 +1254,7 @@ class ItmHeadFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dscores):
         if dscores is None:
-            return None, None, None, None
+            return (None,) * 7
         model = ctx.model
         ar = model.arena()
         pooler, rel = ctx.names
@@ -1163,7 +1265,33 @@ class ItmHeadFn(torch.autograd.Function):
                               ar.g(pooler + '.dense.weight'), ar.g(pooler + '.dense.bias'),
                               ar.g(rel + '.weight').view(-1), ar.g(rel + '.bias'))
         ar.touch(pooler + '.dense.weight', pooler + '.dense.bias', rel + '.weight', rel + '.bias')
-        return dh, None, None, None
+        sink, base, row_idx = ctx.sink
+        if sink is not None:       # the B first-position rows go to the pass's gradient sink (GradSink)
+            ops.scatter_add_rows(dh, row_idx, sink.rows(base), dh.shape[0], dh.shape[1])
+            dh = None
+        return (dh,) + (None,) * 6
+
+
+class ItmLossFn(torch.autograd.Function):
+    """xtrainer.py:2357-2372 on the device in one launch: multi_cls_loss_weight * CE over groups of sample_n scores +
+    bin_cls_loss_weight * BCE-with-logits against the one-hot labels (the reference moves the scores to the CPU for
+    this).  The kernel returns the loss and its gradient together."""
+
+    @staticmethod
+    def forward(ctx, scores, pos, sample_n, w_ce, w_bce):
+        sc = scores.detach().reshape(-1)
+        if sc.dtype != torch.float32:
+            sc = sc.float()
+        loss, dsc = ops.itm_loss_fwd_bwd(sc.contiguous(), pos, int(sample_n), w_ce, w_bce)
+        ctx.dsc, ctx.meta = dsc, (tuple(scores.shape), scores.dtype)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, gloss):
+        shape, dtype = ctx.meta
+        d = ctx.dsc * gloss.reshape(1).float()
+        ctx.dsc = None
+        return d.view(shape).to(dtype), None, None, None, None
 
 
 def mlm_head(model, tensor, pred_mask, y, want_scores):
@@ -1188,11 +1316,11 @@ def mlm_head(model, tensor, pred_mask, y, want_scores):
             base = tensor.view(T * B, d)
         s0, s1, soff = B * d, d, 0
     n = int(y.shape[0])
-    pm = pred_mask.to(tensor.device).reshape(-1)
-    # positions of the True entries in (t, b) order without a host sync: stable sort of ~mask
-    flat = torch.argsort((~pm.bool()).to(torch.uint8), stable=True)[:n]
-    t_idx, b_idx = flat // B, flat % B
-    row_idx = ((soff + t_idx * s0 + b_idx * s1) // d).to(torch.int32).contiguous()
+    pm = pred_mask.to(tensor.device)
+    if pm.dtype not in (torch.bool, torch.uint8):
+        pm = pm != 0
+    # rows of the True entries in (t, b) order: one compaction launch, no host sync (the count is y's length)
+    row_idx = ops.mask_to_rows(pm.contiguous(), B, s0, s1, soff, d, n)
     scores_out = [] if want_scores else None
-    loss = MLMHeadFn.apply(tensor, model, base, row_idx, y.to(tensor.device), scores_out)
+    loss = MLMHeadFn.apply(tensor, model, base, row_idx, y.to(tensor.device), scores_out, _sink_of(tensor, base))
     return loss, (scores_out[0] if want_scores else None)

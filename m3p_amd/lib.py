@@ -74,6 +74,12 @@ SIGNATURES = {
     'm3p_gelu_fwd_q8': (_i, [_p, _p, _p, C.c_longlong, _p, _p, _p]),
     'm3p_transpose_batch_bf16': (_i, [_p, _i, _i, _p]),
     'm3p_transpose_bf16': (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    'm3p_seq_masks': (_i, [_p, _p, _i, _i, _p, _p, _p]),
+    'm3p_mask_to_rows': (_i, [_p, _i, _i, C.c_longlong, C.c_longlong, C.c_longlong, _i, _p, _i, _p]),
+    'm3p_cast_rows_f32_bf16': (_i, [_p, C.c_longlong, C.c_longlong, _i, _i, _i, _p, _p]),
+    'm3p_scale_bf16_dev': (_i, [_p, _i, _p, _p, C.c_longlong, _p]),
+    'm3p_axpy_dev_f32': (_i, [_p, _p, _p, C.c_longlong, _p]),
+    'm3p_itm_loss_fwd_bwd': (_i, [_p, _p, _i, _i, _f, _f, _p, _p, _p]),
     'm3p_probe_mfma_16x16x32': (_i, [_p, _p, _p, _p, _p]),
     'm3p_probe_mfma_fp8_16x16x128': (_i, [_p, _p, _p, _i, _p]),
     'm3p_probe_tr16': (_i, [_p, _p, _p]),

@@ -407,9 +407,16 @@ class TransformerModel(nn.Module):
         if refine_image:     # AoA refiner on the image rows (transformer.py:905-906)
             assert self.n_refine_layers > 0, 'refine_image=True needs params.refine_layers > 0'
             p_ref = self.refine_dropout if self.training else 0.0
-        out = Fn.EncoderFn.apply(self.layer_norm_emb.weight, self, x, lengths, x_img, lengths_img, image_loc, p, pa,
-                                 self._next_seed_step(), p_ref, torch.is_grad_enabled(), text_embed)
+        out = self._tag_pass(Fn.EncoderFn.apply(self.layer_norm_emb.weight, self, x, lengths, x_img, lengths_img, image_loc, p, pa,
+                                                self._next_seed_step(), p_ref, torch.is_grad_enabled(), text_embed))
         return out.view(B, R + T, self.dim).transpose(0, 1)
+
+    def _tag_pass(self, out):
+        """Attach the encoder pass's gradient sink (functional.GradSink) to its output: the heads find it through the
+        views the trainer slices off this tensor."""
+        out._m3p_sink = getattr(self, '_pending_sink', None)
+        self._pending_sink = None
+        return out
 
     @staticmethod
     def _drop_masked_source(src_enc, src_len, enc_mask):
@@ -443,9 +450,10 @@ class TransformerModel(nn.Module):
                 assert self.n_refine_layers > 0, 'refine_image=True needs params.refine_layers > 0'
                 p_ref = self.refine_dropout if self.training else 0.0
             step = self._next_seed_step()
-            h0 = Fn.ImageStreamFn.apply(self.layer_norm_emb.weight, self, x, lengths, image_loc, langs, p, step, p_ref)
-            out = Fn.EncoderFn.apply(self.layer_norm_emb.weight, self, None, lengths, None, None, None, p, pa, step, None,
-                                     torch.is_grad_enabled(), None, None, h0)
+            h0 = Fn.ImageStreamFn.apply(self.layer_norm_emb.weight, self, x, lengths, image_loc, langs, p, step, p_ref,
+                                        torch.is_grad_enabled())
+            out = self._tag_pass(Fn.EncoderFn.apply(self.layer_norm_emb.weight, self, None, lengths, None, None, None, p, pa, step,
+                                                    None, torch.is_grad_enabled(), None, None, h0))
             return out.view(B, R, self.dim).transpose(0, 1)
         assert stream_ == 'text'
         if causal:       # the decoder: causal self-attention (+ attention over src_enc), key / value cache (:1011-1091)
@@ -461,15 +469,17 @@ class TransformerModel(nn.Module):
             from .. import decoder
             return decoder.decoder_forward(self, x, lengths, src_enc=src_enc, src_len=src_len, positions=positions,
                                            langs=langs, cache=cache)
-        assert src_enc is None and cache is None and positions is None, \
-            'the non-causal text stream takes no source encoding, cache or explicit positions (the mlm_step caller)'
+        assert src_enc is None and cache is None, 'the non-causal text stream takes no source encoding or cache (the mlm_step caller)'
         T, B = x.size()
+        if positions is not None:  # transformer.py:1057-1058 (TLM batches: positions restart at the second sentence)
+            assert positions.size() == (T, B)
         if langs is not None:      # transformer.py:1059-1060: + cross_lang_embeddings(langs) on the text rows
             assert self.n_langs > 1 and langs.size() == (T, B), 'language ids need a model with n_langs > 1'
         p = self.dropout if self.training else 0.0
         pa = self.attention_dropout if self.training else 0.0
-        out = Fn.EncoderFn.apply(self.layer_norm_emb.weight, self, x, lengths, None, None, None, p, pa,
-                                 self._next_seed_step(), None, torch.is_grad_enabled(), None, langs)
+        out = self._tag_pass(Fn.EncoderFn.apply(self.layer_norm_emb.weight, self, x, lengths, None, None, None, p, pa,
+                                                self._next_seed_step(), None, torch.is_grad_enabled(), None, langs, None,
+                                                positions))
         return out.view(B, T, self.dim).transpose(0, 1)
 
     def predict(self, tensor, pred_mask=None, y=None, get_scores=None, is_obj=False, is_relation=False,
@@ -483,9 +493,10 @@ class TransformerModel(nn.Module):
                 first = first.to(Fn.BF16)
             if first.stride(-1) != 1:
                 first = first.contiguous()
+            sink = Fn.first_rows_sink(self, tensor)      # (GradSink of the pass, its row buffer, rows of tensor[:, 0]) or Nones
             if is_clcm:
-                return Fn.ItmHeadFn.apply(first, self, 'pooled_layer2', 'seq_relationship2')
-            return Fn.ItmHeadFn.apply(first, self)
+                return Fn.ItmHeadFn.apply(first, self, 'pooled_layer2', 'seq_relationship2', *sink)
+            return Fn.ItmHeadFn.apply(first, self, 'pooled_layer', 'seq_relationship', *sink)
         if is_obj:
             # transformer.py:1205-1210: (scores, loss) of the masked-region classification head; scores are
             # not materialised for all B*R rows (only the masked rows enter the ignore_index mean)

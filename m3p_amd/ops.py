@@ -291,6 +291,72 @@ def cast_bf16(x):
     return out
 
 
+def cast_rows_bf16(x):
+    """fp32 (n0, n1, cols) with ANY leading strides (unit stride along cols) -> contiguous bf16 [n0 * n1, cols]: the cast
+    reads through a transposed view (the collate's (n, R, 2048) features seen as (R, n, 2048)) instead of copying it first."""
+    assert x.dim() == 3 and x.dtype == torch.float32 and x.stride(2) == 1
+    n0, n1, cols = x.shape
+    out = torch.empty((n0 * n1, cols), dtype=BF16, device=x.device)
+    L.check(L.load().m3p_cast_rows_f32_bf16(x.data_ptr(), x.stride(0), x.stride(1), n0, n1, cols, out.data_ptr(), L.stream()),
+            'm3p_cast_rows_f32_bf16')
+    return out
+
+
+def seq_masks(lengths, lengths_b, B, S):
+    """-> (totlen int32 [B], rowmask uint8 [B * S]): totlen = lengths (+ lengths_b), rowmask[b, s] = s < totlen[b]."""
+    dev = lengths.device
+    assert lengths.dtype == torch.int64 and lengths.is_contiguous() and lengths.numel() == B
+    if lengths_b is not None:
+        assert lengths_b.dtype == torch.int64 and lengths_b.is_contiguous() and lengths_b.numel() == B and lengths_b.device == dev
+    totlen = torch.empty((B,), dtype=torch.int32, device=dev)
+    rowmask = torch.empty((B * S,), dtype=torch.uint8, device=dev)
+    L.check(L.load().m3p_seq_masks(lengths.data_ptr(), L.ptr(lengths_b), B, S, totlen.data_ptr(), rowmask.data_ptr(), L.stream()),
+            'm3p_seq_masks')
+    return totlen, rowmask
+
+
+def mask_to_rows(mask, inner, s0, s1, soff, d, n_rows):
+    """Row numbers (int32 [n_rows]) of the True entries of ``mask`` (bool / uint8, flat order t * inner + b) inside the
+    [*, d] row buffer under a strided (T, inner, d) view: (soff + t * s0 + b * s1) // d."""
+    m = mask.reshape(-1)
+    if m.dtype == torch.bool:
+        m = m.view(torch.uint8)
+    assert m.dtype == torch.uint8 and m.is_contiguous()
+    rows = torch.empty((n_rows,), dtype=torch.int32, device=m.device)
+    L.check(L.load().m3p_mask_to_rows(m.data_ptr(), m.numel(), inner, s0, s1, soff, d, rows.data_ptr(), n_rows, L.stream()),
+            'm3p_mask_to_rows')
+    return rows
+
+
+def scale_bf16_dev(x, g):
+    """bf16(g[0] * x) for a bf16 or fp32 ``x`` and a device scalar ``g`` (fp32 [1])."""
+    assert x.is_contiguous() and x.dtype in (BF16, torch.float32) and g.dtype == torch.float32 and g.numel() == 1
+    out = torch.empty(x.shape, dtype=BF16, device=x.device)
+    L.check(L.load().m3p_scale_bf16_dev(x.data_ptr(), int(x.dtype == torch.float32), g.data_ptr(), out.data_ptr(), x.numel(),
+                                        L.stream()), 'm3p_scale_bf16_dev')
+    return out
+
+
+def axpy_dev(dst, src, g):
+    """dst += g[0] * src (fp32, contiguous), g a device scalar."""
+    assert dst.dtype == src.dtype == g.dtype == torch.float32 and dst.is_contiguous() and src.is_contiguous()
+    assert dst.numel() == src.numel()
+    L.check(L.load().m3p_axpy_dev_f32(dst.data_ptr(), src.data_ptr(), g.data_ptr(), dst.numel(), L.stream()), 'm3p_axpy_dev_f32')
+
+
+def itm_loss_fwd_bwd(scores, pos, sample_n, w_ce, w_bce):
+    """-> (loss fp32 [1], dscores fp32 like scores): xtrainer.py:2357-2372 (CE over groups of sample_n + BCE vs one-hot)."""
+    sc = scores.reshape(-1)
+    assert sc.dtype == torch.float32 and sc.is_contiguous() and pos.dtype == torch.int64 and pos.is_contiguous()
+    G = pos.numel()
+    assert sc.numel() == G * sample_n, (sc.numel(), G, sample_n)
+    loss = torch.empty((1,), dtype=torch.float32, device=sc.device)
+    dsc = torch.empty_like(sc)
+    L.check(L.load().m3p_itm_loss_fwd_bwd(sc.data_ptr(), pos.data_ptr(), G, sample_n, float(w_ce), float(w_bce), loss.data_ptr(),
+                                          dsc.data_ptr(), L.stream()), 'm3p_itm_loss_fwd_bwd')
+    return loss, dsc
+
+
 def _drop_args(p):
     return L.thresh24(p), (1.0 / (1.0 - p) if p > 0 else 1.0)
 

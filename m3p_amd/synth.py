@@ -400,3 +400,22 @@ def ic_refine_case():
     sd.update(golden_state_dict(refiner_param_shapes(P), seed=2468, pad_index=None))
     w = torch.from_numpy(np.random.RandomState(781).standard_normal((x_img.shape[0], x_img.shape[1], P.emb_dim)).astype(np.float32))
     return P, sd, x_img, loc, img_len, w
+
+
+def trainer_params(**over):
+    """The fields Trainer / XTrainer read beside the model's (xtrainer.py:37-136, :734-770), at the values the goldens of
+    the text steps are recorded with (dropout 0 models, fp32, no accumulation, clip 5)."""
+    p = dict(encoder_only=True, epoch_size=100, stopping_criterion='', amp=-1, fp16=False, accumulate_gradients=1,
+             multi_gpu=False, local_rank=0, word_mask=0.8, word_keep=0.1, word_rand=0.1, validation_metrics='',
+             dump_path='/nonexistent_m3p_dump', reload_checkpoint='',
+             optimizer='adam_inverse_sqrt,beta1=0.9,beta2=0.98,lr=0.0001', use_memory=0, clip_grad_norm=5,
+             pc_steps=[], ae_steps=[], mass_steps=[], bt_steps=[], cross_modal_steps=[], cross_rel_steps=[],
+             cross_mass_steps=[], cross_ae_steps=[], cross_gan_steps=[], cross_mlm_steps=[], cross_mrm_steps=[],
+             cross_mrfr_steps=[], cross_clcm_steps=[], max_region_num=10, sample_n=2, is_latent=False, refine_image=False,
+             multi_cls_loss_weight=0, bin_cls_loss_weight=1, batch_size=8, sample_alpha=0, word_pred=0.15, is_ntg=False,
+             group_by_size=False, is_freelb=False, t2i_flag=True, i2t_flag=True, langs=['en'])
+    for lam in ('lambda_clm', 'lambda_mlm', 'lambda_pc', 'lambda_ae', 'lambda_mt', 'lambda_bt', 'lambda_mass', 'lambda_ic',
+                'lambda_imlm', 'lambda_ida', 'lambda_tifg', 'lambda_rel', 'lambda_mrm', 'lambda_mrfr', 'lambda_t2i', 'lambda_i2t'):
+        p[lam] = '1'
+    p.update(over)
+    return p

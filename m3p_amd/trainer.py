@@ -31,7 +31,7 @@ from .collate import (batch_sentences, batch_sentences_v2, caption_collate, mt_c
                       retrieval_collate, retrieval_pretrain_collate, slide_collate)
 from .distributed import DataParallel
 from .optim import get_optimizer
-from .utils import parse_lambda_config, to_cuda, update_lambdas
+from .utils import concat_batches, parse_lambda_config, to_cuda, update_lambdas
 
 logger = getLogger()
 
@@ -41,6 +41,12 @@ _REGION_HEADS = {
             'transformer_obj.LayerNorm.bias', 'pred_obj_layer.proj.weight', 'pred_obj_layer.proj.bias'),
     'mrfr': ('mrfr_dense.weight', 'mrfr_dense.bias'),
 }
+
+
+def _add_loss(total, coeff, loss):
+    """total + coeff * loss without the launches a unit coefficient / an empty total would cost."""
+    term = loss if coeff == 1 else coeff * loss
+    return term if total is None else total + term
 
 
 def _unwrap(model):
@@ -222,16 +228,23 @@ class Trainer(object):
         return x if lang2 is None or lang1 < lang2 else x[::-1]
 
     def generate_batch(self, lang1, lang2, name):
-        """xtrainer.py:485-509, the monolingual stream case (MLM).  The TLM case (lang2 given) concatenates two
-        languages with reset positions and language embeddings - not on the MI355X path (the encoder kernels take
-        positions 0..S-1 and ignore language ids, like jointfwd does: transformer.py:937-938)."""
-        if lang2 is not None:
-            raise NotImplementedError('TLM batches (lang2 = %r) need position / language embeddings inputs that the '
-                                      'MI355X text stream does not take; MLM (lang2 = None) is supported' % (lang2,))
+        """xtrainer.py:485-509: the monolingual stream (MLM), a sentence next to its noised copy (lang1 == lang2), or a
+        parallel pair joined with reset positions and per-token language ids (TLM)."""
         params = self.params
-        x, lengths = self.get_cross_lingual_batch(name, lang1, stream=True)
-        langs = x.clone().fill_(params.lang2id[lang1]) if params.n_langs > 1 else None
-        return x, lengths, None, langs, (None, None)
+        lang1_id = params.lang2id[lang1]
+        if lang2 is None:
+            x, lengths = self.get_cross_lingual_batch(name, lang1, stream=True)
+            langs = x.clone().fill_(lang1_id) if params.n_langs > 1 else None
+            return x, lengths, None, langs, (None, None)
+        lang2_id = params.lang2id[lang2]
+        if lang1 == lang2:
+            x2, len2 = self.get_cross_lingual_batch(name, lang1)
+            x1, len1 = self.add_noise(x2, len2)
+        else:
+            (x1, len1), (x2, len2) = self.get_cross_lingual_batch(name, lang1, lang2)
+        x, lengths, positions, langs = concat_batches(x1, len1, lang1_id, x2, len2, lang2_id, params.pad_index,
+                                                      params.eos_index, reset_positions=lang1 != lang2)
+        return x, lengths, positions, langs, (len1, len2)
 
     def round_batch(self, x, lengths, positions, langs):
         """xtrainer.py:654-692."""
@@ -249,19 +262,21 @@ class Trainer(object):
         x, lengths, positions, langs, _ = self.generate_batch(lang1, lang2, 'pred')
         x, lengths, positions, langs, _ = self.round_batch(x, lengths, positions, langs)
         x, y, pred_mask = self.mask_out(x, lengths)
-        return self.mlm_step_on_batch(x, lengths, pred_mask, y, lang1, lambda_coeff, langs=langs)
+        return self.mlm_step_on_batch(x, lengths, pred_mask, y, lang1, lambda_coeff, langs=langs, positions=positions,
+                                      stat=None if lang2 is None else 'MLM-%s-%s' % (lang1, lang2))
 
-    def mlm_step_on_batch(self, x, lengths, pred_mask, y, lang='en', lambda_coeff=1, langs=None):
+    def mlm_step_on_batch(self, x, lengths, pred_mask, y, lang='en', lambda_coeff=1, langs=None, positions=None, stat=None):
         """Loss path of mlm_step on an already masked batch (:751-770)."""
         model = self.model
         model.train()
         self._dp_plan(True, expect=('mlm',))
         n_words = pred_mask.sum()
         x, y, pred_mask, lengths = to_cuda(x, y, pred_mask, lengths)
-        # (langs is None unless params.n_langs > 1: then the stream adds the language embeddings, transformer.py:1059-1060)
-        tensor = model('crossfwd', stream_='text', x=x, lengths=lengths, positions=None, langs=langs, causal=False)
+        # (langs is None unless params.n_langs > 1: then the stream adds the language embeddings, transformer.py:1059-1060;
+        #  positions only for TLM batches, whose second sentence restarts at 0)
+        tensor = model('crossfwd', stream_='text', x=x, lengths=lengths, positions=positions, langs=langs, causal=False)
         _, loss = model('predict', tensor=tensor, pred_mask=pred_mask, y=y, get_scores=False)
-        self._stat('MLM-%s' % lang, loss)
+        self._stat(stat or 'MLM-%s' % lang, loss)
         self.optimize(lambda_coeff * loss)
         self.n_sentences += self.params.batch_size
         self.stats['processed_s'] += lengths.size(0)
@@ -686,6 +701,10 @@ class XTrainer(Trainer):
         dev = relation_scores.device
         pos = to_cuda(torch.as_tensor(np.asarray(pos_labels), dtype=torch.long).reshape(-1))[0] if dev.type == 'cuda' else \
             torch.as_tensor(np.asarray(pos_labels), dtype=torch.long).reshape(-1)
+        if dev.type == 'cuda':      # one fused launch (loss + its gradient) instead of ~20 elementwise ones
+            from . import functional as Fn
+            return Fn.ItmLossFn.apply(relation_scores, pos.contiguous(), params.sample_n,
+                                      float(params.multi_cls_loss_weight), float(params.bin_cls_loss_weight))
         onehot = F.one_hot(pos, params.sample_n).float().view(-1)
         scores = relation_scores.float()
         loss = 0
@@ -783,7 +802,9 @@ class XTrainer(Trainer):
         return self._ascend(delta, norm_type, adv_lr, adv_max_norm)
 
     def free_optimize(self, loss):
-        """:2755-2791 - ``optimize`` without the accumulation bookkeeping: every adversarial step is an optimizer step."""
+        """:2755-2791.  Follows the reference's AMP branch (the configuration its README runs): with
+        ``accumulate_gradients`` > 1 the adversarial passes accumulate like any other step and only boundary iterations
+        clip and step (its amp == -1 branch would step on every pass)."""
         self.optimize(loss)
 
     def _freelb_rel_step(self, batches, dataset, task_name, lambda_coeff):
@@ -929,28 +950,28 @@ class XTrainer(Trainer):
 
         encoder_outputs = model('jointfwd', x=x1, lengths=len1, x_img=x_img, lengths_img=img_len, causal=False,
                                 langs=None, image_loc=img_loc, refine_image=params.refine_image)
-        total_loss = 0
+        total_loss = None
         R = x_img.shape[0]
         _text_out = encoder_outputs[R:]
         if has_mlm:
             _, loss = model('predict', tensor=_text_out, pred_mask=pred_mask_text, y=y_text, get_scores=False)
             self._stat('CMLM-%s' % dataset, loss)
-            total_loss = total_loss + lambda_coeff_mlm * loss
+            total_loss = _add_loss(total_loss, lambda_coeff_mlm, loss)
         _img_out = encoder_outputs[:R].transpose(0, 1)          # (B, R, d), xtrainer.py:2288-2289
         has_masked_region = bool((obj_labels != -1).any()) if torch.is_tensor(obj_labels) else False   # host tensor
         if mrm_on and has_masked_region:          # xtrainer.py:2320-2328
             _, loss = model('predict', tensor=_img_out, pred_mask=None, y=obj_labels.reshape(-1), get_scores=False, is_obj=True)
             self._stat('MRM-%s' % dataset, loss)
-            total_loss = total_loss + lambda_coeff_mrm * loss
+            total_loss = _add_loss(total_loss, lambda_coeff_mrm, loss)
         if mrfr_on and has_masked_region:         # xtrainer.py:2330-2352
             from . import functional as Fn
             loss = Fn.mrfr_head(_unwrap(model), _img_out, obj_labels, ori_att_feats)
             self._stat('MRFR-%s' % dataset, loss)
-            total_loss = total_loss + lambda_coeff_mrfr * loss
+            total_loss = _add_loss(total_loss, lambda_coeff_mrfr, loss)
         relation_scores = model('predict', tensor=encoder_outputs.transpose(0, 1), is_relation=True)
         loss = self._itm_loss(relation_scores, pos_labels)
         self._stat('%s-%s' % (task_name, dataset), loss)
-        total_loss = total_loss + lambda_coeff_rel * loss
+        total_loss = _add_loss(total_loss, lambda_coeff_rel, loss)
 
         if task_name == 'i2t' and len(params.cross_clcm_steps) > 0:        # xtrainer.py:2379-2393
             x2c, len2c = to_cuda(x2, len2)
@@ -960,7 +981,7 @@ class XTrainer(Trainer):
             target2 = torch.as_tensor(clcm_labels).reshape(-1).to(device=relation_scores2.device, dtype=torch.float32)
             loss = F.binary_cross_entropy_with_logits(relation_scores2.view(-1).float(), target2)
             self._stat('CLCM-%s' % dataset, loss)
-            total_loss = total_loss + loss
+            total_loss = _add_loss(total_loss, 1, loss)
 
         self.optimize(total_loss)
         self.n_sentences += params.batch_size

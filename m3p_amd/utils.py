@@ -77,3 +77,27 @@ def update_lambdas(params, n_iter):
 
 def concat_rows(tensors):
     return torch.cat([t.reshape(-1) for t in tensors])
+
+
+def concat_batches(x1, len1, lang1_id, x2, len2, lang2_id, pad_idx, eos_idx, reset_positions):
+    """utils.py:324-349: the two sentences of every column joined into one sequence (TLM input).  With
+    ``reset_positions`` the second sentence follows the first's closing delimiter and its positions restart at 0;
+    without (the same-language denoising case) it overwrites that delimiter and positions run on.
+    -> (x (slen, bs), lengths, positions (slen, bs), langs (slen, bs))."""
+    assert not reset_positions or lang1_id != lang2_id
+    lengths = len1 + len2 - (0 if reset_positions else 1)
+    slen, bs = int(lengths.max()), lengths.size(0)
+    start = len1 if reset_positions else len1 - 1            # where sentence 2 begins, per column
+    t = torch.arange(slen, device=x1.device)[:, None]        # (slen, 1)
+    second = t >= start[None, :]                             # (slen, bs): rows that belong to sentence 2 (or the padding behind it)
+    x = x1.new_full((slen, bs), pad_idx)
+    x[:x1.size(0)] = x1
+    src = (t - start[None, :]).clamp_(0, x2.size(0) - 1)
+    from2 = second & (t < (start + len2)[None, :])
+    x = torch.where(from2, torch.gather(x2, 0, src), x)
+    positions = t.repeat(1, bs)
+    if reset_positions:
+        positions = torch.where(second, positions - len1[None, :], positions)
+    langs = torch.where(second, torch.full_like(x, lang2_id), torch.full_like(x, lang1_id))
+    assert int((x == eos_idx).sum()) == (4 if reset_positions else 3) * bs
+    return x, lengths, positions, langs

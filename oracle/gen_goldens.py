@@ -1064,9 +1064,121 @@ def gen_decoder_goldens():
     print('wrote decoder.npz', {k: v.shape for k, v in out.items() if k.endswith('full')})
 
 
+def gen_tlm_goldens():
+    """tlm_step.npz: the reference's ``mlm_step('en', 'zh', 1)`` (xtrainer.py:734-770 through generate_batch :485-509 and
+    utils.concat_batches :324-349) on the two-language model of synth.mt_case: the batch it builds under fixed seeds (x,
+    lengths, positions, langs, pred_mask, y), the text stream's output on it, the loss, gradients incl. the position
+    and language tables, and the logged loss / lr / parameter norms after the trainer's own step."""
+    for name in ('apex', 'apex.amp', 'apex.parallel'):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    import src.xtrainer as xt
+    from src.model.transformer import TransformerModel
+    P, sd, x1, len1, x2, len2 = synth.mt_case()
+
+    def fresh_model():
+        torch.manual_seed(0)
+        m = TransformerModel(P, is_encoder=True, with_output=True, is_crossModal=True)
+        own = dict(m.named_parameters())
+        with torch.no_grad():
+            for k, v in sd.items():
+                own[k].copy_(v)
+        return m, own
+    for k, v in synth.trainer_params(batch_size=x1.shape[1], langs=['en', 'zh']).items():
+        setattr(P, k, v)
+
+    class _Para:
+        def get_iterator(self, shuffle=True, group_by_size=False, n_sentences=-1):
+            return iter([((x1, len1), (x2, len2))])
+    g = {}
+    # the batch the step builds, and the model's numbers on it (manual path, gradients without an optimizer step)
+    m, own = fresh_model()
+    tr = xt.XTrainer(m, {'para': {('en', 'zh'): {'train': _Para()}}}, P)
+    np.random.seed(77); torch.manual_seed(77)
+    x, lengths, positions, langs, _ = tr.generate_batch('en', 'zh', 'pred')
+    x, lengths, positions, langs, _ = tr.round_batch(x, lengths, positions, langs)
+    x, y, pred_mask = tr.mask_out(x, lengths)
+    g.update(x=x.numpy(), lengths=lengths.numpy(), positions=positions.numpy(), langs=langs.numpy(),
+             pred_mask=pred_mask.numpy(), y=y.numpy())
+    m.train()
+    out = m('crossfwd', stream_='text', x=x, lengths=lengths, positions=positions, langs=langs, causal=False)
+    _, loss = m('predict', tensor=out, pred_mask=pred_mask, y=y, get_scores=False)
+    loss.backward()
+    g['out'], g['loss'] = out.detach().numpy(), loss.detach().numpy()
+    for k in ('position_embeddings.weight', 'cross_lang_embeddings.weight', 'layer_norm_emb.weight', 'attentions.0.q_lin.weight',
+              'ffns.1.lin2.weight', 'pred_layer.proj.bias'):
+        g['grad.' + k] = own[k].grad.numpy()
+    g['grad_norm.embeddings.weight'] = own['embeddings.weight'].grad.norm().numpy()
+    # the trainer's own step under the same seeds: the very same batch, one clipped Adam-inv-sqrt step
+    m2, own2 = fresh_model()
+    tr2 = xt.XTrainer(m2, {'para': {('en', 'zh'): {'train': _Para()}}}, P)
+    np.random.seed(77); torch.manual_seed(77)
+    tr2.mlm_step('en', 'zh', 1.0)
+    g['step_loss'] = np.asarray(tr2.stats['MLM-en-zh'][-1])
+    g['step_lr'] = np.asarray(tr2.optimizers['model'].param_groups[0]['lr'])
+    g['step_processed'] = np.asarray([tr2.stats['processed_s'], tr2.stats['processed_w'], tr2.n_sentences])
+    for k in ('embeddings.weight', 'position_embeddings.weight', 'cross_lang_embeddings.weight', 'attentions.0.q_lin.weight'):
+        g['step_pnorm/' + k] = own2[k].detach().norm().numpy()
+    assert abs(float(g['step_loss']) - float(g['loss'])) < 1e-6
+    from oracle import ref_cpu
+    o = ref_cpu.crossfwd_text(sd, P.n_layers, P.n_heads, x, lengths, langs=langs, positions=positions)
+    print('tlm_step.npz: loss %.6f (trainer %.6f); slen %d, n_pred %d; oracle-vs-reference max|d| %.2e' %
+          (float(loss), float(g['step_loss']), x.shape[0], int(pred_mask.sum()), float((o - out.detach()).abs().max())))
+    assert float((o - out.detach()).abs().max()) < 1e-4
+    np.savez_compressed(os.path.join(OUT, 'tlm_step.npz'), **g)
+
+
+def gen_eval_goldens():
+    """eval_understanding.npz: the reference's XEvaluator.evaluate_t2i / evaluate_i2t (xevaluator.py:1309-1417) called on
+    the cfg1 model - the module imports through stubs for its absent third parties (coco_caption, the HDF5 loaders)."""
+    for name in ('coco_caption', 'coco_caption.pycocotools', 'coco_caption.pycocotools.coco', 'coco_caption.pycocoevalcap',
+                 'coco_caption.pycocoevalcap.eval', 'h5py', 'lmdb'):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules['coco_caption.pycocotools.coco'].COCO = object
+    sys.modules['coco_caption.pycocoevalcap.eval'].COCOEvalCap = object
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    from src.evaluation import xevaluator as xe
+    cfg = synth.CONFIGS['cfg1']
+    g = {}
+    for tag, sample_n, pretrain in (('pre2', 2, True), ('fin4', 4, False)):
+        m, P, hot = build_reference_model(cfg)
+        for k, v in dict(encoder_only=True, multi_gpu=False, is_pretrain=pretrain, n_langs=1, max_region_num=cfg['R'],
+                         sample_n=sample_n, is_latent=False, refine_image=False).items():
+            setattr(P, k, v)
+        ev = types.SimpleNamespace(params=P, model=m)
+        B, R = cfg['B'], cfg['R']
+        batch = synth.make_batch(cfg['T'], R, B, cfg['n_words'], cfg['n_pred'], seed=41 + sample_n)
+        img = batch['x_img'].transpose(0, 1).contiguous()
+        loc = batch['image_loc'].transpose(0, 1).contiguous()
+        mask = torch.ones(B, R, dtype=torch.long)
+        pos = np.random.RandomState(sample_n).randint(0, sample_n, size=B // sample_n).tolist()
+        if pretrain:
+            t2i = ((batch['x'], batch['lengths'], batch['x_labels']),
+                   (img, mask, loc, torch.full((B, R), -1), pos, img.clone(), list(range(B))))
+            i2t = ((batch['x'], batch['lengths'], batch['x_labels']), (batch['x'], batch['lengths']),
+                   (torch.zeros(B), img, mask, loc, torch.full((B, R), -1), pos, img.clone(), list(range(B))))
+        else:
+            t2i = i2t = ((batch['x'], batch['lengths'], torch.zeros_like(batch['x'])), (img, mask, loc, pos, list(range(B))))
+        with torch.no_grad():
+            a_t, n_t = xe.XEvaluator.evaluate_t2i(ev, t2i)
+            a_i, n_i = xe.XEvaluator.evaluate_i2t(ev, i2t)
+            out = m('jointfwd', x=batch['x'], lengths=batch['lengths'], x_img=batch['x_img'], lengths_img=batch['lengths_img'],
+                    causal=False, langs=None, image_loc=batch['image_loc'], refine_image=False)
+            rel = m('predict', tensor=out.transpose(0, 1), is_relation=True).view(-1, sample_n)
+        g[tag + '.pos'] = np.asarray(pos)
+        g[tag + '.t2i'] = np.asarray([a_t, n_t])
+        g[tag + '.i2t'] = np.asarray([a_i, n_i])
+        g[tag + '.scores'] = rel.numpy()
+        top2 = rel.topk(2, dim=1).values
+        g[tag + '.margin'] = (top2[:, 0] - top2[:, 1]).numpy()
+        print('eval_understanding.npz[%s]: t2i %d/%d, i2t %d/%d, min top-2 margin %.4f' % (tag, a_t, n_t, a_i, n_i, float(g[tag + '.margin'].min())))
+    np.savez_compressed(os.path.join(OUT, 'eval_understanding.npz'), **g)
+
+
 if __name__ == '__main__':
     single = {'enum': gen_state_dict_enumeration, 'host': gen_host_goldens, 'mt': gen_mt_goldens, 'noise': gen_noise_goldens, 'ic': gen_ic_goldens, 'langs': gen_text_langs_goldens,
-              'decoder': gen_decoder_goldens, 'refiner': gen_refiner_goldens, 'mt_ic': gen_mt_ic_goldens, 'data': gen_data_goldens, 'ic_refine': gen_ic_refine_goldens, 'spans': gen_span_mask_goldens, 'mass': gen_mass_goldens, 'img_noise': gen_img_noise_goldens, 'freelb': gen_freelb_goldens, 'freelb_ic': gen_freelb_ic_goldens}
+              'decoder': gen_decoder_goldens, 'refiner': gen_refiner_goldens, 'mt_ic': gen_mt_ic_goldens, 'data': gen_data_goldens, 'ic_refine': gen_ic_refine_goldens, 'spans': gen_span_mask_goldens, 'mass': gen_mass_goldens, 'img_noise': gen_img_noise_goldens, 'freelb': gen_freelb_goldens, 'freelb_ic': gen_freelb_ic_goldens,
+              'tlm': gen_tlm_goldens, 'eval': gen_eval_goldens}
     if len(sys.argv) > 1:
         single[sys.argv[1]]()
         sys.exit(0)
@@ -1075,5 +1187,5 @@ if __name__ == '__main__':
                gen_decoder_goldens, gen_text_langs_goldens, gen_mt_goldens, gen_ic_goldens, gen_noise_goldens,
                gen_mt_ic_goldens, gen_data_goldens, gen_ic_refine_goldens,
                gen_span_mask_goldens, gen_mass_goldens, gen_img_noise_goldens,
-               gen_freelb_goldens, gen_freelb_ic_goldens):
+               gen_freelb_goldens, gen_freelb_ic_goldens, gen_tlm_goldens, gen_eval_goldens):
         fn()

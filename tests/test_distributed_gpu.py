@@ -7,7 +7,7 @@ the whole batch:
   * the clip norm, and the parameters after the steps;
   * ranks end bit-identical.
 Scenarios: MLM + ITM; i2t with MRM + MRFR + CLCM (two encoder passes per step); gradient
-accumulation over 2 micro-steps; ITM fine-tuning (no dense vocabulary gradient); text MLM.
+accumulation over 2 micro-steps; ITM fine-tuning (no dense vocabulary gradient); text MLM; translation; captioning.
 Both ranks share cuda:0 over gloo (one MI355X is all a test box has); the same scenarios run
 over RCCL ('nccl') when at least two devices are visible."""
 import os
@@ -32,7 +32,7 @@ def _free_port():
 
 
 def _params(scenario, multi_gpu):
-    two = dict(n_langs=2, id2lang={0: 'en', 1: 'zh'}, lang2id={'en': 0, 'zh': 1}, mt_steps=[('en', 'zh')]) if scenario == 'mt' else {}
+    two = dict(n_langs=2, id2lang={0: 'en', 1: 'zh'}, lang2id={'en': 0, 'zh': 1}, mt_steps=[('en', 'zh')]) if scenario in ('mt', 'ic') else {}
     P = synth.model_params(CFG['emb_dim'], CFG['n_heads'], CFG['n_layers'], CFG['n_words'], **two)
     for k, v in dict(optimizer='adam_inverse_sqrt,beta1=0.9,beta2=0.98,lr=0.0001', clip_grad_norm=5, amp=1, fp16=True,
                      accumulate_gradients=2 if scenario == 'accumulate' else 1, multi_gpu=multi_gpu, local_rank=0,
@@ -42,7 +42,7 @@ def _params(scenario, multi_gpu):
                      cross_mrfr_steps=[('google', 'img')] if scenario == 'clcm' else [],
                      cross_clcm_steps=[('google', 'img')] if scenario == 'clcm' else [],
                      sample_n=2, refine_image=False, multi_cls_loss_weight=1 if scenario == 'finetune' else 0,
-                     bin_cls_loss_weight=1, langs=['en', 'zh'] if scenario == 'mt' else ['en']).items():
+                     bin_cls_loss_weight=1, langs=['en', 'zh'] if scenario in ('mt', 'ic') else ['en']).items():
         setattr(P, k, v)
     return P
 
@@ -55,7 +55,7 @@ def _build(scenario, multi_gpu):
     sd = synth.golden_state_dict(synth.hot_param_shapes(P))
     sd.update(synth.golden_state_dict(synth.region_head_param_shapes(P), seed=4321, pad_index=None))
     sd.update(synth.golden_state_dict(synth.clcm_head_param_shapes(P), seed=9753, pad_index=None))
-    if scenario == 'mt':
+    if scenario in ('mt', 'ic'):
         sd.update(synth.golden_state_dict(synth.cross_attention_param_shapes(P), seed=2468, pad_index=None))
     m.load_state_dict(sd, strict=False)
     m = m.cuda()
@@ -78,7 +78,7 @@ def _slice(full, extra, sl, ng):
     i2t = ((x, lens, lab), (x2, len2), (extra['clcm'][sl].contiguous(), img, mask, loc, obj, pos, ori, list(range(n))))
     fin = ((x, lens, torch.zeros_like(x)), (img, mask, loc, obj, pos, list(range(n))))
     text = (x, lens, full['pred_mask'][:, sl].contiguous(), lab[full['pred_mask'][:, sl]])
-    return dict(t2i=t2i, i2t=i2t, fin=fin, text=text, mt=(x, lens, x2, len2))
+    return dict(t2i=t2i, i2t=i2t, fin=fin, text=text, mt=(x, lens, x2, len2), ic=(x2, len2, img, mask, loc))
 
 
 def _batches(step):
@@ -105,6 +105,8 @@ def _run_step(tr, scenario, tup):
         tr.mlm_step_on_batch(*tup['text'], 'en', 1.0)
     elif scenario == 'mt':          # two differentiated passes per step: encoder stream, then the causal stream over it
         tr.mt_step_on_batch(*tup['mt'], 'en', 'zh', 1.0)
+    elif scenario == 'ic':          # captioning: image stream -> layers-only encoder pass -> causal stream (three passes; the
+        tr.ic_step_on_batch(*tup['ic'], 'google', 'img', 1.0)       # image stream's gradients are the LAST backward writes)
     tr.n_iter += 1
 
 
@@ -198,7 +200,7 @@ def _check(scenario, backend):
     assert diff <= 2.5 * lr_sum, (scenario, diff, lr_sum)    # Adam moves every weight by <= ~lr per step
 
 
-@pytest.mark.parametrize('scenario', ['pretrain', 'clcm', 'accumulate', 'finetune', 'text', 'mt'])
+@pytest.mark.parametrize('scenario', ['pretrain', 'clcm', 'accumulate', 'finetune', 'text', 'mt', 'ic'])
 def test_dp_two_ranks_match_single_process(scenario):
     _check(scenario, 'gloo')
 

@@ -237,3 +237,86 @@ def test_gelu_bwd_and_mse_kernels():
     ref.backward()
     assert abs(float(sq) / (23 * 2048) - float(ref)) < 1e-5 * float(ref)
     assert rel_l2(dpred.float(), p.grad) < 4e-3
+
+
+# ---- host-glue kernels (csrc/glue.hip): each against the chain of tensor ops it replaces ----
+def test_seq_masks_and_mask_to_rows():
+    from m3p_amd import ops
+    B, S, T, R, d = 7, 164, 128, 36, 64
+    g = torch.Generator().manual_seed(3)
+    lens = torch.randint(T // 2, T + 1, (B,), generator=g)
+    limg = torch.full((B,), R, dtype=torch.int64)
+    tot, rm = ops.seq_masks(lens.cuda(), limg.cuda(), B, S)
+    assert torch.equal(tot.cpu().long(), lens + limg)
+    assert torch.equal(rm.cpu().view(B, S).bool(), torch.arange(S)[None, :] < (lens + limg)[:, None])
+    tot1, rm1 = ops.seq_masks(lens.cuda(), None, B, T)
+    assert torch.equal(tot1.cpu().long(), lens) and int(rm1.sum()) == int(lens.sum())
+    # rows of the True entries of a (T, B) mask under the (T, B, d) view out[R:] of a [B, S, d] buffer
+    for T2, B2 in ((128, 7), (128, 1024), (5, 3)):
+        pm = torch.rand(T2, B2, generator=g) < 0.15
+        n = int(pm.sum())
+        s0, s1, soff = d, S * d, R * d                         # element strides of encoder_outputs[R:]
+        rows = ops.mask_to_rows(pm.cuda(), B2, s0, s1, soff, d, n)
+        t_idx, b_idx = pm.nonzero(as_tuple=True)               # (t, b) order
+        assert torch.equal(rows.cpu().long(), (soff + t_idx * s0 + b_idx * s1) // d)
+    assert ops.mask_to_rows(torch.zeros(4, 4, dtype=torch.bool, device='cuda'), 4, 1, 1, 0, 1, 0).numel() == 0
+
+
+def test_strided_cast_and_device_scalar_scaling():
+    from m3p_amd import ops
+    img, imgc = randn_f32((5, 36, 2048), 4)                    # (n, R, 2048) as the collate emits it
+    out = ops.cast_rows_bf16(img.transpose(0, 1))              # the (R, n, 2048) view the model is handed
+    assert torch.equal(out.cpu(), imgc.transpose(0, 1).contiguous().view(-1, 2048).to(BF16))
+    gsc = torch.tensor([0.37], device='cuda')
+    x, xc = randn_bf16((33, 64), 5)
+    assert torch.equal(ops.scale_bf16_dev(x, gsc).cpu(), (xc.to(BF16).float() * gsc.cpu()).to(BF16))
+    y, yc = randn_f32((33, 64), 6)
+    assert torch.equal(ops.scale_bf16_dev(y, gsc).cpu(), (yc * gsc.cpu()).to(BF16))
+    dst, dstc = randn_f32((1001,), 7)
+    src, srcc = randn_f32((1001,), 8)
+    ops.axpy_dev(dst, src, gsc)
+    assert rel_l2(dst, dstc + 0.37 * srcc) < 1e-6
+
+
+@pytest.mark.parametrize('w_ce,w_bce,G,n', [(0.0, 1.0, 128, 2), (1.0, 1.0, 24, 4), (0.5, 0.0, 3, 5), (1.0, 2.0, 700, 2)])
+def test_itm_loss_kernel_vs_torch(w_ce, w_bce, G, n):
+    from m3p_amd import functional as Fn
+    g = torch.Generator().manual_seed(G)
+    sc = (torch.randn(G * n, 1, generator=g) * 3).requires_grad_(True)
+    pos = torch.randint(0, n, (G,), generator=g)
+    ref = w_ce * F.cross_entropy(sc.view(-1, n), pos) + \
+        w_bce * F.binary_cross_entropy_with_logits(sc.view(-1), F.one_hot(pos, n).float().view(-1))
+    ref.backward()
+    scg = sc.detach().cuda().requires_grad_(True)
+    loss = Fn.ItmLossFn.apply(scg, pos.cuda(), n, w_ce, w_bce)
+    (2.0 * loss).backward()
+    assert abs(float(loss) - float(ref)) < 1e-5 * max(1.0, abs(float(ref)))
+    assert rel_l2(scg.grad, 2.0 * sc.grad) < 1e-5
+
+
+def test_gradient_sink_equals_autograd_views():
+    """The heads leave their rows' gradients in the encoder pass's GradSink instead of returning zero-filled views of the
+    whole output: same parameter gradients as the plain autograd route (sink detached), and a consumer outside the
+    protocol (a plain tensor op on the output) still adds up."""
+    from m3p_amd import synth, functional as Fn
+    from m3p_amd.model.transformer import TransformerModel
+    P = synth.model_params(128, 4, 2, 1000)
+    grads = []
+    for use_sink in (True, False):
+        torch.manual_seed(0)
+        m = TransformerModel(P, is_encoder=True, with_output=True, is_crossModal=True)
+        m.load_state_dict(synth.golden_state_dict(synth.hot_param_shapes(P)), strict=False)
+        m = m.cuda().train()
+        m.dropout = m.attention_dropout = 0.0
+        b = synth.make_batch(24, 10, 8, 1000, 4, seed=5, ragged=True)
+        out = m('jointfwd', x=b['x'].cuda(), lengths=b['lengths'].cuda(), x_img=b['x_img'].cuda(),
+                lengths_img=b['lengths_img'].cuda(), causal=False, langs=None, image_loc=b['image_loc'].cuda(), refine_image=False)
+        if not use_sink:
+            out._base._m3p_sink = None
+        _, mlm = m('predict', tensor=out[10:], pred_mask=b['pred_mask'].cuda(), y=b['x_labels'][b['pred_mask']].cuda(), get_scores=False)
+        rel = m('predict', tensor=out.transpose(0, 1), is_relation=True)
+        extra = out.float().pow(2).mean()                     # outside the sink protocol
+        (mlm + rel.float().mean() + extra).backward()
+        torch.cuda.synchronize()
+        grads.append(m.arena().grad.clone())
+    assert rel_l2(grads[0], grads[1]) < 2e-3, rel_l2(grads[0], grads[1])
