@@ -159,8 +159,11 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--batch', type=int, default=256, help='sequences per GPU')
-    ap.add_argument('--config', default='cfg2')
+    ap.add_argument('--batch', type=int, default=None, help='sequences per GPU (default: the preset\'s)')
+    ap.add_argument('--config', default='cfg2',
+                    help='BASELINE.json preset: cfg2 = configs[1] (12L/768d, 256 sequences per GPU; the default N=1 line), '
+                         'cfg3 = configs[2] (the same model at 1024 sequences per GPU = global batch 8192 on 8 GPUs), '
+                         'cfg4 = configs[3] (24L/1024d, 100 + 256; use --batch 64 --fp8), cfg5 = configs[4] shapes')
     ap.add_argument('--dropout', type=float, default=0.1)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--ragged', action='store_true',
@@ -196,9 +199,12 @@ def main():
         assert dist.get_world_size() == world
     torch.cuda.set_device(local_rank)
     cfg = dict(synth.CONFIGS[args.config])
-    cfg['B'] = args.batch
+    if args.batch is not None:
+        cfg['B'] = args.batch
     trainer, tup = build(cfg, args.dropout, world, rank, local_rank, args.refine_layers, args.ragged, args.fp8)
     dp = trainer.model if world > 1 else None
+    if dp is not None:
+        dp.uniform_tokens = not args.ragged      # every rank's batch has the same token-row count: no count exchange at all
 
     def step():
         trainer.pretrain_under_step(tup, 'google', 't2i', 'en', 1.0, 1.0, 1.0, 1.0)
@@ -268,11 +274,34 @@ def main():
         payload = [n for _, _, n in evs]
         e = torch.tensor([sum(exposed) / max(len(exposed), 1)], device='cuda', dtype=torch.float64)
         dist.all_reduce(e, op=dist.ReduceOp.MAX)
-        comm = dict(exposed_ms_per_step=round(float(e.item()), 3),
-                    payload_MB_per_step=round(sum(payload) / max(len(payload), 1) / 1e6, 1),
+        # per-collective bus bandwidth: three more steps with every collective bracketed by events on the side stream
+        dp.exposed_events = None
+        dp.reducer.timings = []
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        fam = {}
+        for label, a, b, nbytes, kind in dp.reducer.timings:
+            if isinstance(label, tuple) and label[0] == 'params':
+                name = 'params ' + (label[1] if isinstance(label[1], str) else 'layer')
+            else:
+                name = 'layer' if isinstance(label, tuple) else str(label)
+            ms = a.elapsed_time(b)
+            factor = (2.0 if kind == 'allreduce' else 1.0) * (world - 1) / world
+            ent = fam.setdefault('%s (%s)' % (name, kind), [0, 0.0, 0.0])
+            ent[0] += 1; ent[1] += nbytes; ent[2] += ms
+        dp.reducer.timings = None
+        buckets = {k: dict(MB=round(v[1] / v[0] / 1e6, 2), ms=round(v[2] / v[0], 3),
+                           busbw_GBps=round(v[1] * ((2.0 if 'allreduce' in k else 1.0) * (world - 1) / world) / (v[2] * 1e-3) / 1e9, 1))
+                   for k, v in fam.items() if v[2] > 0}
+        comm = dict(mode=dp.mode, exposed_ms_per_step=round(float(e.item()), 3),
+                    payload_MB_per_step=round(sum(payload) / max(len(payload), 1) / 1e6, 1), buckets=buckets,
+                    reserved_cus=__import__('m3p_amd.distributed', fromlist=['x']).reserve_cus(),
                     note='exposed = compute-stream wait for the gradient collectives + token-row scatter before clip/Adam '
-                         '(max over ranks); payload = bytes handed to RCCL per rank and step (layer / head / vocabulary '
-                         'buckets fp32, token rows bf16)')
+                         '(max over ranks); payload = bytes handed to RCCL per rank and step in backward (gradient buckets '
+                         'fp32, token rows bf16); buckets = average size / time / bus bandwidth per collective, measured on '
+                         'rank 0 in three extra steps with each collective bracketed by events; zero1 gathers the updated '
+                         'fp32 parameters during the next forward (the "params" rows)')
 
     if rank == 0:
         seqs = args.steps * cfg['B'] * world
@@ -305,7 +334,8 @@ def main():
                         kernel=kname, launches=cnt, avg_ms=round(avg_ms, 4),
                         gemm_time_share=round((gemm_ms_per_step * args.steps if ops.PROFILE_ONLY is not None else
                                                sum(v[0] for v in agg.values())) / (dt * 1e3), 3),
-                        step_frac=round(value / world * fl / 1e12 / PEAK_BF16_TFLOPS, 4))
+                        step_frac=round(value / world * fl / 1e12 / (PEAK_FP8_TFLOPS if args.fp8 else PEAK_BF16_TFLOPS), 4),
+                        step_frac_peak=PEAK_FP8_TFLOPS if args.fp8 else PEAK_BF16_TFLOPS)
         metric = 'pre-train samples/sec (whole node), %dL/%dd seq=%d+%d' % (cfg['n_layers'], cfg['emb_dim'], cfg['T'], cfg['R'])
         out = dict(metric=metric, value=round(value, 2),
                    unit='sequences/s', n_gpus=world, steps=args.steps, warmup=args.warmup,

@@ -374,6 +374,11 @@ M3P_API int m3p_transpose_batch_bf16(const long long* desc, int n_desc, int max_
 M3P_API int m3p_transpose_bf16(const void* src, void* dst, int rows, int cols, int ld_src, int ld_dst,
                                void* stream);
 
+/* Size of the persistent GEMM grids (process-wide; 0 = one workgroup per CU, the default; a multiple of 8: tiles are dealt
+ * out per XCD).  Data parallelism sets num_CUs - r so that RCCL's r channels find free CUs while a GEMM runs - a persistent
+ * workgroup fills its CU's LDS and registers, nothing co-resides with it (m3p_amd/distributed.py). */
+M3P_API int m3p_set_persistent_grid(int workgroups);
+
 /* ------------------------------------------------------------------------------------
  * Host-glue kernels (csrc/glue.hip): index / mask / loss arithmetic the reference does with chains of elementwise
  * tensor ops around the hot path; one launch each, no host reads.

@@ -32,6 +32,16 @@ __device__ unsigned long long g_attn_tl[4096 * 4 * 16];
 #define ATL(k) do { } while (0)
 #endif
 
+#ifndef M3P_ATTN_BWD_KB
+#define M3P_ATTN_BWD_KB 1
+#endif
+#ifndef M3P_ATTN_BWD_KBQ
+#define M3P_ATTN_BWD_KBQ M3P_ATTN_BWD_KB
+#endif
+#ifndef M3P_ATTN_BWD_NW
+#define M3P_ATTN_BWD_NW 4
+#endif
+
 template <int DH> struct AttnCfg {
   static constexpr int ROWB = DH * 2;        // bytes per K/V row in LDS
   static constexpr int CH = DH / 8;          // 16-B chunks per row
@@ -283,8 +293,12 @@ void attn_fwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
 // (the rolled loop spent 28 of its ~110 VALU instructions per step on address updates); 0 = runtime.
 // NTC: number of 16-row tiles known at compile time as well (11 for S = 164): keep-bit word addresses become
 // immediates off one pointer instead of per-tile scalar arithmetic held in (spilled) SGPRs.
-template <int DH, int KT, bool DROP, bool MASK, int NKC, int NTC, int NW = 4>
-__global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 3)   // NW = 4: three 49-KB workgroups per CU; 8: one ~100-KB workgroup (long S)
+// KB: 16-row blocks a wave owns per pass (1 or 2).  With 2, the streamed operand's fragments (Q / dO rows and their
+// transposes in phase A, K / V in phase B) are fetched once for two owned blocks: half the LDS reads per MFMA, and two
+// independent MFMA -> softmax -> MFMA chains per wave to hide each other's waits (counters, r03: the waves of this kernel
+// sit in s_waitcnt 56 % of their cycles; LDS array ~45 % busy).  Costs registers: KB = 2 runs two workgroups per CU.
+template <int DH, int KT, bool DROP, bool MASK, int NKC, int NTC, int NW = 4, int KB = 1, int KBQ = KB>
+__global__ __launch_bounds__(NW * 64, (NW == 8 || (KB == 2 && NW != 6)) ? 2 : 3)   // NW = 4: three 49-KB workgroups per CU; 8: one ~100-KB workgroup (long S)
 void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keylen, const bf16* __restrict__ ctx,
                      const bf16* __restrict__ dctx, const float* __restrict__ lse,
                      const unsigned long long* __restrict__ keepmask, bf16* __restrict__ dqkv,
@@ -385,35 +399,45 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
   stage_rows<DH>(Qg, ld, S, nk * 32, s0, wid, lane, NW);
   stage_rows<DH>(dOg, (size_t)dmodel, S, nk * 32, s1, wid, lane, NW);
   // this wave's first K / V fragments do not depend on LDS: fetch them under the staging latency
-  bf16x8 kf[Cf::KK], vf[Cf::KK];
-  auto load_kv = [&](int kb) {
+  bf16x8 kf[KB][Cf::KK], vf[KB][Cf::KK];
+  auto load_kv = [&](int u, int kb) {
     const int keyc = min(kb * 16 + fq, S - 1);
 #pragma unroll
     for (int kk = 0; kk < Cf::KK; ++kk) {
-      kf[kk] = *reinterpret_cast<const bf16x8*>(Kg + (size_t)keyc * ld + 32 * kk + 8 * fg);
-      vf[kk] = *reinterpret_cast<const bf16x8*>(Vg + (size_t)keyc * ld + 32 * kk + 8 * fg);
+      kf[u][kk] = *reinterpret_cast<const bf16x8*>(Kg + (size_t)keyc * ld + 32 * kk + 8 * fg);
+      vf[u][kk] = *reinterpret_cast<const bf16x8*>(Vg + (size_t)keyc * ld + 32 * kk + 8 * fg);
     }
   };
-  if (wid < nt) load_kv(wid);
+  if (wid * KB < nt) {
+#pragma unroll
+    for (int u = 0; u < KB; ++u) load_kv(u, wid * KB + u);
+  }
   __syncthreads();
 
-  for (int kb = wid; kb < nt; kb += NW) {
-    const int key = kb * 16 + fq;            // this lane's key column
-    const int keyc = min(key, S - 1);
-    const float kbias = (key < klen) ? 0.f : kMasked;
-    if (kb != wid) load_kv(kb);
+  for (int kb0 = wid * KB; kb0 < nt; kb0 += NW * KB) {
+    // (an owned block behind the last key tile - odd tile counts with KB = 2 - runs as an all-masked block: p = 0, nothing stored)
+    int key[KB], keyc[KB];
+    float kbias[KB];
+#pragma unroll
+    for (int u = 0; u < KB; ++u) {
+      key[u] = (kb0 + u) * 16 + fq;            // this lane's key column
+      keyc[u] = min(key[u], S - 1);
+      kbias[u] = (key[u] < klen) ? 0.f : kMasked;
+      if (kb0 != wid * KB) load_kv(u, kb0 + u);
+    }
     // dV^T[d][key] = sum_q dO[q][d] Pd[q][key] ; dK^T[d][key] = sum_q Q[q][d] dS[q][key]
     // streamed over 32-query steps: P / dS of a step are produced (lane = key column, query
     // 16t + 4fg + r) and consumed as MFMA B operands at once — nothing S x S is held
-    f32x4 dv[Cf::NT], dk[Cf::NT];
+    f32x4 dv[KB][Cf::NT], dk[KB][Cf::NT];
 #pragma unroll
-    for (int n = 0; n < Cf::NT; ++n) dv[n] = dk[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int u = 0; u < KB; ++u)
+#pragma unroll
+      for (int n = 0; n < Cf::NT; ++n) dv[u][n] = dk[u][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll(NKC ? NKC : 1)
     for (int kq = 0; kq < nk; ++kq) {
-      f32x4 pd2[2], ds2[2];
-      // the four MFMA chains of a step (scores and dPd of both 16-query tiles) are issued interleaved, k-step
-      // outermost, so that no MFMA waits on the one just issued
-      f32x4 scA[2], dpA[2], dnegA[2];
+      // the MFMA chains of a step (scores and dPd of both 16-query tiles, of every owned block) are issued interleaved,
+      // k-step outermost, so that no MFMA waits on the one just issued
+      f32x4 scA[KB][2], dpA[KB][2], dnegA[2];
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         const int t = 2 * kq + hf;
@@ -421,8 +445,11 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
         // without dropout dPd - D comes straight out of the MFMA (accumulator starts at -D[q])
         dnegA[hf] = f32x4{-sD[16 * t + 4 * fg + 0], -sD[16 * t + 4 * fg + 1], -sD[16 * t + 4 * fg + 2],
                           -sD[16 * t + 4 * fg + 3]};
-        scA[hf] = f32x4{kbias, kbias, kbias, kbias};
-        dpA[hf] = DROP ? f32x4{0.f, 0.f, 0.f, 0.f} : dnegA[hf];
+#pragma unroll
+        for (int u = 0; u < KB; ++u) {
+          scA[u][hf] = f32x4{kbias[u], kbias[u], kbias[u], kbias[u]};
+          dpA[u][hf] = DROP ? f32x4{0.f, 0.f, 0.f, 0.f} : dnegA[hf];
+        }
       }
 #pragma unroll
       for (int kk = 0; kk < Cf::KK; ++kk) {
@@ -432,75 +459,89 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
           if (PAD_TILE(t)) continue;   // query tile that is pure padding (S = 164: rows 176..191)
           const bf16x8 qf = *reinterpret_cast<const bf16x8*>(s0 + t * 16 * Cf::ROWB + r_off[kk]);
           const bf16x8 df = *reinterpret_cast<const bf16x8*>(s1 + t * 16 * Cf::ROWB + r_off[kk]);
-          scA[hf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf[kk], scA[hf], 0, 0, 0);   // S[q][key]
-          dpA[hf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, vf[kk], dpA[hf], 0, 0, 0);   // dPd[q][key]
-        }
-      }
 #pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {
-        const int t = 2 * kq + hf;
-        if (PAD_TILE(t)) {      // (skipping the padded tile measured slower with MASK): contributes zeros
-          pd2[hf] = ds2[hf] = f32x4{0.f, 0.f, 0.f, 0.f};
-          continue;
-        }
-        const f32x4 dneg = dnegA[hf], sc = scA[hf], dp = dpA[hf];
-        uint32_t kbits = 0;
-        if (MASK) {
-          // forward layout: word [qb = t][tile = kb][r = key & 3], bit (q & 15) + 16 ((key & 15) >> 2)
-          const unsigned long long w = mbh[((size_t)min(t, nt - 1) * nt + kb) * 4 + (fq & 3)];
-          kbits = (uint32_t)(w >> (4 * fg + 16 * (fq >> 2)));
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int q = 16 * t + 4 * fg + r;
-          const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[r], kLog2e, -sL[q]));   // padded q: lse = +inf -> 0
-          if (DROP) {
-            float kfac;      // inv_keep if kept, else 0
-            if (MASK) {
-              kfac = __builtin_bit_cast(float, (uint32_t)__builtin_amdgcn_sbfe(kbits, r, 1) & inv_keep_bits);
-            } else {
-              const uint32_t idx = (uint32_t)((b * H + h) * S + min(q, S - 1)) * (uint32_t)S + (uint32_t)keyc;
-              kfac = m3p_keep(idx, seed, thresh24) ? inv_keep : 0.f;
-            }
-            pd2[hf][r] = p * kfac;
-            ds2[hf][r] = p * __builtin_fmaf(dp[r], kfac, dneg[r]);
-          } else {
-            pd2[hf][r] = p;
-            ds2[hf][r] = p * dp[r];
+          for (int u = 0; u < KB; ++u) {
+            scA[u][hf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf[u][kk], scA[u][hf], 0, 0, 0);   // S[q][key]
+            dpA[u][hf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, vf[u][kk], dpA[u][hf], 0, 0, 0);   // dPd[q][key]
           }
         }
       }
-      const bf16x8 pfrag = bf16x8{(bf16)pd2[0][0], (bf16)pd2[0][1], (bf16)pd2[0][2], (bf16)pd2[0][3],
-                                  (bf16)pd2[1][0], (bf16)pd2[1][1], (bf16)pd2[1][2], (bf16)pd2[1][3]};
-      const bf16x8 sfrag = bf16x8{(bf16)ds2[0][0], (bf16)ds2[0][1], (bf16)ds2[0][2], (bf16)ds2[0][3],
-                                  (bf16)ds2[1][0], (bf16)ds2[1][1], (bf16)ds2[1][2], (bf16)ds2[1][3]};
+      bf16x8 pfrag[KB], sfrag[KB];
+#pragma unroll
+      for (int u = 0; u < KB; ++u) {
+        f32x4 pd2[2], ds2[2];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          const int t = 2 * kq + hf;
+          if (PAD_TILE(t)) {      // (skipping the padded tile measured slower with MASK): contributes zeros
+            pd2[hf] = ds2[hf] = f32x4{0.f, 0.f, 0.f, 0.f};
+            continue;
+          }
+          const f32x4 dneg = dnegA[hf], sc = scA[u][hf], dp = dpA[u][hf];
+          uint32_t kbits = 0;
+          if (MASK) {
+            // forward layout: word [qb = t][tile = kb][r = key & 3], bit (q & 15) + 16 ((key & 15) >> 2)
+            const unsigned long long w = mbh[((size_t)min(t, nt - 1) * nt + min(kb0 + u, nt - 1)) * 4 + (fq & 3)];
+            kbits = (uint32_t)(w >> (4 * fg + 16 * (fq >> 2)));
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int q = 16 * t + 4 * fg + r;
+            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[r], kLog2e, -sL[q]));   // padded q: lse = +inf -> 0
+            if (DROP) {
+              float kfac;      // inv_keep if kept, else 0
+              if (MASK) {
+                kfac = __builtin_bit_cast(float, (uint32_t)__builtin_amdgcn_sbfe(kbits, r, 1) & inv_keep_bits);
+              } else {
+                const uint32_t idx = (uint32_t)((b * H + h) * S + min(q, S - 1)) * (uint32_t)S + (uint32_t)keyc[u];
+                kfac = m3p_keep(idx, seed, thresh24) ? inv_keep : 0.f;
+              }
+              pd2[hf][r] = p * kfac;
+              ds2[hf][r] = p * __builtin_fmaf(dp[r], kfac, dneg[r]);
+            } else {
+              pd2[hf][r] = p;
+              ds2[hf][r] = p * dp[r];
+            }
+          }
+        }
+        pfrag[u] = bf16x8{(bf16)pd2[0][0], (bf16)pd2[0][1], (bf16)pd2[0][2], (bf16)pd2[0][3],
+                          (bf16)pd2[1][0], (bf16)pd2[1][1], (bf16)pd2[1][2], (bf16)pd2[1][3]};
+        sfrag[u] = bf16x8{(bf16)ds2[0][0], (bf16)ds2[0][1], (bf16)ds2[0][2], (bf16)ds2[0][3],
+                          (bf16)ds2[1][0], (bf16)ds2[1][1], (bf16)ds2[1][2], (bf16)ds2[1][3]};
+      }
 #pragma unroll
       for (int n = 0; n < Cf::NT; ++n) {
         const char* pq = s0 + kq * 32 * Cf::ROWB + t_off[n];
         const char* pdo = s1 + kq * 32 * Cf::ROWB + t_off[n];
         const bf16x8 qT = cat8(lds_tr16(pq), lds_tr16(pq + 16 * Cf::ROWB));
         const bf16x8 dT = cat8(lds_tr16(pdo), lds_tr16(pdo + 16 * Cf::ROWB));
-        dv[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dT, pfrag, dv[n], 0, 0, 0);
-        dk[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qT, sfrag, dk[n], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < KB; ++u) {
+          dv[u][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dT, pfrag[u], dv[u][n], 0, 0, 0);
+          dk[u][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qT, sfrag[u], dk[u][n], 0, 0, 0);
+        }
       }
       if (NKC) __builtin_amdgcn_sched_barrier(0);   // unrolled steps stay in order: no register blow-up from hoisted loads
     }
-    if (key < S) {
-      bf16* pk = dKg + (size_t)key * ld + 4 * fg;
-      bf16* pv = dVg + (size_t)key * ld + 4 * fg;
 #pragma unroll
-      for (int n = 0; n < Cf::NT; ++n) {
-        const bf16x4 kb4 = bf16x4{(bf16)dk[n][0], (bf16)dk[n][1], (bf16)dk[n][2], (bf16)dk[n][3]};
-        const bf16x4 vb4 = bf16x4{(bf16)dv[n][0], (bf16)dv[n][1], (bf16)dv[n][2], (bf16)dv[n][3]};
-        *reinterpret_cast<bf16x4*>(pk + 16 * n) = kb4;
-        *reinterpret_cast<bf16x4*>(pv + 16 * n) = vb4;
+    for (int u = 0; u < KB; ++u) {
+      if (key[u] < S) {
+        bf16* pk = dKg + (size_t)key[u] * ld + 4 * fg;
+        bf16* pv = dVg + (size_t)key[u] * ld + 4 * fg;
+#pragma unroll
+        for (int n = 0; n < Cf::NT; ++n) {
+          const bf16x4 kb4 = bf16x4{(bf16)dk[u][n][0], (bf16)dk[u][n][1], (bf16)dk[u][n][2], (bf16)dk[u][n][3]};
+          const bf16x4 vb4 = bf16x4{(bf16)dv[u][n][0], (bf16)dv[u][n][1], (bf16)dv[u][n][2], (bf16)dv[u][n][3]};
+          *reinterpret_cast<bf16x4*>(pk + 16 * n) = kb4;
+          *reinterpret_cast<bf16x4*>(pv + 16 * n) = vb4;
+        }
       }
-    }
-    if (dbias_qkv) {   // (rows >= S contribute zeros; the shuffles need all 64 lanes)
+      if (dbias_qkv) {   // (rows >= S contribute zeros; the shuffles need all 64 lanes)
 #pragma unroll
-      for (int n = 0; n < Cf::NT; ++n) {
-        const bool ok = key < S;
-        bias_acc(n, ok ? bf16x4{(bf16)dv[n][0], (bf16)dv[n][1], (bf16)dv[n][2], (bf16)dv[n][3]} : bf16x4{0, 0, 0, 0});
+        for (int n = 0; n < Cf::NT; ++n) {
+          const bool ok = key[u] < S;
+          bias_acc(n, ok ? bf16x4{(bf16)dv[u][n][0], (bf16)dv[u][n][1], (bf16)dv[u][n][2], (bf16)dv[u][n][3]} : bf16x4{0, 0, 0, 0});
+        }
       }
     }
   }
@@ -510,111 +551,137 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
   // ================= phase B: dQ (wave owns query blocks) =================
   stage_rows<DH>(Kg, ld, S, nk * 32, s0, wid, lane, NW);
   stage_rows<DH>(Vg, ld, S, nk * 32, s1, wid, lane, NW);
-  bf16x8 qf[Cf::KK], df[Cf::KK];
-  auto load_qd = [&](int qb) {
+  bf16x8 qf[KBQ][Cf::KK], df[KBQ][Cf::KK];
+  auto load_qd = [&](int u, int qb) {
     const int qc = min(qb * 16 + fq, S - 1);
 #pragma unroll
     for (int kk = 0; kk < Cf::KK; ++kk) {
-      qf[kk] = *reinterpret_cast<const bf16x8*>(Qg + (size_t)qc * ld + 32 * kk + 8 * fg);
-      df[kk] = *reinterpret_cast<const bf16x8*>(dOg + (size_t)qc * dmodel + 32 * kk + 8 * fg);
+      qf[u][kk] = *reinterpret_cast<const bf16x8*>(Qg + (size_t)qc * ld + 32 * kk + 8 * fg);
+      df[u][kk] = *reinterpret_cast<const bf16x8*>(dOg + (size_t)qc * dmodel + 32 * kk + 8 * fg);
     }
   };
-  if (wid < nt) load_qd(wid);
+  if (wid * KBQ < nt) {
+#pragma unroll
+    for (int u = 0; u < KBQ; ++u) load_qd(u, wid * KBQ + u);
+  }
   __syncthreads();
 
-  for (int qb = wid; qb < nt; qb += NW) {
-    const int q = qb * 16 + fq;
-    const int qc = min(q, S - 1);
-    if (qb != wid) load_qd(qb);
-    const float lq = sL[q], dq_ = sD[q];      // lse (log2 units) and D of this lane's query
+  for (int qb0 = wid * KBQ; qb0 < nt; qb0 += NW * KBQ) {
+    int q[KBQ], qc[KBQ];
+    float lq[KBQ], dq_[KBQ];      // lse (log2 units) and D of this lane's queries (a block behind the last tile: lse = +inf -> p = 0)
+    uint32_t rbase[KBQ];
+#pragma unroll
+    for (int u = 0; u < KBQ; ++u) {
+      q[u] = (qb0 + u) * 16 + fq;
+      qc[u] = min(q[u], S - 1);
+      if (qb0 != wid * KBQ) load_qd(u, qb0 + u);
+      const bool in = q[u] < nk * 32;
+      lq[u] = in ? sL[min(q[u], nk * 32 - 1)] : INFINITY;
+      dq_[u] = in ? sD[min(q[u], nk * 32 - 1)] : 0.f;
+      rbase[u] = (uint32_t)((b * H + h) * S + qc[u]) * (uint32_t)S;
+    }
     int klen_it = klen;
     asm volatile("" : "+s"(klen_it));   // opaque per query block: keeps the key-mask tests inside the loop
-    const uint32_t rbase = (uint32_t)((b * H + h) * S + qc) * (uint32_t)S;
     // dQ^T[d][q] = sum_key K[key][d] dS[q][key], streamed over 32-key steps
-    f32x4 dq[Cf::NT];
+    f32x4 dq[KBQ][Cf::NT];
 #pragma unroll
-    for (int n = 0; n < Cf::NT; ++n) dq[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int u = 0; u < KBQ; ++u)
+#pragma unroll
+      for (int n = 0; n < Cf::NT; ++n) dq[u][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll(NKC ? NKC : 1)
     for (int kq = 0; kq < nk; ++kq) {
-      f32x4 ds2[2];
-      f32x4 scB[2], dpB[2];
+      f32x4 scB[KBQ][2], dpB[KBQ][2];
 #pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {
-        scB[hf] = f32x4{0.f, 0.f, 0.f, 0.f};
-        dpB[hf] = DROP ? f32x4{0.f, 0.f, 0.f, 0.f} : f32x4{-dq_, -dq_, -dq_, -dq_};
-      }
+      for (int u = 0; u < KBQ; ++u)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          scB[u][hf] = f32x4{0.f, 0.f, 0.f, 0.f};
+          dpB[u][hf] = DROP ? f32x4{0.f, 0.f, 0.f, 0.f} : f32x4{-dq_[u], -dq_[u], -dq_[u], -dq_[u]};
+        }
 #pragma unroll
       for (int kk = 0; kk < Cf::KK; ++kk) {
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
           const int t = 2 * kq + hf;
           if (PAD_TILE(t)) continue;   // key tile beyond the sequence
-          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(s0 + t * 16 * Cf::ROWB + r_off[kk]);
-          const bf16x8 vf = *reinterpret_cast<const bf16x8*>(s1 + t * 16 * Cf::ROWB + r_off[kk]);
-          scB[hf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[kk], scB[hf], 0, 0, 0);   // S^T[key][q]
-          dpB[hf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, df[kk], dpB[hf], 0, 0, 0);   // dPd^T[key][q]
-        }
-      }
+          const bf16x8 kfr = *reinterpret_cast<const bf16x8*>(s0 + t * 16 * Cf::ROWB + r_off[kk]);
+          const bf16x8 vfr = *reinterpret_cast<const bf16x8*>(s1 + t * 16 * Cf::ROWB + r_off[kk]);
 #pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {
-        const int t = 2 * kq + hf;
-        if (PAD_TILE(t)) {
-          ds2[hf] = f32x4{0.f, 0.f, 0.f, 0.f};
-          continue;
-        }
-        f32x4 sc = scB[hf];
-        const f32x4 dp = dpB[hf];
-        const unsigned long long* mw = MASK ? mbh + ((size_t)qb * nt + min(t, nt - 1)) * 4 : nullptr;   // wave-uniform
-        // keys >= klen: only the tile straddling klen (or behind it) needs per-element tests (wave-uniform branch;
-        // per-element compares are loop-invariant lane masks the compiler hoists into spilled SGPRs)
-        if (16 * t + 16 > klen_it) {
-          asm volatile("");   // (keeps this a branch: if-converted it is 2 VALU ops on every element)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) sc[r] = (16 * t + 4 * fg + r < klen_it) ? sc[r] : kMasked;
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = 16 * t + 4 * fg + r;
-          const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[r], kLog2e, -lq));
-          if (DROP) {
-            float kfac;
-            if (MASK) {
-              // this lane's own bit of the forward ballot: the 64-bit word IS the select mask
-              asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(kfac) : "v"(inv_keep), "s"(mw[r]));
-            } else {
-              kfac = m3p_keep(rbase + (uint32_t)min(key, S - 1), seed, thresh24) ? inv_keep : 0.f;
-            }
-            ds2[hf][r] = p * __builtin_fmaf(dp[r], kfac, -dq_);
-          } else {
-            ds2[hf][r] = p * dp[r];
+          for (int u = 0; u < KBQ; ++u) {
+            scB[u][hf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, qf[u][kk], scB[u][hf], 0, 0, 0);   // S^T[key][q]
+            dpB[u][hf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr, df[u][kk], dpB[u][hf], 0, 0, 0);   // dPd^T[key][q]
           }
         }
       }
-      const bf16x8 sfrag = bf16x8{(bf16)ds2[0][0], (bf16)ds2[0][1], (bf16)ds2[0][2], (bf16)ds2[0][3],
-                                  (bf16)ds2[1][0], (bf16)ds2[1][1], (bf16)ds2[1][2], (bf16)ds2[1][3]};
+      bf16x8 sfrag[KBQ];
+#pragma unroll
+      for (int u = 0; u < KBQ; ++u) {
+        f32x4 ds2[2];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          const int t = 2 * kq + hf;
+          if (PAD_TILE(t)) {
+            ds2[hf] = f32x4{0.f, 0.f, 0.f, 0.f};
+            continue;
+          }
+          f32x4 sc = scB[u][hf];
+          const f32x4 dp = dpB[u][hf];
+          const unsigned long long* mw = MASK ? mbh + ((size_t)min(qb0 + u, nt - 1) * nt + min(t, nt - 1)) * 4 : nullptr;   // wave-uniform
+          // keys >= klen: only the tile straddling klen (or behind it) needs per-element tests (wave-uniform branch;
+          // per-element compares are loop-invariant lane masks the compiler hoists into spilled SGPRs)
+          if (16 * t + 16 > klen_it) {
+            asm volatile("");   // (keeps this a branch: if-converted it is 2 VALU ops on every element)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sc[r] = (16 * t + 4 * fg + r < klen_it) ? sc[r] : kMasked;
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = 16 * t + 4 * fg + r;
+            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[r], kLog2e, -lq[u]));
+            if (DROP) {
+              float kfac;
+              if (MASK) {
+                // this lane's own bit of the forward ballot: the 64-bit word IS the select mask
+                asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(kfac) : "v"(inv_keep), "s"(mw[r]));
+              } else {
+                kfac = m3p_keep(rbase[u] + (uint32_t)min(key, S - 1), seed, thresh24) ? inv_keep : 0.f;
+              }
+              ds2[hf][r] = p * __builtin_fmaf(dp[r], kfac, -dq_[u]);
+            } else {
+              ds2[hf][r] = p * dp[r];
+            }
+          }
+        }
+        sfrag[u] = bf16x8{(bf16)ds2[0][0], (bf16)ds2[0][1], (bf16)ds2[0][2], (bf16)ds2[0][3],
+                          (bf16)ds2[1][0], (bf16)ds2[1][1], (bf16)ds2[1][2], (bf16)ds2[1][3]};
+      }
 #pragma unroll
       for (int n = 0; n < Cf::NT; ++n) {
         const char* pk = s0 + kq * 32 * Cf::ROWB + t_off[n];
         const bf16x8 kT = cat8(lds_tr16(pk), lds_tr16(pk + 16 * Cf::ROWB));
-        dq[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kT, sfrag, dq[n], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < KBQ; ++u) dq[u][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kT, sfrag[u], dq[u][n], 0, 0, 0);
       }
       if (NKC) __builtin_amdgcn_sched_barrier(0);
     }
-    if (q < S) {
-      bf16* pq = dQg + (size_t)q * ld + 4 * fg;
 #pragma unroll
-      for (int n = 0; n < Cf::NT; ++n) {
-        const bf16x4 qb4 = bf16x4{(bf16)(dq[n][0] * qscale), (bf16)(dq[n][1] * qscale), (bf16)(dq[n][2] * qscale),
-                                  (bf16)(dq[n][3] * qscale)};
-        *reinterpret_cast<bf16x4*>(pq + 16 * n) = qb4;
+    for (int u = 0; u < KBQ; ++u) {
+      if (q[u] < S) {
+        bf16* pq = dQg + (size_t)q[u] * ld + 4 * fg;
+#pragma unroll
+        for (int n = 0; n < Cf::NT; ++n) {
+          const bf16x4 qb4 = bf16x4{(bf16)(dq[u][n][0] * qscale), (bf16)(dq[u][n][1] * qscale), (bf16)(dq[u][n][2] * qscale),
+                                    (bf16)(dq[u][n][3] * qscale)};
+          *reinterpret_cast<bf16x4*>(pq + 16 * n) = qb4;
+        }
       }
-    }
-    if (dbias_qkv) {
+      if (dbias_qkv) {
 #pragma unroll
-      for (int n = 0; n < Cf::NT; ++n) {
-        const bool ok = q < S;
-        bias_acc(n, ok ? bf16x4{(bf16)(dq[n][0] * qscale), (bf16)(dq[n][1] * qscale), (bf16)(dq[n][2] * qscale),
-                                   (bf16)(dq[n][3] * qscale)} : bf16x4{0, 0, 0, 0});
+        for (int n = 0; n < Cf::NT; ++n) {
+          const bool ok = q[u] < S;
+          bias_acc(n, ok ? bf16x4{(bf16)(dq[u][n][0] * qscale), (bf16)(dq[u][n][1] * qscale), (bf16)(dq[u][n][2] * qscale),
+                                     (bf16)(dq[u][n][3] * qscale)} : bf16x4{0, 0, 0, 0});
+        }
       }
     }
   }
@@ -669,15 +736,19 @@ int launch_bwd(const bf16* qkv, const int* keylen, const bf16* ctx, const bf16* 
                uint32_t seed, uint32_t thresh24, float inv_keep, hipStream_t st) {
   const int nk = (S + 31) / 32;
   const bool wide = (size_t)2 * ((size_t)2 * nk * 32 * DH * 2) > 160 * 1024;   // one workgroup per CU anyway: eight waves
-  const size_t lds = (size_t)2 * nk * 32 * DH * 2 + (size_t)2 * nk * 32 * sizeof(float) + (wide ? 24 : 12) * DH * sizeof(float);
+  // the M3P sequence (36 regions + 128 tokens: 11 tiles, 6 steps): M3P_ATTN_BWD_KB blocks per wave pass, M3P_ATTN_BWD_NW waves
+  const bool m3p_seq = nk == 6 && (S + 15) / 16 == 11;
+  const int nwaves = wide ? 8 : (m3p_seq ? M3P_ATTN_BWD_NW : 4);
+  const size_t lds = (size_t)2 * nk * 32 * DH * 2 + (size_t)2 * nk * 32 * sizeof(float) + 3 * nwaves * DH * sizeof(float);
 #define M3P_ATTN_BWD(KT, DROP, MASK)                                                                            \
   do {                                                                                                          \
     auto kern = attn_bwd_kernel<DH, KT, DROP, MASK, 0, 0>;                                                      \
     if (wide) kern = attn_bwd_kernel<DH, KT, DROP, MASK, 0, 0, 8>;                                              \
-    if (nk == 6) kern = (S + 15) / 16 == 11 ? attn_bwd_kernel<DH, KT, DROP, MASK, 6, 11> : attn_bwd_kernel<DH, KT, DROP, MASK, 6, 0>;                                                                  \
+    if (nk == 6) kern = attn_bwd_kernel<DH, KT, DROP, MASK, 6, 0>;                                              \
+    if (m3p_seq) kern = attn_bwd_kernel<DH, KT, DROP, MASK, 6, 11, M3P_ATTN_BWD_NW, M3P_ATTN_BWD_KB, M3P_ATTN_BWD_KBQ>;           \
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     if (e != hipSuccess) return (int)e;                                                                         \
-    hipLaunchKernelGGL(kern, dim3(B* H), dim3(wide ? 512 : 256), lds, st, qkv, keylen, ctx, dctx, lse, keepmask, dqkv, dbias, S, H, \
+    hipLaunchKernelGGL(kern, dim3(B* H), dim3(nwaves * 64), lds, st, qkv, keylen, ctx, dctx, lse, keepmask, dqkv, dbias, S, H, \
                        dmodel, qscale, seed, thresh24, inv_keep);                                               \
   } while (0)
   if (nk > 16) return M3P_EINVAL;

@@ -900,7 +900,7 @@ void gemm_nt_w8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
   //  issued one after every fourth MFMA instead of in front of the cluster
   auto mfma_q = [&](auto half_c, const bf16x8 (&af)[4], const bf16x8 (&wf)[4], int ld_s = 0, int ld_p0 = 0, int ld_n = 0) {
     constexpr int I0 = 4 * decltype(half_c)::value;
-    if (M3P_W8_SETPRIO) __builtin_amdgcn_s_setprio(1);
+    if (M3P_W8_SETPRIO == 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -912,8 +912,11 @@ void gemm_nt_w8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    if (M3P_W8_SETPRIO) __builtin_amdgcn_s_setprio(0);
+    if (M3P_W8_SETPRIO == 1) __builtin_amdgcn_s_setprio(0);
   };
+  // M3P_W8_SETPRIO == 2 (A/B build): static priority for the younger half of the workgroup instead of flips around every
+  // MFMA cluster (MI355X_MICROARCH.md "Two waves per SIMD", item 4)
+  if (M3P_W8_SETPRIO == 2 && wid >= 4) __builtin_amdgcn_s_setprio(1);
   using H0 = std::integral_constant<int, 0>;
   using H1 = std::integral_constant<int, 1>;
 
@@ -2143,7 +2146,7 @@ int launch_nt_skinny(const bf16* A, int lda, const bf16* W, int ldw, bf16* C, in
   return M3P_OK;
 }
 
-static int num_cus() {
+static int hw_cus() {
   static int n = 0;
   if (n == 0) {
     int dev = 0;
@@ -2154,6 +2157,13 @@ static int num_cus() {
     if (n <= 0) n = 8;
   }
   return n;
+}
+// workgroups of a persistent grid: one per CU, or what m3p_set_persistent_grid left of them (data parallelism: RCCL's
+// kernels need CUs of their own - a persistent GEMM workgroup fills its CU's LDS, nothing can co-reside with it)
+static int g_persistent_grid = 0;
+static int num_cus() {
+  const int hw = hw_cus();
+  return (g_persistent_grid > 0 && g_persistent_grid < hw) ? g_persistent_grid : hw;
 }
 
 template <int EPI>
@@ -3207,8 +3217,14 @@ int m3p_gemm_nn_streamk_f32(const void* A, int lda, const void* W, int ldw, int 
   return launch_streamk(A, lda, W, ldw, C, ldc, M, N, K, alpha, true, k_valid, stream);
 }
 
+int m3p_set_persistent_grid(int workgroups) {
+  if (workgroups < 0 || (workgroups % 8) != 0) return M3P_EINVAL;
+  g_persistent_grid = workgroups;
+  return M3P_OK;
+}
+
 size_t m3p_gemm_wgrad_workspace_bytes(void) {
-  const size_t grid = (size_t)num_cus();
+  const size_t grid = (size_t)hw_cus();
   return grid * (65536 + 272) * sizeof(float) + grid * sizeof(int);
 }
 

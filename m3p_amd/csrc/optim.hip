@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16* __restr
 
 // batched variant: desc[i] = {src, dst, rows, cols, ld_src, ld_dst} (int64 each), one grid.y slice per matrix
 __global__ __launch_bounds__(256) void transpose_batch_kernel(const long long* __restrict__ desc) {
-  __shared__ bf16 tile[64][66];
+  __shared__ bf16 tile[64][72];       // 144-byte rows: 16-byte aligned for the row-wise stores, 4-bank skew for the column reads
   const long long* dsc = desc + 6 * blockIdx.y;
   const bf16* src = reinterpret_cast<const bf16*>(dsc[0]);
   bf16* dst = reinterpret_cast<bf16*>(dsc[1]);
@@ -216,6 +216,28 @@ __global__ __launch_bounds__(256) void transpose_batch_kernel(const long long* _
   const int tiles_c = (cols + 63) / 64, tiles_r = (rows + 63) / 64;
   if ((int)blockIdx.x >= tiles_c * tiles_r) return;
   const int tr = (blockIdx.x / tiles_c) * 64, tc = (blockIdx.x % tiles_c) * 64;
+  // whole 64 x 64 tiles of 16-byte-aligned matrices (every layer weight): 16-byte accesses on both sides - a lane reads 8
+  // consecutive columns of a row and later writes 8 consecutive rows of a column (2-byte accesses moved 2.2 TB/s: r02)
+  const bool fast = tr + 64 <= rows && tc + 64 <= cols && (ld_src & 7) == 0 && (ld_dst & 7) == 0 &&
+                    (((uintptr_t)src | (uintptr_t)dst) & 15) == 0;
+  if (fast) {
+    const int q = threadIdx.x & 7, rr = threadIdx.x >> 3;          // 8 lanes per 128-byte row piece, 32 rows per pass
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int r = rr + 32 * p;
+      *reinterpret_cast<bf16x8*>(&tile[r][8 * q]) = *reinterpret_cast<const bf16x8*>(src + (size_t)(tr + r) * ld_src + tc + 8 * q);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int c = rr + 32 * p;                                   // output row = source column
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = tile[8 * q + e][c];
+      *reinterpret_cast<bf16x8*>(dst + (size_t)(tc + c) * ld_dst + tr + 8 * q) = o;
+    }
+    return;
+  }
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   for (int i = ty; i < 64; i += 4) {
     const int r = tr + i, c = tc + tx;

@@ -360,3 +360,22 @@ extern "C" __attribute__((visibility("default"))) int m3p_debug_probe_issue2(int
 #undef LAUNCH
   return (int)hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------------
+// Stand-in for a collective's kernel (debug export, not part of the ABI header): `nblocks` workgroups of 512 threads
+// stream `bytes` from src to dst - like RCCL's channels, each workgroup wants a CU of its own and lives as long as its
+// share of the copy takes.  tools/cu_reserve_ab.py runs it on a side stream beside the training step to price the CUs the
+// persistent GEMM grids leave free under data parallelism (m3p_set_persistent_grid).
+// ---------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(512) void side_copy_kernel(const f32x4* __restrict__ src, f32x4* __restrict__ dst, size_t n16) {
+  for (size_t i = (size_t)blockIdx.x * 512 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 512) dst[i] = src[i];
+}
+}  // namespace
+extern "C" __attribute__((visibility("default"))) int m3p_debug_side_copy(const void* src, void* dst, size_t bytes, int nblocks,
+                                                                           void* stream) {
+  if (nblocks <= 0 || (bytes & 15)) return M3P_EINVAL;
+  hipLaunchKernelGGL(side_copy_kernel, dim3(nblocks), dim3(512), 0, (hipStream_t)stream, (const f32x4*)src, (f32x4*)dst, bytes >> 4);
+  M3P_CHECK_LAUNCH();
+  return M3P_OK;
+}

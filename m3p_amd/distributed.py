@@ -2,29 +2,40 @@
 ``torch.distributed`` (backend "nccl" *is* RCCL on ROCm).
 
 Replaces the reference's wiring at M3P/src/xtrainer.py:66-83 (Apex
-``DistributedDataParallel(delay_allreduce=True)`` — one flat all-reduce of every gradient
+``DistributedDataParallel(delay_allreduce=True)`` - one flat all-reduce of every gradient
 *after* backward, fully exposed) and M3P/src/slurm.py:156-170 (process-group init).
 
 Design.  The model's gradients live in ONE flat fp32 arena laid out in forward order, so a
-"bucket" is an arena slice and nothing is copied, flattened or unflattened.  Per optimizer
-step the collectives are issued on a side stream in this fixed, rank-independent order:
+"bucket" is an arena slice and nothing is copied, flattened or unflattened.  Bucket boundaries sit
+on multiples of 512 elements (functional.Arena), so for 2 / 4 / 8 ranks every bucket splits into
+equal 64-aligned shards and the exchange is the sharded-optimizer form (``mode = 'zero1'``,
+numerically the all-reduce's result - SURVEY 8e):
 
-  1. ``vocab``   the tied vocabulary matrix + its bias (768 MB at V = 250 002): only its DENSE
-                 part, the MLM-head weight gradient, which is final as soon as
-                 ``MLMHeadFn.backward`` returns - the very first thing backward does.  The
-                 largest collective therefore overlaps with the whole encoder backward.
-                 Steps without an MLM head (ITM fine-tuning) skip it entirely.
-  2. ``heads``   pooler / relation / region heads (a few MB), when the last encoder backward starts.
-  3. ``layer i`` as soon as layer i's weight-gradient kernels are enqueued (28 MB at 768d).
-  4. ``embed``   positions, embedding LayerNorm, image projection (+ refiner) after the
-                 assembly backward.
-  5. ``tokens``  the embedding-LOOKUP gradient, the only part of the vocabulary matrix that
-                 is produced at the very end of backward, travels as what it is: <= B*T rows.
-                 ``m3p_embed_assemble_bwd`` writes them as bf16 rows instead of scattering,
-                 the ranks all-gather (ids, rows) and every rank scatter-adds all of them in
-                 fp32 (``m3p_scatter_add_token_rows``).  50 MB per rank at B = 256 instead of
-                 a second pass over 768 MB.  (bf16 on the wire, fp32 accumulation: the rows
-                 are gradients of bf16 activations; stated in DESIGN.md §5.)
+  backward   ``reduce_scatter`` of a bucket the moment its last gradient kernel is enqueued, on a side
+             stream, in this fixed, rank-independent order:
+               1. ``vocab``   the tied vocabulary matrix + its bias (768 MB at V = 250 002): only its DENSE
+                              part, the MLM-head weight gradient, final as soon as ``MLMHeadFn.backward``
+                              returns - the first thing backward does - so the largest collective overlaps
+                              with the whole encoder backward.  Steps without an MLM head never reduce it.
+               2. ``heads``   pooler / relation / region heads, when the last encoder backward starts.
+               3. ``layer i`` as soon as layer i's weight-gradient kernels are enqueued (28 MB at 768d).
+               4. ``embed``   positions, embedding LayerNorm, image projection (+ refiner) after the assembly
+                              backward (after the image stream's backward when the step has one).
+               5. ``tokens``  the embedding-LOOKUP gradient, the only part of the vocabulary matrix produced
+                              at the very end of backward, travels as what it is: <= B*T bf16 rows, all-gathered
+                              with their ids and scatter-added in fp32 on every rank (50 MB per rank at B = 256
+                              instead of a second pass over 768 MB).
+  optimizer  the clip norm is the all-reduced sum of the ranks' shard norms (one 8-byte collective); Adam runs on
+             this rank's shard of every bucket only - 1/world of the 9.5 GB the single-GPU step streams;
+  forward    the updated fp32 master shards are ``all_gather``ed bucket by bucket in FORWARD order on the side
+             stream, each followed by its bf16 cast (and, after the last, the transposed copies backward reads);
+             the next step's forward waits per bucket (``params_ready``), so the gather hides under it.
+             Every rank therefore holds the full, identical fp32 master again before anything reads it
+             (checkpoints, evaluation, the fp32 bias / LayerNorm reads of the kernels).
+
+``mode = 'allreduce'`` (other world sizes, or ``M3P_DP_MODE=allreduce``) is round 2's protocol: fp32
+``all_reduce`` per bucket, Adam replicated.  Half of the zero1 wire traffic moves from backward to the next
+forward; the bytes on the wire are the same (ring all-reduce = reduce-scatter + all-gather).
 
 A step may run more than one encoder pass (the CLCM objective runs ``jointfwd`` twice,
 xtrainer.py:2379-2393): passes are counted in forward, and only the LAST backward of a step
@@ -32,6 +43,17 @@ launches layer / embed buckets - earlier ones just accumulate.  ``finish()`` lau
 whatever the plan still owes, waits, applies the token rows; it is idempotent per step (the
 optimizer calls it from ``clip_grad_norm`` and again from ``step``) and re-armed by
 ``step_done()``.  Averaging (1/world) is folded into the Adam kernel's ``grad_scale``.
+
+No call in here blocks the host on the compute stream: the one host read of a step - the largest token-row count
+of ragged batches, needed to size the all-gather - is requested in forward on the side stream and only read at the
+end of backward (``_Pending``); batches the trainer declares uniform (``uniform_tokens``) skip it.
+
+Compute units for RCCL next to the persistent 256-workgroup GEMMs: ``M3P_DP_RESERVE_CUS`` = r makes the GEMM grids leave r
+CUs free (``m3p_set_persistent_grid``) and caps ``NCCL_MAX_NCHANNELS`` at r.  The default is r = 0: measured on one MI355X
+with a 16-workgroup copy kernel on a side stream standing in for the collectives (tools/cu_reserve_ab.py,
+profiles/r03_cu_reserve.txt), 2.7 GB of side traffic per step costs the step 2.6 ms whatever the grids leave free
+(37.6 -> 40.3 ms at 256 workgroups, 41.2 -> 43.1 at 240), while the reservation itself costs 0.4 ms (8 CUs) to 3.6 ms
+(16 CUs: 1968 tiles no longer deal out evenly) - the side kernel finds its slots at kernel boundaries either way.
 """
 import os
 
@@ -50,6 +72,9 @@ def init_distributed_mode(params=None, backend=None):
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
         if backend == 'nccl':
+            # RCCL gets as many channels (one workgroup = one CU each) as the GEMM grids leave free
+            if reserve_cus():
+                os.environ.setdefault('NCCL_MAX_NCHANNELS', str(reserve_cus()))
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, init_method='env://')
     elif torch.cuda.is_available():
@@ -62,53 +87,104 @@ def init_distributed_mode(params=None, backend=None):
     return rank, local_rank, world
 
 
+def reserve_cus():
+    """Compute units the persistent GEMM grids leave to RCCL when world > 1 (a multiple of 8: one per XCD)."""
+    r = int(os.environ.get('M3P_DP_RESERVE_CUS', '0'))
+    return max(0, min(r // 8 * 8, 64))
+
+
 def _all_gather_into(out, inp, group):
-    """out [world * n, ...] <- concatenation of every rank's inp [n, ...] (async work handle)."""
+    """out [world * n, ...] <- concatenation of every rank's inp [n, ...] (async work handle).  ``inp`` may be this
+    rank's slot of ``out`` (the in-place form)."""
     try:
         return dist.all_gather_into_tensor(out, inp, group=group, async_op=True)
-    except (RuntimeError, NotImplementedError):     # backends without the flat form
+    except (RuntimeError, NotImplementedError):     # backends without the flat form (gloo)
         world = dist.get_world_size(group)
-        return dist.all_gather(list(out.chunk(world, dim=0)), inp, group=group, async_op=True)
+        return dist.all_gather(list(out.chunk(world, dim=0)), inp.clone(), group=group, async_op=True)
+
+
+class _Done:
+    def wait(self):
+        pass
+
+
+def _reduce_scatter_inplace(buf, rank, world, group):
+    """Sum ``buf`` over the ranks; this rank's 1/world slice of it receives the result (the other slices keep
+    whatever they held).  -> async work handle."""
+    n = buf.numel() // world
+    mine = buf[rank * n:(rank + 1) * n]
+    if dist.get_backend(group) == 'nccl':
+        return dist.reduce_scatter_tensor(mine, buf, op=dist.ReduceOp.SUM, group=group, async_op=True)
+    # gloo has no reduce-scatter: all-reduce a copy and keep only this rank's slice - the other slices stay
+    # un-reduced exactly as after RCCL's in-place reduce-scatter, so a test cannot lean on them
+    tmp = buf.clone()
+    dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=group)
+    mine.copy_(tmp[rank * n:(rank + 1) * n])
+    return _Done()
 
 
 class BucketReducer:
-    """Arena-slice all-reduce scheduler (works on any flat gradient tensor + [start, end)
+    """Arena-slice collective scheduler (works on any flat gradient tensor + [start, end)
     ranges, so it is testable on CPU with gloo)."""
 
     def __init__(self, flat_grad, process_group=None, use_side_stream=None):
         self.flat = flat_grad
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
         if use_side_stream is None:
             use_side_stream = flat_grad.is_cuda
         self.stream = torch.cuda.Stream() if use_side_stream else None
         self.pending = []
         self.enabled = True
         self.bytes_reduced = 0        # since the last finish(): payload of the launched collectives
+        self.timings = None           # set to [] to record (label, start event, end event, bytes, kind) per collective
 
-    def _on_side_stream(self, launch):
+    def _on_side_stream(self, launch, label=None, nbytes=0, kind='allreduce'):
         if self.stream is None:
             return launch()
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
         with torch.cuda.stream(self.stream):
             self.stream.wait_event(ev)
-            return launch()
+            if self.timings is None:
+                return launch()
+            # (timing mode, bench.py: the collective is waited for on the side stream so that the end event brackets it)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            work = launch()
+            work.wait()
+            e1.record()
+            self.timings.append((label, e0, e1, nbytes, kind))
+            return work
 
-    def reduce_range(self, start, end):
+    def reduce_range(self, start, end, label=None):
         if self.world == 1 or not self.enabled or end <= start:
             return
         buf = self.flat[start:end]
+        nbytes = buf.numel() * buf.element_size()
         self.pending.append(self._on_side_stream(
-            lambda: dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)))
-        self.bytes_reduced += buf.numel() * buf.element_size()
+            lambda: dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True), label, nbytes, 'allreduce'))
+        self.bytes_reduced += nbytes
 
-    def all_gather(self, out, inp):
+    def reduce_scatter_range(self, start, end, label=None):
+        """In-place reduce-scatter of flat[start:end]: rank r's 1/world slice ends up reduced."""
+        if self.world == 1 or not self.enabled or end <= start:
+            return
+        assert (end - start) % self.world == 0
+        buf = self.flat[start:end]
+        nbytes = buf.numel() * buf.element_size()
+        self.pending.append(self._on_side_stream(lambda: _reduce_scatter_inplace(buf, self.rank, self.world, self.pg),
+                                                 label, nbytes, 'reduce_scatter'))
+        self.bytes_reduced += nbytes
+
+    def all_gather(self, out, inp, label=None):
         if self.world == 1:
             out.copy_(inp)
             return
-        self.pending.append(self._on_side_stream(lambda: _all_gather_into(out, inp, self.pg)))
-        self.bytes_reduced += out.numel() * out.element_size()
+        nbytes = out.numel() * out.element_size()
+        self.pending.append(self._on_side_stream(lambda: _all_gather_into(out, inp, self.pg), label, nbytes, 'all_gather'))
+        self.bytes_reduced += nbytes
 
     def finish(self):
         """Block the compute stream (not the host) until every launched collective is done."""
@@ -119,35 +195,85 @@ class BucketReducer:
             torch.cuda.current_stream().wait_stream(self.stream)
 
 
+class _null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+class _Pending:
+    """A host value that a collective on the side stream is still producing (the largest token-row count of a ragged
+    batch): requested in forward, read at the end of backward - by then the side stream has long passed it, so the
+    read does not stall the host behind the compute stream."""
+
+    def __init__(self, dp, n_local):
+        dev = dp._arena.device
+        red = dp.reducer
+        if dev.type == 'cuda':
+            host = torch.tensor([n_local], dtype=torch.int64).pin_memory()
+            self._out = torch.empty(1, dtype=torch.int64).pin_memory()
+            with (torch.cuda.stream(red.stream) if red.stream is not None else _null()):
+                t = host.to(dev, non_blocking=True)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=dp.pg)
+                self._out.copy_(t, non_blocking=True)
+                self._ev = torch.cuda.Event()
+                self._ev.record()
+                self._keep = (t, host)
+        else:
+            t = torch.tensor([n_local], dtype=torch.int64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=dp.pg)
+            self._out, self._ev = t, None
+
+    def value(self):
+        if self._ev is not None:
+            self._ev.synchronize()
+            self._ev = self._keep = None
+        return int(self._out[0])
+
+
 class DataParallel(torch.nn.Module):
     """Wrapper with the surface the reference expects from (Apex) DDP: ``.module``,
     ``__call__(mode, **kw)`` forwarding, parameter broadcast from rank 0 at wrap time
     (xtrainer.py:68-83; used at :519-520, :814 and xevaluator.py:1532)."""
 
-    def __init__(self, module, process_group=None, broadcast=True):
+    def __init__(self, module, process_group=None, broadcast=True, mode=None):
         super().__init__()
         self.module = module
         arena = module.arena()
         self.reducer = BucketReducer(arena.grad, process_group)
         self.pg = process_group
         self.world = self.reducer.world
+        self.rank = self.reducer.rank
         self._arena = arena
         off = arena.offsets
+        # buckets in FORWARD order (the order the parameter all-gathers of zero1 run in)
         self._ranges = {'vocab': (0, off['position_embeddings.weight'][0]),
-                        'embed': (off['position_embeddings.weight'][0], arena.embed_range[1]),
-                        'heads': arena.head_range}
+                        'embed': (off['position_embeddings.weight'][0], arena.embed_range[1])}
         for i, r in enumerate(arena.layer_ranges):
             self._ranges[('layer', i)] = r
+        self._ranges['heads'] = arena.head_range
+        mode = mode or os.environ.get('M3P_DP_MODE') or 'zero1'
+        assert mode in ('zero1', 'allreduce'), mode
+        if mode == 'zero1' and any((e - s) % (64 * self.world) for s, e in self._ranges.values()):
+            mode = 'allreduce'      # (a world size the 512-element bucket alignment does not divide into 64-aligned shards)
+        self.mode = mode if self.world > 1 else 'single'
         self.vocab_dense = True      # plan of the current step: does an MLM head feed the vocabulary matrix?
+        self.uniform_tokens = False  # the trainer's promise that every rank's passes have the same token-row counts
         self._live = 0               # encoder passes that still owe a backward
         self._live_streams = 0       # image-stream passes (ImageStreamFn) that still owe a backward: their gradients land
                                      # in the 'embed' range AFTER the encoder pass they feed has finished its own backward
         self._launched = set()
-        self._tokens = []            # [(ids [n] int64, rows [n, d] bf16, n_max over ranks)]
+        self._tokens = []            # [(ids [n] int64, rows [n, d] bf16, n_max over ranks: int or _Pending)]
         self._tokens_out = None
         self._finished = False
+        self._param_events = {}      # zero1: bucket key -> event on the side stream (master gathered + bf16 cast done)
         self.exposed_events = None   # set to [] to record (start, end) events around finish()'s waits
         object.__setattr__(module, 'ddp_hook', self)    # plain attribute: as a registered submodule it would close a cycle
+        if self.world > 1 and arena.device.type == 'cuda' and reserve_cus():
+            from . import lib as L
+            L.load().m3p_set_persistent_grid(L.num_cus() - reserve_cus())
         if broadcast and self.world > 1:
             dist.broadcast(arena.master, src=0, group=process_group)
             for p in module.parameters():
@@ -168,7 +294,105 @@ class DataParallel(torch.nn.Module):
         if self.world == 1 or not self.reducer.enabled or key in self._launched:
             return
         self._launched.add(key)
-        self.reducer.reduce_range(*self._ranges[key])
+        if self.mode == 'zero1':
+            self.reducer.reduce_scatter_range(*self._ranges[key], label=key)
+        else:
+            self.reducer.reduce_range(*self._ranges[key], label=key)
+
+    # ------------------------------------------------------------------ shards (zero1)
+    def shard_of(self, key):
+        """This rank's [start, end) slice of bucket ``key``."""
+        s, e = self._ranges[key]
+        if self.mode != 'zero1':
+            return s, e
+        n = (e - s) // self.world
+        return s + self.rank * n, s + (self.rank + 1) * n
+
+    def owned(self, start, end):
+        """The parts of [start, end) whose reduced gradient (and optimizer state) live on this rank: everything in
+        all-reduce mode, the intersections with this rank's bucket shards in zero1 mode."""
+        if self.mode != 'zero1':
+            return [(start, end)]
+        out = []
+        for key in self._ranges:
+            a, b = self.shard_of(key)
+            a, b = max(a, start), min(b, end)
+            if a < b:
+                out.append((a, b))
+        return out
+
+    def all_reduce_scalar(self, t):
+        """Sum a device scalar over the ranks on the current stream (the clip norm of sharded gradients)."""
+        if self.mode == 'zero1':
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
+
+    def after_sharded_step(self, touched_ranges):
+        """zero1, called by the optimizer once Adam has run on this rank's shards: zero the rest of the touched gradient
+        ranges (they hold this rank's un-reduced partials), then gather the updated master shards bucket by bucket in
+        forward order on the side stream, each followed by its bf16 cast; the transposed copies come last.  The next
+        forward waits per bucket (``params_ready``).  -> True if it took care of the bf16 copies."""
+        if self.mode != 'zero1':
+            return False
+        ar = self._arena
+        from . import ops
+        for s, e in touched_ranges:
+            pos = s
+            for a, b in self.owned(s, e) + [(e, e)]:
+                if a > pos:
+                    ar.grad[pos:a].zero_()
+                pos = max(pos, b)
+        touched_keys = [k for k, (s, e) in self._ranges.items() if any(a < e and s < b for a, b in touched_ranges)]
+        red = self.reducer
+        cuda = ar.device.type == 'cuda'
+        for key in touched_keys:
+            s, e = self._ranges[key]
+            a, b = self.shard_of(key)
+            red.all_gather(ar.master[s:e], ar.master[a:b], label=('params', key))
+            work = red.pending.pop()
+            if cuda:
+                with torch.cuda.stream(red.stream):
+                    work.wait()                                    # the side stream waits for the collective, the host does not
+                    ops.cast_f32_bf16_into(ar.master[s:e], ar.w16[s:e])
+                    ev = torch.cuda.Event()
+                    ev.record()
+                self._param_events[key] = ev
+            else:
+                work.wait()
+                ar.w16[s:e].copy_(ar.master[s:e])
+        if cuda:
+            with torch.cuda.stream(red.stream):
+                ar._transposes_stale = True
+                ar.refresh_transposes()
+                ev = torch.cuda.Event()
+                ev.record()
+            self._param_events['transposes'] = ev
+        red.bytes_reduced = 0
+        return True
+
+    def params_ready(self, key=None):
+        """Make the current stream wait until bucket ``key``'s parameters (None: all of them, and the transposed
+        copies) are gathered and cast.  A stream-level wait; free when nothing is pending."""
+        if not self._param_events:
+            return
+        if key is None:
+            for ev in self._param_events.values():
+                torch.cuda.current_stream().wait_event(ev)
+            self._param_events = {}
+        else:
+            ev = self._param_events.pop(key, None)
+            if ev is not None:
+                torch.cuda.current_stream().wait_event(ev)
+
+    def full_reduced_grad(self):
+        """The whole reduced gradient arena on every rank (tests / debugging): in zero1 mode the shards are gathered
+        into a copy; in all-reduce mode it is the arena itself.  Call after ``finish()``."""
+        g = self._arena.grad.clone()
+        if self.mode == 'zero1':
+            for key, (s, e) in self._ranges.items():
+                if key in self._launched:
+                    a, b = self.shard_of(key)
+                    _all_gather_into(g[s:e], g[a:b].clone(), self.pg).wait()
+        return g
 
     # ------------------------------------------------------------------ hooks (functional.py)
     @property
@@ -176,21 +400,13 @@ class DataParallel(torch.nn.Module):
         return self.world > 1
 
     def encoder_forward(self, n_tokens):
-        """An encoder pass that will be differentiated.  Returns the largest token-row count of
-        this pass over the ranks (ragged batches: the rows are padded to it for the all-gather);
-        exchanged now, while the communication stream is idle."""
+        """An encoder pass that will be differentiated.  Returns the largest token-row count of this pass over the
+        ranks (ragged batches: the rows are padded to it for the all-gather) - as a value still in flight on the side
+        stream (``_Pending``), read in ``embed_done``."""
         self._live += 1
-        if self.world == 1:
+        if self.world == 1 or self.uniform_tokens or n_tokens == 0:
             return n_tokens
-        t = torch.tensor([n_tokens], dtype=torch.int64, device=self._arena.device)
-        if self.reducer.stream is not None:
-            with torch.cuda.stream(self.reducer.stream):
-                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.pg)
-                n_max = int(t.item())          # waits for the communication stream only
-        else:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.pg)
-            n_max = int(t.item())
-        return n_max
+        return _Pending(self, n_tokens)
 
     def encoder_backward_begin(self):
         """-> True if this is the last pending encoder backward of the step."""
@@ -214,7 +430,7 @@ class DataParallel(torch.nn.Module):
 
     def embed_done(self, last=True, ids=None, rows=None, n_max=None):
         if ids is not None and self.world > 1:
-            self._tokens.append((ids, rows, int(n_max)))
+            self._tokens.append((ids, rows, n_max))
         if last:
             if self._live_streams == 0:      # else the image stream's backward still owes gradients inside this range
                 self._launch('embed')
@@ -238,11 +454,12 @@ class DataParallel(torch.nn.Module):
         dev = self._arena.device
         pad = int(self.module.pad_index)
         d = self._tokens[0][1].shape[1]
-        n_tot = sum(nm for _, _, nm in self._tokens)
+        sizes = [nm.value() if isinstance(nm, _Pending) else int(nm) for _, _, nm in self._tokens]
+        n_tot = sum(sizes)
         ids_s = torch.full((n_tot,), pad, dtype=torch.int64, device=dev)
         rows_s = torch.empty((n_tot, d), dtype=torch.bfloat16, device=dev)
         o = 0
-        for ids, rows, nm in self._tokens:
+        for (ids, rows, _), nm in zip(self._tokens, sizes):
             n = ids.numel()
             ids_s[o:o + n] = ids.reshape(-1)
             rows_s[o:o + n] = rows
@@ -251,8 +468,8 @@ class DataParallel(torch.nn.Module):
             o += nm
         ids_all = torch.empty((self.world * n_tot,), dtype=torch.int64, device=dev)
         rows_all = torch.empty((self.world * n_tot, d), dtype=torch.bfloat16, device=dev)
-        self.reducer.all_gather(ids_all, ids_s)
-        self.reducer.all_gather(rows_all, rows_s)
+        self.reducer.all_gather(ids_all, ids_s, label='token ids')
+        self.reducer.all_gather(rows_all, rows_s, label='token rows')
         self._tokens_out = (ids_all, rows_all, ids_s, rows_s)
         self._tokens = []
 

@@ -22,6 +22,7 @@ from . import rng
 
 BF16 = torch.bfloat16
 ALIGN = 64
+BUCKET_ALIGN = 64 * 8
 
 
 def _round_up(n, a):
@@ -44,9 +45,18 @@ class Arena:
         self.names = list(named.keys())
         self.offsets = OrderedDict()
         off = 0
+        # gradient buckets of the data-parallel reducer (distributed.py) start at these parameters; their boundaries sit
+        # on multiples of BUCKET_ALIGN elements so that a bucket splits into equal, 64-element-aligned shards for 2 / 4 /
+        # 8 ranks (reduce-scatter -> sharded Adam -> all-gather); the padding holds zeros in every arena
+        L_ = model.n_layers
+        bucket_starts = {'position_embeddings.weight', 'pooled_layer.dense.weight'} | \
+            {'attentions.%d.q_lin.weight' % i for i in range(L_)}
         for n, p in named.items():
+            if n in bucket_starts:
+                off = _round_up(off, BUCKET_ALIGN)
             self.offsets[n] = (off, p.numel(), tuple(p.shape))
             off += _round_up(p.numel(), ALIGN)
+        off = _round_up(off, BUCKET_ALIGN)
         self.total = off
         self.master = torch.zeros(off, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
@@ -78,12 +88,12 @@ class Arena:
                 self.wt[('xkv', i)] = torch.zeros((d, 2 * d), dtype=BF16, device=dev)
                 self.wt[('xout', i)] = torch.zeros((d, d), dtype=BF16, device=dev)
         # contiguous arena ranges used as gradient buckets (reverse-backward order) and by the optimizer
+        self.head_range = (self.offsets['pooled_layer.dense.weight'][0], self.total)
         self.layer_ranges = []
         for i in range(L_):
             a = self.offsets['attentions.%d.q_lin.weight' % i][0]
-            last = self.offsets['layer_norm2.%d.bias' % i]
-            self.layer_ranges.append((a, last[0] + _round_up(last[1], ALIGN)))
-        self.head_range = (self.offsets['pooled_layer.dense.weight'][0], self.total)
+            b = self.offsets['attentions.%d.q_lin.weight' % (i + 1)][0] if i + 1 < L_ else self.head_range[0]
+            self.layer_ranges.append((a, b))
         self.embed_range = (0, self.layer_ranges[0][0] if L_ else self.head_range[0])
         self._cast_version = -1
         self._transposes_stale = True
@@ -176,12 +186,21 @@ class Arena:
         self._transposes_stale = True
         self.epoch += 1
 
-    def refresh(self):
+    def refresh(self, wait_params=True):
+        """Bring the bf16 working copy and the transposed copies up to date with the fp32 master.  Under the sharded
+        data-parallel exchange the copies are made on the side stream behind the parameter all-gathers; the current
+        stream then only waits for them (all of them here; EncoderFn.forward waits bucket by bucket instead)."""
+        hook = getattr(self.model, 'ddp_hook', None)
+        if hook is not None and (wait_params or self._cast_version != self.master._version or self._transposes_stale):
+            hook.params_ready(None)
         if self._cast_version != self.master._version:
             L.check(L.load().m3p_cast_f32_bf16(self.master.data_ptr(), self.w16.data_ptr(), self.total, L.stream()),
                     'm3p_cast_f32_bf16')
             self._cast_version = self.master._version
             self._transposes_stale = True
+        self.refresh_transposes()
+
+    def refresh_transposes(self):
         if self._transposes_stale:
             if self._tdesc is None:
                 rows = []
@@ -210,9 +229,12 @@ class Arena:
         if self.model.ddp_hook is not None:
             self.model.ddp_hook.step_done()
 
-    def after_fused_step(self):
-        """The fused Adam kernel updated master + w16 and zeroed every touched gradient range."""
+    def after_fused_step(self, copies_scheduled=False):
+        """The fused Adam kernel updated master + w16 and zeroed every touched gradient range.  copies_scheduled: the
+        data-parallel hook already queued the bf16 cast and the transposes behind its parameter all-gathers."""
         self.mark_updated_by_fused_optimizer()
+        if copies_scheduled:
+            self._transposes_stale = False
         self.touched.clear()
         self.grads_known_zero = True
         if self.model.ddp_hook is not None:
@@ -408,7 +430,12 @@ class EncoderFn(torch.autograd.Function):
     def forward(ctx, anchor, model, x, lengths, x_img, lengths_img, image_loc, p_drop, p_attn, seed_step, p_refine=None,
                 track=False, text_embed=None, langs=None, h0=None, positions=None):
         ar = model.arena()
-        ar.refresh()
+        # sharded data parallelism: the parameters of this step arrive bucket by bucket (in forward order) on the side
+        # stream; wait for what the embedding stage reads now and for each layer in front of its first GEMM
+        ready = model.ddp_hook.params_ready if model.ddp_hook is not None else (lambda key: None)
+        ar.refresh(wait_params=False)
+        ready('vocab')
+        ready('embed')
         dev = ar.device
         d, H, nL = model.dim, model.n_heads, model.n_layers
         dh = d // H
@@ -498,6 +525,7 @@ class EncoderFn(torch.autograd.Function):
             assert M % 256 == 0, 'the fp8 GEMM takes whole 256-row tiles (B * S %% 256 == 0): M = %d' % M
             if model.training:
                 st8.roll()
+            ready(None)                 # (the batched weight quantisation reads every layer's copy)
             st8.quant_weights(ar)
 
         def lin(xin, i, xsite, wsite, w16, epi, pre8=None, **kw):
@@ -509,6 +537,7 @@ class EncoderFn(torch.autograd.Function):
 
         for i in range(nL):
             a, f = 'attentions.%d.' % i, 'ffns.%d.' % i
+            ready(('layer', i))
             qkv = lin(h, i, 'x', 'wqkv', ar.qkv_w16(i), L.EPI_BIAS, bias=ar.qkv_bias(i), scale_cols=d, scale=qscale)
             ctxt, lse, kmask = ops.attn_fwd(qkv, totlen, B, S, H, dh, seed=seed('attn_p', i), p_drop=p_attn,
                                             want_mask=True)
@@ -576,6 +605,8 @@ class EncoderFn(torch.autograd.Function):
         ref_saved, keylen_img, p_refine = ctx.refine
         ctx.refine = None
         hook = model.ddp_hook if ctx.track else None
+        if model.ddp_hook is not None:
+            model.ddp_hook.params_ready(None)        # (the transposed weight copies the data gradients read)
         sunk = ctx.sink.take()
         if dout is None and sunk is None:
             if hook is not None:
@@ -638,7 +669,7 @@ class EncoderFn(torch.autograd.Function):
         if ctx.h0_mode is not None:       # no embedding assembly in this pass: the rows' gradient goes back to whoever made them
             if hook is not None:
                 hook.embed_done(last, ids=None, rows=None, n_max=ctx.tok_rows_max)
-            return (None,) * (N_ENC_ARGS - 1) + (dh_.to(ctx.h0_mode),)
+            return (None,) * 14 + (dh_.to(ctx.h0_mode), None)        # (h0 is the 15th argument, positions the 16th)
         # under data parallelism the token rows' gradients are exchanged as rows, not scattered here
         want_dximg, has_text_embed = ctx.input_grads
         langs, positions = ctx.langs, ctx.positions

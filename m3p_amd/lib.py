@@ -74,6 +74,7 @@ SIGNATURES = {
     'm3p_gelu_fwd_q8': (_i, [_p, _p, _p, C.c_longlong, _p, _p, _p]),
     'm3p_transpose_batch_bf16': (_i, [_p, _i, _i, _p]),
     'm3p_transpose_bf16': (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    'm3p_set_persistent_grid': (_i, [_i]),
     'm3p_seq_masks': (_i, [_p, _p, _i, _i, _p, _p, _p]),
     'm3p_mask_to_rows': (_i, [_p, _i, _i, C.c_longlong, C.c_longlong, C.c_longlong, _i, _p, _i, _p]),
     'm3p_cast_rows_f32_bf16': (_i, [_p, C.c_longlong, C.c_longlong, _i, _i, _i, _p, _p]),
@@ -121,6 +122,12 @@ def ptr(t):
 
 def stream():
     return torch.cuda.current_stream().cuda_stream
+
+
+def num_cus():
+    """Compute units of the current device, rounded down to whole XCD octets like the kernels' own count."""
+    n = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+    return max(n - n % 8, 8)
 
 
 def thresh24(p):

@@ -291,6 +291,13 @@ def cast_bf16(x):
     return out
 
 
+def cast_f32_bf16_into(src, dst):
+    """dst (bf16) <- src (fp32), same element count, on the current stream."""
+    assert src.dtype == torch.float32 and dst.dtype == BF16 and src.is_contiguous() and dst.is_contiguous()
+    assert src.numel() == dst.numel() and src.numel() % 4 == 0
+    L.check(L.load().m3p_cast_f32_bf16(src.data_ptr(), dst.data_ptr(), src.numel(), L.stream()), 'm3p_cast_f32_bf16')
+
+
 def cast_rows_bf16(x):
     """fp32 (n0, n1, cols) with ANY leading strides (unit stride along cols) -> contiguous bf16 [n0 * n1, cols]: the cast
     reads through a transposed view (the collate's (n, R, 2048) features seen as (R, n, 2048)) instead of copying it first."""

@@ -77,13 +77,33 @@ class Adam(optim.Optimizer):
             o, cnt, _ = arena.offsets[name]
             end = o + (cnt + 63) // 64 * 64
             step = self.state[p]['step']
-            if cur is not None and cur['end'] == o and cur['step'] == step and cur['group'] is group:
+            # (the arena pads to 512 elements in front of a gradient bucket: a gap between two consecutive touched
+            #  parameters is that padding - zeros in every arena, a no-op for Adam - and does not split the range)
+            if cur is not None and cur['next'] == name and cur['step'] == step and cur['group'] is group:
                 cur['end'] = end
                 cur['params'].append(p)
             else:
                 cur = dict(start=o, end=end, step=step, group=group, params=[p])
                 ranges.append(cur)
+            cur['next'] = self._next_name(arena, name)
         return ranges
+
+    @staticmethod
+    def _next_name(arena, name):
+        order = getattr(arena, '_name_after', None)
+        if order is None:
+            order = arena._name_after = dict(zip(arena.names, arena.names[1:] + [None]))
+        return order[name]
+
+    @staticmethod
+    def _hook(arena):
+        return getattr(arena.model, 'ddp_hook', None)
+
+    def _owned(self, arena, start, end):
+        """[start, end) restricted to what this rank steps: all of it, or - under the sharded data-parallel exchange
+        (distributed.py, zero1) - its intersections with this rank's bucket shards."""
+        hook = self._hook(arena)
+        return hook.owned(start, end) if hook is not None else [(start, end)]
 
     def clip_grad_norm(self, max_norm):
         """clip_grad_norm_(parameters, max_norm) of xtrainer.py:225, deferred: the global
@@ -95,7 +115,10 @@ class Adam(optim.Optimizer):
                 arena.model.ddp_hook.finish()
             ent['gnorm'].zero_()
             for r in self._active_ranges(arena):
-                ops.sumsq(arena.grad[r['start']:r['end']], ent['gnorm'])
+                for a, b in self._owned(arena, r['start'], r['end']):
+                    ops.sumsq(arena.grad[a:b], ent['gnorm'])
+            if arena.model.ddp_hook is not None:
+                arena.model.ddp_hook.all_reduce_scalar(ent['gnorm'])     # sharded gradients: the norm is the sum over ranks
         self._pending_clip = float(max_norm)
 
     def grad_norm(self):
@@ -120,22 +143,27 @@ class Adam(optim.Optimizer):
             arena = ent['arena']
             if arena.model.ddp_hook is not None:
                 arena.model.ddp_hook.finish()
-            for r in self._active_ranges(arena):
+            active = self._active_ranges(arena)
+            for r in active:
                 group = r['group']
                 beta1, beta2 = group['betas']
                 step = r['step'] + 1
                 bc1 = 1 - beta1 ** step
                 bc2 = 1 - beta2 ** step
                 step_size = group['lr'] * math.sqrt(bc2) / bc1
-                s, e = r['start'], r['end']
-                ops.adam_step(arena.master[s:e], arena.grad[s:e], ent['m'][s:e], ent['v'][s:e], arena.w16[s:e],
-                              group['lr'], beta1, beta2, group['eps'], group['weight_decay'], step_size,
-                              gnorm_sq=ent['gnorm'] if max_norm > 0 else None, max_norm=max_norm,
-                              grad_scale=self.grad_scale, zero_grad=True)
+                for s, e in self._owned(arena, r['start'], r['end']):
+                    ops.adam_step(arena.master[s:e], arena.grad[s:e], ent['m'][s:e], ent['v'][s:e], arena.w16[s:e],
+                                  group['lr'], beta1, beta2, group['eps'], group['weight_decay'], step_size,
+                                  gnorm_sq=ent['gnorm'] if max_norm > 0 else None, max_norm=max_norm,
+                                  grad_scale=self.grad_scale, zero_grad=True)
                 for p in r['params']:
                     self.state[p]['step'] = step
+            # sharded exchange: the other ranks' shards of the updated master come back through an all-gather that the
+            # next forward waits for bucket by bucket (distributed.DataParallel.after_sharded_step)
+            hook = arena.model.ddp_hook
+            gathered = hook is not None and hook.after_sharded_step([(r['start'], r['end']) for r in active])
             # untouched ranges may still hold stale values only if someone wrote them by hand
-            arena.after_fused_step()
+            arena.after_fused_step(copies_scheduled=gathered)
         # parameters outside any arena (never the case on the hot path) — reference loop
         for group in self.param_groups:
             for p in group['params']:

@@ -46,6 +46,8 @@ CONFIGS = {
     'cfg1': dict(emb_dim=128, n_heads=4, n_layers=2, n_words=1000, T=64, R=10, B=8, n_pred=9),
     # BASELINE.json configs[1]: M3P-base on one MI355X
     'cfg2': dict(emb_dim=768, n_heads=12, n_layers=12, n_words=250002, T=128, R=36, B=256, n_pred=19),
+    # configs[2]: the same model data-parallel over 8 MI355X, global batch 8192 = 1024 sequences per GPU (B is the per-GPU share)
+    'cfg3': dict(emb_dim=768, n_heads=12, n_layers=12, n_words=250002, T=128, R=36, B=1024, n_pred=19),
     # configs[3]: M3P-large
     'cfg4': dict(emb_dim=1024, n_heads=16, n_layers=24, n_words=250002, T=256, R=100, B=64, n_pred=38),
     # configs[4]: ITM fine-tune shape

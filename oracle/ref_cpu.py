@@ -191,7 +191,8 @@ def jointfwd(sd, n_layers, n_heads, x, lengths, x_img, lengths_img, image_loc,
     return h.transpose(0, 1)
 
 
-def crossfwd_text(sd, n_layers, n_heads, x, lengths, dropout=0.0, attention_dropout=0.0, keeps=None, langs=None):
+def crossfwd_text(sd, n_layers, n_heads, x, lengths, dropout=0.0, attention_dropout=0.0, keeps=None, langs=None,
+                  positions=None):
     """TransformerModel.crossfwd(stream_='text', causal=False, positions=None, langs=None):
     transformer.py:1050-1102 — the text-only stream behind Trainer.mlm_step (xtrainer.py:757).
     Differs from jointfwd in the order at the input: Emb[x] + Pos -> LN_emb -> dropout -> *mask
@@ -199,7 +200,11 @@ def crossfwd_text(sd, n_layers, n_heads, x, lengths, dropout=0.0, attention_drop
     keeps = keeps or {}
     T, B = x.shape
     mask, attn_mask = get_masks(T, lengths)
-    h = F.embedding(x.t(), sd['embeddings.weight']) + sd['position_embeddings.weight'][:T][None]
+    if positions is None:       # :1011-1014
+        pos = sd['position_embeddings.weight'][:T][None]
+    else:                       # explicit (T, B) positions: TLM batches restart them at the second sentence (:1057-1058)
+        pos = F.embedding(positions.t(), sd['position_embeddings.weight'])
+    h = F.embedding(x.t(), sd['embeddings.weight']) + pos
     if langs is not None:       # :1059-1060 (multilingual models: n_langs > 1)
         h = h + F.embedding(langs.t(), sd['cross_lang_embeddings.weight'])
     h = layer_norm(h, sd['layer_norm_emb.weight'], sd['layer_norm_emb.bias'])

@@ -100,26 +100,29 @@ def test_reducer_single_process_is_noop():
 
 # ---- the DataParallel step protocol on a fake arena (gloo, CPU): what functional.py / optim.py call, in order ----
 class _FakeArena:
-    """Just the bookkeeping m3p_amd.distributed.DataParallel reads from functional.Arena."""
+    """Just the bookkeeping m3p_amd.distributed.DataParallel reads from functional.Arena: buckets on 512-element
+    boundaries (vocabulary matrix + bias | positions | layers | heads)."""
 
     def __init__(self, V=50, d=8, n_layers=2):
         from collections import OrderedDict
-        sizes = OrderedDict([('embeddings.weight', V * d), ('pred_layer.proj.bias', 64), ('position_embeddings.weight', 128)])
+        self.offsets = OrderedDict([('embeddings.weight', (0, V * d, (V, d))), ('pred_layer.proj.bias', (448, 64, (64,))),
+                                    ('position_embeddings.weight', (512, 128, (128,)))])
+        off = 1024
+        self.layer_ranges = []
         for i in range(n_layers):
-            sizes['layer%d' % i] = 192
-        sizes['pooled_layer.dense.weight'] = 64
-        self.offsets, off = OrderedDict(), 0
-        for k, n in sizes.items():
-            self.offsets[k] = (off, n, (n,))
-            off += n
-        self.total = off
+            self.offsets['layer%d' % i] = (off, 192, (192,))
+            self.layer_ranges.append((off, off + 512))
+            off += 512
+        self.offsets['pooled_layer.dense.weight'] = (off, 64, (64,))
+        self.head_range = (off, off + 512)
+        self.total = off + 512
+        self.embed_range = (0, 1024)
         self.device = torch.device('cpu')
-        self.master = torch.zeros(off)
-        self.grad = torch.zeros(off)
-        self.layer_ranges = [(self.offsets['layer%d' % i][0], self.offsets['layer%d' % i][0] + 192) for i in range(n_layers)]
-        self.embed_range = (0, self.layer_ranges[0][0])
-        self.head_range = (self.offsets['pooled_layer.dense.weight'][0], off)
+        self.master = torch.zeros(self.total)
+        self.grad = torch.zeros(self.total)
+        self.w16 = torch.zeros(self.total, dtype=torch.bfloat16)
         self.V, self.d = V, d
+        self._transposes_stale = False
 
     def g(self, name):
         o, n, _ = self.offsets[name]
@@ -129,6 +132,9 @@ class _FakeArena:
         pass
 
     def mark_master_changed(self):
+        pass
+
+    def refresh_transposes(self):
         pass
 
 
@@ -149,7 +155,7 @@ def _cpu_scatter(rows, ids, dst, pad_index):
     dst.index_add_(0, ids[keep], rows[keep].float())
 
 
-def _protocol_worker(rank, world, port, q):
+def _protocol_worker(rank, world, port, q, mode):
     try:
         os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
         torch.set_num_threads(1)
@@ -160,7 +166,8 @@ def _protocol_worker(rank, world, port, q):
         model = _FakeModel()
         ar = model.arena()
         ar.master.fill_(float(rank + 1))
-        dp = DataParallel(model)
+        dp = DataParallel(model, mode=mode)
+        assert dp.mode == mode
         assert float(ar.master[0]) == 1.0                       # broadcast from rank 0
         results = {}
 
@@ -181,11 +188,25 @@ def _protocol_worker(rank, world, port, q):
                 _cpu_scatter(rows, ids, out, model.pad_index)
             return out
 
+        def reduced(launched_only_check=None):
+            """what the optimizer would see: the reduced gradient, every rank's shard in its place"""
+            own = torch.zeros(ar.total, dtype=torch.bool)
+            for a, b in dp.owned(0, ar.total):
+                own[a:b] = True
+            full = dp.full_reduced_grad()
+            return full, own
+
+        # the shards of a bucket tile it exactly, across ranks
+        cover = torch.zeros(ar.total)
+        for a, b in dp.owned(0, ar.total):
+            cover[a:b] += 1
+        dist.all_reduce(cover)
+        assert bool((cover == (1 if mode == 'zero1' else world)).all())
+
         # --- step A: one encoder pass + MLM head, finish() called twice (clip, then step); ragged token counts
         dp.plan_step(True)
         n_loc = 5 + 2 * rank
-        n_max = dp.encoder_forward(n_loc)
-        assert n_max == 5 + 2 * (world - 1)
+        n_max = dp.encoder_forward(n_loc)                       # still in flight: read in embed_done
         fill(1.0 + rank)
         dp.mlm_head_done()
         last = dp.encoder_backward_begin()
@@ -198,8 +219,13 @@ def _protocol_worker(rank, world, port, q):
         dp.finish()                                             # idempotent: nothing is reduced twice
         tot = sum(1.0 + r for r in range(world))
         want = torch.full_like(ar.grad, tot)
-        want[:ar.V * ar.d] += expected_tokens([(5 + 2 * r, 100 + r) for r in range(world)]).view(-1)
-        results['A'] = float((ar.grad - want).abs().max())
+        tokw = torch.zeros_like(ar.grad)
+        tokw[:ar.V * ar.d] = expected_tokens([(5 + 2 * r, 100 + r) for r in range(world)]).view(-1)
+        full, own = reduced()
+        # (token rows are scatter-added on every rank after the reduction: a gathered shard carries them once)
+        results['A'] = float((full - want - tokw).abs().max())
+        if mode == 'zero1':      # outside its shards a rank still holds its own partial sums (+ the rows): never the reduced value
+            assert float((ar.grad[~own] - (1.0 + rank) - tokw[~own]).abs().max()) < 1e-5
         dp.step_done()
 
         # --- step B: two encoder passes (CLCM): the first backward must not launch layer buckets
@@ -223,7 +249,7 @@ def _protocol_worker(rank, world, port, q):
         want = torch.zeros_like(ar.grad)
         want[ar.layer_ranges[1][0]:ar.layer_ranges[1][1]] = tot + 10.0 * world
         want[:ar.V * ar.d] += expected_tokens([(6, 300 + r) for r in range(world)] + [(4, 200 + r) for r in range(world)]).view(-1)
-        results['B'] = float((ar.grad - want).abs().max())
+        results['B'] = float((reduced()[0] - want).abs().max())
         dp.step_done()
 
         # --- step C: gradient accumulation: a no_sync micro-step keeps its token rows for the boundary; no MLM head
@@ -249,14 +275,49 @@ def _protocol_worker(rank, world, port, q):
         want = torch.zeros_like(ar.grad)
         want[ar.layer_ranges[0][0]:ar.layer_ranges[0][1]] = 2.0 * world
         want[:ar.V * ar.d] += expected_tokens([(3, 400 + r) for r in range(world)] + [(3, 500 + r) for r in range(world)]).view(-1)
-        results['C'] = float((ar.grad - want).abs().max())
+        results['C'] = float((reduced()[0] - want).abs().max())
         dp.step_done()
 
         # --- step D: no encoder backward at all (finish() owes every bucket)
         dp.plan_step(True)
         fill(2.0)
         dp.finish()
-        results['D'] = float((ar.grad - 2.0 * world).abs().max())
+        results['D'] = float((reduced()[0] - 2.0 * world).abs().max())
+        dp.step_done()
+
+        # --- step E: an image-stream pass feeds the encoder pass: 'embed' waits for the stream's backward
+        dp.plan_step(False)
+        fill(0.0)
+        dp.stream_forward()
+        nm = dp.encoder_forward(0)
+        assert dp.encoder_backward_begin()
+        dp.layer_done(1, True); dp.layer_done(0, True)
+        dp.embed_done(True, ids=None, rows=None, n_max=nm)
+        assert 'embed' not in dp._launched
+        ar.grad[512:640] += 3.0 + rank                          # what the image stream's backward writes (inside 'embed')
+        dp.stream_backward_end()
+        assert 'embed' in dp._launched
+        dp.finish()
+        want = torch.zeros_like(ar.grad)
+        want[512:640] = sum(3.0 + r for r in range(world))
+        results['E'] = float((reduced()[0] - want).abs().max())
+        dp.step_done()
+
+        # --- step F: the sharded optimizer step: every rank updates its shards only; afterwards all hold the same master
+        dp.plan_step(True)
+        fill(1.0)
+        dp.finish()
+        ar.master.fill_(-1.0)
+        for a, b in dp.owned(0, ar.total):
+            ar.master[a:b] = torch.arange(a, b, dtype=torch.float32)      # "Adam" on the shard
+        took = dp.after_sharded_step([(0, ar.total)])
+        assert took == (mode == 'zero1')
+        if mode == 'zero1':
+            results['F'] = float((ar.master - torch.arange(ar.total, dtype=torch.float32)).abs().max())
+            results['F16'] = float((ar.w16.float() - ar.master.to(torch.bfloat16).float()).abs().max())
+            results['Fz'] = float(ar.grad[~reduced()[1]].abs().max())     # un-reduced partials outside the shards: zeroed
+        dp.step_done()
+
         if rank == 0:
             q.put(('ok', results))
         dist.barrier()
@@ -268,12 +329,12 @@ def _protocol_worker(rank, world, port, q):
         raise
 
 
-def test_data_parallel_step_protocol_two_ranks():
-    world = 2
+@pytest.mark.parametrize('world,mode', [(2, 'zero1'), (4, 'zero1'), (2, 'allreduce')])
+def test_data_parallel_step_protocol(world, mode):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_protocol_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_protocol_worker, args=(r, world, port, q, mode)) for r in range(world)]
     for p in procs:
         p.start()
     status, res = q.get(timeout=240)

@@ -64,8 +64,9 @@ def _build(scenario, multi_gpu):
 
 def _slice(full, extra, sl, ng):
     """Columns ``sl`` of the synthetic batch as the tuples the collates emit."""
-    x, lab = full['x'][:, sl].contiguous(), full['x_labels'][:, sl].contiguous()
     lens = full['lengths'][sl].contiguous()
+    tmax = int(lens.max())               # a rank's batch is as long as ITS longest sentence: token-row counts differ across ranks
+    x, lab = full['x'][:tmax, sl].contiguous(), full['x_labels'][:tmax, sl].contiguous()
     img = full['x_img'][:, sl].transpose(0, 1).contiguous()
     loc = full['image_loc'][:, sl].transpose(0, 1).contiguous()
     n = x.shape[1]
@@ -77,7 +78,7 @@ def _slice(full, extra, sl, ng):
     x2, len2 = extra['x2'][:, sl].contiguous(), extra['len2'][sl].contiguous()
     i2t = ((x, lens, lab), (x2, len2), (extra['clcm'][sl].contiguous(), img, mask, loc, obj, pos, ori, list(range(n))))
     fin = ((x, lens, torch.zeros_like(x)), (img, mask, loc, obj, pos, list(range(n))))
-    text = (x, lens, full['pred_mask'][:, sl].contiguous(), lab[full['pred_mask'][:, sl]])
+    text = (x, lens, full['pred_mask'][:tmax, sl].contiguous(), lab[full['pred_mask'][:tmax, sl]])
     return dict(t2i=t2i, i2t=i2t, fin=fin, text=text, mt=(x, lens, x2, len2), ic=(x2, len2, img, mask, loc))
 
 
@@ -121,7 +122,9 @@ def _capture_grads(tr, m):
         if hook is not None:
             hook.finish()
         torch.cuda.synchronize()
-        snaps.append(((m.arena().grad * opt.grad_scale).cpu(), opt.grad_norm()))
+        # (under the sharded exchange a rank holds the reduced gradient of its shards only: gather them for the comparison)
+        g = hook.full_reduced_grad() if hook is not None else m.arena().grad
+        snaps.append(((g * opt.grad_scale).cpu(), opt.grad_norm()))
         return inner(closure)
     opt.step = step
     return snaps
@@ -145,13 +148,14 @@ def _drive(scenario, world, rank):
     return tr, m, snaps
 
 
-def _worker(rank, world, port, q, scenario, backend):
+def _worker(rank, world, port, q, scenario, backend, mode='zero1'):
     try:
         os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                          HSA_ENABLE_IPC_MODE_LEGACY='0')
+                          HSA_ENABLE_IPC_MODE_LEGACY='0', M3P_DP_MODE=mode)
         torch.cuda.set_device(rank if backend == 'nccl' else 0)
         dist.init_process_group(backend, rank=rank, world_size=world)
         tr, m, snaps = _drive(scenario, world, rank)
+        assert tr.model.mode == mode, (tr.model.mode, mode)
         pm = m.arena().master.clone()
         gathered = [torch.zeros_like(pm) for _ in range(world)]
         dist.all_gather(gathered, pm)
@@ -169,12 +173,11 @@ def _worker(rank, world, port, q, scenario, backend):
         raise
 
 
-def _check(scenario, backend):
-    world = 2
+def _check(scenario, backend, world=2, mode='zero1'):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, scenario, backend)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, scenario, backend, mode)) for r in range(world)]
     for p in procs:
         p.start()
     status, snaps, pm, same, leftover, _ = q.get(timeout=600)
@@ -203,6 +206,15 @@ def _check(scenario, backend):
 @pytest.mark.parametrize('scenario', ['pretrain', 'clcm', 'accumulate', 'finetune', 'text', 'mt', 'ic'])
 def test_dp_two_ranks_match_single_process(scenario):
     _check(scenario, 'gloo')
+
+
+def test_dp_four_ranks_ragged_token_counts():
+    _check('pretrain', 'gloo', world=4)
+
+
+@pytest.mark.parametrize('scenario', ['pretrain', 'finetune'])
+def test_dp_all_reduce_mode(scenario):
+    _check(scenario, 'gloo', mode='allreduce')
 
 
 @pytest.mark.parametrize('scenario', ['pretrain', 'clcm'])

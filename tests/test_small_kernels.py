@@ -320,3 +320,17 @@ def test_gradient_sink_equals_autograd_views():
         torch.cuda.synchronize()
         grads.append(m.arena().grad.clone())
     assert rel_l2(grads[0], grads[1]) < 2e-3, rel_l2(grads[0], grads[1])
+
+
+def test_batched_transpose_fast_and_ragged_tiles():
+    from m3p_amd import ops
+    mats = []
+    for k, (r, c) in enumerate([(768, 2304), (128, 192), (130, 200), (64, 64), (3072, 768)]):
+        a, ac = randn_bf16((r, c), 10 + k)
+        dst = torch.zeros((c, (r + 7) // 8 * 8), dtype=BF16, device='cuda')
+        mats.append((a, ac, dst))
+    rows = [[a.data_ptr(), dst.data_ptr(), a.shape[0], a.shape[1], a.stride(0), dst.stride(0)] for a, _, dst in mats]
+    mt = max(((a.shape[0] + 63) // 64) * ((a.shape[1] + 63) // 64) for a, _, _ in mats)
+    ops.transpose_batch(torch.tensor(rows, dtype=torch.int64, device='cuda'), len(rows), mt)
+    for a, ac, dst in mats:
+        assert torch.equal(dst[:, :a.shape[0]].cpu(), ac.to(BF16).t()), tuple(a.shape)

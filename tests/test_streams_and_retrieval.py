@@ -330,8 +330,8 @@ def test_trainer_entry_points_track_the_reference_run(golden_dir):
     own = dict(m.named_parameters())
     for k in ('embeddings.weight', 'attentions.0.q_lin.weight', 'layer_norm2.1.weight', 'pred_layer.proj.bias'):
         assert abs(float(own[k].detach().norm()) - float(G['mlm_step_pnorm/' + k])) < 1e-4 * float(G['mlm_step_pnorm/' + k]), k
-    with pytest.raises(NotImplementedError):
-        tr.mlm_step('en', 'en', 1.0)            # TLM batches are outside the MI355X text stream
+    with pytest.raises(KeyError):
+        tr.mlm_step('en', 'en', 1.0)            # the lang1 == lang2 batch reads data['mono'] (xtrainer.py:497-501): none here
     assert tr.mlm_step('en', None, 0) is None   # lambda 0: nothing happens (xtrainer.py:740-741)
 
     m3, P3, _ = _build(cfg, dict(common, sample_n=4, multi_cls_loss_weight=1, bin_cls_loss_weight=1))

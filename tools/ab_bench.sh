@@ -1,8 +1,17 @@
 #!/bin/bash
-# A/B of two library builds on the full training step, interleaved in one GPU session
-for rep in 1 2; do
-for lib in m3p_amd/libm3p_hip.so m3p_amd/libm3p_hip_alt.so; do
-  echo "== $lib"
-  M3P_HIP_LIB=$PWD/$lib python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['kernel'], d['roofline']['avg_ms'])"
+# Same-box A/B of the benchmarked step: the tree under _ab/base (a `git archive` of an earlier commit, built separately)
+# against the working tree, alternating, N rounds.   tools/ab_bench.sh [rounds] [extra bench.py args...]
+#   -> gpurun_out/ab/{base,new}_<i>.json and a summary line per run
+R=${1:-2}; shift
+mkdir -p gpurun_out/ab
+for i in $(seq 1 $R); do
+  (cd _ab/base && python bench.py --no-cpu-baseline --steps 30 --warmup 5 "$@" 2>/dev/null | tail -1) > gpurun_out/ab/base_$i.json
+  python bench.py --no-cpu-baseline --steps 30 --warmup 5 "$@" 2>/dev/null | tail -1 > gpurun_out/ab/new_$i.json
 done
-done
+python - <<'PY'
+import json,glob
+for f in sorted(glob.glob('gpurun_out/ab/*.json')):
+    try:
+        d=json.loads(open(f).read().strip().splitlines()[-1]); print(f, d['ms_per_step'], d['value'], d['roofline']['kernel'], d['roofline']['avg_ms'])
+    except Exception as e: print(f, 'ERR', e)
+PY
