@@ -378,6 +378,13 @@ M3P_API int m3p_transpose_bf16(const void* src, void* dst, int rows, int cols, i
  * out per XCD).  Data parallelism sets num_CUs - r so that RCCL's r channels find free CUs while a GEMM runs - a persistent
  * workgroup fills its CU's LDS and registers, nothing co-resides with it (m3p_amd/distributed.py). */
 M3P_API int m3p_set_persistent_grid(int workgroups);
+/* Dynamic tile queues for the persistent NT GEMM (process-wide; counters = NULL switches back to the static schedule).
+ * counters: n_slots x 8 int32 in device memory, zeroed by the caller once; every eligible m3p_gemm_nt_bf16 launch (eight-wave
+ * kernel, more output tiles than workgroups, K >= 512) takes the next slot - one counter per XCD - and its workgroups pop
+ * their output tiles from per-XCD queues instead of a fixed round-robin share, so a CU that runs slower (a collective's kernel
+ * resident beside the GEMM under data parallelism) takes fewer tiles instead of stretching the launch; the ring is cleared
+ * with a memset node on the launching stream when it wraps (all launches on ONE stream).  Results are the static schedule's. */
+M3P_API int m3p_set_tile_queue(int32_t* counters, int n_slots);
 
 /* ------------------------------------------------------------------------------------
  * Host-glue kernels (csrc/glue.hip): index / mask / loss arithmetic the reference does with chains of elementwise

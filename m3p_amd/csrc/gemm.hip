@@ -786,11 +786,11 @@ void gemm_nt_ring_kernel(const bf16* __restrict__ A, int lda, const bf16* __rest
 // k-step 1.  The epilogue stages through the vacated stage (the request for K-tile +2 waits for it on an output tile's
 // last K-tile).  128 accumulator + 96 fragment registers per lane: the compiler's allocation (no literal AGPR numbers).
 // ---------------------------------------------------------------------------------
-template <int EPI>
+template <int EPI, bool DYN = false>
 __global__ __launch_bounds__(512)
 void gemm_nt_w8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ W, int ldw,
                        bf16* __restrict__ C, int ldc, int M, int N, int K, M3PEpilogue ep,
-                       int tiles_m, int tiles_n) {
+                       int tiles_m, int tiles_n, int* __restrict__ tile_ctr) {
   constexpr int BM = 256, BN = 256, NWAVES = 8;
   constexpr int A_BYTES = BM * ROWB, STAGE = (BM + BN) * ROWB;      // 32 KB, 64 KB
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -809,10 +809,24 @@ void gemm_nt_w8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
   };
   const int nwg = gridDim.x;
   const int per_xcd = nwg >> 3;
-  const int slot = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  const int xcd = blockIdx.x & 7;
+  const int slot = xcd * per_xcd + (blockIdx.x >> 3);
+  if (slot >= ntiles) return;
+  // Tile schedule.  Static: workgroup `slot` takes tiles slot, slot + nwg, ...  Dynamic (tile_ctr != NULL, data parallelism):
+  // the first tile is the static one, every further tile is popped from its XCD's queue - the same tiles in the same order
+  // (position p of XCD x = tile (p / per_xcd) * nwg + x * per_xcd + p % per_xcd), but a workgroup whose CU is shared with a
+  // collective's kernel simply pops fewer of them instead of holding the whole launch back (profiles/r03_dynamic_tiles.txt).
+  // One lane pops (an L2 atomic) while the loader is three K-tiles into a tile, hands the result to the other waves through
+  // four bytes of wave 0's epilogue staging rows (idle inside the K loop) across two K-tile barriers, and the loader picks
+  // it up when it moves on nk - 3 K-tiles later: nothing waits for the atomic.
+  const int nk = K / BK;
+  constexpr bool dyn = DYN;       // (a separate instantiation: the queue's bookkeeping costs a dozen registers)
   auto tile_of = [&](int q) { return q * nwg + slot; };
-  const int my_tiles = (ntiles > slot) ? (ntiles - slot + nwg - 1) / nwg : 0;
-  if (my_tiles == 0) return;
+  const int my_tiles = (ntiles - slot + nwg - 1) / nwg;      // (static schedule)
+  const int total = my_tiles * nk;
+  int t_ld = slot, t_cmp = slot, t_next = -1;               // (dynamic schedule: tiles being loaded / computed, the popped one)
+  int pop_state = 0;        // 1: popped this K-tile (wave 0 publishes after the barrier), 2: published (everyone reads after the next)
+  unsigned popped = 0;
   // kSpare: the epilogue stages through the 32 KB beside the two stages (swizzled 128-byte rows: 4 KB per wave, or 2 KB
   // for the 16-row pieces of the multiply epilogues, whose derivative table lives there too) instead of the stage the
   // output tile's last K-tile vacated: the next tile's K-tile 1 is then requested on schedule and nobody has to meet at a
@@ -823,8 +837,7 @@ void gemm_nt_w8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
   constexpr int kTabBytes = (EPI == M3P_EPI_DGELU && M3P_DGELU_LUT) ? GELU_TAB_N * (int)sizeof(float) : 0;
   float* gtab = (EPI == M3P_EPI_DGELU && M3P_DGELU_LUT) ? reinterpret_cast<float*>(smem + 2 * STAGE) : nullptr;
   if (EPI == M3P_EPI_DGELU && M3P_DGELU_LUT) gelu_grad_table_fill(gtab, tid, 512);
-  const int nk = K / BK;
-  const int total = my_tiles * nk;
+  int* const mbox = reinterpret_cast<int*>(smem + 2 * STAGE + kTabBytes);
 
   // ---- load cursor: one LDS-DMA = 8 rows x 128 B; piece i of wave w covers row group w + 8 i of an operand
   //      (lane -> row l >> 3, LDS slot l & 7, source chunk slot ^ (row & 7)); groups are 64 rows apart
@@ -832,10 +845,11 @@ void gemm_nt_w8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
   const bf16* a_src;
   const bf16* w_src;
   const size_t a_step = (size_t)64 * lda, w_step = (size_t)64 * ldw;
-  int l_q = 0, l_kt = 0;
-  auto set_load_tile = [&](int q) {
+  int l_kt = 0, l_q = 0;
+  bool l_alive = true;      // (dynamic) the load cursor points at a K-tile of this workgroup's stream
+  auto set_load_tile = [&](int t) {
     int tm, tn;
-    split_tile(tile_of(q), tm, tn);
+    split_tile(t, tm, tn);
     a_src = A + (size_t)(tm * BM + wid * 8 + sr) * lda + sc * 8;
     w_src = W + (size_t)(tn * BN + wid * 8 + sr) * ldw + sc * 8;
   };
@@ -848,7 +862,21 @@ void gemm_nt_w8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
       __builtin_amdgcn_global_load_lds(GLB_PTR(w_src + (piece - 4) * w_step + k0), LDS_PTR(sa + A_BYTES + (wid + (piece - 4) * NWAVES) * 1024), 16, 0, 0);
   };
   auto load_done = [&]() {
-    if (++l_kt == nk) { l_kt = 0; ++l_q; if (l_q < my_tiles) set_load_tile(l_q); }
+    if constexpr (!dyn) {
+      if (++l_kt == nk) { l_kt = 0; ++l_q; if (l_q < my_tiles) set_load_tile(tile_of(l_q)); }
+    } else {
+      ++l_kt;
+      if (l_kt == 3) {
+        pop_state = 1;
+        if (wid == 0 && lane == 0) popped = __hip_atomic_fetch_add(reinterpret_cast<unsigned*>(tile_ctr) + xcd, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (l_kt == nk) {
+        l_kt = 0;
+        t_ld = t_next;
+        t_next = -1;
+        if (t_ld >= 0) set_load_tile(t_ld); else l_alive = false;
+      }
+    }
   };
   auto stage_next = [&](int s) {
 #pragma unroll
@@ -938,9 +966,12 @@ void gemm_nt_w8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
 #define W8_KSTAMP0() do { } while (0)
 #endif
   // ---- prologue: K-tiles 0 and 1 into stages 0 and 1
-  set_load_tile(0);
+  set_load_tile(slot);
   stage_next(0);
-  if (total > 1) {
+#define W8_H1 (dyn ? h1d : (step + 1 < total))
+#define W8_MORE2 (dyn ? l_alive : more2)
+  bool h1d = l_alive;        // (dynamic) K-tile step + 1 of the stream exists (was, or is being, requested)
+  if (dyn ? h1d : (total > 1)) {
     stage_next(1);
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   } else {
@@ -953,7 +984,7 @@ void gemm_nt_w8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
   read_w(b_addr[0], fw0);
   read_a_lo(a_addr[0], fa0);
   W8_LGKM0();
-  int c_q = 0, c_kt = 0;
+  int c_kt = 0, c_q = 0;
   const bool io_aligned = ((ldc & 7) == 0) && (((uintptr_t)C & 15) == 0) &&
                           (!(EPI == M3P_EPI_BIAS_GELU) || (((ep.ld_out2 & 7) == 0) && (((uintptr_t)ep.out2 & 15) == 0))) &&
                           (!ep.bias || (((uintptr_t)ep.bias & 15) == 0)) &&
@@ -980,10 +1011,11 @@ void gemm_nt_w8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
   W8_TSEG(4);
 #endif
   W8_KSTAMP0();
-  for (int step = 0; step < total; ++step) {
+  for (int step = 0; dyn || step < total; ++step) {
     const int cur = step & 1, nxt = cur ^ 1;
     const bool last_kt = (c_kt + 1 == nk);
-    const bool more2 = (step + 2 < total);
+    // K-tile step + 2 exists (it is requested during this step).  Dynamic: known once quarter 1 has advanced the load cursor
+    const bool more2 = dyn ? false : (step + 2 < total);
     const uint32_t so = cur * STAGE;
     const bool pend = M3P_W8_SPREAD && spread_pending;      // the request for K-tile +1 started in the previous quarter 3
     // quarter 0: k-step 0, rows 0-63 | fetch k-step 0, rows 64-127
@@ -1015,17 +1047,31 @@ void gemm_nt_w8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
     asm volatile("" ::: "memory");
     W8_KSTAMP(5);
     __builtin_amdgcn_sched_barrier(0);
+    if (dyn && pop_state) {
+      if (pop_state == 1) {
+        if (wid == 0 && lane == 0) {
+          const int p = per_xcd + (int)popped, q = p / per_xcd;
+          const int t = q * nwg + xcd * per_xcd + (p - q * per_xcd);
+          *mbox = (t < ntiles) ? t : -1;
+        }
+        pop_state = 2;
+      } else {
+        t_next = __builtin_amdgcn_readfirstlane(*mbox);
+        pop_state = 0;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
     // quarter 3: k-step 1, rows 64-127 | request K-tile +2 into the vacated stage | fetch K-tile +1's first fragments
     // (on an output tile's last K-tile both wait for the epilogue, which stages through that stage and wants the registers)
     // (epilogues with an aux tile ask for it FIRST: vmcnt retires in order, so a load issued behind the three LDS-DMAs
     //  would wait for them too - on an output tile's last K-tile the request moves into the epilogue, behind the aux loads)
-    const bool req = more2 && (!last_kt || (kSpare && !kAuxE));
+    const bool req = W8_MORE2 && (!last_kt || (kSpare && !kAuxE));
     if (req) {
       if (!M3P_W8_SPREAD) stage_next(cur);
       else if (!M3P_W8_INTERLEAVE) { issue_load(cur, 0); issue_load(cur, 1); issue_load(cur, 2); }
       if (M3P_W8_SPREAD) spread_pending = true;
     }
-    if (step + 1 < total && !last_kt) {
+    if (W8_H1 && !last_kt) {
       read_w(b_addr[0] + nxt * STAGE, fw0);
       read_a_lo(a_addr[0] + nxt * STAGE, fa0);
     }
@@ -1044,8 +1090,9 @@ void gemm_nt_w8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
       // ---- epilogue of output tile c_q through the vacated stage `cur`
       W8_TSEG(0);
       c_kt = 0;
-      const int t = tile_of(c_q);
-      ++c_q;
+      // (dynamic, nk >= 8: the loader moved on to the next tile two K-tiles ago; -1 behind the last one)
+      const int t = dyn ? t_cmp : tile_of(c_q);
+      if (dyn) t_cmp = t_ld; else ++c_q;
       int tm, tn;
       split_tile(t, tm, tn);
       const int m0 = tm * BM, n0 = tn * BN;
@@ -1061,7 +1108,7 @@ void gemm_nt_w8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
         u32x4 ta[2], tb[2];
         aux16_issue(ep, mw, nw, lane, ta);
         __builtin_amdgcn_sched_barrier(0);
-        if (more2) { issue_load(cur, 0); issue_load(cur, 1); issue_load(cur, 2); spread_pending = true; }
+        if (W8_MORE2) { issue_load(cur, 0); issue_load(cur, 1); issue_load(cur, 2); spread_pending = true; }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int hp = 0; hp < 8; hp += 2) {
@@ -1081,7 +1128,7 @@ void gemm_nt_w8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
         if (kSpare && kAuxE) {
           load_aux_rows_issue<EPI>(ep, mw, nw, lane, aux0);
           __builtin_amdgcn_sched_barrier(0);
-          if (more2) { issue_load(cur, 0); issue_load(cur, 1); issue_load(cur, 2); spread_pending = true; }
+          if (W8_MORE2) { issue_load(cur, 0); issue_load(cur, 1); issue_load(cur, 2); spread_pending = true; }
           __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
@@ -1103,7 +1150,7 @@ void gemm_nt_w8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
           __builtin_amdgcn_sched_barrier(0);      // one piece at a time: hoisted loads of the next piece cost registers
         }
       } else {
-        if (kSpare && kAuxE && more2) { issue_load(cur, 0); issue_load(cur, 1); issue_load(cur, 2); spread_pending = true; }
+        if (kSpare && kAuxE && W8_MORE2) { issue_load(cur, 0); issue_load(cur, 1); issue_load(cur, 2); spread_pending = true; }
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -1114,13 +1161,13 @@ void gemm_nt_w8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
       for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (step + 1 < total) {
+      if (W8_H1) {
         if (!kSpare) {
           // the staging rows are where K-tile +2 goes: nobody requests it before every wave is done with its round trip
           W8_LGKM0();
           __builtin_amdgcn_s_barrier();
           asm volatile("" ::: "memory");
-          if (more2) stage_next(cur);
+          if (W8_MORE2) stage_next(cur);
         }
         read_w(b_addr[0] + nxt * STAGE, fw0);
         read_a_lo(a_addr[0] + nxt * STAGE, fa0);
@@ -1128,6 +1175,10 @@ void gemm_nt_w8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
       }
       W8_TSEG(3);
       W8_KSTAMP0();
+    }
+    if (dyn) {
+      if (!h1d) break;
+      h1d = l_alive;
     }
   }
   if ((EPI == M3P_EPI_DGELU || EPI == M3P_EPI_MUL) && ep.colsum && csum_nw >= 0) flush_csum();
@@ -1139,6 +1190,8 @@ void gemm_nt_w8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
       g_ring_tl[256 * 8 * 8 + (blockIdx.x * 8 + wid) * 8 + k] = kq[k];
     }
 #endif
+#undef W8_H1
+#undef W8_MORE2
 #undef W8_TSEG
 #undef W8_KSTAMP
 #undef W8_KSTAMP0
@@ -2166,6 +2219,10 @@ static int num_cus() {
   return (g_persistent_grid > 0 && g_persistent_grid < hw) ? g_persistent_grid : hw;
 }
 
+// dynamic tile queues of the eight-wave kernel (m3p_set_tile_queue): a ring of 8-counter slots, one slot per launch
+static int* g_tq_pool = nullptr;
+static int g_tq_slots = 0, g_tq_next = 0;
+
 template <int EPI>
 int launch_nt(const bf16* A, int lda, const bf16* W, int ldw, bf16* C, int ldc, int M, int N, int K,
               const M3PEpilogue& ep, hipStream_t st) {
@@ -2198,7 +2255,29 @@ int launch_nt(const bf16* A, int lda, const bf16* W, int ldw, bf16* C, int ldc, 
     int grid = num_cus();
     const int ntiles = tiles_m * tiles_n;
     if (ntiles < grid) grid = (ntiles + 7) / 8 * 8;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_m, tiles_n);
+    // dynamic tile queue (ep.tile_ctr: eight zeroed counters, one per XCD) only where a workgroup takes several tiles
+    int* ctr = nullptr;
+    if (g_tq_pool && ntiles > grid && K >= 8 * BK) {
+      if (g_tq_next == g_tq_slots) {       // ring used up: clear it behind everything this stream has launched so far
+        hipError_t e = hipMemsetAsync(g_tq_pool, 0, (size_t)g_tq_slots * 8 * sizeof(int), st);
+        if (e != hipSuccess) return (int)e;
+        g_tq_next = 0;
+      }
+      ctr = g_tq_pool + 8 * g_tq_next++;
+    }
+    if (ctr) {
+      auto kern_d = gemm_nt_w8_kernel<EPI, true>;
+      static bool attr_set8d = false;
+      if (!attr_set8d) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern_d, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set8d = true;
+      }
+      hipLaunchKernelGGL(kern_d, dim3(grid), dim3(512), lds, st, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_m, tiles_n, ctr);
+      M3P_CHECK_LAUNCH();
+      return M3P_OK;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_m, tiles_n, ctr);
     M3P_CHECK_LAUNCH();
     return M3P_OK;
   }
@@ -3220,6 +3299,14 @@ int m3p_gemm_nn_streamk_f32(const void* A, int lda, const void* W, int ldw, int 
 int m3p_set_persistent_grid(int workgroups) {
   if (workgroups < 0 || (workgroups % 8) != 0) return M3P_EINVAL;
   g_persistent_grid = workgroups;
+  return M3P_OK;
+}
+
+int m3p_set_tile_queue(int32_t* counters, int n_slots) {
+  if (counters && (n_slots <= 0 || ((uintptr_t)counters & 3))) return M3P_EINVAL;
+  g_tq_pool = counters;
+  g_tq_slots = counters ? n_slots : 0;
+  g_tq_next = 0;
   return M3P_OK;
 }
 

@@ -271,6 +271,10 @@ class DataParallel(torch.nn.Module):
         self._param_events = {}      # zero1: bucket key -> event on the side stream (master gathered + bf16 cast done)
         self.exposed_events = None   # set to [] to record (start, end) events around finish()'s waits
         object.__setattr__(module, 'ddp_hook', self)    # plain attribute: as a registered submodule it would close a cycle
+        if self.world > 1 and arena.device.type == 'cuda' and os.environ.get('M3P_DP_TILE_QUEUE', '1') != '0':
+            # the collectives' kernels share CUs with the persistent GEMMs: let slowed-down CUs take fewer tiles
+            from . import ops
+            ops.set_tile_queue(True)
         if self.world > 1 and arena.device.type == 'cuda' and reserve_cus():
             from . import lib as L
             L.load().m3p_set_persistent_grid(L.num_cus() - reserve_cus())

@@ -75,6 +75,7 @@ SIGNATURES = {
     'm3p_transpose_batch_bf16': (_i, [_p, _i, _i, _p]),
     'm3p_transpose_bf16': (_i, [_p, _p, _i, _i, _i, _i, _p]),
     'm3p_set_persistent_grid': (_i, [_i]),
+    'm3p_set_tile_queue': (_i, [_p, _i]),
     'm3p_seq_masks': (_i, [_p, _p, _i, _i, _p, _p, _p]),
     'm3p_mask_to_rows': (_i, [_p, _i, _i, C.c_longlong, C.c_longlong, C.c_longlong, _i, _p, _i, _p]),
     'm3p_cast_rows_f32_bf16': (_i, [_p, C.c_longlong, C.c_longlong, _i, _i, _i, _p, _p]),
@@ -103,9 +104,13 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the .so is stale
         fn.restype = res
         fn.argtypes = args
+    _lib_tq = os.environ.get('M3P_TILE_QUEUE', '0') != '0'     # developer switch: dynamic tile queues without data parallelism
     if os.environ.get('M3P_VARIANT'):      # developer switch between GEMM kernel generations (A/B runs)
         lib.m3p_debug_set_variant(int(os.environ['M3P_VARIANT']))
     _lib = lib
+    if _lib_tq and torch.cuda.is_available():
+        from . import ops
+        ops.set_tile_queue(True)
     return lib
 
 

@@ -291,6 +291,24 @@ def cast_bf16(x):
     return out
 
 
+_TILE_QUEUE = {}      # device index -> the counter ring handed to m3p_set_tile_queue (kept alive here)
+
+
+def set_tile_queue(enable=True, slots=4096):
+    """Dynamic tile queues for the persistent NT GEMM (include/m3p_hip.h: m3p_set_tile_queue): workgroups pop output tiles
+    from per-XCD queues, so CUs slowed down by a co-resident collective kernel take fewer tiles.  Process-wide; all GEMMs on
+    one stream."""
+    dev = torch.cuda.current_device()
+    if not enable:
+        L.check(L.load().m3p_set_tile_queue(None, 0), 'm3p_set_tile_queue')
+        _TILE_QUEUE.pop(dev, None)
+        return
+    pool = torch.zeros(slots * 8, dtype=torch.int32, device='cuda')
+    torch.cuda.current_stream().synchronize()
+    L.check(L.load().m3p_set_tile_queue(pool.data_ptr(), slots), 'm3p_set_tile_queue')
+    _TILE_QUEUE[dev] = pool
+
+
 def cast_f32_bf16_into(src, dst):
     """dst (bf16) <- src (fp32), same element count, on the current stream."""
     assert src.dtype == torch.float32 and dst.dtype == BF16 and src.is_contiguous() and dst.is_contiguous()

@@ -30,6 +30,8 @@ def main():
     ap.add_argument('--channels', type=int, default=16)
     ap.add_argument('--mb', type=int, default=96, help='MB copied per side launch (a layer bucket is 28 MB reduced = ~2 x that moved)')
     ap.add_argument('--launches', type=int, default=14)
+    ap.add_argument('--queue-ab', action='store_true', help='A/B of the dynamic tile queues (m3p_set_tile_queue) instead of the grid sizes')
+    ap.add_argument('--profile-arm', default=None, help="'side' / 'none': only run that arm at the full grid (for rocprofv3 --stats)")
     args = ap.parse_args()
     torch.set_num_threads(4)
     import bench
@@ -79,6 +81,21 @@ def main():
     ncu = L.num_cus()
     for _ in range(6):
         step(False)
+    if args.profile_arm:
+        print(run(ncu, args.profile_arm == 'side'))
+        return
+    if args.queue_ab:
+        from m3p_amd import ops
+        print('# step = cfg2 B=%d; side traffic = %d launches x %d MB per step on %d workgroups; tile queue off / on' % (args.batch, args.launches, args.mb, args.channels))
+        print('# queue side  ms/step  side ms/step')
+        for rnd in range(3):
+            for q in (False, True):
+                ops.set_tile_queue(q)
+                for with_side in (False, True):
+                    ms, sm = run(ncu, with_side)
+                    print('%-5s %-5s %7.2f  %8.2f' % ('on' if q else 'off', 'yes' if with_side else 'no', ms, sm), flush=True)
+        ops.set_tile_queue(False)
+        return
     print('# step = cfg2 B=%d; side traffic = %d launches x %d MB per step on %d workgroups (stand-in for RCCL channels)'
           % (args.batch, args.launches, args.mb, args.channels))
     print('# grid  side  ms/step  side-stream ms/step (first side launch -> last done)  side GB/s (read + write)')
