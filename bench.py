@@ -321,7 +321,7 @@ def main():
             ach = flops / (avg_ms * 1e-3) / 1e12
             kname = '%s M=%d N=%d K=%d' % (kind, M, N, K)
             traffic, tsrc = None, None
-            for rel in ('profiles/r02_traffic.json', 'profiles/r01_traffic.json'):
+            for rel in ('profiles/r03_traffic.json', 'profiles/r02_traffic.json', 'profiles/r01_traffic.json'):
                 tpath = os.path.join(ROOT, rel)
                 if os.path.exists(tpath):   # HBM bytes/launch from the committed rocprofv3 --pmc passes of this command
                     traffic = json.load(open(tpath)).get('bench_keys', {}).get(kname)

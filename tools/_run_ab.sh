@@ -1,4 +1,8 @@
-mkdir -p gpurun_out/r3g
-M3P_TILE_QUEUE=1 python -m pytest tests/test_gemm.py tests/test_model_parity.py -m gpu -x -q 2>&1 | tail -3
-python -m pytest tests/test_gemm.py -m gpu -x -q 2>&1 | tail -2
-python tools/cu_reserve_ab.py --queue-ab --launches 56 2>/dev/null | tee gpurun_out/r3g/queue_ab.txt
+mkdir -p gpurun_out/r3h
+rm -rf gpurun_out/counters
+bash tools/collect_counters.sh > gpurun_out/r3h/collect.log 2>&1
+python bench.py > gpurun_out/r3h/bench_default.json 2> gpurun_out/r3h/bench_default.err; tail -c 600 gpurun_out/r3h/bench_default.json
+python bench.py --config cfg3 --no-cpu-baseline --steps 10 --warmup 3 > gpurun_out/r3h/bench_cfg3.json 2>/dev/null; cut -c1-260 gpurun_out/r3h/bench_cfg3.json
+python bench.py --config cfg4 --batch 64 --no-cpu-baseline --steps 10 --warmup 3 > gpurun_out/r3h/bench_cfg4_bf16.json 2>/dev/null; cut -c1-260 gpurun_out/r3h/bench_cfg4_bf16.json
+python bench.py --config cfg4 --batch 64 --fp8 --no-cpu-baseline --steps 10 --warmup 3 > gpurun_out/r3h/bench_cfg4_fp8.json 2>/dev/null; cut -c1-260 gpurun_out/r3h/bench_cfg4_fp8.json
+python bench.py --ragged --no-cpu-baseline > gpurun_out/r3h/bench_ragged.json 2>/dev/null; cut -c1-200 gpurun_out/r3h/bench_ragged.json

@@ -39,7 +39,7 @@ for name, (calls, avg_ns) in sorted(stats.items(), key=lambda kv: -kv[1][0] * kv
 
 # the dominant instance of bench.py's roofline block: the dGELU data gradient (epilogue 5 runs only on this shape in the
 # step), on whichever NT kernel the dispatch picked
-dg = [k for k in kernels if 'gemm_nt_w8_kernel<5>' in k] or [k for k in kernels if 'gemm_nt_ring_kernel<5>' in k]
+dg = [k for k in kernels if 'gemm_nt_w8_kernel<5' in k and 'true' not in k.split('gemm_nt_w8_kernel<5')[1][:8]] or [k for k in kernels if 'gemm_nt_ring_kernel<5>' in k]
 bench_keys = {'gemm_nt/dgelu M=41984 N=3072 K=768': kernels[dg[0]]['hbm_bytes_per_launch']} if dg else {}
 note = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, tools/collect_counters.sh) of `python bench.py --steps 3 "
         "--warmup 1 --no-cpu-baseline`; values are KB per launch averaged over all launches of the kernel. hbm_bytes = (2*FETCH_SIZE + "
