@@ -38,6 +38,9 @@ __device__ unsigned long long g_attn_tl[4096 * 4 * 16];
 #ifndef M3P_ATTN_BWD_KBQ
 #define M3P_ATTN_BWD_KBQ M3P_ATTN_BWD_KB
 #endif
+#ifndef M3P_ATTN_BWD_WPS
+#define M3P_ATTN_BWD_WPS 3      // waves per SIMD the register allocation must leave room for (four-wave workgroups)
+#endif
 #ifndef M3P_ATTN_BWD_NW
 #define M3P_ATTN_BWD_NW 4
 #endif
@@ -298,7 +301,7 @@ void attn_fwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
 // independent MFMA -> softmax -> MFMA chains per wave to hide each other's waits (counters, r03: the waves of this kernel
 // sit in s_waitcnt 56 % of their cycles; LDS array ~45 % busy).  Costs registers: KB = 2 runs two workgroups per CU.
 template <int DH, int KT, bool DROP, bool MASK, int NKC, int NTC, int NW = 4, int KB = 1, int KBQ = KB>
-__global__ __launch_bounds__(NW * 64, (NW == 8 || (KB == 2 && NW != 6)) ? 2 : 3)   // NW = 4: three 49-KB workgroups per CU; 8: one ~100-KB workgroup (long S)
+__global__ __launch_bounds__(NW * 64, NTC == 11 ? M3P_ATTN_BWD_WPS : ((NW == 8 || KB == 2) ? 2 : 3))   // NW = 4: three 49-KB workgroups per CU; 8: one ~100-KB workgroup (long S)
 void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keylen, const bf16* __restrict__ ctx,
                      const bf16* __restrict__ dctx, const float* __restrict__ lse,
                      const unsigned long long* __restrict__ keepmask, bf16* __restrict__ dqkv,
@@ -695,7 +698,7 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
       if (part != 1) {
         float tot = 0.f;
 #pragma unroll
-        for (int w = 0; w < NW; w += 2) tot += sB[w * 3 * DH + i] + sB[(w + 1) * 3 * DH + i];
+        for (int w = 0; w < NW; ++w) tot += sB[w * 3 * DH + i];
         atomicAdd(dbias_qkv + part * dmodel + h * DH + c, tot);
       }
     }
