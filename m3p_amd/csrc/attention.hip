@@ -28,8 +28,15 @@ namespace {
 #ifdef M3P_ATTN_TL
 __device__ unsigned long long g_attn_tl[4096 * 4 * 16];
 #define ATL(k) do { if (blockIdx.x < 4096 && lane == 0 && wid < 4) g_attn_tl[(blockIdx.x * 4 + wid) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+// backward kernel (the last launch wins the buffer): 0 start, 1 D / lse done, 2 Q / dO staged (barrier passed), 3 phase A loop done,
+// 4 barrier passed, 5 K / V staged (barrier passed), 6 phase B loop done, 7 end; sums: 8 waiting for the owned block's K / V rows (A),
+// 9 the same for Q / dO rows (B), 10 phase A output stores issued, 11 phase B output stores issued
+#define BTL(i) do { tl[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define BTL_SUM(i, t0) do { tl[i] += __builtin_amdgcn_s_memtime() - (t0); } while (0)
 #else
 #define ATL(k) do { } while (0)
+#define BTL(k) do { } while (0)
+#define BTL_SUM(i, t0) do { } while (0)
 #endif
 
 #ifndef M3P_ATTN_BWD_KB
@@ -58,6 +65,27 @@ template <int DH> struct AttnCfg {
 __device__ __forceinline__ bf16x4 lds_tr16(const char* p) {
   s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
   return __builtin_bit_cast(bf16x4, v);
+}
+// sum over the 16 lanes of a DPP row (lanes 16 g .. 16 g + 15), result in every lane of the row: quad butterflies, then two
+// rotations of the row.  Four VALU adds with DPP operands; __shfl_xor goes through ds_bpermute (an LDS-pipeline round trip each).
+__device__ __forceinline__ float row16_sum(float v) {
+#define M3P_DPP_ADD(ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, true))
+  M3P_DPP_ADD(0xB1);      // quad_perm [1,0,3,2]
+  M3P_DPP_ADD(0x4E);      // quad_perm [2,3,0,1]
+  M3P_DPP_ADD(0x124);     // row_ror:4
+  M3P_DPP_ADD(0x128);     // row_ror:8
+#undef M3P_DPP_ADD
+  return v;
+}
+// sum over groups of CH (4 or 8) consecutive lanes, result in every lane of the group
+template <int CH>
+__device__ __forceinline__ float chunks_sum(float v) {
+#define M3P_DPP_ADD(ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, true))
+  M3P_DPP_ADD(0xB1);      // quad_perm [1,0,3,2]
+  M3P_DPP_ADD(0x4E);      // quad_perm [2,3,0,1]
+  if (CH == 8) M3P_DPP_ADD(0x141);   // row_half_mirror: lane j of each 8 <- lane 7 - j (the other quad's sum)
+#undef M3P_DPP_ADD
+  return v;
 }
 __device__ __forceinline__ bf16x8 cat8(bf16x4 a, bf16x4 b) {
   return bf16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
@@ -312,14 +340,23 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  // block ownership rotates with the workgroup: with 11 blocks over four waves one wave owns two instead of three, and the
+  // same wave id of every workgroup on a CU sits on the same SIMD - without the rotation one SIMD of four idles a third of
+  // both phases while the other three carry the launch (the forward kernel does the same)
+  const int wrot = (NW & (NW - 1)) ? wid : ((wid + (blockIdx.x >> 3)) & (NW - 1));
   const int nt = NTC ? NTC : ((S + 15) >> 4);
   const int nk = NKC ? NKC : ((S + 31) >> 5);
   const size_t ld = 3 * (size_t)dmodel;
-  const bf16* Qg = qkv + (size_t)b * S * ld + h * DH;
+#ifdef M3P_ATTN_ALIAS      // experiment: every workgroup reads the operands of batch rows 0..3 (cache-resident), writes its own
+  const int b_rd = b & 3;
+#else
+  const int b_rd = b;
+#endif
+  const bf16* Qg = qkv + (size_t)b_rd * S * ld + h * DH;
   const bf16* Kg = Qg + dmodel;
   const bf16* Vg = Qg + 2 * dmodel;
-  const bf16* Og = ctx + (size_t)b * S * dmodel + h * DH;
-  const bf16* dOg = dctx + (size_t)b * S * dmodel + h * DH;
+  const bf16* Og = ctx + (size_t)b_rd * S * dmodel + h * DH;
+  const bf16* dOg = dctx + (size_t)b_rd * S * dmodel + h * DH;
   bf16* dQg = dqkv + (size_t)b * S * ld + h * DH;
   bf16* dKg = dQg + dmodel;
   bf16* dVg = dQg + 2 * dmodel;
@@ -356,9 +393,7 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
     for (int n = 0; n < Cf::NT; ++n)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float sfl = bsum[n][r];
-        sfl += __shfl_xor(sfl, 1, 64); sfl += __shfl_xor(sfl, 2, 64);
-        sfl += __shfl_xor(sfl, 4, 64); sfl += __shfl_xor(sfl, 8, 64);
+        const float sfl = row16_sum(bsum[n][r]);
         if (fq == 0) sBw[part * DH + 16 * n + 4 * fg + r] = sfl;
         bsum[n][r] = 0.f;
       }
@@ -380,28 +415,30 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
   constexpr float kLog2e = 1.4426950408889634f;
   constexpr float kMasked = -1.0e30f;    // score of a masked key: exp2 of it is exactly 0
   const uint32_t inv_keep_bits = __builtin_bit_cast(uint32_t, inv_keep);
-  // ---- prologue: D[q] = rowsum(dO * O), lse -> LDS (padded rows: D = 0, lse = +inf so P = 0)
-  for (int q = tid; q < nk * 32; q += NW * 64) {
-    float dsum = 0.f, l = INFINITY;
-    if (q < S) {
-      const bf16* op = Og + (size_t)q * dmodel;
-      const bf16* dp = dOg + (size_t)q * dmodel;
+#ifdef M3P_ATTN_TL
+  unsigned long long tl[16];
+  for (int i = 0; i < 16; ++i) tl[i] = 0;
+  unsigned long long tw;
+#endif
+  BTL(0);
+  // Q and dO tiles are requested first (LDS-DMA, asynchronous), then this wave's first K / V fragments (they do not depend on
+  // LDS).  D[q] = rowsum(dO * O) is taken from the dO rows THIS wave staged (a wave may read its own LDS-DMA rows after its own
+  // vmcnt(0), no barrier needed) times the matching O chunks fetched from global beside them: dO is read from HBM once
+  // instead of twice (r03: 818 MB per launch against 516 MB algorithmic) and all waves share the work.
+  constexpr bool kDfromLds = NKC != 0;
+  constexpr int kStageInstr = NKC * 32 / Cf::RPI;                       // LDS-DMA instructions per tile
+  constexpr int kNIW = kDfromLds ? (kStageInstr + NW - 1) / NW : 1;     // ... of which this wave issues at most
+  bf16x8 orow[kNIW];
+  if (kDfromLds) {
+    const int rin = lane / Cf::CH, c = lane % Cf::CH;
 #pragma unroll
-      for (int c = 0; c < DH / 8; ++c) {
-        const bf16x8 ov = *reinterpret_cast<const bf16x8*>(op + 8 * c);
-        const bf16x8 dv = *reinterpret_cast<const bf16x8*>(dp + 8 * c);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) dsum += (float)ov[e] * (float)dv[e];
-      }
-      l = lse_bh[q] * kLog2e;          // probabilities are rebuilt as exp2(S log2e - lse log2e): fma + v_exp
+    for (int j = 0; j < kNIW; ++j) {
+      const int row = (wid + j * NW) * Cf::RPI + rin;                   // (same row / chunk as this lane's piece of stage_rows)
+      orow[j] = *reinterpret_cast<const bf16x8*>(Og + (size_t)min(row, S - 1) * dmodel + Cf::swz(c, row) * 8);
     }
-    sD[q] = dsum;
-    sL[q] = l;
   }
-  // ================= phase A: dV, dK (wave owns key blocks) =================
   stage_rows<DH>(Qg, ld, S, nk * 32, s0, wid, lane, NW);
   stage_rows<DH>(dOg, (size_t)dmodel, S, nk * 32, s1, wid, lane, NW);
-  // this wave's first K / V fragments do not depend on LDS: fetch them under the staging latency
   bf16x8 kf[KB][Cf::KK], vf[KB][Cf::KK];
   auto load_kv = [&](int u, int kb) {
     const int keyc = min(kb * 16 + fq, S - 1);
@@ -411,13 +448,68 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
       vf[u][kk] = *reinterpret_cast<const bf16x8*>(Vg + (size_t)keyc * ld + 32 * kk + 8 * fg);
     }
   };
-  if (wid * KB < nt) {
+  if (wrot * KB < nt) {
 #pragma unroll
-    for (int u = 0; u < KB; ++u) load_kv(u, wid * KB + u);
+    for (int u = 0; u < KB; ++u) load_kv(u, wrot * KB + u);
   }
+  // ---- prologue: D[q] = rowsum(dO * O), lse -> LDS (padded rows: D = 0, lse = +inf so P = 0)
+  for (int q = tid; q < nk * 32; q += NW * 64) {
+    float dsum = 0.f, l = INFINITY;
+    if (q < S) {
+      if (!kDfromLds) {
+        const bf16* op = Og + (size_t)q * dmodel;
+        const bf16* dp = dOg + (size_t)q * dmodel;
+#pragma unroll
+        for (int c = 0; c < DH / 8; ++c) {
+          const bf16x8 ov = *reinterpret_cast<const bf16x8*>(op + 8 * c);
+          const bf16x8 dv = *reinterpret_cast<const bf16x8*>(dp + 8 * c);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) dsum += (float)ov[e] * (float)dv[e];
+        }
+      }
+      l = lse_bh[q] * kLog2e;          // probabilities are rebuilt as exp2(S log2e - lse log2e): fma + v_exp
+    }
+    if (!kDfromLds) sD[q] = dsum;
+    sL[q] = l;
+  }
+  if (kDfromLds) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's LDS-DMA rows (and its O chunks) have landed
+    const int rin = lane / Cf::CH, c = lane % Cf::CH;
+#pragma unroll
+    for (int j = 0; j < kNIW; ++j) {
+      const int i = wid + j * NW;
+      if (i < kStageInstr) {
+        const bf16x8 dv = *reinterpret_cast<const bf16x8*>(s1 + i * 1024 + lane * 16);
+        float part = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) part += (float)orow[j][e] * (float)dv[e];
+        part = chunks_sum<Cf::CH>(part);
+        const int row = i * Cf::RPI + rin;
+        if (c == 0) sD[row] = row < S ? part : 0.f;
+      }
+    }
+  }
+  BTL(1);
+  // ================= phase A: dV, dK (wave owns key blocks) =================
   __syncthreads();
+  BTL(2);
 
-  for (int kb0 = wid * KB; kb0 < nt; kb0 += NW * KB) {
+  // keep-bit words of a step are requested two steps ahead (unrolled steps only: the buffers alternate at compile time): the
+  // words are read once per launch, so every one of them is an L2 miss the step would otherwise wait for in full
+  constexpr bool kPreA = MASK && NKC != 0;
+  unsigned long long mwA[2][KB][2];
+  auto mask_words_A = [&](int kb0_, int kq_, int par) {
+#pragma unroll
+    for (int u = 0; u < KB; ++u)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf)
+        mwA[par][u][hf] = mbh[((size_t)min(2 * kq_ + hf, nt - 1) * nt + min(kb0_ + u, nt - 1)) * 4 + (fq & 3)];
+  };
+  if (kPreA) {
+    mask_words_A(wrot * KB, 0, 0);
+    mask_words_A(wrot * KB, 1, 1);
+  }
+  for (int kb0 = wrot * KB; kb0 < nt; kb0 += NW * KB) {
     // (an owned block behind the last key tile - odd tile counts with KB = 2 - runs as an all-masked block: p = 0, nothing stored)
     int key[KB], keyc[KB];
     float kbias[KB];
@@ -426,8 +518,13 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
       key[u] = (kb0 + u) * 16 + fq;            // this lane's key column
       keyc[u] = min(key[u], S - 1);
       kbias[u] = (key[u] < klen) ? 0.f : kMasked;
-      if (kb0 != wid * KB) load_kv(u, kb0 + u);
+      if (kb0 != wrot * KB) load_kv(u, kb0 + u);
     }
+#ifdef M3P_ATTN_TL
+    tw = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    BTL_SUM(8, tw);
+#endif
     // dV^T[d][key] = sum_q dO[q][d] Pd[q][key] ; dK^T[d][key] = sum_q Q[q][d] dS[q][key]
     // streamed over 32-query steps: P / dS of a step are produced (lane = key column, query
     // 16t + 4fg + r) and consumed as MFMA B operands at once — nothing S x S is held
@@ -484,7 +581,8 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
           uint32_t kbits = 0;
           if (MASK) {
             // forward layout: word [qb = t][tile = kb][r = key & 3], bit (q & 15) + 16 ((key & 15) >> 2)
-            const unsigned long long w = mbh[((size_t)min(t, nt - 1) * nt + min(kb0 + u, nt - 1)) * 4 + (fq & 3)];
+            const unsigned long long w = kPreA ? mwA[kq & 1][u][hf]
+                                               : mbh[((size_t)min(t, nt - 1) * nt + min(kb0 + u, nt - 1)) * 4 + (fq & 3)];
             kbits = (uint32_t)(w >> (4 * fg + 16 * (fq >> 2)));
           }
 #pragma unroll
@@ -512,6 +610,10 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
         sfrag[u] = bf16x8{(bf16)ds2[0][0], (bf16)ds2[0][1], (bf16)ds2[0][2], (bf16)ds2[0][3],
                           (bf16)ds2[1][0], (bf16)ds2[1][1], (bf16)ds2[1][2], (bf16)ds2[1][3]};
       }
+      if (kPreA) {      // (behind the last step of a block: the first steps of the next owned block, clamped on the last one)
+        if (kq + 2 < nk) mask_words_A(kb0, kq + 2, kq & 1);
+        else mask_words_A(kb0 + NW * KB, kq + 2 - nk, kq & 1);
+      }
 #pragma unroll
       for (int n = 0; n < Cf::NT; ++n) {
         const char* pq = s0 + kq * 32 * Cf::ROWB + t_off[n];
@@ -526,6 +628,9 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
       }
       if (NKC) __builtin_amdgcn_sched_barrier(0);   // unrolled steps stay in order: no register blow-up from hoisted loads
     }
+#ifdef M3P_ATTN_TL
+    tw = __builtin_amdgcn_s_memtime();
+#endif
 #pragma unroll
     for (int u = 0; u < KB; ++u) {
       if (key[u] < S) {
@@ -547,9 +652,12 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
         }
       }
     }
+    BTL_SUM(10, tw);
   }
+  BTL(3);
   if (dbias_qkv) bias_flush(2);
   __syncthreads();   // everyone done with Q / dO tiles
+  BTL(4);
 
   // ================= phase B: dQ (wave owns query blocks) =================
   stage_rows<DH>(Kg, ld, S, nk * 32, s0, wid, lane, NW);
@@ -563,13 +671,14 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
       df[u][kk] = *reinterpret_cast<const bf16x8*>(dOg + (size_t)qc * dmodel + 32 * kk + 8 * fg);
     }
   };
-  if (wid * KBQ < nt) {
+  if (wrot * KBQ < nt) {
 #pragma unroll
-    for (int u = 0; u < KBQ; ++u) load_qd(u, wid * KBQ + u);
+    for (int u = 0; u < KBQ; ++u) load_qd(u, wrot * KBQ + u);
   }
   __syncthreads();
+  BTL(5);
 
-  for (int qb0 = wid * KBQ; qb0 < nt; qb0 += NW * KBQ) {
+  for (int qb0 = wrot * KBQ; qb0 < nt; qb0 += NW * KBQ) {
     int q[KBQ], qc[KBQ];
     float lq[KBQ], dq_[KBQ];      // lse (log2 units) and D of this lane's queries (a block behind the last tile: lse = +inf -> p = 0)
     uint32_t rbase[KBQ];
@@ -577,14 +686,35 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
     for (int u = 0; u < KBQ; ++u) {
       q[u] = (qb0 + u) * 16 + fq;
       qc[u] = min(q[u], S - 1);
-      if (qb0 != wid * KBQ) load_qd(u, qb0 + u);
+      if (qb0 != wrot * KBQ) load_qd(u, qb0 + u);
       const bool in = q[u] < nk * 32;
       lq[u] = in ? sL[min(q[u], nk * 32 - 1)] : INFINITY;
       dq_[u] = in ? sD[min(q[u], nk * 32 - 1)] : 0.f;
       rbase[u] = (uint32_t)((b * H + h) * S + qc[u]) * (uint32_t)S;
     }
+#ifdef M3P_ATTN_TL
+    tw = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    BTL_SUM(9, tw);
+#endif
     int klen_it = klen;
     asm volatile("" : "+s"(klen_it));   // opaque per query block: keeps the key-mask tests inside the loop
+    // keep-bit words (wave-uniform: scalar loads, one s_load_dwordx16 per step) are requested one step ahead.  (They share
+    // lgkmcnt with the LDS reads and return out of order, so the next LDS wait still waits for them; fetching them with a vector
+    // load, a dword per lane, and v_readlane at the use measured slower: 219 us against 211.)
+    constexpr bool kPreB = MASK && NKC != 0;
+    unsigned long long mwB[2][KBQ][2][4];
+    auto mask_words_B = [&](int kq_, int par) {
+#pragma unroll
+      for (int u = 0; u < KBQ; ++u)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          const unsigned long long* mw_ = mbh + ((size_t)min(qb0 + u, nt - 1) * nt + min(2 * kq_ + hf, nt - 1)) * 4;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mwB[par][u][hf][r] = mw_[r];
+        }
+    };
+    if (kPreB) mask_words_B(0, 0);
     // dQ^T[d][q] = sum_key K[key][d] dS[q][key], streamed over 32-key steps
     f32x4 dq[KBQ][Cf::NT];
 #pragma unroll
@@ -593,6 +723,7 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
       for (int n = 0; n < Cf::NT; ++n) dq[u][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll(NKC ? NKC : 1)
     for (int kq = 0; kq < nk; ++kq) {
+      if (kPreB && kq + 1 < nk) mask_words_B(kq + 1, (kq + 1) & 1);
       f32x4 scB[KBQ][2], dpB[KBQ][2];
 #pragma unroll
       for (int u = 0; u < KBQ; ++u)
@@ -645,7 +776,7 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
               float kfac;
               if (MASK) {
                 // this lane's own bit of the forward ballot: the 64-bit word IS the select mask
-                asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(kfac) : "v"(inv_keep), "s"(mw[r]));
+                asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(kfac) : "v"(inv_keep), "s"(kPreB ? mwB[kq & 1][u][hf][r] : mw[r]));
               } else {
                 kfac = m3p_keep(rbase[u] + (uint32_t)min(key, S - 1), seed, thresh24) ? inv_keep : 0.f;
               }
@@ -667,6 +798,9 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
       }
       if (NKC) __builtin_amdgcn_sched_barrier(0);
     }
+#ifdef M3P_ATTN_TL
+    tw = __builtin_amdgcn_s_memtime();
+#endif
 #pragma unroll
     for (int u = 0; u < KBQ; ++u) {
       if (q[u] < S) {
@@ -687,7 +821,9 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
         }
       }
     }
+    BTL_SUM(11, tw);
   }
+  BTL(6);
 
   // ---- bias gradients: column sums of the bf16 dQ / dV rows this block wrote (k: zero, see above)
   if (dbias_qkv) {
@@ -703,6 +839,11 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
       }
     }
   }
+#ifdef M3P_ATTN_TL
+  BTL(7);
+  if (lane == 0 && blockIdx.x < 4096 && wid < 4)
+    for (int i = 0; i < 16; ++i) g_attn_tl[(blockIdx.x * 4 + wid) * 16 + i] = tl[i];
+#endif
 }
 
 #undef PAD_TILE

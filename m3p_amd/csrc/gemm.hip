@@ -786,6 +786,13 @@ void gemm_nt_ring_kernel(const bf16* __restrict__ A, int lda, const bf16* __rest
 // k-step 1.  The epilogue stages through the vacated stage (the request for K-tile +2 waits for it on an output tile's
 // last K-tile).  128 accumulator + 96 fragment registers per lane: the compiler's allocation (no literal AGPR numbers).
 // ---------------------------------------------------------------------------------
+template <class T>
+__device__ __forceinline__ const T* uniform_ptr(const T* p) {      // a wave-uniform pointer the compiler may not know to be one
+  const uint64_t v = reinterpret_cast<uint64_t>(p);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return reinterpret_cast<const T*>(((uint64_t)hi << 32) | lo);
+}
+
 template <int EPI, bool DYN = false>
 __global__ __launch_bounds__(512)
 void gemm_nt_w8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ W, int ldw,
@@ -847,15 +854,51 @@ void gemm_nt_w8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
   const size_t a_step = (size_t)64 * lda, w_step = (size_t)64 * ldw;
   int l_kt = 0, l_q = 0;
   bool l_alive = true;      // (dynamic) the load cursor points at a K-tile of this workgroup's stream
+#ifndef M3P_W8_IMM
+#define M3P_W8_IMM 1
+#endif
+#ifndef M3P_W8_SADDR
+#define M3P_W8_SADDR 1
+#endif
+  // M3P_W8_IMM: a wave stages 32 CONSECUTIVE rows of each operand (pieces 1 KB apart in LDS) and the four pieces of an operand
+  // share one M0: the destination is picked by the instruction's immediate offset (-2048 .. +1024), which moves the global
+  // source by the same bytes - compensated in the source pointer (tools/probe_dma_offset.py; the four-wave kernels do the
+  // same).  Per LDS-DMA that saves the M0 write and its hazard nop (probe_issue.py: ~32 of the ~70 ticks a piece costs).
   auto set_load_tile = [&](int t) {
     int tm, tn;
     split_tile(t, tm, tn);
-    a_src = A + (size_t)(tm * BM + wid * 8 + sr) * lda + sc * 8;
-    w_src = W + (size_t)(tn * BN + wid * 8 + sr) * ldw + sc * 8;
+    if (M3P_W8_IMM) {       // (uniform: the lane's part is a_lane / w_lane)
+      a_src = A + (size_t)(tm * BM + wid * 32) * lda;
+      w_src = W + (size_t)(tn * BN + wid * 32) * ldw;
+    } else {
+      a_src = A + (size_t)(tm * BM + wid * 8 + sr) * lda + sc * 8;
+      w_src = W + (size_t)(tn * BN + wid * 8 + sr) * ldw + sc * 8;
+    }
   };
+  const size_t a_step8 = (size_t)8 * lda, w_step8 = (size_t)8 * ldw;
+  // scalar base + 32-bit lane offset: the address form the LDS-DMA takes without any per-piece vector arithmetic
+  const uint32_t a_lane = (uint32_t)(sr * lda + sc * 8) * 2u, w_lane = (uint32_t)(sr * ldw + sc * 8) * 2u;
   auto issue_load = [&](int s, int piece) {
     char* sa = smem + s * STAGE;
     const int k0 = l_kt * BK;
+    if (M3P_W8_IMM) {
+      const int pc = piece & 3;
+      char* base = sa + (piece < 4 ? 0 : A_BYTES) + wid * 4096 + 2048;
+      // (source compensated by the immediate: (pc - 2) * 1024 bytes = (pc - 2) * 512 elements)
+      // (uniform_ptr keeps the sum scalar: otherwise the lane offset is folded in first, loop-invariantly, and every piece pays
+      //  a 64-bit vector add again)
+      const bf16* row = uniform_ptr((piece < 4 ? a_src + pc * a_step8 : w_src + pc * w_step8) + k0 - (pc - 2) * 512);
+      uint32_t lane_off = piece < 4 ? a_lane : w_lane;
+      if (M3P_W8_SADDR) asm volatile("" : "+v"(lane_off));      // (the zero-extension has to sit beside the DMA for the scalar-base form to be selected)
+      const char* src = reinterpret_cast<const char*>(row) + lane_off;
+      switch (pc) {
+        case 0: __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(base), 16, -2048, 0); break;
+        case 1: __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(base), 16, -1024, 0); break;
+        case 2: __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(base), 16, 0, 0); break;
+        default: __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(base), 16, 1024, 0); break;
+      }
+      return;
+    }
     if (piece < 4)
       __builtin_amdgcn_global_load_lds(GLB_PTR(a_src + piece * a_step + k0), LDS_PTR(sa + (wid + piece * NWAVES) * 1024), 16, 0, 0);
     else
