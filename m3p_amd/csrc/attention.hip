@@ -39,6 +39,12 @@ __device__ unsigned long long g_attn_tl[4096 * 4 * 16];
 #define BTL_SUM(i, t0) do { } while (0)
 #endif
 
+#ifndef M3P_ATTN_BWD_NEXTFRAG
+#define M3P_ATTN_BWD_NEXTFRAG 1
+#endif
+#ifndef M3P_ATTN_BWD_TRPRE
+#define M3P_ATTN_BWD_TRPRE 0
+#endif
 #ifndef M3P_ATTN_BWD_KB
 #define M3P_ATTN_BWD_KB 1
 #endif
@@ -76,6 +82,18 @@ __device__ __forceinline__ float row16_sum(float v) {
   M3P_DPP_ADD(0x128);     // row_ror:8
 #undef M3P_DPP_ADD
   return v;
+}
+// bit r (0..3) of `bits` as an all-ones / all-zeros word.  (asm: written as sbfe the compiler turns `value & mask` into a bit
+// test, a compare and a select - three instructions for two.)
+__device__ __forceinline__ uint32_t bit_to_mask(uint32_t bits, int r) {
+  uint32_t o;
+  switch (r) {
+    case 0: asm("v_bfe_i32 %0, %1, 0, 1" : "=v"(o) : "v"(bits)); break;
+    case 1: asm("v_bfe_i32 %0, %1, 1, 1" : "=v"(o) : "v"(bits)); break;
+    case 2: asm("v_bfe_i32 %0, %1, 2, 1" : "=v"(o) : "v"(bits)); break;
+    default: asm("v_bfe_i32 %0, %1, 3, 1" : "=v"(o) : "v"(bits)); break;
+  }
+  return o;
 }
 // sum over groups of CH (4 or 8) consecutive lanes, result in every lane of the group
 template <int CH>
@@ -375,28 +393,28 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
   const int fq = lane & 15, fg = lane >> 4;
   float* sB = sD + nk * 32;           // [NW waves][3][DH] bias-gradient accumulators (q | k | v), one slot per wave
   float* sBw = sB + wid * 3 * DH;
-  // bias gradients = column sums of the bf16 dQ/dK/dV rows this block writes.  Each lane keeps
-  // running sums of ITS rows in registers (part x d-tile x 4 columns); the reduction over the
-  // 16 lanes (fq) that hold different rows of the same columns happens once per wave at the
-  // end of the kernel (doing the shuffles + LDS update per 16-row block cost 93 of 386 us).
-  // The k-bias gradient is identically zero (softmax is invariant to a per-query shift of the
-  // scores, so sum_key dS[q][key] = 0): it is written as exact 0 instead of the rounding
-  // noise a column sum of bf16 dK rows would give.
+  // bias gradients = column sums of the bf16 dQ/dK/dV rows this block writes.  Each lane keeps running sums of ITS rows in
+  // registers (part x d-tile x 4 columns); the reduction over the 16 lanes (fq) that hold different rows of the same columns
+  // happens once per phase - four DPP adds per value - into the wave's LDS slot, and the slots are summed at the end of the
+  // kernel.  (Per owned block instead - 16 registers fewer - the DPP chains and the LDS read-modify-write cost 2.6 k ticks a
+  // block, r03 timeline; with ds_bpermute shuffles it was 93 of 386 us once.)  The k-bias gradient is identically zero
+  // (softmax is invariant to a per-query shift of the scores, so sum_key dS[q][key] = 0): it is written as exact 0 instead of
+  // the rounding noise a column sum of bf16 dK rows would give.
   f32x4 bsum[Cf::NT];       // phase A: v-bias sums, flushed to LDS, then reused for q in phase B
 #pragma unroll
   for (int n = 0; n < Cf::NT; ++n) bsum[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-  auto bias_acc = [&](int n, const bf16x4& v4) {
+  auto bias_acc = [&](int, int n, const bf16x4& v4) {
     bsum[n] += f32x4{(float)v4[0], (float)v4[1], (float)v4[2], (float)v4[3]};
   };
   auto bias_flush = [&](int part) {
 #pragma unroll
-    for (int n = 0; n < Cf::NT; ++n)
+    for (int n = 0; n < Cf::NT; ++n) {
+      f32x4 x = bsum[n];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float sfl = row16_sum(bsum[n][r]);
-        if (fq == 0) sBw[part * DH + 16 * n + 4 * fg + r] = sfl;
-        bsum[n][r] = 0.f;
-      }
+      for (int r = 0; r < 4; ++r) x[r] = row16_sum(x[r]);
+      if (fq == 0) *reinterpret_cast<f32x4*>(sBw + part * DH + 16 * n + 4 * fg) = x;
+      bsum[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
   };
 
   int r_off[Cf::KK];   // row-major fragment (row 16t + fq, chunk 4kk + fg)
@@ -414,7 +432,6 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
 #define PAD_TILE(t) (NTC ? (t) >= NTC : (M3P_ATTN_SKIP_PAD && !MASK && (t) >= nt))
   constexpr float kLog2e = 1.4426950408889634f;
   constexpr float kMasked = -1.0e30f;    // score of a masked key: exp2 of it is exactly 0
-  const uint32_t inv_keep_bits = __builtin_bit_cast(uint32_t, inv_keep);
 #ifdef M3P_ATTN_TL
   unsigned long long tl[16];
   for (int i = 0; i < 16; ++i) tl[i] = 0;
@@ -448,11 +465,24 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
       vf[u][kk] = *reinterpret_cast<const bf16x8*>(Vg + (size_t)keyc * ld + 32 * kk + 8 * fg);
     }
   };
+  // (not with dropout re-hashed instead of read from the forward's keep bits: that variant has no registers to spare)
+  constexpr bool kNextFrag = M3P_ATTN_BWD_NEXTFRAG && !(DROP && !MASK);
+  bf16x8 kfn[KB][Cf::KK], vfn[KB][Cf::KK];     // the next owned block's, in flight while this one is computed
+  auto load_kv_next = [&](int u, int kb) {
+    const int keyc = min(kb * 16 + fq, S - 1);
+#pragma unroll
+    for (int kk = 0; kk < Cf::KK; ++kk) {
+      kfn[u][kk] = *reinterpret_cast<const bf16x8*>(Kg + (size_t)keyc * ld + 32 * kk + 8 * fg);
+      vfn[u][kk] = *reinterpret_cast<const bf16x8*>(Vg + (size_t)keyc * ld + 32 * kk + 8 * fg);
+    }
+  };
   if (wrot * KB < nt) {
 #pragma unroll
     for (int u = 0; u < KB; ++u) load_kv(u, wrot * KB + u);
   }
   // ---- prologue: D[q] = rowsum(dO * O), lse -> LDS (padded rows: D = 0, lse = +inf so P = 0)
+  const float log2_inv_keep = DROP ? __builtin_amdgcn_logf(inv_keep) : 0.f;     // (v_log_f32 is log2)
+  const float keep_prob = DROP ? __builtin_amdgcn_rcpf(inv_keep) : 1.f;
   for (int q = tid; q < nk * 32; q += NW * 64) {
     float dsum = 0.f, l = INFINITY;
     if (q < S) {
@@ -467,9 +497,11 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
           for (int e = 0; e < 8; ++e) dsum += (float)ov[e] * (float)dv[e];
         }
       }
-      l = lse_bh[q] * kLog2e;          // probabilities are rebuilt as exp2(S log2e - lse log2e): fma + v_exp
+      // probabilities are rebuilt as exp2(S log2e - lse log2e): fma + v_exp.  With dropout the rebuilt value is p / keep
+      // (log2(1 / keep) folded into the stored lse) and D is stored as D * keep: Pd = (p / keep) [kept], dS = Pd dPd - (p / keep) (D keep)
+      l = lse_bh[q] * kLog2e - log2_inv_keep;
     }
-    if (!kDfromLds) sD[q] = dsum;
+    if (!kDfromLds) sD[q] = dsum * keep_prob;
     sL[q] = l;
   }
   if (kDfromLds) {
@@ -485,7 +517,7 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
         for (int e = 0; e < 8; ++e) part += (float)orow[j][e] * (float)dv[e];
         part = chunks_sum<Cf::CH>(part);
         const int row = i * Cf::RPI + rin;
-        if (c == 0) sD[row] = row < S ? part : 0.f;
+        if (c == 0) sD[row] = row < S ? part * keep_prob : 0.f;
       }
     }
   }
@@ -518,7 +550,15 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
       key[u] = (kb0 + u) * 16 + fq;            // this lane's key column
       keyc[u] = min(key[u], S - 1);
       kbias[u] = (key[u] < klen) ? 0.f : kMasked;
-      if (kb0 != wrot * KB) load_kv(u, kb0 + u);
+      if (kNextFrag) {
+        if (kb0 != wrot * KB) {
+#pragma unroll
+          for (int kk = 0; kk < Cf::KK; ++kk) { kf[u][kk] = kfn[u][kk]; vf[u][kk] = vfn[u][kk]; }
+        }
+        if (kb0 + NW * KB < nt) load_kv_next(u, kb0 + NW * KB + u);
+      } else if (kb0 != wrot * KB) {
+        load_kv(u, kb0 + u);
+      }
     }
 #ifdef M3P_ATTN_TL
     tw = __builtin_amdgcn_s_memtime();
@@ -537,6 +577,13 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
     for (int kq = 0; kq < nk; ++kq) {
       // the MFMA chains of a step (scores and dPd of both 16-query tiles, of every owned block) are issued interleaved,
       // k-step outermost, so that no MFMA waits on the one just issued
+#ifdef M3P_ATTN_TL
+      __builtin_amdgcn_sched_barrier(0);
+      unsigned long long ts0 = __builtin_amdgcn_s_memtime(), ts1;
+#define STEP_SEG(i) do { __builtin_amdgcn_sched_barrier(0); ts1 = __builtin_amdgcn_s_memtime(); tl[i] += ts1 - ts0; ts0 = ts1; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define STEP_SEG(i) do { } while (0)
+#endif
       f32x4 scA[KB][2], dpA[KB][2], dnegA[2];
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
@@ -566,6 +613,20 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
           }
         }
       }
+      STEP_SEG(12);      // 12: fragments read, score / dPd MFMAs issued
+      // the transposed Q / dO fragments of the first d-tiles are requested before the softmax arithmetic instead of behind it
+      constexpr int kTrPre = M3P_ATTN_BWD_TRPRE;
+      bf16x8 qTp[kTrPre ? kTrPre : 1], dTp[kTrPre ? kTrPre : 1];
+      if (kTrPre) {
+#pragma unroll
+        for (int n = 0; n < kTrPre; ++n) {
+          const char* pq = s0 + kq * 32 * Cf::ROWB + t_off[n];
+          const char* pdo = s1 + kq * 32 * Cf::ROWB + t_off[n];
+          qTp[n] = cat8(lds_tr16(pq), lds_tr16(pq + 16 * Cf::ROWB));
+          dTp[n] = cat8(lds_tr16(pdo), lds_tr16(pdo + 16 * Cf::ROWB));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
       bf16x8 pfrag[KB], sfrag[KB];
 #pragma unroll
       for (int u = 0; u < KB; ++u) {
@@ -589,16 +650,16 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
           for (int r = 0; r < 4; ++r) {
             const int q = 16 * t + 4 * fg + r;
             const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[r], kLog2e, -sL[q]));   // padded q: lse = +inf -> 0
-            if (DROP) {
-              float kfac;      // inv_keep if kept, else 0
+            if (DROP) {      // p = P / keep here, dneg = -D keep
+              float pd;
               if (MASK) {
-                kfac = __builtin_bit_cast(float, (uint32_t)__builtin_amdgcn_sbfe(kbits, r, 1) & inv_keep_bits);
+                pd = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, p) & bit_to_mask(kbits, r));
               } else {
                 const uint32_t idx = (uint32_t)((b * H + h) * S + min(q, S - 1)) * (uint32_t)S + (uint32_t)keyc[u];
-                kfac = m3p_keep(idx, seed, thresh24) ? inv_keep : 0.f;
+                pd = m3p_keep(idx, seed, thresh24) ? p : 0.f;
               }
-              pd2[hf][r] = p * kfac;
-              ds2[hf][r] = p * __builtin_fmaf(dp[r], kfac, dneg[r]);
+              pd2[hf][r] = pd;
+              ds2[hf][r] = __builtin_fmaf(pd, dp[r], p * dneg[r]);
             } else {
               pd2[hf][r] = p;
               ds2[hf][r] = p * dp[r];
@@ -610,6 +671,7 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
         sfrag[u] = bf16x8{(bf16)ds2[0][0], (bf16)ds2[0][1], (bf16)ds2[0][2], (bf16)ds2[0][3],
                           (bf16)ds2[1][0], (bf16)ds2[1][1], (bf16)ds2[1][2], (bf16)ds2[1][3]};
       }
+      STEP_SEG(13);      // 13: P / dS built (waits for the MFMA results, the keep words, lse / D)
       if (kPreA) {      // (behind the last step of a block: the first steps of the next owned block, clamped on the last one)
         if (kq + 2 < nk) mask_words_A(kb0, kq + 2, kq & 1);
         else mask_words_A(kb0 + NW * KB, kq + 2 - nk, kq & 1);
@@ -618,14 +680,15 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
       for (int n = 0; n < Cf::NT; ++n) {
         const char* pq = s0 + kq * 32 * Cf::ROWB + t_off[n];
         const char* pdo = s1 + kq * 32 * Cf::ROWB + t_off[n];
-        const bf16x8 qT = cat8(lds_tr16(pq), lds_tr16(pq + 16 * Cf::ROWB));
-        const bf16x8 dT = cat8(lds_tr16(pdo), lds_tr16(pdo + 16 * Cf::ROWB));
+        const bf16x8 qT = (n < kTrPre) ? qTp[n < kTrPre ? n : 0] : cat8(lds_tr16(pq), lds_tr16(pq + 16 * Cf::ROWB));
+        const bf16x8 dT = (n < kTrPre) ? dTp[n < kTrPre ? n : 0] : cat8(lds_tr16(pdo), lds_tr16(pdo + 16 * Cf::ROWB));
 #pragma unroll
         for (int u = 0; u < KB; ++u) {
           dv[u][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dT, pfrag[u], dv[u][n], 0, 0, 0);
           dk[u][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qT, sfrag[u], dk[u][n], 0, 0, 0);
         }
       }
+      STEP_SEG(14);      // 14: transposed fragments read, dV / dK MFMAs issued
       if (NKC) __builtin_amdgcn_sched_barrier(0);   // unrolled steps stay in order: no register blow-up from hoisted loads
     }
 #ifdef M3P_ATTN_TL
@@ -648,7 +711,7 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
 #pragma unroll
         for (int n = 0; n < Cf::NT; ++n) {
           const bool ok = key[u] < S;
-          bias_acc(n, ok ? bf16x4{(bf16)dv[u][n][0], (bf16)dv[u][n][1], (bf16)dv[u][n][2], (bf16)dv[u][n][3]} : bf16x4{0, 0, 0, 0});
+          bias_acc(2, n, ok ? bf16x4{(bf16)dv[u][n][0], (bf16)dv[u][n][1], (bf16)dv[u][n][2], (bf16)dv[u][n][3]} : bf16x4{0, 0, 0, 0});
         }
       }
     }
@@ -671,6 +734,15 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
       df[u][kk] = *reinterpret_cast<const bf16x8*>(dOg + (size_t)qc * dmodel + 32 * kk + 8 * fg);
     }
   };
+  bf16x8 qfn[KBQ][Cf::KK], dfn[KBQ][Cf::KK];
+  auto load_qd_next = [&](int u, int qb) {
+    const int qc = min(qb * 16 + fq, S - 1);
+#pragma unroll
+    for (int kk = 0; kk < Cf::KK; ++kk) {
+      qfn[u][kk] = *reinterpret_cast<const bf16x8*>(Qg + (size_t)qc * ld + 32 * kk + 8 * fg);
+      dfn[u][kk] = *reinterpret_cast<const bf16x8*>(dOg + (size_t)qc * dmodel + 32 * kk + 8 * fg);
+    }
+  };
   if (wrot * KBQ < nt) {
 #pragma unroll
     for (int u = 0; u < KBQ; ++u) load_qd(u, wrot * KBQ + u);
@@ -686,7 +758,15 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
     for (int u = 0; u < KBQ; ++u) {
       q[u] = (qb0 + u) * 16 + fq;
       qc[u] = min(q[u], S - 1);
-      if (qb0 != wrot * KBQ) load_qd(u, qb0 + u);
+      if (kNextFrag) {
+        if (qb0 != wrot * KBQ) {
+#pragma unroll
+          for (int kk = 0; kk < Cf::KK; ++kk) { qf[u][kk] = qfn[u][kk]; df[u][kk] = dfn[u][kk]; }
+        }
+        if (qb0 + NW * KBQ < nt) load_qd_next(u, qb0 + NW * KBQ + u);
+      } else if (qb0 != wrot * KBQ) {
+        load_qd(u, qb0 + u);
+      }
       const bool in = q[u] < nk * 32;
       lq[u] = in ? sL[min(q[u], nk * 32 - 1)] : INFINITY;
       dq_[u] = in ? sD[min(q[u], nk * 32 - 1)] : 0.f;
@@ -773,12 +853,12 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
             const int key = 16 * t + 4 * fg + r;
             const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[r], kLog2e, -lq[u]));
             if (DROP) {
-              float kfac;
+              float kfac;      // 1 if kept, else 0 (p = P / keep here, dq_ = D keep)
               if (MASK) {
                 // this lane's own bit of the forward ballot: the 64-bit word IS the select mask
-                asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(kfac) : "v"(inv_keep), "s"(kPreB ? mwB[kq & 1][u][hf][r] : mw[r]));
+                asm("v_cndmask_b32_e64 %0, 0, 1.0, %1" : "=v"(kfac) : "s"(kPreB ? mwB[kq & 1][u][hf][r] : mw[r]));
               } else {
-                kfac = m3p_keep(rbase[u] + (uint32_t)min(key, S - 1), seed, thresh24) ? inv_keep : 0.f;
+                kfac = m3p_keep(rbase[u] + (uint32_t)min(key, S - 1), seed, thresh24) ? 1.f : 0.f;
               }
               ds2[hf][r] = p * __builtin_fmaf(dp[r], kfac, -dq_[u]);
             } else {
@@ -816,7 +896,7 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
 #pragma unroll
         for (int n = 0; n < Cf::NT; ++n) {
           const bool ok = q[u] < S;
-          bias_acc(n, ok ? bf16x4{(bf16)(dq[u][n][0] * qscale), (bf16)(dq[u][n][1] * qscale), (bf16)(dq[u][n][2] * qscale),
+          bias_acc(0, n, ok ? bf16x4{(bf16)(dq[u][n][0] * qscale), (bf16)(dq[u][n][1] * qscale), (bf16)(dq[u][n][2] * qscale),
                                      (bf16)(dq[u][n][3] * qscale)} : bf16x4{0, 0, 0, 0});
         }
       }

@@ -42,6 +42,9 @@ print('  wave total                 %8.0f' % tot.mean())
 for k, nm in ((8, 'A: wait for owned K / V rows'), (9, 'B: wait for owned Q / dO rows'), (10, 'A: output stores'), (11, 'B: output stores')):
     x = t[:, :, k].ravel()
     print('  of which %-28s %8.0f  (%4.1f %%)' % (nm, x.mean(), 100 * x.mean() / tot.mean()))
+for k, nm in ((12, 'A step: row fragments + score / dPd MFMAs issued'), (13, 'A step: P / dS arithmetic (incl. waiting for the MFMAs, keep words)'), (14, 'A step: transposed fragments + dV / dK MFMAs issued')):
+    x = t[:, :, k].ravel()
+    print('  phase A steps, %-70s %8.0f  (%4.1f %% of phase A)' % (nm, x.mean(), 100 * x.mean() / d[..., 2].mean()))
 # workgroup residency against the launch: 3072 workgroups, 768 resident at a time if three fit a CU
 span = t[:, :, 7].max() - t[:, :, 0].min()
 life = t[:, :, 7].max(1) - t[:, :, 0].min(1)
