@@ -31,7 +31,7 @@ for k, spec in enumerate(sys.argv[1:]):
     arms.append((spec, fn))
 
 SHAPES = [('QKV fwd', 2304, 768, 1), ('FFN1 fwd', 3072, 768, 1), ('out_lin fwd', 768, 768, 3), ('FFN2 fwd', 768, 3072, 3),
-          ('dx1', 768, 3072, 4), ('dh', 768, 2304, 4), ('dctx', 768, 768, 0), ('dU dgelu', 3072, 768, 5)]
+          ('dx1', 768, 3072, 4), ('dh', 768, 2304, 4), ('dctx', 768, 768, 0), ('dU dgelu', 3072, 768, 5), ('dU mul', 3072, 768, 6)]
 M = int(os.environ.get('AB_M', '41984'))
 st = torch.cuda.current_stream().cuda_stream
 print('%-14s' % 'shape' + ''.join('%22s' % a[0] for a in arms))
@@ -46,7 +46,7 @@ for name, N, K, epi in SHAPES:
     ep = L.Epilogue()
     ep.bias = bias.data_ptr() if epi in (1, 2, 3) else None
     ep.aux = aux.data_ptr() if epi in (3, 4, 5, 6) else None
-    ep.colsum = cs.data_ptr() if epi == 5 else None
+    ep.colsum = cs.data_ptr() if epi in (5, 6) else None
     ep.ld_aux = N
     ep.alpha = 1.0
     ep.seed = 3
