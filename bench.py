@@ -39,14 +39,14 @@ def flops_train_per_seq(d, L, T, R, V, n_pred):
     return 6.0 * macs
 
 
-def build(cfg, dropout, world, rank, local_rank, refine_layers=0, ragged=False, fp8=False, lr='0.0001'):
+def build(cfg, dropout, world, rank, local_rank, refine_layers=0, ragged=False, fp8=False, lr='0.0001', wrapped=None):
     from m3p_amd import synth
     from m3p_amd.model.transformer import TransformerModel
     from m3p_amd.trainer import XTrainer
     P = synth.model_params(cfg['emb_dim'], cfg['n_heads'], cfg['n_layers'], cfg['n_words'], dropout=dropout,
                            attention_dropout=dropout, refine_layers=refine_layers)
     for k, v in dict(optimizer='adam_inverse_sqrt,beta1=0.9,beta2=0.98,lr=%s' % lr, clip_grad_norm=5, amp=1, fp16=True,
-                     accumulate_gradients=1, multi_gpu=world > 1, local_rank=local_rank, epoch_size=100000,
+                     accumulate_gradients=1, multi_gpu=(world > 1) if wrapped is None else wrapped, local_rank=local_rank, epoch_size=100000,
                      cross_mlm_steps=[('google', 'img')], cross_mrm_steps=[], cross_mrfr_steps=[], cross_clcm_steps=[],
                      sample_n=2, refine_image=refine_layers > 0, multi_cls_loss_weight=0, bin_cls_loss_weight=1,
                      batch_size=cfg['B'], dump_path='/nonexistent_m3p_dump', fp8_gemm=fp8).items():
@@ -197,12 +197,16 @@ def main():
     assert world == args.gpus, 'WORLD_SIZE=%d but --gpus %d' % (world, args.gpus)
     if world > 1:
         assert dist.get_world_size() == world
+    # M3P_DP_FORCE=1 under torchrun --nproc-per-node 1 (development): the one rank is wrapped and runs its collectives over
+    # RCCL, so the N > 1 code of this file executes on a one-GPU box; the line says so in "parallelism"
+    forced = world == 1 and dist.is_initialized()
+    multi = world > 1 or forced
     torch.cuda.set_device(local_rank)
     cfg = dict(synth.CONFIGS[args.config])
     if args.batch is not None:
         cfg['B'] = args.batch
-    trainer, tup = build(cfg, args.dropout, world, rank, local_rank, args.refine_layers, args.ragged, args.fp8)
-    dp = trainer.model if world > 1 else None
+    trainer, tup = build(cfg, args.dropout, world, rank, local_rank, args.refine_layers, args.ragged, args.fp8, wrapped=multi)
+    dp = trainer.model if multi else None
     if dp is not None:
         dp.uniform_tokens = not args.ragged      # every rank's batch has the same token-row count: no count exchange at all
 
@@ -225,7 +229,7 @@ def main():
         cur = timed_group()
         groups += 1
         stable = abs(cur - prev) <= 0.02 * prev
-        if world > 1:      # ranks must leave the loop together
+        if multi:      # ranks must leave the loop together
             flag = torch.tensor([1.0 if stable else 0.0], device='cuda')
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             stable = bool(flag.item())
@@ -251,7 +255,7 @@ def main():
     ops.PROFILE_ONLY = max(warm_agg.items(), key=lambda kv: kv[1])[0] if warm_agg else None
     if dp is not None:
         dp.exposed_events = []
-    if world > 1:
+    if multi:
         dist.barrier()
         torch.cuda.synchronize()
     ops.PROFILE = {}
@@ -259,13 +263,13 @@ def main():
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
         torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     prof, ops.PROFILE = ops.PROFILE, None
     comm = None
-    if world > 1:
+    if multi:
         t = torch.tensor([dt], device='cuda', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -287,7 +291,6 @@ def main():
             else:
                 name = 'layer' if isinstance(label, tuple) else str(label)
             ms = a.elapsed_time(b)
-            factor = (2.0 if kind == 'allreduce' else 1.0) * (world - 1) / world
             ent = fam.setdefault('%s (%s)' % (name, kind), [0, 0.0, 0.0])
             ent[0] += 1; ent[1] += nbytes; ent[2] += ms
         dp.reducer.timings = None
@@ -355,12 +358,14 @@ def main():
             out['comm'] = comm
         if shared:
             out['data'] = 'synthetic; DRY RUN: %d ranks sharing one GPU over gloo - not a measurement' % world
+        if forced:
+            out['config']['parallelism'] = 'dp1 wrapped (M3P_DP_FORCE: one rank running its collectives over RCCL; development run)'
         if world == 1 and not args.no_cpu_baseline:
             del trainer
             torch.cuda.empty_cache()
             out['cpu_baseline'] = cpu_baseline(cfg, args.dropout)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

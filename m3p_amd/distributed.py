@@ -68,7 +68,8 @@ def init_distributed_mode(params=None, backend=None):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1 and not dist.is_initialized():
+    forced = os.environ.get('M3P_DP_FORCE') == '1' and 'MASTER_ADDR' in os.environ     # (tests: a one-rank world that still runs its collectives)
+    if (world > 1 or forced) and not dist.is_initialized():
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
         if backend == 'nccl':
@@ -132,6 +133,8 @@ class BucketReducer:
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
+        # a world of one rank runs no collective - unless M3P_DP_FORCE=1 (tests: the RCCL branches on a one-GPU box)
+        self.single = self.world == 1 and not (dist.is_initialized() and os.environ.get('M3P_DP_FORCE') == '1')
         if use_side_stream is None:
             use_side_stream = flat_grad.is_cuda
         self.stream = torch.cuda.Stream() if use_side_stream else None
@@ -159,7 +162,7 @@ class BucketReducer:
             return work
 
     def reduce_range(self, start, end, label=None):
-        if self.world == 1 or not self.enabled or end <= start:
+        if self.single or not self.enabled or end <= start:
             return
         buf = self.flat[start:end]
         nbytes = buf.numel() * buf.element_size()
@@ -169,7 +172,7 @@ class BucketReducer:
 
     def reduce_scatter_range(self, start, end, label=None):
         """In-place reduce-scatter of flat[start:end]: rank r's 1/world slice ends up reduced."""
-        if self.world == 1 or not self.enabled or end <= start:
+        if self.single or not self.enabled or end <= start:
             return
         assert (end - start) % self.world == 0
         buf = self.flat[start:end]
@@ -179,7 +182,7 @@ class BucketReducer:
         self.bytes_reduced += nbytes
 
     def all_gather(self, out, inp, label=None):
-        if self.world == 1:
+        if self.single:
             out.copy_(inp)
             return
         nbytes = out.numel() * out.element_size()
@@ -245,6 +248,7 @@ class DataParallel(torch.nn.Module):
         self.reducer = BucketReducer(arena.grad, process_group)
         self.pg = process_group
         self.world = self.reducer.world
+        self.single = self.reducer.single
         self.rank = self.reducer.rank
         self._arena = arena
         off = arena.offsets
@@ -258,7 +262,7 @@ class DataParallel(torch.nn.Module):
         assert mode in ('zero1', 'allreduce'), mode
         if mode == 'zero1' and any((e - s) % (64 * self.world) for s, e in self._ranges.values()):
             mode = 'allreduce'      # (a world size the 512-element bucket alignment does not divide into 64-aligned shards)
-        self.mode = mode if self.world > 1 else 'single'
+        self.mode = mode if not self.single else 'single'
         self.vocab_dense = True      # plan of the current step: does an MLM head feed the vocabulary matrix?
         self.uniform_tokens = False  # the trainer's promise that every rank's passes have the same token-row counts
         self._live = 0               # encoder passes that still owe a backward
@@ -271,14 +275,14 @@ class DataParallel(torch.nn.Module):
         self._param_events = {}      # zero1: bucket key -> event on the side stream (master gathered + bf16 cast done)
         self.exposed_events = None   # set to [] to record (start, end) events around finish()'s waits
         object.__setattr__(module, 'ddp_hook', self)    # plain attribute: as a registered submodule it would close a cycle
-        if self.world > 1 and arena.device.type == 'cuda' and os.environ.get('M3P_DP_TILE_QUEUE', '1') != '0':
+        if not self.single and arena.device.type == 'cuda' and os.environ.get('M3P_DP_TILE_QUEUE', '1') != '0':
             # the collectives' kernels share CUs with the persistent GEMMs: let slowed-down CUs take fewer tiles
             from . import ops
             ops.set_tile_queue(True)
-        if self.world > 1 and arena.device.type == 'cuda' and reserve_cus():
+        if not self.single and arena.device.type == 'cuda' and reserve_cus():
             from . import lib as L
             L.load().m3p_set_persistent_grid(L.num_cus() - reserve_cus())
-        if broadcast and self.world > 1:
+        if broadcast and not self.single:
             dist.broadcast(arena.master, src=0, group=process_group)
             for p in module.parameters():
                 if getattr(p, '_m3p_arena', None) is None:
@@ -295,7 +299,7 @@ class DataParallel(torch.nn.Module):
         self.vocab_dense = bool(vocab_dense)
 
     def _launch(self, key):
-        if self.world == 1 or not self.reducer.enabled or key in self._launched:
+        if self.single or not self.reducer.enabled or key in self._launched:
             return
         self._launched.add(key)
         if self.mode == 'zero1':
@@ -401,14 +405,14 @@ class DataParallel(torch.nn.Module):
     # ------------------------------------------------------------------ hooks (functional.py)
     @property
     def active(self):
-        return self.world > 1
+        return not self.single
 
     def encoder_forward(self, n_tokens):
         """An encoder pass that will be differentiated.  Returns the largest token-row count of this pass over the
         ranks (ragged batches: the rows are padded to it for the all-gather) - as a value still in flight on the side
         stream (``_Pending``), read in ``embed_done``."""
         self._live += 1
-        if self.world == 1 or self.uniform_tokens or n_tokens == 0:
+        if self.single or self.uniform_tokens or n_tokens == 0:
             return n_tokens
         return _Pending(self, n_tokens)
 
@@ -433,7 +437,7 @@ class DataParallel(torch.nn.Module):
             self._launch(('layer', i))
 
     def embed_done(self, last=True, ids=None, rows=None, n_max=None):
-        if ids is not None and self.world > 1:
+        if ids is not None and not self.single:
             self._tokens.append((ids, rows, n_max))
         if last:
             if self._live_streams == 0:      # else the image stream's backward still owes gradients inside this range
@@ -453,7 +457,7 @@ class DataParallel(torch.nn.Module):
             self._launch('embed')
 
     def _exchange_tokens(self):
-        if self.world == 1 or not self.reducer.enabled or not self._tokens or self._tokens_out is not None:
+        if self.single or not self.reducer.enabled or not self._tokens or self._tokens_out is not None:
             return
         dev = self._arena.device
         pad = int(self.module.pad_index)
@@ -495,7 +499,7 @@ class DataParallel(torch.nn.Module):
         """Called before clip/Adam (from both): launch whatever the step's plan still owes (a
         step that ran no encoder backward, an encoder pass whose backward never came), wait,
         and apply the gathered token rows.  Idempotent until ``step_done()``."""
-        if self.world == 1 or not self.reducer.enabled or self._finished:
+        if self.single or not self.reducer.enabled or self._finished:
             return
         if self.vocab_dense:
             self._launch('vocab')

@@ -137,7 +137,7 @@ class Trainer(object):
         actually runs depends on the rank's batch (any masked word / region?), and ranks must agree on the ranges
         the optimizer steps and zeroes."""
         model = getattr(self, 'model')
-        if isinstance(model, DataParallel) and model.world > 1:
+        if isinstance(model, DataParallel) and not model.single:
             model.plan_step(vocab_dense)
             arena = model.module.arena()
             for head in expect:

@@ -133,8 +133,8 @@ def _capture_grads(tr, m):
 N_STEPS = 2
 
 
-def _drive(scenario, world, rank):
-    tr, m = _build(scenario, world > 1)
+def _drive(scenario, world, rank, wrapped=None):
+    tr, m = _build(scenario, world > 1 if wrapped is None else wrapped)
     snaps = _capture_grads(tr, m)
     micro = 2 if scenario == 'accumulate' else 1
     tr.n_iter = 1 if micro == 2 else 0                        # so that micro-steps go (non-boundary, boundary)
@@ -151,10 +151,10 @@ def _drive(scenario, world, rank):
 def _worker(rank, world, port, q, scenario, backend, mode='zero1'):
     try:
         os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                          HSA_ENABLE_IPC_MODE_LEGACY='0', M3P_DP_MODE=mode)
+                          HSA_ENABLE_IPC_MODE_LEGACY='0', M3P_DP_MODE=mode, M3P_DP_FORCE='1' if world == 1 else '0')
         torch.cuda.set_device(rank if backend == 'nccl' else 0)
         dist.init_process_group(backend, rank=rank, world_size=world)
-        tr, m, snaps = _drive(scenario, world, rank)
+        tr, m, snaps = _drive(scenario, world, rank, wrapped=True)
         assert tr.model.mode == mode, (tr.model.mode, mode)
         pm = m.arena().master.clone()
         gathered = [torch.zeros_like(pm) for _ in range(world)]
@@ -215,6 +215,14 @@ def test_dp_four_ranks_ragged_token_counts():
 @pytest.mark.parametrize('scenario', ['pretrain', 'finetune'])
 def test_dp_all_reduce_mode(scenario):
     _check(scenario, 'gloo', mode='allreduce')
+
+
+@pytest.mark.parametrize('mode', ['zero1', 'allreduce'])
+def test_dp_one_rank_over_rccl(mode):
+    """The RCCL-only branches (in-place reduce_scatter_tensor / all_gather_into_tensor on the arena buckets, the side stream,
+    the tile queues data parallelism switches on) on the one device a test box has: a world of one rank, wrapped, must
+    reproduce the unwrapped step."""
+    _check('pretrain', 'nccl', world=1, mode=mode)
 
 
 @pytest.mark.parametrize('scenario', ['pretrain', 'clcm'])
