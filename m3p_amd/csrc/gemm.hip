@@ -2299,8 +2299,11 @@ int launch_nt(const bf16* A, int lda, const bf16* W, int ldw, bf16* C, int ldc, 
     const int ntiles = tiles_m * tiles_n;
     if (ntiles < grid) grid = (ntiles + 7) / 8 * 8;
     // dynamic tile queue (ep.tile_ctr: eight zeroed counters, one per XCD) only where a workgroup takes several tiles
+    // (not for the multiply epilogues: with the queue's bookkeeping on top of their aux pieces and column sums the instantiation
+    //  spills ~100 bytes per lane - 0.31 against 0.28 ms on the dGELU product, more than the queue returns on 12 launches a step)
+    constexpr bool kQueueOk = !(EPI == M3P_EPI_DGELU || EPI == M3P_EPI_MUL);
     int* ctr = nullptr;
-    if (g_tq_pool && ntiles > grid && K >= 8 * BK) {
+    if (kQueueOk && g_tq_pool && ntiles > grid && K >= 8 * BK) {
       if (g_tq_next == g_tq_slots) {       // ring used up: clear it behind everything this stream has launched so far
         hipError_t e = hipMemsetAsync(g_tq_pool, 0, (size_t)g_tq_slots * 8 * sizeof(int), st);
         if (e != hipSuccess) return (int)e;
@@ -2308,7 +2311,7 @@ int launch_nt(const bf16* A, int lda, const bf16* W, int ldw, bf16* C, int ldc, 
       }
       ctr = g_tq_pool + 8 * g_tq_next++;
     }
-    if (ctr) {
+    if constexpr (kQueueOk) if (ctr) {
       auto kern_d = gemm_nt_w8_kernel<EPI, true>;
       static bool attr_set8d = false;
       if (!attr_set8d) {
