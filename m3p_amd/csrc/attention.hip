@@ -466,7 +466,7 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
     }
   };
   // (not with dropout re-hashed instead of read from the forward's keep bits: that variant has no registers to spare)
-  constexpr bool kNextFrag = M3P_ATTN_BWD_NEXTFRAG && !(DROP && !MASK);
+  constexpr bool kNextFrag = M3P_ATTN_BWD_NEXTFRAG && NKC != 0 && NTC != 0 && !(DROP && !MASK);      // (nor the less specialised instantiations: they spill with 16 more)
   bf16x8 kfn[KB][Cf::KK], vfn[KB][Cf::KK];     // the next owned block's, in flight while this one is computed
   auto load_kv_next = [&](int u, int kb) {
     const int keyc = min(kb * 16 + fq, S - 1);

@@ -60,14 +60,23 @@ def test_eight_wave_gemm_fits_two_waves_per_simd(tmp_path):
     subprocess.run(cmd, check=True, capture_output=True, timeout=900)
     body = out.read_text()
     seen = 0
-    for m in re.finditer(r'^(_ZN\S*gemm_nt_w8_kernelILi(\d)E\S*):', body, re.M):
+    queued = 0
+    for m in re.finditer(r'^(_ZN\S*gemm_nt_w8_kernelILi(\d)ELb([01])E\S*):', body, re.M):
         k = body.index('; Kernel info:', body.index('.Lfunc_end', m.end()))
         info = dict(re.findall(r'; (\w+): (\d+)', body[k:k + 700]))
-        epi = int(m.group(2))
+        epi, dyn = int(m.group(2)), m.group(3) == '1'
         assert int(info['Occupancy']) >= 2 and int(info['NumVgprs']) <= 256, (m.group(1), info)
-        assert int(info['ScratchSize']) <= (0 if epi <= 4 else 32), (m.group(1), info['ScratchSize'])
-        seen += 1
-    assert seen == 7
+        if dyn:
+            # the tile-queue instantiations (data parallelism only) carry a dozen registers of bookkeeping: a few dwords of
+            # scratch at most, and none exists for the multiply epilogues (they spilled ~100 bytes: the launcher keeps those
+            # on the static schedule)
+            assert epi <= 4, m.group(1)
+            assert int(info['ScratchSize']) <= 32, (m.group(1), info['ScratchSize'])
+            queued += 1
+        else:
+            assert int(info['ScratchSize']) <= (0 if epi <= 4 else 32), (m.group(1), info['ScratchSize'])
+            seen += 1
+    assert seen == 7 and queued == 5, (seen, queued)
     for m in re.finditer(r'^(_ZN\S*gemm_nt_w8f8_kernel\S*):', body, re.M):
         k = body.index('; Kernel info:', body.index('.Lfunc_end', m.end()))
         info = dict(re.findall(r'; (\w+): (\d+)', body[k:k + 700]))
