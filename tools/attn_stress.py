@@ -19,9 +19,14 @@ for rnd in range(rounds):
         qkv = (torch.randn((B * S, 3 * d), device='cuda', generator=g) * 0.7).to(torch.bfloat16)
         dctx = torch.randn((B * S, d), device='cuda', generator=g).to(torch.bfloat16)
         keylen = torch.randint(max(S // 2, 1), S + 1, (B,), device='cuda', dtype=torch.int32, generator=g)
-        ctx, lse = ops.attn_fwd(qkv, keylen, B, S, H, dh, seed=seed, p_drop=p)
+        # (every other dropout round hands the backward the forward's keep-bit words - the training path - instead of the seed)
+        km = None
+        if p > 0 and rnd % 4 == 0:
+            ctx, lse, km = ops.attn_fwd(qkv, keylen, B, S, H, dh, seed=seed, p_drop=p, want_mask=True)
+        else:
+            ctx, lse = ops.attn_fwd(qkv, keylen, B, S, H, dh, seed=seed, p_drop=p)
         dbias = torch.zeros(3 * d, device='cuda')
-        dqkv = ops.attn_bwd(qkv, keylen, ctx, dctx, lse, B, S, H, dh, dbias_qkv=dbias, seed=seed, p_drop=p)
+        dqkv = ops.attn_bwd(qkv, keylen, ctx, dctx, lse, B, S, H, dh, dbias_qkv=dbias, seed=seed, p_drop=p, keepmask=km)
         x = qkv.float().requires_grad_(True)
         q, k, v = x.view(B, S, 3, H, dh).permute(2, 0, 3, 1, 4)
         sc = q @ k.transpose(2, 3)
