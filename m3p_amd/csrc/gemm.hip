@@ -245,6 +245,19 @@ template <bool SW>
 __device__ __forceinline__ int ep_off(int row, int bcol) {
   return SW ? row * 128 + ((((bcol >> 4) ^ (row & 7)) << 4) | (bcol & 15)) : row * EP_PITCH + bcol;
 }
+// The 8-byte accesses in the accumulator layout (lane = row fr of 16, four columns) put rows r and r + 8 of a 16-row block on
+// the same banks (the chunk swizzle only knows row & 7): a two-way conflict on every such instruction (r03 counters: LDS bank
+// conflicts in 5-9 % of the eight-wave kernel's cycles, all of them in the epilogue).  In the swizzled layout the 8-byte half
+// inside the 16-byte chunk is therefore flipped for rows with bit 3 set (ep_off8); the 16-byte row-layout side of the same
+// staging rows swaps the halves in registers (flip_halves - its rows are it * 8 + lane / 8, so bit 3 is a compile-time fact).
+template <bool SW>
+__device__ __forceinline__ int ep_off8(int row, int bcol) {
+  return ep_off<SW>(row, bcol) ^ (SW ? (row & 8) : 0);
+}
+template <class V4>
+__device__ __forceinline__ V4 flip_halves(const V4& t, bool flip) {
+  return flip ? V4{t[2], t[3], t[0], t[1]} : t;
+}
 
 // gelu_erf'(u) of a bf16 u is a function of 16 bits: the dGELU epilogue looks it up instead of
 // evaluating erf/exp (~20 exposed VALU instructions per element).  The table covers |u| in
@@ -316,13 +329,13 @@ __device__ __forceinline__ void load_aux_rows_finish(int lane, char* r1, const u
   if (!kAux) return;
   const int srow = lane >> 3, sch = lane & 7;
 #pragma unroll
-  for (int it = 0; it < 4; ++it) *reinterpret_cast<u32x4*>(r1 + ep_off<SW>(it * 8 + srow, sch * 16)) = t[it];
+  for (int it = 0; it < 4; ++it) *reinterpret_cast<u32x4*>(r1 + ep_off<SW>(it * 8 + srow, sch * 16)) = flip_halves(t[it], SW && (it & 1));
   const int fr = lane & 15, fg = lane >> 4;
 #pragma unroll
   for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      auxv[ii][j] = *reinterpret_cast<const bf16x4*>(r1 + ep_off<SW>(ii * 16 + fr, (j * 16 + fg * 4) * 2));
+      auxv[ii][j] = *reinterpret_cast<const bf16x4*>(r1 + ep_off8<SW>(ii * 16 + fr, (j * 16 + fg * 4) * 2));
 }
 template <int EPI, bool SW = false>
 __device__ __forceinline__ void load_aux_rows(const M3PEpilogue& ep, int mrow0, int nw, int lane, char* r1, bf16x4 (&auxv)[2][4]) {
@@ -358,7 +371,7 @@ __device__ __forceinline__ void epilogue_half(const M3PEpilogue& ep, bf16* __res
     for (int ii = 0; ii < 2; ++ii) {
       const int rl = ii * 16 + fr;                  // row inside the staged half
       const int mrow = mrow0 + rl;                  // global row
-      const int lo = ep_off<SW>(rl, (j * 16 + fg * 4) * 2);
+      const int lo = ep_off8<SW>(rl, (j * 16 + fg * 4) * 2);
       f32x4 v = rows[ii][j];
       if (EPI == M3P_EPI_NONE || EPI == M3P_EPI_BIAS || EPI == M3P_EPI_RES) v = v * mulc + bias4;
       else if (EPI != M3P_EPI_DGELU && EPI != M3P_EPI_MUL) v += bias4;      // (those two have no bias: 32 exposed adds per half)
@@ -398,19 +411,19 @@ __device__ __forceinline__ void epilogue_half(const M3PEpilogue& ep, bf16* __res
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
     const int row = it * 8 + srow;
-    *reinterpret_cast<uint4*>(Cp + (size_t)row * ldc) = *reinterpret_cast<const uint4*>(r1 + ep_off<SW>(row, sch * 16));
+    *reinterpret_cast<u32x4*>(Cp + (size_t)row * ldc) = flip_halves(*reinterpret_cast<const u32x4*>(r1 + ep_off<SW>(row, sch * 16)), SW && (it & 1));
   }
   if (EPI == M3P_EPI_BIAS_GELU) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int ii = 0; ii < 2; ++ii)
-        *reinterpret_cast<bf16x4*>(r1 + ep_off<SW>(ii * 16 + fr, (j * 16 + fg * 4) * 2)) = ukeep[ii][j];
+        *reinterpret_cast<bf16x4*>(r1 + ep_off8<SW>(ii * 16 + fr, (j * 16 + fg * 4) * 2)) = ukeep[ii][j];
     bf16* Up = reinterpret_cast<bf16*>(ep.out2) + (size_t)mrow0 * ep.ld_out2 + nw + sch * 8;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int row = it * 8 + srow;
-      *reinterpret_cast<uint4*>(Up + (size_t)row * ep.ld_out2) = *reinterpret_cast<const uint4*>(r1 + ep_off<SW>(row, sch * 16));
+      *reinterpret_cast<u32x4*>(Up + (size_t)row * ep.ld_out2) = flip_halves(*reinterpret_cast<const u32x4*>(r1 + ep_off<SW>(row, sch * 16)), SW && (it & 1));
     }
   }
 }
@@ -433,10 +446,10 @@ __device__ __forceinline__ void epilogue_piece16(const M3PEpilogue& ep, bf16* __
   const int srow = lane >> 3, sch = lane & 7;
   // aux rows -> accumulator layout through the staging rows
   *reinterpret_cast<u32x4*>(r1 + ep_off<true>(srow, sch * 16)) = t[0];
-  *reinterpret_cast<u32x4*>(r1 + ep_off<true>(8 + srow, sch * 16)) = t[1];
+  *reinterpret_cast<u32x4*>(r1 + ep_off<true>(8 + srow, sch * 16)) = flip_halves(t[1], true);
   bf16x4 auxv[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) auxv[j] = *reinterpret_cast<const bf16x4*>(r1 + ep_off<true>(fr, (j * 16 + fg * 4) * 2));
+  for (int j = 0; j < 4; ++j) auxv[j] = *reinterpret_cast<const bf16x4*>(r1 + ep_off8<true>(fr, (j * 16 + fg * 4) * 2));
   // the sixteen table reads of a piece are independent: all addresses first, all reads in flight together, one wait (left
   // inside the per-element expression the compiler chains address -> read -> wait -> multiply sixteen times: ~130 clocks each)
   float tv[4][4];
@@ -481,14 +494,14 @@ __device__ __forceinline__ void epilogue_piece16(const M3PEpilogue& ep, bf16* __
       v *= f32x4{(float)a[0], (float)a[1], (float)a[2], (float)a[3]};
     }
     const bf16x4 ob = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-    *reinterpret_cast<bf16x4*>(r1 + ep_off<true>(fr, (j * 16 + fg * 4) * 2)) = ob;
+    *reinterpret_cast<bf16x4*>(r1 + ep_off8<true>(fr, (j * 16 + fg * 4) * 2)) = ob;
     csum[j] += f32x4{(float)ob[0], (float)ob[1], (float)ob[2], (float)ob[3]};
   }
   bf16* Cp = C + (size_t)mrow0 * ldc + nw + sch * 8;
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
     const int row = it * 8 + srow;
-    *reinterpret_cast<uint4*>(Cp + (size_t)row * ldc) = *reinterpret_cast<const uint4*>(r1 + ep_off<true>(row, sch * 16));
+    *reinterpret_cast<u32x4*>(Cp + (size_t)row * ldc) = flip_halves(*reinterpret_cast<const u32x4*>(r1 + ep_off<true>(row, sch * 16)), it & 1);
   }
 }
 
