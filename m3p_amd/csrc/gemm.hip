@@ -2609,6 +2609,7 @@ void gemm_wgrad_w4_kernel(const bf16* __restrict__ dY, int lddy, const bf16* __r
   WgCursor lc = locate(g0);
   int l_issued = 0;
   const int l_hi = lane >> 5, l_pos = lane & 31;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   int y_off[8], x_off[8];      // element offsets of this lane's 16 bytes inside the K-tile, immediates compensated
 #pragma unroll
   for (int p = 0; p < 8; ++p) {
@@ -2627,6 +2628,8 @@ void gemm_wgrad_w4_kernel(const bf16* __restrict__ dY, int lddy, const bf16* __r
     x_base = X + mbase * ldx + tj * TJ;
   };
   set_load_ktile();
+  // (written as instructions in the scalar-base form - SGPR pair + 32-bit lane offset, no 64-bit vector add per piece - the
+  //  loads measured the same, 6.88 against 6.80 ms: the adds fit the free issue slots between two MFMAs.  The builtin stays.)
 #define WG_LD1(PTR, IMM) __builtin_amdgcn_global_load_lds(GLB_PTR(PTR), LDS_PTR(sl), 16, IMM, 0)
   auto issue_load = [&](int s, int piece) {
     char* sl = smem + s * STAGE + (piece < 8 ? 0 : Y_BYTES) + wid * 8192 + 4096;
@@ -2642,25 +2645,35 @@ void gemm_wgrad_w4_kernel(const bf16* __restrict__ dY, int lddy, const bf16* __r
       default: WG_LD1(src, 3072); break;
     }
   };
+  const size_t y_step = (size_t)KT * lddy, x_step = (size_t)KT * ldx;
   auto load_done = [&]() {
     // past the end of this workgroup's stream the last K-tile is re-loaded into a stage nobody
-    // reads again (keeps the loop body and the vmcnt bookkeeping uniform)
-    if (++l_issued < total) { advance(lc); set_load_ktile(); }
+    // reads again (keeps the loop body and the vmcnt bookkeeping uniform).
+    // Within a tile the bases just move on by 64 rows: recomputing them (a division by tiles_j, two 64-bit products) was ~60
+    // scalar instructions per K-tile in front of the mid-step barrier, with the matrix pipe running dry behind them.
+    if (++l_issued < total) {
+      if (++lc.mt == lc.len) { lc.mt = 0; lc.t += nwg; set_load_ktile(); }
+      else { y_base += y_step; x_base += x_step; }
+    }
   };
 
   // ---- fragment addressing (tr16): lane (t = l & 15, g = l >> 4) reads row 8g + (t >> 2) (+4 for the
   // second half, +32 for k-step 1), 8-byte piece (t & 3) of 16-column sub-tile c
   const int wi = wid >> 1, wj = wid & 1;
   const int ft = lane & 15, fg = lane >> 4;
-  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const int frow = fg * 8 + (ft >> 2);
   const int fsw = ((ft >> 2) | ((fg & 1) << 2)) << 1;
-  uint32_t y_addr[8], x_addr[8];
+  // (one address per fragment column AND stage: the stage offset, 64 KB, is beyond the instruction's 16-bit immediate, and a
+  //  v_add per read - 32 per K-tile - is not free for a wave alone on its SIMD: every vector instruction between two MFMAs of
+  //  the same wave delays the second one.  7.74 -> 7.45 ms over the step's weight gradients, tools/ab_wgrad.py.)
+  uint32_t y_addr[2][8], x_addr[2][8];
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
     const int qy = wi * 16 + 2 * c + ((ft & 3) >> 1), qx = wj * 16 + 2 * c + ((ft & 3) >> 1);
-    y_addr[c] = lds0 + frow * ROWB + ((qy ^ fsw) << 4) + ((ft & 1) << 3);
-    x_addr[c] = lds0 + Y_BYTES + frow * ROWB + ((qx ^ fsw) << 4) + ((ft & 1) << 3);
+    y_addr[0][c] = lds0 + frow * ROWB + ((qy ^ fsw) << 4) + ((ft & 1) << 3);
+    x_addr[0][c] = lds0 + Y_BYTES + frow * ROWB + ((qx ^ fsw) << 4) + ((ft & 1) << 3);
+    y_addr[1][c] = y_addr[0][c] + STAGE;
+    x_addr[1][c] = x_addr[0][c] + STAGE;
   }
   // one fragment = two tr16 reads (rows +0 / +4); OFF selects the k-step (0 / 16384).  The outputs are EARLY-CLOBBER: without
   // the '&' the compiler may give the first read's destination the address register (it did, in 21 of the kernel's 80 pairs),
@@ -2677,151 +2690,161 @@ void gemm_wgrad_w4_kernel(const bf16* __restrict__ dY, int lddy, const bf16* __r
 #define WG_ACC(B, A) "a[((" #B ")*8+(" #A "))*4:((" #B ")*8+(" #A "))*4+3]"
 #define WG_M(YF, XF, B, A) do { if (FIRST) asm volatile("v_mfma_f32_16x16x32_bf16 " WG_ACC(B, A) ", %0, %1, 0" :: "v"(YF[A]), "v"(XF[B])); \
                                 else asm volatile("v_mfma_f32_16x16x32_bf16 " WG_ACC(B, A) ", %0, %1, " WG_ACC(B, A) :: "v"(YF[A]), "v"(XF[B])); } while (0)
-#define WG_L(PIECE) do { if (!(dbg_flags & 2)) issue_load(s_cur, PIECE); __builtin_amdgcn_sched_barrier(0); } while (0)
-#define WG_LP(PIECE) do { if (pend && !(dbg_flags & 2)) issue_load(s_cur ^ 1, PIECE); __builtin_amdgcn_sched_barrier(0); } while (0)
+  // (the ablation switches of tools/gemm_timeline.py are compile-time: as run-time tests they were a scalar compare + branch per
+  //  LDS-DMA - 21 per K-tile - in a wave that has no partner on its SIMD to issue around them)
+#ifdef M3P_WG_DBG
+#define WG_DBG(bit) (dbg_flags & (bit))
+#else
+#define WG_DBG(bit) 0
+#endif
+#define WG_L(PIECE) do { if (!WG_DBG(2)) issue_load(s_cur, PIECE); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define WG_LP(PIECE) do { if (PEND && !WG_DBG(2)) issue_load(s_cur ^ 1, PIECE); __builtin_amdgcn_sched_barrier(0); } while (0)
   auto frag = [](const s16x4& lo, const s16x4& hi) {
     return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
   };
 
   s16x4 yl[8], yh[8], xl[8], xh[8];     // raw halves of the fragments being fetched
   bf16x8 yf0[8], xf0[8], yf1[8], xf1[8];
-  auto phase1 = [&](auto first_c, int s_cur, bool pend) {
+  // the stage is a compile-time fact of each phase body (the K loop is unrolled by two): fragment addresses and LDS-DMA
+  // destinations are then plain registers / immediates
+  auto phase1 = [&](auto first_c, auto stage_c, auto pend_c) {
     constexpr bool FIRST = decltype(first_c)::value;
-    const uint32_t so = s_cur * STAGE;
+    constexpr int s_cur = decltype(stage_c)::value;
+    constexpr bool PEND = decltype(pend_c)::value;     // (false in a workgroup's very first step only: nothing to top up yet)
     __builtin_amdgcn_sched_barrier(0);
     WG_M(yf0, xf0, 0, 0);
-    WG_M(yf0, xf0, 0, 1); WG_TR2(yl[0], yh[0], y_addr[0] + so, 16384);
+    WG_M(yf0, xf0, 0, 1); WG_TR2(yl[0], yh[0], y_addr[s_cur][0], 16384);
     WG_M(yf0, xf0, 0, 2); WG_LP(11);
     WG_M(yf0, xf0, 0, 3);
     WG_M(yf0, xf0, 0, 4);
-    WG_M(yf0, xf0, 0, 5); WG_TR2(yl[1], yh[1], y_addr[1] + so, 16384);
+    WG_M(yf0, xf0, 0, 5); WG_TR2(yl[1], yh[1], y_addr[s_cur][1], 16384);
     WG_M(yf0, xf0, 0, 6); WG_LP(12);
     WG_M(yf0, xf0, 0, 7);
     WG_M(yf0, xf0, 1, 0);
-    WG_M(yf0, xf0, 1, 1); WG_TR2(yl[2], yh[2], y_addr[2] + so, 16384);
+    WG_M(yf0, xf0, 1, 1); WG_TR2(yl[2], yh[2], y_addr[s_cur][2], 16384);
     WG_M(yf0, xf0, 1, 2); WG_LP(13);
     WG_M(yf0, xf0, 1, 3);
     WG_M(yf0, xf0, 1, 4);
-    WG_M(yf0, xf0, 1, 5); WG_TR2(yl[3], yh[3], y_addr[3] + so, 16384);
+    WG_M(yf0, xf0, 1, 5); WG_TR2(yl[3], yh[3], y_addr[s_cur][3], 16384);
     WG_M(yf0, xf0, 1, 6); WG_LP(14);
     WG_M(yf0, xf0, 1, 7);
     WG_M(yf0, xf0, 2, 0);
-    WG_M(yf0, xf0, 2, 1); WG_TR2(yl[4], yh[4], y_addr[4] + so, 16384);
+    WG_M(yf0, xf0, 2, 1); WG_TR2(yl[4], yh[4], y_addr[s_cur][4], 16384);
     WG_M(yf0, xf0, 2, 2); WG_LP(15);
     WG_M(yf0, xf0, 2, 3);
     WG_M(yf0, xf0, 2, 4);
-    WG_M(yf0, xf0, 2, 5); WG_TR2(yl[5], yh[5], y_addr[5] + so, 16384);
+    WG_M(yf0, xf0, 2, 5); WG_TR2(yl[5], yh[5], y_addr[s_cur][5], 16384);
     WG_M(yf0, xf0, 2, 6);
     WG_M(yf0, xf0, 2, 7);
     WG_M(yf0, xf0, 3, 0);
-    WG_M(yf0, xf0, 3, 1); WG_TR2(yl[6], yh[6], y_addr[6] + so, 16384);
+    WG_M(yf0, xf0, 3, 1); WG_TR2(yl[6], yh[6], y_addr[s_cur][6], 16384);
     WG_M(yf0, xf0, 3, 2);
     WG_M(yf0, xf0, 3, 3);
     WG_M(yf0, xf0, 3, 4);
-    WG_M(yf0, xf0, 3, 5); WG_TR2(yl[7], yh[7], y_addr[7] + so, 16384);
+    WG_M(yf0, xf0, 3, 5); WG_TR2(yl[7], yh[7], y_addr[s_cur][7], 16384);
     WG_M(yf0, xf0, 3, 6);
     WG_M(yf0, xf0, 3, 7);
     WG_M(yf0, xf0, 4, 0);
-    WG_M(yf0, xf0, 4, 1); WG_TR2(xl[0], xh[0], x_addr[0] + so, 16384);
+    WG_M(yf0, xf0, 4, 1); WG_TR2(xl[0], xh[0], x_addr[s_cur][0], 16384);
     WG_M(yf0, xf0, 4, 2);
     WG_M(yf0, xf0, 4, 3);
     WG_M(yf0, xf0, 4, 4);
-    WG_M(yf0, xf0, 4, 5); WG_TR2(xl[1], xh[1], x_addr[1] + so, 16384);
+    WG_M(yf0, xf0, 4, 5); WG_TR2(xl[1], xh[1], x_addr[s_cur][1], 16384);
     WG_M(yf0, xf0, 4, 6);
     WG_M(yf0, xf0, 4, 7);
     WG_M(yf0, xf0, 5, 0);
-    WG_M(yf0, xf0, 5, 1); WG_TR2(xl[2], xh[2], x_addr[2] + so, 16384);
+    WG_M(yf0, xf0, 5, 1); WG_TR2(xl[2], xh[2], x_addr[s_cur][2], 16384);
     WG_M(yf0, xf0, 5, 2);
     WG_M(yf0, xf0, 5, 3);
     WG_M(yf0, xf0, 5, 4);
-    WG_M(yf0, xf0, 5, 5); WG_TR2(xl[3], xh[3], x_addr[3] + so, 16384);
+    WG_M(yf0, xf0, 5, 5); WG_TR2(xl[3], xh[3], x_addr[s_cur][3], 16384);
     WG_M(yf0, xf0, 5, 6);
     WG_M(yf0, xf0, 5, 7);
     WG_M(yf0, xf0, 6, 0);
-    WG_M(yf0, xf0, 6, 1); WG_TR2(xl[4], xh[4], x_addr[4] + so, 16384);
+    WG_M(yf0, xf0, 6, 1); WG_TR2(xl[4], xh[4], x_addr[s_cur][4], 16384);
     WG_M(yf0, xf0, 6, 2);
     WG_M(yf0, xf0, 6, 3);
     WG_M(yf0, xf0, 6, 4);
-    WG_M(yf0, xf0, 6, 5); WG_TR2(xl[5], xh[5], x_addr[5] + so, 16384);
+    WG_M(yf0, xf0, 6, 5); WG_TR2(xl[5], xh[5], x_addr[s_cur][5], 16384);
     WG_M(yf0, xf0, 6, 6);
     WG_M(yf0, xf0, 6, 7);
     WG_M(yf0, xf0, 7, 0);
-    WG_M(yf0, xf0, 7, 1); WG_TR2(xl[6], xh[6], x_addr[6] + so, 16384);
+    WG_M(yf0, xf0, 7, 1); WG_TR2(xl[6], xh[6], x_addr[s_cur][6], 16384);
     WG_M(yf0, xf0, 7, 2);
     WG_M(yf0, xf0, 7, 3);
     WG_M(yf0, xf0, 7, 4);
-    WG_M(yf0, xf0, 7, 5); WG_TR2(xl[7], xh[7], x_addr[7] + so, 16384);
+    WG_M(yf0, xf0, 7, 5); WG_TR2(xl[7], xh[7], x_addr[s_cur][7], 16384);
     WG_M(yf0, xf0, 7, 6);
     WG_M(yf0, xf0, 7, 7);
     __builtin_amdgcn_sched_barrier(0);
-    if (pend) load_done();
+    if (PEND) load_done();
   };
-  auto phase2 = [&](int s_cur) {
+  auto phase2 = [&](auto stage_c) {
     constexpr bool FIRST = false;
-    const uint32_t so = (s_cur ^ 1) * STAGE;
+    constexpr int s_cur = decltype(stage_c)::value;
     __builtin_amdgcn_sched_barrier(0);
     WG_M(yf1, xf1, 0, 0); WG_L(0);
-    WG_M(yf1, xf1, 0, 1); WG_TR2(yl[0], yh[0], y_addr[0] + so, 0);
+    WG_M(yf1, xf1, 0, 1); WG_TR2(yl[0], yh[0], y_addr[s_cur ^ 1][0], 0);
     WG_M(yf1, xf1, 0, 2);
     WG_M(yf1, xf1, 0, 3);
     WG_M(yf1, xf1, 0, 4);
-    WG_M(yf1, xf1, 0, 5); WG_TR2(yl[1], yh[1], y_addr[1] + so, 0);
+    WG_M(yf1, xf1, 0, 5); WG_TR2(yl[1], yh[1], y_addr[s_cur ^ 1][1], 0);
     WG_M(yf1, xf1, 0, 6); WG_L(1);
     WG_M(yf1, xf1, 0, 7);
     WG_M(yf1, xf1, 1, 0);
-    WG_M(yf1, xf1, 1, 1); WG_TR2(yl[2], yh[2], y_addr[2] + so, 0);
+    WG_M(yf1, xf1, 1, 1); WG_TR2(yl[2], yh[2], y_addr[s_cur ^ 1][2], 0);
     WG_M(yf1, xf1, 1, 2);
     WG_M(yf1, xf1, 1, 3);
     WG_M(yf1, xf1, 1, 4); WG_L(2);
-    WG_M(yf1, xf1, 1, 5); WG_TR2(yl[3], yh[3], y_addr[3] + so, 0);
+    WG_M(yf1, xf1, 1, 5); WG_TR2(yl[3], yh[3], y_addr[s_cur ^ 1][3], 0);
     WG_M(yf1, xf1, 1, 6);
     WG_M(yf1, xf1, 1, 7);
     WG_M(yf1, xf1, 2, 0);
-    WG_M(yf1, xf1, 2, 1); WG_TR2(yl[4], yh[4], y_addr[4] + so, 0);
+    WG_M(yf1, xf1, 2, 1); WG_TR2(yl[4], yh[4], y_addr[s_cur ^ 1][4], 0);
     WG_M(yf1, xf1, 2, 2); WG_L(3);
     WG_M(yf1, xf1, 2, 3);
     WG_M(yf1, xf1, 2, 4);
-    WG_M(yf1, xf1, 2, 5); WG_TR2(yl[5], yh[5], y_addr[5] + so, 0);
+    WG_M(yf1, xf1, 2, 5); WG_TR2(yl[5], yh[5], y_addr[s_cur ^ 1][5], 0);
     WG_M(yf1, xf1, 2, 6);
     WG_M(yf1, xf1, 2, 7);
     WG_M(yf1, xf1, 3, 0); WG_L(4);
-    WG_M(yf1, xf1, 3, 1); WG_TR2(yl[6], yh[6], y_addr[6] + so, 0);
+    WG_M(yf1, xf1, 3, 1); WG_TR2(yl[6], yh[6], y_addr[s_cur ^ 1][6], 0);
     WG_M(yf1, xf1, 3, 2);
     WG_M(yf1, xf1, 3, 3);
     WG_M(yf1, xf1, 3, 4);
-    WG_M(yf1, xf1, 3, 5); WG_TR2(yl[7], yh[7], y_addr[7] + so, 0);
+    WG_M(yf1, xf1, 3, 5); WG_TR2(yl[7], yh[7], y_addr[s_cur ^ 1][7], 0);
     WG_M(yf1, xf1, 3, 6); WG_L(5);
     WG_M(yf1, xf1, 3, 7);
     WG_M(yf1, xf1, 4, 0);
-    WG_M(yf1, xf1, 4, 1); WG_TR2(xl[0], xh[0], x_addr[0] + so, 0);
+    WG_M(yf1, xf1, 4, 1); WG_TR2(xl[0], xh[0], x_addr[s_cur ^ 1][0], 0);
     WG_M(yf1, xf1, 4, 2);
     WG_M(yf1, xf1, 4, 3);
     WG_M(yf1, xf1, 4, 4); WG_L(6);
-    WG_M(yf1, xf1, 4, 5); WG_TR2(xl[1], xh[1], x_addr[1] + so, 0);
+    WG_M(yf1, xf1, 4, 5); WG_TR2(xl[1], xh[1], x_addr[s_cur ^ 1][1], 0);
     WG_M(yf1, xf1, 4, 6);
     WG_M(yf1, xf1, 4, 7);
     WG_M(yf1, xf1, 5, 0);
-    WG_M(yf1, xf1, 5, 1); WG_TR2(xl[2], xh[2], x_addr[2] + so, 0);
+    WG_M(yf1, xf1, 5, 1); WG_TR2(xl[2], xh[2], x_addr[s_cur ^ 1][2], 0);
     WG_M(yf1, xf1, 5, 2); WG_L(7);
     WG_M(yf1, xf1, 5, 3);
     WG_M(yf1, xf1, 5, 4);
-    WG_M(yf1, xf1, 5, 5); WG_TR2(xl[3], xh[3], x_addr[3] + so, 0);
+    WG_M(yf1, xf1, 5, 5); WG_TR2(xl[3], xh[3], x_addr[s_cur ^ 1][3], 0);
     WG_M(yf1, xf1, 5, 6);
     WG_M(yf1, xf1, 5, 7);
     WG_M(yf1, xf1, 6, 0); WG_L(8);
-    WG_M(yf1, xf1, 6, 1); WG_TR2(xl[4], xh[4], x_addr[4] + so, 0);
+    WG_M(yf1, xf1, 6, 1); WG_TR2(xl[4], xh[4], x_addr[s_cur ^ 1][4], 0);
     WG_M(yf1, xf1, 6, 2);
     WG_M(yf1, xf1, 6, 3);
     WG_M(yf1, xf1, 6, 4);
-    WG_M(yf1, xf1, 6, 5); WG_TR2(xl[5], xh[5], x_addr[5] + so, 0);
+    WG_M(yf1, xf1, 6, 5); WG_TR2(xl[5], xh[5], x_addr[s_cur ^ 1][5], 0);
     WG_M(yf1, xf1, 6, 6); WG_L(9);
     WG_M(yf1, xf1, 6, 7);
     WG_M(yf1, xf1, 7, 0);
-    WG_M(yf1, xf1, 7, 1); WG_TR2(xl[6], xh[6], x_addr[6] + so, 0);
+    WG_M(yf1, xf1, 7, 1); WG_TR2(xl[6], xh[6], x_addr[s_cur ^ 1][6], 0);
     WG_M(yf1, xf1, 7, 2);
     WG_M(yf1, xf1, 7, 3);
     WG_M(yf1, xf1, 7, 4);
-    WG_M(yf1, xf1, 7, 5); WG_TR2(xl[7], xh[7], x_addr[7] + so, 0);
+    WG_M(yf1, xf1, 7, 5); WG_TR2(xl[7], xh[7], x_addr[s_cur ^ 1][7], 0);
     WG_M(yf1, xf1, 7, 6); WG_L(10);
     WG_M(yf1, xf1, 7, 7);
     __builtin_amdgcn_sched_barrier(0);
@@ -2839,8 +2862,8 @@ void gemm_wgrad_w4_kernel(const bf16* __restrict__ dY, int lddy, const bf16* __r
   asm volatile("" ::: "memory");
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
-    WG_TR2(yl[c], yh[c], y_addr[c], 0);
-    WG_TR2(xl[c], xh[c], x_addr[c], 0);
+    WG_TR2(yl[c], yh[c], y_addr[0][c], 0);
+    WG_TR2(xl[c], xh[c], x_addr[0][c], 0);
   }
   WG_LGKM0();
 #pragma unroll
@@ -2849,10 +2872,10 @@ void gemm_wgrad_w4_kernel(const bf16* __restrict__ dY, int lddy, const bf16* __r
   WgCursor cc = locate(g0);
   bool first = true;
   int n_seg = 0;
-  for (int step = 0; step < total; ++step) {
-    const int s_cur = step & 1;
-    if (first) phase1(std::true_type{}, s_cur, step > 0);
-    else phase1(std::false_type{}, s_cur, step > 0);
+  auto kstep = [&](auto stage_c, int step) {
+    if (step == 0) phase1(std::true_type{}, stage_c, std::false_type{});
+    else if (first) phase1(std::true_type{}, stage_c, std::true_type{});
+    else phase1(std::false_type{}, stage_c, std::true_type{});
     first = false;
     WG_LGKM0();
 #pragma unroll
@@ -2860,7 +2883,7 @@ void gemm_wgrad_w4_kernel(const bf16* __restrict__ dY, int lddy, const bf16* __r
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();      // K-tile step+1 visible to all; stage s_cur fully read by all
     asm volatile("" ::: "memory");
-    phase2(s_cur);
+    phase2(stage_c);
     WG_LGKM0();
 #pragma unroll
     for (int c = 0; c < 8; ++c) { yf0[c] = frag(yl[c], yh[c]); xf0[c] = frag(xl[c], xh[c]); }
@@ -2939,7 +2962,7 @@ void gemm_wgrad_w4_kernel(const bf16* __restrict__ dY, int lddy, const bf16* __r
           for (int a = 0; a < 8; ++a)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-              if (!(dbg_flags & 1)) unsafeAtomicAdd(dcol + (size_t)(a * 16 + r) * lddw, alpha * v[a * 4 + r]);
+              if (!WG_DBG(1)) unsafeAtomicAdd(dcol + (size_t)(a * 16 + r) * lddw, alpha * v[a * 4 + r]);
         }
       }
       if (to_ws && tid == 0) ws_tile[slot] = cc.t;
@@ -2947,6 +2970,10 @@ void gemm_wgrad_w4_kernel(const bf16* __restrict__ dY, int lddy, const bf16* __r
       first = true;
     }
     advance(cc);
+  };
+  for (int step = 0; step < total; step += 2) {
+    kstep(std::integral_constant<int, 0>{}, step);
+    if (step + 1 < total) kstep(std::integral_constant<int, 1>{}, step + 1);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // junk loads of the tail must not outlive the LDS allocation
 #undef WG_LD1
@@ -2955,6 +2982,7 @@ void gemm_wgrad_w4_kernel(const bf16* __restrict__ dY, int lddy, const bf16* __r
 #undef WG_ACC
 #undef WG_M
 #undef WG_L
+#undef WG_DBG
 #undef WG_LP
 }
 
