@@ -505,7 +505,7 @@ __device__ __forceinline__ void epilogue_piece16(const M3PEpilogue& ep, bf16* __
   }
 }
 
-#if defined(M3P_RING_TL) || defined(M3P_W8_TL)
+#if defined(M3P_RING_TL) || defined(M3P_W8_TL) || defined(M3P_WG_TL)
 __device__ unsigned long long g_ring_tl[256 * 8 * 16];  // debug build: per-wave cycle sums of the eight-wave kernel's segments
                                                         // ([256][8][8] segments, then [256][8][8] K-tile phases of the w8 kernel)
 #endif
@@ -2651,7 +2651,12 @@ void gemm_wgrad_w4_kernel(const bf16* __restrict__ dY, int lddy, const bf16* __r
     // reads again (keeps the loop body and the vmcnt bookkeeping uniform).
     // Within a tile the bases just move on by 64 rows: recomputing them (a division by tiles_j, two 64-bit products) was ~60
     // scalar instructions per K-tile in front of the mid-step barrier, with the matrix pipe running dry behind them.
-    if (++l_issued < total) {
+    // (one segment per workgroup - every layer weight: branch-free, a select and two 64-bit adds)
+    if (!rr) {
+      const bool more = ++l_issued < total;
+      y_base += more ? y_step : 0;
+      x_base += more ? x_step : 0;
+    } else if (++l_issued < total) {
       if (++lc.mt == lc.len) { lc.mt = 0; lc.t += nwg; set_load_ktile(); }
       else { y_base += y_step; x_base += x_step; }
     }
@@ -2872,19 +2877,38 @@ void gemm_wgrad_w4_kernel(const bf16* __restrict__ dY, int lddy, const bf16* __r
   WgCursor cc = locate(g0);
   bool first = true;
   int n_seg = 0;
+  // -DM3P_WG_TL: s_memtime sums per segment of a K-tile (tools/wgrad_timeline.py): 0 phase 1 (64 MFMAs + reads + LDS-DMAs issued),
+  // 1 its closing lgkmcnt(0), 2 vmcnt(0), 3 s_barrier, 4 phase 2, 5 its closing lgkmcnt(0), 6 step tail / flush, 7 K-tiles
+#ifdef M3P_WG_TL
+  unsigned long long wtl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long wt0 = __builtin_amdgcn_s_memtime(), wt1;
+#define WG_TSEG(k) do { __builtin_amdgcn_sched_barrier(0); wt1 = __builtin_amdgcn_s_memtime(); wtl[k] += wt1 - wt0; wt0 = wt1; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define WG_TSEG(k) do { } while (0)
+#endif
   auto kstep = [&](auto stage_c, int step) {
+    WG_TSEG(6);
     if (step == 0) phase1(std::true_type{}, stage_c, std::false_type{});
     else if (first) phase1(std::true_type{}, stage_c, std::true_type{});
     else phase1(std::false_type{}, stage_c, std::true_type{});
     first = false;
+    WG_TSEG(0);
     WG_LGKM0();
+    WG_TSEG(1);
 #pragma unroll
     for (int c = 0; c < 8; ++c) { yf1[c] = frag(yl[c], yh[c]); xf1[c] = frag(xl[c], xh[c]); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WG_TSEG(2);
     __builtin_amdgcn_s_barrier();      // K-tile step+1 visible to all; stage s_cur fully read by all
     asm volatile("" ::: "memory");
+    WG_TSEG(3);
     phase2(stage_c);
+    WG_TSEG(4);
     WG_LGKM0();
+    WG_TSEG(5);
+#ifdef M3P_WG_TL
+    wtl[7] += 1;
+#endif
 #pragma unroll
     for (int c = 0; c < 8; ++c) { yf0[c] = frag(yl[c], yh[c]); xf0[c] = frag(xl[c], xh[c]); }
 
@@ -2976,6 +3000,12 @@ void gemm_wgrad_w4_kernel(const bf16* __restrict__ dY, int lddy, const bf16* __r
     if (step + 1 < total) kstep(std::integral_constant<int, 1>{}, step + 1);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // junk loads of the tail must not outlive the LDS allocation
+#ifdef M3P_WG_TL
+  WG_TSEG(6);
+  if (lane == 0)
+    for (int k = 0; k < 8; ++k) g_ring_tl[(blockIdx.x * 4 + wid) * 8 + k] = wtl[k];
+#endif
+#undef WG_TSEG
 #undef WG_LD1
 #undef WG_TR2
 #undef WG_LGKM0
@@ -3313,7 +3343,7 @@ int m3p_gemm_nt_fp8(const void* A, int lda, int a_is_bf8, const void* W, int ldw
 // [256 workgroups][8 waves][8 segments]: 0 K loop, 1 bias / row copies, 2 aux fetch + wait, 3 epilogue half (compute,
 // staging, stores), 4 column sums, 5 zeroing + end barrier  (tools/ring_timeline.py)
 __attribute__((visibility("default"))) int m3p_debug_ring_timeline(void* out, size_t bytes) {
-#if defined(M3P_RING_TL) || defined(M3P_W8_TL)
+#if defined(M3P_RING_TL) || defined(M3P_W8_TL) || defined(M3P_WG_TL)
   if (bytes > sizeof(g_ring_tl)) return M3P_EINVAL;
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ring_tl), bytes);
 #else
