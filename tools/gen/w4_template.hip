@@ -70,21 +70,30 @@ void gemm_nt_w4_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
   const int l_col = ((lane & 7) ^ l_row) * 8;
   // (only full tiles come here - the launcher sends ragged shapes to the ring kernel - so the
   //  eight row groups of a slice are a uniform stride apart and two pointers are enough)
-  const bf16* a_src0;
-  const bf16* w_src0;
-  const long a_step = 8 * (long)lda - 512, w_step = 8 * (long)ldw - 512;     // next row group, next immediate
+  // Source of piece p = (wave-uniform base of this K-tile's slice, advanced by the scalar unit once per K-tile) + (this lane's
+  // element offset for the piece, a register set up once): one vector add per piece.  (A per-lane pointer + k0 + p * step was
+  // half a dozen scalar instructions per piece on top - and this wave has no partner on its SIMD to issue around them.)
+  int a_poff[8], w_poff[8];
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    a_poff[p] = (l_row + 8 * p) * lda + l_col + 2048 - 512 * p;       // next row group, next immediate
+    w_poff[p] = (l_row + 8 * p) * ldw + l_col + 2048 - 512 * p;
+  }
+  const bf16* a_tile;       // this wave's slice of the tile the load cursor points at, K-tile 0
+  const bf16* w_tile;
+  const bf16* a_base;       // ... at the cursor's K-tile
+  const bf16* w_base;
   int l_q = 0, l_kt = 0;
   auto set_load_tile = [&](int q) {
     int tm, tn;
     split_tile(tile_of(q), tm, tn);
-    a_src0 = A + (size_t)(tm * BM + wid * 64 + l_row) * lda + l_col + 2048;
-    w_src0 = W + (size_t)(tn * BN + wid * 64 + l_row) * ldw + l_col + 2048;
+    a_base = a_tile = A + (size_t)(tm * BM + wid * 64) * lda;
+    w_base = w_tile = W + (size_t)(tn * BN + wid * 64) * ldw;
   };
 #define W4_LD1(PTR, IMM) __builtin_amdgcn_global_load_lds(GLB_PTR(PTR), LDS_PTR(sl), 16, IMM, 0)
   auto issue_load = [&](int s, int piece) {
-    const int k0 = (ABL & 4) ? 0 : l_kt * KT;
     char* sl = smem + s * STAGE + (piece < 8 ? 0 : A_BYTES) + wid * 8192 + 4096;
-    const bf16* src = (piece < 8) ? a_src0 + (k0 + (piece & 7) * a_step) : w_src0 + (k0 + (piece & 7) * w_step);
+    const bf16* src = (piece < 8) ? a_base + a_poff[piece & 7] : w_base + w_poff[piece & 7];
     switch (piece & 7) {
       case 0: W4_LD1(src, -4096); break;
       case 1: W4_LD1(src, -3072); break;
@@ -97,19 +106,24 @@ void gemm_nt_w4_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
     }
   };
   auto load_done = [&]() {
+    // (past the end of the stream the last tile's K-tiles are requested again into stages nobody reads)
     if (++l_kt == nk) { l_kt = 0; ++l_q; if (l_q < my_tiles) set_load_tile(l_q); }
+    if (!(ABL & 4)) { a_base = a_tile + l_kt * KT; w_base = w_tile + l_kt * KT; }
   };
 
   // ---- fragment addressing (as in the ring kernel: 128-B rows, chunk ^= row & 7)
   const int wm = wid >> 1, wn = wid & 1;
   const int fr = lane & 15, fg = lane >> 4;
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-  uint32_t a_addr[2], b_addr[2];      // per k-step; fragment i at + i * 2048, stage at + s * STAGE
+  uint32_t a_addr[2], b_addr[2];      // per k-step; fragment i at + i * 2048
+  uint32_t a_addr1[2], b_addr1[2];    // the same in stage 1 (the K loop is unrolled by two: the stage is a compile-time fact)
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
     const int ch = ((fg + 4 * ks) ^ (fr & 7)) * 16;
     a_addr[ks] = lds0 + (wm * 128 + fr) * 128 + ch;
     b_addr[ks] = lds0 + A_BYTES + (wn * 128 + fr) * 128 + ch;
+    a_addr1[ks] = a_addr[ks] + STAGE;
+    b_addr1[ks] = b_addr[ks] + STAGE;
   }
 #define W4_DSR(dst, addr, off) do { if (!(ABL & 1)) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr)); } while (0)
 #define W4_LGKM0() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -125,24 +139,27 @@ void gemm_nt_w4_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
 #define W4_M(FA, FW, I, J) do { if (FIRST) asm volatile("v_mfma_f32_16x16x32_bf16 " W4_ACC(I, J) ", %1, %0, 0" :: "v"(FA[I]), "v"(FW[J])); \
                                 else asm volatile("v_mfma_f32_16x16x32_bf16 " W4_ACC(I, J) ", %1, %0, " W4_ACC(I, J) :: "v"(FA[I]), "v"(FW[J])); } while (0)
 #define W4_L(PIECE) do { if (!(ABL & 2)) issue_load(s_cur, PIECE); __builtin_amdgcn_sched_barrier(0); } while (0)
-#define W4_LP(PIECE) do { if (!(ABL & 2) && pend) issue_load(s_cur ^ 1, PIECE); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define W4_LP(PIECE) do { if (!(ABL & 2) && PEND) issue_load(s_cur ^ 1, PIECE); __builtin_amdgcn_sched_barrier(0); } while (0)
 
   bf16x8 fa0[8], fw0[8], fa1[8], fw1[8];
   // phase 1: k-step 0 of the current K-tile from registers; fetch its k-step 1 fragments; finish
   // the LDS-DMA list phase 2 of the previous iteration started (`pend`)
-  auto phase1 = [&](auto first_c, int s_cur, bool pend) {
+  auto phase1 = [&](auto first_c, auto stage_c, auto pend_c) {
     constexpr bool FIRST = decltype(first_c)::value;   // first K-tile of an output tile: C operand = 0
-    const uint32_t ra1 = a_addr[1] + s_cur * STAGE, rb1 = b_addr[1] + s_cur * STAGE;
+    constexpr int s_cur = decltype(stage_c)::value;
+    constexpr bool PEND = decltype(pend_c)::value;     // (false in a workgroup's very first step only)
+    const uint32_t ra1 = s_cur ? a_addr1[1] : a_addr[1], rb1 = s_cur ? b_addr1[1] : b_addr[1];
     __builtin_amdgcn_sched_barrier(0);
 @PHASE1@
     __builtin_amdgcn_sched_barrier(0);
-    if (pend) load_done();
+    if (PEND) load_done();
   };
   // phase 2: k-step 1; the stage just vacated by everyone (barrier) starts receiving K-tile +2,
   // and k-step 0 of the next K-tile comes out of the other stage
-  auto phase2 = [&](int s_cur) {
+  auto phase2 = [&](auto stage_c) {
     constexpr bool FIRST = false;
-    const uint32_t ra0n = a_addr[0] + (s_cur ^ 1) * STAGE, rb0n = b_addr[0] + (s_cur ^ 1) * STAGE;
+    constexpr int s_cur = decltype(stage_c)::value;
+    const uint32_t ra0n = s_cur ? a_addr[0] : a_addr1[0], rb0n = s_cur ? b_addr[0] : b_addr1[0];
     __builtin_amdgcn_sched_barrier(0);
 @PHASE2@
     __builtin_amdgcn_sched_barrier(0);
@@ -174,8 +191,7 @@ void gemm_nt_w4_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
   f32x4 bias_lo[4], bias_hi[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) bias_lo[j] = bias_hi[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int step = 0; step < total; ++step) {
-    const int s_cur = step & 1;
+  auto kstep = [&](auto stage_c, int step) {
     if (c_kt == 0) {
       // bias values of this output tile: fetched now, used after the last K-tile (a load inside
       // the epilogue is a stall with nothing to hide behind)
@@ -185,9 +201,10 @@ void gemm_nt_w4_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
         load_bias4<EPI>(ep, btn * BN + wn * 128, lane, bias_lo);
         load_bias4<EPI>(ep, btn * BN + wn * 128 + 64, lane, bias_hi);
       }
-      phase1(std::true_type{}, s_cur, step > 0);
+      if (step == 0) phase1(std::true_type{}, stage_c, std::false_type{});
+      else phase1(std::true_type{}, stage_c, std::true_type{});
     } else {
-      phase1(std::false_type{}, s_cur, step > 0);
+      phase1(std::false_type{}, stage_c, std::true_type{});
     }
     W4_TSEG(0);
     W4_LGKM0();
@@ -198,7 +215,7 @@ void gemm_nt_w4_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
     __builtin_amdgcn_s_barrier();      // K-tile step+1 visible to all; stage s_cur fully read by all
     asm volatile("" ::: "memory");
     W4_TSEG(3);
-    phase2(s_cur);
+    phase2(stage_c);
     W4_TSEG(0);
     W4_LGKM0();
     W4_TSEG(1);
@@ -282,6 +299,10 @@ void gemm_nt_w4_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
       }
       W4_TSEG(4);
     }
+  };
+  for (int step = 0; step < total; step += 2) {
+    kstep(std::integral_constant<int, 0>{}, step);
+    if (step + 1 < total) kstep(std::integral_constant<int, 1>{}, step + 1);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // junk loads of the tail must not outlive the LDS allocation
   if (TL) {
