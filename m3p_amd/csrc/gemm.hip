@@ -3459,7 +3459,7 @@ int m3p_gemm_wgrad_bf16(const void* dY, int lddy, const void* X, int ldx, float*
   if (lddy < ((N + 7) / 8) * 8 || ldx < ((K + 7) / 8) * 8) return M3P_EINVAL;
   if (((uintptr_t)dY & 15) || ((uintptr_t)X & 15)) return M3P_EINVAL;
   if (g_variant >= 1 && g_variant != 3 && (M % 64) == 0 && M >= 4096 && (N % 256) == 0 && (K % 256) == 0 &&
-      (N / 256) * (K / 256) >= ((g_ablate & 16) ? 1 : 12)) {      // (9 tiles, 768x768: the 8-wave kernel's 18 half-size tiles balance better)
+      (N / 256) * (K / 256) >= ((g_ablate & 16) ? 1 : 9)) {      // (768 x 768 = 9 tiles included since the four-wave kernel lost its scalar overhead: 63 against 74 us on the ring kernel)
     // full 256x256 tiles: four-wave kernel
     const int ti = N / 256, tj = K / 256;
     const size_t lds = 2 * 65536;

@@ -15,13 +15,15 @@ sys.path.insert(0, ROOT)
 from m3p_amd import lib as L   # noqa: E402
 
 check = '--check' in sys.argv
-names = [a for a in sys.argv[1:] if not a.startswith('--')]
+names = [a for a in sys.argv[1:] if not a.startswith('--')]      # <file under m3p_amd/>[:<m3p_debug_set_variant value>]
 tmp = tempfile.mkdtemp()
 arms = []
 for k, name in enumerate(names):
     path = os.path.join(tmp, 'arm%d.so' % k)
-    shutil.copy(os.path.join(ROOT, 'm3p_amd', name), path)
+    shutil.copy(os.path.join(ROOT, 'm3p_amd', name.split(':')[0]), path)
     h = C.CDLL(path)
+    if ':' in name:
+        h.m3p_debug_set_variant(int(name.split(':')[1]))
     for fn in ('m3p_gemm_wgrad_bf16', 'm3p_gemm_wgrad_workspace_bytes'):
         getattr(h, fn).restype, getattr(h, fn).argtypes = L.SIGNATURES[fn]
     arms.append((name, h))
