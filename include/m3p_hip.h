@@ -125,6 +125,14 @@ M3P_API size_t m3p_gemm_wgrad_workspace_bytes(void);
 M3P_API int m3p_gemm_wgrad_bf16(const void* dY, int lddy, const void* X, int ldx, float* dW, int lddw,
                                 int M, int N, int K, float alpha, void* workspace, size_t workspace_bytes,
                                 void* stream);
+/* Two weight gradients over the same M rows in ONE launch of the four-wave kernel (and one reduction): dWa += dYa^T Xa,
+ * dWb += dYb^T Xb.  The attention sub-layer's out_lin (768 x 768: 9 output tiles) and q/k/v (27 tiles) gradients of
+ * MultiHeadAttention (transformer.py:178-181, :208) together fill the 256 CUs as evenly as one FFN gradient does - apart they
+ * end in two end-of-kernel flushes and two reductions.  Falls back to two m3p_gemm_wgrad_bf16 calls when the shapes are not
+ * whole 256 x 256 tiles, M % 64 != 0, the tiles of both together exceed half the CUs, or there is no workspace. */
+M3P_API int m3p_gemm_wgrad_pair_bf16(const void* dYa, int lddya, const void* Xa, int ldxa, float* dWa, int lddwa, int Na, int Ka,
+                                     const void* dYb, int lddyb, const void* Xb, int ldxb, float* dWb, int lddwb, int Nb, int Kb,
+                                     int M, float alpha, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * LayerNorm (eps = 1e-12 in the reference: transformer.py:244,660,694,709)

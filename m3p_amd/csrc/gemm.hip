@@ -1570,6 +1570,11 @@ void gemm_nt_w8f8_kernel(const uint8_t* __restrict__ A, int lda, const uint8_t* 
 struct WgCursor {
   int c, t, mt, len;   // chunk, tile, K-tile inside the chunk, K-tiles in this chunk
 };
+// second product of a paired weight-gradient launch (tiles_i * tiles_j == 0: none)
+struct WgradProblem {
+  const bf16* dY; const bf16* X; float* dW;
+  int lddy, ldx, lddw, tiles_i, tiles_j;
+};
 
 // ---------------------------------------------------------------------------------
 // NT kernel, stream-K version with fp32 atomic output: Cf[M,N] += alpha * A[M,K] W[N,K]^T for
@@ -2571,17 +2576,27 @@ void gemm_wgrad_kernel(const bf16* __restrict__ dY, int lddy, const bf16* __rest
 // Full tiles only (N % 256 == 0, K % 256 == 0, M % 64 == 0): everything else stays on the ring kernel.
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256)
-void gemm_wgrad_w4_kernel(const bf16* __restrict__ dY, int lddy, const bf16* __restrict__ X, int ldx,
-                          float* __restrict__ dW, int lddw, int M, int N, int K, float alpha,
-                          int tiles_i, int tiles_j, int WR_CHUNK, float* __restrict__ ws, int* __restrict__ ws_tile,
-                          int dbg_flags) {
+void gemm_wgrad_w4_kernel(const bf16* __restrict__ dY_a, int lddy_a, const bf16* __restrict__ X_a, int ldx_a,
+                          float* __restrict__ dW_a, int lddw_a, int M, int N, int K, float alpha,
+                          int tiles_i, int tiles_j_a, int WR_CHUNK, float* __restrict__ ws, int* __restrict__ ws_tile,
+                          int dbg_flags, WgradProblem pb) {
+  // Two products over the same M in one launch (pb.tiles != 0; one-segment-per-workgroup mode only): the tiles of product b
+  // follow those of product a in the tile numbering, every workgroup picks its product once, before the K loop.  36 tiles of
+  // out_lin + q/k/v then share one launch, one end-of-kernel flush and one reduction instead of 9 tiles x 28 chunks beside
+  // 27 x 9.
+  const bf16* dY = dY_a;
+  const bf16* X = X_a;
+  float* dW = dW_a;
+  int lddy = lddy_a, ldx = ldx_a, lddw = lddw_a, tiles_j = tiles_j_a;
+  int tile_id0 = 0;
   constexpr int TI = 256, TJ = 256, KT = 64;
   constexpr int ROWB = 512;                          // bytes per LDS row of either operand
   constexpr int Y_BYTES = KT * ROWB, STAGE = 2 * Y_BYTES;      // 32 KB, 64 KB
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ntile = tiles_i * tiles_j;
+  const int ntile_a = tiles_i * tiles_j_a;
+  const int ntile = ntile_a + pb.tiles_i * pb.tiles_j;
   const int nmt = M / KT;
   const long long total_all = (long long)ntile * nmt;
   const int nwg = gridDim.x;
@@ -2608,6 +2623,11 @@ void gemm_wgrad_w4_kernel(const bf16* __restrict__ dY, int lddy, const bf16* __r
     if (slot >= C * ntile) return;
     const int c = slot / ntile;
     seg_tile = slot - c * ntile;
+    if (seg_tile >= ntile_a) {
+      dY = pb.dY; X = pb.X; dW = pb.dW; lddy = pb.lddy; ldx = pb.ldx; lddw = pb.lddw; tiles_j = pb.tiles_j;
+      seg_tile -= ntile_a;
+      tile_id0 = ntile_a;
+    }
     seg_m0 = (int)((long long)c * nmt / C);
     seg_len = (int)((long long)(c + 1) * nmt / C) - seg_m0;
     total = seg_len;
@@ -3010,7 +3030,7 @@ void gemm_wgrad_w4_kernel(const bf16* __restrict__ dY, int lddy, const bf16* __r
               if (!WG_DBG(1)) unsafeAtomicAdd(dcol + (size_t)(a * 16 + r) * lddw, alpha * v[a * 4 + r]);
         }
       }
-      if (to_ws && tid == 0) ws_tile[slot] = cc.t;
+      if (to_ws && tid == 0) ws_tile[slot] = tile_id0 + cc.t;
       ++n_seg;
       first = true;
     }
@@ -3041,9 +3061,11 @@ void gemm_wgrad_w4_kernel(const bf16* __restrict__ dY, int lddy, const bf16* __r
 // grid = (16 row groups, ntile); block = 256 threads, each 4 rows x 4 consecutive columns.
 __global__ __launch_bounds__(256)
 void wgrad_reduce_kernel(const float* __restrict__ ws, const int* __restrict__ ws_tile, int nslots,
-                         float* __restrict__ dW, int lddw, int tiles_j, float alpha) {
+                         float* __restrict__ dW, int lddw, int tiles_j, float alpha, int ntile_a, WgradProblem pb) {
   const int t = blockIdx.y, rg = blockIdx.x;
-  const int ti = t / tiles_j, tj = t - ti * tiles_j;
+  int tl = t;
+  if (t >= ntile_a) { tl = t - ntile_a; dW = pb.dW; lddw = pb.lddw; tiles_j = pb.tiles_j; }      // (second product of a paired launch)
+  const int ti = tl / tiles_j, tj = tl - ti * tiles_j;
   const int col = (threadIdx.x & 63) * 4, row0 = rg * 16 + (threadIdx.x >> 6) * 4;
   f32x4 acc[4];
 #pragma unroll
@@ -3453,44 +3475,74 @@ size_t m3p_gemm_wgrad_workspace_bytes(void) {
   return grid * (65536 + 272) * sizeof(float) + grid * sizeof(int);
 }
 
+// four-wave kernel + reduction; pb: optional second product over the same M (paired launch), nullptr = none
+static bool wgrad_w4_ok(int M, int N, int K, int lddy, int ldx, const void* dY, const void* X) {
+  return g_variant >= 1 && g_variant != 3 && (M % 64) == 0 && M >= 4096 && (N % 256) == 0 && (K % 256) == 0 &&
+         (lddy % 8) == 0 && (ldx % 8) == 0 && !((uintptr_t)dY & 15) && !((uintptr_t)X & 15);
+}
+static int launch_wgrad_w4(const void* dY, int lddy, const void* X, int ldx, float* dW, int lddw, int M, int N, int K,
+                           float alpha, void* workspace, size_t workspace_bytes, void* stream, const WgradProblem* pb_in) {
+  const int ti = N / 256, tj = K / 256;
+  WgradProblem pb = {};
+  if (pb_in) pb = *pb_in;
+  const int ntile = ti * tj + pb.tiles_i * pb.tiles_j;
+  const size_t lds = 2 * 65536;
+  static bool attr_set_w = false;
+  if (!attr_set_w) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_wgrad_w4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    attr_set_w = true;
+  }
+  const int grid = num_cus();
+  const int nmt = M / 64;
+  long long share = ((long long)ntile * nmt + grid - 1) / grid;
+  int chunk = (int)(share < nmt ? (share < 1 ? 1 : share) : nmt);
+  if ((long long)ntile >= 4LL * grid) chunk = 0;   // many tiles: round-robin whole tiles
+  if (pb_in && chunk == 0) return M3P_EINVAL;       // (pairs only in the one-segment-per-workgroup mode; the caller checks)
+  // workspace for first-segment partials: one 256-KB slot per workgroup + a tile-id word each, owned by the
+  // CALLER (m3p_gemm_wgrad_workspace_bytes): launches that may overlap on different streams need one each.
+  // Without it the partial tiles go to dW with fp32 atomics (slower: DESIGN.md section 4).
+  float* ws = nullptr;
+  if (workspace && workspace_bytes >= m3p_gemm_wgrad_workspace_bytes() && (((uintptr_t)workspace & 15) == 0) && chunk != 0 &&
+      (lddw % 4) == 0 && (((uintptr_t)dW & 15) == 0) && (!pb_in || ((pb.lddw % 4) == 0 && (((uintptr_t)pb.dW & 15) == 0))))
+    ws = (float*)workspace;
+  int* ws_tile = ws ? (int*)(ws + (size_t)grid * (65536 + 272)) : nullptr;
+  hipLaunchKernelGGL(gemm_wgrad_w4_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, (const bf16*)dY, lddy,
+                     (const bf16*)X, ldx, dW, lddw, M, N, K, alpha, ti, tj, chunk, ws, ws_tile, g_ablate, pb);
+  M3P_CHECK_LAUNCH();
+  if (ws) {
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(16, ntile), dim3(256), 0, (hipStream_t)stream, (const float*)ws,
+                       (const int*)ws_tile, grid, dW, lddw, tj, alpha, ti * tj, pb);
+    M3P_CHECK_LAUNCH();
+  }
+  return M3P_OK;
+}
+
+int m3p_gemm_wgrad_pair_bf16(const void* dYa, int lddya, const void* Xa, int ldxa, float* dWa, int lddwa, int Na, int Ka,
+                             const void* dYb, int lddyb, const void* Xb, int ldxb, float* dWb, int lddwb, int Nb, int Kb,
+                             int M, float alpha, void* workspace, size_t workspace_bytes, void* stream) {
+  if (M <= 0 || Na <= 0 || Ka <= 0 || Nb <= 0 || Kb <= 0) return M3P_EINVAL;
+  const bool pair = wgrad_w4_ok(M, Na, Ka, lddya, ldxa, dYa, Xa) && wgrad_w4_ok(M, Nb, Kb, lddyb, ldxb, dYb, Xb) &&
+                    workspace && workspace_bytes >= m3p_gemm_wgrad_workspace_bytes() &&
+                    (long long)((Na / 256) * (Ka / 256) + (Nb / 256) * (Kb / 256)) * 2 <= num_cus();
+  if (!pair) {
+    int rc = m3p_gemm_wgrad_bf16(dYa, lddya, Xa, ldxa, dWa, lddwa, M, Na, Ka, alpha, workspace, workspace_bytes, stream);
+    if (rc != M3P_OK) return rc;
+    return m3p_gemm_wgrad_bf16(dYb, lddyb, Xb, ldxb, dWb, lddwb, M, Nb, Kb, alpha, workspace, workspace_bytes, stream);
+  }
+  if (lddya < Na || ldxa < Ka || lddyb < Nb || ldxb < Kb) return M3P_EINVAL;
+  WgradProblem pb = {(const bf16*)dYb, (const bf16*)Xb, dWb, lddyb, ldxb, lddwb, Nb / 256, Kb / 256};
+  return launch_wgrad_w4(dYa, lddya, Xa, ldxa, dWa, lddwa, M, Na, Ka, alpha, workspace, workspace_bytes, stream, &pb);
+}
+
 int m3p_gemm_wgrad_bf16(const void* dY, int lddy, const void* X, int ldx, float* dW, int lddw, int M, int N, int K,
                         float alpha, void* workspace, size_t workspace_bytes, void* stream) {
   if (M <= 0 || N <= 0 || K <= 0 || (lddy % 8) != 0 || (ldx % 8) != 0) return M3P_EINVAL;
   if (lddy < ((N + 7) / 8) * 8 || ldx < ((K + 7) / 8) * 8) return M3P_EINVAL;
   if (((uintptr_t)dY & 15) || ((uintptr_t)X & 15)) return M3P_EINVAL;
-  if (g_variant >= 1 && g_variant != 3 && (M % 64) == 0 && M >= 4096 && (N % 256) == 0 && (K % 256) == 0 &&
+  if (wgrad_w4_ok(M, N, K, lddy, ldx, dY, X) &&
       (N / 256) * (K / 256) >= ((g_ablate & 16) ? 1 : 9)) {      // (768 x 768 = 9 tiles included since the four-wave kernel lost its scalar overhead: 63 against 74 us on the ring kernel)
-    // full 256x256 tiles: four-wave kernel
-    const int ti = N / 256, tj = K / 256;
-    const size_t lds = 2 * 65536;
-    static bool attr_set_w = false;
-    if (!attr_set_w) {
-      hipError_t e = hipFuncSetAttribute((const void*)gemm_wgrad_w4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return (int)e;
-      attr_set_w = true;
-    }
-    const int grid = num_cus();
-    const int nmt = M / 64;
-    long long share = ((long long)ti * tj * nmt + grid - 1) / grid;
-    int chunk = (int)(share < nmt ? (share < 1 ? 1 : share) : nmt);
-    if ((long long)ti * tj >= 4LL * grid) chunk = 0;   // many tiles: round-robin whole tiles
-    // workspace for first-segment partials: one 256-KB slot per workgroup + a tile-id word each, owned by the
-    // CALLER (m3p_gemm_wgrad_workspace_bytes): launches that may overlap on different streams need one each.
-    // Without it the partial tiles go to dW with fp32 atomics (slower: DESIGN.md section 4).
-    float* ws = nullptr;
-    if (workspace && workspace_bytes >= m3p_gemm_wgrad_workspace_bytes() && (((uintptr_t)workspace & 15) == 0) && chunk != 0 &&
-        (lddw % 4) == 0 && (((uintptr_t)dW & 15) == 0))
-      ws = (float*)workspace;
-    int* ws_tile = ws ? (int*)(ws + (size_t)grid * (65536 + 272)) : nullptr;
-    hipLaunchKernelGGL(gemm_wgrad_w4_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, (const bf16*)dY, lddy,
-                       (const bf16*)X, ldx, dW, lddw, M, N, K, alpha, ti, tj, chunk, ws, ws_tile, g_ablate);
-    M3P_CHECK_LAUNCH();
-    if (ws) {
-      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(16, ti * tj), dim3(256), 0, (hipStream_t)stream, (const float*)ws,
-                         (const int*)ws_tile, grid, dW, lddw, tj, alpha);
-      M3P_CHECK_LAUNCH();
-    }
-    return M3P_OK;
+    return launch_wgrad_w4(dY, lddy, X, ldx, dW, lddw, M, N, K, alpha, workspace, workspace_bytes, stream, nullptr);
   }
   if (g_variant >= 1 && (M % BK) == 0 && M >= 4096) {
     const int ti = (N + WR_I - 1) / WR_I, tj = (K + WR_J - 1) / WR_J;

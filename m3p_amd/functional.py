@@ -656,11 +656,11 @@ class EncoderFn(torch.autograd.Function):
                                            seed=seed('attn_out', i), p_drop=p_drop)
             if dAO is None:
                 dAO = dpre1
-            ops.gemm_wgrad(dAO, ctxt, ar.g(a + 'out_lin.weight'))
             dctx = dgrad(dAO, i, 'dao', 'wout', ar.wt[('out', i)], L.EPI_NONE)
             dqkv = ops.attn_bwd(qkv, totlen, ctxt, dctx, lse[0], B, S, H, dh, dbias_qkv=ar.qkv_bias(i, grad=True),
                                 seed=seed('attn_p', i), p_drop=p_attn, keepmask=lse[1])
-            ops.gemm_wgrad(dqkv, h_in, ar.qkv_wgrad(i))
+            # out_lin's and q/k/v's weight gradients in one launch (9 + 27 output tiles fill the CUs like one FFN gradient)
+            ops.gemm_wgrad_pair(dqkv, h_in, ar.qkv_wgrad(i), dAO, ctxt, ar.g(a + 'out_lin.weight'))
             dh_ = dgrad(dqkv, i, 'dqkv', 'wqkv', ar.wt[('qkv', i)], L.EPI_RES, aux=dpre1)
             del dqkv, dctx, dAO, dpre1, dx1
             ar.touch_layer(i)

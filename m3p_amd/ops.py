@@ -184,6 +184,23 @@ def gemm_wgrad(dy, x, dw, alpha=1.0, n=None, k=None):
     return dw
 
 
+def gemm_wgrad_pair(dy_a, x_a, dw_a, dy_b, x_b, dw_b, alpha=1.0):
+    """dw_a += alpha * dy_a^T @ x_a and dw_b += alpha * dy_b^T @ x_b (same M) in one launch where the shapes allow."""
+    _chk_bf16(dy_a, x_a, dy_b, x_b)
+    assert dw_a.dtype == torch.float32 and dw_b.dtype == torch.float32 and dw_a.stride(-1) == 1 and dw_b.stride(-1) == 1
+    M = dy_a.shape[0]
+    assert x_a.shape[0] == M and dy_b.shape[0] == M and x_b.shape[0] == M
+    Na, Ka, Nb, Kb = dy_a.shape[1], x_a.shape[1], dy_b.shape[1], x_b.shape[1]
+    assert dw_a.shape[0] >= Na and dw_a.shape[1] >= Ka and dw_b.shape[0] >= Nb and dw_b.shape[1] >= Kb
+    e0 = _prof_begin(('gemm_wgrad_pair', M, Na + Nb, Ka))
+    ws = _wgrad_workspace(dy_a.device)
+    rc = L.load().m3p_gemm_wgrad_pair_bf16(dy_a.data_ptr(), dy_a.stride(0), x_a.data_ptr(), x_a.stride(0), dw_a.data_ptr(), dw_a.stride(0),
+                                           Na, Ka, dy_b.data_ptr(), dy_b.stride(0), x_b.data_ptr(), x_b.stride(0), dw_b.data_ptr(),
+                                           dw_b.stride(0), Nb, Kb, M, alpha, ws.data_ptr(), ws.numel(), L.stream())
+    L.check(rc, 'm3p_gemm_wgrad_pair_bf16')
+    _prof_end(e0, ('gemm_wgrad_pair', M, Na + Nb, Ka))
+
+
 def layernorm_fwd(x, gamma, beta, rowmask=None, eps=1e-12):
     _chk_bf16(x)
     rows, d = x.shape

@@ -323,6 +323,25 @@ def test_gemm_wgrad_at_the_benchmarked_sizes(N, K):
                              'differs in %s' % (err, rel_l2(dw2.double(), ref64), rel_l2(ref32.double(), ref64), where))
 
 
+@pytest.mark.parametrize('M,Na,Ka,Nb,Kb', [(41984, 2304, 768, 768, 768), (8192, 768, 768, 256, 512), (4096, 3072, 768, 768, 3072),
+                                           (1000, 100, 64, 768, 768)])
+def test_gemm_wgrad_pair(M, Na, Ka, Nb, Kb):
+    """Two weight gradients over the same rows in one launch (the attention sub-layer's q/k/v + out_lin pair at the benchmarked
+    size; a small pair; a pair with too many tiles and a ragged one, which fall back to two launches): both against fp64
+    products, accumulating into non-zero gradients."""
+    from m3p_amd import ops
+    g = torch.Generator(device='cuda').manual_seed(M + Na)
+    mk = lambda n, sc: (torch.randn((M, (n + 7) // 8 * 8), device='cuda', generator=g) * sc).to(torch.bfloat16)   # noqa: E731
+    dya, xa, dyb, xb = mk(Na, 0.1), mk(Ka, 1.0), mk(Nb, 0.1), mk(Kb, 1.0)
+    dwa, dwb = torch.ones((Na, Ka), device='cuda'), torch.full((Nb, Kb), 2.0, device='cuda')
+    ops.gemm_wgrad_pair(dya[:, :Na], xa[:, :Ka], dwa, dyb[:, :Nb], xb[:, :Kb], dwb)
+    for dw, dy, x, n, k, c in ((dwa, dya, xa, Na, Ka, 1.0), (dwb, dyb, xb, Nb, Kb, 2.0)):
+        ref = torch.full((n, k), c, dtype=torch.float64, device='cuda')
+        for m0 in range(0, M, 8192):
+            ref += dy[m0:m0 + 8192, :n].double().t() @ x[m0:m0 + 8192, :k].double()
+        assert rel_l2(dw.double(), ref) < 1e-5, (n, k)
+
+
 def test_gemm_wgrad_with_fresh_operands_of_changing_shapes():
     """~900 weight-gradient launches, each on freshly allocated operands of another shape, against fp64 products: the pattern
     under which one launch in ~300 returned a wrong half-fragment's worth of one tile before the fragment asm's outputs were

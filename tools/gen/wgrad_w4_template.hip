@@ -11,17 +11,27 @@
 // Full tiles only (N % 256 == 0, K % 256 == 0, M % 64 == 0): everything else stays on the ring kernel.
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256)
-void gemm_wgrad_w4_kernel(const bf16* __restrict__ dY, int lddy, const bf16* __restrict__ X, int ldx,
-                          float* __restrict__ dW, int lddw, int M, int N, int K, float alpha,
-                          int tiles_i, int tiles_j, int WR_CHUNK, float* __restrict__ ws, int* __restrict__ ws_tile,
-                          int dbg_flags) {
+void gemm_wgrad_w4_kernel(const bf16* __restrict__ dY_a, int lddy_a, const bf16* __restrict__ X_a, int ldx_a,
+                          float* __restrict__ dW_a, int lddw_a, int M, int N, int K, float alpha,
+                          int tiles_i, int tiles_j_a, int WR_CHUNK, float* __restrict__ ws, int* __restrict__ ws_tile,
+                          int dbg_flags, WgradProblem pb) {
+  // Two products over the same M in one launch (pb.tiles != 0; one-segment-per-workgroup mode only): the tiles of product b
+  // follow those of product a in the tile numbering, every workgroup picks its product once, before the K loop.  36 tiles of
+  // out_lin + q/k/v then share one launch, one end-of-kernel flush and one reduction instead of 9 tiles x 28 chunks beside
+  // 27 x 9.
+  const bf16* dY = dY_a;
+  const bf16* X = X_a;
+  float* dW = dW_a;
+  int lddy = lddy_a, ldx = ldx_a, lddw = lddw_a, tiles_j = tiles_j_a;
+  int tile_id0 = 0;
   constexpr int TI = 256, TJ = 256, KT = 64;
   constexpr int ROWB = 512;                          // bytes per LDS row of either operand
   constexpr int Y_BYTES = KT * ROWB, STAGE = 2 * Y_BYTES;      // 32 KB, 64 KB
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ntile = tiles_i * tiles_j;
+  const int ntile_a = tiles_i * tiles_j_a;
+  const int ntile = ntile_a + pb.tiles_i * pb.tiles_j;
   const int nmt = M / KT;
   const long long total_all = (long long)ntile * nmt;
   const int nwg = gridDim.x;
@@ -48,6 +58,11 @@ void gemm_wgrad_w4_kernel(const bf16* __restrict__ dY, int lddy, const bf16* __r
     if (slot >= C * ntile) return;
     const int c = slot / ntile;
     seg_tile = slot - c * ntile;
+    if (seg_tile >= ntile_a) {
+      dY = pb.dY; X = pb.X; dW = pb.dW; lddy = pb.lddy; ldx = pb.ldx; lddw = pb.lddw; tiles_j = pb.tiles_j;
+      seg_tile -= ntile_a;
+      tile_id0 = ntile_a;
+    }
     seg_m0 = (int)((long long)c * nmt / C);
     seg_len = (int)((long long)(c + 1) * nmt / C) - seg_m0;
     total = seg_len;
@@ -324,7 +339,7 @@ void gemm_wgrad_w4_kernel(const bf16* __restrict__ dY, int lddy, const bf16* __r
               if (!WG_DBG(1)) unsafeAtomicAdd(dcol + (size_t)(a * 16 + r) * lddw, alpha * v[a * 4 + r]);
         }
       }
-      if (to_ws && tid == 0) ws_tile[slot] = cc.t;
+      if (to_ws && tid == 0) ws_tile[slot] = tile_id0 + cc.t;
       ++n_seg;
       first = true;
     }
@@ -355,9 +370,11 @@ void gemm_wgrad_w4_kernel(const bf16* __restrict__ dY, int lddy, const bf16* __r
 // grid = (16 row groups, ntile); block = 256 threads, each 4 rows x 4 consecutive columns.
 __global__ __launch_bounds__(256)
 void wgrad_reduce_kernel(const float* __restrict__ ws, const int* __restrict__ ws_tile, int nslots,
-                         float* __restrict__ dW, int lddw, int tiles_j, float alpha) {
+                         float* __restrict__ dW, int lddw, int tiles_j, float alpha, int ntile_a, WgradProblem pb) {
   const int t = blockIdx.y, rg = blockIdx.x;
-  const int ti = t / tiles_j, tj = t - ti * tiles_j;
+  int tl = t;
+  if (t >= ntile_a) { tl = t - ntile_a; dW = pb.dW; lddw = pb.lddw; tiles_j = pb.tiles_j; }      // (second product of a paired launch)
+  const int ti = tl / tiles_j, tj = tl - ti * tiles_j;
   const int col = (threadIdx.x & 63) * 4, row0 = rg * 16 + (threadIdx.x >> 6) * 4;
   f32x4 acc[4];
 #pragma unroll
