@@ -390,8 +390,10 @@ M3P_API int m3p_set_persistent_grid(int workgroups);
  * counters: n_slots x 8 int32 in device memory, zeroed by the caller once; every eligible m3p_gemm_nt_bf16 launch (eight-wave
  * kernel, more output tiles than workgroups, K >= 512) takes the next slot - one counter per XCD - and its workgroups pop
  * their output tiles from per-XCD queues instead of a fixed round-robin share, so a CU that runs slower (a collective's kernel
- * resident beside the GEMM under data parallelism) takes fewer tiles instead of stretching the launch; the ring is cleared
- * with a memset node on the launching stream when it wraps (all launches on ONE stream).  Results are the static schedule's. */
+ * resident beside the GEMM under data parallelism) takes fewer tiles instead of stretching the launch.  The ring binds to the
+ * stream of the first queued launch after this call and is cleared by a memset on that stream when it wraps; launches on any
+ * other stream take the static schedule (never a slot another stream's kernel may still be popping from).  Slot hand-out is
+ * serialised inside the library; call this setter with no GEMM of the old ring in flight.  Results are the static schedule's. */
 M3P_API int m3p_set_tile_queue(int32_t* counters, int n_slots);
 
 /* ------------------------------------------------------------------------------------

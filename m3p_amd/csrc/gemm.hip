@@ -19,6 +19,7 @@
 // again on the ds_read_b128 (cdna guide rule 21), which makes the fragment reads
 // conflict-free.  Persistent kernels deal tiles so that each XCD (private L2) walks a
 // strip-blocked run of tiles that share their operand panels.
+#include <mutex>
 #include <type_traits>
 #include "common.hpp"
 #include "../../include/m3p_hip.h"
@@ -2302,8 +2303,29 @@ static int num_cus() {
 }
 
 // dynamic tile queues of the eight-wave kernel (m3p_set_tile_queue): a ring of 8-counter slots, one slot per launch
+// The ring belongs to ONE stream - the first one a queued launch arrives on after m3p_set_tile_queue (slots are cleared by a
+// memset on that stream, behind everything it has launched): a launch on any other stream takes the static schedule, so a
+// slot is never handed out while a kernel of another stream may still be popping from it.  Slot hand-out is under a mutex
+// (forward launches from the Python thread, backward from the autograd thread; ctypes drops the GIL around the calls).
 static int* g_tq_pool = nullptr;
 static int g_tq_slots = 0, g_tq_next = 0;
+static hipStream_t g_tq_stream = nullptr;
+static bool g_tq_bound = false;
+static std::mutex g_tq_mu;
+// -> counters of a fresh slot, or nullptr (no queue / foreign stream / memset failed: *err set)
+static int* tq_acquire(hipStream_t st, hipError_t* err) {
+  *err = hipSuccess;
+  std::lock_guard<std::mutex> lk(g_tq_mu);
+  if (!g_tq_pool) return nullptr;
+  if (!g_tq_bound) { g_tq_stream = st; g_tq_bound = true; }
+  if (st != g_tq_stream) return nullptr;
+  if (g_tq_next == g_tq_slots) {       // ring used up: clear it behind everything this stream has launched so far
+    *err = hipMemsetAsync(g_tq_pool, 0, (size_t)g_tq_slots * 8 * sizeof(int), st);
+    if (*err != hipSuccess) return nullptr;
+    g_tq_next = 0;
+  }
+  return g_tq_pool + 8 * g_tq_next++;
+}
 
 template <int EPI>
 int launch_nt(const bf16* A, int lda, const bf16* W, int ldw, bf16* C, int ldc, int M, int N, int K,
@@ -2343,12 +2365,9 @@ int launch_nt(const bf16* A, int lda, const bf16* W, int ldw, bf16* C, int ldc, 
     constexpr bool kQueueOk = !(EPI == M3P_EPI_DGELU || EPI == M3P_EPI_MUL);
     int* ctr = nullptr;
     if (kQueueOk && g_tq_pool && ntiles > grid && K >= 8 * BK) {
-      if (g_tq_next == g_tq_slots) {       // ring used up: clear it behind everything this stream has launched so far
-        hipError_t e = hipMemsetAsync(g_tq_pool, 0, (size_t)g_tq_slots * 8 * sizeof(int), st);
-        if (e != hipSuccess) return (int)e;
-        g_tq_next = 0;
-      }
-      ctr = g_tq_pool + 8 * g_tq_next++;
+      hipError_t e;
+      ctr = tq_acquire(st, &e);
+      if (e != hipSuccess) return (int)e;
     }
     if constexpr (kQueueOk) if (ctr) {
       auto kern_d = gemm_nt_w8_kernel<EPI, true>;
@@ -3464,9 +3483,11 @@ int m3p_set_persistent_grid(int workgroups) {
 
 int m3p_set_tile_queue(int32_t* counters, int n_slots) {
   if (counters && (n_slots <= 0 || ((uintptr_t)counters & 3))) return M3P_EINVAL;
+  std::lock_guard<std::mutex> lk(g_tq_mu);
   g_tq_pool = counters;
   g_tq_slots = counters ? n_slots : 0;
   g_tq_next = 0;
+  g_tq_bound = false;        // the next queued launch binds the ring to its stream
   return M3P_OK;
 }
 
@@ -3523,7 +3544,10 @@ int m3p_gemm_wgrad_pair_bf16(const void* dYa, int lddya, const void* Xa, int ldx
                              int M, float alpha, void* workspace, size_t workspace_bytes, void* stream) {
   if (M <= 0 || Na <= 0 || Ka <= 0 || Nb <= 0 || Kb <= 0) return M3P_EINVAL;
   const bool pair = wgrad_w4_ok(M, Na, Ka, lddya, ldxa, dYa, Xa) && wgrad_w4_ok(M, Nb, Kb, lddyb, ldxb, dYb, Xb) &&
-                    workspace && workspace_bytes >= m3p_gemm_wgrad_workspace_bytes() &&
+                    workspace && workspace_bytes >= m3p_gemm_wgrad_workspace_bytes() && (((uintptr_t)workspace & 15) == 0) &&
+                    // (the workspace form's own conditions - launch_wgrad_w4 - so that a pair never lands on the atomic flush)
+                    (lddwa % 4) == 0 && (lddwb % 4) == 0 && (((uintptr_t)dWa | (uintptr_t)dWb) & 15) == 0 &&
+                    lddwa >= Ka && lddwb >= Kb &&
                     (long long)((Na / 256) * (Ka / 256) + (Nb / 256) * (Kb / 256)) * 2 <= num_cus();
   if (!pair) {
     int rc = m3p_gemm_wgrad_bf16(dYa, lddya, Xa, ldxa, dWa, lddwa, M, Na, Ka, alpha, workspace, workspace_bytes, stream);
@@ -3537,7 +3561,7 @@ int m3p_gemm_wgrad_pair_bf16(const void* dYa, int lddya, const void* Xa, int ldx
 
 int m3p_gemm_wgrad_bf16(const void* dY, int lddy, const void* X, int ldx, float* dW, int lddw, int M, int N, int K,
                         float alpha, void* workspace, size_t workspace_bytes, void* stream) {
-  if (M <= 0 || N <= 0 || K <= 0 || (lddy % 8) != 0 || (ldx % 8) != 0) return M3P_EINVAL;
+  if (M <= 0 || N <= 0 || K <= 0 || (lddy % 8) != 0 || (ldx % 8) != 0 || !dW || lddw < K) return M3P_EINVAL;
   if (lddy < ((N + 7) / 8) * 8 || ldx < ((K + 7) / 8) * 8) return M3P_EINVAL;
   if (((uintptr_t)dY & 15) || ((uintptr_t)X & 15)) return M3P_EINVAL;
   if (wgrad_w4_ok(M, N, K, lddy, ldx, dY, X) &&

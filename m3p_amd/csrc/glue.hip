@@ -110,13 +110,20 @@ void itm_loss_kernel(const float* __restrict__ scores, const long long* __restri
   const float inv_g = 1.f / (float)G, inv_all = 1.f / ((float)G * (float)n);
   for (int g = threadIdx.x; g < G; g += blockDim.x) {
     const float* s = scores + (size_t)g * n;
-    const int p = (int)pos[g];
-    float mx = -INFINITY;
-    for (int j = 0; j < n; ++j) mx = fmaxf(mx, s[j]);
-    float se = 0.f;
-    for (int j = 0; j < n; ++j) se += __expf(s[j] - mx);
-    const float lse = mx + __logf(se);
-    float l = 0.f;
+    const long long p64 = pos[g];
+    // a label outside [0, n) is a caller bug (F.one_hot / cross_entropy raise on it): no out-of-bounds read, and the loss
+    // comes back NaN so that it cannot go unnoticed
+    const bool bad = p64 < 0 || p64 >= n;
+    const int p = bad ? 0 : (int)p64;
+    float lse = 0.f;
+    if (w_ce != 0.f) {
+      float mx = -INFINITY;
+      for (int j = 0; j < n; ++j) mx = fmaxf(mx, s[j]);
+      float se = 0.f;
+      for (int j = 0; j < n; ++j) se += __expf(s[j] - mx);
+      lse = mx + __logf(se);
+    }
+    float l = bad ? __builtin_nanf("") : 0.f;
     if (w_ce != 0.f) l += w_ce * inv_g * (lse - s[p]);
     for (int j = 0; j < n; ++j) {
       const float y = (j == p) ? 1.f : 0.f;
@@ -156,7 +163,7 @@ int m3p_seq_masks(const int64_t* lengths, const int64_t* lengths_b, int B, int S
 
 int m3p_mask_to_rows(const uint8_t* mask, int n_mask, int inner, long long s0, long long s1, long long soff, int d,
                      int32_t* rows, int n_rows, void* stream) {
-  if (n_mask <= 0 || n_mask > (1 << 20) || inner <= 0 || d <= 0 || n_rows < 0 || !mask || (n_rows && !rows)) return M3P_EINVAL;
+  if (n_mask <= 0 || inner <= 0 || d <= 0 || n_rows < 0 || !mask || (n_rows && !rows)) return M3P_EINVAL;
   if (n_rows == 0) return M3P_OK;
   hipLaunchKernelGGL(mask_to_rows_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, mask, n_mask, inner, s0, s1, soff, d,
                      rows, n_rows);

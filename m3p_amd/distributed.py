@@ -30,8 +30,10 @@ numerically the all-reduce's result - SURVEY 8e):
   forward    the updated fp32 master shards are ``all_gather``ed bucket by bucket in FORWARD order on the side
              stream, each followed by its bf16 cast (and, after the last, the transposed copies backward reads);
              the next step's forward waits per bucket (``params_ready``), so the gather hides under it.
-             Every rank therefore holds the full, identical fp32 master again before anything reads it
-             (checkpoints, evaluation, the fp32 bias / LayerNorm reads of the kernels).
+             Every rank therefore holds the full, identical fp32 master again before anything reads it: the
+             kernels' fp32 bias / LayerNorm reads sit behind ``params_ready(key)`` in forward, checkpoints behind
+             ``params_ready(None)`` in ``Trainer._state_dicts``.  The Adam moments are NOT gathered: a checkpoint
+             carries the saving rank's shards (the reference's reload restores ``num_updates`` only, and so does ours).
 
 ``mode = 'allreduce'`` (other world sizes, or ``M3P_DP_MODE=allreduce``) is round 2's protocol: fp32
 ``all_reduce`` per bucket, Adam replicated.  Half of the zero1 wire traffic moves from backward to the next

@@ -368,6 +368,13 @@ class TransformerModel(nn.Module):
             self._arena = Fn.Arena(self)
         return self._arena
 
+    def state_dict(self, *args, **kw):
+        # under sharded data parallelism the fp32 master is completed by all-gathers on a side stream: wait for them
+        # (stream-level) before anything copies the parameters out
+        if self.ddp_hook is not None:
+            self.ddp_hook.params_ready(None)
+        return super().state_dict(*args, **kw)
+
     def load_state_dict(self, state_dict, strict=True, **kw):
         res = super().load_state_dict(state_dict, strict=strict, **kw)
         if self._arena is not None:

@@ -4,12 +4,14 @@ Each allocates its outputs with torch (device memory + caching allocator are plu
 passes raw device pointers and the current HIP stream across the C ABI and raises on any
 error code.  The autograd layer (m3p_amd/functional.py) composes these."""
 import ctypes as C
+import os
 
 import torch
 
 from . import lib as L
 
 BF16 = torch.bfloat16
+_DEBUG_CHECKS = os.environ.get('M3P_DEBUG_CHECKS') == '1'      # host-synchronising consistency checks (tests, debugging)
 
 # bench.py sets this to a dict to time individual GEMM launches with HIP events recorded on
 # the launch stream: {(kind, M, N, K): [(start_event, end_event), ...]}
@@ -365,6 +367,8 @@ def mask_to_rows(mask, inner, s0, s1, soff, d, n_rows):
         m = m.view(torch.uint8)
     assert m.dtype == torch.uint8 and m.is_contiguous()
     rows = torch.empty((n_rows,), dtype=torch.int32, device=m.device)
+    if _DEBUG_CHECKS:      # (M3P_DEBUG_CHECKS=1: a host sync per call - fewer True entries than n_rows would point the tail at row 0)
+        assert int(m.sum().item()) == n_rows, 'mask holds %d True entries, the caller counted %d' % (int(m.sum().item()), n_rows)
     L.check(L.load().m3p_mask_to_rows(m.data_ptr(), m.numel(), inner, s0, s1, soff, d, rows.data_ptr(), n_rows, L.stream()),
             'm3p_mask_to_rows')
     return rows

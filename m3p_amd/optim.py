@@ -185,31 +185,37 @@ class Adam(optim.Optimizer):
         return loss
 
 
+def inverse_sqrt_schedule(peak_lr, warmup, floor_lr, power):
+    """lr(t) of optim.py:116-133 as one closed form: a straight line from `floor_lr` (t = 0) to `peak_lr` (t = warmup),
+    then peak_lr * (warmup / t) ** power.  Returned as a function of the update count."""
+    def lr_at(t):
+        if t < warmup:
+            return floor_lr + (peak_lr - floor_lr) * t / warmup
+        return peak_lr * (warmup / t) ** power
+    return lr_at
+
+
 class AdamInverseSqrtWithWarmup(Adam):
-    """optim.py:89-139."""
+    """Adam whose lr follows `inverse_sqrt_schedule` (optim.py:89-139): built at the floor rate, every `step()` counts
+    one update per parameter group (`num_updates`, which checkpoints carry) and moves the group's lr along the curve."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, warmup_updates=4000,
                  warmup_init_lr=1e-7, exp_factor=0.5):
         super().__init__(params, lr=warmup_init_lr, betas=betas, eps=eps, weight_decay=weight_decay)
-        self.warmup_updates = warmup_updates
-        self.warmup_init_lr = warmup_init_lr
-        warmup_end_lr = lr
-        self.lr_step = (warmup_end_lr - warmup_init_lr) / warmup_updates
-        self.exp_factor = exp_factor
-        self.decay_factor = warmup_end_lr * warmup_updates ** self.exp_factor
-        for param_group in self.param_groups:
-            param_group['num_updates'] = 0
+        self.schedule = dict(peak_lr=lr, warmup=warmup_updates, floor_lr=warmup_init_lr, power=exp_factor)
+        self._lr_at = inverse_sqrt_schedule(**self.schedule)
+        for group in self.param_groups:
+            group['num_updates'] = 0
 
     def get_lr_for_step(self, num_updates):
-        if num_updates < self.warmup_updates:
-            return self.warmup_init_lr + num_updates * self.lr_step
-        return self.decay_factor * (num_updates ** -self.exp_factor)
+        return self._lr_at(num_updates)
 
     def step(self, closure=None):
-        super().step(closure)
-        for param_group in self.param_groups:
-            param_group['num_updates'] += 1
-            param_group['lr'] = self.get_lr_for_step(param_group['num_updates'])
+        out = super().step(closure)
+        for group in self.param_groups:
+            group['num_updates'] += 1
+            group['lr'] = self._lr_at(group['num_updates'])
+        return out
 
 
 def clip_grad_norm_(parameters, max_norm, optimizer):

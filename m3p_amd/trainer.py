@@ -89,7 +89,13 @@ class Trainer(object):
         self.set_parameters()
         assert params.amp >= 1 or not params.fp16
         # bf16 compute with fp32 master weights is the only precision mode of this build;
-        # `amp`/`fp16` are accepted for flag compatibility (no loss scaling: bf16 keeps fp32's range)
+        # `amp`/`fp16` are accepted for flag compatibility (no loss scaling: bf16 keeps fp32's range).
+        # The reference's amp == -1 branch (xtrainer.py:218-228) trains in fp32; here it runs the SAME bf16 kernels
+        # (MI355X fp32 MFMA is 1/16 of the bf16 rate) - said once per run so nobody reads the flag as a precision promise
+        if params.amp == -1 and not getattr(Trainer, '_warned_fp32', False):
+            Trainer._warned_fp32 = True
+            logger.warning('amp == -1 requests fp32 training in the reference; this build computes in bf16 with fp32 '
+                           'master weights, gradients and optimizer state (INTEGRATION.md, "precision")')
         self.set_optimizers()
         if getattr(params, 'multi_gpu', False):
             logger.info('Using m3p_amd.distributed.DataParallel (bucketed RCCL all-reduce) ...')
@@ -521,6 +527,15 @@ class Trainer(object):
         return loss.detach()
 
     def _state_dicts(self):
+        # sharded data parallelism (distributed.py, zero1): the other ranks' shards of the updated fp32 master arrive through
+        # all-gathers on the side stream that only the next forward waits for - a save straight after an optimizer step has to
+        # wait for them too (a stream-level wait, no collective: every rank holds the full master once they have landed, so
+        # master-only callers like save_best_model are fine).  The Adam MOMENTS stay sharded: a checkpoint holds this rank's
+        # shards of them (zeros elsewhere); neither the reference's reload (xtrainer.py:586-592) nor ours reads them back.
+        for n in self.MODEL_NAMES:
+            hook = getattr(_unwrap(getattr(self, n)), 'ddp_hook', None)
+            if hook is not None:
+                hook.params_ready(None)
         return {n: {k: v.detach().cpu().clone() for k, v in _unwrap(getattr(self, n)).state_dict().items()}
                 for n in self.MODEL_NAMES}
 
