@@ -51,7 +51,14 @@ enum {
   M3P_EPI_BIAS_DROP_RES = 3, /* C = dropout(acc + bias) + aux                            */
   M3P_EPI_RES = 4,           /* C = alpha*acc + aux                                      */
   M3P_EPI_DGELU = 5,         /* C = acc * gelu_erf'(aux); colsum[n] += sum_m C (optional) */
-  M3P_EPI_MUL = 6            /* C = acc * aux;            colsum[n] += sum_m C (optional) */
+  M3P_EPI_MUL = 6,           /* C = acc * aux;            colsum[n] += sum_m C (optional) */
+  M3P_EPI_MULQ = 7           /* C = acc * decode(aux);    colsum likewise.  aux = the one-byte gelu' codes m3p_gelu_fwd_gq
+                                wrote for this [M, N] in the GEMM's fragment order (M, N multiples of 256, M >= 1024,
+                                K % 64 == 0: the eight-wave kernel only - anything else returns M3P_EINVAL) */
+  ,
+  M3P_EPI_BIAS_GELUQ = 8     /* u = acc + bias (fp32) is NOT stored; C = gelu_erf(u); out2 = uint8 [M * N]: gelu_erf'(u) as
+                                one-byte codes in the fragment order M3P_EPI_MULQ reads (same shape limits; bias required):
+                                the FFN lin1 + activation of transformer.py:223 with what backward needs kept in a byte */
 };
 
 typedef struct M3PEpilogue {
@@ -341,6 +348,12 @@ M3P_API int m3p_adam_step(float* p, float* g, float* m, float* v, void* w16, lon
  * dh (nullable, may alias u): also writes gelu_erf'(u) in bf16, which the backward FFN dgrad
  * then applies with M3P_EPI_MUL instead of recomputing the derivative in the GEMM epilogue. */
 M3P_API int m3p_gelu_fwd(const void* u, void* h, void* dh, long long n, void* stream);
+/* The same activation for the persistent-GEMM FFN (transformer.py:223-225, gelu :48-56) leaving what backward needs in ONE
+ * byte per element: h (bf16 [M, N], contiguous) = gelu_erf(u), gq (uint8, M * N bytes) = gelu_erf'(u) quantised to 256
+ * levels over [-0.13, 1.13] (|error| <= 2.5e-3), stored in the fragment order of the eight-wave NT GEMM's 256 x 256 tiles
+ * so that the FFN data gradient m3p_gemm_nt_bf16(..., M3P_EPI_MULQ, aux = gq) multiplies by it without a layout change.
+ * u itself is not needed after this call.  M % 256 == 0, N % 256 == 0; u, h contiguous and 16-byte aligned. */
+M3P_API int m3p_gelu_fwd_gq(const void* u, void* h, void* gq, int M, int N, void* stream);
 /* The same pass also writing h8 = e4m3(scale * h) (uint8 [n]) and raising *amax to max |h| (nullable): the operand of the
  * fp8 lin2 product without a second pass over h (m3p_quant_fp8 of h gives the same bytes). */
 M3P_API int m3p_gelu_fwd_q8(const void* u, void* h, void* h8, long long n, const float* scale, float* amax, void* stream);

@@ -73,6 +73,22 @@ __device__ __forceinline__ float gelu_erf_grad_f(float x) {
   return g.cdf + x * g.pdf;
 }
 
+// gelu_erf'(u) in ONE byte for the FFN data gradient (M3P_EPI_MULQ): gelu' lies in [-0.1290, 1.1290], the code is the
+// nearest of 256 levels over [-0.13, 1.13] (step 1.26 / 255 = 4.9e-3: |error| <= 2.5e-3, rms 1.4e-3 - the size of the bf16
+// rounding of the gradient it multiplies), decoded with one fma.  The range is symmetric about 1/2 like gelu' itself
+// (gelu'(-u) = 1 - gelu'(u)  <->  code(-u) = 255 - code(u)).
+constexpr float GQ_OFF = 0.13f, GQ_STEP = 1.26f / 255.0f, GQ_INV = 255.0f / 1.26f;
+__device__ __forceinline__ uint32_t gelu_grad_code(float g) {
+  return (uint32_t)__builtin_rintf(fminf(fmaxf((g + GQ_OFF) * GQ_INV, 0.f), 255.f));
+}
+// Fragment order of the code bytes of an [M, N] activation (M, N multiples of 256): the bytes of a 256 x 256 tile follow the
+// eight-wave GEMM's accumulator layout, so that its epilogue fetches a 16-row block of a wave's share with ONE coalesced
+// 16-byte load per lane and no trip through LDS:   tile (tm, tn) -> wave w = 4 (row half) + (64-column quarter)
+//   -> row block i (16 rows) -> lane l = 16 fg + fr -> 16 bytes (j, r): element (row 128 wm + 16 i + fr, col 64 wn + 16 j + 4 fg + r)
+__device__ __forceinline__ size_t gq_block_offset(int tm, int tn, int tiles_n, int w, int i) {
+  return ((((size_t)tm * tiles_n + tn) * 8 + w) * 8 + i) * 1024;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

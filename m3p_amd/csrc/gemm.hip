@@ -506,6 +506,110 @@ __device__ __forceinline__ void epilogue_piece16(const M3PEpilogue& ep, bf16* __
   }
 }
 
+// 16-row piece of the byte-derivative epilogue (M3P_EPI_MULQ): out = acc * decode(code), column sums.  `q` holds this
+// lane's sixteen codes of the piece in accumulator order (dword j = columns 16 j + 4 fg .. + 3 of row fr: the fragment-order
+// layout of common.hpp, fetched by the caller with one 16-byte load) - no aux trip through LDS, three VALU per element.
+__device__ __forceinline__ void epilogue_pieceq(bf16* __restrict__ C, int ldc, int mrow0, int nw, char* r1, const f32x4 (&rows)[4],
+                                                const u32x4& q, int lane, f32x4 (&csum)[4]) {
+  const int fr = lane & 15, fg = lane >> 4;
+  const int srow = lane >> 3, sch = lane & 7;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint32_t w = q[j];
+    f32x4 g = f32x4{(float)(w & 0xFFu), (float)((w >> 8) & 0xFFu), (float)((w >> 16) & 0xFFu), (float)(w >> 24)};   // v_cvt_f32_ubyte0..3
+    g = g * GQ_STEP - GQ_OFF;
+    const f32x4 v = rows[j] * g;
+    const bf16x4 ob = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+    *reinterpret_cast<bf16x4*>(r1 + ep_off8<true>(fr, (j * 16 + fg * 4) * 2)) = ob;
+    csum[j] += f32x4{(float)ob[0], (float)ob[1], (float)ob[2], (float)ob[3]};
+  }
+  bf16* Cp = C + (size_t)mrow0 * ldc + nw + sch * 8;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int row = it * 8 + srow;
+    *reinterpret_cast<u32x4*>(Cp + (size_t)row * ldc) = flip_halves(*reinterpret_cast<const u32x4*>(r1 + ep_off<true>(row, sch * 16)), it & 1);
+  }
+}
+
+#ifndef M3P_MULQ_MODE
+#define M3P_MULQ_MODE 0
+#endif
+// the same for a 32-row piece (two 16-row blocks through 4 KB of swizzled staging rows, four 16-byte row stores per lane)
+__device__ __forceinline__ void epilogue_halfq(bf16* __restrict__ C, int ldc, int mrow0, int nw, char* r1, const f32x4 (&rows0)[4],
+                                               const f32x4 (&rows1)[4], const u32x4& q0, const u32x4& q1, int lane, f32x4 (&csum)[4]) {
+  const int fr = lane & 15, fg = lane >> 4;
+  const int srow = lane >> 3, sch = lane & 7;
+#pragma unroll
+  for (int ii = 0; ii < 2; ++ii) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t w = ii ? q1[j] : q0[j];
+      f32x4 g = f32x4{(float)(w & 0xFFu), (float)((w >> 8) & 0xFFu), (float)((w >> 16) & 0xFFu), (float)(w >> 24)};
+      g = g * GQ_STEP - GQ_OFF;
+      const f32x4 v = (ii ? rows1[j] : rows0[j]) * g;
+      const bf16x4 ob = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+      *reinterpret_cast<bf16x4*>(r1 + ep_off8<true>(ii * 16 + fr, (j * 16 + fg * 4) * 2)) = ob;
+      csum[j] += f32x4{(float)ob[0], (float)ob[1], (float)ob[2], (float)ob[3]};
+    }
+  }
+  bf16* Cp = C + (size_t)mrow0 * ldc + nw + sch * 8;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int row = it * 8 + srow;
+    *reinterpret_cast<u32x4*>(Cp + (size_t)row * ldc) = flip_halves(*reinterpret_cast<const u32x4*>(r1 + ep_off<true>(row, sch * 16)), it & 1);
+  }
+}
+
+// 32-row piece of the FFN1 epilogue that leaves BOTH things the layer needs of u = acc + bias (M3P_EPI_BIAS_GELUQ):
+// h = gelu_erf(u) staged to row order like any output tile, and gelu_erf'(u) as one byte per element written
+// straight from the accumulator layout in fragment order (16 bytes per lane and 16-row block: 1 KB per wave instruction,
+// no staging) - what M3P_EPI_MULQ reads back the same way.  u itself is never stored.  The arithmetic is written on
+// four-element vectors so that the polynomial runs on packed f32 instructions (the epilogue has the VALU to itself).
+__device__ __forceinline__ void epilogue_half_geluq(bf16* __restrict__ C, int ldc, uint8_t* __restrict__ qout, int mrow0, int nw,
+                                                    char* r1, const f32x4 (&rows0)[4], const f32x4 (&rows1)[4],
+                                                    const f32x4 (&biasv)[4], int lane) {
+  const int fr = lane & 15, fg = lane >> 4;
+  const int srow = lane >> 3, sch = lane & 7;
+#pragma unroll
+  for (int ii = 0; ii < 2; ++ii) {
+    u32x4 code;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      // (x stays fp32: with u never stored there is no bf16 copy anything else would have to agree with)
+      const f32x4 x = (ii ? rows1[j] : rows0[j]) + biasv[j];
+      // gelu_parts (common.hpp) on a vector: Phi(|x|) = 1 - (poly(t) t e) / 2, t = 1 / (1 + p z), z = |x| / sqrt 2, e = exp(-z^2)
+      f32x4 z, t, e;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) z[r] = fabsf(x[r]);
+      z *= 0.70710678118654752440f;
+      const f32x4 den = z * 0.3275911f + 1.0f;
+      const f32x4 ez = z * z * -1.4426950408889634f;          // exp(-z^2) = exp2(-z^2 log2 e)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { t[r] = __builtin_amdgcn_rcpf(den[r]); e[r] = __builtin_amdgcn_exp2f(ez[r]); }
+      f32x4 poly = t * 1.061405429f - 1.453152027f;
+      poly = poly * t + 1.421413741f;
+      poly = poly * t - 0.284496736f;
+      poly = poly * t + 0.254829592f;
+      const f32x4 tail = poly * t * e * 0.5f;                 // 1 - Phi(|x|)
+      f32x4 cdf;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cdf[r] = (x[r] >= 0.f) ? 1.0f - tail[r] : tail[r];
+      const f32x4 hv = x * cdf;
+      const f32x4 gd = x * e * 0.39894228040143267794f + cdf;                  // gelu'(x) = Phi + x phi
+      const f32x4 qf = gd * GQ_INV + (GQ_OFF * GQ_INV + 0.5f);                 // in [0.7, 255.3): truncation = round to nearest
+      code[j] = (uint32_t)qf[0] | ((uint32_t)qf[1] << 8) | ((uint32_t)qf[2] << 16) | ((uint32_t)qf[3] << 24);
+      *reinterpret_cast<bf16x4*>(r1 + ep_off8<true>(ii * 16 + fr, (j * 16 + fg * 4) * 2)) = bf16x4{(bf16)hv[0], (bf16)hv[1], (bf16)hv[2], (bf16)hv[3]};
+    }
+    *reinterpret_cast<u32x4*>(qout + ii * 1024 + lane * 16) = code;
+  }
+  bf16* Cp = C + (size_t)mrow0 * ldc + nw + sch * 8;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int row = it * 8 + srow;
+    *reinterpret_cast<u32x4*>(Cp + (size_t)row * ldc) = flip_halves(*reinterpret_cast<const u32x4*>(r1 + ep_off<true>(row, sch * 16)), it & 1);
+  }
+}
+
 #if defined(M3P_RING_TL) || defined(M3P_W8_TL) || defined(M3P_WG_TL)
 __device__ unsigned long long g_ring_tl[256 * 8 * 16];  // debug build: per-wave cycle sums of the eight-wave kernel's segments
                                                         // ([256][8][8] segments, then [256][8][8] K-tile phases of the w8 kernel)
@@ -853,7 +957,7 @@ void gemm_nt_w8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
   // output tile's last K-tile vacated: the next tile's K-tile 1 is then requested on schedule and nobody has to meet at a
   // barrier after the epilogue.
   constexpr bool kSpare = M3P_W8_SPARE_EPILOGUE;
-  constexpr bool kMulE = (EPI == M3P_EPI_DGELU || EPI == M3P_EPI_MUL);
+  constexpr bool kMulE = (EPI == M3P_EPI_DGELU || EPI == M3P_EPI_MUL || EPI == M3P_EPI_MULQ);
   constexpr bool kAuxE = (EPI == M3P_EPI_BIAS_DROP_RES || EPI == M3P_EPI_RES || kMulE);
   constexpr int kTabBytes = (EPI == M3P_EPI_DGELU && M3P_DGELU_LUT) ? GELU_TAB_N * (int)sizeof(float) : 0;
   float* gtab = (EPI == M3P_EPI_DGELU && M3P_DGELU_LUT) ? reinterpret_cast<float*>(smem + 2 * STAGE) : nullptr;
@@ -1154,12 +1258,80 @@ void gemm_nt_w8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
       split_tile(t, tm, tn);
       const int m0 = tm * BM, n0 = tn * BN;
       const int mw = m0 + wm * 128, nw = n0 + wn * 64;
-      if ((EPI == M3P_EPI_DGELU || EPI == M3P_EPI_MUL) && ep.colsum && csum_nw != nw) {
+      if (kMulE && ep.colsum && csum_nw != nw) {
         if (csum_nw >= 0) flush_csum();
         csum_nw = nw;
       }
       const bool fast = io_aligned && (m0 + BM <= M) && (n0 + BN <= N);
-      if (fast && kSpare && kMulE) {
+      if constexpr (EPI == M3P_EPI_BIAS_GELUQ) {
+        if (fast) {
+          char* r1 = smem + 2 * STAGE + wid * 4096;
+          f32x4 biasv[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) biasv[j] = *reinterpret_cast<const f32x4*>(ep.bias + nw + j * 16 + (lane >> 4) * 4);
+          uint8_t* qo = reinterpret_cast<uint8_t*>(ep.out2) + gq_block_offset(tm, tn, tiles_n, wid, 0);
+#pragma unroll
+          for (int hf = 0; hf < 4; ++hf) {
+            epilogue_half_geluq(C, ldc, qo + 2048 * hf, mw + 32 * hf, nw, r1, acc[2 * hf], acc[2 * hf + 1], biasv, lane);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        W8_TSEG(2);
+      } else if constexpr (EPI == M3P_EPI_MULQ) {
+        // byte derivative in fragment order: one 16-byte load per lane and 16-row piece (the launcher admits whole tiles
+        // only, so `fast` always holds).  M3P_MULQ_MODE (A/B builds): 0 = codes two pieces ahead, three LDS-DMA pieces of
+        // K-tile +2 at the head of the epilogue and five inside the next K-tile (the aux epilogues' schedule); 1 = all eight
+        // code loads first, then ALL eight LDS-DMA pieces (the stage is free, and nothing behind them has to wait for them in
+        // the in-order vmcnt queue); 2 = mode 1 with 32-row pieces through 4 KB of staging per wave
+        if (fast) {
+          const uint8_t* qp = reinterpret_cast<const uint8_t*>(ep.aux) + gq_block_offset(tm, tn, tiles_n, wid, 0) + lane * 16;
+#if M3P_MULQ_MODE == 0
+          char* r1 = smem + 2 * STAGE + wid * 2048;
+          u32x4 qa = *reinterpret_cast<const u32x4*>(qp), qb = *reinterpret_cast<const u32x4*>(qp + 1024);
+          __builtin_amdgcn_sched_barrier(0);
+          if (W8_MORE2) { issue_load(cur, 0); issue_load(cur, 1); issue_load(cur, 2); spread_pending = true; }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int hp = 0; hp < 8; hp += 2) {
+            u32x4 qc = qa, qd = qb;
+            if (hp + 2 < 8) qc = *reinterpret_cast<const u32x4*>(qp + (hp + 2) * 1024);
+            epilogue_pieceq(C, ldc, mw + 16 * hp, nw, r1, acc[hp], qa, lane, csum);
+            __builtin_amdgcn_sched_barrier(0);
+            if (hp + 3 < 8) qd = *reinterpret_cast<const u32x4*>(qp + (hp + 3) * 1024);
+            epilogue_pieceq(C, ldc, mw + 16 * (hp + 1), nw, r1, acc[hp + 1], qb, lane, csum);
+            __builtin_amdgcn_sched_barrier(0);
+            qa = qc; qb = qd;
+          }
+#else
+          u32x4 qv[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) qv[i] = *reinterpret_cast<const u32x4*>(qp + i * 1024);
+          __builtin_amdgcn_sched_barrier(0);
+          if (W8_MORE2) {
+#pragma unroll
+            for (int pc = 0; pc < 8; ++pc) issue_load(cur, pc);
+            load_done();
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#if M3P_MULQ_MODE == 1
+          char* r1 = smem + 2 * STAGE + wid * 2048;
+#pragma unroll
+          for (int hp = 0; hp < 8; ++hp) {
+            epilogue_pieceq(C, ldc, mw + 16 * hp, nw, r1, acc[hp], qv[hp], lane, csum);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+#else
+          char* r1 = smem + 2 * STAGE + wid * 4096;
+#pragma unroll
+          for (int hf = 0; hf < 4; ++hf) {
+            epilogue_halfq(C, ldc, mw + 32 * hf, nw, r1, acc[2 * hf], acc[2 * hf + 1], qv[2 * hf], qv[2 * hf + 1], lane, csum);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+#endif
+#endif
+        }
+        W8_TSEG(2);
+      } else if (fast && kSpare && kMulE) {
         // 16-row pieces, the aux rows of the next piece in flight while this one is computed
         char* r1 = smem + 2 * STAGE + kTabBytes + wid * 2048;
         u32x4 ta[2], tb[2];
@@ -1238,7 +1410,7 @@ void gemm_nt_w8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
       h1d = l_alive;
     }
   }
-  if ((EPI == M3P_EPI_DGELU || EPI == M3P_EPI_MUL) && ep.colsum && csum_nw >= 0) flush_csum();
+  if (kMulE && ep.colsum && csum_nw >= 0) flush_csum();
 #ifdef M3P_W8_TL
   tacc[6] = __builtin_amdgcn_s_memtime();
   if (lane == 0)
@@ -2444,6 +2616,32 @@ int launch_nt(const bf16* A, int lda, const bf16* W, int ldw, bf16* C, int ldc, 
   return M3P_OK;
 }
 
+// M3P_EPI_MULQ: the byte-derivative epilogue exists on the eight-wave kernel only (its aux layout IS that kernel's tiling)
+// M3P_EPI_BIAS_GELUQ: likewise (it writes that layout)
+template <int EPI>
+static int launch_nt_gq(const bf16* A, int lda, const bf16* W, int ldw, bf16* C, int ldc, int M, int N, int K,
+                        const M3PEpilogue& ep, hipStream_t st) {
+  if (M < 1024 || (M % 256) || (N % 256) || N < 512 || (K % 64) || (lda % 8) || (ldw % 8) || (ldc % 8) || ((uintptr_t)C & 15))
+    return M3P_EINVAL;
+  if (EPI == M3P_EPI_MULQ && (!ep.aux || ((uintptr_t)ep.aux & 15))) return M3P_EINVAL;
+  if (EPI == M3P_EPI_BIAS_GELUQ && (!ep.out2 || ((uintptr_t)ep.out2 & 15) || !ep.bias || ((uintptr_t)ep.bias & 15))) return M3P_EINVAL;
+  const int tiles_m = M / 256, tiles_n = N / 256;
+  const size_t lds = 2 * 512 * ROWB + 8 * ((EPI == M3P_EPI_BIAS_GELUQ || M3P_MULQ_MODE == 2) ? 4096 : 2048);
+  auto kern = gemm_nt_w8_kernel<EPI>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  int grid = num_cus();
+  const int ntiles = tiles_m * tiles_n;
+  if (ntiles < grid) grid = (ntiles + 7) / 8 * 8;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_m, tiles_n, (int*)nullptr);
+  M3P_CHECK_LAUNCH();
+  return M3P_OK;
+}
+
 // ---------------------------------------------------------------------------------
 // weight-gradient kernel: dW[i,j] += alpha * sum_m dY[m,i] X[m,j]
 // LDS tiles are [64 m][128 cols] bf16 (256-B rows, as in HBM); MFMA operands need 8
@@ -3370,6 +3568,8 @@ int m3p_gemm_nt_bf16(const void* A, int lda, const void* W, int ldw, void* C, in
     case M3P_EPI_RES: return launch_nt<M3P_EPI_RES>(a, lda, w, ldw, c, ldc, M, N, K, ep, st);
     case M3P_EPI_DGELU: return launch_nt<M3P_EPI_DGELU>(a, lda, w, ldw, c, ldc, M, N, K, ep, st);
     case M3P_EPI_MUL: return launch_nt<M3P_EPI_MUL>(a, lda, w, ldw, c, ldc, M, N, K, ep, st);
+    case M3P_EPI_MULQ: return launch_nt_gq<M3P_EPI_MULQ>(a, lda, w, ldw, c, ldc, M, N, K, ep, st);
+    case M3P_EPI_BIAS_GELUQ: return launch_nt_gq<M3P_EPI_BIAS_GELUQ>(a, lda, w, ldw, c, ldc, M, N, K, ep, st);
     default: return M3P_EINVAL;
   }
 }

@@ -270,6 +270,51 @@ __global__ __launch_bounds__(256) void gelu_fwd_kernel(const bf16* u, bf16* __re
   }
 }
 
+// The same pass leaving gelu'(u) as one byte per element in the eight-wave GEMM's fragment order (common.hpp): a workgroup
+// takes 16 rows x 256 columns = one row block of the four column quarters of a tile (4 KB of codes).  Phase 1 walks the
+// rows in 16-byte pieces (coalesced u reads and h writes) and drops the codes into LDS in row order; phase 2 reads them in
+// accumulator order (lane = 16 fg + fr holds columns 16 j + 4 fg .. + 3 of row fr) and writes 1 KB per wave, coalesced.
+__global__ __launch_bounds__(256) void gelu_fwd_gq_kernel(const bf16* __restrict__ u, bf16* __restrict__ h, uint8_t* __restrict__ gq,
+                                                          int N, int tiles_n, int nblocks) {
+  __shared__ __attribute__((aligned(16))) uint8_t codes[16][256 + 16];
+  const int t = threadIdx.x;
+  for (int b = blockIdx.x; b < nblocks; b += gridDim.x) {
+    const int rb = b / tiles_n, tn = b - rb * tiles_n;        // 16-row block, column tile
+    const size_t row0 = (size_t)rb * 16;
+    const int col0 = tn * 256;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int r = (t >> 5) + 8 * half, c = (t & 31) * 8;
+      const size_t off = (row0 + r) * (size_t)N + col0 + c;
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(u + off);
+      bf16x8 o;
+      uint32_t lo = 0, hi = 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float x = (float)v[j];
+        const GeluParts g = gelu_parts(x);
+        o[j] = (bf16)(x * g.cdf);
+        const uint32_t q = gelu_grad_code(g.cdf + x * g.pdf);
+        if (j < 4) lo |= q << (8 * j); else hi |= q << (8 * (j - 4));
+      }
+      *reinterpret_cast<bf16x8*>(h + off) = o;
+      *reinterpret_cast<uint2*>(&codes[r][c]) = uint2{lo, hi};
+    }
+    __syncthreads();
+    {
+      const int wn = t >> 6, l = t & 63, fr = l & 15, fg = l >> 4;
+      uint4 q;
+      q.x = *reinterpret_cast<const uint32_t*>(&codes[fr][wn * 64 + 0 + fg * 4]);
+      q.y = *reinterpret_cast<const uint32_t*>(&codes[fr][wn * 64 + 16 + fg * 4]);
+      q.z = *reinterpret_cast<const uint32_t*>(&codes[fr][wn * 64 + 32 + fg * 4]);
+      q.w = *reinterpret_cast<const uint32_t*>(&codes[fr][wn * 64 + 48 + fg * 4]);
+      const int tm = rb >> 4, ib = rb & 15, wm = ib >> 3, i = ib & 7;
+      *reinterpret_cast<uint4*>(gq + gq_block_offset(tm, tn, tiles_n, wm * 4 + wn, i) + l * 16) = q;
+    }
+    __syncthreads();
+  }
+}
+
 // The same pass also emitting the e4m3 copy of h the fp8 lin2 product reads (fp8 path: a separate quantisation pass would
 // read the 280-MB activation again) + the running max |h| for the next step's scale.  The 8-bit value is the
 // quantisation of the ROUNDED bf16 h, i.e. exactly what m3p_quant_fp8 would produce from h.
@@ -377,6 +422,18 @@ int m3p_gelu_fwd(const void* u, void* h, void* dh, long long n, void* stream) {
     hipLaunchKernelGGL(gelu_fwd_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)u, (bf16*)h, (bf16*)dh, n8);
   else
     hipLaunchKernelGGL(gelu_fwd_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)u, (bf16*)h, (bf16*)nullptr, n8);
+  M3P_CHECK_LAUNCH();
+  return M3P_OK;
+}
+
+int m3p_gelu_fwd_gq(const void* u, void* h, void* gq, int M, int N, void* stream) {
+  if (M <= 0 || N <= 0 || (M % 256) || (N % 256) || !u || !h || !gq) return M3P_EINVAL;
+  if (((uintptr_t)u & 15) || ((uintptr_t)h & 15) || ((uintptr_t)gq & 15)) return M3P_EINVAL;
+  const long long nb = (long long)(M / 16) * (N / 256);
+  if (nb > 0x7fffffffLL) return M3P_EINVAL;
+  const int blocks = (int)(nb < 16384 ? nb : 16384);
+  hipLaunchKernelGGL(gelu_fwd_gq_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)u, (bf16*)h, (uint8_t*)gq, N,
+                     N / 256, (int)nb);
   M3P_CHECK_LAUNCH();
   return M3P_OK;
 }

@@ -33,6 +33,11 @@ def _round_up(n, a):
 # 0 (default) = the dgrad epilogue recomputes gelu'(u) (EPI_DGELU).  -40 us per dgrad, +40 us per gelu pass.
 _VOCAB_FULL_TILES = os.environ.get('M3P_VOCAB_FULL_TILES', '1') != '0'    # developer switch for A/B runs (Arena.V_pad)
 _GELU_GRAD_IN_FWD = os.environ.get('M3P_GELU_GRAD_IN_FWD', '0') != '0'   # measured equal in the step (47.97 vs 47.97 ms): off
+# round 4: gelu'(u) kept as ONE byte per element in the dU GEMM's fragment order (ops.gelu_fwd_gq / EPI_MULQ) instead of u itself;
+# M3P_GELU_BYTE_GRAD=0 is the round-3 path (bf16 u + derivative table in the epilogue) for A/B runs
+# 2 (default) = lin1's epilogue computes GELU and the byte itself (EPI_BIAS_GELUQ: no separate activation pass);
+# 1 = bias epilogue + ops.gelu_fwd_gq pass
+_GELU_BYTE_GRAD = int(os.environ.get('M3P_GELU_BYTE_GRAD', '2'))
 
 class Arena:
     """Flat storage behind a TransformerModel's hot parameters (see model/transformer.py)."""
@@ -547,13 +552,24 @@ class EncoderFn(torch.autograd.Function):
             x1, mean1, rstd1 = ops.layernorm_fwd(pre1, ar.p('layer_norm1.%d.weight' % i), ar.p('layer_norm1.%d.bias' % i))
             hact8 = None
             u_holds_grad = False     # does the pass below leave gelu'(u) in u's buffer? (backward then only multiplies)
-            if M >= 1024 or st8 is not None:
+            if st8 is None and not _GELU_GRAD_IN_FWD and _GELU_BYTE_GRAD == 2 and track and ops.gq_eligible(M, 4 * d):
+                # lin1 + GELU in ONE launch: the epilogue writes h and, for backward, gelu'(u) as one byte per element in the
+                # dU GEMM's own fragment order (EPI_MULQ decodes it with one fma); u is never stored
+                u = torch.empty((M * 4 * d,), dtype=torch.uint8, device=dev)
+                hact = ops.gemm_nt(x1, ar.w(f + 'lin1.weight'), L.EPI_BIAS_GELUQ, bias=ar.p(f + 'lin1.bias'), out2=u)
+                u_holds_grad = 'q'
+            elif M >= 1024 or st8 is not None:
                 # persistent GEMM: bias in the epilogue, GELU as its own HBM-speed pass
                 # The same pass leaves gelu'(u) in u's buffer: the backward dgrad then only multiplies
                 # (EPI_MUL, runs on the four-wave GEMM) instead of evaluating erf/exp in its epilogue.
                 u = lin(x1, i, 'x1', 'w1', ar.w(f + 'lin1.weight'), L.EPI_BIAS, bias=ar.p(f + 'lin1.bias'))
                 if st8 is not None and 'w2' in fp8mod.FWD_SITES and 'w2' not in fp8mod.BWD_SITES and not _GELU_GRAD_IN_FWD:
                     hact, hact8 = st8.gelu_quant(u, i)           # GELU and the 8-bit copy for lin2 in one pass
+                elif st8 is None and not _GELU_GRAD_IN_FWD and _GELU_BYTE_GRAD and track and ops.gq_eligible(M, 4 * d):
+                    # what backward needs of u is gelu'(u): one byte per element in the dU GEMM's own fragment order
+                    # (EPI_MULQ decodes it with one fma - no derivative table, no aux trip through LDS); u is dropped here
+                    hact, u = ops.gelu_fwd_gq(u)
+                    u_holds_grad = 'q'
                 else:
                     u_holds_grad = _GELU_GRAD_IN_FWD or (st8 is not None and 'w2' in fp8mod.BWD_SITES)
                     hact = ops.gelu_fwd(u, grad_inplace=u_holds_grad)
@@ -643,8 +659,11 @@ class EncoderFn(torch.autograd.Function):
             if dY2 is None:
                 dY2 = dpre2
             ops.gemm_wgrad(dY2, hact, ar.g(f + 'lin2.weight'))
-            dU = dgrad(dY2, i, 'dy2', 'w2', ar.wt[('lin2', i)], L.EPI_MUL if ctx.u_holds_grad else L.EPI_DGELU, aux=u,
-                       colsum=ar.g(f + 'lin1.bias'))
+            if ctx.u_holds_grad == 'q':
+                dU = ops.gemm_nt(dY2, ar.wt[('lin2', i)], L.EPI_MULQ, aux=u, colsum=ar.g(f + 'lin1.bias'))
+            else:
+                dU = dgrad(dY2, i, 'dy2', 'w2', ar.wt[('lin2', i)], L.EPI_MUL if ctx.u_holds_grad else L.EPI_DGELU, aux=u,
+                           colsum=ar.g(f + 'lin1.bias'))
             del hact, u, pre2
             ops.gemm_wgrad(dU, x1, ar.g(f + 'lin1.weight'))
             dx1 = dgrad(dU, i, 'du', 'w1', ar.wt[('lin1', i)], L.EPI_RES, aux=dpre2)

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # M3P_HIP_LIB: developer override used for A/B runs of two builds inside one GPU session
 LIB_PATH = os.environ.get('M3P_HIP_LIB') or os.path.join(_HERE, 'libm3p_hip.so')
 
-EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_DROP_RES, EPI_RES, EPI_DGELU, EPI_MUL = range(7)
+EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_DROP_RES, EPI_RES, EPI_DGELU, EPI_MUL, EPI_MULQ, EPI_BIAS_GELUQ = range(9)
 
 
 class M3PError(RuntimeError):
@@ -72,6 +72,7 @@ SIGNATURES = {
     'm3p_gelu_bwd': (_i, [_p, _p, _p, C.c_longlong, _p]),
     'm3p_mse_fwd_bwd': (_i, [_p, _i, _p, _i, _p, _p, _i, _i, _f, _p]),
     'm3p_gelu_fwd': (_i, [_p, _p, _p, C.c_longlong, _p]),
+    'm3p_gelu_fwd_gq': (_i, [_p, _p, _p, _i, _i, _p]),
     'm3p_gelu_fwd_q8': (_i, [_p, _p, _p, C.c_longlong, _p, _p, _p]),
     'm3p_transpose_batch_bf16': (_i, [_p, _i, _i, _p]),
     'm3p_transpose_bf16': (_i, [_p, _p, _i, _i, _i, _i, _p]),

@@ -17,7 +17,7 @@ _DEBUG_CHECKS = os.environ.get('M3P_DEBUG_CHECKS') == '1'      # host-synchronis
 # the launch stream: {(kind, M, N, K): [(start_event, end_event), ...]}
 PROFILE = None
 _EPI_NAMES = ['gemm_nt/none', 'gemm_nt/bias', 'gemm_nt/bias_gelu', 'gemm_nt/bias_drop_res', 'gemm_nt/res',
-              'gemm_nt/dgelu', 'gemm_nt/mul']
+              'gemm_nt/dgelu', 'gemm_nt/mul', 'gemm_nt/mulq', 'gemm_nt/bias_geluq']
 
 
 PROFILE_ONLY = None     # if set: the one (kind, M, N, K) instance that is timed (bench.py: the dominant kernel)
@@ -48,9 +48,16 @@ def gemm_nt(a, w, epilogue=L.EPI_NONE, bias=None, aux=None, out=None, out2=None,
             scale_cols=0, scale=1.0, alpha=1.0, seed=0, p_drop=0.0, n=None):
     """C[M,N] = epi(a[M,K] @ w[N,K]^T).  a, w bf16 (row pitch = stride(0)); returns C (bf16).
     ``n`` restricts the number of output columns (rows of w) used."""
-    _chk_bf16(a, w, aux, out, out2)
     M, K = a.shape
     N = w.shape[0] if n is None else n
+    if epilogue == L.EPI_MULQ:     # aux = the byte codes of gelu_fwd_gq for this [M, N], in the GEMM's fragment order
+        _chk_bf16(a, w, out)
+        assert aux is not None and aux.dtype == torch.uint8 and aux.is_contiguous() and aux.numel() == M * N
+    elif epilogue == L.EPI_BIAS_GELUQ:      # out2 = where those codes go (uint8 [M * N]); C = gelu(a w^T + bias)
+        _chk_bf16(a, w, out)
+        assert out2 is not None and out2.dtype == torch.uint8 and out2.is_contiguous() and out2.numel() == M * N and bias is not None
+    else:
+        _chk_bf16(a, w, aux, out, out2)
     assert w.shape[1] == K and a.stride(1) == 1 and w.stride(1) == 1
     if out is None:
         out = torch.empty((M, N), dtype=BF16, device=a.device)
@@ -59,8 +66,8 @@ def gemm_nt(a, w, epilogue=L.EPI_NONE, bias=None, aux=None, out=None, out2=None,
     ep.aux = L.ptr(aux)
     ep.out2 = L.ptr(out2)
     ep.colsum = L.ptr(colsum)
-    ep.ld_aux = aux.stride(0) if aux is not None else 0
-    ep.ld_out2 = out2.stride(0) if out2 is not None else 0
+    ep.ld_aux = aux.stride(0) if (aux is not None and epilogue != L.EPI_MULQ) else 0
+    ep.ld_out2 = out2.stride(0) if (out2 is not None and epilogue != L.EPI_BIAS_GELUQ) else 0
     ep.scale_cols = scale_cols
     ep.scale = scale
     ep.alpha = alpha
@@ -585,6 +592,34 @@ def gelu_fwd(u, grad_inplace=False):
     L.check(L.load().m3p_gelu_fwd(u.data_ptr(), h.data_ptr(), u.data_ptr() if grad_inplace else None, u.numel(), L.stream()),
             'm3p_gelu_fwd')
     return h
+
+
+GQ_OFF, GQ_STEP = 0.13, 1.26 / 255.0       # the byte code of gelu' (csrc/common.hpp): gelu' ~ code * GQ_STEP - GQ_OFF
+
+
+def gq_eligible(M, N):
+    """Shapes whose FFN runs on the byte-derivative form: whole 256 x 256 tiles of the eight-wave kernel."""
+    return M >= 1024 and M % 256 == 0 and N % 256 == 0 and N >= 512
+
+
+def gelu_fwd_gq(u):
+    """(h = gelu_erf(u) bf16 [M, N], gq uint8 [M * N]): gq holds gelu_erf'(u) as one byte per element in the fragment
+    order of the eight-wave GEMM (include/m3p_hip.h: m3p_gelu_fwd_gq) - what gemm_nt(..., EPI_MULQ, aux=gq) multiplies by.
+    u is dead afterwards."""
+    _chk_bf16(u)
+    M, N = u.shape
+    assert u.is_contiguous() and gq_eligible(M, N), (M, N)
+    h = torch.empty_like(u)
+    gq = torch.empty((M * N,), dtype=torch.uint8, device=u.device)
+    L.check(L.load().m3p_gelu_fwd_gq(u.data_ptr(), h.data_ptr(), gq.data_ptr(), M, N, L.stream()), 'm3p_gelu_fwd_gq')
+    return h, gq
+
+
+def gq_unpack(gq, M, N):
+    """The decoded derivative as a float [M, N] matrix in row order (tests): inverse of the fragment-order layout."""
+    t = gq.view(M // 256, N // 256, 2, 4, 8, 4, 16, 4, 4)       # tm, tn, wm, wn, i, fg, fr, j, r
+    t = t.permute(0, 2, 4, 6, 1, 3, 7, 5, 8).reshape(M, N)     # rows: tm, wm, i, fr   cols: tn, wn, j, fg, r
+    return t.float() * GQ_STEP - GQ_OFF
 
 
 def gelu_fwd_q8(u, scale, amax=None):

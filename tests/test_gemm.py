@@ -295,6 +295,46 @@ def test_gemm_nt_at_the_benchmarked_sizes(M, N, K):
     del c, ref
 
 
+@pytest.mark.parametrize('M,N,K', [(1024, 512, 64), (2048, 768, 256), (41984, 3072, 768)])
+def test_gelu_byte_derivative_and_its_dgrad(M, N, K):
+    """FFN activation with gelu'(u) kept as ONE byte per element (m3p_gelu_fwd_gq) and the data gradient that consumes it
+    (M3P_EPI_MULQ: dU = (dY W) * decode(code), column sums): h against torch's erf-GELU, the decoded derivative against
+    the exact one within the code's half step (1.26 / 255 / 2 = 2.5e-3), the product tightly against the fp32 product times
+    the decoded derivative and - the bar that matters for training - against the exact derivative."""
+    from m3p_amd import ops, lib as L
+    g = torch.Generator(device='cuda').manual_seed(M + N + K)
+    u = (torch.randn((M, N), device='cuda', generator=g) * 1.5).to(torch.bfloat16)
+    u[0, :8] = torch.tensor([0.0, -0.0, 1e-4, -1e-4, 9.0, -9.0, 0.7518, -0.7518], device='cuda').to(torch.bfloat16)
+    x = u.float()
+    h, gq = ops.gelu_fwd_gq(u.clone())
+    assert rel_l2(h.float(), torch.nn.functional.gelu(x)) < 3e-3
+    exact = 0.5 * (1 + torch.erf(x / math.sqrt(2))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi)
+    dec = ops.gq_unpack(gq, M, N)
+    assert float((dec - exact).abs().max()) <= 0.5 * ops.GQ_STEP + 1e-5
+    a = (torch.randn((M, K), device='cuda', generator=g)).to(torch.bfloat16)
+    w = (torch.randn((N, K), device='cuda', generator=g) * 0.05).to(torch.bfloat16)
+    ref = _ref_on_gpu(a, w)
+    cs = torch.zeros(N, device='cuda')
+    c = ops.gemm_nt(a, w, L.EPI_MULQ, aux=gq, colsum=cs)
+    assert rel_l2(c.float(), ref * dec) < 4e-3
+    assert rel_l2(cs, (ref * dec).sum(0)) < 2e-2
+    assert rel_l2(c.float(), ref * exact) < 8e-3          # (the byte adds ~3e-3 of relative error to the bf16 output's ~2e-3)
+    # shapes outside whole eight-wave tiles are refused, not mis-read
+    with pytest.raises(L.M3PError):
+        ops.gemm_nt(a[:1000], w, L.EPI_MULQ, aux=gq[:1000 * N])
+    # the producer fused into the lin1 GEMM (M3P_EPI_BIAS_GELUQ): h = gelu(a w^T + b) and the same byte layout
+    bias = torch.randn((N,), device='cuda', generator=g)
+    q2 = torch.empty(M * N, dtype=torch.uint8, device='cuda')
+    h2 = ops.gemm_nt(a, w, L.EPI_BIAS_GELUQ, bias=bias, out2=q2)
+    pre = ref + bias
+    assert rel_l2(h2.float(), torch.nn.functional.gelu(pre)) < 4e-3
+    exact2 = 0.5 * (1 + torch.erf(pre / math.sqrt(2))) + pre * torch.exp(-0.5 * pre * pre) / math.sqrt(2 * math.pi)
+    # (the kernel's u is its own fp32 accumulation: against the library product's the codes may sit one level off where
+    #  the derivative is steep - 1.5 steps covers it; on average they agree to the code's own rms)
+    d2 = (ops.gq_unpack(q2, M, N) - exact2).abs()
+    assert float(d2.max()) <= 1.5 * ops.GQ_STEP and float(d2.pow(2).mean().sqrt()) < 0.4 * ops.GQ_STEP
+
+
 @pytest.mark.parametrize('N,K', [(2304, 768), (768, 768), (3072, 768), (768, 3072)])
 def test_gemm_wgrad_at_the_benchmarked_sizes(N, K):
     from m3p_amd import ops
