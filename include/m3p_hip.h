@@ -59,6 +59,12 @@ enum {
   M3P_EPI_BIAS_GELUQ = 8     /* u = acc + bias (fp32) is NOT stored; C = gelu_erf(u); out2 = uint8 [M * N]: gelu_erf'(u) as
                                 one-byte codes in the fragment order M3P_EPI_MULQ reads (same shape limits; bias required):
                                 the FFN lin1 + activation of transformer.py:223 with what backward needs kept in a byte */
+  ,
+  M3P_EPI_BIAS_LSE = 9       /* C = acc + bias (M3P_EPI_BIAS without alpha / column scale) and, for the cross-entropy over the
+                                N columns (PredLayer, transformer.py:104-117): out2 = float2 [N / 64][M], the (maximum, sum of
+                                exp(x - maximum)) of every row over each 64-column block, columns >= ld_out2 (= V, the valid
+                                vocabulary) left out; m3p_ce_lse_from_blocks folds them into the rows' log-sum-exp.  Same
+                                shape limits as M3P_EPI_MULQ */
 };
 
 typedef struct M3PEpilogue {
@@ -317,6 +323,16 @@ M3P_API int m3p_ce_fwd_bwd(void* logits, int ld, int n_rows, int V, const int64_
  * transformer.py:111) - produced by the pass that writes the gradient, instead of a second pass over it: colsum[c]
  * (fp32 [ld], OVERWRITTEN) = sum over rows of the rounded bf16 gradient; row_lse [n_rows] receives the log-sum-exp.
  * workspace: m3p_ce_colsum_workspace_bytes(ld, n_rows) bytes owned by the caller (16-byte aligned). */
+/* Log-sum-exp and loss of every row from the 64-column block statistics the vocabulary projection left behind
+ * (M3P_EPI_BIAS_LSE): row_lse[r] = log sum_c exp(logit[r, c]), row_loss[r] = row_lse[r] - logits[r, target[r]].
+ * stats float2 [n_blocks][n_rows]; scratch: float2 [32][n_rows] (caller-owned).  Replaces the first pass of m3p_ce_fwd_bwd_colsum;
+ * follow with m3p_ce_bwd_colsum. */
+M3P_API int m3p_ce_lse_from_blocks(const void* stats, int n_blocks, int n_rows, const void* logits, int ld, const int64_t* target,
+                                   float* row_loss, float* row_lse, void* scratch, void* stream);
+/* The second half of m3p_ce_fwd_bwd_colsum alone: logits <- grad_scale * (softmax - onehot) in place given the rows' log-sum-exp,
+ * colsum [ld] <- column sums of the rounded gradient.  Same workspace. */
+M3P_API int m3p_ce_bwd_colsum(void* logits, int ld, int n_rows, int V, const int64_t* target, const float* row_lse,
+                              float grad_scale, float* colsum, void* workspace, size_t workspace_bytes, void* stream);
 M3P_API size_t m3p_ce_colsum_workspace_bytes(int ld, int n_rows);
 M3P_API int m3p_ce_fwd_bwd_colsum(void* logits, int ld, int n_rows, int V, const int64_t* target, float* row_loss,
                                   float* row_lse, float grad_scale, float* colsum, void* workspace,

@@ -531,6 +531,61 @@ __device__ __forceinline__ void epilogue_pieceq(bf16* __restrict__ C, int ldc, i
   }
 }
 
+// 32-row piece of the vocabulary projection's epilogue (M3P_EPI_BIAS_LSE): logits = acc + bias as for M3P_EPI_BIAS, plus what
+// the cross-entropy needs of them while they are still in registers - per (row, 64-column block of this wave) the block's
+// maximum and sum of exp(logit - max) over the columns < V, written to stats[block][row] (consecutive rows of a block are
+// consecutive: 16 lanes store 128 bytes).  A row's log-sum-exp is then a reduction over N / 64 pairs instead of a second
+// pass over the 2.4 GB of logits.  The statistics are taken on the fp32 values (the stored logits are their bf16 rounding).
+__device__ __forceinline__ void epilogue_half_lse(bf16* __restrict__ C, int ldc, float2* __restrict__ stats, int V, int mrow0, int nw,
+                                                  char* r1, const f32x4 (&rows0)[4], const f32x4 (&rows1)[4],
+                                                  const f32x4 (&biasv)[4], int lane, bool edge) {
+  constexpr float kLog2e = 1.4426950408889634f;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int srow = lane >> 3, sch = lane & 7;
+#pragma unroll
+  for (int ii = 0; ii < 2; ++ii) {
+    f32x4 x[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      x[j] = (ii ? rows1[j] : rows0[j]) + biasv[j];
+      *reinterpret_cast<bf16x4*>(r1 + ep_off8<true>(ii * 16 + fr, (j * 16 + fg * 4) * 2)) = bf16x4{(bf16)x[j][0], (bf16)x[j][1], (bf16)x[j][2], (bf16)x[j][3]};
+    }
+    if (edge) {        // (wave-uniform: only the last column tile holds columns >= V)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (nw + j * 16 + fg * 4 + r >= V) x[j][r] = -INFINITY;
+    }
+    f32x4 m4 = x[0];
+#pragma unroll
+    for (int j = 1; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) m4[r] = fmaxf(m4[r], x[j][r]);
+    float m = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    const float mb = (m == -INFINITY) ? 0.f : m * kLog2e;
+    f32x4 s4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f32x4 a = x[j] * kLog2e - mb;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s4[r] += __builtin_amdgcn_exp2f(a[r]);
+    }
+    float sm = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+    sm += __shfl_xor(sm, 16, 64);
+    sm += __shfl_xor(sm, 32, 64);
+    if (fg == 0) stats[mrow0 + ii * 16 + fr] = float2{m, sm};
+  }
+  bf16* Cp = C + (size_t)mrow0 * ldc + nw + sch * 8;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int row = it * 8 + srow;
+    *reinterpret_cast<u32x4*>(Cp + (size_t)row * ldc) = flip_halves(*reinterpret_cast<const u32x4*>(r1 + ep_off<true>(row, sch * 16)), it & 1);
+  }
+}
+
 #ifndef M3P_MULQ_MODE
 #define M3P_MULQ_MODE 0
 #endif
@@ -1263,7 +1318,23 @@ void gemm_nt_w8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
         csum_nw = nw;
       }
       const bool fast = io_aligned && (m0 + BM <= M) && (n0 + BN <= N);
-      if constexpr (EPI == M3P_EPI_BIAS_GELUQ) {
+      if constexpr (EPI == M3P_EPI_BIAS_LSE) {
+        if (fast) {
+          char* r1 = smem + 2 * STAGE + wid * 4096;
+          f32x4 biasv[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) biasv[j] = *reinterpret_cast<const f32x4*>(ep.bias + nw + j * 16 + (lane >> 4) * 4);
+          const int V = ep.ld_out2;
+          float2* st = reinterpret_cast<float2*>(ep.out2) + (size_t)(tn * 4 + wn) * M;
+          const bool edge = (nw + 64 > V);
+#pragma unroll
+          for (int hf = 0; hf < 4; ++hf) {
+            epilogue_half_lse(C, ldc, st, V, mw + 32 * hf, nw, r1, acc[2 * hf], acc[2 * hf + 1], biasv, lane, edge);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        W8_TSEG(2);
+      } else if constexpr (EPI == M3P_EPI_BIAS_GELUQ) {
         if (fast) {
           char* r1 = smem + 2 * STAGE + wid * 4096;
           f32x4 biasv[4];
@@ -2617,16 +2688,18 @@ int launch_nt(const bf16* A, int lda, const bf16* W, int ldw, bf16* C, int ldc, 
 }
 
 // M3P_EPI_MULQ: the byte-derivative epilogue exists on the eight-wave kernel only (its aux layout IS that kernel's tiling)
-// M3P_EPI_BIAS_GELUQ: likewise (it writes that layout)
+// M3P_EPI_BIAS_GELUQ: likewise (it writes that layout); M3P_EPI_BIAS_LSE: its statistics are per 64-column wave block
 template <int EPI>
 static int launch_nt_gq(const bf16* A, int lda, const bf16* W, int ldw, bf16* C, int ldc, int M, int N, int K,
                         const M3PEpilogue& ep, hipStream_t st) {
   if (M < 1024 || (M % 256) || (N % 256) || N < 512 || (K % 64) || (lda % 8) || (ldw % 8) || (ldc % 8) || ((uintptr_t)C & 15))
     return M3P_EINVAL;
   if (EPI == M3P_EPI_MULQ && (!ep.aux || ((uintptr_t)ep.aux & 15))) return M3P_EINVAL;
-  if (EPI == M3P_EPI_BIAS_GELUQ && (!ep.out2 || ((uintptr_t)ep.out2 & 15) || !ep.bias || ((uintptr_t)ep.bias & 15))) return M3P_EINVAL;
+  if ((EPI == M3P_EPI_BIAS_GELUQ || EPI == M3P_EPI_BIAS_LSE) && (!ep.out2 || ((uintptr_t)ep.out2 & 15) || !ep.bias || ((uintptr_t)ep.bias & 15)))
+    return M3P_EINVAL;
+  if (EPI == M3P_EPI_BIAS_LSE && (ep.ld_out2 <= 0 || ep.ld_out2 > N)) return M3P_EINVAL;
   const int tiles_m = M / 256, tiles_n = N / 256;
-  const size_t lds = 2 * 512 * ROWB + 8 * ((EPI == M3P_EPI_BIAS_GELUQ || M3P_MULQ_MODE == 2) ? 4096 : 2048);
+  const size_t lds = 2 * 512 * ROWB + 8 * ((EPI != M3P_EPI_MULQ || M3P_MULQ_MODE == 2) ? 4096 : 2048);
   auto kern = gemm_nt_w8_kernel<EPI>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -3570,6 +3643,7 @@ int m3p_gemm_nt_bf16(const void* A, int lda, const void* W, int ldw, void* C, in
     case M3P_EPI_MUL: return launch_nt<M3P_EPI_MUL>(a, lda, w, ldw, c, ldc, M, N, K, ep, st);
     case M3P_EPI_MULQ: return launch_nt_gq<M3P_EPI_MULQ>(a, lda, w, ldw, c, ldc, M, N, K, ep, st);
     case M3P_EPI_BIAS_GELUQ: return launch_nt_gq<M3P_EPI_BIAS_GELUQ>(a, lda, w, ldw, c, ldc, M, N, K, ep, st);
+    case M3P_EPI_BIAS_LSE: return launch_nt_gq<M3P_EPI_BIAS_LSE>(a, lda, w, ldw, c, ldc, M, N, K, ep, st);
     default: return M3P_EINVAL;
   }
 }

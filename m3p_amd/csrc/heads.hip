@@ -175,6 +175,53 @@ __global__ __launch_bounds__(1024) void ce_stats_kernel(const bf16* __restrict__
 }
 
 constexpr int CE_RB = 64, CE_CB = 2048;      // rows / columns of a gradient tile
+// log-sum-exp of the rows from the (maximum, sum) pairs of their 64-column blocks (the vocabulary projection's
+// M3P_EPI_BIAS_LSE epilogue, stats [n_blocks][n_rows]).  Stage 1: a workgroup owns 64 rows and one of CE_LSE_SPLIT ranges of
+// blocks; its four waves take every fourth block of the range (a wave reads 64 consecutive rows of a block: 512 bytes) and
+// fold through LDS -> part [split][row].  Stage 2: a thread per row folds the splits and reads the target's logit.
+constexpr int CE_LSE_SPLIT = 32;
+__device__ __forceinline__ void lse_fold(float& m, float& s, float m2, float s2) {
+  const float mm = fmaxf(m, m2);
+  const float a = (m == -INFINITY) ? 0.f : s * __expf(m - mm);
+  const float b = (m2 == -INFINITY) ? 0.f : s2 * __expf(m2 - mm);
+  m = mm;
+  s = a + b;
+}
+__global__ __launch_bounds__(256) void ce_lse_partial_kernel(const float2* __restrict__ stats, int n_blocks, int n_rows,
+                                                             float2* __restrict__ part) {
+  __shared__ float2 sh[4][64];
+  const int r = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int row = blockIdx.x * 64 + r;
+  const int per = (n_blocks + CE_LSE_SPLIT - 1) / CE_LSE_SPLIT;
+  const int b0 = blockIdx.y * per, b1 = min(n_blocks, b0 + per);
+  float m = -INFINITY, s = 0.f;
+  for (int b = b0 + q; b < b1; b += 4) {
+    const float2 v = stats[(size_t)b * n_rows + row];
+    lse_fold(m, s, v.x, v.y);
+  }
+  sh[q][r] = float2{m, s};
+  __syncthreads();
+  if (q == 0) {
+#pragma unroll
+    for (int k = 1; k < 4; ++k) lse_fold(m, s, sh[k][r].x, sh[k][r].y);
+    part[(size_t)blockIdx.y * n_rows + row] = float2{m, s};
+  }
+}
+__global__ __launch_bounds__(256) void ce_lse_final_kernel(const float2* __restrict__ part, int n_rows, const bf16* __restrict__ logits,
+                                                           int ld, const int64_t* __restrict__ target, float* __restrict__ row_loss,
+                                                           float* __restrict__ row_lse) {
+  const int row = blockIdx.x * 256 + threadIdx.x;
+  if (row >= n_rows) return;
+  float m = -INFINITY, s = 0.f;
+  for (int k = 0; k < CE_LSE_SPLIT; ++k) {
+    const float2 v = part[(size_t)k * n_rows + row];
+    lse_fold(m, s, v.x, v.y);
+  }
+  const float lse = m + __logf(s);
+  row_lse[row] = lse;
+  row_loss[row] = lse - (float)logits[(size_t)row * ld + target[row]];
+}
+
 __global__ __launch_bounds__(256) void ce_grad_tile_kernel(bf16* __restrict__ logits, int ld, int n_rows, int V,
                                                            const int64_t* __restrict__ target, const float* __restrict__ row_lse,
                                                            float gscale, float* __restrict__ part) {
@@ -245,9 +292,32 @@ int m3p_ce_fwd_bwd_colsum(void* logits, int ld, int n_rows, int V, const int64_t
       ((uintptr_t)workspace & 15))
     return M3P_EINVAL;
   if (workspace_bytes < m3p_ce_colsum_workspace_bytes(ld, n_rows)) return M3P_EINVAL;
+  hipLaunchKernelGGL(ce_stats_kernel, dim3(n_rows), dim3(1024), 0, (hipStream_t)stream, (const bf16*)logits, ld, V, target, row_loss, row_lse);
+  return m3p_ce_bwd_colsum(logits, ld, n_rows, V, target, row_lse, grad_scale, colsum, workspace, workspace_bytes, stream);
+}
+
+int m3p_ce_lse_from_blocks(const void* stats, int n_blocks, int n_rows, const void* logits, int ld, const int64_t* target,
+                           float* row_loss, float* row_lse, void* scratch, void* stream) {
+  if (n_blocks <= 0 || n_rows <= 0 || (n_rows % 64) != 0 || !stats || !logits || !target || !row_loss || !row_lse || !scratch ||
+      ((uintptr_t)stats & 7) || ((uintptr_t)scratch & 7))
+    return M3P_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(ce_lse_partial_kernel, dim3(n_rows / 64, CE_LSE_SPLIT), dim3(256), 0, st, (const float2*)stats, n_blocks, n_rows,
+                     (float2*)scratch);
+  hipLaunchKernelGGL(ce_lse_final_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, st, (const float2*)scratch, n_rows,
+                     (const bf16*)logits, ld, target, row_loss, row_lse);
+  M3P_CHECK_LAUNCH();
+  return M3P_OK;
+}
+
+int m3p_ce_bwd_colsum(void* logits, int ld, int n_rows, int V, const int64_t* target, const float* row_lse,
+                      float grad_scale, float* colsum, void* workspace, size_t workspace_bytes, void* stream) {
+  if (n_rows <= 0 || V <= 0 || ld < V || (ld % 8) != 0 || ((uintptr_t)logits & 15) || ((uintptr_t)colsum & 15) ||
+      ((uintptr_t)workspace & 15) || !row_lse)
+    return M3P_EINVAL;
+  if (workspace_bytes < m3p_ce_colsum_workspace_bytes(ld, n_rows)) return M3P_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int groups = (n_rows + CE_RB - 1) / CE_RB;
-  hipLaunchKernelGGL(ce_stats_kernel, dim3(n_rows), dim3(1024), 0, st, (const bf16*)logits, ld, V, target, row_loss, row_lse);
   hipLaunchKernelGGL(ce_grad_tile_kernel, dim3((ld + CE_CB - 1) / CE_CB, groups), dim3(256), 0, st, (bf16*)logits, ld, n_rows, V,
                      target, (const float*)row_lse, grad_scale, (float*)workspace);
   if (hipMemsetAsync(colsum, 0, (size_t)ld * sizeof(float), st) != hipSuccess) return M3P_EINVAL;

@@ -38,6 +38,9 @@ _GELU_GRAD_IN_FWD = os.environ.get('M3P_GELU_GRAD_IN_FWD', '0') != '0'   # measu
 # 2 (default) = lin1's epilogue computes GELU and the byte itself (EPI_BIAS_GELUQ: no separate activation pass);
 # 1 = bias epilogue + ops.gelu_fwd_gq pass
 _GELU_BYTE_GRAD = int(os.environ.get('M3P_GELU_BYTE_GRAD', '2'))
+# round 4: the vocabulary projection's epilogue leaves block-wise (max, sum exp) for the cross-entropy (EPI_BIAS_LSE); 0 = the
+# round-3 path (a separate statistics pass over the logits) for A/B runs
+_CE_FUSED_LSE = os.environ.get('M3P_CE_FUSED_LSE', '1') != '0'
 
 class Arena:
     """Flat storage behind a TransformerModel's hot parameters (see model/transformer.py)."""
@@ -1053,12 +1056,26 @@ class MLMHeadFn(torch.autograd.Function):
         ctx.sink = sink
         hsel = ops.gather_rows(base, row_idx, n, d)
         logits = torch.empty((n, ar.V_pad), dtype=BF16, device=hsel.device)
-        n_cols = ar.V_pad if (_VOCAB_FULL_TILES and n >= 1024 and n % 256 == 0) else V   # whole tiles: the eight-wave kernel
-        ops.gemm_nt(hsel, ar.w('embeddings.weight'), L.EPI_BIAS, bias=ar.p('pred_layer.proj.bias'), out=logits, n=n_cols)
+        full_tiles = _VOCAB_FULL_TILES and n >= 1024 and n % 256 == 0
+        n_cols = ar.V_pad if full_tiles else V   # whole tiles: the eight-wave kernel
+        fused_lse = _CE_FUSED_LSE and full_tiles
+        stats = None
+        if fused_lse:
+            # the projection's epilogue also leaves (max, sum exp) of every row per 64-column block: the cross-entropy's
+            # log-sum-exp becomes a reduction over V / 64 pairs instead of a pass over the 2.4 GB of logits
+            # (the bias vector is read up to V_pad like the matrix: the arena bytes behind it)
+            o = ar.offsets['pred_layer.proj.bias'][0]
+            stats = torch.empty((ar.V_pad // 64, n, 2), dtype=torch.float32, device=hsel.device)
+            ops.gemm_nt(hsel, ar.w('embeddings.weight'), L.EPI_BIAS_LSE, bias=ar.master[o:o + ar.V_pad], out=logits, n=n_cols,
+                        out2=stats, scale_cols=V)
+        else:
+            ops.gemm_nt(hsel, ar.w('embeddings.weight'), L.EPI_BIAS, bias=ar.p('pred_layer.proj.bias'), out=logits, n=n_cols)
         if scores_out is not None:
             scores_out.append(logits[:, :V].float())
         dbias = None
-        if _VOCAB_FULL_TILES and n >= 1024:
+        if fused_lse:
+            loss_sum, _, dbias = ops.ce_from_block_stats(logits, V, y, stats, 1.0 / n, 1.0 / n)
+        elif _VOCAB_FULL_TILES and n >= 1024:
             # the pass that writes the gradient also sums its columns (the output-bias gradient up to the upstream scale):
             # no second pass over 2.4 GB in backward
             loss_sum, _, dbias = ops.ce_fwd_bwd_colsum(logits, V, y, 1.0 / n, 1.0 / n)

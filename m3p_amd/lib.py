@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # M3P_HIP_LIB: developer override used for A/B runs of two builds inside one GPU session
 LIB_PATH = os.environ.get('M3P_HIP_LIB') or os.path.join(_HERE, 'libm3p_hip.so')
 
-EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_DROP_RES, EPI_RES, EPI_DGELU, EPI_MUL, EPI_MULQ, EPI_BIAS_GELUQ = range(9)
+EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_DROP_RES, EPI_RES, EPI_DGELU, EPI_MUL, EPI_MULQ, EPI_BIAS_GELUQ, EPI_BIAS_LSE = range(10)
 
 
 class M3PError(RuntimeError):
@@ -64,6 +64,8 @@ SIGNATURES = {
     'm3p_ce_fwd_bwd': (_i, [_p, _i, _i, _i, _p, _p, _p, _f, _f, _p]),
     'm3p_ce_colsum_workspace_bytes': (C.c_size_t, [_i, _i]),
     'm3p_ce_fwd_bwd_colsum': (_i, [_p, _i, _i, _i, _p, _p, _p, _f, _p, _p, C.c_size_t, _p]),
+    'm3p_ce_lse_from_blocks': (_i, [_p, _i, _i, _p, _i, _p, _p, _p, _p, _p]),
+    'm3p_ce_bwd_colsum': (_i, [_p, _i, _i, _i, _p, _p, _f, _p, _p, C.c_size_t, _p]),
     'm3p_colsum_bf16': (_i, [_p, _i, _i, _i, _p, _p, _p]),
     'm3p_sumsq_f32': (_i, [_p, C.c_longlong, _p, _p]),
     'm3p_adam_step': (_i, [_p, _p, _p, _p, _p, C.c_longlong, _f, _f, _f, _f, _f, _f, _p, _f, _f, _i, _p]),

@@ -17,7 +17,7 @@ _DEBUG_CHECKS = os.environ.get('M3P_DEBUG_CHECKS') == '1'      # host-synchronis
 # the launch stream: {(kind, M, N, K): [(start_event, end_event), ...]}
 PROFILE = None
 _EPI_NAMES = ['gemm_nt/none', 'gemm_nt/bias', 'gemm_nt/bias_gelu', 'gemm_nt/bias_drop_res', 'gemm_nt/res',
-              'gemm_nt/dgelu', 'gemm_nt/mul', 'gemm_nt/mulq', 'gemm_nt/bias_geluq']
+              'gemm_nt/dgelu', 'gemm_nt/mul', 'gemm_nt/mulq', 'gemm_nt/bias_geluq', 'gemm_nt/bias_lse']
 
 
 PROFILE_ONLY = None     # if set: the one (kind, M, N, K) instance that is timed (bench.py: the dominant kernel)
@@ -53,6 +53,10 @@ def gemm_nt(a, w, epilogue=L.EPI_NONE, bias=None, aux=None, out=None, out2=None,
     if epilogue == L.EPI_MULQ:     # aux = the byte codes of gelu_fwd_gq for this [M, N], in the GEMM's fragment order
         _chk_bf16(a, w, out)
         assert aux is not None and aux.dtype == torch.uint8 and aux.is_contiguous() and aux.numel() == M * N
+    elif epilogue == L.EPI_BIAS_LSE:        # out2 = float32 [N / 64, M, 2] block statistics; scale_cols = V (valid columns)
+        _chk_bf16(a, w, out)
+        assert out2 is not None and out2.dtype == torch.float32 and out2.is_contiguous() and out2.numel() == (N // 64) * M * 2
+        assert bias is not None and 0 < scale_cols <= N
     elif epilogue == L.EPI_BIAS_GELUQ:      # out2 = where those codes go (uint8 [M * N]); C = gelu(a w^T + bias)
         _chk_bf16(a, w, out)
         assert out2 is not None and out2.dtype == torch.uint8 and out2.is_contiguous() and out2.numel() == M * N and bias is not None
@@ -67,8 +71,10 @@ def gemm_nt(a, w, epilogue=L.EPI_NONE, bias=None, aux=None, out=None, out2=None,
     ep.out2 = L.ptr(out2)
     ep.colsum = L.ptr(colsum)
     ep.ld_aux = aux.stride(0) if (aux is not None and epilogue != L.EPI_MULQ) else 0
-    ep.ld_out2 = out2.stride(0) if (out2 is not None and epilogue != L.EPI_BIAS_GELUQ) else 0
+    ep.ld_out2 = out2.stride(0) if (out2 is not None and epilogue not in (L.EPI_BIAS_GELUQ, L.EPI_BIAS_LSE)) else 0
     ep.scale_cols = scale_cols
+    if epilogue == L.EPI_BIAS_LSE:
+        ep.ld_out2, ep.scale_cols = scale_cols, 0
     ep.scale = scale
     ep.alpha = alpha
     ep.seed = seed
@@ -558,6 +564,28 @@ def ce_fwd_bwd_colsum(logits, V, target, loss_scale, grad_scale):
     rc = L.load().m3p_ce_fwd_bwd_colsum(logits.data_ptr(), ld, n, V, target.data_ptr(), row_loss.data_ptr(), row_lse.data_ptr(),
                                         grad_scale, cs.data_ptr(), ws.data_ptr(), ws.numel(), L.stream())
     L.check(rc, 'm3p_ce_fwd_bwd_colsum')
+    return (row_loss.sum() * loss_scale).reshape(1), row_loss, cs
+
+
+def ce_from_block_stats(logits, V, target, stats, loss_scale, grad_scale):
+    """ce_fwd_bwd_colsum with the first pass replaced by the 64-column block statistics the vocabulary projection wrote
+    (gemm_nt(..., EPI_BIAS_LSE, out2=stats)): the rows' log-sum-exp is a reduction over N / 64 pairs, not over the logits."""
+    n, ld = logits.shape[0], logits.stride(0)
+    dev = logits.device
+    row_loss = torch.empty(n, dtype=torch.float32, device=dev)
+    row_lse = torch.empty(n, dtype=torch.float32, device=dev)
+    cs = torch.empty(ld, dtype=torch.float32, device=dev)
+    scratch = torch.empty((32, n, 2), dtype=torch.float32, device=dev)
+    assert target.dtype == torch.int64 and stats.dtype == torch.float32 and stats.shape[1] == n
+    L.check(L.load().m3p_ce_lse_from_blocks(stats.data_ptr(), stats.shape[0], n, logits.data_ptr(), ld, target.data_ptr(),
+                                            row_loss.data_ptr(), row_lse.data_ptr(), scratch.data_ptr(), L.stream()),
+            'm3p_ce_lse_from_blocks')
+    need = L.load().m3p_ce_colsum_workspace_bytes(ld, n)
+    ws = _CE_WS.get(dev)
+    if ws is None or ws.numel() < need:
+        ws = _CE_WS[dev] = torch.empty(need, dtype=torch.uint8, device=dev)
+    L.check(L.load().m3p_ce_bwd_colsum(logits.data_ptr(), ld, n, V, target.data_ptr(), row_lse.data_ptr(), grad_scale, cs.data_ptr(),
+                                       ws.data_ptr(), ws.numel(), L.stream()), 'm3p_ce_bwd_colsum')
     return (row_loss.sum() * loss_scale).reshape(1), row_loss, cs
 
 

@@ -335,6 +335,40 @@ def test_gelu_byte_derivative_and_its_dgrad(M, N, K):
     assert float(d2.max()) <= 1.5 * ops.GQ_STEP and float(d2.pow(2).mean().sqrt()) < 0.4 * ops.GQ_STEP
 
 
+@pytest.mark.parametrize('M,N,V,K', [(1024, 1280, 1217, 128), (1024, 512, 512, 64), (2048, 2560, 2500, 768)])
+def test_projection_with_block_statistics_and_the_cross_entropy_from_them(M, N, V, K):
+    """The vocabulary projection that also leaves (max, sum exp) per row and 64-column block (M3P_EPI_BIAS_LSE), and the
+    cross-entropy built on them (m3p_ce_lse_from_blocks + m3p_ce_bwd_colsum), against the two-pass form on the plain
+    projection and against torch: same logits bit for bit, log-sum-exp / loss / gradient / bias gradient within fp32 / bf16
+    rounding.  V < N leaves pad columns (and, in the first case, a whole 64-column block) out of the statistics."""
+    from m3p_amd import ops, lib as L
+    g = torch.Generator(device='cuda').manual_seed(M + N + K)
+    a = torch.randn((M, K), device='cuda', generator=g).to(torch.bfloat16)
+    w = (torch.randn((N, K), device='cuda', generator=g) * (1.2 / math.sqrt(K))).to(torch.bfloat16)      # logits ~ N(0, 1.2^2) + bias
+    bias = torch.randn((N,), device='cuda', generator=g) * 0.5
+    y = torch.randint(0, V, (M,), device='cuda', generator=g)
+    plain = ops.gemm_nt(a, w, L.EPI_BIAS, bias=bias)
+    stats = torch.empty((N // 64, M, 2), dtype=torch.float32, device='cuda')
+    logits = ops.gemm_nt(a, w, L.EPI_BIAS_LSE, bias=bias, out2=stats, scale_cols=V)
+    assert torch.equal(plain, logits)
+    ref = torch.nn.functional.cross_entropy(plain[:, :V].float(), y, reduction='none')
+    ref_lse = torch.logsumexp(plain[:, :V].float(), dim=1)
+    l2 = plain.clone()
+    loss_a, rows_a, cs_a = ops.ce_fwd_bwd_colsum(l2, V, y, 1.0 / M, 1.0 / M)
+    loss_b, rows_b, cs_b = ops.ce_from_block_stats(logits, V, y, stats, 1.0 / M, 1.0 / M)
+    # (the block statistics are taken on the fp32 accumulators, the two-pass form reads the bf16 logits back: the rows'
+    #  log-sum-exp differ by the logits' rounding, a few 1e-3 at most)
+    assert float((rows_b - ref).abs().max()) < 2e-2 and abs(float(loss_b) - float(ref.mean())) < 2e-3
+    assert abs(float(loss_b) - float(loss_a)) < 2e-3
+    assert rel_l2(logits[:, :V].float(), l2[:, :V].float()) < 1e-2           # both now hold the gradient
+    assert float(logits[:, V:].float().abs().max()) == 0.0 if V < N else True
+    p = torch.softmax(plain[:, :V].float(), dim=1)
+    p[torch.arange(M, device='cuda'), y] -= 1.0
+    assert rel_l2(logits[:, :V].float(), p / M) < 1e-2
+    assert rel_l2(cs_b[:V], (p / M).sum(0)) < 2e-2
+    del ref_lse
+
+
 @pytest.mark.parametrize('N,K', [(2304, 768), (768, 768), (3072, 768), (768, 3072)])
 def test_gemm_wgrad_at_the_benchmarked_sizes(N, K):
     from m3p_amd import ops
