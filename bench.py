@@ -306,6 +306,33 @@ def main():
                          'rank 0 in three extra steps with each collective bracketed by events; zero1 gathers the updated '
                          'fp32 parameters during the next forward (the "params" rows)')
 
+    # sustained engine clock under this very workload: amdsmi's sclk (torch.cuda.clock_rate()) sampled from a host thread
+    # every 2 ms over five more steps AFTER the timed region (the sampler never runs inside it).  The 2.5 PF of the roofline
+    # is the matrix peak at the 2.4 GHz ceiling; clock x 256 CUs x 4096 FLOP/clk is what the chip could do at the clock its
+    # power budget actually let it hold (MI355X_MICROARCH.md, DVFS section)
+    clock = None
+    if rank == 0 and not multi:
+        import threading
+        samples, stop = [], threading.Event()
+
+        def _sample():
+            while not stop.is_set():
+                try:
+                    samples.append(torch.cuda.clock_rate())
+                except Exception:      # (no amdsmi on this box: the block is simply absent)
+                    return
+                time.sleep(0.002)
+        th = threading.Thread(target=_sample, daemon=True)
+        th.start()
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize()
+        stop.set()
+        th.join(timeout=2)
+        if len(samples) >= 10:
+            s_mhz = sorted(samples)
+            clock = dict(sclk_ghz_mean=round(sum(samples) / len(samples) / 1e3, 3), sclk_ghz_median=round(s_mhz[len(s_mhz) // 2] / 1e3, 3),
+                         samples=len(samples), source='torch.cuda.clock_rate() (amdsmi sclk) every 2 ms over 5 extra steps after the timed region')
     if rank == 0:
         seqs = args.steps * cfg['B'] * world
         value = seqs / dt
@@ -324,10 +351,13 @@ def main():
             ach = flops / (avg_ms * 1e-3) / 1e12
             kname = '%s M=%d N=%d K=%d' % (kind, M, N, K)
             traffic, tsrc = None, None
-            for rel in ('profiles/r03_traffic.json', 'profiles/r02_traffic.json', 'profiles/r01_traffic.json'):
+            counter_clock = None
+            for rel in ('profiles/r04_traffic.json', 'profiles/r03_traffic.json', 'profiles/r02_traffic.json', 'profiles/r01_traffic.json'):
                 tpath = os.path.join(ROOT, rel)
                 if os.path.exists(tpath):   # HBM bytes/launch from the committed rocprofv3 --pmc passes of this command
-                    traffic = json.load(open(tpath)).get('bench_keys', {}).get(kname)
+                    tj = json.load(open(tpath))
+                    traffic = tj.get('bench_keys', {}).get(kname)
+                    counter_clock = counter_clock or tj.get('gemm_clock_ghz')
                     if traffic is not None:
                         tsrc = rel + ' (committed rocprofv3 --pmc passes of this command; not measured in this run)'
                         break
@@ -339,6 +369,17 @@ def main():
                                                sum(v[0] for v in agg.values())) / (dt * 1e3), 3),
                         step_frac=round(value / world * fl / 1e12 / (PEAK_FP8_TFLOPS if args.fp8 else PEAK_BF16_TFLOPS), 4),
                         step_frac_peak=PEAK_FP8_TFLOPS if args.fp8 else PEAK_BF16_TFLOPS)
+            # secondary roofline: the same two fractions against the matrix peak AT THE SUSTAINED CLOCK (x2 for fp8)
+            ghz = (clock or {}).get('sclk_ghz_mean') or counter_clock
+            if ghz:
+                pk = ghz * 256 * 4096 / 1e3 * (2.0 if kind.startswith('gemm_fp8') else 1.0)
+                pk_step = ghz * 256 * 4096 / 1e3 * (2.0 if args.fp8 else 1.0)
+                roof['at_sustained_clock'] = dict(
+                    clock_ghz=ghz, peak=round(pk, 1), frac=round(ach / pk, 4),
+                    step_frac=round(value / world * fl / 1e12 / pk_step, 4),
+                    clock_source=(clock['source'] if clock else 'GRBM_GUI_ACTIVE / dispatch duration over the GEMM kernels, committed '
+                                  'rocprofv3 pass (profiles/*_counters.md); not measured in this run'),
+                    live=clock, counters_gemm_clock_ghz=counter_clock)
         metric = 'pre-train samples/sec (whole node), %dL/%dd seq=%d+%d' % (cfg['n_layers'], cfg['emb_dim'], cfg['T'], cfg['R'])
         out = dict(metric=metric, value=round(value, 2),
                    unit='sequences/s', n_gpus=world, steps=args.steps, warmup=args.warmup,

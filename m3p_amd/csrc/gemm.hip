@@ -322,7 +322,13 @@ __device__ __forceinline__ void load_aux_rows_issue(const M3PEpilogue& ep, int m
   const int srow = lane >> 3, sch = lane & 7;
   const bf16* X = reinterpret_cast<const bf16*>(ep.aux) + (size_t)(mrow0 + srow) * ep.ld_aux + nw + sch * 8;
 #pragma unroll
-  for (int it = 0; it < 4; ++it) t[it] = *reinterpret_cast<const u32x4*>(X + (size_t)(it * 8) * ep.ld_aux);
+  for (int it = 0; it < 4; ++it) {
+#ifdef M3P_ABL_NOAUX      // (timing ablation: what the aux tile's trip from memory costs the epilogue - results are garbage)
+    t[it] = u32x4{(uint32_t)lane, 0x3f803f80u, 0x3f803f80u, (uint32_t)it};
+#else
+    t[it] = *reinterpret_cast<const u32x4*>(X + (size_t)(it * 8) * ep.ld_aux);
+#endif
+  }
 }
 template <int EPI, bool SW = false>
 __device__ __forceinline__ void load_aux_rows_finish(int lane, char* r1, const u32x4 (&t)[4], bf16x4 (&auxv)[2][4]) {
@@ -577,85 +583,6 @@ __device__ __forceinline__ void epilogue_half_lse(bf16* __restrict__ C, int ldc,
     sm += __shfl_xor(sm, 16, 64);
     sm += __shfl_xor(sm, 32, 64);
     if (fg == 0) stats[mrow0 + ii * 16 + fr] = float2{m, sm};
-  }
-  bf16* Cp = C + (size_t)mrow0 * ldc + nw + sch * 8;
-#pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int row = it * 8 + srow;
-    *reinterpret_cast<u32x4*>(Cp + (size_t)row * ldc) = flip_halves(*reinterpret_cast<const u32x4*>(r1 + ep_off<true>(row, sch * 16)), it & 1);
-  }
-}
-
-#ifndef M3P_MULQ_MODE
-#define M3P_MULQ_MODE 0
-#endif
-// the same for a 32-row piece (two 16-row blocks through 4 KB of swizzled staging rows, four 16-byte row stores per lane)
-__device__ __forceinline__ void epilogue_halfq(bf16* __restrict__ C, int ldc, int mrow0, int nw, char* r1, const f32x4 (&rows0)[4],
-                                               const f32x4 (&rows1)[4], const u32x4& q0, const u32x4& q1, int lane, f32x4 (&csum)[4]) {
-  const int fr = lane & 15, fg = lane >> 4;
-  const int srow = lane >> 3, sch = lane & 7;
-#pragma unroll
-  for (int ii = 0; ii < 2; ++ii) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const uint32_t w = ii ? q1[j] : q0[j];
-      f32x4 g = f32x4{(float)(w & 0xFFu), (float)((w >> 8) & 0xFFu), (float)((w >> 16) & 0xFFu), (float)(w >> 24)};
-      g = g * GQ_STEP - GQ_OFF;
-      const f32x4 v = (ii ? rows1[j] : rows0[j]) * g;
-      const bf16x4 ob = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-      *reinterpret_cast<bf16x4*>(r1 + ep_off8<true>(ii * 16 + fr, (j * 16 + fg * 4) * 2)) = ob;
-      csum[j] += f32x4{(float)ob[0], (float)ob[1], (float)ob[2], (float)ob[3]};
-    }
-  }
-  bf16* Cp = C + (size_t)mrow0 * ldc + nw + sch * 8;
-#pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int row = it * 8 + srow;
-    *reinterpret_cast<u32x4*>(Cp + (size_t)row * ldc) = flip_halves(*reinterpret_cast<const u32x4*>(r1 + ep_off<true>(row, sch * 16)), it & 1);
-  }
-}
-
-// 32-row piece of the FFN1 epilogue that leaves BOTH things the layer needs of u = acc + bias (M3P_EPI_BIAS_GELUQ):
-// h = gelu_erf(u) staged to row order like any output tile, and gelu_erf'(u) as one byte per element written
-// straight from the accumulator layout in fragment order (16 bytes per lane and 16-row block: 1 KB per wave instruction,
-// no staging) - what M3P_EPI_MULQ reads back the same way.  u itself is never stored.  The arithmetic is written on
-// four-element vectors so that the polynomial runs on packed f32 instructions (the epilogue has the VALU to itself).
-__device__ __forceinline__ void epilogue_half_geluq(bf16* __restrict__ C, int ldc, uint8_t* __restrict__ qout, int mrow0, int nw,
-                                                    char* r1, const f32x4 (&rows0)[4], const f32x4 (&rows1)[4],
-                                                    const f32x4 (&biasv)[4], int lane) {
-  const int fr = lane & 15, fg = lane >> 4;
-  const int srow = lane >> 3, sch = lane & 7;
-#pragma unroll
-  for (int ii = 0; ii < 2; ++ii) {
-    u32x4 code;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      // (x stays fp32: with u never stored there is no bf16 copy anything else would have to agree with)
-      const f32x4 x = (ii ? rows1[j] : rows0[j]) + biasv[j];
-      // gelu_parts (common.hpp) on a vector: Phi(|x|) = 1 - (poly(t) t e) / 2, t = 1 / (1 + p z), z = |x| / sqrt 2, e = exp(-z^2)
-      f32x4 z, t, e;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) z[r] = fabsf(x[r]);
-      z *= 0.70710678118654752440f;
-      const f32x4 den = z * 0.3275911f + 1.0f;
-      const f32x4 ez = z * z * -1.4426950408889634f;          // exp(-z^2) = exp2(-z^2 log2 e)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { t[r] = __builtin_amdgcn_rcpf(den[r]); e[r] = __builtin_amdgcn_exp2f(ez[r]); }
-      f32x4 poly = t * 1.061405429f - 1.453152027f;
-      poly = poly * t + 1.421413741f;
-      poly = poly * t - 0.284496736f;
-      poly = poly * t + 0.254829592f;
-      const f32x4 tail = poly * t * e * 0.5f;                 // 1 - Phi(|x|)
-      f32x4 cdf;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) cdf[r] = (x[r] >= 0.f) ? 1.0f - tail[r] : tail[r];
-      const f32x4 hv = x * cdf;
-      const f32x4 gd = x * e * 0.39894228040143267794f + cdf;                  // gelu'(x) = Phi + x phi
-      const f32x4 qf = gd * GQ_INV + (GQ_OFF * GQ_INV + 0.5f);                 // in [0.7, 255.3): truncation = round to nearest
-      code[j] = (uint32_t)qf[0] | ((uint32_t)qf[1] << 8) | ((uint32_t)qf[2] << 16) | ((uint32_t)qf[3] << 24);
-      *reinterpret_cast<bf16x4*>(r1 + ep_off8<true>(ii * 16 + fr, (j * 16 + fg * 4) * 2)) = bf16x4{(bf16)hv[0], (bf16)hv[1], (bf16)hv[2], (bf16)hv[3]};
-    }
-    *reinterpret_cast<u32x4*>(qout + ii * 1024 + lane * 16) = code;
   }
   bf16* Cp = C + (size_t)mrow0 * ldc + nw + sch * 8;
 #pragma unroll
@@ -1349,14 +1276,13 @@ void gemm_nt_w8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
         }
         W8_TSEG(2);
       } else if constexpr (EPI == M3P_EPI_MULQ) {
-        // byte derivative in fragment order: one 16-byte load per lane and 16-row piece (the launcher admits whole tiles
-        // only, so `fast` always holds).  M3P_MULQ_MODE (A/B builds): 0 = codes two pieces ahead, three LDS-DMA pieces of
-        // K-tile +2 at the head of the epilogue and five inside the next K-tile (the aux epilogues' schedule); 1 = all eight
-        // code loads first, then ALL eight LDS-DMA pieces (the stage is free, and nothing behind them has to wait for them in
-        // the in-order vmcnt queue); 2 = mode 1 with 32-row pieces through 4 KB of staging per wave
+        // byte derivative in fragment order: one 16-byte load per lane and 16-row piece, two pieces ahead (the launcher admits
+        // whole tiles only, so `fast` always holds).  Measured and removed: all eight code loads
+        // up front with all eight LDS-DMA pieces of K-tile +2 behind them; 32-row pieces; the codes prefetched by LDS-DMA a
+        // whole K-tile ahead into the idle staging rows - all within 1 % of this form, while a build that reads no codes at
+        // all is 23 us faster: what the codes cost is their 129 MB on the fabric, not their latency.
         if (fast) {
           const uint8_t* qp = reinterpret_cast<const uint8_t*>(ep.aux) + gq_block_offset(tm, tn, tiles_n, wid, 0) + lane * 16;
-#if M3P_MULQ_MODE == 0
           char* r1 = smem + 2 * STAGE + wid * 2048;
           u32x4 qa = *reinterpret_cast<const u32x4*>(qp), qb = *reinterpret_cast<const u32x4*>(qp + 1024);
           __builtin_amdgcn_sched_barrier(0);
@@ -1373,33 +1299,6 @@ void gemm_nt_w8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
             __builtin_amdgcn_sched_barrier(0);
             qa = qc; qb = qd;
           }
-#else
-          u32x4 qv[8];
-#pragma unroll
-          for (int i = 0; i < 8; ++i) qv[i] = *reinterpret_cast<const u32x4*>(qp + i * 1024);
-          __builtin_amdgcn_sched_barrier(0);
-          if (W8_MORE2) {
-#pragma unroll
-            for (int pc = 0; pc < 8; ++pc) issue_load(cur, pc);
-            load_done();
-          }
-          __builtin_amdgcn_sched_barrier(0);
-#if M3P_MULQ_MODE == 1
-          char* r1 = smem + 2 * STAGE + wid * 2048;
-#pragma unroll
-          for (int hp = 0; hp < 8; ++hp) {
-            epilogue_pieceq(C, ldc, mw + 16 * hp, nw, r1, acc[hp], qv[hp], lane, csum);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-#else
-          char* r1 = smem + 2 * STAGE + wid * 4096;
-#pragma unroll
-          for (int hf = 0; hf < 4; ++hf) {
-            epilogue_halfq(C, ldc, mw + 32 * hf, nw, r1, acc[2 * hf], acc[2 * hf + 1], qv[2 * hf], qv[2 * hf + 1], lane, csum);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-#endif
-#endif
         }
         W8_TSEG(2);
       } else if (fast && kSpare && kMulE) {
@@ -2699,7 +2598,7 @@ static int launch_nt_gq(const bf16* A, int lda, const bf16* W, int ldw, bf16* C,
     return M3P_EINVAL;
   if (EPI == M3P_EPI_BIAS_LSE && (ep.ld_out2 <= 0 || ep.ld_out2 > N)) return M3P_EINVAL;
   const int tiles_m = M / 256, tiles_n = N / 256;
-  const size_t lds = 2 * 512 * ROWB + 8 * ((EPI != M3P_EPI_MULQ || M3P_MULQ_MODE == 2) ? 4096 : 2048);
+  const size_t lds = 2 * 512 * ROWB + 8 * (EPI != M3P_EPI_MULQ ? 4096 : 2048);
   auto kern = gemm_nt_w8_kernel<EPI>;
   static bool attr_set = false;
   if (!attr_set) {

@@ -195,7 +195,15 @@ __global__ __launch_bounds__(256) void ce_lse_partial_kernel(const float2* __res
   const int per = (n_blocks + CE_LSE_SPLIT - 1) / CE_LSE_SPLIT;
   const int b0 = blockIdx.y * per, b1 = min(n_blocks, b0 + per);
   float m = -INFINITY, s = 0.f;
-  for (int b = b0 + q; b < b1; b += 4) {
+  int b = b0 + q;
+  for (; b + 12 < b1; b += 16) {           // four independent loads in flight per thread: the fold is a dependent chain
+    float2 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = stats[(size_t)(b + 4 * k) * n_rows + row];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) lse_fold(m, s, v[k].x, v[k].y);
+  }
+  for (; b < b1; b += 4) {
     const float2 v = stats[(size_t)b * n_rows + row];
     lse_fold(m, s, v.x, v.y);
   }

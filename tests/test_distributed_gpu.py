@@ -230,3 +230,27 @@ def test_dp_two_ranks_over_rccl(scenario):
     if torch.cuda.device_count() < 2:
         pytest.skip('RCCL needs two devices (the driver\'s multi-GPU bench exercises it)')
     _check(scenario, 'nccl')
+
+
+def test_bench_multi_gpu_half_runs_unattended():
+    """bench.py's N > 1 half (launcher environment, wrapped model, `comm` block with the exposed wait and the per-bucket
+    bus bandwidth) is otherwise first executed by the driver's 8-GPU run: here it runs as a forced one-rank world under
+    torch.distributed.run on the one device a test box has, and the JSON line must parse with the fields the driver reads."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, M3P_DP_FORCE='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+           '--master-port', '29613', os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '2', '--warmup', '1',
+           '--no-cpu-baseline', '--batch', '32']
+    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = [ln for ln in res.stdout.splitlines() if ln.startswith('{')][-1]
+    out = json.loads(line)
+    assert out['n_gpus'] == 1 and out['steps'] == 2 and out['value'] > 0 and out['scaling'] == 'weak'
+    comm = out['comm']
+    assert comm['mode'] in ('zero1', 'allreduce') and comm['exposed_ms_per_step'] >= 0
+    assert comm['buckets'] and all(b['ms'] > 0 and b['MB'] > 0 for b in comm['buckets'].values())
+    assert any(k.startswith('params') for k in comm['buckets']) == (comm['mode'] == 'zero1')

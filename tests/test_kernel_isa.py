@@ -74,9 +74,10 @@ def test_eight_wave_gemm_fits_two_waves_per_simd(tmp_path):
             assert int(info['ScratchSize']) <= 32, (m.group(1), info['ScratchSize'])
             queued += 1
         else:
-            assert int(info['ScratchSize']) <= (0 if epi <= 4 else 32), (m.group(1), info['ScratchSize'])
+            # (7 - 9: the round-4 epilogues - byte-derivative multiply, bias-GELU + byte, bias + block statistics - no scratch)
+            assert int(info['ScratchSize']) <= (32 if epi in (5, 6) else 0), (m.group(1), info['ScratchSize'])
             seen += 1
-    assert seen == 7 and queued == 5, (seen, queued)
+    assert seen == 10 and queued == 5, (seen, queued)
     for m in re.finditer(r'^(_ZN\S*gemm_nt_w8f8_kernel\S*):', body, re.M):
         k = body.index('; Kernel info:', body.index('.Lfunc_end', m.end()))
         info = dict(re.findall(r'; (\w+): (\d+)', body[k:k + 700]))
