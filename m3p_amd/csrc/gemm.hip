@@ -592,6 +592,56 @@ __device__ __forceinline__ void epilogue_half_lse(bf16* __restrict__ C, int ldc,
   }
 }
 
+// 32-row piece of the FFN1 epilogue that leaves BOTH things the layer needs of u = acc + bias (M3P_EPI_BIAS_GELUQ):
+// h = gelu_erf(u) staged to row order like any output tile, and gelu_erf'(u) as one byte per element written
+// straight from the accumulator layout in fragment order (16 bytes per lane and 16-row block: 1 KB per wave instruction,
+// no staging) - what M3P_EPI_MULQ reads back the same way.  u itself is never stored.  The arithmetic is written on
+// four-element vectors so that the polynomial runs on packed f32 instructions (the epilogue has the VALU to itself).
+__device__ __forceinline__ void epilogue_half_geluq(bf16* __restrict__ C, int ldc, uint8_t* __restrict__ qout, int mrow0, int nw,
+                                                    char* r1, const f32x4 (&rows0)[4], const f32x4 (&rows1)[4],
+                                                    const f32x4 (&biasv)[4], int lane) {
+  const int fr = lane & 15, fg = lane >> 4;
+  const int srow = lane >> 3, sch = lane & 7;
+#pragma unroll
+  for (int ii = 0; ii < 2; ++ii) {
+    u32x4 code;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      // (x stays fp32: with u never stored there is no bf16 copy anything else would have to agree with)
+      const f32x4 x = (ii ? rows1[j] : rows0[j]) + biasv[j];
+      // gelu_parts (common.hpp) on a vector: Phi(|x|) = 1 - (poly(t) t e) / 2, t = 1 / (1 + p z), z = |x| / sqrt 2, e = exp(-z^2)
+      f32x4 z, t, e;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) z[r] = fabsf(x[r]);
+      z *= 0.70710678118654752440f;
+      const f32x4 den = z * 0.3275911f + 1.0f;
+      const f32x4 ez = z * z * -1.4426950408889634f;          // exp(-z^2) = exp2(-z^2 log2 e)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { t[r] = __builtin_amdgcn_rcpf(den[r]); e[r] = __builtin_amdgcn_exp2f(ez[r]); }
+      f32x4 poly = t * 1.061405429f - 1.453152027f;
+      poly = poly * t + 1.421413741f;
+      poly = poly * t - 0.284496736f;
+      poly = poly * t + 0.254829592f;
+      const f32x4 tail = poly * t * e * 0.5f;                 // 1 - Phi(|x|)
+      f32x4 cdf;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cdf[r] = (x[r] >= 0.f) ? 1.0f - tail[r] : tail[r];
+      const f32x4 hv = x * cdf;
+      const f32x4 gd = x * e * 0.39894228040143267794f + cdf;                  // gelu'(x) = Phi + x phi
+      const f32x4 qf = gd * GQ_INV + (GQ_OFF * GQ_INV + 0.5f);                 // in [0.7, 255.3): truncation = round to nearest
+      code[j] = (uint32_t)qf[0] | ((uint32_t)qf[1] << 8) | ((uint32_t)qf[2] << 16) | ((uint32_t)qf[3] << 24);
+      *reinterpret_cast<bf16x4*>(r1 + ep_off8<true>(ii * 16 + fr, (j * 16 + fg * 4) * 2)) = bf16x4{(bf16)hv[0], (bf16)hv[1], (bf16)hv[2], (bf16)hv[3]};
+    }
+    *reinterpret_cast<u32x4*>(qout + ii * 1024 + lane * 16) = code;
+  }
+  bf16* Cp = C + (size_t)mrow0 * ldc + nw + sch * 8;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int row = it * 8 + srow;
+    *reinterpret_cast<u32x4*>(Cp + (size_t)row * ldc) = flip_halves(*reinterpret_cast<const u32x4*>(r1 + ep_off<true>(row, sch * 16)), it & 1);
+  }
+}
+
 #if defined(M3P_RING_TL) || defined(M3P_W8_TL) || defined(M3P_WG_TL)
 __device__ unsigned long long g_ring_tl[256 * 8 * 16];  // debug build: per-wave cycle sums of the eight-wave kernel's segments
                                                         // ([256][8][8] segments, then [256][8][8] K-tile phases of the w8 kernel)
