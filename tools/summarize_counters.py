@@ -7,15 +7,20 @@ import collections, csv, glob, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, 'gpurun_out', 'counters')
 
+def newest(pattern):
+    """gpurun merges a call's files into what earlier calls left behind: only the newest run of a pass counts"""
+    fs = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return fs[-1:]
+
 def counters(sub):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
-    for f in glob.glob(os.path.join(src, sub, '*', '*counter_collection.csv')):
+    for f in newest(os.path.join(src, sub, '*', '*counter_collection.csv')):
         for r in csv.DictReader(open(f)):
             acc[r['Kernel_Name']][r['Counter_Name']].append(float(r['Counter_Value']))
     return acc
 
 stats = {}
-for f in glob.glob(os.path.join(src, 'stats', '*', '*kernel_stats.csv')):
+for f in newest(os.path.join(src, 'stats', '*', '*kernel_stats.csv')):
     for r in csv.DictReader(open(f)):
         stats[r['Name']] = (int(r['Calls']), float(r['AverageNs']))
 fetch, write, sq, tcc = counters('fetch'), counters('write'), counters('sq'), counters('tcc')
@@ -27,7 +32,7 @@ fetch, write, sq, tcc = counters('fetch'), counters('write'), counters('sq'), co
 # not reported.
 OVH_US = 7.0
 clk = collections.defaultdict(lambda: [0.0, 0.0, 0])
-for f in glob.glob(os.path.join(src, 'clk', '*', '*counter_collection.csv')):
+for f in newest(os.path.join(src, 'clk', '*', '*counter_collection.csv')):
     for r in csv.DictReader(open(f)):
         if r['Counter_Name'] == 'GRBM_GUI_ACTIVE':
             e = clk[r['Kernel_Name']]
