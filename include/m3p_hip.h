@@ -138,6 +138,13 @@ M3P_API size_t m3p_gemm_wgrad_workspace_bytes(void);
 M3P_API int m3p_gemm_wgrad_bf16(const void* dY, int lddy, const void* X, int ldx, float* dW, int lddw,
                                 int M, int N, int K, float alpha, void* workspace, size_t workspace_bytes,
                                 void* stream);
+/* The same product STORED instead of accumulated: dW = alpha * dY^T X, for a gradient the caller knows to be all zeros (the
+ * first product of a step into it).  Only for shapes the four-wave kernel deals out as whole tiles (N, K multiples of 256,
+ * M % 64 == 0, at least four 256 x 256 tiles per CU - the tied vocabulary matrix, autograd of transformer.py:111): every tile
+ * is then flushed exactly once and a plain store replaces 4-byte atomic read-modify-writes of a 768-MB matrix no cache holds.
+ * Anything else returns M3P_ENOTIMPL and the caller accumulates with m3p_gemm_wgrad_bf16. */
+M3P_API int m3p_gemm_wgrad_store_bf16(const void* dY, int lddy, const void* X, int ldx, float* dW, int lddw, int M, int N, int K,
+                                      float alpha, void* workspace, size_t workspace_bytes, void* stream);
 /* Two weight gradients over the same M rows in ONE launch of the four-wave kernel (and one reduction): dWa += dYa^T Xa,
  * dWb += dYb^T Xb.  The attention sub-layer's out_lin (768 x 768: 9 output tiles) and q/k/v (27 tiles) gradients of
  * MultiHeadAttention (transformer.py:178-181, :208) together fill the 256 CUs as evenly as one FFN gradient does - apart they

@@ -2818,7 +2818,7 @@ __global__ __launch_bounds__(256)
 void gemm_wgrad_w4_kernel(const bf16* __restrict__ dY_a, int lddy_a, const bf16* __restrict__ X_a, int ldx_a,
                           float* __restrict__ dW_a, int lddw_a, int M, int N, int K, float alpha,
                           int tiles_i, int tiles_j_a, int WR_CHUNK, float* __restrict__ ws, int* __restrict__ ws_tile,
-                          int dbg_flags, WgradProblem pb) {
+                          int dbg_flags, int overwrite, WgradProblem pb) {
   // Two products over the same M in one launch (pb.tiles != 0; one-segment-per-workgroup mode only): the tiles of product b
   // follow those of product a in the tile numbering, every workgroup picks its product once, before the K loop.  36 tiles of
   // out_lin + q/k/v then share one launch, one end-of-kernel flush and one reduction instead of 9 tiles x 28 chunks beside
@@ -3266,7 +3266,10 @@ void gemm_wgrad_w4_kernel(const bf16* __restrict__ dY_a, int lddy_a, const bf16*
           for (int a = 0; a < 8; ++a)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-              if (!WG_DBG(1)) unsafeAtomicAdd(dcol + (size_t)(a * 16 + r) * lddw, alpha * v[a * 4 + r]);
+              // overwrite (whole-tile round-robin mode on a gradient the caller knows to be zero: the vocabulary matrix's
+              // first product of a step): a plain store - the atomic is a read-modify-write of 768 MB that is not in any cache
+              if (overwrite) dcol[(size_t)(a * 16 + r) * lddw] = alpha * v[a * 4 + r];
+              else if (!WG_DBG(1)) unsafeAtomicAdd(dcol + (size_t)(a * 16 + r) * lddw, alpha * v[a * 4 + r]);
         }
       }
       if (to_ws && tid == 0) ws_tile[slot] = tile_id0 + cc.t;
@@ -3725,7 +3728,8 @@ static bool wgrad_w4_ok(int M, int N, int K, int lddy, int ldx, const void* dY, 
          (lddy % 8) == 0 && (ldx % 8) == 0 && !((uintptr_t)dY & 15) && !((uintptr_t)X & 15);
 }
 static int launch_wgrad_w4(const void* dY, int lddy, const void* X, int ldx, float* dW, int lddw, int M, int N, int K,
-                           float alpha, void* workspace, size_t workspace_bytes, void* stream, const WgradProblem* pb_in) {
+                           float alpha, void* workspace, size_t workspace_bytes, void* stream, const WgradProblem* pb_in,
+                           bool store = false) {
   const int ti = N / 256, tj = K / 256;
   WgradProblem pb = {};
   if (pb_in) pb = *pb_in;
@@ -3743,6 +3747,7 @@ static int launch_wgrad_w4(const void* dY, int lddy, const void* X, int ldx, flo
   int chunk = (int)(share < nmt ? (share < 1 ? 1 : share) : nmt);
   if ((long long)ntile >= 4LL * grid) chunk = 0;   // many tiles: round-robin whole tiles
   if (pb_in && chunk == 0) return M3P_EINVAL;       // (pairs only in the one-segment-per-workgroup mode; the caller checks)
+  if (store && chunk != 0) return M3P_ENOTIMPL;     // (a plain store needs every tile flushed exactly once: whole-tile round-robin mode)
   // workspace for first-segment partials: one 256-KB slot per workgroup + a tile-id word each, owned by the
   // CALLER (m3p_gemm_wgrad_workspace_bytes): launches that may overlap on different streams need one each.
   // Without it the partial tiles go to dW with fp32 atomics (slower: DESIGN.md section 4).
@@ -3752,7 +3757,7 @@ static int launch_wgrad_w4(const void* dY, int lddy, const void* X, int ldx, flo
     ws = (float*)workspace;
   int* ws_tile = ws ? (int*)(ws + (size_t)grid * (65536 + 272)) : nullptr;
   hipLaunchKernelGGL(gemm_wgrad_w4_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, (const bf16*)dY, lddy,
-                     (const bf16*)X, ldx, dW, lddw, M, N, K, alpha, ti, tj, chunk, ws, ws_tile, g_ablate, pb);
+                     (const bf16*)X, ldx, dW, lddw, M, N, K, alpha, ti, tj, chunk, ws, ws_tile, g_ablate, store ? 1 : 0, pb);
   M3P_CHECK_LAUNCH();
   if (ws) {
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(16, ntile), dim3(256), 0, (hipStream_t)stream, (const float*)ws,
@@ -3780,6 +3785,14 @@ int m3p_gemm_wgrad_pair_bf16(const void* dYa, int lddya, const void* Xa, int ldx
   if (lddya < Na || ldxa < Ka || lddyb < Nb || ldxb < Kb) return M3P_EINVAL;
   WgradProblem pb = {(const bf16*)dYb, (const bf16*)Xb, dWb, lddyb, ldxb, lddwb, Nb / 256, Kb / 256};
   return launch_wgrad_w4(dYa, lddya, Xa, ldxa, dWa, lddwa, M, Na, Ka, alpha, workspace, workspace_bytes, stream, &pb);
+}
+
+int m3p_gemm_wgrad_store_bf16(const void* dY, int lddy, const void* X, int ldx, float* dW, int lddw, int M, int N, int K,
+                              float alpha, void* workspace, size_t workspace_bytes, void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || (lddy % 8) != 0 || (ldx % 8) != 0 || !dW || lddw < K) return M3P_EINVAL;
+  if (lddy < N || ldx < K || ((uintptr_t)dY & 15) || ((uintptr_t)X & 15)) return M3P_EINVAL;
+  if (!wgrad_w4_ok(M, N, K, lddy, ldx, dY, X)) return M3P_ENOTIMPL;
+  return launch_wgrad_w4(dY, lddy, X, ldx, dW, lddw, M, N, K, alpha, workspace, workspace_bytes, stream, nullptr, true);
 }
 
 int m3p_gemm_wgrad_bf16(const void* dY, int lddy, const void* X, int ldx, float* dW, int lddw, int M, int N, int K,

@@ -1089,6 +1089,9 @@ class MLMHeadFn(torch.autograd.Function):
     def backward(ctx, gloss):
         model = ctx.model
         ar = model.arena()
+        # first product of the step into the tied matrix's gradient (nothing has touched it, or the bias gradient its pad rows
+        # alias, since the optimizer zeroed them): the weight gradient may store instead of adding
+        fresh = 'embeddings.weight' not in ar.touched and 'pred_layer.proj.bias' not in ar.touched
         ar.touch('embeddings.weight', 'pred_layer.proj.bias')
         d, V = model.dim, model.n_words
         hsel, dlogits, row_idx, shape, stride, soff, base, dbias = ctx.saved
@@ -1101,7 +1104,7 @@ class MLMHeadFn(torch.autograd.Function):
             # exact zeros (the CE kernel wrote them), so rows V .. V_pad - 1 of "the matrix" - the head of the bias
             # gradient that follows it in the arena - receive += 0
             o = ar.offsets['embeddings.weight'][0]
-            ops.gemm_wgrad(dlogits, hs, ar.grad[o:o + ar.V_pad * d].view(ar.V_pad, d), n=ar.V_pad, k=d)
+            ops.gemm_wgrad(dlogits, hs, ar.grad[o:o + ar.V_pad * d].view(ar.V_pad, d), n=ar.V_pad, k=d, dw_is_zero=fresh)
         else:
             ops.gemm_wgrad(dlogits, hs, ar.g('embeddings.weight'), n=V, k=d)
         if dbias is not None:

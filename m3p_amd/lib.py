@@ -43,6 +43,7 @@ SIGNATURES = {
     'm3p_gemm_nn_streamk_f32': (_i, [_p, _i, _p, _i, _i, _p, _i, _i, _i, _i, _f, _p]),
     'm3p_gemm_wgrad_workspace_bytes': (C.c_size_t, []),
     'm3p_gemm_wgrad_bf16': (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _f, _p, C.c_size_t, _p]),
+    'm3p_gemm_wgrad_store_bf16': (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _f, _p, C.c_size_t, _p]),
     'm3p_gemm_wgrad_pair_bf16': (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _f, _p, C.c_size_t, _p]),
     'm3p_layernorm_fwd': (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p]),
     'm3p_layernorm_bwd': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _u32, _u32, _f, _p]),

@@ -182,8 +182,9 @@ def _wgrad_workspace(device):
     return ws
 
 
-def gemm_wgrad(dy, x, dw, alpha=1.0, n=None, k=None):
-    """dw[N,K] (fp32) += alpha * dy[M,N]^T @ x[M,K]."""
+def gemm_wgrad(dy, x, dw, alpha=1.0, n=None, k=None, dw_is_zero=False):
+    """dw[N,K] (fp32) += alpha * dy[M,N]^T @ x[M,K].  dw_is_zero: the caller knows dw[:N, :K] to hold zeros - shapes dealt out
+    as whole tiles (the vocabulary matrix) are then stored instead of accumulated with atomics; same result."""
     _chk_bf16(dy, x)
     assert dw.dtype == torch.float32 and dw.stride(-1) == 1
     M = dy.shape[0]
@@ -192,6 +193,14 @@ def gemm_wgrad(dy, x, dw, alpha=1.0, n=None, k=None):
     assert x.shape[0] == M and dw.shape[0] >= N and dw.shape[1] >= K
     e0 = _prof_begin(('gemm_wgrad', M, N, K))
     ws = _wgrad_workspace(dy.device)
+    if dw_is_zero:
+        rc = L.load().m3p_gemm_wgrad_store_bf16(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), dw.data_ptr(),
+                                                dw.stride(0), M, N, K, alpha, ws.data_ptr(), ws.numel(), L.stream())
+        if rc == 0:
+            _prof_end(e0, ('gemm_wgrad', M, N, K))
+            return dw
+        if rc != -2:        # (M3P_ENOTIMPL: not a whole-tile shape - accumulate below)
+            L.check(rc, 'm3p_gemm_wgrad_store_bf16')
     rc = L.load().m3p_gemm_wgrad_bf16(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), dw.data_ptr(),
                                       dw.stride(0), M, N, K, alpha, ws.data_ptr(), ws.numel(), L.stream())
     L.check(rc, 'm3p_gemm_wgrad_bf16')

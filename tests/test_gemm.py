@@ -406,6 +406,26 @@ def test_gemm_wgrad_pair(M, Na, Ka, Nb, Kb):
         assert rel_l2(dw.double(), ref) < 1e-5, (n, k)
 
 
+def test_gemm_wgrad_stored_into_a_zero_gradient():
+    """dw_is_zero: shapes the four-wave kernel deals out as whole tiles (>= 4 tiles per CU - the vocabulary matrix's form)
+    are stored instead of accumulated with atomics; the result must equal the accumulating call's on zeros, and a shape
+    that is not dealt out that way must quietly accumulate (here: into zeros, so the same answer)."""
+    from m3p_amd import ops
+    for M, N, K in ((4096, 16384, 4096), (4096, 768, 768)):
+        g = torch.Generator(device='cuda').manual_seed(N + K)
+        dy = (torch.randn((M, N), device='cuda', generator=g) * 0.1).to(torch.bfloat16)
+        x = torch.randn((M, K), device='cuda', generator=g).to(torch.bfloat16)
+        stored = torch.full((N, K), float('nan'), device='cuda') if N > 768 else torch.zeros((N, K), device='cuda')
+        ops.gemm_wgrad(dy, x, stored, alpha=0.5, dw_is_zero=True)       # (NaN-filled: a store must not read what was there)
+        added = torch.zeros((N, K), device='cuda')
+        ops.gemm_wgrad(dy, x, added, alpha=0.5)
+        assert torch.isfinite(stored).all()
+        assert rel_l2(stored.double(), added.double()) < 1e-6
+        ref = 0.5 * (dy[:, :256].double().t() @ x.double())
+        assert rel_l2(stored[:256].double(), ref) < 1e-5
+        del stored, added, ref
+
+
 def test_gemm_wgrad_pair_with_gradients_the_workspace_form_cannot_take():
     """A pair whose gradient views are 4 bytes off 16-byte alignment (or have an odd pitch): the entry point must fall back to
     two single launches (each of which flushes with atomics) instead of pairing on the atomic path - both against fp64."""

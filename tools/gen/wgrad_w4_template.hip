@@ -14,7 +14,7 @@ __global__ __launch_bounds__(256)
 void gemm_wgrad_w4_kernel(const bf16* __restrict__ dY_a, int lddy_a, const bf16* __restrict__ X_a, int ldx_a,
                           float* __restrict__ dW_a, int lddw_a, int M, int N, int K, float alpha,
                           int tiles_i, int tiles_j_a, int WR_CHUNK, float* __restrict__ ws, int* __restrict__ ws_tile,
-                          int dbg_flags, WgradProblem pb) {
+                          int dbg_flags, int overwrite, WgradProblem pb) {
   // Two products over the same M in one launch (pb.tiles != 0; one-segment-per-workgroup mode only): the tiles of product b
   // follow those of product a in the tile numbering, every workgroup picks its product once, before the K loop.  36 tiles of
   // out_lin + q/k/v then share one launch, one end-of-kernel flush and one reduction instead of 9 tiles x 28 chunks beside
@@ -336,7 +336,10 @@ void gemm_wgrad_w4_kernel(const bf16* __restrict__ dY_a, int lddy_a, const bf16*
           for (int a = 0; a < 8; ++a)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-              if (!WG_DBG(1)) unsafeAtomicAdd(dcol + (size_t)(a * 16 + r) * lddw, alpha * v[a * 4 + r]);
+              // overwrite (whole-tile round-robin mode on a gradient the caller knows to be zero: the vocabulary matrix's
+              // first product of a step): a plain store - the atomic is a read-modify-write of 768 MB that is not in any cache
+              if (overwrite) dcol[(size_t)(a * 16 + r) * lddw] = alpha * v[a * 4 + r];
+              else if (!WG_DBG(1)) unsafeAtomicAdd(dcol + (size_t)(a * 16 + r) * lddw, alpha * v[a * 4 + r]);
         }
       }
       if (to_ws && tid == 0) ws_tile[slot] = tile_id0 + cc.t;
