@@ -124,6 +124,13 @@ M3P_API int m3p_gemm_nt_streamk_f32(const void* A, int lda, const void* W, int l
  * multiple of 64): rows >= k_valid are not read - the matching columns of A must be zeros. */
 M3P_API int m3p_gemm_nn_streamk_f32(const void* A, int lda, const void* W, int ldw, int k_valid, float* C,
                                     int ldc, int M, int N, int K, float alpha, void* stream);
+/* The same product for whole-tile shapes on the four-wave kernel (round 4): Cf[M,N] (fp32) += alpha * A[M,K] x W[K,N], A read as
+ * an NT activation panel (K contiguous), W through transposing LDS reads, (tile, K-chunk) segments dealt to the CUs, partial
+ * tiles folded through the caller's weight-gradient workspace (m3p_gemm_wgrad_workspace_bytes) - no atomics.  ALL K rows of W
+ * are read (unlike k_valid above): where A holds zero columns, W must still hold finite numbers.  M % 256 == 0, N % 256 == 0,
+ * K % 64 == 0, K >= 4096, lda / ldw % 8 == 0; anything else returns M3P_ENOTIMPL (use the stream-K form). */
+M3P_API int m3p_gemm_nn_w4_f32(const void* A, int lda, const void* W, int ldw, float* C, int ldc, int M, int N, int K, float alpha,
+                               void* workspace, size_t workspace_bytes, void* stream);
 
 /* Weight gradient: dW[N,K] (fp32, pitch lddw) += alpha * sum_m dY[m,n] * X[m,k]
  * (dY bf16 [M,N] pitch lddy, X bf16 [M,K] pitch ldx).  Accumulates with fp32 atomics

@@ -2814,6 +2814,13 @@ void gemm_wgrad_kernel(const bf16* __restrict__ dY, int lddy, const bf16* __rest
 // ends with fp32 atomics straight from the AGPRs, the next one starts with C = 0.
 // Full tiles only (N % 256 == 0, K % 256 == 0, M % 64 == 0): everything else stays on the ring kernel.
 // ---------------------------------------------------------------------------------
+// YROWS (the vocabulary DATA gradient dH [n, d] += dlogits [n, V] x E [V, d], round 4): the first operand is given with the
+// contraction index CONTIGUOUS - dY_a[i * lddy + m], rows = output rows - i.e. as an NT GEMM's activation panel; its K-tile is
+// staged as 256 rows x 128 B (chunk ^= row & 7 on the source, like the NT kernels) and its fragments are plain ds_read_b128,
+// which deliver exactly what the two transposing reads deliver for a contraction-strided operand: eight consecutive
+// contraction elements of one output row per lane.  Everything else - the second operand's transposing reads, the MFMA
+// stream, the (tile, chunk) schedule, the workspace flush and the reduction - is the weight-gradient kernel's.
+template <bool YROWS>
 __global__ __launch_bounds__(256)
 void gemm_wgrad_w4_kernel(const bf16* __restrict__ dY_a, int lddy_a, const bf16* __restrict__ X_a, int ldx_a,
                           float* __restrict__ dW_a, int lddw_a, int M, int N, int K, float alpha,
@@ -2898,13 +2905,17 @@ void gemm_wgrad_w4_kernel(const bf16* __restrict__ dY_a, int lddy_a, const bf16*
     const int gc = l_pos ^ (f << 1);
     y_off[p] = row * lddy + gc * 8 - (-4096 + 1024 * p) / 2;
     x_off[p] = row * ldx + gc * 8 - (-4096 + 1024 * p) / 2;
+    if (YROWS) {      // piece p of wave w = rows 64 w + 8 p .. + 7 of the 256-row panel, 128 B each: lane -> (row l >> 3, slot l & 7)
+      const int yrow = wid * 64 + 8 * p + (lane >> 3);
+      y_off[p] = yrow * lddy + (((lane & 7) ^ (yrow & 7)) * 8) - (-4096 + 1024 * p) / 2;
+    }
   }
   const bf16* y_base;
   const bf16* x_base;
   auto set_load_ktile = [&]() {
     const int ti = lc.t / tiles_j, tj = lc.t - ti * tiles_j;
     const size_t mbase = (size_t)(seg_m0 + lc.mt) * KT;
-    y_base = dY + mbase * lddy + ti * TI;
+    y_base = YROWS ? dY + (size_t)(ti * TI) * lddy + mbase : dY + mbase * lddy + ti * TI;
     x_base = X + mbase * ldx + tj * TJ;
   };
   set_load_ktile();
@@ -2925,7 +2936,7 @@ void gemm_wgrad_w4_kernel(const bf16* __restrict__ dY_a, int lddy_a, const bf16*
       default: WG_LD1(src, 3072); break;
     }
   };
-  const size_t y_step = (size_t)KT * lddy, x_step = (size_t)KT * ldx;
+  const size_t y_step = YROWS ? (size_t)KT : (size_t)KT * lddy, x_step = (size_t)KT * ldx;
   auto load_done = [&]() {
     // past the end of this workgroup's stream the last K-tile is re-loaded into a stage nobody
     // reads again (keeps the loop body and the vmcnt bookkeeping uniform).
@@ -2960,6 +2971,15 @@ void gemm_wgrad_w4_kernel(const bf16* __restrict__ dY_a, int lddy_a, const bf16*
     y_addr[1][c] = y_addr[0][c] + STAGE;
     x_addr[1][c] = x_addr[0][c] + STAGE;
   }
+  // YROWS: fragment c of k-step ks = 16 bytes of row 128 wi + 16 c + ft at chunk (fg + 4 ks) ^ (row & 7)
+  uint32_t yk_addr[2][2][8];      // [k-step][stage][c]
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      yk_addr[ks][0][c] = lds0 + (wi * 128 + 16 * c + ft) * 128 + (((fg + 4 * ks) ^ (ft & 7)) << 4);
+      yk_addr[ks][1][c] = yk_addr[ks][0][c] + STAGE;
+    }
   // one fragment = two tr16 reads (rows +0 / +4); OFF selects the k-step (0 / 16384).  The outputs are EARLY-CLOBBER: without
   // the '&' the compiler may give the first read's destination the address register (it did, in 21 of the kernel's 80 pairs),
   // and when the wave stalls between the two reads for longer than the LDS latency the first read's data IS the second
@@ -2968,6 +2988,10 @@ void gemm_wgrad_w4_kernel(const bf16* __restrict__ dY_a, int lddy_a, const bf16*
   // in ~20 runs of the suite)
 #define WG_TR2(LO, HI, ADDR, OFF) asm volatile("ds_read_b64_tr_b16 %0, %2 offset:" #OFF "\n\tds_read_b64_tr_b16 %1, %2 offset:" #OFF "+2048" \
                                                : "=&v"(LO), "=&v"(HI) : "v"(ADDR))
+// the first operand's fragment c of k-step KS from stage S: two transposing reads, or (YROWS) one ds_read_b128
+#define WG_YRD(C, S, KS) do { if constexpr (YROWS) asm volatile("ds_read_b128 %0, %1" : "=v"(yq[C]) : "v"(yk_addr[KS][S][C])); \
+                              else if constexpr ((KS) == 0) WG_TR2(yl[C], yh[C], y_addr[S][C], 0);                           \
+                              else WG_TR2(yl[C], yh[C], y_addr[S][C], 16384); } while (0)
 #define WG_LGKM0() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 
   asm volatile("" ::: "a0", "a255");     // reserve all 256 AGPRs (see gemm_nt_w4_kernel)
@@ -2989,6 +3013,8 @@ void gemm_wgrad_w4_kernel(const bf16* __restrict__ dY_a, int lddy_a, const bf16*
   };
 
   s16x4 yl[8], yh[8], xl[8], xh[8];     // raw halves of the fragments being fetched
+  bf16x8 yq[8];                         // (YROWS: the first operand's fragments arrive whole)
+  auto yfrag = [&](int c) { if constexpr (YROWS) return yq[c]; else return frag(yl[c], yh[c]); };
   bf16x8 yf0[8], xf0[8], yf1[8], xf1[8];
   // the stage is a compile-time fact of each phase body (the K loop is unrolled by two): fragment addresses and LDS-DMA
   // destinations are then plain registers / immediates
@@ -2998,35 +3024,35 @@ void gemm_wgrad_w4_kernel(const bf16* __restrict__ dY_a, int lddy_a, const bf16*
     constexpr bool PEND = decltype(pend_c)::value;     // (false in a workgroup's very first step only: nothing to top up yet)
     __builtin_amdgcn_sched_barrier(0);
     WG_M(yf0, xf0, 0, 0);
-    WG_M(yf0, xf0, 0, 1); WG_TR2(yl[0], yh[0], y_addr[s_cur][0], 16384);
+    WG_M(yf0, xf0, 0, 1); WG_YRD(0, s_cur, 1);
     WG_M(yf0, xf0, 0, 2); WG_LP(11);
     WG_M(yf0, xf0, 0, 3);
     WG_M(yf0, xf0, 0, 4);
-    WG_M(yf0, xf0, 0, 5); WG_TR2(yl[1], yh[1], y_addr[s_cur][1], 16384);
+    WG_M(yf0, xf0, 0, 5); WG_YRD(1, s_cur, 1);
     WG_M(yf0, xf0, 0, 6); WG_LP(12);
     WG_M(yf0, xf0, 0, 7);
     WG_M(yf0, xf0, 1, 0);
-    WG_M(yf0, xf0, 1, 1); WG_TR2(yl[2], yh[2], y_addr[s_cur][2], 16384);
+    WG_M(yf0, xf0, 1, 1); WG_YRD(2, s_cur, 1);
     WG_M(yf0, xf0, 1, 2); WG_LP(13);
     WG_M(yf0, xf0, 1, 3);
     WG_M(yf0, xf0, 1, 4);
-    WG_M(yf0, xf0, 1, 5); WG_TR2(yl[3], yh[3], y_addr[s_cur][3], 16384);
+    WG_M(yf0, xf0, 1, 5); WG_YRD(3, s_cur, 1);
     WG_M(yf0, xf0, 1, 6); WG_LP(14);
     WG_M(yf0, xf0, 1, 7);
     WG_M(yf0, xf0, 2, 0);
-    WG_M(yf0, xf0, 2, 1); WG_TR2(yl[4], yh[4], y_addr[s_cur][4], 16384);
+    WG_M(yf0, xf0, 2, 1); WG_YRD(4, s_cur, 1);
     WG_M(yf0, xf0, 2, 2); WG_LP(15);
     WG_M(yf0, xf0, 2, 3);
     WG_M(yf0, xf0, 2, 4);
-    WG_M(yf0, xf0, 2, 5); WG_TR2(yl[5], yh[5], y_addr[s_cur][5], 16384);
+    WG_M(yf0, xf0, 2, 5); WG_YRD(5, s_cur, 1);
     WG_M(yf0, xf0, 2, 6);
     WG_M(yf0, xf0, 2, 7);
     WG_M(yf0, xf0, 3, 0);
-    WG_M(yf0, xf0, 3, 1); WG_TR2(yl[6], yh[6], y_addr[s_cur][6], 16384);
+    WG_M(yf0, xf0, 3, 1); WG_YRD(6, s_cur, 1);
     WG_M(yf0, xf0, 3, 2);
     WG_M(yf0, xf0, 3, 3);
     WG_M(yf0, xf0, 3, 4);
-    WG_M(yf0, xf0, 3, 5); WG_TR2(yl[7], yh[7], y_addr[s_cur][7], 16384);
+    WG_M(yf0, xf0, 3, 5); WG_YRD(7, s_cur, 1);
     WG_M(yf0, xf0, 3, 6);
     WG_M(yf0, xf0, 3, 7);
     WG_M(yf0, xf0, 4, 0);
@@ -3069,35 +3095,35 @@ void gemm_wgrad_w4_kernel(const bf16* __restrict__ dY_a, int lddy_a, const bf16*
     constexpr int s_cur = decltype(stage_c)::value;
     __builtin_amdgcn_sched_barrier(0);
     WG_M(yf1, xf1, 0, 0); WG_L(0);
-    WG_M(yf1, xf1, 0, 1); WG_TR2(yl[0], yh[0], y_addr[s_cur ^ 1][0], 0);
+    WG_M(yf1, xf1, 0, 1); WG_YRD(0, s_cur ^ 1, 0);
     WG_M(yf1, xf1, 0, 2);
     WG_M(yf1, xf1, 0, 3);
     WG_M(yf1, xf1, 0, 4);
-    WG_M(yf1, xf1, 0, 5); WG_TR2(yl[1], yh[1], y_addr[s_cur ^ 1][1], 0);
+    WG_M(yf1, xf1, 0, 5); WG_YRD(1, s_cur ^ 1, 0);
     WG_M(yf1, xf1, 0, 6); WG_L(1);
     WG_M(yf1, xf1, 0, 7);
     WG_M(yf1, xf1, 1, 0);
-    WG_M(yf1, xf1, 1, 1); WG_TR2(yl[2], yh[2], y_addr[s_cur ^ 1][2], 0);
+    WG_M(yf1, xf1, 1, 1); WG_YRD(2, s_cur ^ 1, 0);
     WG_M(yf1, xf1, 1, 2);
     WG_M(yf1, xf1, 1, 3);
     WG_M(yf1, xf1, 1, 4); WG_L(2);
-    WG_M(yf1, xf1, 1, 5); WG_TR2(yl[3], yh[3], y_addr[s_cur ^ 1][3], 0);
+    WG_M(yf1, xf1, 1, 5); WG_YRD(3, s_cur ^ 1, 0);
     WG_M(yf1, xf1, 1, 6);
     WG_M(yf1, xf1, 1, 7);
     WG_M(yf1, xf1, 2, 0);
-    WG_M(yf1, xf1, 2, 1); WG_TR2(yl[4], yh[4], y_addr[s_cur ^ 1][4], 0);
+    WG_M(yf1, xf1, 2, 1); WG_YRD(4, s_cur ^ 1, 0);
     WG_M(yf1, xf1, 2, 2); WG_L(3);
     WG_M(yf1, xf1, 2, 3);
     WG_M(yf1, xf1, 2, 4);
-    WG_M(yf1, xf1, 2, 5); WG_TR2(yl[5], yh[5], y_addr[s_cur ^ 1][5], 0);
+    WG_M(yf1, xf1, 2, 5); WG_YRD(5, s_cur ^ 1, 0);
     WG_M(yf1, xf1, 2, 6);
     WG_M(yf1, xf1, 2, 7);
     WG_M(yf1, xf1, 3, 0); WG_L(4);
-    WG_M(yf1, xf1, 3, 1); WG_TR2(yl[6], yh[6], y_addr[s_cur ^ 1][6], 0);
+    WG_M(yf1, xf1, 3, 1); WG_YRD(6, s_cur ^ 1, 0);
     WG_M(yf1, xf1, 3, 2);
     WG_M(yf1, xf1, 3, 3);
     WG_M(yf1, xf1, 3, 4);
-    WG_M(yf1, xf1, 3, 5); WG_TR2(yl[7], yh[7], y_addr[s_cur ^ 1][7], 0);
+    WG_M(yf1, xf1, 3, 5); WG_YRD(7, s_cur ^ 1, 0);
     WG_M(yf1, xf1, 3, 6); WG_L(5);
     WG_M(yf1, xf1, 3, 7);
     WG_M(yf1, xf1, 4, 0);
@@ -3147,12 +3173,12 @@ void gemm_wgrad_w4_kernel(const bf16* __restrict__ dY_a, int lddy_a, const bf16*
   asm volatile("" ::: "memory");
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
-    WG_TR2(yl[c], yh[c], y_addr[0][c], 0);
+    WG_YRD(c, 0, 0);
     WG_TR2(xl[c], xh[c], x_addr[0][c], 0);
   }
   WG_LGKM0();
 #pragma unroll
-  for (int c = 0; c < 8; ++c) { yf0[c] = frag(yl[c], yh[c]); xf0[c] = frag(xl[c], xh[c]); }
+  for (int c = 0; c < 8; ++c) { yf0[c] = yfrag(c); xf0[c] = frag(xl[c], xh[c]); }
 
   WgCursor cc = locate(g0);
   bool first = true;
@@ -3176,7 +3202,7 @@ void gemm_wgrad_w4_kernel(const bf16* __restrict__ dY_a, int lddy_a, const bf16*
     WG_LGKM0();
     WG_TSEG(1);
 #pragma unroll
-    for (int c = 0; c < 8; ++c) { yf1[c] = frag(yl[c], yh[c]); xf1[c] = frag(xl[c], xh[c]); }
+    for (int c = 0; c < 8; ++c) { yf1[c] = yfrag(c); xf1[c] = frag(xl[c], xh[c]); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     WG_TSEG(2);
     __builtin_amdgcn_s_barrier();      // K-tile step+1 visible to all; stage s_cur fully read by all
@@ -3190,7 +3216,7 @@ void gemm_wgrad_w4_kernel(const bf16* __restrict__ dY_a, int lddy_a, const bf16*
     wtl[7] += 1;
 #endif
 #pragma unroll
-    for (int c = 0; c < 8; ++c) { yf0[c] = frag(yl[c], yh[c]); xf0[c] = frag(xl[c], xh[c]); }
+    for (int c = 0; c < 8; ++c) { yf0[c] = yfrag(c); xf0[c] = frag(xl[c], xh[c]); }
 
     const bool last_of_tile = (cc.mt + 1 == cc.len) || (step + 1 == total);
     if (last_of_tile) {
@@ -3291,6 +3317,7 @@ void gemm_wgrad_w4_kernel(const bf16* __restrict__ dY_a, int lddy_a, const bf16*
 #undef WG_TSEG
 #undef WG_LD1
 #undef WG_TR2
+#undef WG_YRD
 #undef WG_LGKM0
 #undef WG_ACC
 #undef WG_M
@@ -3727,6 +3754,8 @@ static bool wgrad_w4_ok(int M, int N, int K, int lddy, int ldx, const void* dY, 
   return g_variant >= 1 && g_variant != 3 && (M % 64) == 0 && M >= 4096 && (N % 256) == 0 && (K % 256) == 0 &&
          (lddy % 8) == 0 && (ldx % 8) == 0 && !((uintptr_t)dY & 15) && !((uintptr_t)X & 15);
 }
+extern "C++" {
+template <bool YROWS = false>
 static int launch_wgrad_w4(const void* dY, int lddy, const void* X, int ldx, float* dW, int lddw, int M, int N, int K,
                            float alpha, void* workspace, size_t workspace_bytes, void* stream, const WgradProblem* pb_in,
                            bool store = false) {
@@ -3737,7 +3766,7 @@ static int launch_wgrad_w4(const void* dY, int lddy, const void* X, int ldx, flo
   const size_t lds = 2 * 65536;
   static bool attr_set_w = false;
   if (!attr_set_w) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_wgrad_w4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_wgrad_w4_kernel<YROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     attr_set_w = true;
   }
@@ -3756,7 +3785,7 @@ static int launch_wgrad_w4(const void* dY, int lddy, const void* X, int ldx, flo
       (lddw % 4) == 0 && (((uintptr_t)dW & 15) == 0) && (!pb_in || ((pb.lddw % 4) == 0 && (((uintptr_t)pb.dW & 15) == 0))))
     ws = (float*)workspace;
   int* ws_tile = ws ? (int*)(ws + (size_t)grid * (65536 + 272)) : nullptr;
-  hipLaunchKernelGGL(gemm_wgrad_w4_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, (const bf16*)dY, lddy,
+  hipLaunchKernelGGL(gemm_wgrad_w4_kernel<YROWS>, dim3(grid), dim3(256), lds, (hipStream_t)stream, (const bf16*)dY, lddy,
                      (const bf16*)X, ldx, dW, lddw, M, N, K, alpha, ti, tj, chunk, ws, ws_tile, g_ablate, store ? 1 : 0, pb);
   M3P_CHECK_LAUNCH();
   if (ws) {
@@ -3765,6 +3794,18 @@ static int launch_wgrad_w4(const void* dY, int lddy, const void* X, int ldx, flo
     M3P_CHECK_LAUNCH();
   }
   return M3P_OK;
+}
+}  // extern "C++"
+
+// Cf[M,N] += alpha * A[M,K] x W[K,N] on the four-wave kernel (YROWS form): the weight-gradient machinery with the roles
+//   contraction = K, output rows = M (first operand A, contraction-contiguous), output columns = N (second operand W, rows = contraction)
+int m3p_gemm_nn_w4_f32(const void* A, int lda, const void* W, int ldw, float* C, int ldc, int M, int N, int K, float alpha,
+                       void* workspace, size_t workspace_bytes, void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || !A || !W || !C) return M3P_EINVAL;
+  if ((K % 64) || K < 4096 || (M % 256) || (N % 256) || (lda % 8) || (ldw % 8) || lda < K || ldw < N || ldc < N ||
+      ((uintptr_t)A & 15) || ((uintptr_t)W & 15) || g_variant < 1 || g_variant == 3)
+    return M3P_ENOTIMPL;
+  return launch_wgrad_w4<true>(A, lda, W, ldw, C, ldc, K, M, N, alpha, workspace, workspace_bytes, stream, nullptr);
 }
 
 int m3p_gemm_wgrad_pair_bf16(const void* dYa, int lddya, const void* Xa, int ldxa, float* dWa, int lddwa, int Na, int Ka,
@@ -3784,7 +3825,7 @@ int m3p_gemm_wgrad_pair_bf16(const void* dYa, int lddya, const void* Xa, int ldx
   }
   if (lddya < Na || ldxa < Ka || lddyb < Nb || ldxb < Kb) return M3P_EINVAL;
   WgradProblem pb = {(const bf16*)dYb, (const bf16*)Xb, dWb, lddyb, ldxb, lddwb, Nb / 256, Kb / 256};
-  return launch_wgrad_w4(dYa, lddya, Xa, ldxa, dWa, lddwa, M, Na, Ka, alpha, workspace, workspace_bytes, stream, &pb);
+  return launch_wgrad_w4<>(dYa, lddya, Xa, ldxa, dWa, lddwa, M, Na, Ka, alpha, workspace, workspace_bytes, stream, &pb);
 }
 
 int m3p_gemm_wgrad_store_bf16(const void* dY, int lddy, const void* X, int ldx, float* dW, int lddw, int M, int N, int K,
@@ -3792,7 +3833,7 @@ int m3p_gemm_wgrad_store_bf16(const void* dY, int lddy, const void* X, int ldx, 
   if (M <= 0 || N <= 0 || K <= 0 || (lddy % 8) != 0 || (ldx % 8) != 0 || !dW || lddw < K) return M3P_EINVAL;
   if (lddy < N || ldx < K || ((uintptr_t)dY & 15) || ((uintptr_t)X & 15)) return M3P_EINVAL;
   if (!wgrad_w4_ok(M, N, K, lddy, ldx, dY, X)) return M3P_ENOTIMPL;
-  return launch_wgrad_w4(dY, lddy, X, ldx, dW, lddw, M, N, K, alpha, workspace, workspace_bytes, stream, nullptr, true);
+  return launch_wgrad_w4<>(dY, lddy, X, ldx, dW, lddw, M, N, K, alpha, workspace, workspace_bytes, stream, nullptr, true);
 }
 
 int m3p_gemm_wgrad_bf16(const void* dY, int lddy, const void* X, int ldx, float* dW, int lddw, int M, int N, int K,
@@ -3802,7 +3843,7 @@ int m3p_gemm_wgrad_bf16(const void* dY, int lddy, const void* X, int ldx, float*
   if (((uintptr_t)dY & 15) || ((uintptr_t)X & 15)) return M3P_EINVAL;
   if (wgrad_w4_ok(M, N, K, lddy, ldx, dY, X) &&
       (N / 256) * (K / 256) >= ((g_ablate & 16) ? 1 : 9)) {      // (768 x 768 = 9 tiles included since the four-wave kernel lost its scalar overhead: 63 against 74 us on the ring kernel)
-    return launch_wgrad_w4(dY, lddy, X, ldx, dW, lddw, M, N, K, alpha, workspace, workspace_bytes, stream, nullptr);
+    return launch_wgrad_w4<>(dY, lddy, X, ldx, dW, lddw, M, N, K, alpha, workspace, workspace_bytes, stream, nullptr);
   }
   if (g_variant >= 1 && (M % BK) == 0 && M >= 4096) {
     const int ti = (N + WR_I - 1) / WR_I, tj = (K + WR_J - 1) / WR_J;

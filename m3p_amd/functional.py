@@ -41,6 +41,8 @@ _GELU_BYTE_GRAD = int(os.environ.get('M3P_GELU_BYTE_GRAD', '2'))
 # round 4: the vocabulary projection's epilogue leaves block-wise (max, sum exp) for the cross-entropy (EPI_BIAS_LSE); 0 = the
 # round-3 path (a separate statistics pass over the logits) for A/B runs
 _CE_FUSED_LSE = os.environ.get('M3P_CE_FUSED_LSE', '1') != '0'
+# round 4: the vocabulary data gradient on the four-wave (tile, K-chunk) kernel instead of stream-K with atomics; 0 = round 3
+_VOCAB_DGRAD_W4 = os.environ.get('M3P_VOCAB_DGRAD_W4', '1') != '0'
 
 class Arena:
     """Flat storage behind a TransformerModel's hot parameters (see model/transformer.py)."""
@@ -1112,7 +1114,9 @@ class MLMHeadFn(torch.autograd.Function):
         else:
             ops.colsum(dlogits, V, ar.g('pred_layer.proj.bias'), scale=g)
         dH32 = torch.zeros((n, d), dtype=torch.float32, device=dlogits.device)
-        ops.gemm_nn_streamk(dlogits, ar.w('embeddings.weight'), dH32)     # E [V, d] read in place: no transposed copy
+        # E [V, d] read in place (no transposed copy); whole 256-row tiles of predictions run on the four-wave kernel, which
+        # reads all V_pad rows of "the matrix" - the bf16 arena behind E, finite numbers against dlogits' exact-zero pad columns
+        ops.gemm_nn(dlogits, ar.w('embeddings.weight'), dH32, k_rows_readable=ar.V_pad if _VOCAB_DGRAD_W4 else None)
         dH = ops.scale_bf16_dev(dH32, g)
         # gradient wrt `tensor` (a strided view of the encoder output): the rows go to the pass's gradient sink, or - for a
         # tensor that is not an encoder pass's output - onto a zeroed twin of the underlying row buffer

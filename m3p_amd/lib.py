@@ -41,6 +41,7 @@ SIGNATURES = {
     'm3p_quant_fp8_batch': (_i, [_p, _i, _i, _p]),
     'm3p_gemm_nt_streamk_f32': (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _f, _p]),
     'm3p_gemm_nn_streamk_f32': (_i, [_p, _i, _p, _i, _i, _p, _i, _i, _i, _i, _f, _p]),
+    'm3p_gemm_nn_w4_f32': (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _f, _p, C.c_size_t, _p]),
     'm3p_gemm_wgrad_workspace_bytes': (C.c_size_t, []),
     'm3p_gemm_wgrad_bf16': (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _f, _p, C.c_size_t, _p]),
     'm3p_gemm_wgrad_store_bf16': (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _f, _p, C.c_size_t, _p]),

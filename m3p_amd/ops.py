@@ -170,6 +170,28 @@ def gemm_nn_streamk(a, w_kn, out_f32, alpha=1.0):
     return out_f32
 
 
+def gemm_nn(a, w_kn, out_f32, alpha=1.0, k_rows_readable=None):
+    """out_f32[M,N] (fp32) += alpha * a[M,K] @ w_kn[:K].  Whole-tile shapes whose second operand is readable (finite) for all
+    K rows - k_rows_readable >= K: the rows behind w_kn's own k_valid are memory the caller vouches for, e.g. the arena
+    behind the vocabulary matrix - run on the four-wave kernel (m3p_gemm_nn_w4_f32, no atomics); everything else on the
+    stream-K form."""
+    _chk_bf16(a, w_kn)
+    M, K = a.shape
+    k_valid, N = w_kn.shape
+    if (k_rows_readable or k_valid) >= K and M % 256 == 0 and N % 256 == 0 and K % 64 == 0 and K >= 4096:
+        assert out_f32.dtype == torch.float32 and out_f32.shape == (M, N) and w_kn.stride(1) == 1
+        e0 = _prof_begin(('gemm_nn/w4', M, N, K))
+        ws = _wgrad_workspace(a.device)
+        rc = L.load().m3p_gemm_nn_w4_f32(a.data_ptr(), a.stride(0), w_kn.data_ptr(), w_kn.stride(0), out_f32.data_ptr(),
+                                         out_f32.stride(0), M, N, K, alpha, ws.data_ptr(), ws.numel(), L.stream())
+        if rc == 0:
+            _prof_end(e0, ('gemm_nn/w4', M, N, K))
+            return out_f32
+        if rc != -2:
+            L.check(rc, 'm3p_gemm_nn_w4_f32')
+    return gemm_nn_streamk(a, w_kn, out_f32, alpha)
+
+
 _WGRAD_WS = {}     # (device index, stream) -> workspace tensor of the four-wave weight-gradient kernel
 
 

@@ -261,6 +261,31 @@ def test_gemm_nn_streamk(M, N, K, kv):
 
 
 
+@pytest.mark.parametrize('M,N,K', [(256, 256, 4096), (512, 768, 8192), (4864, 768, 250112)])
+def test_gemm_nn_on_the_four_wave_kernel(M, N, K):
+    """C[M,N] += alpha * A[M,K] x W[K,N] with A contraction-contiguous and W row-major over the contraction (the vocabulary
+    data gradient dH = dlogits x E): the four-wave (tile, K-chunk) kernel with its first operand staged as an NT panel,
+    against an fp64 product in slices and against the stream-K form; accumulates into a non-zero C."""
+    from m3p_amd import ops
+    g = torch.Generator(device='cuda').manual_seed(M + N + K)
+    a = (torch.randn((M, K), device='cuda', generator=g) * 0.05).to(torch.bfloat16)
+    w = torch.randn((K, N), device='cuda', generator=g).to(torch.bfloat16)
+    out = torch.full((M, N), 0.5, device='cuda')
+    ops.gemm_nn(a, w, out, alpha=2.0)
+    ref = torch.full((M, N), 0.5, dtype=torch.float64, device='cuda')
+    for k0 in range(0, K, 16384):
+        ref += 2.0 * (a[:, k0:k0 + 16384].double() @ w[k0:k0 + 16384].double())
+    assert rel_l2(out.double(), ref) < 1e-5
+    out2 = torch.full((M, N), 0.5, device='cuda')
+    ops.gemm_nn_streamk(a, w, out2, alpha=2.0)
+    assert rel_l2(out.double(), out2.double()) < 1e-5
+    # a second operand shorter than the contraction goes to the stream-K form unless the caller vouches for the rows behind it
+    out3 = torch.zeros((M, N), device='cuda')
+    a2 = a.clone(); a2[:, K - 64:] = 0
+    ops.gemm_nn(a2, w[:K - 64], out3)
+    assert rel_l2(out3.double(), a2[:, :K - 64].double() @ w[:K - 64].double()) < 1e-5
+
+
 def _ref_on_gpu(a, w):
     """fp32 product of the bf16 operands with PyTorch on the device (the checker at sizes a CPU product takes minutes)."""
     return a.float() @ w.float().t()

@@ -10,6 +10,13 @@
 // ends with fp32 atomics straight from the AGPRs, the next one starts with C = 0.
 // Full tiles only (N % 256 == 0, K % 256 == 0, M % 64 == 0): everything else stays on the ring kernel.
 // ---------------------------------------------------------------------------------
+// YROWS (the vocabulary DATA gradient dH [n, d] += dlogits [n, V] x E [V, d], round 4): the first operand is given with the
+// contraction index CONTIGUOUS - dY_a[i * lddy + m], rows = output rows - i.e. as an NT GEMM's activation panel; its K-tile is
+// staged as 256 rows x 128 B (chunk ^= row & 7 on the source, like the NT kernels) and its fragments are plain ds_read_b128,
+// which deliver exactly what the two transposing reads deliver for a contraction-strided operand: eight consecutive
+// contraction elements of one output row per lane.  Everything else - the second operand's transposing reads, the MFMA
+// stream, the (tile, chunk) schedule, the workspace flush and the reduction - is the weight-gradient kernel's.
+template <bool YROWS>
 __global__ __launch_bounds__(256)
 void gemm_wgrad_w4_kernel(const bf16* __restrict__ dY_a, int lddy_a, const bf16* __restrict__ X_a, int ldx_a,
                           float* __restrict__ dW_a, int lddw_a, int M, int N, int K, float alpha,
@@ -94,13 +101,17 @@ void gemm_wgrad_w4_kernel(const bf16* __restrict__ dY_a, int lddy_a, const bf16*
     const int gc = l_pos ^ (f << 1);
     y_off[p] = row * lddy + gc * 8 - (-4096 + 1024 * p) / 2;
     x_off[p] = row * ldx + gc * 8 - (-4096 + 1024 * p) / 2;
+    if (YROWS) {      // piece p of wave w = rows 64 w + 8 p .. + 7 of the 256-row panel, 128 B each: lane -> (row l >> 3, slot l & 7)
+      const int yrow = wid * 64 + 8 * p + (lane >> 3);
+      y_off[p] = yrow * lddy + (((lane & 7) ^ (yrow & 7)) * 8) - (-4096 + 1024 * p) / 2;
+    }
   }
   const bf16* y_base;
   const bf16* x_base;
   auto set_load_ktile = [&]() {
     const int ti = lc.t / tiles_j, tj = lc.t - ti * tiles_j;
     const size_t mbase = (size_t)(seg_m0 + lc.mt) * KT;
-    y_base = dY + mbase * lddy + ti * TI;
+    y_base = YROWS ? dY + (size_t)(ti * TI) * lddy + mbase : dY + mbase * lddy + ti * TI;
     x_base = X + mbase * ldx + tj * TJ;
   };
   set_load_ktile();
@@ -121,7 +132,7 @@ void gemm_wgrad_w4_kernel(const bf16* __restrict__ dY_a, int lddy_a, const bf16*
       default: WG_LD1(src, 3072); break;
     }
   };
-  const size_t y_step = (size_t)KT * lddy, x_step = (size_t)KT * ldx;
+  const size_t y_step = YROWS ? (size_t)KT : (size_t)KT * lddy, x_step = (size_t)KT * ldx;
   auto load_done = [&]() {
     // past the end of this workgroup's stream the last K-tile is re-loaded into a stage nobody
     // reads again (keeps the loop body and the vmcnt bookkeeping uniform).
@@ -156,6 +167,15 @@ void gemm_wgrad_w4_kernel(const bf16* __restrict__ dY_a, int lddy_a, const bf16*
     y_addr[1][c] = y_addr[0][c] + STAGE;
     x_addr[1][c] = x_addr[0][c] + STAGE;
   }
+  // YROWS: fragment c of k-step ks = 16 bytes of row 128 wi + 16 c + ft at chunk (fg + 4 ks) ^ (row & 7)
+  uint32_t yk_addr[2][2][8];      // [k-step][stage][c]
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      yk_addr[ks][0][c] = lds0 + (wi * 128 + 16 * c + ft) * 128 + (((fg + 4 * ks) ^ (ft & 7)) << 4);
+      yk_addr[ks][1][c] = yk_addr[ks][0][c] + STAGE;
+    }
   // one fragment = two tr16 reads (rows +0 / +4); OFF selects the k-step (0 / 16384).  The outputs are EARLY-CLOBBER: without
   // the '&' the compiler may give the first read's destination the address register (it did, in 21 of the kernel's 80 pairs),
   // and when the wave stalls between the two reads for longer than the LDS latency the first read's data IS the second
@@ -164,6 +184,10 @@ void gemm_wgrad_w4_kernel(const bf16* __restrict__ dY_a, int lddy_a, const bf16*
   // in ~20 runs of the suite)
 #define WG_TR2(LO, HI, ADDR, OFF) asm volatile("ds_read_b64_tr_b16 %0, %2 offset:" #OFF "\n\tds_read_b64_tr_b16 %1, %2 offset:" #OFF "+2048" \
                                                : "=&v"(LO), "=&v"(HI) : "v"(ADDR))
+// the first operand's fragment c of k-step KS from stage S: two transposing reads, or (YROWS) one ds_read_b128
+#define WG_YRD(C, S, KS) do { if constexpr (YROWS) asm volatile("ds_read_b128 %0, %1" : "=v"(yq[C]) : "v"(yk_addr[KS][S][C])); \
+                              else if constexpr ((KS) == 0) WG_TR2(yl[C], yh[C], y_addr[S][C], 0);                           \
+                              else WG_TR2(yl[C], yh[C], y_addr[S][C], 16384); } while (0)
 #define WG_LGKM0() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 
   asm volatile("" ::: "a0", "a255");     // reserve all 256 AGPRs (see gemm_nt_w4_kernel)
@@ -185,6 +209,8 @@ void gemm_wgrad_w4_kernel(const bf16* __restrict__ dY_a, int lddy_a, const bf16*
   };
 
   s16x4 yl[8], yh[8], xl[8], xh[8];     // raw halves of the fragments being fetched
+  bf16x8 yq[8];                         // (YROWS: the first operand's fragments arrive whole)
+  auto yfrag = [&](int c) { if constexpr (YROWS) return yq[c]; else return frag(yl[c], yh[c]); };
   bf16x8 yf0[8], xf0[8], yf1[8], xf1[8];
   // the stage is a compile-time fact of each phase body (the K loop is unrolled by two): fragment addresses and LDS-DMA
   // destinations are then plain registers / immediates
@@ -217,12 +243,12 @@ void gemm_wgrad_w4_kernel(const bf16* __restrict__ dY_a, int lddy_a, const bf16*
   asm volatile("" ::: "memory");
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
-    WG_TR2(yl[c], yh[c], y_addr[0][c], 0);
+    WG_YRD(c, 0, 0);
     WG_TR2(xl[c], xh[c], x_addr[0][c], 0);
   }
   WG_LGKM0();
 #pragma unroll
-  for (int c = 0; c < 8; ++c) { yf0[c] = frag(yl[c], yh[c]); xf0[c] = frag(xl[c], xh[c]); }
+  for (int c = 0; c < 8; ++c) { yf0[c] = yfrag(c); xf0[c] = frag(xl[c], xh[c]); }
 
   WgCursor cc = locate(g0);
   bool first = true;
@@ -246,7 +272,7 @@ void gemm_wgrad_w4_kernel(const bf16* __restrict__ dY_a, int lddy_a, const bf16*
     WG_LGKM0();
     WG_TSEG(1);
 #pragma unroll
-    for (int c = 0; c < 8; ++c) { yf1[c] = frag(yl[c], yh[c]); xf1[c] = frag(xl[c], xh[c]); }
+    for (int c = 0; c < 8; ++c) { yf1[c] = yfrag(c); xf1[c] = frag(xl[c], xh[c]); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     WG_TSEG(2);
     __builtin_amdgcn_s_barrier();      // K-tile step+1 visible to all; stage s_cur fully read by all
@@ -260,7 +286,7 @@ void gemm_wgrad_w4_kernel(const bf16* __restrict__ dY_a, int lddy_a, const bf16*
     wtl[7] += 1;
 #endif
 #pragma unroll
-    for (int c = 0; c < 8; ++c) { yf0[c] = frag(yl[c], yh[c]); xf0[c] = frag(xl[c], xh[c]); }
+    for (int c = 0; c < 8; ++c) { yf0[c] = yfrag(c); xf0[c] = frag(xl[c], xh[c]); }
 
     const bool last_of_tile = (cc.mt + 1 == cc.len) || (step + 1 == total);
     if (last_of_tile) {
@@ -361,6 +387,7 @@ void gemm_wgrad_w4_kernel(const bf16* __restrict__ dY_a, int lddy_a, const bf16*
 #undef WG_TSEG
 #undef WG_LD1
 #undef WG_TR2
+#undef WG_YRD
 #undef WG_LGKM0
 #undef WG_ACC
 #undef WG_M
