@@ -78,7 +78,8 @@ typedef struct M3PEpilogue {
   float scale;
   float alpha;        /* accumulator multiplier (NONE, BIAS, RES); 0 is treated as 1    */
   uint32_t seed;      /* dropout stream key (DROP_RES)                                 */
-  uint32_t thresh24;  /* drop iff (hash >> 8) < thresh24; 0 = no dropout               */
+  uint32_t thresh24;  /* round(p * 2^24); 0 = no dropout.  Element i of a stream is dropped iff the low (i even) / high (i odd)
+                         16 bits of hash32(i >> 1, seed) are < thresh24 >> 8 (csrc/common.hpp; NumPy twin m3p_amd/rng.py)  */
   float inv_keep;     /* 1 / (1 - p)                                                   */
   const float* descale_a;  /* m3p_gemm_nt_fp8 only: device scalars, the accumulators are multiplied by    */
   const float* descale_b;  /* (*descale_a) * (*descale_b) (NULL = 1) before the epilogue                  */

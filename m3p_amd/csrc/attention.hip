@@ -248,7 +248,10 @@ void attn_fwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
     const float inv = 1.0f / sum;
     if (qb == wrot) ATL(4);
     const uint32_t rbase = (uint32_t)((b * H + h) * S + qc) * (uint32_t)S;
-    const uint32_t thr32 = thresh24 << 8;   // (hash >> 8) >= thresh24  <=>  hash >= thresh24 << 8  (thresh24 < 2^24: p < 1)
+    // one hash per PAIR of keys (common.hpp): key k of query row q is element rbase + k; with an even row length S every
+    // row starts on an even element and the lane's four consecutive keys 16 t + 4 fg + r are two whole pairs
+    const uint32_t thr16 = thresh24 >> 8;
+    const bool even_rows = (S & 1) == 0;
     // keep-mask words for backward: word [qb][t][r], bit l = keep(query 16qb + (l & 15),
     // key 16t + 4(l >> 4) + r) - the compare's lane mask as it comes out of the VALU
     unsigned long long* mrow = keepmask ? keepmask + ((size_t)(b * H + h) * nt + qb) * nt * 4 : nullptr;
@@ -263,6 +266,26 @@ void attn_fwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
     for (int kk = 0; kk < KT; ++kk) {
       float p[8];
       const float invk = DROP ? inv * inv_keep : inv;
+      bool kq[8] = {true, true, true, true, true, true, true, true};
+      if (DROP) {
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          const int t = 2 * kk + hf;
+          if (t < nt) {
+            const uint32_t base = rbase + (uint32_t)(16 * t + 4 * fg);
+            bool k4[4];
+            if (even_rows) {       // (wave-uniform)
+              const uint32_t h0 = m3p_hash32(base >> 1, seed), h1 = m3p_hash32((base >> 1) + 1u, seed);
+              k4[0] = (h0 & 0xFFFFu) >= thr16; k4[1] = (h0 >> 16) >= thr16;
+              k4[2] = (h1 & 0xFFFFu) >= thr16; k4[3] = (h1 >> 16) >= thr16;
+            } else {
+              m3p_keep_run<4>(base, seed, thresh24, k4);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) kq[4 * hf + r] = k4[r];
+          }
+        }
+      }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int t = 2 * kk + (j >> 2), r = j & 3;
@@ -270,8 +293,7 @@ void attn_fwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
         if (t < nt) {
           v = s[t][r] * invk;
           if (DROP) {
-            const int key = 16 * t + 4 * fg + r;
-            const bool keep = m3p_hash32(rbase + (uint32_t)key, seed) >= thr32;   // == m3p_keep(idx, seed, thresh24)
+            const bool keep = kq[j];
             const unsigned long long kw = __builtin_amdgcn_ballot_w64(keep);
             // (s_nop: a v_writelane that reads an SGPR the v_cmp just wrote gets the stale value without wait
             //  states - measured; the assembler does not insert them for inline asm)

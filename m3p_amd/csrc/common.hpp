@@ -26,9 +26,12 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
   } while (0)
 
 // ---------------------------------------------------------------------------
-// counter-based dropout RNG: one 32-bit hash per element, layout independent, so the
-// forward kernel, the backward kernel and the NumPy twin in tests/ (m3p_amd/rng.py)
-// all regenerate the same keep mask from (seed, linear element index).
+// counter-based dropout RNG, layout independent, so the forward kernel, the backward kernel and the NumPy twin in tests/
+// (m3p_amd/rng.py) all regenerate the same keep mask from (seed, linear element index).  ONE 32-bit hash serves TWO
+// elements (round 4): element idx takes the low (idx even) or high (idx odd) 16 bits of hash32(idx >> 1) and is kept iff
+// they are >= thresh16 = thresh24 >> 8 (p = 0.1: 6553 / 65536, i.e. P(drop) = 0.09999; the scale stays 1 / (1 - p)).
+// The hash is three quarter-rate multiplies + seven other VALU instructions - wherever four or eight consecutive elements
+// sit in one lane (every dropout site) half of them are now enough.
 // ---------------------------------------------------------------------------
 __host__ __device__ __forceinline__ uint32_t m3p_hash32(uint32_t idx, uint32_t seed) {
   uint32_t h = idx * 0x9E3779B1u + seed;
@@ -37,9 +40,31 @@ __host__ __device__ __forceinline__ uint32_t m3p_hash32(uint32_t idx, uint32_t s
   h ^= h >> 15;
   return h;
 }
-// keep iff top 24 bits >= thresh24, thresh24 = round(p * 2^24)  ->  P(keep) = 1 - p
+// thresh24 = round(p * 2^24) is what the C ABI carries; the decision uses its top 16 bits
 __host__ __device__ __forceinline__ bool m3p_keep(uint32_t idx, uint32_t seed, uint32_t thresh24) {
-  return (m3p_hash32(idx, seed) >> 8) >= thresh24;
+  const uint32_t h = m3p_hash32(idx >> 1, seed);
+  return ((idx & 1u) ? (h >> 16) : (h & 0xFFFFu)) >= (thresh24 >> 8);
+}
+// keep decisions of NE consecutive elements starting at an EVEN index: NE / 2 hashes
+template <int NE>
+__host__ __device__ __forceinline__ void m3p_keep_even(uint32_t base, uint32_t seed, uint32_t thresh24, bool (&k)[NE]) {
+  static_assert((NE & 1) == 0, "pairs");
+  const uint32_t t16 = thresh24 >> 8, pb = base >> 1;
+#pragma unroll
+  for (int q = 0; q < NE / 2; ++q) {
+    const uint32_t h = m3p_hash32(pb + (uint32_t)q, seed);
+    k[2 * q] = (h & 0xFFFFu) >= t16;
+    k[2 * q + 1] = (h >> 16) >= t16;
+  }
+}
+// ... starting anywhere: NE / 2 + 1 hashes (the odd start shifts the pairs by one element)
+template <int NE>
+__host__ __device__ __forceinline__ void m3p_keep_run(uint32_t base, uint32_t seed, uint32_t thresh24, bool (&k)[NE]) {
+  bool w[NE + 2];
+  m3p_keep_even<NE + 2>(base & ~1u, seed, thresh24, w);
+  const bool odd = (base & 1u) != 0;
+#pragma unroll
+  for (int j = 0; j < NE; ++j) k[j] = odd ? w[j + 1] : w[j];
 }
 
 // ---------------------------------------------------------------------------

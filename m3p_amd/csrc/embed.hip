@@ -113,8 +113,9 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(EmbedFwdArgs a) {
           f32x4 o = (v[i] - mu) * rs * Vec4<float>::load(a.g_img + 4 * c) + Vec4<float>::load(a.be_img + 4 * c);
           if (a.thresh24) {
             const uint32_t base = (uint32_t)ri * (uint32_t)d + 4u * c;
+            { bool kp[4]; m3p_keep_even<4>(base, a.seed_img, a.thresh24, kp);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = m3p_keep(base + j, a.seed_img, a.thresh24) ? o[j] * a.inv_keep : 0.f;
+          for (int j = 0; j < 4; ++j) o[j] = kp[j] ? o[j] * a.inv_keep : 0.f; }
           }
           v[i] = o;
           if (a.img_mode == 1) Vec4<bf16>::store(a.img_rows + ((size_t)b * a.R + s) * d + 4 * c, o);
@@ -150,8 +151,9 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(EmbedFwdArgs a) {
         f32x4 o = (v[i] - mu) * rs * Vec4<float>::load(a.g_emb + 4 * c) + Vec4<float>::load(a.be_emb + 4 * c);
         if (a.thresh24) {
           const uint32_t base = (uint32_t)m * (uint32_t)d + 4u * c;
+          { bool kp[4]; m3p_keep_even<4>(base, a.seed_emb, a.thresh24, kp);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) o[j] = m3p_keep(base + j, a.seed_emb, a.thresh24) ? o[j] * a.inv_keep : 0.f;
+          for (int j = 0; j < 4; ++j) o[j] = kp[j] ? o[j] * a.inv_keep : 0.f; }
         }
         Vec4<bf16>::store(a.h + (size_t)m * d + 4 * c, o);
       }
@@ -219,8 +221,9 @@ __global__ __launch_bounds__(256) void embed_bwd_rows_kernel(EmbedBwdArgs a) {
         dy[i] = Vec4<bf16>::load(a.dh + m * d + 4 * c);
         if (a.thresh24) {
           const uint32_t base = (uint32_t)m * (uint32_t)d + 4u * c;
+          { bool kp[4]; m3p_keep_even<4>(base, a.seed_emb, a.thresh24, kp);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) dy[i][j] = m3p_keep(base + j, a.seed_emb, a.thresh24) ? dy[i][j] * a.inv_keep : 0.f;
+          for (int j = 0; j < 4; ++j) dy[i][j] = kp[j] ? dy[i][j] * a.inv_keep : 0.f; }
         }
         xh[i] = (Vec4<bf16>::load(a.z + m * d + 4 * c) - mu) * rs;
         const f32x4 gd = dy[i] * g[i];
@@ -311,8 +314,9 @@ __global__ __launch_bounds__(256) void embed_bwd_img_kernel(EmbedBwdArgs a) {
         dy[i] = Vec4<bf16>::load(a.dz + m * d + 4 * c);
         if (a.thresh24) {
           const uint32_t base = (uint32_t)ri * (uint32_t)d + 4u * c;
+          { bool kp[4]; m3p_keep_even<4>(base, a.seed_img, a.thresh24, kp);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) dy[i][j] = m3p_keep(base + j, a.seed_img, a.thresh24) ? dy[i][j] * a.inv_keep : 0.f;
+          for (int j = 0; j < 4; ++j) dy[i][j] = kp[j] ? dy[i][j] * a.inv_keep : 0.f; }
         }
         xh[i] = (Vec4<bf16>::load(a.e + ri * d + 4 * c) - mu) * rs;
         const f32x4 gd = dy[i] * g[i];

@@ -73,8 +73,10 @@ __device__ __forceinline__ void epilogue_store(const M3PEpilogue& ep, bf16* __re
   if (EPI == M3P_EPI_BIAS_DROP_RES) {
     if (ep.thresh24) {
       const uint32_t base = (uint32_t)m * (uint32_t)N + (uint32_t)n;
+      bool kp[4];
+      m3p_keep_run<4>(base, ep.seed, ep.thresh24, kp);        // (any N: the run may start on an odd element)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = m3p_keep(base + r, ep.seed, ep.thresh24) ? v[r] * ep.inv_keep : 0.f;
+      for (int r = 0; r < 4; ++r) v[r] = kp[r] ? v[r] * ep.inv_keep : 0.f;
     }
   }
   if (EPI == M3P_EPI_BIAS_DROP_RES || EPI == M3P_EPI_RES || EPI == M3P_EPI_DGELU || EPI == M3P_EPI_MUL) {
@@ -388,9 +390,11 @@ __device__ __forceinline__ void epilogue_half(const M3PEpilogue& ep, bf16* __res
         for (int r = 0; r < 4; ++r) v[r] = gelu_erf_f((float)ukeep[ii][j][r]);
       }
       if (EPI == M3P_EPI_BIAS_DROP_RES && ep.thresh24) {
-        const uint32_t base = (uint32_t)mrow * (uint32_t)N + (uint32_t)n;
+        const uint32_t base = (uint32_t)mrow * (uint32_t)N + (uint32_t)n;      // (whole tiles: N and n are multiples of 4)
+        bool kp[4];
+        m3p_keep_even<4>(base, ep.seed, ep.thresh24, kp);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = m3p_keep(base + r, ep.seed, ep.thresh24) ? v[r] * ep.inv_keep : 0.f;
+        for (int r = 0; r < 4; ++r) v[r] = kp[r] ? v[r] * ep.inv_keep : 0.f;
       }
       if (kAux) {
         const bf16x4 t = auxv[ii][j];       // residual / pre-activation tile, fetched by the caller ahead of time

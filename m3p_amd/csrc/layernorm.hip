@@ -123,12 +123,11 @@ void ln_bwd_kernel(const bf16* __restrict__ dy_a, const bf16* __restrict__ dy_b,
           // bias gradient is the column sum of exactly those values
           bf16x4 ob = bf16x4{(bf16)o[0], (bf16)o[1], (bf16)o[2], (bf16)o[3]};
           f32x4 od;
-          const uint32_t base = (uint32_t)r * (uint32_t)d + 4u * (uint32_t)c;
+          const uint32_t base = (uint32_t)r * (uint32_t)d + 4u * (uint32_t)c;      // (d % 4 == 0: even)
+          bool kp[4] = {true, true, true, true};
+          if (thresh24) m3p_keep_even<4>(base, seed, thresh24, kp);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const bool keep = thresh24 ? m3p_keep(base + e, seed, thresh24) : true;
-            od[e] = keep ? (float)ob[e] * (thresh24 ? inv_keep : 1.f) : 0.f;
-          }
+          for (int e = 0; e < 4; ++e) od[e] = kp[e] ? (float)ob[e] * (thresh24 ? inv_keep : 1.f) : 0.f;
           bf16x4 odb = bf16x4{(bf16)od[0], (bf16)od[1], (bf16)od[2], (bf16)od[3]};
           if (dx_drop) *reinterpret_cast<bf16x4*>(dx_drop + ro + 4 * c) = odb;
           acc_d[i] += f32x4{(float)odb[0], (float)odb[1], (float)odb[2], (float)odb[3]};
@@ -222,10 +221,11 @@ void ln_bwd_hw_kernel(const bf16* __restrict__ dy_a, const bf16* __restrict__ dy
       *reinterpret_cast<bf16x8*>(dx + ro + c) = ob;
       if (dx_drop || dbias_drop) {
         const uint32_t base = (uint32_t)r * (uint32_t)D + (uint32_t)c;
+        bool kp[8] = {true, true, true, true, true, true, true, true};
+        if (thresh24) m3p_keep_even<8>(base, seed, thresh24, kp);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const bool keep = thresh24 ? m3p_keep(base + e, seed, thresh24) : true;
-          odb[e] = (bf16)(keep ? (float)ob[e] * (thresh24 ? inv_keep : 1.f) : 0.f);
+          odb[e] = (bf16)(kp[e] ? (float)ob[e] * (thresh24 ? inv_keep : 1.f) : 0.f);
           acc_d[i][e] += (float)odb[e];
         }
         if (dx_drop) *reinterpret_cast<bf16x8*>(dx_drop + ro + c) = odb;

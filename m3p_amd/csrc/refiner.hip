@@ -23,8 +23,10 @@ __global__ __launch_bounds__(256) void dropout_rows_kernel(const bf16* __restric
     f32x4 v = Vec4<bf16>::load(x + (size_t)r * ldx + c);
     if (thresh24) {
       const uint32_t base = (uint32_t)r * rng_ld + rng_col0 + (uint32_t)c;
+      bool kp[4];
+      m3p_keep_run<4>(base, seed, thresh24, kp);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = m3p_keep(base + j, seed, thresh24) ? v[j] * inv_keep : 0.f;
+      for (int j = 0; j < 4; ++j) v[j] = kp[j] ? v[j] * inv_keep : 0.f;
     }
     if (res) v = round_bf16(v) + Vec4<bf16>::load(res + (size_t)r * ldres + c);   // the dropped branch is a bf16 tensor in the reference
     Vec4<bf16>::store(y + (size_t)r * ldy + c, v);

@@ -18,9 +18,14 @@ def hash32(idx, seed):
 
 
 def keep_mask(n_elems, seed, p, shape=None):
-    """Boolean keep mask for elements 0..n_elems-1 of a dropout stream."""
-    thresh = int(round(float(p) * (1 << 24)))
-    k = (hash32(np.arange(n_elems, dtype=np.uint64), seed) >> np.uint32(8)) >= np.uint32(thresh)
+    """Boolean keep mask for elements 0..n_elems-1 of a dropout stream: element i takes the low (i even) or high (i odd)
+    16 bits of hash32(i >> 1) and is kept iff they are >= thresh24 >> 8, thresh24 = round(p * 2^24) (csrc/common.hpp:
+    one hash serves two elements)."""
+    thresh16 = int(round(float(p) * (1 << 24))) >> 8
+    idx = np.arange(n_elems, dtype=np.uint64)
+    h = hash32(idx >> np.uint64(1), seed)
+    half = np.where((idx & np.uint64(1)) != 0, h >> np.uint32(16), h & np.uint32(0xFFFF))
+    k = half >= np.uint32(thresh16)
     return k.reshape(shape) if shape is not None else k
 
 
