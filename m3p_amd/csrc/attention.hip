@@ -133,7 +133,7 @@ __device__ __forceinline__ void stage_rows(const bf16* __restrict__ g, size_t ld
 // NW: waves per workgroup.  4 with three ~48-KB workgroups per CU at S = 164 (168 registers per lane); 8 for long
 // sequences whose K + V tiles leave room for one workgroup per CU only (S = 356: 96 KB) - two waves per SIMD
 // instead of one to hide each other's latencies.
-template <int DH, int KT, bool DROP, int NTC, int NW = 4>
+template <int DH, int KT, bool DROP, int NTC, int NW = 4, bool EVENS = false>     // EVENS: the row length S is even (launcher's promise)
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 3)
 void attn_fwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keylen, bf16* __restrict__ ctx,
                      float* __restrict__ lse, unsigned long long* __restrict__ keepmask, int S, int H, int dmodel,
@@ -251,7 +251,9 @@ void attn_fwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
     // one hash per PAIR of keys (common.hpp): key k of query row q is element rbase + k; with an even row length S every
     // row starts on an even element and the lane's four consecutive keys 16 t + 4 fg + r are two whole pairs
     const uint32_t thr16 = thresh24 >> 8;
-    const bool even_rows = (S & 1) == 0;
+    // (a compile-time fact in the instantiation the M3P sequence runs on: left to a run-time test the compiler merges the two
+    //  forms into one that computes the odd form's third hash for everybody - 101 against 91 us)
+    const bool even_rows = EVENS || (S & 1) == 0;
     // keep-mask words for backward: word [qb][t][r], bit l = keep(query 16qb + (l & 15),
     // key 16t + 4(l >> 4) + r) - the compare's lane mask as it comes out of the VALU
     unsigned long long* mrow = keepmask ? keepmask + ((size_t)(b * H + h) * nt + qb) * nt * 4 : nullptr;
@@ -274,11 +276,14 @@ void attn_fwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
           if (t < nt) {
             const uint32_t base = rbase + (uint32_t)(16 * t + 4 * fg);
             bool k4[4];
-            if (even_rows) {       // (wave-uniform)
+            if (even_rows) {       // (wave-uniform; the empty asm keeps the compiler from if-converting the two forms into one
+                                   //  that computes the odd form's third hash for everybody)
+              asm volatile("" ::: "memory");
               const uint32_t h0 = m3p_hash32(base >> 1, seed), h1 = m3p_hash32((base >> 1) + 1u, seed);
               k4[0] = (h0 & 0xFFFFu) >= thr16; k4[1] = (h0 >> 16) >= thr16;
               k4[2] = (h1 & 0xFFFFu) >= thr16; k4[3] = (h1 >> 16) >= thr16;
             } else {
+              asm volatile("" ::: "memory");
               m3p_keep_run<4>(base, seed, thresh24, k4);
             }
 #pragma unroll
@@ -293,13 +298,21 @@ void attn_fwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
         if (t < nt) {
           v = s[t][r] * invk;
           if (DROP) {
+#if defined(M3P_ATTN_ABL) && (M3P_ATTN_ABL & 2)       // (timing ablation: no hash - a keep decision that costs nothing)
+            const bool keep = ((lane + j) & 15) != 0;
+#else
             const bool keep = kq[j];
+#endif
             const unsigned long long kw = __builtin_amdgcn_ballot_w64(keep);
             // (s_nop: a v_writelane that reads an SGPR the v_cmp just wrote gets the stale value without wait
             //  states - measured; the assembler does not insert them for inline asm)
+            #if !(defined(M3P_ATTN_ABL) && (M3P_ATTN_ABL & 1))     // (timing ablation bit 0: no ballot words - backward would read garbage)
             asm("s_nop 3\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4"
                 : "+v"(mlo[(4 * t + r) >> 6]), "+v"(mhi[(4 * t + r) >> 6])
                 : "s"((uint32_t)kw), "s"((uint32_t)(kw >> 32)), "i"((4 * t + r) & 63));
+#else
+            (void)kw;
+#endif
             v = keep ? v : 0.f;
           }
         }
@@ -960,7 +973,8 @@ int launch_fwd(const bf16* qkv, const int* keylen, bf16* ctx, float* lse, unsign
   do {                                                                                                          \
     constexpr int NW0 = (KT == 16) ? 8 : 4;   /* S > 384 is always `wide`: no four-wave instantiation (it spills) */ \
     auto kern = thresh24 ? attn_fwd_kernel<DH, KT, true, 0, NW0> : attn_fwd_kernel<DH, KT, false, 0, NW0>;       \
-    if (nt == 11 && KT == 6) kern = thresh24 ? attn_fwd_kernel<DH, 6, true, 11> : attn_fwd_kernel<DH, 6, false, 11>; \
+    if (nt == 11 && KT == 6) kern = thresh24 ? ((S & 1) ? attn_fwd_kernel<DH, 6, true, 11> : attn_fwd_kernel<DH, 6, true, 11, 4, true>) \
+                                             : attn_fwd_kernel<DH, 6, false, 11>; \
     if (wide) kern = thresh24 ? attn_fwd_kernel<DH, KT, true, 0, 8> : attn_fwd_kernel<DH, KT, false, 0, 8>;       \
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     if (e != hipSuccess) return (int)e;                                                                         \
