@@ -304,7 +304,7 @@ def main():
                          '(max over ranks); payload = bytes handed to RCCL per rank and step in backward (gradient buckets '
                          'fp32, token rows bf16); buckets = average size / time / bus bandwidth per collective, measured on '
                          'rank 0 in three extra steps with each collective bracketed by events; zero1 gathers the updated '
-                         'fp32 parameters during the next forward (the "params" rows)')
+                         'bf16 working copy during the next forward (the "params" rows; the fp32-read vectors travel in one packed all-reduce)')
 
     # sustained engine clock under this very workload: amdsmi's sclk (torch.cuda.clock_rate()) sampled from a host thread
     # every 2 ms over five more steps AFTER the timed region (the sampler never runs inside it).  The 2.5 PF of the roofline

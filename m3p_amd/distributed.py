@@ -27,13 +27,19 @@ numerically the all-reduce's result - SURVEY 8e):
                               instead of a second pass over 768 MB).
   optimizer  the clip norm is the all-reduced sum of the ranks' shard norms (one 8-byte collective); Adam runs on
              this rank's shard of every bucket only - 1/world of the 9.5 GB the single-GPU step streams;
-  forward    the updated fp32 master shards are ``all_gather``ed bucket by bucket in FORWARD order on the side
-             stream, each followed by its bf16 cast (and, after the last, the transposed copies backward reads);
-             the next step's forward waits per bucket (``params_ready``), so the gather hides under it.
-             Every rank therefore holds the full, identical fp32 master again before anything reads it: the
-             kernels' fp32 bias / LayerNorm reads sit behind ``params_ready(key)`` in forward, checkpoints behind
-             ``params_ready(None)`` in ``Trainer._state_dicts``.  The Adam moments are NOT gathered: a checkpoint
-             carries the saving rank's shards (the reference's reload restores ``num_updates`` only, and so does ours).
+  forward    what the next forward needs of the other ranks' updates (round 4: half the bytes of round 3's fp32 master gather):
+               * the **bf16 working copy** - Adam writes it together with the master for its shard - is ``all_gather``ed bucket
+                 by bucket in FORWARD order on the side stream (0.56 GB per step instead of 1.12), the transposed copies
+                 backward reads follow; the next step's forward waits per bucket (``params_ready``);
+               * the parameters the kernels read in **fp32** (biases, LayerNorm weights, the position / location tables,
+                 the ITM score vector - everything but the big GEMM matrices, ~5 M elements) travel as fp32: every rank
+                 packs them, zeroes what it does not own, one ``all_reduce`` (each element has exactly one non-zero
+                 contributor, so the sum is the owner's value bit for bit), and writes them back into its master.
+             The fp32 master of the big MATRICES therefore stays sharded between checkpoints: a rank holds the current
+             values of its own shards only (``master_partial``).  ``materialize_master()`` - a collective every rank must
+             call, which ``Trainer.save_* / end_epoch`` do before their master-rank test - gathers the rest;
+             ``TransformerModel.state_dict()`` refuses to hand out a partial master.  The Adam moments are never gathered: a
+             checkpoint carries the saving rank's shards (the reference's reload restores ``num_updates`` only, and so does ours).
 
 ``mode = 'allreduce'`` (other world sizes, or ``M3P_DP_MODE=allreduce``) is round 2's protocol: fp32
 ``all_reduce`` per bucket, Adam replicated.  Half of the zero1 wire traffic moves from backward to the next
@@ -274,7 +280,9 @@ class DataParallel(torch.nn.Module):
         self._tokens = []            # [(ids [n] int64, rows [n, d] bf16, n_max over ranks: int or _Pending)]
         self._tokens_out = None
         self._finished = False
-        self._param_events = {}      # zero1: bucket key -> event on the side stream (master gathered + bf16 cast done)
+        self._param_events = {}      # zero1: bucket key -> event on the side stream (bf16 copy gathered); 'vectors', 'transposes'
+        self.master_partial = False  # zero1: the fp32 master of the big matrices is current on its owner rank only
+        self._vec = None             # (index int64 [n], own mask fp32 [n]) of the fp32-read parameters, built on first use
         self.exposed_events = None   # set to [] to record (start, end) events around finish()'s waits
         object.__setattr__(module, 'ddp_hook', self)    # plain attribute: as a registered submodule it would close a cycle
         if not self.single and arena.device.type == 'cuda' and os.environ.get('M3P_DP_TILE_QUEUE', '1') != '0':
@@ -338,13 +346,12 @@ class DataParallel(torch.nn.Module):
 
     def after_sharded_step(self, touched_ranges):
         """zero1, called by the optimizer once Adam has run on this rank's shards: zero the rest of the touched gradient
-        ranges (they hold this rank's un-reduced partials), then gather the updated master shards bucket by bucket in
-        forward order on the side stream, each followed by its bf16 cast; the transposed copies come last.  The next
-        forward waits per bucket (``params_ready``).  -> True if it took care of the bf16 copies."""
+        ranges (they hold this rank's un-reduced partials), exchange the fp32-read parameters (one packed all-reduce), then
+        gather the updated bf16 working copy bucket by bucket in forward order on the side stream; the transposed copies
+        come last.  The next forward waits per bucket (``params_ready``).  -> True if it took care of the bf16 copies."""
         if self.mode != 'zero1':
             return False
         ar = self._arena
-        from . import ops
         for s, e in touched_ranges:
             pos = s
             for a, b in self.owned(s, e) + [(e, e)]:
@@ -354,21 +361,39 @@ class DataParallel(torch.nn.Module):
         touched_keys = [k for k, (s, e) in self._ranges.items() if any(a < e and s < b for a, b in touched_ranges)]
         red = self.reducer
         cuda = ar.device.type == 'cuda'
+        # (1) the fp32-read parameters: packed, masked to what this rank owns, summed over the ranks, written back
+        idx, own = self._vector_index()
+        if idx.numel():
+            def _exchange():
+                stage = ar.master.index_select(0, idx) * own
+                if not self.single:
+                    dist.all_reduce(stage, op=dist.ReduceOp.SUM, group=self.pg)
+                ar.master.index_copy_(0, idx, stage)
+            if cuda:
+                ev0 = torch.cuda.Event()
+                ev0.record(torch.cuda.current_stream())
+                with torch.cuda.stream(red.stream):
+                    red.stream.wait_event(ev0)
+                    _exchange()
+                    ev = torch.cuda.Event()
+                    ev.record()
+                self._param_events['vectors'] = ev
+            else:
+                _exchange()
+        # (2) the bf16 working copy, bucket by bucket in forward order (Adam wrote this rank's shard of it with the master)
         for key in touched_keys:
             s, e = self._ranges[key]
             a, b = self.shard_of(key)
-            red.all_gather(ar.master[s:e], ar.master[a:b], label=('params', key))
+            red.all_gather(ar.w16[s:e], ar.w16[a:b], label=('params', key))
             work = red.pending.pop()
             if cuda:
                 with torch.cuda.stream(red.stream):
                     work.wait()                                    # the side stream waits for the collective, the host does not
-                    ops.cast_f32_bf16_into(ar.master[s:e], ar.w16[s:e])
                     ev = torch.cuda.Event()
                     ev.record()
                 self._param_events[key] = ev
             else:
                 work.wait()
-                ar.w16[s:e].copy_(ar.master[s:e])
         if cuda:
             with torch.cuda.stream(red.stream):
                 ar._transposes_stale = True
@@ -376,14 +401,62 @@ class DataParallel(torch.nn.Module):
                 ev = torch.cuda.Event()
                 ev.record()
             self._param_events['transposes'] = ev
+        self.master_partial = True
         red.bytes_reduced = 0
         return True
+
+    # parameters the kernels consume through the bf16 working copy ONLY (the big GEMM operands): their fp32 master may stay
+    # sharded.  Everything else in the arena is treated as fp32-read and kept current on every rank.
+    _MATRIX_SUFFIXES = ('q_lin.weight', 'k_lin.weight', 'v_lin.weight', 'out_lin.weight', 'lin1.weight', 'lin2.weight')
+
+    def _is_sharded_matrix(self, name):
+        if name in ('embeddings.weight', 'image_embeddings.image_embeddings.weight'):
+            return True
+        return name.startswith(('attentions.', 'ffns.', 'encoder_attn.')) and name.endswith(self._MATRIX_SUFFIXES)
+
+    def _vector_index(self):
+        if self._vec is None:
+            ar = self._arena
+            pieces, masks = [], []
+            for name, (o, cnt, _) in ar.offsets.items():
+                if self._is_sharded_matrix(name):
+                    continue
+                pieces.append(torch.arange(o, o + cnt, dtype=torch.int64))
+                m = torch.zeros(cnt, dtype=torch.float32)
+                for a, b in self.owned(o, o + cnt):
+                    m[a - o:b - o] = 1.0
+                masks.append(m)
+            if pieces:
+                self._vec = (torch.cat(pieces).to(ar.device), torch.cat(masks).to(ar.device))
+            else:
+                self._vec = (torch.zeros(0, dtype=torch.int64, device=ar.device), torch.zeros(0, device=ar.device))
+        return self._vec
+
+    def materialize_master(self):
+        """Collective (every rank): gather the fp32 master shards of the big matrices so that every rank holds the full,
+        current master - for checkpoints, ``state_dict()``, tests.  A no-op when nothing is partial."""
+        if self.mode != 'zero1' or not self.master_partial:
+            return
+        self.params_ready(None)
+        ar = self._arena
+        for key, (s, e) in self._ranges.items():
+            a, b = self.shard_of(key)
+            if self.single:
+                continue
+            _all_gather_into(ar.master[s:e], ar.master[a:b], self.pg).wait()
+        self.master_partial = False
+        # (the bf16 copy is already current everywhere; the gather wrote the master in place: keep the cast version in step)
+        if hasattr(ar, '_cast_version'):
+            ar._cast_version = ar.master._version
 
     def params_ready(self, key=None):
         """Make the current stream wait until bucket ``key``'s parameters (None: all of them, and the transposed
         copies) are gathered and cast.  A stream-level wait; free when nothing is pending."""
         if not self._param_events:
             return
+        ev = self._param_events.pop('vectors', None)      # the fp32-read parameters: every consumer needs them
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
         if key is None:
             for ev in self._param_events.values():
                 torch.cuda.current_stream().wait_event(ev)

@@ -186,9 +186,13 @@ class Arena:
 
     # ---- freshness of the bf16 copies
     def mark_master_changed(self):
+        """The WHOLE fp32 master was (re)written on this rank - load_state_dict, the data-parallel broadcast."""
         self._cast_version = -1
         self._transposes_stale = True
         self.epoch += 1
+        hook = getattr(self.model, 'ddp_hook', None)
+        if hook is not None:
+            hook.master_partial = False
 
     def mark_updated_by_fused_optimizer(self):
         """Adam wrote master and w16 together through raw pointers: only transposes are stale."""
@@ -204,6 +208,11 @@ class Arena:
         if hook is not None and (wait_params or self._cast_version != self.master._version or self._transposes_stale):
             hook.params_ready(None)
         if self._cast_version != self.master._version:
+            if hook is not None and getattr(hook, 'master_partial', False):
+                # sharded data parallelism keeps the fp32 master of the big matrices current on its owner rank only: a cast
+                # from it would overwrite the (current) bf16 copy with stale values
+                raise RuntimeError('a parameter was modified in place while the fp32 master is sharded across the ranks: '
+                                   'call DataParallel.materialize_master() on every rank first')
             L.check(L.load().m3p_cast_f32_bf16(self.master.data_ptr(), self.w16.data_ptr(), self.total, L.stream()),
                     'm3p_cast_f32_bf16')
             self._cast_version = self.master._version

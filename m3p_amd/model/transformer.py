@@ -373,6 +373,11 @@ class TransformerModel(nn.Module):
         # (stream-level) before anything copies the parameters out
         if self.ddp_hook is not None:
             self.ddp_hook.params_ready(None)
+            if getattr(self.ddp_hook, 'master_partial', False):
+                # (a collective cannot hide inside state_dict(): often only the master rank calls it)
+                raise RuntimeError('the fp32 master of the big matrices is sharded across the data-parallel ranks: call '
+                                   'DataParallel.materialize_master() on EVERY rank before state_dict() '
+                                   '(Trainer.save_* / end_epoch do)')
         return super().state_dict(*args, **kw)
 
     def load_state_dict(self, state_dict, strict=True, **kw):

@@ -526,6 +526,14 @@ class Trainer(object):
         self.stats['processed_w'] += n_words
         return loss.detach()
 
+    def _sync_master(self):
+        """Sharded data parallelism keeps the fp32 master of the big matrices on its owner rank between steps: gather it
+        (a collective - EVERY rank comes through here, before any master-rank test) so that whoever saves holds all of it."""
+        for n in self.MODEL_NAMES:
+            hook = getattr(_unwrap(getattr(self, n)), 'ddp_hook', None)
+            if hook is not None:
+                hook.materialize_master()
+
     def _state_dicts(self):
         # sharded data parallelism (distributed.py, zero1): the other ranks' shards of the updated fp32 master arrive through
         # all-gathers on the side stream that only the next forward waits for - a save straight after an optimizer step has to
@@ -544,6 +552,7 @@ class Trainer(object):
 
     def save_model(self, name):
         """{'model': state_dict, 'params': dict} (:511-529), written by the master rank only."""
+        self._sync_master()
         if not getattr(self.params, 'is_master', True):
             return None
         path = os.path.join(self.params.dump_path, '%s.pth' % name)
@@ -556,6 +565,7 @@ class Trainer(object):
     def save_checkpoint(self, name='checkpoint', include_optimizers=True):
         """:531-560: model + optimizer ``state_dict()`` (param_groups with num_updates / lr, and the Adam moments)
         + epoch counters + best metrics; master rank only."""
+        self._sync_master()
         if not getattr(self.params, 'is_master', True):
             return None
         path = os.path.join(self.params.dump_path, '%s.pth' % name)
@@ -610,12 +620,14 @@ class Trainer(object):
 
     def save_periodic(self):
         """:601-608."""
+        self._sync_master()
         every = getattr(self.params, 'save_periodic', 0)
         if getattr(self.params, 'is_master', True) and every > 0 and self.epoch % every == 0:
             self.save_model('periodic-%i' % self.epoch)
 
     def save_best_model(self, scores):
         """:610-625: one 'best-<metric>' model + checkpoint per validation metric that improved."""
+        self._sync_master()
         if not getattr(self.params, 'is_master', True):
             return
         for metric, biggest in self.metrics:
@@ -631,6 +643,7 @@ class Trainer(object):
 
     def end_epoch(self, scores):
         """:627-650: early stopping on the stopping criterion, then the rolling checkpoint."""
+        self._sync_master()
         if self.stopping_criterion is not None and (getattr(self.params, 'is_master', True)
                                                     or not self.stopping_criterion[0].endswith('_mt_bleu')):
             metric, biggest = self.stopping_criterion

@@ -308,13 +308,33 @@ def _protocol_worker(rank, world, port, q, mode):
         fill(1.0)
         dp.finish()
         ar.master.fill_(-1.0)
+        want = torch.arange(ar.total, dtype=torch.float32)
         for a, b in dp.owned(0, ar.total):
-            ar.master[a:b] = torch.arange(a, b, dtype=torch.float32)      # "Adam" on the shard
+            ar.master[a:b] = want[a:b]                                    # "Adam" on the shard: master and bf16 copy together
+            ar.w16[a:b] = want[a:b].to(torch.bfloat16)
         took = dp.after_sharded_step([(0, ar.total)])
         assert took == (mode == 'zero1')
         if mode == 'zero1':
-            results['F'] = float((ar.master - torch.arange(ar.total, dtype=torch.float32)).abs().max())
-            results['F16'] = float((ar.w16.float() - ar.master.to(torch.bfloat16).float()).abs().max())
+            # the bf16 working copy is whole on every rank; of the fp32 master, everything but the big matrix
+            # (embeddings.weight in this arena) is current everywhere, the matrix only where this rank owns it ...
+            results['F16'] = float((ar.w16.float() - want.to(torch.bfloat16).float()).abs().max())
+            vec = torch.ones(ar.total, dtype=torch.bool)
+            o, n, _ = ar.offsets['embeddings.weight']
+            vec[o:o + n] = False
+            named = torch.zeros(ar.total, dtype=torch.bool)
+            for _, (po, pn, _) in ar.offsets.items():
+                named[po:po + pn] = True
+            results['Fvec'] = float((ar.master - want)[vec & named].abs().max())
+            own = torch.zeros(ar.total, dtype=torch.bool)
+            for a, b in dp.owned(0, ar.total):
+                own[a:b] = True
+            stale = bool(((ar.master == -1.0) & ~own & ~vec & named).any())      # (what nobody sent: the matrix's foreign shards)
+            results['Fstale'] = 0.0 if (stale or world == 1) else 1.0
+            assert dp.master_partial
+            # ... until every rank asks for the rest
+            dp.materialize_master()
+            assert not dp.master_partial
+            results['F'] = float((ar.master - want)[named | own].abs().max())
             results['Fz'] = float(ar.grad[~reduced()[1]].abs().max())     # un-reduced partials outside the shards: zeroed
         dp.step_done()
 

@@ -156,6 +156,7 @@ def _worker(rank, world, port, q, scenario, backend, mode='zero1'):
         dist.init_process_group(backend, rank=rank, world_size=world)
         tr, m, snaps = _drive(scenario, world, rank, wrapped=True)
         assert tr.model.mode == mode, (tr.model.mode, mode)
+        tr.model.materialize_master()        # (zero1 keeps the big matrices' fp32 master sharded between steps)
         pm = m.arena().master.clone()
         gathered = [torch.zeros_like(pm) for _ in range(world)]
         dist.all_gather(gathered, pm)
