@@ -73,6 +73,10 @@ bench_keys = {'gemm_nt/dgelu M=41984 N=3072 K=768': kernels[dg[0]]['hbm_bytes_pe
 mq = [k for k in kernels if 'gemm_nt_w8_kernel<7' in k]
 if mq:
     bench_keys['gemm_nt/mulq M=41984 N=3072 K=768'] = kernels[mq[0]]['hbm_bytes_per_launch']
+# ... and lin1 + GELU + byte (epilogue 8) is the other instance that only this shape runs: the bench line's dominant kernel
+gq = [k for k in kernels if 'gemm_nt_w8_kernel<8' in k]
+if gq:
+    bench_keys['gemm_nt/bias_geluq M=41984 N=3072 K=768'] = kernels[gq[0]]['hbm_bytes_per_launch']
 # the weight-gradient kernel runs several shapes under one name: no per-shape traffic (bench.py prints null for it)
 # sustained clock over the GEMM kernels, launch-time weighted: the secondary roofline of bench.py
 gw = [(kernels[k]['clock_ghz'], stats_calls * stats_ns) for k, (stats_calls, stats_ns) in
