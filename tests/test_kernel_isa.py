@@ -101,12 +101,13 @@ def test_attention_kernels_keep_their_occupancy(tmp_path):
         args = m.group(3).rstrip('E')
         rehash = m.group(2) == 'bwd' and 'Lb1ELb0E' in args    # dropout without the forward's keep bits: legacy path
         assert info['ScratchSize'] == '0' or rehash, (m.group(1), info['ScratchSize'])
-        if m.group(2) == 'fwd' and args.endswith('Li11ELi4') or m.group(2) == 'bwd' and args.endswith('Li6ELi11ELi4'):
+        # (forward: <DH, KT, DROP, NTC = 11, NW = 4, EVENS>; backward: <DH, 16, DROP, MASK, 6, 11, NW = 4, KB, KBQ>)
+        if m.group(2) == 'fwd' and 'Li11ELi4ELb' in args or m.group(2) == 'bwd' and 'Li6ELi11ELi4ELi' in args:
             assert int(info['Occupancy']) >= 3, (m.group(1), info['Occupancy'], info['NumVgprs'])
             seen += 1
-        if args.endswith('Li8'):
+        if re.search(r'ELi8(ELb[01]|ELi1ELi1)$', args):
             assert int(info['Occupancy']) >= 2, (m.group(1), info['Occupancy'])
-    assert seen >= 3
+    assert seen >= 8, seen
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason='hipcc not installed')
