@@ -285,8 +285,11 @@ class DataParallel(torch.nn.Module):
         self._vec = None             # (index int64 [n], own mask fp32 [n]) of the fp32-read parameters, built on first use
         self.exposed_events = None   # set to [] to record (start, end) events around finish()'s waits
         object.__setattr__(module, 'ddp_hook', self)    # plain attribute: as a registered submodule it would close a cycle
-        if not self.single and arena.device.type == 'cuda' and os.environ.get('M3P_DP_TILE_QUEUE', '1') != '0':
-            # the collectives' kernels share CUs with the persistent GEMMs: let slowed-down CUs take fewer tiles
+        if not self.single and arena.device.type == 'cuda' and os.environ.get('M3P_DP_TILE_QUEUE', '0') != '0':
+            # the collectives' kernels share CUs with the persistent GEMMs: dynamic per-XCD tile queues let slowed-down CUs take
+            # fewer tiles.  OFF by default since round 4: the queue instantiations cost 0.57 ms of an undisturbed step, and with
+            # the exchange down to ~1.7 GB per step (bf16 parameter gather) the stand-in measurement of round 3 (static +8.4 ms,
+            # queues +4.9 ms under 10.7 GB of side traffic) scales to about the same 1.4 ms either way - DESIGN.md section 5
             from . import ops
             ops.set_tile_queue(True)
         if not self.single and arena.device.type == 'cuda' and reserve_cus():

@@ -151,7 +151,8 @@ def _drive(scenario, world, rank, wrapped=None):
 def _worker(rank, world, port, q, scenario, backend, mode='zero1'):
     try:
         os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                          HSA_ENABLE_IPC_MODE_LEGACY='0', M3P_DP_MODE=mode, M3P_DP_FORCE='1' if world == 1 else '0')
+                          HSA_ENABLE_IPC_MODE_LEGACY='0', M3P_DP_MODE=mode, M3P_DP_FORCE='1' if world == 1 else '0',
+                          M3P_DP_TILE_QUEUE='1')       # (opt-in since round 4: keep the queue instantiations under test)
         torch.cuda.set_device(rank if backend == 'nccl' else 0)
         dist.init_process_group(backend, rank=rank, world_size=world)
         tr, m, snaps = _drive(scenario, world, rank, wrapped=True)
