@@ -475,7 +475,7 @@ class DataParallel(torch.nn.Module):
         g = self._arena.grad.clone()
         if self.mode == 'zero1':
             for key, (s, e) in self._ranges.items():
-                if key in self._launched:
+                if key in self._launched or key == 'vocab':      # (token rows are applied to a rank's own vocabulary shard only)
                     a, b = self.shard_of(key)
                     _all_gather_into(g[s:e], g[a:b].clone(), self.pg).wait()
         return g
@@ -594,6 +594,16 @@ class DataParallel(torch.nn.Module):
         if self._tokens_out is not None:
             from . import ops
             ids_all, rows_all = self._tokens_out[:2]
+            if self.mode == 'zero1' and self.world > 1:
+                # sharded exchange: this rank steps (and norms) its own shard of the vocabulary gradient only, so of the N x
+                # B x T gathered rows it needs those whose matrix row intersects that shard - the others become pad rows,
+                # which the scatter kernel skips after reading their id (at 8 ranks: 1/8 of the atomics on average)
+                o, cnt, shape = self._arena.offsets['embeddings.weight']
+                a, b = self.shard_of('vocab')
+                dd = shape[1]
+                lo, hi = max(a - o, 0) // dd, -(-(min(b, o + cnt) - o) // dd)
+                ids_all = torch.where((ids_all >= lo) & (ids_all < hi), ids_all,
+                                      torch.full_like(ids_all, int(self.module.pad_index)))
             ops.scatter_add_token_rows(rows_all, ids_all, self._arena.g('embeddings.weight'), self.module.pad_index)
             self._arena.touch('embeddings.weight')
             self._tokens_out = None
