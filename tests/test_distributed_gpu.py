@@ -157,7 +157,18 @@ def _worker(rank, world, port, q, scenario, backend, mode='zero1'):
         dist.init_process_group(backend, rank=rank, world_size=world)
         tr, m, snaps = _drive(scenario, world, rank, wrapped=True)
         assert tr.model.mode == mode, (tr.model.mode, mode)
-        tr.model.materialize_master()        # (zero1 keeps the big matrices' fp32 master sharded between steps)
+        if mode == 'zero1':
+            # between steps the big matrices' fp32 master is current on its owner rank only: state_dict() must refuse to
+            # hand that out, and materialize_master() - a collective, every rank - must complete it
+            assert tr.model.master_partial
+            try:
+                m.state_dict()
+                raise AssertionError('state_dict() handed out a partial master')
+            except RuntimeError as e:
+                assert 'materialize_master' in str(e)
+        tr.model.materialize_master()
+        assert not tr.model.master_partial
+        m.state_dict()
         pm = m.arena().master.clone()
         gathered = [torch.zeros_like(pm) for _ in range(world)]
         dist.all_gather(gathered, pm)
