@@ -23,6 +23,7 @@
 #ifndef M3P_HIP_H
 #define M3P_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -52,25 +53,25 @@ enum {
   M3P_EPI_RES = 4,           /* C = alpha*acc + aux                                      */
   M3P_EPI_DGELU = 5,         /* C = acc * gelu_erf'(aux); colsum[n] += sum_m C (optional) */
   M3P_EPI_MUL = 6,           /* C = acc * aux;            colsum[n] += sum_m C (optional) */
-  M3P_EPI_MULQ = 7           /* C = acc * decode(aux);    colsum likewise.  aux = the one-byte gelu' codes m3p_gelu_fwd_gq
-                                wrote for this [M, N] in the GEMM's fragment order (M, N multiples of 256, M >= 1024,
-                                K % 64 == 0: the eight-wave kernel only - anything else returns M3P_EINVAL) */
-  ,
-  M3P_EPI_BIAS_GELUQ = 8     /* u = acc + bias (fp32) is NOT stored; C = gelu_erf(u); out2 = uint8 [M * N]: gelu_erf'(u) as
-                                one-byte codes in the fragment order M3P_EPI_MULQ reads (same shape limits; bias required):
-                                the FFN lin1 + activation of transformer.py:223 with what backward needs kept in a byte */
-  ,
+  /* round 4 - the three below run on the eight-wave 256 x 256 kernel only: M, N multiples of 256, M >= 1024, N >= 512,
+   * K % 64 == 0, 16-byte aligned bases; anything else returns M3P_EINVAL */
+  M3P_EPI_MULQ = 7,          /* C = acc * decode(aux); colsum[n] += sum_m C (optional).  aux = uint8 [M * N]: the one-byte
+                                gelu_erf' codes of this [M, N] in the GEMM's fragment order (written by M3P_EPI_BIAS_GELUQ
+                                or m3p_gelu_fwd_gq): the FFN data gradient through GELU, autograd of transformer.py:223-225 */
+  M3P_EPI_BIAS_GELUQ = 8,    /* u = acc + bias (fp32, NOT stored); C = gelu_erf(u); out2 = uint8 [M * N]: gelu_erf'(u) as one-byte
+                                codes in the fragment order M3P_EPI_MULQ reads (bias required): the FFN's lin1 + activation of
+                                transformer.py:223 (gelu :48-56) with what backward needs of u kept in a byte */
   M3P_EPI_BIAS_LSE = 9       /* C = acc + bias (M3P_EPI_BIAS without alpha / column scale) and, for the cross-entropy over the
                                 N columns (PredLayer, transformer.py:104-117): out2 = float2 [N / 64][M], the (maximum, sum of
                                 exp(x - maximum)) of every row over each 64-column block, columns >= ld_out2 (= V, the valid
-                                vocabulary) left out; m3p_ce_lse_from_blocks folds them into the rows' log-sum-exp.  Same
-                                shape limits as M3P_EPI_MULQ */
+                                vocabulary) left out; m3p_ce_lse_from_blocks folds them into the rows' log-sum-exp */
 };
 
 typedef struct M3PEpilogue {
   const float* bias;  /* [N] fp32 or NULL                                             */
-  const void* aux;    /* bf16 [M, ld_aux]: residual (DROP_RES, RES) / pre-activation (DGELU) */
-  void* out2;         /* bf16 [M, ld_out2]: pre-activation output (BIAS_GELU)          */
+  const void* aux;    /* bf16 [M, ld_aux]: residual (DROP_RES, RES) / pre-activation (DGELU); uint8 codes (MULQ) */
+  void* out2;         /* bf16 [M, ld_out2]: pre-activation output (BIAS_GELU); uint8 codes (BIAS_GELUQ); float2 block
+                         statistics (BIAS_LSE, with ld_out2 = the number of valid columns)    */
   float* colsum;      /* fp32 [N] accumulated with atomics, or NULL (DGELU)            */
   int32_t ld_aux;
   int32_t ld_out2;

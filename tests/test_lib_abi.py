@@ -45,3 +45,18 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(L, 'LIB_PATH', str(tmp_path / 'nope.so'))
     with pytest.raises(L.M3PError):
         L.load()
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/m3p_hip.h is the contract a C / cgo / JNI binding compiles against: it must parse as C on its own (it once
+    relied on a C++ translation unit having pulled in size_t)."""
+    import shutil
+    import subprocess
+    gcc = shutil.which('gcc')
+    if gcc is None:
+        pytest.skip('no gcc')
+    src = tmp_path / 'use.c'
+    src.write_text('#include "m3p_hip.h"\nint probe(void) { M3PEpilogue ep = {0}; return (int)sizeof(ep) + M3P_EPI_BIAS_LSE; }\n')
+    res = subprocess.run([gcc, '-std=c99', '-Wall', '-Werror', '-fsyntax-only', '-I', os.path.join(ROOT, 'include'), str(src)],
+                         capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
