@@ -32,7 +32,7 @@ numerically the all-reduce's result - SURVEY 8e):
                  by bucket in FORWARD order on the side stream (0.56 GB per step instead of 1.12), the transposed copies
                  backward reads follow; the next step's forward waits per bucket (``params_ready``);
                * the parameters the kernels read in **fp32** (biases, LayerNorm weights, the position / location tables,
-                 the ITM score vector - everything but the big GEMM matrices, ~5 M elements) travel as fp32: every rank
+                 the ITM score vector - everything that is not a GEMM operand, under 1 M elements) travel as fp32: every rank
                  packs them, zeroes what it does not own, one ``all_reduce`` (each element has exactly one non-zero
                  contributor, so the sum is the owner's value bit for bit), and writes them back into its master.
              The fp32 master of the big MATRICES therefore stays sharded between checkpoints: a rank holds the current
@@ -408,14 +408,16 @@ class DataParallel(torch.nn.Module):
         red.bytes_reduced = 0
         return True
 
-    # parameters the kernels consume through the bf16 working copy ONLY (the big GEMM operands): their fp32 master may stay
-    # sharded.  Everything else in the arena is treated as fp32-read and kept current on every rank.
-    _MATRIX_SUFFIXES = ('q_lin.weight', 'k_lin.weight', 'v_lin.weight', 'out_lin.weight', 'lin1.weight', 'lin2.weight')
+    # Parameters the kernels consume through the bf16 working copy ONLY - every GEMM operand: the vocabulary matrix, the layers',
+    # heads' and refiner's linear weights, the region projection - may keep their fp32 master sharded.  The kernels read in
+    # fp32: biases and LayerNorm parameters (1-D), the small score / location projections, and the three tables named here.
+    _MATRIX_MIN_ELEMS = 65536
+    _FP32_TABLES = ('position_embeddings.weight', 'cross_lang_embeddings.weight',
+                    'image_embeddings.image_location_embeddings.weight')
 
     def _is_sharded_matrix(self, name):
-        if name in ('embeddings.weight', 'image_embeddings.image_embeddings.weight'):
-            return True
-        return name.startswith(('attentions.', 'ffns.', 'encoder_attn.')) and name.endswith(self._MATRIX_SUFFIXES)
+        o, cnt, shape = self._arena.offsets[name]
+        return len(shape) == 2 and cnt >= self._MATRIX_MIN_ELEMS and name not in self._FP32_TABLES
 
     def _vector_index(self):
         if self._vec is None:

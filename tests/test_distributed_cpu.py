@@ -314,6 +314,7 @@ def _protocol_worker(rank, world, port, q, mode):
         dp.finish()
         ar.master.fill_(-1.0)
         want = torch.arange(ar.total, dtype=torch.float32)
+        dp._MATRIX_MIN_ELEMS = 256            # (this arena's 50 x 8 "vocabulary matrix" is to count as a sharded GEMM operand)
         for a, b in dp.owned(0, ar.total):
             ar.master[a:b] = want[a:b]                                    # "Adam" on the shard: master and bf16 copy together
             ar.w16[a:b] = want[a:b].to(torch.bfloat16)
