@@ -2073,31 +2073,56 @@ void gemm_nt_w4_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
   const int l_col = ((lane & 7) ^ l_row) * 8;
   // (only full tiles come here - the launcher sends ragged shapes to the ring kernel - so the
   //  eight row groups of a slice are a uniform stride apart and two pointers are enough)
-  // Source of piece p = (wave-uniform base of this K-tile's slice, advanced by the scalar unit once per K-tile) + (this lane's
-  // element offset for the piece, a register set up once): one vector add per piece.  (A per-lane pointer + k0 + p * step was
-  // half a dozen scalar instructions per piece on top - and this wave has no partner on its SIMD to issue around them.)
-  int a_poff[8], w_poff[8];
-#pragma unroll
-  for (int p = 0; p < 8; ++p) {
-    a_poff[p] = (l_row + 8 * p) * lda + l_col + 2048 - 512 * p;       // next row group, next immediate
-    w_poff[p] = (l_row + 8 * p) * ldw + l_col + 2048 - 512 * p;
-  }
+  // Source of piece p = (wave-uniform pointer: this K-tile's slice + 8 p rows, less what the immediate adds) + (the lane's 32-bit
+  // byte offset, one register per operand for the whole kernel): the LDS-DMA's scalar-base address form, no vector arithmetic
+  // per piece and no per-piece address registers.  (Sixteen 64-bit lane addresses live across the K-tile made the compiler
+  // park values in the AGPRs - which are this kernel's accumulators.)
+  const uint32_t a_lane = (uint32_t)(l_row * lda + l_col) * 2u, w_lane = (uint32_t)(l_row * ldw + l_col) * 2u;
+  const size_t a_step8 = (size_t)8 * lda, w_step8 = (size_t)8 * ldw;
   const bf16* a_tile;       // this wave's slice of the tile the load cursor points at, K-tile 0
   const bf16* w_tile;
   const bf16* a_base;       // ... at the cursor's K-tile
   const bf16* w_base;
+#ifndef M3P_W4_BUFDMA
+#define M3P_W4_BUFDMA 1
+#endif
+  __amdgpu_buffer_rsrc_t a_rsrc, w_rsrc;
   int l_q = 0, l_kt = 0;
   auto set_load_tile = [&](int q) {
     int tm, tn;
     split_tile(tile_of(q), tm, tn);
     a_base = a_tile = A + (size_t)(tm * BM + wid * 64) * lda;
     w_base = w_tile = W + (size_t)(tn * BN + wid * 64) * ldw;
+    if (M3P_W4_BUFDMA) {
+      a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(uniform_ptr(a_tile)), 0, 0xffffffff, 0x00020000);
+      w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(uniform_ptr(w_tile)), 0, 0xffffffff, 0x00020000);
+    }
   };
 #define W4_LD1(PTR, IMM) __builtin_amdgcn_global_load_lds(GLB_PTR(PTR), LDS_PTR(sl), 16, IMM, 0)
+#define W4_LDB(IMM) __builtin_amdgcn_raw_ptr_buffer_load_lds(piece < 8 ? a_rsrc : w_rsrc, LDS_PTR(sl), 16, piece < 8 ? a_lane : w_lane, soff, IMM, 0)
+  // M3P_W4_BUFDMA: the transfer as buffer_load_dwordx4 ... lds (resource = this wave's slice of the operand tile, scalar offset
+  // = K-tile + piece, one 32-bit lane offset for the whole kernel) instead of global_load_lds_dwordx4.  The immediate of the
+  // buffer form is unsigned 12-bit: pieces 0-3 and 4-7 of an operand get an M0 each (slice, slice + 4 KB), immediates 0..3072.
   auto issue_load = [&](int s, int piece) {
+    const int pc = piece & 7;
+    if (M3P_W4_BUFDMA) {
+      char* sl = smem + s * STAGE + (piece < 8 ? 0 : A_BYTES) + wid * 8192 + (pc >> 2) * 4096;
+      const uint32_t k_off = (ABL & 4) ? 0u : (uint32_t)l_kt * (KT * 2);
+      const uint32_t soff = __builtin_amdgcn_readfirstlane(k_off + (uint32_t)pc * (uint32_t)((piece < 8 ? lda : ldw) * 16) - (uint32_t)(pc & 3) * 1024u);
+      switch (pc & 3) {
+        case 0: W4_LDB(0); break;
+        case 1: W4_LDB(1024); break;
+        case 2: W4_LDB(2048); break;
+        default: W4_LDB(3072); break;
+      }
+      return;
+    }
     char* sl = smem + s * STAGE + (piece < 8 ? 0 : A_BYTES) + wid * 8192 + 4096;
-    const bf16* src = (piece < 8) ? a_base + a_poff[piece & 7] : w_base + w_poff[piece & 7];
-    switch (piece & 7) {
+    const bf16* row = uniform_ptr((piece < 8 ? a_base + pc * a_step8 : w_base + pc * w_step8) - (pc - 4) * 512);
+    uint32_t lane_off = piece < 8 ? a_lane : w_lane;
+    asm volatile("" : "+v"(lane_off));      // (the zero-extension has to sit beside the DMA for the scalar-base form to be selected)
+    const char* src = reinterpret_cast<const char*>(row) + lane_off;
+    switch (pc) {
       case 0: W4_LD1(src, -4096); break;
       case 1: W4_LD1(src, -3072); break;
       case 2: W4_LD1(src, -2048); break;
@@ -2145,6 +2170,168 @@ void gemm_nt_w4_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
 #define W4_LP(PIECE) do { if (!(ABL & 2) && PEND) issue_load(s_cur ^ 1, PIECE); __builtin_amdgcn_sched_barrier(0); } while (0)
 
   bf16x8 fa0[8], fw0[8], fa1[8], fw1[8];
+#ifndef M3P_W4_SCHED2
+#define M3P_W4_SCHED2 1
+#endif
+#define W4_WAIT_LGKM(N) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(" #N ")" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define W4_WAIT_VM(N) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define W4_BAR() do { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define W4_LD() do { load_done(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#if M3P_W4_SCHED2
+  // One K-tile (tile j in stage s, tile j+1 landing in stage s^1) = 128 MFMAs with every memory instruction in their shadow.
+  // What decides the schedule is the time a global -> LDS transfer is given to land:
+  //   MFMA   1..15  k-step 1 of tile j: W fragments out of stage s        (k-step 0 is in registers since the previous K-tile)
+  //         17..43  ... and the A fragments
+  //         20      lgkmcnt + barrier: nobody reads W of stage s any more  -> W of tile j+2 starts arriving there (21..49)
+  //         50      lgkmcnt(0) + barrier: nor A                            -> A of tile j+2 (53..)
+  //        107      vmcnt(16) + barrier: tile j+1 (requested one K-tile ago) has landed for everyone
+  //        108..123 k-step 0 of tile j+1 into the registers k-step 0 of tile j vacated at MFMA 63
+  // so a transfer has between 1.2 and 1.7 K-tiles (2500-3500 clocks) to land where the two-phase form above gives the last
+  // five pieces of a K-tile 46 MFMAs (740 clocks, less than an HBM miss), and the three barriers sit where their condition
+  // has long been true.
+  auto ktile = [&](auto first_c, auto stage_c) {
+    constexpr bool FIRST0 = decltype(first_c)::value;   // first K-tile of an output tile: C operand = 0 in k-step 0
+    constexpr int s_cur = decltype(stage_c)::value;
+    const uint32_t ra1 = s_cur ? a_addr1[1] : a_addr[1], rb1 = s_cur ? b_addr1[1] : b_addr[1];
+    const uint32_t ra0n = s_cur ? a_addr[0] : a_addr1[0], rb0n = s_cur ? b_addr[0] : b_addr1[0];
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      constexpr bool FIRST = FIRST0;
+    W4_M(fa0, fw0, 0, 0);
+      W4_M(fa0, fw0, 0, 1); W4_DSR(fw1[0], rb1, 0);
+      W4_M(fa0, fw0, 0, 2);
+      W4_M(fa0, fw0, 0, 3); W4_DSR(fw1[1], rb1, 2048);
+      W4_M(fa0, fw0, 0, 4);
+      W4_M(fa0, fw0, 0, 5); W4_DSR(fw1[2], rb1, 4096);
+      W4_M(fa0, fw0, 0, 6);
+      W4_M(fa0, fw0, 0, 7); W4_DSR(fw1[3], rb1, 6144);
+      W4_M(fa0, fw0, 1, 0);
+      W4_M(fa0, fw0, 1, 1); W4_DSR(fw1[4], rb1, 8192);
+      W4_M(fa0, fw0, 1, 2);
+      W4_M(fa0, fw0, 1, 3); W4_DSR(fw1[5], rb1, 10240);
+      W4_M(fa0, fw0, 1, 4);
+      W4_M(fa0, fw0, 1, 5); W4_DSR(fw1[6], rb1, 12288);
+      W4_M(fa0, fw0, 1, 6);
+      W4_M(fa0, fw0, 1, 7); W4_DSR(fw1[7], rb1, 14336);
+      W4_M(fa0, fw0, 2, 0);
+      W4_M(fa0, fw0, 2, 1); W4_DSR(fa1[0], ra1, 0);
+      W4_M(fa0, fw0, 2, 2);
+      W4_M(fa0, fw0, 2, 3); W4_DSR(fa1[1], ra1, 2048);
+      W4_M(fa0, fw0, 2, 4); W4_WAIT_LGKM(2); W4_BAR(); W4_TSEG(0);
+      W4_M(fa0, fw0, 2, 5); W4_L(8);
+      W4_M(fa0, fw0, 2, 6);
+      W4_M(fa0, fw0, 2, 7); W4_DSR(fa1[2], ra1, 4096);
+      W4_M(fa0, fw0, 3, 0);
+      W4_M(fa0, fw0, 3, 1);
+      W4_M(fa0, fw0, 3, 2); W4_L(9);
+      W4_M(fa0, fw0, 3, 3); W4_DSR(fa1[3], ra1, 6144);
+      W4_M(fa0, fw0, 3, 4);
+      W4_M(fa0, fw0, 3, 5);
+      W4_M(fa0, fw0, 3, 6);
+      W4_M(fa0, fw0, 3, 7); W4_DSR(fa1[4], ra1, 8192); W4_L(10);
+      W4_M(fa0, fw0, 4, 0);
+      W4_M(fa0, fw0, 4, 1);
+      W4_M(fa0, fw0, 4, 2);
+      W4_M(fa0, fw0, 4, 3); W4_DSR(fa1[5], ra1, 10240);
+      W4_M(fa0, fw0, 4, 4); W4_L(11);
+      W4_M(fa0, fw0, 4, 5);
+      W4_M(fa0, fw0, 4, 6);
+      W4_M(fa0, fw0, 4, 7); W4_DSR(fa1[6], ra1, 12288);
+      W4_M(fa0, fw0, 5, 0);
+      W4_M(fa0, fw0, 5, 1); W4_L(12);
+      W4_M(fa0, fw0, 5, 2);
+      W4_M(fa0, fw0, 5, 3); W4_DSR(fa1[7], ra1, 14336);
+      W4_M(fa0, fw0, 5, 4);
+      W4_M(fa0, fw0, 5, 5);
+      W4_M(fa0, fw0, 5, 6); W4_L(13);
+      W4_M(fa0, fw0, 5, 7);
+      W4_M(fa0, fw0, 6, 0);
+      W4_M(fa0, fw0, 6, 1);
+      W4_M(fa0, fw0, 6, 2); W4_WAIT_LGKM(0); W4_BAR(); W4_TSEG(1);
+      W4_M(fa0, fw0, 6, 3);
+      W4_M(fa0, fw0, 6, 4); W4_L(14);
+      W4_M(fa0, fw0, 6, 5);
+      W4_M(fa0, fw0, 6, 6);
+      W4_M(fa0, fw0, 6, 7);
+      W4_M(fa0, fw0, 7, 0);
+      W4_M(fa0, fw0, 7, 1); W4_L(15);
+      W4_M(fa0, fw0, 7, 2);
+      W4_M(fa0, fw0, 7, 3);
+      W4_M(fa0, fw0, 7, 4);
+      W4_M(fa0, fw0, 7, 5);
+      W4_M(fa0, fw0, 7, 6); W4_L(0);
+      W4_M(fa0, fw0, 7, 7);
+    }
+    {
+      constexpr bool FIRST = false;
+    W4_M(fa1, fw1, 0, 0);
+      W4_M(fa1, fw1, 0, 1);
+      W4_M(fa1, fw1, 0, 2);
+      W4_M(fa1, fw1, 0, 3); W4_L(1);
+      W4_M(fa1, fw1, 0, 4);
+      W4_M(fa1, fw1, 0, 5);
+      W4_M(fa1, fw1, 0, 6);
+      W4_M(fa1, fw1, 0, 7);
+      W4_M(fa1, fw1, 1, 0); W4_L(2);
+      W4_M(fa1, fw1, 1, 1);
+      W4_M(fa1, fw1, 1, 2);
+      W4_M(fa1, fw1, 1, 3);
+      W4_M(fa1, fw1, 1, 4);
+      W4_M(fa1, fw1, 1, 5); W4_L(3);
+      W4_M(fa1, fw1, 1, 6);
+      W4_M(fa1, fw1, 1, 7);
+      W4_M(fa1, fw1, 2, 0);
+      W4_M(fa1, fw1, 2, 1);
+      W4_M(fa1, fw1, 2, 2); W4_L(4);
+      W4_M(fa1, fw1, 2, 3);
+      W4_M(fa1, fw1, 2, 4);
+      W4_M(fa1, fw1, 2, 5);
+      W4_M(fa1, fw1, 2, 6);
+      W4_M(fa1, fw1, 2, 7); W4_L(5);
+      W4_M(fa1, fw1, 3, 0);
+      W4_M(fa1, fw1, 3, 1);
+      W4_M(fa1, fw1, 3, 2);
+      W4_M(fa1, fw1, 3, 3);
+      W4_M(fa1, fw1, 3, 4); W4_L(6);
+      W4_M(fa1, fw1, 3, 5);
+      W4_M(fa1, fw1, 3, 6);
+      W4_M(fa1, fw1, 3, 7);
+      W4_M(fa1, fw1, 4, 0);
+      W4_M(fa1, fw1, 4, 1); W4_L(7);
+      W4_M(fa1, fw1, 4, 2); W4_LD();
+      W4_M(fa1, fw1, 4, 3);
+      W4_M(fa1, fw1, 4, 4);
+      W4_M(fa1, fw1, 4, 5);
+      W4_M(fa1, fw1, 4, 6);
+      W4_M(fa1, fw1, 4, 7);
+      W4_M(fa1, fw1, 5, 0);
+      W4_M(fa1, fw1, 5, 1);
+      W4_M(fa1, fw1, 5, 2);
+      W4_M(fa1, fw1, 5, 3); W4_TSEG(2); W4_WAIT_VM(16); W4_TSEG(3); W4_BAR(); W4_TSEG(4);
+      W4_M(fa1, fw1, 5, 4); W4_DSR(fw0[0], rb0n, 0);
+      W4_M(fa1, fw1, 5, 5); W4_DSR(fw0[1], rb0n, 2048);
+      W4_M(fa1, fw1, 5, 6); W4_DSR(fw0[2], rb0n, 4096);
+      W4_M(fa1, fw1, 5, 7); W4_DSR(fw0[3], rb0n, 6144);
+      W4_M(fa1, fw1, 6, 0); W4_DSR(fw0[4], rb0n, 8192);
+      W4_M(fa1, fw1, 6, 1); W4_DSR(fw0[5], rb0n, 10240);
+      W4_M(fa1, fw1, 6, 2); W4_DSR(fw0[6], rb0n, 12288);
+      W4_M(fa1, fw1, 6, 3); W4_DSR(fw0[7], rb0n, 14336);
+      W4_M(fa1, fw1, 6, 4); W4_DSR(fa0[0], ra0n, 0);
+      W4_M(fa1, fw1, 6, 5); W4_DSR(fa0[1], ra0n, 2048);
+      W4_M(fa1, fw1, 6, 6); W4_DSR(fa0[2], ra0n, 4096);
+      W4_M(fa1, fw1, 6, 7); W4_DSR(fa0[3], ra0n, 6144);
+      W4_M(fa1, fw1, 7, 0); W4_DSR(fa0[4], ra0n, 8192);
+      W4_M(fa1, fw1, 7, 1); W4_DSR(fa0[5], ra0n, 10240);
+      W4_M(fa1, fw1, 7, 2); W4_DSR(fa0[6], ra0n, 12288);
+      W4_M(fa1, fw1, 7, 3); W4_DSR(fa0[7], ra0n, 14336);
+      W4_M(fa1, fw1, 7, 4);
+      W4_M(fa1, fw1, 7, 5);
+      W4_M(fa1, fw1, 7, 6);
+      W4_M(fa1, fw1, 7, 7); W4_WAIT_LGKM(0); W4_TSEG(5);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+#else
   // phase 1: k-step 0 of the current K-tile from registers; fetch its k-step 1 fragments; finish
   // the LDS-DMA list phase 2 of the previous iteration started (`pend`)
   auto phase1 = [&](auto first_c, auto stage_c, auto pend_c) {
@@ -2293,6 +2480,7 @@ void gemm_nt_w4_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
     W4_M(fa1, fw1, 7, 7);
     __builtin_amdgcn_sched_barrier(0);
   };
+#endif
 
   // ---- prologue: K-tiles 0 and 1 into stages 0 and 1
   set_load_tile(0);
@@ -2330,6 +2518,12 @@ void gemm_nt_w4_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
         load_bias4<EPI>(ep, btn * BN + wn * 128, lane, bias_lo);
         load_bias4<EPI>(ep, btn * BN + wn * 128 + 64, lane, bias_hi);
       }
+#if M3P_W4_SCHED2
+      ktile(std::true_type{}, stage_c);
+    } else {
+      ktile(std::false_type{}, stage_c);
+    }
+#else
       if (step == 0) phase1(std::true_type{}, stage_c, std::false_type{});
       else phase1(std::true_type{}, stage_c, std::true_type{});
     } else {
@@ -2348,6 +2542,7 @@ void gemm_nt_w4_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
     W4_TSEG(0);
     W4_LGKM0();
     W4_TSEG(1);
+#endif
     if (++c_kt == nk) {
       // ---- epilogue of output tile c_q out of the wave-private staging area
       c_kt = 0;
@@ -2426,7 +2621,7 @@ void gemm_nt_w4_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
           for (int j = 0; j < 4; ++j) csum[j] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
       }
-      W4_TSEG(4);
+      W4_TSEG(M3P_W4_SCHED2 ? 6 : 4);
     }
   };
   for (int step = 0; step < total; step += 2) {
@@ -2435,18 +2630,23 @@ void gemm_nt_w4_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // junk loads of the tail must not outlive the LDS allocation
   if (TL) {
-    W4_TSEG(6);
+    W4_TSEG(M3P_W4_SCHED2 ? 7 : 6);
     if (lane == 0)
       for (int k = 0; k < 8; ++k) dbg[((size_t)blockIdx.x * 8 + wid) * 8 + k] = tacc[k];
   }
 #undef W4_TSEG
 #undef W4_LD1
+#undef W4_LDB
 #undef W4_ACC
 #undef W4_DSR
 #undef W4_LGKM0
 #undef W4_M
 #undef W4_L
 #undef W4_LP
+#undef W4_WAIT_LGKM
+#undef W4_WAIT_VM
+#undef W4_BAR
+#undef W4_LD
 }
 
 // W4-END
@@ -2574,7 +2774,14 @@ int launch_nt(const bf16* A, int lda, const bf16* W, int ldw, bf16* C, int ldc, 
 #ifndef M3P_W8_MAX_W_BYTES
 #define M3P_W8_MAX_W_BYTES (1LL << 40)      // (no limit: the vocabulary projection - W = 384 MB - measured 2.18 -> 1.85 ms on this kernel)
 #endif
-  if (M >= 1024 && (g_variant == 1 || g_variant == 6) && (N >= 512) && (2LL * N * K <= M3P_W8_MAX_W_BYTES) && (K % 64) == 0 && (lda % 8) == 0 &&
+  // Long contractions go to the four-wave kernel since its K-tile runs in one piece with buffer-form transfers (round 4):
+  // 159 against 174 us on dx1 (K = 3072), 125 against 131 on dh (K = 2304), 169 against 177 on lin2 forward; at K = 768 the
+  // eight-wave kernel's second wave per SIMD (which hides its epilogue's stores) still wins - 137 against 148 us on q/k/v.
+#ifndef M3P_W4_MIN_K
+#define M3P_W4_MIN_K 2048
+#endif
+  const bool w4_first = g_variant == 1 && deep && K >= M3P_W4_MIN_K && EPI != M3P_EPI_MUL && !g_tq_pool;      // (the tile queue of data parallelism lives in the eight-wave kernel)
+  if (M >= 1024 && (g_variant == 1 || g_variant == 6) && !w4_first && (N >= 512) && (2LL * N * K <= M3P_W8_MAX_W_BYTES) && (K % 64) == 0 && (lda % 8) == 0 &&
       (ldw % 8) == 0 && (M % 256) == 0 && (N % 256) == 0) {
     const int tiles_m = M / 256, tiles_n = N / 256;
     const size_t lds = 2 * 512 * ROWB + (EPI == M3P_EPI_DGELU && M3P_DGELU_LUT ? GELU_TAB_N * sizeof(float) : 0) +
@@ -2950,17 +3157,57 @@ void gemm_wgrad_w4_kernel(const bf16* __restrict__ dY_a, int lddy_a, const bf16*
   }
   const bf16* y_base;
   const bf16* x_base;
+#ifndef M3P_WG_BUFDMA
+#define M3P_WG_BUFDMA 1
+#endif
+  // M3P_WG_BUFDMA: the transfers as buffer_load_dwordx4 ... lds - resource = the K-tile's base, scalar offset = the piece's
+  // rows, a 32-bit lane offset (four per operand: the swizzle of a row depends on the piece's parity and half) - instead of
+  // global_load_lds_dwordx4 with a 64-bit lane address per piece.  In the NT kernel the buffer form costs the issuing wave
+  // ~16 clocks a piece where the global form costs ~37 (tools/gemm_timeline.py).  The buffer form's immediate is unsigned
+  // 12-bit: pieces 0-3 and 4-7 of an operand get an M0 each.
+  __amdgpu_buffer_rsrc_t y_rsrc, x_rsrc;
+  uint32_t y_voff[4], x_voff[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int f = ((2 * (k & 1) + l_hi) & 3) | ((k >> 1) << 2);        // pieces p with (p & 1, p >= 4) = (k & 1, k >> 1)
+    const int gc = l_pos ^ (f << 1);
+    y_voff[k] = (uint32_t)(l_hi * lddy + gc * 8) * 2u;
+    x_voff[k] = (uint32_t)(l_hi * ldx + gc * 8) * 2u;
+    if (YROWS) y_voff[k] = (uint32_t)((lane >> 3) * lddy + (((lane & 7) ^ (lane >> 3)) * 8)) * 2u;
+  }
+  auto set_rsrc = [&]() {
+    if (M3P_WG_BUFDMA) {
+      y_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(uniform_ptr(y_base)), 0, 0xffffffff, 0x00020000);
+      x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(uniform_ptr(x_base)), 0, 0xffffffff, 0x00020000);
+    }
+  };
   auto set_load_ktile = [&]() {
     const int ti = lc.t / tiles_j, tj = lc.t - ti * tiles_j;
     const size_t mbase = (size_t)(seg_m0 + lc.mt) * KT;
     y_base = YROWS ? dY + (size_t)(ti * TI) * lddy + mbase : dY + mbase * lddy + ti * TI;
     x_base = X + mbase * ldx + tj * TJ;
+    set_rsrc();
   };
   set_load_ktile();
   // (written as instructions in the scalar-base form - SGPR pair + 32-bit lane offset, no 64-bit vector add per piece - the
-  //  loads measured the same, 6.88 against 6.80 ms: the adds fit the free issue slots between two MFMAs.  The builtin stays.)
+  //  global loads measured the same, 6.88 against 6.80 ms: the adds fit the free issue slots between two MFMAs.)
 #define WG_LD1(PTR, IMM) __builtin_amdgcn_global_load_lds(GLB_PTR(PTR), LDS_PTR(sl), 16, IMM, 0)
+#define WG_LDB(IMM) __builtin_amdgcn_raw_ptr_buffer_load_lds(piece < 8 ? y_rsrc : x_rsrc, LDS_PTR(sl), 16, voff, soff, IMM, 0)
   auto issue_load = [&](int s, int piece) {
+    if (M3P_WG_BUFDMA) {
+      const int pc = piece & 7, k = (pc & 1) + 2 * (pc >> 2);
+      char* sl = smem + s * STAGE + (piece < 8 ? 0 : Y_BYTES) + wid * 8192 + (pc >> 2) * 4096;
+      const uint32_t voff = piece < 8 ? y_voff[YROWS ? 0 : k] : x_voff[k];
+      const uint32_t rows = (piece < 8 && YROWS) ? (uint32_t)(wid * 64 + 8 * pc) : (uint32_t)(wid * 16 + 2 * pc);
+      const uint32_t soff = __builtin_amdgcn_readfirstlane(rows * (uint32_t)((piece < 8 ? lddy : ldx) * 2) - (uint32_t)(pc & 3) * 1024u);
+      switch (pc & 3) {
+        case 0: WG_LDB(0); break;
+        case 1: WG_LDB(1024); break;
+        case 2: WG_LDB(2048); break;
+        default: WG_LDB(3072); break;
+      }
+      return;
+    }
     char* sl = smem + s * STAGE + (piece < 8 ? 0 : Y_BYTES) + wid * 8192 + 4096;
     const bf16* src = (piece < 8) ? y_base + y_off[piece & 7] : x_base + x_off[piece & 7];
     switch (piece & 7) {
@@ -2985,9 +3232,10 @@ void gemm_wgrad_w4_kernel(const bf16* __restrict__ dY_a, int lddy_a, const bf16*
       const bool more = ++l_issued < total;
       y_base += more ? y_step : 0;
       x_base += more ? x_step : 0;
+      set_rsrc();
     } else if (++l_issued < total) {
       if (++lc.mt == lc.len) { lc.mt = 0; lc.t += nwg; set_load_ktile(); }
-      else { y_base += y_step; x_base += x_step; }
+      else { y_base += y_step; x_base += x_step; set_rsrc(); }
     }
   };
 
@@ -3199,6 +3447,160 @@ void gemm_wgrad_w4_kernel(const bf16* __restrict__ dY_a, int lddy_a, const bf16*
     __builtin_amdgcn_sched_barrier(0);
   };
 
+#ifndef M3P_WG_SCHED2
+#define M3P_WG_SCHED2 1
+#endif
+#define WG_WAIT_LGKM(N) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(" #N ")" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define WG_WAIT_VM(N) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define WG_BAR() do { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define WG_LD() do { load_done(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define WG_SET1() do { _Pragma("unroll") for (int c = 0; c < 8; ++c) { yf1[c] = yfrag(c); xf1[c] = frag(xl[c], xh[c]); } __builtin_amdgcn_sched_barrier(0); } while (0)
+#define WG_SET0() do { _Pragma("unroll") for (int c = 0; c < 8; ++c) { yf0[c] = yfrag(c); xf0[c] = frag(xl[c], xh[c]); } __builtin_amdgcn_sched_barrier(0); } while (0)
+  // M3P_WG_SCHED2: the K-tile in one piece, as in gemm_nt_w4_kernel - the first operand's region of the stage is released by
+  // a barrier as soon as its k-step-1 fragments are in registers (MFMA 20), the second's at MFMA 50, the next K-tile is waited
+  // for at MFMA 107 (vmcnt(16): this K-tile's own sixteen transfers stay in flight): a transfer has 1.2-1.7 K-tiles to land
+  // where the two-phase form gives the last five of a K-tile 46 MFMAs and waits ~200-270 clocks per K-tile at its vmcnt(0).
+  auto wktile = [&](auto first_c, auto stage_c) {
+    constexpr bool FIRST0 = decltype(first_c)::value;
+    constexpr int s_cur = decltype(stage_c)::value;
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      constexpr bool FIRST = FIRST0;
+    WG_M(yf0, xf0, 0, 0);
+      WG_M(yf0, xf0, 0, 1); WG_YRD(0, s_cur, 1);
+      WG_M(yf0, xf0, 0, 2);
+      WG_M(yf0, xf0, 0, 3); WG_YRD(1, s_cur, 1);
+      WG_M(yf0, xf0, 0, 4);
+      WG_M(yf0, xf0, 0, 5); WG_YRD(2, s_cur, 1);
+      WG_M(yf0, xf0, 0, 6);
+      WG_M(yf0, xf0, 0, 7); WG_YRD(3, s_cur, 1);
+      WG_M(yf0, xf0, 1, 0);
+      WG_M(yf0, xf0, 1, 1); WG_YRD(4, s_cur, 1);
+      WG_M(yf0, xf0, 1, 2);
+      WG_M(yf0, xf0, 1, 3); WG_YRD(5, s_cur, 1);
+      WG_M(yf0, xf0, 1, 4);
+      WG_M(yf0, xf0, 1, 5); WG_YRD(6, s_cur, 1);
+      WG_M(yf0, xf0, 1, 6);
+      WG_M(yf0, xf0, 1, 7); WG_YRD(7, s_cur, 1);
+      WG_M(yf0, xf0, 2, 0);
+      WG_M(yf0, xf0, 2, 1); WG_TR2(xl[0], xh[0], x_addr[s_cur][0], 16384);
+      WG_M(yf0, xf0, 2, 2);
+      WG_M(yf0, xf0, 2, 3); WG_TR2(xl[1], xh[1], x_addr[s_cur][1], 16384);
+      WG_M(yf0, xf0, 2, 4); WG_WAIT_LGKM(4); WG_BAR();
+      WG_M(yf0, xf0, 2, 5); WG_L(0);
+      WG_M(yf0, xf0, 2, 6);
+      WG_M(yf0, xf0, 2, 7); WG_TR2(xl[2], xh[2], x_addr[s_cur][2], 16384);
+      WG_M(yf0, xf0, 3, 0);
+      WG_M(yf0, xf0, 3, 1);
+      WG_M(yf0, xf0, 3, 2); WG_L(1);
+      WG_M(yf0, xf0, 3, 3); WG_TR2(xl[3], xh[3], x_addr[s_cur][3], 16384);
+      WG_M(yf0, xf0, 3, 4);
+      WG_M(yf0, xf0, 3, 5);
+      WG_M(yf0, xf0, 3, 6);
+      WG_M(yf0, xf0, 3, 7); WG_TR2(xl[4], xh[4], x_addr[s_cur][4], 16384); WG_L(2);
+      WG_M(yf0, xf0, 4, 0);
+      WG_M(yf0, xf0, 4, 1);
+      WG_M(yf0, xf0, 4, 2);
+      WG_M(yf0, xf0, 4, 3); WG_TR2(xl[5], xh[5], x_addr[s_cur][5], 16384);
+      WG_M(yf0, xf0, 4, 4); WG_L(3);
+      WG_M(yf0, xf0, 4, 5);
+      WG_M(yf0, xf0, 4, 6);
+      WG_M(yf0, xf0, 4, 7); WG_TR2(xl[6], xh[6], x_addr[s_cur][6], 16384);
+      WG_M(yf0, xf0, 5, 0);
+      WG_M(yf0, xf0, 5, 1); WG_L(4);
+      WG_M(yf0, xf0, 5, 2);
+      WG_M(yf0, xf0, 5, 3); WG_TR2(xl[7], xh[7], x_addr[s_cur][7], 16384);
+      WG_M(yf0, xf0, 5, 4);
+      WG_M(yf0, xf0, 5, 5);
+      WG_M(yf0, xf0, 5, 6); WG_L(5);
+      WG_M(yf0, xf0, 5, 7);
+      WG_M(yf0, xf0, 6, 0);
+      WG_M(yf0, xf0, 6, 1);
+      WG_M(yf0, xf0, 6, 2); WG_WAIT_LGKM(0); WG_SET1(); WG_BAR();
+      WG_M(yf0, xf0, 6, 3);
+      WG_M(yf0, xf0, 6, 4); WG_L(6);
+      WG_M(yf0, xf0, 6, 5);
+      WG_M(yf0, xf0, 6, 6);
+      WG_M(yf0, xf0, 6, 7);
+      WG_M(yf0, xf0, 7, 0);
+      WG_M(yf0, xf0, 7, 1); WG_L(7);
+      WG_M(yf0, xf0, 7, 2);
+      WG_M(yf0, xf0, 7, 3);
+      WG_M(yf0, xf0, 7, 4);
+      WG_M(yf0, xf0, 7, 5);
+      WG_M(yf0, xf0, 7, 6); WG_L(8);
+      WG_M(yf0, xf0, 7, 7);
+    }
+    {
+      constexpr bool FIRST = false;
+    WG_M(yf1, xf1, 0, 0);
+      WG_M(yf1, xf1, 0, 1);
+      WG_M(yf1, xf1, 0, 2);
+      WG_M(yf1, xf1, 0, 3); WG_L(9);
+      WG_M(yf1, xf1, 0, 4);
+      WG_M(yf1, xf1, 0, 5);
+      WG_M(yf1, xf1, 0, 6);
+      WG_M(yf1, xf1, 0, 7);
+      WG_M(yf1, xf1, 1, 0); WG_L(10);
+      WG_M(yf1, xf1, 1, 1);
+      WG_M(yf1, xf1, 1, 2);
+      WG_M(yf1, xf1, 1, 3);
+      WG_M(yf1, xf1, 1, 4);
+      WG_M(yf1, xf1, 1, 5); WG_L(11);
+      WG_M(yf1, xf1, 1, 6);
+      WG_M(yf1, xf1, 1, 7);
+      WG_M(yf1, xf1, 2, 0);
+      WG_M(yf1, xf1, 2, 1);
+      WG_M(yf1, xf1, 2, 2); WG_L(12);
+      WG_M(yf1, xf1, 2, 3);
+      WG_M(yf1, xf1, 2, 4);
+      WG_M(yf1, xf1, 2, 5);
+      WG_M(yf1, xf1, 2, 6);
+      WG_M(yf1, xf1, 2, 7); WG_L(13);
+      WG_M(yf1, xf1, 3, 0);
+      WG_M(yf1, xf1, 3, 1);
+      WG_M(yf1, xf1, 3, 2);
+      WG_M(yf1, xf1, 3, 3);
+      WG_M(yf1, xf1, 3, 4); WG_L(14);
+      WG_M(yf1, xf1, 3, 5);
+      WG_M(yf1, xf1, 3, 6);
+      WG_M(yf1, xf1, 3, 7);
+      WG_M(yf1, xf1, 4, 0);
+      WG_M(yf1, xf1, 4, 1); WG_L(15);
+      WG_M(yf1, xf1, 4, 2); WG_LD();
+      WG_M(yf1, xf1, 4, 3);
+      WG_M(yf1, xf1, 4, 4);
+      WG_M(yf1, xf1, 4, 5);
+      WG_M(yf1, xf1, 4, 6);
+      WG_M(yf1, xf1, 4, 7);
+      WG_M(yf1, xf1, 5, 0);
+      WG_M(yf1, xf1, 5, 1);
+      WG_M(yf1, xf1, 5, 2);
+      WG_M(yf1, xf1, 5, 3); WG_WAIT_VM(16); WG_BAR();
+      WG_M(yf1, xf1, 5, 4); WG_YRD(0, s_cur ^ 1, 0);
+      WG_M(yf1, xf1, 5, 5); WG_YRD(1, s_cur ^ 1, 0);
+      WG_M(yf1, xf1, 5, 6); WG_YRD(2, s_cur ^ 1, 0);
+      WG_M(yf1, xf1, 5, 7); WG_YRD(3, s_cur ^ 1, 0);
+      WG_M(yf1, xf1, 6, 0); WG_YRD(4, s_cur ^ 1, 0);
+      WG_M(yf1, xf1, 6, 1); WG_YRD(5, s_cur ^ 1, 0);
+      WG_M(yf1, xf1, 6, 2); WG_YRD(6, s_cur ^ 1, 0);
+      WG_M(yf1, xf1, 6, 3); WG_YRD(7, s_cur ^ 1, 0);
+      WG_M(yf1, xf1, 6, 4); WG_TR2(xl[0], xh[0], x_addr[s_cur ^ 1][0], 0);
+      WG_M(yf1, xf1, 6, 5); WG_TR2(xl[1], xh[1], x_addr[s_cur ^ 1][1], 0);
+      WG_M(yf1, xf1, 6, 6); WG_TR2(xl[2], xh[2], x_addr[s_cur ^ 1][2], 0);
+      WG_M(yf1, xf1, 6, 7); WG_TR2(xl[3], xh[3], x_addr[s_cur ^ 1][3], 0);
+      WG_M(yf1, xf1, 7, 0); WG_TR2(xl[4], xh[4], x_addr[s_cur ^ 1][4], 0);
+      WG_M(yf1, xf1, 7, 1); WG_TR2(xl[5], xh[5], x_addr[s_cur ^ 1][5], 0);
+      WG_M(yf1, xf1, 7, 2); WG_TR2(xl[6], xh[6], x_addr[s_cur ^ 1][6], 0);
+      WG_M(yf1, xf1, 7, 3); WG_TR2(xl[7], xh[7], x_addr[s_cur ^ 1][7], 0);
+      WG_M(yf1, xf1, 7, 4);
+      WG_M(yf1, xf1, 7, 5);
+      WG_M(yf1, xf1, 7, 6);
+      WG_M(yf1, xf1, 7, 7); WG_WAIT_LGKM(0); WG_SET0();
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
   // ---- prologue: K-tiles 0 and 1 of the stream into stages 0 and 1
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
@@ -3231,6 +3633,11 @@ void gemm_wgrad_w4_kernel(const bf16* __restrict__ dY_a, int lddy_a, const bf16*
 #define WG_TSEG(k) do { } while (0)
 #endif
   auto kstep = [&](auto stage_c, int step) {
+#if M3P_WG_SCHED2
+    if (first) wktile(std::true_type{}, stage_c);
+    else wktile(std::false_type{}, stage_c);
+    first = false;
+#else
     WG_TSEG(6);
     if (step == 0) phase1(std::true_type{}, stage_c, std::false_type{});
     else if (first) phase1(std::true_type{}, stage_c, std::true_type{});
@@ -3255,6 +3662,8 @@ void gemm_wgrad_w4_kernel(const bf16* __restrict__ dY_a, int lddy_a, const bf16*
 #endif
 #pragma unroll
     for (int c = 0; c < 8; ++c) { yf0[c] = yfrag(c); xf0[c] = frag(xl[c], xh[c]); }
+
+#endif
 
     const bool last_of_tile = (cc.mt + 1 == cc.len) || (step + 1 == total);
     if (last_of_tile) {
@@ -3354,6 +3763,7 @@ void gemm_wgrad_w4_kernel(const bf16* __restrict__ dY_a, int lddy_a, const bf16*
 #endif
 #undef WG_TSEG
 #undef WG_LD1
+#undef WG_LDB
 #undef WG_TR2
 #undef WG_YRD
 #undef WG_LGKM0

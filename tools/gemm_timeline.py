@@ -19,6 +19,8 @@ torch.cuda.synchronize()
 d = dbg.view(256, 8, 8).double()
 d = d[:, :4]       # four waves per workgroup
 names = ['groups (reads+dma+mfma issue)', 'lgkm wait', 'vmcnt wait', 'barrier', 'epilogue', 'loop glue', 'drain', '-']
+if os.environ.get('W4_SCHED2', '1') == '1':      # the one-piece K-tile: MFMA 0..20 + barrier 1 | ..50 + barrier 2 | ..107 | vmcnt wait | barrier 3 | ..127 + lgkmcnt(0)
+    names = ['MFMA 0-20, W reads, barrier 1', 'MFMA 21-50, A reads, W DMAs, barrier 2', 'MFMA 51-107, A DMAs', 'vmcnt(16) wait', 'barrier 3', 'MFMA 108-127, 16 reads, lgkmcnt(0)', 'epilogue', 'drain']
 tot = d.sum(-1).mean()
 print('shape', M, N, K, ' mean cycles per wave: %.0f' % tot)
 for k, n in enumerate(names):

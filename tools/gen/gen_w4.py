@@ -73,8 +73,63 @@ for k in range(WG_P2):
 wbody = open(os.path.join(ROOT, 'tools', 'gen', 'wgrad_w4_template.hip')).read()
 wbody = wbody.replace('@PHASE1@', wg_mfma_lines('yf0', 'xf0', wex1)).replace('@PHASE2@', wg_mfma_lines('yf1', 'xf1', wex2))
 
+# ---- the NT kernel's one-piece K-tile (M3P_W4_SCHED2): slots are MFMA indices 0..127 (k-step 0 = 0..63)
+KT_BAR1 = int(os.environ.get('W4_BAR1', '20'))          # after this MFMA: W of the stage is dead
+KT_BAR2 = int(os.environ.get('W4_BAR2', '50'))          # ... and A
+KT_BAR3 = int(os.environ.get('W4_BAR3', '107'))         # the next K-tile has landed
+KT_DMA_W = [int(x) for x in os.environ.get('W4_DMA_W', '21,26,31,36,41,46,52,57').split(',')]
+KT_DMA_A = [int(x) for x in os.environ.get('W4_DMA_A', '62,67,72,77,82,87,92,97').split(',')]
+kt = {}
+for r in range(8):                                      # W fragments of k-step 1: MFMAs 1..15
+    add(kt, 2 * r + 1, 'W4_DSR(fw1[%d], rb1, %d);' % (r, r * 2048))
+a_slots = [17, 19] + [23 + 4 * k for k in range(6)]     # A fragments: two before the first barrier, the rest between the W transfers
+for r, sl in enumerate(a_slots):
+    add(kt, sl, 'W4_DSR(fa1[%d], ra1, %d);' % (r, r * 2048))
+n_after = sum(1 for sl in a_slots if sl <= KT_BAR1)
+add(kt, KT_BAR1, 'W4_WAIT_LGKM(%d); W4_BAR(); W4_TSEG(0);' % n_after)
+for k, sl in enumerate(KT_DMA_W):
+    add(kt, sl, 'W4_L(%d);' % (8 + k))
+assert max(a_slots) < KT_BAR2
+add(kt, KT_BAR2, 'W4_WAIT_LGKM(0); W4_BAR(); W4_TSEG(1);')
+for k, sl in enumerate(KT_DMA_A):
+    add(kt, sl, 'W4_L(%d);' % k)
+add(kt, max(KT_DMA_A) + 1, 'W4_LD();')
+assert max(KT_DMA_A) + 1 < KT_BAR3
+add(kt, KT_BAR3, 'W4_TSEG(2); W4_WAIT_VM(16); W4_TSEG(3); W4_BAR(); W4_TSEG(4);')
+for r in range(16):                                     # k-step 0 of the next K-tile
+    add(kt, KT_BAR3 + 1 + r, ('W4_DSR(fw0[%d], rb0n, %d);' % (r, r * 2048)) if r < 8 else ('W4_DSR(fa0[%d], ra0n, %d);' % (r - 8, (r - 8) * 2048)))
+assert KT_BAR3 + 16 <= 127
+add(kt, 127, 'W4_WAIT_LGKM(0); W4_TSEG(5);')
+kt_a = {n: v for n, v in kt.items() if n < 64}
+kt_b = {n - 64: v for n, v in kt.items() if n >= 64}
+
+# ---- the weight-gradient kernel's one-piece K-tile (M3P_WG_SCHED2): the NT kernel's slots, a "read" = one fragment
+wkt = {}
+for c in range(8):                                      # first operand's fragments of k-step 1
+    add(wkt, 2 * c + 1, 'WG_YRD(%d, s_cur, 1);' % c)
+for c, sl in enumerate(a_slots):                        # second operand's: two before the first barrier (= 4 read instructions)
+    add(wkt, sl, 'WG_TR2(xl[%d], xh[%d], x_addr[s_cur][%d], 16384);' % (c, c, c))
+add(wkt, KT_BAR1, 'WG_WAIT_LGKM(%d); WG_BAR();' % (2 * n_after))
+for k, sl in enumerate(KT_DMA_W):
+    add(wkt, sl, 'WG_L(%d);' % k)                       # (the first operand's region is pieces 0..7 here)
+add(wkt, KT_BAR2, 'WG_WAIT_LGKM(0); WG_SET1(); WG_BAR();')
+for k, sl in enumerate(KT_DMA_A):
+    add(wkt, sl, 'WG_L(%d);' % (8 + k))
+add(wkt, max(KT_DMA_A) + 1, 'WG_LD();')
+WGK_BAR3 = int(os.environ.get('WGK_BAR3', str(KT_BAR3)))    # (a fragment is two read instructions here: the tail may want more room)
+WGK_RSTEP = int(os.environ.get('WGK_RSTEP', '1'))
+assert max(KT_DMA_A) + 1 < WGK_BAR3 and WGK_BAR3 + 1 + 15 * WGK_RSTEP <= 126
+add(wkt, WGK_BAR3, 'WG_WAIT_VM(16); WG_BAR();')
+for r in range(16):
+    add(wkt, WGK_BAR3 + 1 + r * WGK_RSTEP, ('WG_YRD(%d, s_cur ^ 1, 0);' % r) if r < 8 else ('WG_TR2(xl[%d], xh[%d], x_addr[s_cur ^ 1][%d], 0);' % (r - 8, r - 8, r - 8)))
+add(wkt, 127, 'WG_WAIT_LGKM(0); WG_SET0();')
+wkt_a = {n: v for n, v in wkt.items() if n < 64}
+wkt_b = {n - 64: v for n, v in wkt.items() if n >= 64}
+wbody = wbody.replace('@WKT_A@', wg_mfma_lines('yf0', 'xf0', wkt_a).replace('\n    ', '\n      ')).replace('@WKT_B@', wg_mfma_lines('yf1', 'xf1', wkt_b).replace('\n    ', '\n      '))
+
 body = open(os.path.join(ROOT, 'tools', 'gen', 'w4_template.hip')).read()
 body = body.replace('@PHASE1@', mfma_lines('fa0', 'fw0', ex1)).replace('@PHASE2@', mfma_lines('fa1', 'fw1', ex2))
+body = body.replace('@KT_A@', mfma_lines('fa0', 'fw0', kt_a).replace('\n    ', '\n      ')).replace('@KT_B@', mfma_lines('fa1', 'fw1', kt_b).replace('\n    ', '\n      '))
 p = os.path.join(ROOT, 'm3p_amd', 'csrc', 'gemm.hip')
 s = open(p).read()
 a = s.index('// W4-BEGIN')

@@ -70,31 +70,56 @@ void gemm_nt_w4_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
   const int l_col = ((lane & 7) ^ l_row) * 8;
   // (only full tiles come here - the launcher sends ragged shapes to the ring kernel - so the
   //  eight row groups of a slice are a uniform stride apart and two pointers are enough)
-  // Source of piece p = (wave-uniform base of this K-tile's slice, advanced by the scalar unit once per K-tile) + (this lane's
-  // element offset for the piece, a register set up once): one vector add per piece.  (A per-lane pointer + k0 + p * step was
-  // half a dozen scalar instructions per piece on top - and this wave has no partner on its SIMD to issue around them.)
-  int a_poff[8], w_poff[8];
-#pragma unroll
-  for (int p = 0; p < 8; ++p) {
-    a_poff[p] = (l_row + 8 * p) * lda + l_col + 2048 - 512 * p;       // next row group, next immediate
-    w_poff[p] = (l_row + 8 * p) * ldw + l_col + 2048 - 512 * p;
-  }
+  // Source of piece p = (wave-uniform pointer: this K-tile's slice + 8 p rows, less what the immediate adds) + (the lane's 32-bit
+  // byte offset, one register per operand for the whole kernel): the LDS-DMA's scalar-base address form, no vector arithmetic
+  // per piece and no per-piece address registers.  (Sixteen 64-bit lane addresses live across the K-tile made the compiler
+  // park values in the AGPRs - which are this kernel's accumulators.)
+  const uint32_t a_lane = (uint32_t)(l_row * lda + l_col) * 2u, w_lane = (uint32_t)(l_row * ldw + l_col) * 2u;
+  const size_t a_step8 = (size_t)8 * lda, w_step8 = (size_t)8 * ldw;
   const bf16* a_tile;       // this wave's slice of the tile the load cursor points at, K-tile 0
   const bf16* w_tile;
   const bf16* a_base;       // ... at the cursor's K-tile
   const bf16* w_base;
+#ifndef M3P_W4_BUFDMA
+#define M3P_W4_BUFDMA 1
+#endif
+  __amdgpu_buffer_rsrc_t a_rsrc, w_rsrc;
   int l_q = 0, l_kt = 0;
   auto set_load_tile = [&](int q) {
     int tm, tn;
     split_tile(tile_of(q), tm, tn);
     a_base = a_tile = A + (size_t)(tm * BM + wid * 64) * lda;
     w_base = w_tile = W + (size_t)(tn * BN + wid * 64) * ldw;
+    if (M3P_W4_BUFDMA) {
+      a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(uniform_ptr(a_tile)), 0, 0xffffffff, 0x00020000);
+      w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(uniform_ptr(w_tile)), 0, 0xffffffff, 0x00020000);
+    }
   };
 #define W4_LD1(PTR, IMM) __builtin_amdgcn_global_load_lds(GLB_PTR(PTR), LDS_PTR(sl), 16, IMM, 0)
+#define W4_LDB(IMM) __builtin_amdgcn_raw_ptr_buffer_load_lds(piece < 8 ? a_rsrc : w_rsrc, LDS_PTR(sl), 16, piece < 8 ? a_lane : w_lane, soff, IMM, 0)
+  // M3P_W4_BUFDMA: the transfer as buffer_load_dwordx4 ... lds (resource = this wave's slice of the operand tile, scalar offset
+  // = K-tile + piece, one 32-bit lane offset for the whole kernel) instead of global_load_lds_dwordx4.  The immediate of the
+  // buffer form is unsigned 12-bit: pieces 0-3 and 4-7 of an operand get an M0 each (slice, slice + 4 KB), immediates 0..3072.
   auto issue_load = [&](int s, int piece) {
+    const int pc = piece & 7;
+    if (M3P_W4_BUFDMA) {
+      char* sl = smem + s * STAGE + (piece < 8 ? 0 : A_BYTES) + wid * 8192 + (pc >> 2) * 4096;
+      const uint32_t k_off = (ABL & 4) ? 0u : (uint32_t)l_kt * (KT * 2);
+      const uint32_t soff = __builtin_amdgcn_readfirstlane(k_off + (uint32_t)pc * (uint32_t)((piece < 8 ? lda : ldw) * 16) - (uint32_t)(pc & 3) * 1024u);
+      switch (pc & 3) {
+        case 0: W4_LDB(0); break;
+        case 1: W4_LDB(1024); break;
+        case 2: W4_LDB(2048); break;
+        default: W4_LDB(3072); break;
+      }
+      return;
+    }
     char* sl = smem + s * STAGE + (piece < 8 ? 0 : A_BYTES) + wid * 8192 + 4096;
-    const bf16* src = (piece < 8) ? a_base + a_poff[piece & 7] : w_base + w_poff[piece & 7];
-    switch (piece & 7) {
+    const bf16* row = uniform_ptr((piece < 8 ? a_base + pc * a_step8 : w_base + pc * w_step8) - (pc - 4) * 512);
+    uint32_t lane_off = piece < 8 ? a_lane : w_lane;
+    asm volatile("" : "+v"(lane_off));      // (the zero-extension has to sit beside the DMA for the scalar-base form to be selected)
+    const char* src = reinterpret_cast<const char*>(row) + lane_off;
+    switch (pc) {
       case 0: W4_LD1(src, -4096); break;
       case 1: W4_LD1(src, -3072); break;
       case 2: W4_LD1(src, -2048); break;
@@ -142,6 +167,42 @@ void gemm_nt_w4_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
 #define W4_LP(PIECE) do { if (!(ABL & 2) && PEND) issue_load(s_cur ^ 1, PIECE); __builtin_amdgcn_sched_barrier(0); } while (0)
 
   bf16x8 fa0[8], fw0[8], fa1[8], fw1[8];
+#ifndef M3P_W4_SCHED2
+#define M3P_W4_SCHED2 1
+#endif
+#define W4_WAIT_LGKM(N) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(" #N ")" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define W4_WAIT_VM(N) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define W4_BAR() do { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define W4_LD() do { load_done(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#if M3P_W4_SCHED2
+  // One K-tile (tile j in stage s, tile j+1 landing in stage s^1) = 128 MFMAs with every memory instruction in their shadow.
+  // What decides the schedule is the time a global -> LDS transfer is given to land:
+  //   MFMA   1..15  k-step 1 of tile j: W fragments out of stage s        (k-step 0 is in registers since the previous K-tile)
+  //         17..43  ... and the A fragments
+  //         20      lgkmcnt + barrier: nobody reads W of stage s any more  -> W of tile j+2 starts arriving there (21..49)
+  //         50      lgkmcnt(0) + barrier: nor A                            -> A of tile j+2 (53..)
+  //        107      vmcnt(16) + barrier: tile j+1 (requested one K-tile ago) has landed for everyone
+  //        108..123 k-step 0 of tile j+1 into the registers k-step 0 of tile j vacated at MFMA 63
+  // so a transfer has between 1.2 and 1.7 K-tiles (2500-3500 clocks) to land where the two-phase form above gives the last
+  // five pieces of a K-tile 46 MFMAs (740 clocks, less than an HBM miss), and the three barriers sit where their condition
+  // has long been true.
+  auto ktile = [&](auto first_c, auto stage_c) {
+    constexpr bool FIRST0 = decltype(first_c)::value;   // first K-tile of an output tile: C operand = 0 in k-step 0
+    constexpr int s_cur = decltype(stage_c)::value;
+    const uint32_t ra1 = s_cur ? a_addr1[1] : a_addr[1], rb1 = s_cur ? b_addr1[1] : b_addr[1];
+    const uint32_t ra0n = s_cur ? a_addr[0] : a_addr1[0], rb0n = s_cur ? b_addr[0] : b_addr1[0];
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      constexpr bool FIRST = FIRST0;
+@KT_A@
+    }
+    {
+      constexpr bool FIRST = false;
+@KT_B@
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+#else
   // phase 1: k-step 0 of the current K-tile from registers; fetch its k-step 1 fragments; finish
   // the LDS-DMA list phase 2 of the previous iteration started (`pend`)
   auto phase1 = [&](auto first_c, auto stage_c, auto pend_c) {
@@ -164,6 +225,7 @@ void gemm_nt_w4_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
 @PHASE2@
     __builtin_amdgcn_sched_barrier(0);
   };
+#endif
 
   // ---- prologue: K-tiles 0 and 1 into stages 0 and 1
   set_load_tile(0);
@@ -201,6 +263,12 @@ void gemm_nt_w4_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
         load_bias4<EPI>(ep, btn * BN + wn * 128, lane, bias_lo);
         load_bias4<EPI>(ep, btn * BN + wn * 128 + 64, lane, bias_hi);
       }
+#if M3P_W4_SCHED2
+      ktile(std::true_type{}, stage_c);
+    } else {
+      ktile(std::false_type{}, stage_c);
+    }
+#else
       if (step == 0) phase1(std::true_type{}, stage_c, std::false_type{});
       else phase1(std::true_type{}, stage_c, std::true_type{});
     } else {
@@ -219,6 +287,7 @@ void gemm_nt_w4_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
     W4_TSEG(0);
     W4_LGKM0();
     W4_TSEG(1);
+#endif
     if (++c_kt == nk) {
       // ---- epilogue of output tile c_q out of the wave-private staging area
       c_kt = 0;
@@ -297,7 +366,7 @@ void gemm_nt_w4_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
           for (int j = 0; j < 4; ++j) csum[j] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
       }
-      W4_TSEG(4);
+      W4_TSEG(M3P_W4_SCHED2 ? 6 : 4);
     }
   };
   for (int step = 0; step < total; step += 2) {
@@ -306,17 +375,22 @@ void gemm_nt_w4_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // junk loads of the tail must not outlive the LDS allocation
   if (TL) {
-    W4_TSEG(6);
+    W4_TSEG(M3P_W4_SCHED2 ? 7 : 6);
     if (lane == 0)
       for (int k = 0; k < 8; ++k) dbg[((size_t)blockIdx.x * 8 + wid) * 8 + k] = tacc[k];
   }
 #undef W4_TSEG
 #undef W4_LD1
+#undef W4_LDB
 #undef W4_ACC
 #undef W4_DSR
 #undef W4_LGKM0
 #undef W4_M
 #undef W4_L
 #undef W4_LP
+#undef W4_WAIT_LGKM
+#undef W4_WAIT_VM
+#undef W4_BAR
+#undef W4_LD
 }
 

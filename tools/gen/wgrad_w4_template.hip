@@ -108,17 +108,57 @@ void gemm_wgrad_w4_kernel(const bf16* __restrict__ dY_a, int lddy_a, const bf16*
   }
   const bf16* y_base;
   const bf16* x_base;
+#ifndef M3P_WG_BUFDMA
+#define M3P_WG_BUFDMA 1
+#endif
+  // M3P_WG_BUFDMA: the transfers as buffer_load_dwordx4 ... lds - resource = the K-tile's base, scalar offset = the piece's
+  // rows, a 32-bit lane offset (four per operand: the swizzle of a row depends on the piece's parity and half) - instead of
+  // global_load_lds_dwordx4 with a 64-bit lane address per piece.  In the NT kernel the buffer form costs the issuing wave
+  // ~16 clocks a piece where the global form costs ~37 (tools/gemm_timeline.py).  The buffer form's immediate is unsigned
+  // 12-bit: pieces 0-3 and 4-7 of an operand get an M0 each.
+  __amdgpu_buffer_rsrc_t y_rsrc, x_rsrc;
+  uint32_t y_voff[4], x_voff[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int f = ((2 * (k & 1) + l_hi) & 3) | ((k >> 1) << 2);        // pieces p with (p & 1, p >= 4) = (k & 1, k >> 1)
+    const int gc = l_pos ^ (f << 1);
+    y_voff[k] = (uint32_t)(l_hi * lddy + gc * 8) * 2u;
+    x_voff[k] = (uint32_t)(l_hi * ldx + gc * 8) * 2u;
+    if (YROWS) y_voff[k] = (uint32_t)((lane >> 3) * lddy + (((lane & 7) ^ (lane >> 3)) * 8)) * 2u;
+  }
+  auto set_rsrc = [&]() {
+    if (M3P_WG_BUFDMA) {
+      y_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(uniform_ptr(y_base)), 0, 0xffffffff, 0x00020000);
+      x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(uniform_ptr(x_base)), 0, 0xffffffff, 0x00020000);
+    }
+  };
   auto set_load_ktile = [&]() {
     const int ti = lc.t / tiles_j, tj = lc.t - ti * tiles_j;
     const size_t mbase = (size_t)(seg_m0 + lc.mt) * KT;
     y_base = YROWS ? dY + (size_t)(ti * TI) * lddy + mbase : dY + mbase * lddy + ti * TI;
     x_base = X + mbase * ldx + tj * TJ;
+    set_rsrc();
   };
   set_load_ktile();
   // (written as instructions in the scalar-base form - SGPR pair + 32-bit lane offset, no 64-bit vector add per piece - the
-  //  loads measured the same, 6.88 against 6.80 ms: the adds fit the free issue slots between two MFMAs.  The builtin stays.)
+  //  global loads measured the same, 6.88 against 6.80 ms: the adds fit the free issue slots between two MFMAs.)
 #define WG_LD1(PTR, IMM) __builtin_amdgcn_global_load_lds(GLB_PTR(PTR), LDS_PTR(sl), 16, IMM, 0)
+#define WG_LDB(IMM) __builtin_amdgcn_raw_ptr_buffer_load_lds(piece < 8 ? y_rsrc : x_rsrc, LDS_PTR(sl), 16, voff, soff, IMM, 0)
   auto issue_load = [&](int s, int piece) {
+    if (M3P_WG_BUFDMA) {
+      const int pc = piece & 7, k = (pc & 1) + 2 * (pc >> 2);
+      char* sl = smem + s * STAGE + (piece < 8 ? 0 : Y_BYTES) + wid * 8192 + (pc >> 2) * 4096;
+      const uint32_t voff = piece < 8 ? y_voff[YROWS ? 0 : k] : x_voff[k];
+      const uint32_t rows = (piece < 8 && YROWS) ? (uint32_t)(wid * 64 + 8 * pc) : (uint32_t)(wid * 16 + 2 * pc);
+      const uint32_t soff = __builtin_amdgcn_readfirstlane(rows * (uint32_t)((piece < 8 ? lddy : ldx) * 2) - (uint32_t)(pc & 3) * 1024u);
+      switch (pc & 3) {
+        case 0: WG_LDB(0); break;
+        case 1: WG_LDB(1024); break;
+        case 2: WG_LDB(2048); break;
+        default: WG_LDB(3072); break;
+      }
+      return;
+    }
     char* sl = smem + s * STAGE + (piece < 8 ? 0 : Y_BYTES) + wid * 8192 + 4096;
     const bf16* src = (piece < 8) ? y_base + y_off[piece & 7] : x_base + x_off[piece & 7];
     switch (piece & 7) {
@@ -143,9 +183,10 @@ void gemm_wgrad_w4_kernel(const bf16* __restrict__ dY_a, int lddy_a, const bf16*
       const bool more = ++l_issued < total;
       y_base += more ? y_step : 0;
       x_base += more ? x_step : 0;
+      set_rsrc();
     } else if (++l_issued < total) {
       if (++lc.mt == lc.len) { lc.mt = 0; lc.t += nwg; set_load_ktile(); }
-      else { y_base += y_step; x_base += x_step; }
+      else { y_base += y_step; x_base += x_step; set_rsrc(); }
     }
   };
 
@@ -231,6 +272,34 @@ void gemm_wgrad_w4_kernel(const bf16* __restrict__ dY_a, int lddy_a, const bf16*
     __builtin_amdgcn_sched_barrier(0);
   };
 
+#ifndef M3P_WG_SCHED2
+#define M3P_WG_SCHED2 1
+#endif
+#define WG_WAIT_LGKM(N) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(" #N ")" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define WG_WAIT_VM(N) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define WG_BAR() do { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define WG_LD() do { load_done(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define WG_SET1() do { _Pragma("unroll") for (int c = 0; c < 8; ++c) { yf1[c] = yfrag(c); xf1[c] = frag(xl[c], xh[c]); } __builtin_amdgcn_sched_barrier(0); } while (0)
+#define WG_SET0() do { _Pragma("unroll") for (int c = 0; c < 8; ++c) { yf0[c] = yfrag(c); xf0[c] = frag(xl[c], xh[c]); } __builtin_amdgcn_sched_barrier(0); } while (0)
+  // M3P_WG_SCHED2: the K-tile in one piece, as in gemm_nt_w4_kernel - the first operand's region of the stage is released by
+  // a barrier as soon as its k-step-1 fragments are in registers (MFMA 20), the second's at MFMA 50, the next K-tile is waited
+  // for at MFMA 107 (vmcnt(16): this K-tile's own sixteen transfers stay in flight): a transfer has 1.2-1.7 K-tiles to land
+  // where the two-phase form gives the last five of a K-tile 46 MFMAs and waits ~200-270 clocks per K-tile at its vmcnt(0).
+  auto wktile = [&](auto first_c, auto stage_c) {
+    constexpr bool FIRST0 = decltype(first_c)::value;
+    constexpr int s_cur = decltype(stage_c)::value;
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      constexpr bool FIRST = FIRST0;
+@WKT_A@
+    }
+    {
+      constexpr bool FIRST = false;
+@WKT_B@
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
   // ---- prologue: K-tiles 0 and 1 of the stream into stages 0 and 1
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
@@ -263,6 +332,11 @@ void gemm_wgrad_w4_kernel(const bf16* __restrict__ dY_a, int lddy_a, const bf16*
 #define WG_TSEG(k) do { } while (0)
 #endif
   auto kstep = [&](auto stage_c, int step) {
+#if M3P_WG_SCHED2
+    if (first) wktile(std::true_type{}, stage_c);
+    else wktile(std::false_type{}, stage_c);
+    first = false;
+#else
     WG_TSEG(6);
     if (step == 0) phase1(std::true_type{}, stage_c, std::false_type{});
     else if (first) phase1(std::true_type{}, stage_c, std::true_type{});
@@ -287,6 +361,8 @@ void gemm_wgrad_w4_kernel(const bf16* __restrict__ dY_a, int lddy_a, const bf16*
 #endif
 #pragma unroll
     for (int c = 0; c < 8; ++c) { yf0[c] = yfrag(c); xf0[c] = frag(xl[c], xh[c]); }
+
+#endif
 
     const bool last_of_tile = (cc.mt + 1 == cc.len) || (step + 1 == total);
     if (last_of_tile) {
@@ -386,6 +462,7 @@ void gemm_wgrad_w4_kernel(const bf16* __restrict__ dY_a, int lddy_a, const bf16*
 #endif
 #undef WG_TSEG
 #undef WG_LD1
+#undef WG_LDB
 #undef WG_TR2
 #undef WG_YRD
 #undef WG_LGKM0
