@@ -1052,12 +1052,20 @@ void gemm_nt_w8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
   // share one M0: the destination is picked by the instruction's immediate offset (-2048 .. +1024), which moves the global
   // source by the same bytes - compensated in the source pointer (tools/probe_dma_offset.py; the four-wave kernels do the
   // same).  Per LDS-DMA that saves the M0 write and its hazard nop (probe_issue.py: ~32 of the ~70 ticks a piece costs).
+#ifndef M3P_W8_BUFDMA
+#define M3P_W8_BUFDMA 1     // the transfers as buffer_load_dwordx4 ... lds (resource = the wave's slice of the operand tile, scalar offset = K-tile + piece)
+#endif
+  __amdgpu_buffer_rsrc_t a_rsrc, w_rsrc;
   auto set_load_tile = [&](int t) {
     int tm, tn;
     split_tile(t, tm, tn);
     if (M3P_W8_IMM) {       // (uniform: the lane's part is a_lane / w_lane)
       a_src = A + (size_t)(tm * BM + wid * 32) * lda;
       w_src = W + (size_t)(tn * BN + wid * 32) * ldw;
+      if (M3P_W8_BUFDMA) {
+        a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(uniform_ptr(a_src)), 0, 0xffffffff, 0x00020000);
+        w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(uniform_ptr(w_src)), 0, 0xffffffff, 0x00020000);
+      }
     } else {
       a_src = A + (size_t)(tm * BM + wid * 8 + sr) * lda + sc * 8;
       w_src = W + (size_t)(tn * BN + wid * 8 + sr) * ldw + sc * 8;
@@ -1069,6 +1077,20 @@ void gemm_nt_w8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
   auto issue_load = [&](int s, int piece) {
     char* sa = smem + s * STAGE;
     const int k0 = l_kt * BK;
+    if (M3P_W8_IMM && M3P_W8_BUFDMA) {
+      const int pc = piece & 3;
+      char* base = sa + (piece < 4 ? 0 : A_BYTES) + wid * 4096;
+      const uint32_t soff = __builtin_amdgcn_readfirstlane((uint32_t)k0 * 2u + (uint32_t)pc * (uint32_t)((piece < 4 ? lda : ldw) * 16) - (uint32_t)pc * 1024u);
+#define W8_LDB(IMM) __builtin_amdgcn_raw_ptr_buffer_load_lds(piece < 4 ? a_rsrc : w_rsrc, LDS_PTR(base), 16, piece < 4 ? a_lane : w_lane, soff, IMM, 0)
+      switch (pc) {
+        case 0: W8_LDB(0); break;
+        case 1: W8_LDB(1024); break;
+        case 2: W8_LDB(2048); break;
+        default: W8_LDB(3072); break;
+      }
+#undef W8_LDB
+      return;
+    }
     if (M3P_W8_IMM) {
       const int pc = piece & 3;
       char* base = sa + (piece < 4 ? 0 : A_BYTES) + wid * 4096 + 2048;
