@@ -262,6 +262,21 @@ __device__ __forceinline__ V4 flip_halves(const V4& t, bool flip) {
   return flip ? V4{t[2], t[3], t[0], t[1]} : t;
 }
 
+// LDS accesses the compiler does not see (ALDS = true in the epilogue helpers below).  Why: a kernel whose K loop keeps
+// buffer_load ... lds transfers in flight makes the compiler put s_waitcnt vmcnt(0) in front of EVERY LDS access it knows of
+// (the transfer might alias it) - and vmcnt(0) also waits for the previous piece's global stores, a full memory round trip
+// per staged piece.  The staging buffers never alias the stages; with these the waits are ours (lgkm_wait ties the wait to
+// the values it is for, so that their uses cannot be scheduled in front of it).
+typedef unsigned int u32x4_lds __attribute__((ext_vector_type(4)));
+#ifndef M3P_EPI_ALDS
+#define M3P_EPI_ALDS 0       // 1: the eight-wave kernel's epilogues stage through these too.  Measured neutral there (two waves per
+#endif                       // SIMD: the partner wave runs under the vmcnt(0)) - QKV 150 / 150 us, lin1 + GELU + byte 246 / 243, byte dgrad 214 / 216
+__device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p; }
+__device__ __forceinline__ void lds_w64(uint32_t a, const bf16x4& v) { asm volatile("ds_write_b64 %0, %1" :: "v"(a), "v"(v)); }
+__device__ __forceinline__ void lds_w128(uint32_t a, const u32x4_lds& v) { asm volatile("ds_write_b128 %0, %1" :: "v"(a), "v"(v)); }
+__device__ __forceinline__ void lds_r64(uint32_t a, bf16x4& v) { asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(a)); }
+__device__ __forceinline__ void lds_r128(uint32_t a, u32x4_lds& v) { asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(a)); }
+
 // gelu_erf'(u) of a bf16 u is a function of 16 bits: the dGELU epilogue looks it up instead of
 // evaluating erf/exp (~20 exposed VALU instructions per element).  The table covers |u| in
 // [2^-15, 8) (exponents -15..2 x 128 mantissas = 2304 fp32 entries, 9 KB of LDS), built from what
@@ -341,37 +356,47 @@ __device__ __forceinline__ void load_aux_rows_issue(const M3PEpilogue& ep, int m
 #endif
   }
 }
-template <int EPI, bool SW = false>
+template <int EPI, bool SW = false, bool ALDS = false>
 __device__ __forceinline__ void load_aux_rows_finish(int lane, char* r1, const u32x4 (&t)[4], bf16x4 (&auxv)[2][4]) {
   constexpr bool kAux = (EPI == M3P_EPI_BIAS_DROP_RES || EPI == M3P_EPI_RES || EPI == M3P_EPI_DGELU || EPI == M3P_EPI_MUL);
   if (!kAux) return;
   const int srow = lane >> 3, sch = lane & 7;
+  const int fr = lane & 15, fg = lane >> 4;
+  if (ALDS) {
+    const uint32_t la = lds_addr(r1);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) lds_w128(la + ep_off<SW>(it * 8 + srow, sch * 16), flip_halves(t[it], SW && (it & 1)));
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) lds_r64(la + ep_off8<SW>(ii * 16 + fr, (j * 16 + fg * 4) * 2), auxv[ii][j]);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(auxv[0][0]), "+v"(auxv[0][1]), "+v"(auxv[0][2]), "+v"(auxv[0][3]),
+                                         "+v"(auxv[1][0]), "+v"(auxv[1][1]), "+v"(auxv[1][2]), "+v"(auxv[1][3]));
+    return;
+  }
 #pragma unroll
   for (int it = 0; it < 4; ++it) *reinterpret_cast<u32x4*>(r1 + ep_off<SW>(it * 8 + srow, sch * 16)) = flip_halves(t[it], SW && (it & 1));
-  const int fr = lane & 15, fg = lane >> 4;
 #pragma unroll
   for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       auxv[ii][j] = *reinterpret_cast<const bf16x4*>(r1 + ep_off8<SW>(ii * 16 + fr, (j * 16 + fg * 4) * 2));
 }
-template <int EPI, bool SW = false>
+template <int EPI, bool SW = false, bool ALDS = false>
 __device__ __forceinline__ void load_aux_rows(const M3PEpilogue& ep, int mrow0, int nw, int lane, char* r1, bf16x4 (&auxv)[2][4]) {
   u32x4 t[4];
   load_aux_rows_issue<EPI>(ep, mrow0, nw, lane, t);
-  load_aux_rows_finish<EPI, SW>(lane, r1, t, auxv);
+  load_aux_rows_finish<EPI, SW, ALDS>(lane, r1, t, auxv);
 }
 
-template <int EPI, bool SW = false>
-__device__ __forceinline__ void epilogue_half(const M3PEpilogue& ep, bf16* __restrict__ C, int ldc, int N,
-                                              int mrow0, int nw, char* r1, const f32x4 (&rows)[2][4],
-                                              const f32x4 (&biasv)[4], const bf16x4 (&auxv)[2][4], int lane, f32x4 (&csum)[4],
-                                              const float* gtab = nullptr) {
+// epilogue_half in two parts: the arithmetic on a 32 x 64 piece and its staging writes (accumulator layout -> r1) ...
+template <int EPI, bool SW = false, bool ALDS = false>
+__device__ __forceinline__ void epilogue_half_write(const M3PEpilogue& ep, int N, int mrow0, int nw, char* r1, const f32x4 (&rows)[2][4],
+                                                    const f32x4 (&biasv)[4], const bf16x4 (&auxv)[2][4], int lane, f32x4 (&csum)[4],
+                                                    bf16x4 (&ukeep)[2][4], const float* gtab = nullptr) {
   const int fr = lane & 15, fg = lane >> 4;
-  const int srow = lane >> 3, sch = lane & 7;
   constexpr bool kAux = (EPI == M3P_EPI_BIAS_DROP_RES || EPI == M3P_EPI_RES || EPI == M3P_EPI_DGELU || EPI == M3P_EPI_MUL);
   const float alpha = (ep.alpha == 0.f) ? 1.f : ep.alpha;
-  bf16x4 ukeep[2][4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int n = nw + j * 16 + fg * 4;
@@ -423,9 +448,69 @@ __device__ __forceinline__ void epilogue_half(const M3PEpilogue& ep, bf16* __res
         }
       }
       const bf16x4 ob = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-      *reinterpret_cast<bf16x4*>(r1 + lo) = ob;
+      if (ALDS) lds_w64(lds_addr(r1) + lo, ob);
+      else *reinterpret_cast<bf16x4*>(r1 + lo) = ob;
       if (EPI == M3P_EPI_DGELU || EPI == M3P_EPI_MUL) csum[j] += f32x4{(float)ob[0], (float)ob[1], (float)ob[2], (float)ob[3]};
     }
+  }
+}
+// ... the staged piece read back as rows (16 bytes per lane, 8 lanes per 128-byte row segment) ...
+template <bool SW, bool ALDS = false>
+__device__ __forceinline__ void epilogue_rows_read(const char* r1, int lane, u32x4 (&R)[4]) {
+  const int srow = lane >> 3, sch = lane & 7;
+  if (ALDS) {      // (issued only: the caller waits - lgkm_wait_rows - and flips the halves of rows 8-15, 24-31 then)
+    const uint32_t la = lds_addr(r1);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) lds_r128(la + ep_off<SW>(it * 8 + srow, sch * 16), R[it]);
+    return;
+  }
+#pragma unroll
+  for (int it = 0; it < 4; ++it) R[it] = flip_halves(*reinterpret_cast<const u32x4*>(r1 + ep_off<SW>(it * 8 + srow, sch * 16)), SW && (it & 1));
+}
+// (16-row pieces: two row instructions)  read + wait + store in one go, asm accesses
+__device__ __forceinline__ void epilogue_rows16_flush_alds(bf16* __restrict__ C, int ldc, int mrow0, int nw, const char* r1, int lane) {
+  const int srow = lane >> 3, sch = lane & 7;
+  const uint32_t la = lds_addr(r1);
+  u32x4 R[2];
+  lds_r128(la + ep_off<true>(srow, sch * 16), R[0]);
+  lds_r128(la + ep_off<true>(8 + srow, sch * 16), R[1]);
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(R[0]), "+v"(R[1]));
+  bf16* Cp = C + (size_t)mrow0 * ldc + nw + sch * 8;
+  *reinterpret_cast<u32x4*>(Cp + (size_t)srow * ldc) = R[0];
+  *reinterpret_cast<u32x4*>(Cp + (size_t)(8 + srow) * ldc) = flip_halves(R[1], true);
+}
+// the wait that belongs to epilogue_rows_read<SW, true>: `younger` (8 or 0) LDS instructions of this wave may stay in flight
+template <bool SW>
+__device__ __forceinline__ void lgkm_wait_rows(u32x4 (&R)[4], bool younger8) {
+  if (younger8) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(R[0]), "+v"(R[1]), "+v"(R[2]), "+v"(R[3]));
+  else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(R[0]), "+v"(R[1]), "+v"(R[2]), "+v"(R[3]));
+#pragma unroll
+  for (int it = 0; it < 4; ++it) R[it] = flip_halves(R[it], SW && (it & 1));
+}
+// ... and stored.  (Apart so that a kernel with nobody else on its SIMD can keep a piece's LDS round trip in flight under
+// the next piece's accumulator reads and arithmetic: gemm_nt_w4_kernel.)
+__device__ __forceinline__ void epilogue_rows_store(bf16* __restrict__ C, int ldc, int mrow0, int nw, int lane, const u32x4 (&R)[4]) {
+  const int srow = lane >> 3, sch = lane & 7;
+  bf16* Cp = C + (size_t)mrow0 * ldc + nw + sch * 8;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) *reinterpret_cast<u32x4*>(Cp + (size_t)(it * 8 + srow) * ldc) = R[it];
+}
+template <int EPI, bool SW = false, bool ALDS = false>
+__device__ __forceinline__ void epilogue_half(const M3PEpilogue& ep, bf16* __restrict__ C, int ldc, int N,
+                                              int mrow0, int nw, char* r1, const f32x4 (&rows)[2][4],
+                                              const f32x4 (&biasv)[4], const bf16x4 (&auxv)[2][4], int lane, f32x4 (&csum)[4],
+                                              const float* gtab = nullptr) {
+  const int fr = lane & 15, fg = lane >> 4;
+  const int srow = lane >> 3, sch = lane & 7;
+  bf16x4 ukeep[2][4];
+  constexpr bool kA = ALDS && EPI != M3P_EPI_BIAS_GELU;      // (the two-output epilogue keeps plain accesses: not on the hot path)
+  epilogue_half_write<EPI, SW, kA>(ep, N, mrow0, nw, r1, rows, biasv, auxv, lane, csum, ukeep, gtab);
+  if (kA) {
+    u32x4 R[4];
+    epilogue_rows_read<SW, true>(r1, lane, R);
+    lgkm_wait_rows<SW>(R, false);
+    epilogue_rows_store(C, ldc, mrow0, nw, lane, R);
+    return;
   }
   bf16* Cp = C + (size_t)mrow0 * ldc + nw + sch * 8;
 #pragma unroll
@@ -539,9 +624,11 @@ __device__ __forceinline__ void epilogue_pieceq(bf16* __restrict__ C, int ldc, i
     g = g * GQ_STEP - GQ_OFF;
     const f32x4 v = rows[j] * g;
     const bf16x4 ob = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-    *reinterpret_cast<bf16x4*>(r1 + ep_off8<true>(fr, (j * 16 + fg * 4) * 2)) = ob;
+    if (M3P_EPI_ALDS) lds_w64(lds_addr(r1) + ep_off8<true>(fr, (j * 16 + fg * 4) * 2), ob);
+    else *reinterpret_cast<bf16x4*>(r1 + ep_off8<true>(fr, (j * 16 + fg * 4) * 2)) = ob;
     csum[j] += f32x4{(float)ob[0], (float)ob[1], (float)ob[2], (float)ob[3]};
   }
+  if (M3P_EPI_ALDS) { epilogue_rows16_flush_alds(C, ldc, mrow0, nw, r1, lane); return; }
   bf16* Cp = C + (size_t)mrow0 * ldc + nw + sch * 8;
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
@@ -567,7 +654,8 @@ __device__ __forceinline__ void epilogue_half_lse(bf16* __restrict__ C, int ldc,
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       x[j] = (ii ? rows1[j] : rows0[j]) + biasv[j];
-      *reinterpret_cast<bf16x4*>(r1 + ep_off8<true>(ii * 16 + fr, (j * 16 + fg * 4) * 2)) = bf16x4{(bf16)x[j][0], (bf16)x[j][1], (bf16)x[j][2], (bf16)x[j][3]};
+      if (M3P_EPI_ALDS) lds_w64(lds_addr(r1) + ep_off8<true>(ii * 16 + fr, (j * 16 + fg * 4) * 2), bf16x4{(bf16)x[j][0], (bf16)x[j][1], (bf16)x[j][2], (bf16)x[j][3]});
+      else *reinterpret_cast<bf16x4*>(r1 + ep_off8<true>(ii * 16 + fr, (j * 16 + fg * 4) * 2)) = bf16x4{(bf16)x[j][0], (bf16)x[j][1], (bf16)x[j][2], (bf16)x[j][3]};
     }
     if (edge) {        // (wave-uniform: only the last column tile holds columns >= V)
 #pragma unroll
@@ -596,6 +684,13 @@ __device__ __forceinline__ void epilogue_half_lse(bf16* __restrict__ C, int ldc,
     sm += __shfl_xor(sm, 16, 64);
     sm += __shfl_xor(sm, 32, 64);
     if (fg == 0) stats[mrow0 + ii * 16 + fr] = float2{m, sm};
+  }
+  if (M3P_EPI_ALDS) {
+    u32x4 R[4];
+    epilogue_rows_read<true, true>(r1, lane, R);
+    lgkm_wait_rows<true>(R, false);
+    epilogue_rows_store(C, ldc, mrow0, nw, lane, R);
+    return;
   }
   bf16* Cp = C + (size_t)mrow0 * ldc + nw + sch * 8;
 #pragma unroll
@@ -668,9 +763,17 @@ __device__ __forceinline__ void epilogue_half_geluq(bf16* __restrict__ C, int ld
       const f32x4 qf = gd * GQ_INV + (GQ_OFF * GQ_INV + 0.5f);                 // in [0.7, 255.3): truncation = round to nearest
       code[j] = (uint32_t)qf[0] | ((uint32_t)qf[1] << 8) | ((uint32_t)qf[2] << 16) | ((uint32_t)qf[3] << 24);
 #endif
-      *reinterpret_cast<bf16x4*>(r1 + ep_off8<true>(ii * 16 + fr, (j * 16 + fg * 4) * 2)) = bf16x4{(bf16)hv[0], (bf16)hv[1], (bf16)hv[2], (bf16)hv[3]};
+      if (M3P_EPI_ALDS) lds_w64(lds_addr(r1) + ep_off8<true>(ii * 16 + fr, (j * 16 + fg * 4) * 2), bf16x4{(bf16)hv[0], (bf16)hv[1], (bf16)hv[2], (bf16)hv[3]});
+      else *reinterpret_cast<bf16x4*>(r1 + ep_off8<true>(ii * 16 + fr, (j * 16 + fg * 4) * 2)) = bf16x4{(bf16)hv[0], (bf16)hv[1], (bf16)hv[2], (bf16)hv[3]};
     }
     *reinterpret_cast<u32x4*>(qout + ii * 1024 + lane * 16) = code;
+  }
+  if (M3P_EPI_ALDS) {
+    u32x4 R[4];
+    epilogue_rows_read<true, true>(r1, lane, R);
+    lgkm_wait_rows<true>(R, false);
+    epilogue_rows_store(C, ldc, mrow0, nw, lane, R);
+    return;
   }
   bf16* Cp = C + (size_t)mrow0 * ldc + nw + sch * 8;
 #pragma unroll
@@ -1448,13 +1551,14 @@ void gemm_nt_w8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
 #pragma unroll
             for (int j = 0; j < 4; ++j) rows[ii][j] = acc[2 * hf + ii][j];
           bf16x4 auxv[2][4];
-          if (kSpare && kAuxE && hf == 0) load_aux_rows_finish<EPI, kSpare>(lane, r1, aux0, auxv);
-          else load_aux_rows<EPI, kSpare>(ep, mw + 32 * hf, nw, lane, r1, auxv);
+          constexpr bool kAlds = M3P_EPI_ALDS && kSpare;      // (staging accesses the compiler does not see: no vmcnt(0) per piece)
+          if (kSpare && kAuxE && hf == 0) load_aux_rows_finish<EPI, kSpare, kAlds>(lane, r1, aux0, auxv);
+          else load_aux_rows<EPI, kSpare, kAlds>(ep, mw + 32 * hf, nw, lane, r1, auxv);
 #ifdef M3P_W8_TL
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           W8_TSEG(1);
 #endif
-          epilogue_half<EPI, kSpare>(ep, C, ldc, N, mw + 32 * hf, nw, r1, rows, biasv, auxv, lane, csum, gtab);
+          epilogue_half<EPI, kSpare, kAlds>(ep, C, ldc, N, mw + 32 * hf, nw, r1, rows, biasv, auxv, lane, csum, gtab);
           W8_TSEG(2);
           __builtin_amdgcn_sched_barrier(0);      // one piece at a time: hoisted loads of the next piece cost registers
         }
@@ -2526,7 +2630,7 @@ void gemm_nt_w4_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
                           (!(EPI == M3P_EPI_BIAS_GELU) || (((ep.ld_out2 & 7) == 0) && (((uintptr_t)ep.out2 & 15) == 0))) &&
                           (!ep.bias || (((uintptr_t)ep.bias & 15) == 0)) &&
                           (!ep.aux || (((ep.ld_aux & 7) == 0) && (((uintptr_t)ep.aux & 15) == 0)));
-  char* r1 = smem + 2 * STAGE + wid * EP_HALF;
+  char* r1 = smem + 2 * STAGE + wid * 8192;      // (8 KB per wave: two swizzled 4-KB buffers for the pipelined epilogues, or one padded 4.5-KB one)
   f32x4 bias_lo[4], bias_hi[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) bias_lo[j] = bias_hi[j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -2580,6 +2684,58 @@ void gemm_nt_w4_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
       f32x4 csum[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) csum[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#define W4_RD(II, JJ, I, J)                                                         \
+  asm volatile("v_accvgpr_read_b32 %0, a[((" #I ")*8+(" #J "))*4+0]\n\t"            \
+               "v_accvgpr_read_b32 %1, a[((" #I ")*8+(" #J "))*4+1]\n\t"            \
+               "v_accvgpr_read_b32 %2, a[((" #I ")*8+(" #J "))*4+2]\n\t"            \
+               "v_accvgpr_read_b32 %3, a[((" #I ")*8+(" #J "))*4+3]"                \
+               : "=v"(t0), "=v"(t1), "=v"(t2), "=v"(t3));                           \
+  rows[II][JJ] = f32x4{t0, t1, t2, t3}
+#define W4_SLICE(RG, CH)                                                                      \
+  W4_RD(0, 0, 2 * RG, 4 * CH); W4_RD(0, 1, 2 * RG, 4 * CH + 1); W4_RD(0, 2, 2 * RG, 4 * CH + 2); W4_RD(0, 3, 2 * RG, 4 * CH + 3); \
+  W4_RD(1, 0, 2 * RG + 1, 4 * CH); W4_RD(1, 1, 2 * RG + 1, 4 * CH + 1); W4_RD(1, 2, 2 * RG + 1, 4 * CH + 2); W4_RD(1, 3, 2 * RG + 1, 4 * CH + 3)
+#ifndef M3P_W4_PIPE_EPI
+#define M3P_W4_PIPE_EPI 1
+#endif
+      // The plain epilogues with LDS accesses the compiler does not see (see lds_w64 ...): with transfers for the next output
+      // tile in flight it puts s_waitcnt vmcnt(0) in front of every staging access it knows of, i.e. every piece waits for the
+      // previous piece's global stores (~1150 clocks a piece, 9.2 k per output tile, a fifth of a K = 768 launch -
+      // tools/gemm_timeline.py).  Two swizzled 4-KB buffers per wave, alternating: with the two stages the whole 160 KB of the CU.
+      constexpr bool kPipe = M3P_W4_PIPE_EPI && (EPI == M3P_EPI_NONE || EPI == M3P_EPI_BIAS || EPI == M3P_EPI_RES || EPI == M3P_EPI_BIAS_DROP_RES);
+      if (kPipe && fast) {
+        char* rb = smem + 2 * STAGE + wid * 8192;
+        u32x4 tq[4];
+        load_aux_rows_issue<EPI>(ep, mw, nw, lane, tq);
+#pragma nounroll
+        for (int p = 0; p < 8; ++p) {
+          const int ch = p >> 2, rg = p & 3;
+          f32x4 rows[2][4];
+          float t0, t1, t2, t3;
+          switch (p) {
+            case 0: W4_SLICE(0, 0); break;
+            case 1: W4_SLICE(1, 0); break;
+            case 2: W4_SLICE(2, 0); break;
+            case 3: W4_SLICE(3, 0); break;
+            case 4: W4_SLICE(0, 1); break;
+            case 5: W4_SLICE(1, 1); break;
+            case 6: W4_SLICE(2, 1); break;
+            default: W4_SLICE(3, 1); break;
+          }
+          char* rc = rb + (p & 1) * 4096;
+          bf16x4 aux_cur[2][4];
+          load_aux_rows_finish<EPI, true, true>(lane, rc, tq, aux_cur);
+          if (p + 1 < 8) load_aux_rows_issue<EPI>(ep, mw + 32 * ((p + 1) & 3), nw + 64 * ((p + 1) >> 2), lane, tq);
+          bf16x4 ukeep[2][4];
+          epilogue_half_write<EPI, true, true>(ep, N, mw + 32 * rg, nw + 64 * ch, rc, rows, ch ? bias_hi : bias_lo, aux_cur, lane, csum, ukeep);
+          // (read back at once: straight-line code between the asm reads and their wait, so that no compiler-made copy of the
+          //  destination registers can slip in between; what the asm accesses buy is the absence of vmcnt(0) - the stores of
+          //  piece p are in flight under piece p + 1)
+          u32x4 R[4];
+          epilogue_rows_read<true, true>(rc, lane, R);
+          lgkm_wait_rows<true>(R, false);
+          epilogue_rows_store(C, ldc, mw + 32 * rg, nw + 64 * ch, lane, R);
+        }
+      } else
 #pragma nounroll
       for (int p = 0; p < 8; ++p) {
         const int ch = p >> 2, rg = p & 3;        // column half outer: the bias-gradient sums run over rows
@@ -2593,16 +2749,6 @@ void gemm_nt_w4_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
           else load_aux_rows<EPI>(ep, mw + 32 * rg, nw + 64 * ch, lane, r1, aux_cur);
         }
         f32x4 rows[2][4];
-#define W4_RD(II, JJ, I, J)                                                         \
-  asm volatile("v_accvgpr_read_b32 %0, a[((" #I ")*8+(" #J "))*4+0]\n\t"            \
-               "v_accvgpr_read_b32 %1, a[((" #I ")*8+(" #J "))*4+1]\n\t"            \
-               "v_accvgpr_read_b32 %2, a[((" #I ")*8+(" #J "))*4+2]\n\t"            \
-               "v_accvgpr_read_b32 %3, a[((" #I ")*8+(" #J "))*4+3]"                \
-               : "=v"(t0), "=v"(t1), "=v"(t2), "=v"(t3));                           \
-  rows[II][JJ] = f32x4{t0, t1, t2, t3}
-#define W4_SLICE(RG, CH)                                                                      \
-  W4_RD(0, 0, 2 * RG, 4 * CH); W4_RD(0, 1, 2 * RG, 4 * CH + 1); W4_RD(0, 2, 2 * RG, 4 * CH + 2); W4_RD(0, 3, 2 * RG, 4 * CH + 3); \
-  W4_RD(1, 0, 2 * RG + 1, 4 * CH); W4_RD(1, 1, 2 * RG + 1, 4 * CH + 1); W4_RD(1, 2, 2 * RG + 1, 4 * CH + 2); W4_RD(1, 3, 2 * RG + 1, 4 * CH + 3)
         float t0, t1, t2, t3;
         switch (p) {
           case 0: W4_SLICE(0, 0); break;
@@ -2614,8 +2760,6 @@ void gemm_nt_w4_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
           case 6: W4_SLICE(2, 1); break;
           default: W4_SLICE(3, 1); break;
         }
-#undef W4_SLICE
-#undef W4_RD
         const int mrow0 = mw + 32 * rg, ncol0 = nw + 64 * ch;
         if (fast) {
           epilogue_half<EPI>(ep, C, ldc, N, mrow0, ncol0, r1, rows, ch ? bias_hi : bias_lo, aux_cur, lane, csum);
@@ -2643,6 +2787,8 @@ void gemm_nt_w4_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
           for (int j = 0; j < 4; ++j) csum[j] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
       }
+#undef W4_SLICE
+#undef W4_RD
       W4_TSEG(M3P_W4_SCHED2 ? 6 : 4);
     }
   };
@@ -2848,7 +2994,7 @@ int launch_nt(const bf16* A, int lda, const bf16* W, int ldw, bf16* C, int ldc, 
       (M % 256) == 0 && (N % 256) == 0) {
     constexpr int BM = 256, BN = 256;
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
-    const size_t lds = 2 * (BM + BN) * 128 + 4 * EP_HALF;
+    const size_t lds = 2 * (BM + BN) * 128 + 4 * 8192;      // the two stages + 8 KB of epilogue staging per wave: all 160 KB
     auto kern = gemm_nt_w4_kernel<EPI, false>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -4143,7 +4289,7 @@ __attribute__((visibility("default"))) int m3p_debug_gemm_timeline(const void* A
   if ((M % 256) || (N % 256) || (K % 64)) return M3P_EINVAL;
   M3PEpilogue ep = {};
   const int tm = M / 256, tn = N / 256;
-  const size_t lds4 = 2 * 512 * 128 + 4 * EP_HALF;
+  const size_t lds4 = 2 * 512 * 128 + 4 * 8192;
   auto k4 = gemm_nt_w4_kernel<M3P_EPI_NONE, true, 0>;
   if (g_ablate == 1) k4 = gemm_nt_w4_kernel<M3P_EPI_NONE, true, 1>;
   if (g_ablate == 2) k4 = gemm_nt_w4_kernel<M3P_EPI_NONE, true, 2>;

@@ -249,7 +249,7 @@ void gemm_nt_w4_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
                           (!(EPI == M3P_EPI_BIAS_GELU) || (((ep.ld_out2 & 7) == 0) && (((uintptr_t)ep.out2 & 15) == 0))) &&
                           (!ep.bias || (((uintptr_t)ep.bias & 15) == 0)) &&
                           (!ep.aux || (((ep.ld_aux & 7) == 0) && (((uintptr_t)ep.aux & 15) == 0)));
-  char* r1 = smem + 2 * STAGE + wid * EP_HALF;
+  char* r1 = smem + 2 * STAGE + wid * 8192;      // (8 KB per wave: two swizzled 4-KB buffers for the pipelined epilogues, or one padded 4.5-KB one)
   f32x4 bias_lo[4], bias_hi[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) bias_lo[j] = bias_hi[j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -303,6 +303,58 @@ void gemm_nt_w4_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
       f32x4 csum[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) csum[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#define W4_RD(II, JJ, I, J)                                                         \
+  asm volatile("v_accvgpr_read_b32 %0, a[((" #I ")*8+(" #J "))*4+0]\n\t"            \
+               "v_accvgpr_read_b32 %1, a[((" #I ")*8+(" #J "))*4+1]\n\t"            \
+               "v_accvgpr_read_b32 %2, a[((" #I ")*8+(" #J "))*4+2]\n\t"            \
+               "v_accvgpr_read_b32 %3, a[((" #I ")*8+(" #J "))*4+3]"                \
+               : "=v"(t0), "=v"(t1), "=v"(t2), "=v"(t3));                           \
+  rows[II][JJ] = f32x4{t0, t1, t2, t3}
+#define W4_SLICE(RG, CH)                                                                      \
+  W4_RD(0, 0, 2 * RG, 4 * CH); W4_RD(0, 1, 2 * RG, 4 * CH + 1); W4_RD(0, 2, 2 * RG, 4 * CH + 2); W4_RD(0, 3, 2 * RG, 4 * CH + 3); \
+  W4_RD(1, 0, 2 * RG + 1, 4 * CH); W4_RD(1, 1, 2 * RG + 1, 4 * CH + 1); W4_RD(1, 2, 2 * RG + 1, 4 * CH + 2); W4_RD(1, 3, 2 * RG + 1, 4 * CH + 3)
+#ifndef M3P_W4_PIPE_EPI
+#define M3P_W4_PIPE_EPI 1
+#endif
+      // The plain epilogues with LDS accesses the compiler does not see (see lds_w64 ...): with transfers for the next output
+      // tile in flight it puts s_waitcnt vmcnt(0) in front of every staging access it knows of, i.e. every piece waits for the
+      // previous piece's global stores (~1150 clocks a piece, 9.2 k per output tile, a fifth of a K = 768 launch -
+      // tools/gemm_timeline.py).  Two swizzled 4-KB buffers per wave, alternating: with the two stages the whole 160 KB of the CU.
+      constexpr bool kPipe = M3P_W4_PIPE_EPI && (EPI == M3P_EPI_NONE || EPI == M3P_EPI_BIAS || EPI == M3P_EPI_RES || EPI == M3P_EPI_BIAS_DROP_RES);
+      if (kPipe && fast) {
+        char* rb = smem + 2 * STAGE + wid * 8192;
+        u32x4 tq[4];
+        load_aux_rows_issue<EPI>(ep, mw, nw, lane, tq);
+#pragma nounroll
+        for (int p = 0; p < 8; ++p) {
+          const int ch = p >> 2, rg = p & 3;
+          f32x4 rows[2][4];
+          float t0, t1, t2, t3;
+          switch (p) {
+            case 0: W4_SLICE(0, 0); break;
+            case 1: W4_SLICE(1, 0); break;
+            case 2: W4_SLICE(2, 0); break;
+            case 3: W4_SLICE(3, 0); break;
+            case 4: W4_SLICE(0, 1); break;
+            case 5: W4_SLICE(1, 1); break;
+            case 6: W4_SLICE(2, 1); break;
+            default: W4_SLICE(3, 1); break;
+          }
+          char* rc = rb + (p & 1) * 4096;
+          bf16x4 aux_cur[2][4];
+          load_aux_rows_finish<EPI, true, true>(lane, rc, tq, aux_cur);
+          if (p + 1 < 8) load_aux_rows_issue<EPI>(ep, mw + 32 * ((p + 1) & 3), nw + 64 * ((p + 1) >> 2), lane, tq);
+          bf16x4 ukeep[2][4];
+          epilogue_half_write<EPI, true, true>(ep, N, mw + 32 * rg, nw + 64 * ch, rc, rows, ch ? bias_hi : bias_lo, aux_cur, lane, csum, ukeep);
+          // (read back at once: straight-line code between the asm reads and their wait, so that no compiler-made copy of the
+          //  destination registers can slip in between; what the asm accesses buy is the absence of vmcnt(0) - the stores of
+          //  piece p are in flight under piece p + 1)
+          u32x4 R[4];
+          epilogue_rows_read<true, true>(rc, lane, R);
+          lgkm_wait_rows<true>(R, false);
+          epilogue_rows_store(C, ldc, mw + 32 * rg, nw + 64 * ch, lane, R);
+        }
+      } else
 #pragma nounroll
       for (int p = 0; p < 8; ++p) {
         const int ch = p >> 2, rg = p & 3;        // column half outer: the bias-gradient sums run over rows
@@ -316,16 +368,6 @@ void gemm_nt_w4_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
           else load_aux_rows<EPI>(ep, mw + 32 * rg, nw + 64 * ch, lane, r1, aux_cur);
         }
         f32x4 rows[2][4];
-#define W4_RD(II, JJ, I, J)                                                         \
-  asm volatile("v_accvgpr_read_b32 %0, a[((" #I ")*8+(" #J "))*4+0]\n\t"            \
-               "v_accvgpr_read_b32 %1, a[((" #I ")*8+(" #J "))*4+1]\n\t"            \
-               "v_accvgpr_read_b32 %2, a[((" #I ")*8+(" #J "))*4+2]\n\t"            \
-               "v_accvgpr_read_b32 %3, a[((" #I ")*8+(" #J "))*4+3]"                \
-               : "=v"(t0), "=v"(t1), "=v"(t2), "=v"(t3));                           \
-  rows[II][JJ] = f32x4{t0, t1, t2, t3}
-#define W4_SLICE(RG, CH)                                                                      \
-  W4_RD(0, 0, 2 * RG, 4 * CH); W4_RD(0, 1, 2 * RG, 4 * CH + 1); W4_RD(0, 2, 2 * RG, 4 * CH + 2); W4_RD(0, 3, 2 * RG, 4 * CH + 3); \
-  W4_RD(1, 0, 2 * RG + 1, 4 * CH); W4_RD(1, 1, 2 * RG + 1, 4 * CH + 1); W4_RD(1, 2, 2 * RG + 1, 4 * CH + 2); W4_RD(1, 3, 2 * RG + 1, 4 * CH + 3)
         float t0, t1, t2, t3;
         switch (p) {
           case 0: W4_SLICE(0, 0); break;
@@ -337,8 +379,6 @@ void gemm_nt_w4_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
           case 6: W4_SLICE(2, 1); break;
           default: W4_SLICE(3, 1); break;
         }
-#undef W4_SLICE
-#undef W4_RD
         const int mrow0 = mw + 32 * rg, ncol0 = nw + 64 * ch;
         if (fast) {
           epilogue_half<EPI>(ep, C, ldc, N, mrow0, ncol0, r1, rows, ch ? bias_hi : bias_lo, aux_cur, lane, csum);
@@ -366,6 +406,8 @@ void gemm_nt_w4_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
           for (int j = 0; j < 4; ++j) csum[j] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
       }
+#undef W4_SLICE
+#undef W4_RD
       W4_TSEG(M3P_W4_SCHED2 ? 6 : 4);
     }
   };
