@@ -238,20 +238,34 @@ __global__ __launch_bounds__(256) void ce_grad_tile_kernel(bf16* __restrict__ lo
   if (col0 >= ld) return;
   const int r0 = blockIdx.y * CE_RB, r1 = min(n_rows, r0 + CE_RB);
   float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int r = r0; r < r1; ++r) {
-    bf16* p = logits + (size_t)r * ld + col0;
-    const bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
-    const float lb = row_lse[r] * kLog2e;
-    const int tc = (int)(target[r] - col0);          // the target's position inside this thread's eight columns (or outside)
-    bf16x8 g;
+  // four rows' loads in flight before the first use: the gradient is written over the logits, so left to itself the compiler
+  // keeps every load behind the previous row's store (one 16-byte load in flight per thread: 5.0 TB/s on 4.9 GB)
+  constexpr int U = 4;
+  for (int rb = r0; rb < r1; rb += U) {
+    bf16x8 v[U];
+    float lb[U];
+    int tc[U];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float q = (col0 + j < V) ? __builtin_amdgcn_exp2f(__builtin_fmaf((float)v[j], kLog2e, -lb)) : 0.f;
-      if (j == tc) q -= 1.f;
-      g[j] = (bf16)(q * gscale);
-      cs[j] += (float)g[j];                          // the sum of the ROUNDED gradient: what summing the bf16 tensor gives
+    for (int u = 0; u < U; ++u) {
+      const int r = min(rb + u, r1 - 1);
+      v[u] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(logits + (size_t)r * ld + col0));
+      lb[u] = row_lse[r] * kLog2e;
+      tc[u] = (int)(target[r] - col0);               // the target's position inside this thread's eight columns (or outside)
     }
-    *reinterpret_cast<bf16x8*>(p) = g;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (rb + u < r1) {
+        bf16x8 g;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float q = (col0 + j < V) ? __builtin_amdgcn_exp2f(__builtin_fmaf((float)v[u][j], kLog2e, -lb[u])) : 0.f;
+          if (j == tc[u]) q -= 1.f;
+          g[j] = (bf16)(q * gscale);
+          cs[j] += (float)g[j];                      // the sum of the ROUNDED gradient: what summing the bf16 tensor gives
+        }
+        *reinterpret_cast<bf16x8*>(logits + (size_t)(rb + u) * ld + col0) = g;
+      }
+    }
   }
   float* out = part + (size_t)blockIdx.y * ld + col0;
   *reinterpret_cast<f32x4*>(out) = f32x4{cs[0], cs[1], cs[2], cs[3]};
