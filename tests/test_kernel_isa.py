@@ -142,3 +142,57 @@ def test_no_lds_read_may_overwrite_the_address_of_the_next_one(tmp_path):
                 assert not (prev[0] <= addr <= prev[1]), '%s:%d: %s  then  %s' % (src, i, text[i - 1].strip(), l.strip())
             prev = (lo, hi, addr)
     assert n_pairs >= 80          # the tr16 pairs of the weight-gradient kernel are seen at all
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason='hipcc not installed')
+def test_nothing_touches_an_inline_lds_reads_destination_before_its_wait(tmp_path):
+    """The four-wave kernels read LDS through inline asm the compiler does not see as loads (fragment reads of the K loop,
+    the epilogue's staging rows): the destination registers hold the data only after OUR s_waitcnt lgkmcnt.  To the compiler
+    they are defined at once - given control flow between a read and its wait it copies them (phi moves) in front of the
+    wait, which is how a pipelined form of the epilogue went wrong in round 4.  Checked on the ISA: between an inline
+    ds_read and the next s_waitcnt lgkmcnt no compiler-generated instruction may name a register of its destination."""
+    out = tmp_path / 'gemm.s'
+    cmd = [HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-munsafe-fp-atomics', '-ffp-contract=fast',
+           '-Wno-unused-result', '--cuda-device-only', '-S', os.path.join(ROOT, 'm3p_amd', 'csrc', 'gemm.hip'), '-o', str(out)]
+    subprocess.run(cmd, check=True, capture_output=True, timeout=600)
+    text = out.read_text().splitlines()
+    rd = re.compile(r'^\s*ds_read\w*\s+v\[(\d+):(\d+)\]')
+    reg = re.compile(r'\bv(?:\[(\d+):(\d+)\]|(\d+))')
+    starts = [i for i, l in enumerate(text) if re.match(r'^_ZN\S*gemm_(?:nt|wgrad)_w4_kernel\S*:', l)]
+    assert len(starts) >= 9
+    n_reads = 0
+    for st in starts:
+        in_asm, pending = False, []        # pending: destination ranges of inline reads not yet waited for
+        for i in range(st + 1, len(text)):
+            l = text[i]
+            if l.startswith('.Lfunc_end'):
+                break
+            s = l.strip()
+            if 'ASMSTART' in l:
+                in_asm = True
+                continue
+            if 'ASMEND' in l:
+                in_asm = False
+                continue
+            if not s or s.startswith(';') or s.startswith('.'):
+                continue
+            if s.startswith('s_waitcnt') and 'lgkmcnt' in s:
+                pending = []
+                continue
+            m = rd.match(l)
+            if in_asm and m:
+                pending.append((int(m.group(1)), int(m.group(2))))
+                n_reads += 1
+                continue
+            if in_asm or not pending:
+                continue
+            if s.endswith(':') or s.startswith('s_cbranch') or s.startswith('s_branch'):
+                # (a label or branch: the linear scan no longer follows the program; reads of the K loop are always waited
+                #  for inside their straight-line K-tile, so anything still pending here is a finding)
+                assert not pending, '%s: control flow between an inline LDS read and its wait (line %d)' % (text[st].split(':')[0], i)
+            for a, b, c in reg.findall(s):
+                lo, hi = (int(a), int(b)) if a else (int(c), int(c))
+                for plo, phi in pending:
+                    assert hi < plo or lo > phi, '%s line %d: `%s` names v[%d:%d] before its lgkmcnt wait' % (
+                        text[st].split(':')[0], i, s, plo, phi)
+    assert n_reads > 1000
