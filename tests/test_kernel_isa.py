@@ -196,3 +196,11 @@ def test_nothing_touches_an_inline_lds_reads_destination_before_its_wait(tmp_pat
                     assert hi < plo or lo > phi, '%s line %d: `%s` names v[%d:%d] before its lgkmcnt wait' % (
                         text[st].split(':')[0], i, s, plo, phi)
     assert n_reads > 1000
+
+
+def test_generated_kernel_bodies_are_up_to_date():
+    """The two four-wave GEMM bodies in gemm.hip are generated (tools/gen/gen_w4.py: the MFMA / memory-instruction schedule is
+    a table there); the committed file must be what the generator makes of the committed templates."""
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'gen', 'gen_w4.py'), '--check'], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr or r.stdout

@@ -138,5 +138,7 @@ s = s[:a] + '// W4-BEGIN (generated by tools/gen/gen_w4.py from tools/gen/w4_tem
 a = s.index('// WGW4-BEGIN')
 b = s.index('// WGW4-END')
 s = s[:a] + '// WGW4-BEGIN (generated by tools/gen/gen_w4.py from tools/gen/wgrad_w4_template.hip - edit those)\n' + wbody + s[b:]
+if '--check' in sys.argv:       # (tests: the committed kernel bodies are what the generator makes of the committed templates)
+    sys.exit(0 if s == open(p).read() else 'm3p_amd/csrc/gemm.hip is out of date: run tools/gen/gen_w4.py')
 open(p, 'w').write(s)
 print('generated', len(body.splitlines()), 'lines; phase-2 loads:', P2_LOADS)
