@@ -366,6 +366,12 @@ M3P_API int m3p_colsum_bf16(const void* x, int ld, int n, int ncols, float* out,
 /* *out += sum(g^2) in double (clip_grad_norm_, xtrainer.py:225). n % 4 == 0. */
 M3P_API int m3p_sumsq_f32(const float* g, long long n, double* out, void* stream);
 
+/* The same over n_ranges pieces base[starts[r] .. starts[r] + counts[r]) of one buffer (starts / counts: HOST arrays, element
+ * units, counts % 4 == 0, pieces 16-byte aligned) in one launch: the sharded data-parallel step (m3p_amd/distributed.py, zero1)
+ * owns a piece of every gradient bucket.  clip_grad_norm_, xtrainer.py:225. */
+M3P_API int m3p_sumsq_ranges_f32(const float* base, const long long* starts, const long long* counts, int n_ranges, double* out,
+                                 void* stream);
+
 /* One fused pass over a flat fp32 range:  g' = g * grad_scale * clip_coef,
  *   clip_coef = min(1, max_norm / (sqrt(*gnorm_sq) * grad_scale + 1e-6))   (if gnorm_sq && max_norm > 0)
  *   m = b1 m + (1-b1) g';  v = b2 v + (1-b2) g'^2;  p -= wd*lr*p;  p -= step_size * m / (sqrt(v) + eps)

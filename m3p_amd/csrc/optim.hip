@@ -12,7 +12,54 @@ namespace {
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, size_t n4, double* __restrict__ out) {
   __shared__ double red[4];
   float acc = 0.f;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+  // four 16-byte loads in flight per thread: the bucket-sized launches of the sharded data-parallel step (15 of ~75 MB) ran
+  // at 2 TB/s with one
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < n4; i += 4 * stride) {
+    f32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g + 4 * (i + u * stride)));
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc += (v[u][0] * v[u][0] + v[u][1] * v[u][1]) + (v[u][2] * v[u][2] + v[u][3] * v[u][3]);
+  }
+  for (; i < n4; i += stride) {
+    const f32x4 v = Vec4<float>::load(g + 4 * i);
+    acc += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = (double)acc;
+  __syncthreads();
+  if (threadIdx.x == 0) unsafeAtomicAdd(out, (red[0] + red[1]) + (red[2] + red[3]));
+}
+
+// the same over up to SUMSQ_MAX_RANGES ranges of one buffer in ONE launch (the sharded data-parallel step owns a piece of every
+// bucket: fifteen launches of ~30 us for what one launch does in the time the bytes take).  Blocks are dealt to the ranges
+// in proportion to their sizes (blk0[r] = first block of range r).
+constexpr int SUMSQ_MAX_RANGES = 32;
+struct SumsqRanges {
+  const float* g[SUMSQ_MAX_RANGES];
+  unsigned long long n4[SUMSQ_MAX_RANGES];
+  int blk0[SUMSQ_MAX_RANGES + 1];
+  int n;
+};
+__global__ __launch_bounds__(256) void sumsq_ranges_kernel(SumsqRanges a, double* __restrict__ out) {
+  __shared__ double red[4];
+  int r = 0;
+  while (r + 1 < a.n && (int)blockIdx.x >= a.blk0[r + 1]) ++r;
+  const float* __restrict__ g = a.g[r];
+  const size_t n4 = a.n4[r];
+  const size_t stride = (size_t)(a.blk0[r + 1] - a.blk0[r]) * blockDim.x;
+  size_t i = (size_t)((int)blockIdx.x - a.blk0[r]) * blockDim.x + threadIdx.x;
+  float acc = 0.f;
+  for (; i + 3 * stride < n4; i += 4 * stride) {
+    f32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g + 4 * (i + u * stride)));
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc += (v[u][0] * v[u][0] + v[u][1] * v[u][1]) + (v[u][2] * v[u][2] + v[u][3] * v[u][3]);
+  }
+  for (; i < n4; i += stride) {
     const f32x4 v = Vec4<float>::load(g + 4 * i);
     acc += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
   }
@@ -483,9 +530,47 @@ int m3p_quant_fp8_batch(const long long* desc, int n_desc, int blocks_per_matrix
 int m3p_sumsq_f32(const float* g, long long n, double* out, void* stream) {
   if (n <= 0 || (n % 4) != 0 || ((uintptr_t)g & 15)) return M3P_EINVAL;
   const size_t n4 = (size_t)n / 4;
-  const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+  const size_t want = (n4 + 1023) / 1024;      // ~four quads per thread
+  const int blocks = (int)(want < 1 ? 1 : (want < 2048 ? want : 2048));
   hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, n4, out);
   M3P_CHECK_LAUNCH();
+  return M3P_OK;
+}
+
+int m3p_sumsq_ranges_f32(const float* base, const long long* starts, const long long* counts, int n_ranges, double* out, void* stream) {
+  if (!base || !starts || !counts || !out || n_ranges <= 0) return M3P_EINVAL;
+  int done = 0;
+  while (done < n_ranges) {            // (more ranges than one launch's descriptor holds: several launches)
+    SumsqRanges a;
+    a.n = 0;
+    long long total4 = 0;
+    for (int r = done; r < n_ranges && a.n < SUMSQ_MAX_RANGES; ++r) {
+      if (counts[r] < 0 || (counts[r] % 4) != 0 || starts[r] < 0 || (((uintptr_t)(base + starts[r])) & 15)) return M3P_EINVAL;
+      if (counts[r] == 0) continue;
+      a.g[a.n] = base + starts[r];
+      a.n4[a.n] = (unsigned long long)counts[r] / 4;
+      total4 += counts[r] / 4;
+      ++a.n;
+    }
+    int taken = 0;
+    for (int r = done, k = 0; r < n_ranges && k < SUMSQ_MAX_RANGES; ++r) { if (counts[r] != 0) ++k; ++taken; }
+    done += taken;
+    if (a.n == 0) continue;
+    // ~four quads per thread, at most 2048 blocks, at least one block per range
+    long long want = (total4 + 1023) / 1024;
+    if (want > 2048) want = 2048;
+    if (want < a.n) want = a.n;
+    int b = 0;
+    for (int r = 0; r < a.n; ++r) {
+      a.blk0[r] = b;
+      long long share = (long long)((double)a.n4[r] / (double)total4 * (double)want);
+      if (share < 1) share = 1;
+      b += (int)share;
+    }
+    a.blk0[a.n] = b;
+    hipLaunchKernelGGL(sumsq_ranges_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, a, out);
+    M3P_CHECK_LAUNCH();
+  }
   return M3P_OK;
 }
 

@@ -70,6 +70,7 @@ SIGNATURES = {
     'm3p_ce_bwd_colsum': (_i, [_p, _i, _i, _i, _p, _p, _f, _p, _p, C.c_size_t, _p]),
     'm3p_colsum_bf16': (_i, [_p, _i, _i, _i, _p, _p, _p]),
     'm3p_sumsq_f32': (_i, [_p, C.c_longlong, _p, _p]),
+    'm3p_sumsq_ranges_f32': (_i, [_p, _p, _p, _i, _p, _p]),
     'm3p_adam_step': (_i, [_p, _p, _p, _p, _p, C.c_longlong, _f, _f, _f, _f, _f, _f, _p, _f, _f, _i, _p]),
     'm3p_itm_score_fwd': (_i, [_p, _p, _p, _p, _p, _i, _i, _p]),
     'm3p_itm_score_bwd': (_i, [_p, _p, _p, _p, _p, _i, _p, _p, _p, _i, _i, _p]),

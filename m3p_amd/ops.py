@@ -629,6 +629,19 @@ def sumsq(g, out):
     L.check(L.load().m3p_sumsq_f32(g.data_ptr(), g.numel(), out.data_ptr(), L.stream()), 'm3p_sumsq_f32')
 
 
+def sumsq_ranges(buf, ranges, out):
+    """out += sum of squares over the pieces buf[a:b] for (a, b) in ranges - one launch (m3p_sumsq_ranges_f32)."""
+    ranges = [(int(a), int(b)) for a, b in ranges if b > a]
+    if not ranges:
+        return
+    if len(ranges) == 1:
+        return sumsq(buf[ranges[0][0]:ranges[0][1]], out)
+    n = len(ranges)
+    starts = (C.c_longlong * n)(*[a for a, _ in ranges])
+    counts = (C.c_longlong * n)(*[b - a for a, b in ranges])
+    L.check(L.load().m3p_sumsq_ranges_f32(buf.data_ptr(), starts, counts, n, out.data_ptr(), L.stream()), 'm3p_sumsq_ranges_f32')
+
+
 def adam_step(p, g, m, v, w16, lr, beta1, beta2, eps, weight_decay, step_size, gnorm_sq=None, max_norm=0.0,
               grad_scale=1.0, zero_grad=True):
     n = p.numel()

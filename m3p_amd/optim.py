@@ -114,9 +114,10 @@ class Adam(optim.Optimizer):
             if arena.model.ddp_hook is not None:
                 arena.model.ddp_hook.finish()
             ent['gnorm'].zero_()
+            pieces = []
             for r in self._active_ranges(arena):
-                for a, b in self._owned(arena, r['start'], r['end']):
-                    ops.sumsq(arena.grad[a:b], ent['gnorm'])
+                pieces.extend(self._owned(arena, r['start'], r['end']))
+            ops.sumsq_ranges(arena.grad, pieces, ent['gnorm'])      # (one launch however many shards this rank owns)
             if arena.model.ddp_hook is not None:
                 arena.model.ddp_hook.all_reduce_scalar(ent['gnorm'])     # sharded gradients: the norm is the sum over ranks
         self._pending_clip = float(max_norm)

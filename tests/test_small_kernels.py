@@ -334,3 +334,18 @@ def test_batched_transpose_fast_and_ragged_tiles():
     ops.transpose_batch(torch.tensor(rows, dtype=torch.int64, device='cuda'), len(rows), mt)
     for a, ac, dst in mats:
         assert torch.equal(dst[:, :a.shape[0]].cpu(), ac.to(BF16).t()), tuple(a.shape)
+
+
+@pytest.mark.gpu
+def test_sumsq_over_ranges_in_one_launch():
+    """m3p_sumsq_ranges_f32 (the gradient norm of a rank's shards under the sharded data-parallel step) against the
+    piecewise sums, including an empty piece, a tiny one and more pieces than one launch's descriptor holds."""
+    from m3p_amd import ops
+    g = torch.Generator(device='cuda').manual_seed(11)
+    buf = torch.randn(3_000_000, device='cuda', generator=g)
+    cuts = [(0, 4), (8, 8), (1024, 500_000), (500_004, 500_008), (1_000_000, 2_999_996)]
+    cuts += [(2_000_000 + 1024 * i, 2_000_000 + 1024 * i + 512) for i in range(40)]
+    out = torch.zeros(1, dtype=torch.float64, device='cuda')
+    ops.sumsq_ranges(buf, cuts, out)
+    ref = sum(float(buf[a:b].double().pow(2).sum()) for a, b in cuts)
+    assert abs(float(out) - ref) <= 1e-6 * ref
