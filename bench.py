@@ -260,8 +260,11 @@ def main():
         torch.cuda.synchronize()
     ops.PROFILE = {}
     t0 = time.perf_counter()
+    host_ms = []
     for _ in range(args.steps):
+        h0 = time.perf_counter()
         step()
+        host_ms.append((time.perf_counter() - h0) * 1e3)      # (time to ENQUEUE a step: the host must stay ahead of the GPU)
     torch.cuda.synchronize()
     if multi:
         dist.barrier()
@@ -393,7 +396,8 @@ def main():
                                             if args.refine_layers else '') + (', ragged text lengths U[T/2, T]' if args.ragged else '')
                                            + (', fp8 layer projections + data gradients' if args.fp8 else '')),
                                per_gpu_batch=cfg['B'], global_batch=cfg['B'] * world, seq_len=cfg['T'] + cfg['R'],
-                               parallelism='dp%d' % world, flops_train_per_seq=fl, prewarm_steps=3 * groups),
+                               parallelism='dp%d' % world, flops_train_per_seq=fl, prewarm_steps=3 * groups,
+                               host_enqueue_ms_per_step=round(sorted(host_ms)[len(host_ms) // 2], 2)),
                    roofline=roof)
         if comm is not None:
             out['comm'] = comm

@@ -24,13 +24,14 @@ def main():
     ap.add_argument('csv')
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--top', type=int, default=25)
+    ap.add_argument('--marker', default='adam_kernel', help='a kernel launched once per step (the sharded data-parallel step launches Adam per shard: use ce_grad_tile_kernel)')
     a = ap.parse_args()
     rows = []
     with open(a.csv) as f:
         for r in csv.DictReader(f):
             rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']))
     rows.sort()
-    adam = [i for i, r in enumerate(rows) if 'adam_kernel' in r[2]]
+    adam = [i for i, r in enumerate(rows) if a.marker in r[2]]
     assert len(adam) > a.steps, 'not enough steps in the trace'
     lo, hi = adam[-a.steps - 1] + 1, adam[-1] + 1
     seg = rows[lo:hi]
