@@ -7,5 +7,5 @@ cd $R
 t=$(ls $out/wrapped/*/*kernel_trace.csv | head -1)
 python tools/trace_gaps.py $t --steps 3 --top 30 --marker ce_grad_tile_kernel 2>&1 | tee $out/gaps.txt
 m=$(ls $out/wrapped/*/*memory_copy_trace.csv | head -1)
-python tools/trace_window.py $t $m 2>&1 | tee $out/window.txt
+python tools/trace_window.py $t $m --from scatter_add_token_rows --to seq_masks_kernel 2>&1 | tee $out/window.txt
 rm -f $out/wrapped/*/*trace.csv
