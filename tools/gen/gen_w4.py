@@ -86,16 +86,26 @@ a_slots = [17, 19] + [23 + 4 * k for k in range(6)]     # A fragments: two befor
 for r, sl in enumerate(a_slots):
     add(kt, sl, 'W4_DSR(fa1[%d], ra1, %d);' % (r, r * 2048))
 n_after = sum(1 for sl in a_slots if sl <= KT_BAR1)
-add(kt, KT_BAR1, 'W4_WAIT_LGKM(%d); W4_BAR(); W4_TSEG(0);' % n_after)
+BAR_LAG = int(os.environ.get('W4_BAR_LAG', '0'))        # 1: one MFMA between a wait and its barrier (the pipe has work while the wave waits)
+if BAR_LAG:
+    add(kt, KT_BAR1, 'W4_WAIT_LGKM(%d);' % n_after); add(kt, KT_BAR1 + 1, 'W4_BAR(); W4_TSEG(0);')
+else:
+    add(kt, KT_BAR1, 'W4_WAIT_LGKM(%d); W4_BAR(); W4_TSEG(0);' % n_after)
 for k, sl in enumerate(KT_DMA_W):
     add(kt, sl, 'W4_L(%d);' % (8 + k))
 assert max(a_slots) < KT_BAR2
-add(kt, KT_BAR2, 'W4_WAIT_LGKM(0); W4_BAR(); W4_TSEG(1);')
+if BAR_LAG:
+    add(kt, KT_BAR2, 'W4_WAIT_LGKM(0);'); add(kt, KT_BAR2 + 1, 'W4_BAR(); W4_TSEG(1);')
+else:
+    add(kt, KT_BAR2, 'W4_WAIT_LGKM(0); W4_BAR(); W4_TSEG(1);')
 for k, sl in enumerate(KT_DMA_A):
     add(kt, sl, 'W4_L(%d);' % k)
 add(kt, max(KT_DMA_A) + 1, 'W4_LD();')
 assert max(KT_DMA_A) + 1 < KT_BAR3
-add(kt, KT_BAR3, 'W4_TSEG(2); W4_WAIT_VM(16); W4_TSEG(3); W4_BAR(); W4_TSEG(4);')
+if BAR_LAG:
+    add(kt, KT_BAR3 - 1, 'W4_TSEG(2); W4_WAIT_VM(16); W4_TSEG(3);'); add(kt, KT_BAR3, 'W4_BAR(); W4_TSEG(4);')
+else:
+    add(kt, KT_BAR3, 'W4_TSEG(2); W4_WAIT_VM(16); W4_TSEG(3); W4_BAR(); W4_TSEG(4);')
 for r in range(16):                                     # k-step 0 of the next K-tile
     add(kt, KT_BAR3 + 1 + r, ('W4_DSR(fw0[%d], rb0n, %d);' % (r, r * 2048)) if r < 8 else ('W4_DSR(fa0[%d], ra0n, %d);' % (r - 8, (r - 8) * 2048)))
 assert KT_BAR3 + 16 <= 127
