@@ -249,7 +249,7 @@ void gemm_nt_w4_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
                           (!(EPI == M3P_EPI_BIAS_GELU) || (((ep.ld_out2 & 7) == 0) && (((uintptr_t)ep.out2 & 15) == 0))) &&
                           (!ep.bias || (((uintptr_t)ep.bias & 15) == 0)) &&
                           (!ep.aux || (((ep.ld_aux & 7) == 0) && (((uintptr_t)ep.aux & 15) == 0)));
-  char* r1 = smem + 2 * STAGE + wid * 8192;      // (8 KB per wave: two swizzled 4-KB buffers for the pipelined epilogues, or one padded 4.5-KB one)
+  char* r1 = smem + 2 * STAGE + wid * EP_HALF;
   f32x4 bias_lo[4], bias_hi[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) bias_lo[j] = bias_hi[j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -319,10 +319,11 @@ void gemm_nt_w4_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
       // The plain epilogues with LDS accesses the compiler does not see (see lds_w64 ...): with transfers for the next output
       // tile in flight it puts s_waitcnt vmcnt(0) in front of every staging access it knows of, i.e. every piece waits for the
       // previous piece's global stores (~1150 clocks a piece, 9.2 k per output tile, a fifth of a K = 768 launch -
-      // tools/gemm_timeline.py).  Two swizzled 4-KB buffers per wave, alternating: with the two stages the whole 160 KB of the CU.
+      // tools/gemm_timeline.py).  One swizzled 4-KB buffer inside each wave's 4.5-KB staging area (146 KB of LDS in all: a
+      // collective's kernel can still share the CU).
       constexpr bool kPipe = M3P_W4_PIPE_EPI && (EPI == M3P_EPI_NONE || EPI == M3P_EPI_BIAS || EPI == M3P_EPI_RES || EPI == M3P_EPI_BIAS_DROP_RES);
       if (kPipe && fast) {
-        char* rb = smem + 2 * STAGE + wid * 8192;
+        char* rb = smem + 2 * STAGE + wid * EP_HALF;      // (one swizzled 4-KB buffer inside the wave's 4.5-KB staging area)
         u32x4 tq[4];
         load_aux_rows_issue<EPI>(ep, mw, nw, lane, tq);
 #pragma nounroll
@@ -340,7 +341,7 @@ void gemm_nt_w4_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
             case 6: W4_SLICE(2, 1); break;
             default: W4_SLICE(3, 1); break;
           }
-          char* rc = rb + (p & 1) * 4096;
+          char* rc = rb;     // (one buffer: a wave's LDS instructions complete in order, piece p + 1's writes queue behind piece p's reads)
           bf16x4 aux_cur[2][4];
           load_aux_rows_finish<EPI, true, true>(lane, rc, tq, aux_cur);
           if (p + 1 < 8) load_aux_rows_issue<EPI>(ep, mw + 32 * ((p + 1) & 3), nw + 64 * ((p + 1) >> 2), lane, tq);
