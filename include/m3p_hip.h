@@ -17,8 +17,8 @@
  *     launched); >0 = a hipError_t.  Nothing throws across the ABI;
  *   - the library never allocates and keeps no per-call state: re-entrant (the autograd engine calls from its
  *     own thread).  What IS process-global: idempotent one-time initialisation (the CU count, the dynamic-LDS
- *     attribute of each kernel) and the developer switch m3p_debug_set_variant (A/B runs of kernel generations;
- *     not in this header, never called by the product).
+ *     attribute of each kernel), the two schedule setters m3p_set_persistent_grid / m3p_set_tile_queue and the developer
+ *     switch m3p_debug_set_variant (A/B runs of kernel generations; never called by the product).
  */
 #ifndef M3P_HIP_H
 #define M3P_HIP_H
@@ -140,9 +140,11 @@ M3P_API int m3p_gemm_nn_w4_f32(const void* A, int lda, const void* W, int ldw, f
  * zero_grad).  Replaces autograd's addmm-backward for every nn.Linear weight above.
  * Requires N % 16 == 0 ... see source; lddy/ldx % 8 == 0.
  * workspace (optional, device memory, 16-byte aligned, >= m3p_gemm_wgrad_workspace_bytes()): scratch for the
- * four-wave kernel's partial tiles (one 256-KB slot per CU, folded into dW by a reduce kernel, no atomics).  It
- * belongs to the caller - the library never allocates - and must not be shared by launches that can run
- * concurrently (different streams).  NULL: partial tiles are added to dW with atomics instead. */
+ * four-wave kernel's partial tiles (one 256-KB slot per CU, folded into dW by a reduce kernel in slot order, no atomics:
+ * bit-reproducible).  It belongs to the caller - the library never allocates - and must not be shared by launches that can
+ * run concurrently (different streams).  NULL: partial tiles are added to dW with atomics instead.
+ * (Round 5 built the reduction INTO the launch - write-through partials, an arrival counter per tile, every chunk's
+ * workgroup summing a 1/C stripe in slot order - correct and slower: DESIGN.md section 4, profiles/r05_wgrad_inkernel_*.) */
 M3P_API size_t m3p_gemm_wgrad_workspace_bytes(void);
 M3P_API int m3p_gemm_wgrad_bf16(const void* dY, int lddy, const void* X, int ldx, float* dW, int lddw,
                                 int M, int N, int K, float alpha, void* workspace, size_t workspace_bytes,
@@ -387,8 +389,8 @@ M3P_API int m3p_adam_step(float* p, float* g, float* m, float* v, void* w16, lon
  * then applies with M3P_EPI_MUL instead of recomputing the derivative in the GEMM epilogue. */
 M3P_API int m3p_gelu_fwd(const void* u, void* h, void* dh, long long n, void* stream);
 /* The same activation for the persistent-GEMM FFN (transformer.py:223-225, gelu :48-56) leaving what backward needs in ONE
- * byte per element: h (bf16 [M, N], contiguous) = gelu_erf(u), gq (uint8, M * N bytes) = gelu_erf'(u) quantised to 256
- * levels over [-0.13, 1.13] (|error| <= 2.5e-3), stored in the fragment order of the eight-wave NT GEMM's 256 x 256 tiles
+ * byte per element: h (bf16 [M, N], contiguous) = gelu_erf(u), gq (uint8, M * N bytes) = gelu_erf'(u) quantised to the
+ * grid (code - 27) / 200 (0 and 1 exact, |error| <= 2.5e-3), stored in the fragment order of the eight-wave NT GEMM's 256 x 256 tiles
  * so that the FFN data gradient m3p_gemm_nt_bf16(..., M3P_EPI_MULQ, aux = gq) multiplies by it without a layout change.
  * u itself is not needed after this call.  M % 256 == 0, N % 256 == 0; u, h contiguous and 16-byte aligned. */
 M3P_API int m3p_gelu_fwd_gq(const void* u, void* h, void* gq, int M, int N, void* stream);
@@ -446,6 +448,32 @@ M3P_API int m3p_set_persistent_grid(int workgroups);
  * other stream take the static schedule (never a slot another stream's kernel may still be popping from).  Slot hand-out is
  * serialised inside the library; call this setter with no GEMM of the old ring in flight.  Results are the static schedule's. */
 M3P_API int m3p_set_tile_queue(int32_t* counters, int n_slots);
+
+/* Which kernel a product of this shape WOULD run on, given the process-wide switches above (no launch, no device access): the
+ * dispatch tables in csrc/gemm.hip (nt_plan / wgrad_plan) are the single place that decides, the launchers switch on the same
+ * value.  Tests use it to assert that a model-level parity case really exercised the kernel family the benchmark runs on
+ * (tests/test_model_parity.py[tiles]).  Returns an M3P_KERN_* id, or M3P_EINVAL for a shape the entry point would refuse.
+ * m3p_gemm_wgrad_plan assumes 16-byte aligned operands with pitches that are multiples of 8. */
+enum {
+  M3P_KERN_NT_SKINNY = 1,        /* M <= 128: fragments straight from global memory                       */
+  M3P_KERN_NT_W8 = 2,            /* eight waves, 256 x 256 tile, 128 x 64 per wave                         */
+  M3P_KERN_NT_W8_QUEUE = 3,      /* the same with per-XCD dynamic tile queues (m3p_set_tile_queue)         */
+  M3P_KERN_NT_W4 = 4,            /* four waves, 256 x 256 tile, 128 x 128 per wave (K >= 2048)             */
+  M3P_KERN_NT_RING = 5,          /* eight waves, 256 x 128 tile, three-stage ring: ragged shapes           */
+  M3P_KERN_NT_128 = 6,           /* 128 x 128, two stages: M < 1024                                        */
+  M3P_KERN_WGRAD_W4_CHUNKS = 10, /* four waves, one (tile, M-chunk) segment per workgroup + ordered reduce kernel */
+  M3P_KERN_WGRAD_W4_TILES = 11,  /* four waves, whole tiles round-robin (the vocabulary matrix)            */
+  M3P_KERN_WGRAD_RING = 12,      /* stream-K 256 x 128 with fp32 atomics: ragged N / K                     */
+  M3P_KERN_WGRAD_128 = 13        /* 128 x 128 split-M: small M                                             */
+};
+M3P_API int m3p_gemm_nt_plan(int M, int N, int K, int epilogue);
+M3P_API int m3p_gemm_wgrad_plan(int M, int N, int K);
+
+/* Developer switch (process-wide, NEVER called by the product; tools/ab_*.py and M3P_VARIANT in m3p_amd/lib.py use it for A/B
+ * runs of kernel generations): low byte 0 = force the 128 x 128 kernels, 1 = the tables above (default), 2 = four-wave NT
+ * wherever it applies, 3 = ring kernels, 6 = eight-wave NT, 7 = round 1's choice, 9 = default without the skinny kernel; the
+ * higher bits are ablation flags of the timeline builds.  Every launch reads it: set it only with no GEMM call in flight. */
+M3P_API void m3p_debug_set_variant(int v);
 
 /* ------------------------------------------------------------------------------------
  * Host-glue kernels (csrc/glue.hip): index / mask / loss arithmetic the reference does with chains of elementwise

@@ -28,7 +28,7 @@
 static int g_variant = 1;  // debug: 0 = force the 128x128 2-stage kernel, 1 = auto (skinny for M <= 128, eight-wave 256x256 for full tiles, ring otherwise),
                            // 2 = force the four-wave 256x256 kernel, 3 = force ring, 6 = force eight-wave 256x256, 7 = the round-1 auto choice (w4 / ring), 9 = auto without the skinny kernel
 static int g_ablate = 0;  // debug: timeline kernels only (bit0 = no fragment reads, bit1 = no LDS-DMA)
-extern "C" __attribute__((visibility("default"))) void m3p_debug_set_variant(int v) { g_variant = v & 0xff; g_ablate = v >> 8; }
+extern "C" void m3p_debug_set_variant(int v) { g_variant = v & 0xff; g_ablate = v >> 8; }     // (declared in the header's developer section)
 
 namespace {
 
@@ -654,8 +654,14 @@ __device__ __forceinline__ void epilogue_half_lse(bf16* __restrict__ C, int ldc,
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       x[j] = (ii ? rows1[j] : rows0[j]) + biasv[j];
-      if (M3P_EPI_ALDS) lds_w64(lds_addr(r1) + ep_off8<true>(ii * 16 + fr, (j * 16 + fg * 4) * 2), bf16x4{(bf16)x[j][0], (bf16)x[j][1], (bf16)x[j][2], (bf16)x[j][3]});
-      else *reinterpret_cast<bf16x4*>(r1 + ep_off8<true>(ii * 16 + fr, (j * 16 + fg * 4) * 2)) = bf16x4{(bf16)x[j][0], (bf16)x[j][1], (bf16)x[j][2], (bf16)x[j][3]};
+      const bf16x4 xb = bf16x4{(bf16)x[j][0], (bf16)x[j][1], (bf16)x[j][2], (bf16)x[j][3]};
+      if (M3P_EPI_ALDS) lds_w64(lds_addr(r1) + ep_off8<true>(ii * 16 + fr, (j * 16 + fg * 4) * 2), xb);
+      else *reinterpret_cast<bf16x4*>(r1 + ep_off8<true>(ii * 16 + fr, (j * 16 + fg * 4) * 2)) = xb;
+      // the statistics are taken on the ROUNDED logits - the very values the cross-entropy's gradient pass and its target term
+      // read back - so that softmax rows sum to one and the gradient rows to zero exactly as with a statistics pass over the
+      // stored logits (one shift per element)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) x[j][r] = (float)xb[r];
     }
     if (edge) {        // (wave-uniform: only the last column tile holds columns >= V)
 #pragma unroll
@@ -760,7 +766,7 @@ __device__ __forceinline__ void epilogue_half_geluq(bf16* __restrict__ C, int ld
       cw = __builtin_amdgcn_cvt_pk_u8_f32(qf[2], 2, cw); cw = __builtin_amdgcn_cvt_pk_u8_f32(qf[3], 3, cw);
       code[j] = cw;
 #else
-      const f32x4 qf = gd * GQ_INV + (GQ_OFF * GQ_INV + 0.5f);                 // in [0.7, 255.3): truncation = round to nearest
+      const f32x4 qf = gd * GQ_INV + (GQ_OFF * GQ_INV + 0.5f);                 // in [1.7, 253.3): truncation = round to nearest
       code[j] = (uint32_t)qf[0] | ((uint32_t)qf[1] << 8) | ((uint32_t)qf[2] << 16) | ((uint32_t)qf[3] << 24);
 #endif
       if (M3P_EPI_ALDS) lds_w64(lds_addr(r1) + ep_off8<true>(ii * 16 + fr, (j * 16 + fg * 4) * 2), bf16x4{(bf16)hv[0], (bf16)hv[1], (bf16)hv[2], (bf16)hv[3]});
@@ -2926,32 +2932,77 @@ static int* tq_acquire(hipStream_t st, hipError_t* err) {
   return g_tq_pool + 8 * g_tq_next++;
 }
 
-template <int EPI>
-int launch_nt(const bf16* A, int lda, const bf16* W, int ldw, bf16* C, int ldc, int M, int N, int K,
-              const M3PEpilogue& ep, hipStream_t st) {
-  // full-tile shapes go to the 4-wave 256x256 kernel (measured on M=41984 against the 8-wave ring
-  // kernel: K=3072,N=768 1000 vs 855 TF; N=3072,K=768 910 vs 815; 768x768 980 vs 925); ragged
-  // shapes and the vocabulary projection's m-fast order stay on the ring kernel
-  if (M <= 128 && g_variant >= 1 && g_variant != 9 && (K % 128) == 0 && (lda % 8) == 0 && (ldw % 8) == 0 &&
-      (((uintptr_t)A | (uintptr_t)W) & 15) == 0 && EPI != M3P_EPI_DGELU && EPI != M3P_EPI_MUL) {
-    if (M <= 16) return launch_nt_skinny<EPI, 1>(A, lda, W, ldw, C, ldc, M, N, K, ep, st);
-    if (M <= 32) return launch_nt_skinny<EPI, 2>(A, lda, W, ldw, C, ldc, M, N, K, ep, st);
-    if (M <= 64) return launch_nt_skinny<EPI, 4>(A, lda, W, ldw, C, ldc, M, N, K, ep, st);
-    return launch_nt_skinny<EPI, 8>(A, lda, W, ldw, C, ldc, M, N, K, ep, st);
-  }
-  const bool deep = (N >= 512) && (2LL * N * K <= (64LL << 20)) && EPI != M3P_EPI_DGELU;   // (dGELU epilogue: 240 VGPRs there, measured slower in the step)
 #ifndef M3P_W8_MAX_W_BYTES
 #define M3P_W8_MAX_W_BYTES (1LL << 40)      // (no limit: the vocabulary projection - W = 384 MB - measured 2.18 -> 1.85 ms on this kernel)
 #endif
-  // Long contractions go to the four-wave kernel since its K-tile runs in one piece with buffer-form transfers (round 4):
-  // 159 against 174 us on dx1 (K = 3072), 125 against 131 on dh (K = 2304), 169 against 177 on lin2 forward; at K = 768 the
-  // eight-wave kernel's second wave per SIMD (which hides its epilogue's stores) still wins - 137 against 148 us on q/k/v.
 #ifndef M3P_W4_MIN_K
 #define M3P_W4_MIN_K 2048
 #endif
-  const bool w4_first = g_variant == 1 && deep && K >= M3P_W4_MIN_K && EPI != M3P_EPI_MUL && !g_tq_pool;      // (the tile queue of data parallelism lives in the eight-wave kernel)
-  if (M >= 1024 && (g_variant == 1 || g_variant == 6) && !w4_first && (N >= 512) && (2LL * N * K <= M3P_W8_MAX_W_BYTES) && (K % 64) == 0 && (lda % 8) == 0 &&
-      (ldw % 8) == 0 && (M % 256) == 0 && (N % 256) == 0) {
+static bool tq_enabled() {
+  std::lock_guard<std::mutex> lk(g_tq_mu);
+  return g_tq_pool != nullptr;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// WHICH KERNEL RUNS AN NT PRODUCT - the one place that decides (m3p_gemm_nt_plan reports it; launch_nt switches on it).
+// Rows are tried top to bottom; "whole tiles" = M >= 1024, M % 256 == 0, N % 256 == 0, N >= 512, K % 64 == 0 (the entry point has
+// already checked K % 64, lda / ldw % 8 and 16-byte operand bases).
+//
+//   shape / epilogue                                      kernel                     why (measured where)
+//   ----------------------------------------------------  -------------------------  -------------------------------------------------
+//   MULQ / BIAS_GELUQ / BIAS_LSE (whole tiles only,       eight-wave 256x256         their byte / statistics layouts ARE that kernel's
+//     anything else -> M3P_EINVAL)                                                     (tile, wave, row block, lane) order
+//   M <= 128, K % 128 == 0, not DGELU / MUL               skinny (no LDS)            one decoding step / [CLS] rows: every W row read once
+//   whole tiles, K >= 2048, not DGELU / MUL,              four-wave 256x256          K-tile in one piece, buffer-form transfers: dx1 159 vs
+//     no tile queue armed                                                              174 us, dh 125 vs 131, lin2 fwd 169 vs 177 (round 4)
+//   whole tiles (any K)                                   eight-wave 256x256         second wave per SIMD hides epilogue + LDS-DMA issue:
+//     + tile queue armed, > 1 tile per workgroup,           (queue instantiation)      q/k/v 137 vs 148 us at K = 768; vocabulary projection
+//       K >= 512, not DGELU / MUL                                                      1.85 vs 2.18 ms
+//   M >= 1024 otherwise (ragged M or N, N < 512)          ring 256x128, 3 stages     any shape; strip order for the vocabulary matrices
+//   M < 1024                                              128x128, 2 stages          small-M fallback (cfg1, tests)
+//
+// Developer overrides (m3p_debug_set_variant, never set by the product): 0 forces the last row, 2 the four-wave kernel wherever it
+// applies, 3 the ring kernel, 6 the eight-wave kernel, 7 round 1's choice (four-wave / ring), 9 = auto without the skinny kernel.
+// ---------------------------------------------------------------------------------------------------------------------
+static int nt_plan(int epi, int M, int N, int K, int* queue) {
+  if (queue) *queue = 0;
+  const bool whole = M >= 1024 && (M % 256) == 0 && (N % 256) == 0 && N >= 512 && (K % 64) == 0;
+  if (epi == M3P_EPI_MULQ || epi == M3P_EPI_BIAS_GELUQ || epi == M3P_EPI_BIAS_LSE) return whole ? M3P_KERN_NT_W8 : M3P_EINVAL;
+  const bool mul_epi = epi == M3P_EPI_DGELU || epi == M3P_EPI_MUL;
+  if (M <= 128 && g_variant >= 1 && g_variant != 9 && (K % 128) == 0 && !mul_epi) return M3P_KERN_NT_SKINNY;
+  // (dGELU epilogue on the four-wave kernel: 240 VGPRs, measured slower in the step)
+  const bool deep = N >= 512 && 2LL * N * K <= (64LL << 20) && epi != M3P_EPI_DGELU;
+  const bool armed = tq_enabled();     // (the tile queue of data parallelism lives in the eight-wave kernel)
+  const bool w4_first = g_variant == 1 && deep && K >= M3P_W4_MIN_K && epi != M3P_EPI_MUL && !armed;
+  if (whole && (g_variant == 1 || g_variant == 6) && !w4_first && 2LL * N * K <= M3P_W8_MAX_W_BYTES) {
+    // dynamic tile queue only where a workgroup takes several tiles (not for the multiply epilogues: with the queue's
+    // bookkeeping on top of their aux pieces and column sums the instantiation spills ~100 bytes per lane)
+    int grid = num_cus();
+    const int ntiles = (M / 256) * (N / 256);
+    if (ntiles < grid) grid = (ntiles + 7) / 8 * 8;
+    if (queue) *queue = (!mul_epi && armed && ntiles > grid && K >= 8 * BK) ? 1 : 0;
+    return M3P_KERN_NT_W8;
+  }
+  if (M >= 1024 && (M % 256) == 0 && (N % 256) == 0 && (g_variant == 2 || ((g_variant == 1 || g_variant == 7) && deep)))
+    return M3P_KERN_NT_W4;
+  if (M >= 1024 && g_variant >= 1) return M3P_KERN_NT_RING;
+  return M3P_KERN_NT_128;
+}
+
+template <int EPI>
+int launch_nt(const bf16* A, int lda, const bf16* W, int ldw, bf16* C, int ldc, int M, int N, int K,
+              const M3PEpilogue& ep, hipStream_t st) {
+  int want_queue = 0;
+  const int plan = nt_plan(EPI, M, N, K, &want_queue);
+  if (plan == M3P_KERN_NT_SKINNY) {
+    if constexpr (EPI != M3P_EPI_DGELU && EPI != M3P_EPI_MUL) {
+      if (M <= 16) return launch_nt_skinny<EPI, 1>(A, lda, W, ldw, C, ldc, M, N, K, ep, st);
+      if (M <= 32) return launch_nt_skinny<EPI, 2>(A, lda, W, ldw, C, ldc, M, N, K, ep, st);
+      if (M <= 64) return launch_nt_skinny<EPI, 4>(A, lda, W, ldw, C, ldc, M, N, K, ep, st);
+      return launch_nt_skinny<EPI, 8>(A, lda, W, ldw, C, ldc, M, N, K, ep, st);
+    }
+  }
+  if (plan == M3P_KERN_NT_W8) {
     const int tiles_m = M / 256, tiles_n = N / 256;
     const size_t lds = 2 * 512 * ROWB + (EPI == M3P_EPI_DGELU && M3P_DGELU_LUT ? GELU_TAB_N * sizeof(float) : 0) +
                        (M3P_W8_SPARE_EPILOGUE ? ((EPI == M3P_EPI_DGELU || EPI == M3P_EPI_MUL) ? 8 * 2048 : 8 * 4096) : 0);
@@ -2970,7 +3021,7 @@ int launch_nt(const bf16* A, int lda, const bf16* W, int ldw, bf16* C, int ldc, 
     //  spills ~100 bytes per lane - 0.31 against 0.28 ms on the dGELU product, more than the queue returns on 12 launches a step)
     constexpr bool kQueueOk = !(EPI == M3P_EPI_DGELU || EPI == M3P_EPI_MUL);
     int* ctr = nullptr;
-    if (kQueueOk && g_tq_pool && ntiles > grid && K >= 8 * BK) {
+    if (kQueueOk && want_queue) {
       hipError_t e;
       ctr = tq_acquire(st, &e);
       if (e != hipSuccess) return (int)e;
@@ -2991,8 +3042,7 @@ int launch_nt(const bf16* A, int lda, const bf16* W, int ldw, bf16* C, int ldc, 
     M3P_CHECK_LAUNCH();
     return M3P_OK;
   }
-  if (M >= 1024 && (g_variant == 2 || ((g_variant == 1 || g_variant == 7) && deep)) && (K % 64) == 0 && (lda % 8) == 0 && (ldw % 8) == 0 &&
-      (M % 256) == 0 && (N % 256) == 0) {
+  if (plan == M3P_KERN_NT_W4) {
     constexpr int BM = 256, BN = 256;
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     const size_t lds = 2 * (BM + BN) * 128 + 4 * EP_HALF;
@@ -3012,7 +3062,7 @@ int launch_nt(const bf16* A, int lda, const bf16* W, int ldw, bf16* C, int ldc, 
     M3P_CHECK_LAUNCH();
     return M3P_OK;
   }
-  if (M >= 1024 && g_variant >= 1) {
+  if (plan == M3P_KERN_NT_RING) {
     constexpr int BM = 256, BN = 128;
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     const size_t lds = 3 * (BM + BN) * ROWB + (EPI == M3P_EPI_DGELU && M3P_DGELU_LUT ? GELU_TAB_N * sizeof(float) : 0);
@@ -4414,6 +4464,41 @@ static int launch_wgrad_w4(const void* dY, int lddy, const void* X, int ldx, flo
 }
 }  // extern "C++"
 
+// ---------------------------------------------------------------------------------------------------------------------
+// WHICH KERNEL RUNS A WEIGHT GRADIENT dW[N,K] += dY[M,N]^T X[M,K] (m3p_gemm_wgrad_plan reports it):
+//
+//   shape                                                  kernel                                   why
+//   -----------------------------------------------------  ---------------------------------------  --------------------------------
+//   M % 64 == 0, M >= 4096, N % 256 == 0, K % 256 == 0,    four-wave 256x256, one (tile, M-chunk)   1063 / 858 / 983 TF on FFN1 / FFN2 /
+//     >= 9 output tiles, < 4 tiles per CU                    segment per workgroup; partial tiles     QKV against 845 / 751 / 808 on the
+//                                                            go to the caller's workspace and a       ring kernel; no atomics, summed in
+//                                                            reduce kernel (16 x ntile blocks) sums   slot order (bit-reproducible)
+//                                                            them into dW in slot order
+//   same, >= 4 tiles per CU (the vocabulary matrix)        four-wave, whole tiles round-robin       each tile flushed once: fp32 atomics,
+//                                                                                                    or plain stores (m3p_gemm_wgrad_store_bf16)
+//   M % 64 == 0, M >= 4096 otherwise                       ring stream-K 256x128 (atomics)          ragged N / K
+//   anything else                                          128x128 split-M (atomics)                small M (cfg1, tests)
+// ---------------------------------------------------------------------------------------------------------------------
+static int wgrad_plan(int M, int N, int K, bool aligned) {
+  if (aligned && g_variant >= 1 && g_variant != 3 && (M % 64) == 0 && M >= 4096 && (N % 256) == 0 && (K % 256) == 0 &&
+      (N / 256) * (K / 256) >= ((g_ablate & 16) ? 1 : 9))
+    return ((long long)(N / 256) * (K / 256) >= 4LL * num_cus()) ? M3P_KERN_WGRAD_W4_TILES : M3P_KERN_WGRAD_W4_CHUNKS;
+  if (g_variant >= 1 && (M % BK) == 0 && M >= 4096) return M3P_KERN_WGRAD_RING;
+  return M3P_KERN_WGRAD_128;
+}
+
+int m3p_gemm_nt_plan(int M, int N, int K, int epilogue) {
+  if (M <= 0 || N <= 0 || K <= 0 || (K % BK) != 0 || epilogue < 0 || epilogue > M3P_EPI_BIAS_LSE) return M3P_EINVAL;
+  int queue = 0;
+  const int plan = nt_plan(epilogue, M, N, K, &queue);
+  return (plan == M3P_KERN_NT_W8 && queue) ? M3P_KERN_NT_W8_QUEUE : plan;
+}
+
+int m3p_gemm_wgrad_plan(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0) return M3P_EINVAL;
+  return wgrad_plan(M, N, K, true);
+}
+
 // Cf[M,N] += alpha * A[M,K] x W[K,N] on the four-wave kernel (YROWS form): the weight-gradient machinery with the roles
 //   contraction = K, output rows = M (first operand A, contraction-contiguous), output columns = N (second operand W, rows = contraction)
 int m3p_gemm_nn_w4_f32(const void* A, int lda, const void* W, int ldw, float* C, int ldc, int M, int N, int K, float alpha,
@@ -4458,11 +4543,11 @@ int m3p_gemm_wgrad_bf16(const void* dY, int lddy, const void* X, int ldx, float*
   if (M <= 0 || N <= 0 || K <= 0 || (lddy % 8) != 0 || (ldx % 8) != 0 || !dW || lddw < K) return M3P_EINVAL;
   if (lddy < ((N + 7) / 8) * 8 || ldx < ((K + 7) / 8) * 8) return M3P_EINVAL;
   if (((uintptr_t)dY & 15) || ((uintptr_t)X & 15)) return M3P_EINVAL;
-  if (wgrad_w4_ok(M, N, K, lddy, ldx, dY, X) &&
-      (N / 256) * (K / 256) >= ((g_ablate & 16) ? 1 : 9)) {      // (768 x 768 = 9 tiles included since the four-wave kernel lost its scalar overhead: 63 against 74 us on the ring kernel)
+  const int plan = wgrad_plan(M, N, K, wgrad_w4_ok(M, N, K, lddy, ldx, dY, X));
+  if (plan == M3P_KERN_WGRAD_W4_CHUNKS || plan == M3P_KERN_WGRAD_W4_TILES) {      // (768 x 768 = 9 tiles included since the four-wave kernel lost its scalar overhead: 63 against 74 us on the ring kernel)
     return launch_wgrad_w4<>(dY, lddy, X, ldx, dW, lddw, M, N, K, alpha, workspace, workspace_bytes, stream, nullptr);
   }
-  if (g_variant >= 1 && (M % BK) == 0 && M >= 4096) {
+  if (plan == M3P_KERN_WGRAD_RING) {
     const int ti = (N + WR_I - 1) / WR_I, tj = (K + WR_J - 1) / WR_J;
     const size_t lds = 3 * WR_STAGE;
     static bool attr_set_r = false;

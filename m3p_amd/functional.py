@@ -111,6 +111,15 @@ class Arena:
         self.epoch = 0          # bumped whenever the weights change (load / cast / optimizer step): 8-bit copies key on it
         self.grads_known_zero = True
         self.touched = set()   # names of parameters that received gradient since the last zero_grad
+        # Lazy zero of the tied vocabulary matrix's gradient (round 5).  When a step's MLM head STORED its weight gradient over
+        # grad[o : o + V_pad * d] (whole-tile sizes, first product into the zeroed matrix), the next step will almost always do
+        # the same - so the fused Adam pass does not write 768 MB of zeros there only for them to be overwritten (0.77 GB of the
+        # 9.5 GB it streams).  `stale` = (start, count) of a range that is LOGICALLY zero but physically still holds the last
+        # gradient: the store path clears it for free, every other writer (g() hands out the views; an autograd hook covers
+        # gradients autograd itself accumulates) and zero_grad() / readers go through ensure_zero() first.
+        self.stale = None
+        self.vocab_stored = False      # the last MLM-head backward took the store path
+        self._vocab_range = None
         self._layer_names = [[n for n in self.names if n.startswith(('attentions.%d.' % i, 'layer_norm1.%d.' % i,
                                                                      'ffns.%d.' % i, 'layer_norm2.%d.' % i))]
                              for i in range(L_)]
@@ -120,6 +129,12 @@ class Arena:
     def touch(self, *names):
         self.touched.update(names)
         self.grads_known_zero = False
+
+    def range_untouched(self, start, count):
+        """No parameter whose gradient overlaps grad[start : start + count] has received gradient since the last zero_grad
+        (what a kernel that STORES into that range instead of accumulating needs to know)."""
+        end = start + count
+        return not any(o < end and o + cnt > start for n in self.touched for (o, cnt, _) in (self.offsets[n],))
 
     def touch_layer(self, i, cross=False):
         self.touched.update(self._layer_names[i])
@@ -135,7 +150,36 @@ class Arena:
 
     def g(self, name):
         o, cnt, shape = self.offsets[name]
+        if self.stale is not None and o < self.stale[0] + self.stale[1] and o + cnt > self.stale[0]:
+            self.ensure_zero()
         return self.grad[o:o + cnt].view(shape)
+
+    def vocab_range(self):
+        """(start, count) of what the vocabulary weight gradient's store covers: the matrix and its pad rows."""
+        if self._vocab_range is None:
+            self._vocab_range = (self.offsets['embeddings.weight'][0], self.V_pad * self.model.dim)
+        return self._vocab_range
+
+    def ensure_zero(self):
+        """Make a lazily zeroed range physically zero (a writer that accumulates, or a reader, is about to touch it)."""
+        if self.stale is not None:
+            s0, cnt = self.stale
+            self.stale = None
+            self.grad[s0:s0 + cnt].zero_()
+
+    def defer_vocab_zero(self):
+        """Called by the optimizer instead of zeroing the vocabulary range.  Arms an autograd hook on the parameters inside the
+        range once: gradients that autograd itself accumulates into param.grad (jointfwd(text_embed=...)) find zeros."""
+        s0, cnt = self.vocab_range()
+        self.stale = (s0, cnt)
+        if not getattr(self, '_lazy_hooks', False):
+            self._lazy_hooks = True
+            for n, (o, c, _) in self.offsets.items():
+                if o < s0 + cnt and o + c > s0:
+                    def _hook(grad, _self=self):
+                        _self.ensure_zero()
+                        return grad
+                    self.params[n].register_hook(_hook)
 
     def p(self, name):
         return self.params[name]
@@ -244,6 +288,7 @@ class Arena:
         if not self.grads_known_zero:
             self.grad.zero_()
             self.grads_known_zero = True
+            self.stale = None
         self.touched.clear()
         if self.model.ddp_hook is not None:
             self.model.ddp_hook.step_done()
@@ -256,6 +301,7 @@ class Arena:
             self._transposes_stale = False
         self.touched.clear()
         self.grads_known_zero = True
+        self.vocab_stored = False
         if self.model.ddp_hook is not None:
             self.model.ddp_hook.step_done()
 
@@ -1102,8 +1148,12 @@ class MLMHeadFn(torch.autograd.Function):
         ar = model.arena()
         # first product of the step into the tied matrix's gradient (nothing has touched it, or the bias gradient its pad rows
         # alias, since the optimizer zeroed them): the weight gradient may store instead of adding
-        fresh = 'embeddings.weight' not in ar.touched and 'pred_layer.proj.bias' not in ar.touched
+        # The store covers grad[o : o + V_pad * d]: the matrix AND (V_pad - V) * d elements behind it, so every parameter whose
+        # gradient overlaps that range must be untouched too (with V ~ 95k and d = 1024 the pad rows run past the bias
+        # gradient into position_embeddings' - which an accumulation micro-step without an MLM head may already have written).
+        fresh = ar.range_untouched(ar.offsets['embeddings.weight'][0], ar.V_pad * model.dim)
         ar.touch('embeddings.weight', 'pred_layer.proj.bias')
+        ar.vocab_stored = False
         d, V = model.dim, model.n_words
         hsel, dlogits, row_idx, shape, stride, soff, base, dbias = ctx.saved
         ctx.saved = None
@@ -1115,7 +1165,14 @@ class MLMHeadFn(torch.autograd.Function):
             # exact zeros (the CE kernel wrote them), so rows V .. V_pad - 1 of "the matrix" - the head of the bias
             # gradient that follows it in the arena - receive += 0
             o = ar.offsets['embeddings.weight'][0]
-            ops.gemm_wgrad(dlogits, hs, ar.grad[o:o + ar.V_pad * d].view(ar.V_pad, d), n=ar.V_pad, k=d, dw_is_zero=fresh)
+            will_store = fresh and L.load().m3p_gemm_wgrad_plan(n, ar.V_pad, d) == L.KERN_WGRAD_W4_TILES
+            if will_store and ar.stale == ar.vocab_range():
+                ar.stale = None          # (lazily zeroed by the optimizer: the store below covers exactly that range)
+            else:
+                ar.ensure_zero()
+            ar.vocab_stored = ops.gemm_wgrad(dlogits, hs, ar.grad[o:o + ar.V_pad * d].view(ar.V_pad, d), n=ar.V_pad, k=d,
+                                             dw_is_zero=fresh, report_store=True)
+            assert ar.vocab_stored or not will_store, 'the dispatch table promised a stored vocabulary weight gradient'
         else:
             ops.gemm_wgrad(dlogits, hs, ar.g('embeddings.weight'), n=V, k=d)
         if dbias is not None:

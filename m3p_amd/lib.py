@@ -14,6 +14,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('M3P_HIP_LIB') or os.path.join(_HERE, 'libm3p_hip.so')
 
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_DROP_RES, EPI_RES, EPI_DGELU, EPI_MUL, EPI_MULQ, EPI_BIAS_GELUQ, EPI_BIAS_LSE = range(10)
+# kernel ids of m3p_gemm_nt_plan / m3p_gemm_wgrad_plan (include/m3p_hip.h)
+KERN_NT_SKINNY, KERN_NT_W8, KERN_NT_W8_QUEUE, KERN_NT_W4, KERN_NT_RING, KERN_NT_128 = range(1, 7)
+KERN_WGRAD_W4_CHUNKS, KERN_WGRAD_W4_TILES, KERN_WGRAD_RING, KERN_WGRAD_128 = range(10, 14)
 
 
 class M3PError(RuntimeError):
@@ -83,6 +86,9 @@ SIGNATURES = {
     'm3p_transpose_bf16': (_i, [_p, _p, _i, _i, _i, _i, _p]),
     'm3p_set_persistent_grid': (_i, [_i]),
     'm3p_set_tile_queue': (_i, [_p, _i]),
+    'm3p_gemm_nt_plan': (_i, [_i, _i, _i, _i]),
+    'm3p_gemm_wgrad_plan': (_i, [_i, _i, _i]),
+    'm3p_debug_set_variant': (None, [_i]),
     'm3p_seq_masks': (_i, [_p, _p, _i, _i, _p, _p, _p]),
     'm3p_mask_to_rows': (_i, [_p, _i, _i, C.c_longlong, C.c_longlong, C.c_longlong, _i, _p, _i, _p]),
     'm3p_cast_rows_f32_bf16': (_i, [_p, C.c_longlong, C.c_longlong, _i, _i, _i, _p, _p]),

@@ -204,7 +204,7 @@ def _wgrad_workspace(device):
     return ws
 
 
-def gemm_wgrad(dy, x, dw, alpha=1.0, n=None, k=None, dw_is_zero=False):
+def gemm_wgrad(dy, x, dw, alpha=1.0, n=None, k=None, dw_is_zero=False, report_store=False):
     """dw[N,K] (fp32) += alpha * dy[M,N]^T @ x[M,K].  dw_is_zero: the caller knows dw[:N, :K] to hold zeros - shapes dealt out
     as whole tiles (the vocabulary matrix) are then stored instead of accumulated with atomics; same result."""
     _chk_bf16(dy, x)
@@ -220,14 +220,14 @@ def gemm_wgrad(dy, x, dw, alpha=1.0, n=None, k=None, dw_is_zero=False):
                                                 dw.stride(0), M, N, K, alpha, ws.data_ptr(), ws.numel(), L.stream())
         if rc == 0:
             _prof_end(e0, ('gemm_wgrad', M, N, K))
-            return dw
+            return True if report_store else dw
         if rc != -2:        # (M3P_ENOTIMPL: not a whole-tile shape - accumulate below)
             L.check(rc, 'm3p_gemm_wgrad_store_bf16')
     rc = L.load().m3p_gemm_wgrad_bf16(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), dw.data_ptr(),
                                       dw.stride(0), M, N, K, alpha, ws.data_ptr(), ws.numel(), L.stream())
     L.check(rc, 'm3p_gemm_wgrad_bf16')
     _prof_end(e0, ('gemm_wgrad', M, N, K))
-    return dw
+    return False if report_store else dw
 
 
 def gemm_wgrad_pair(dy_a, x_a, dw_a, dy_b, x_b, dw_b, alpha=1.0):
@@ -666,7 +666,7 @@ def gelu_fwd(u, grad_inplace=False):
     return h
 
 
-GQ_OFF, GQ_STEP = 0.13, 1.26 / 255.0       # the byte code of gelu' (csrc/common.hpp): gelu' ~ code * GQ_STEP - GQ_OFF
+GQ_OFF, GQ_STEP = 0.135, 0.005       # the byte code of gelu' (csrc/common.hpp): gelu' ~ code * GQ_STEP - GQ_OFF
 
 
 def gq_eligible(M, N):

@@ -20,7 +20,12 @@ import re
 import torch
 from torch import optim
 
+import os
+
 from . import ops
+
+# developer switch for A/B runs: 0 = the fused Adam pass zeroes the vocabulary gradient like every other range (round 4)
+_LAZY_VOCAB_ZERO = os.environ.get('M3P_LAZY_VOCAB_ZERO', '1') != '0'
 
 
 class Adam(optim.Optimizer):
@@ -152,11 +157,20 @@ class Adam(optim.Optimizer):
                 bc1 = 1 - beta1 ** step
                 bc2 = 1 - beta2 ** step
                 step_size = group['lr'] * math.sqrt(bc2) / bc1
-                for s, e in self._owned(arena, r['start'], r['end']):
+                pieces = [(s, e, True) for s, e in self._owned(arena, r['start'], r['end'])]
+                # single GPU, and this step's MLM head stored its weight gradient over the tied vocabulary matrix (it will
+                # again next step): that range is not zeroed here - Arena.defer_vocab_zero, functional.py
+                if arena.model.ddp_hook is None and getattr(arena, 'vocab_stored', False) and _LAZY_VOCAB_ZERO:
+                    v0, vc = arena.vocab_range()
+                    if len(pieces) == 1 and pieces[0][0] <= v0 and v0 + vc <= pieces[0][1]:
+                        s, e, _ = pieces[0]
+                        pieces = [(a, b, z) for a, b, z in ((s, v0, True), (v0, v0 + vc, False), (v0 + vc, e, True)) if b > a]
+                        arena.defer_vocab_zero()
+                for s, e, zero in pieces:
                     ops.adam_step(arena.master[s:e], arena.grad[s:e], ent['m'][s:e], ent['v'][s:e], arena.w16[s:e],
                                   group['lr'], beta1, beta2, group['eps'], group['weight_decay'], step_size,
                                   gnorm_sq=ent['gnorm'] if max_norm > 0 else None, max_norm=max_norm,
-                                  grad_scale=self.grad_scale, zero_grad=True)
+                                  grad_scale=self.grad_scale, zero_grad=zero)
                 for p in r['params']:
                     self.state[p]['step'] = step
             # sharded exchange: the other ranks' shards of the updated master come back through an all-gather that the

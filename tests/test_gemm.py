@@ -324,7 +324,7 @@ def test_gemm_nt_at_the_benchmarked_sizes(M, N, K):
 def test_gelu_byte_derivative_and_its_dgrad(M, N, K):
     """FFN activation with gelu'(u) kept as ONE byte per element (m3p_gelu_fwd_gq) and the data gradient that consumes it
     (M3P_EPI_MULQ: dU = (dY W) * decode(code), column sums): h against torch's erf-GELU, the decoded derivative against
-    the exact one within the code's half step (1.26 / 255 / 2 = 2.5e-3), the product tightly against the fp32 product times
+    the exact one within the code's half step (2.5e-3; dead and saturated units decode to exactly 0 and 1), the product tightly against the fp32 product times
     the decoded derivative and - the bar that matters for training - against the exact derivative."""
     from m3p_amd import ops, lib as L
     g = torch.Generator(device='cuda').manual_seed(M + N + K)
@@ -336,6 +336,7 @@ def test_gelu_byte_derivative_and_its_dgrad(M, N, K):
     exact = 0.5 * (1 + torch.erf(x / math.sqrt(2))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi)
     dec = ops.gq_unpack(gq, M, N)
     assert float((dec - exact).abs().max()) <= 0.5 * ops.GQ_STEP + 1e-5
+    assert abs(float(dec[0, 4]) - 1.0) < 1e-6 and abs(float(dec[0, 5])) < 1e-6          # u = +9 / -9: the grid contains both ends
     a = (torch.randn((M, K), device='cuda', generator=g)).to(torch.bfloat16)
     w = (torch.randn((N, K), device='cuda', generator=g) * 0.05).to(torch.bfloat16)
     ref = _ref_on_gpu(a, w)

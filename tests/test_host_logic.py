@@ -143,3 +143,25 @@ def test_state_dict_is_the_reference_enumeration_and_checkpoints_round_trip(gold
     back = torch.load(out, map_location='cpu', weights_only=False)
     assert set(back.keys()) == {'model', 'params'} and sorted(back['model'].keys()) == sorted(ref.keys())
     assert all(torch.equal(back['model'][k], want[k]) for k in want)
+
+
+def test_store_range_check_sees_every_parameter_the_pad_rows_reach():
+    """MLMHeadFn.backward may STORE the tied matrix's weight gradient over grad[o : o + V_pad * d] only if nothing that overlaps the
+    range has been written since zero_grad - the pad rows reach past the matrix into whatever follows it in the arena (ADVICE r4:
+    with a wide model and few pad columns' worth of bias that is position_embeddings' gradient, not only the bias's)."""
+    from types import SimpleNamespace
+    from m3p_amd.functional import Arena
+    V, d, V_pad = 1000, 64, 1024                       # pad rows: 24 * 64 = 1536 elements > V = 1000 bias elements
+    offsets = {'embeddings.weight': (0, V * d, (V, d)), 'pred_layer.proj.bias': (V * d, V, (V,)),
+               'position_embeddings.weight': (V * d + 1024, 512 * d, (512, d)), 'layer_norm_emb.weight': (V * d + 1024 + 512 * d, d, (d,))}
+    ar = SimpleNamespace(offsets=offsets, touched=set())
+    fresh = lambda: Arena.range_untouched(ar, 0, V_pad * d)    # noqa: E731
+    assert fresh()
+    ar.touched = {'layer_norm_emb.weight'}              # behind the range: harmless
+    assert fresh()
+    ar.touched = {'position_embeddings.weight'}         # a no-MLM accumulation micro-step wrote it; the pad rows would wipe it
+    assert not fresh()
+    ar.touched = {'pred_layer.proj.bias'}
+    assert not fresh()
+    ar.touched = {'embeddings.weight'}
+    assert not fresh()

@@ -13,6 +13,95 @@ from tests.util import encoder_keep_masks, rel_l2, max_abs
 
 pytestmark = pytest.mark.gpu
 
+# 'mid': the cfg2 width at a short ragged sequence; 'large': the geometry of BASELINE configs[3] (M3P-large: d=1024,
+# 16 heads, 100 regions + 256 tokens = 356 keys -> the 12-step attention instantiation) at 2 layers / small V;
+# 'tiny': smallest shapes: one region, six tokens, two sequences, head dim 32, one layer, one MLM target each.
+# 'tiles' / 'tiles768' (round 5): sizes at which EVERY whole-tile branch of the benchmarked dispatch fires - M = B * S and the
+# number of predicted rows are multiples of 256 (M >= 1024, n = 4096): lin1 + GELU + one-byte gelu' epilogue, byte-decoding dU
+# epilogue, vocabulary projection with block statistics, vocabulary data gradient on the four-wave (tile, K-chunk) kernel, paired
+# out_lin + q/k/v weight gradient, and - 'tiles768' only: cfg2's own layer geometry (d = 768, 12 heads, 36 + 128 positions: the
+# 6-step / 11-tile attention instantiation, K = 3072 products on the four-wave NT kernel) with a vocabulary of >= 1024 output
+# tiles, so that the tied matrix's weight gradient is dealt out as whole tiles and STORED instead of accumulated.
+CFGS = {'mid': dict(emb_dim=768, n_heads=12, n_layers=2, n_words=5000, T=40, R=36, B=6, n_pred=6),
+        'large': dict(emb_dim=1024, n_heads=16, n_layers=2, n_words=5000, T=256, R=100, B=4, n_pred=38),
+        'tiny': dict(emb_dim=128, n_heads=4, n_layers=1, n_words=300, T=6, R=1, B=2, n_pred=1),
+        'tiles': dict(emb_dim=256, n_heads=4, n_layers=2, n_words=5000, T=48, R=16, B=256, n_pred=16),
+        'tiles768': dict(emb_dim=768, n_heads=12, n_layers=1, n_words=88000, T=128, R=36, B=128, n_pred=32)}
+
+
+def _cfg(name):
+    return synth.CONFIGS['cfg1'] if name == 'cfg1' else CFGS[name]
+
+
+class _DispatchSpy:
+    """Records which launches the step took: epilogues handed to ops.gemm_nt, calls of the stream-K / paired / stored forms,
+    and the return codes of the library's store entry point."""
+
+    def __init__(self, monkeypatch):
+        from m3p_amd import lib as L, ops
+        self.epilogues, self.nt_shapes, self.wgrad_zero, self.store_rc = [], [], [], []
+        self.streamk = self.pairs = 0
+        real_nt, real_sk, real_pair, real_wg = ops.gemm_nt, ops.gemm_nn_streamk, ops.gemm_wgrad_pair, ops.gemm_wgrad
+        lib = L.load()
+        real_store = lib.m3p_gemm_wgrad_store_bf16
+
+        def nt(a, w, epilogue=0, **kw):
+            self.epilogues.append(epilogue)
+            self.nt_shapes.append((epilogue, a.shape[0], kw.get('n') or w.shape[0], a.shape[1]))
+            return real_nt(a, w, epilogue, **kw)
+
+        def sk(*a, **kw):
+            self.streamk += 1
+            return real_sk(*a, **kw)
+
+        def pair(*a, **kw):
+            self.pairs += 1
+            return real_pair(*a, **kw)
+
+        def wg(*a, **kw):
+            self.wgrad_zero.append(bool(kw.get('dw_is_zero')))
+            return real_wg(*a, **kw)
+
+        def store(*a):
+            rc = real_store(*a)
+            self.store_rc.append(rc)
+            return rc
+        monkeypatch.setattr(ops, 'gemm_nt', nt)
+        monkeypatch.setattr(ops, 'gemm_nn_streamk', sk)
+        monkeypatch.setattr(ops, 'gemm_wgrad_pair', pair)
+        monkeypatch.setattr(ops, 'gemm_wgrad', wg)
+        monkeypatch.setattr(lib, 'm3p_gemm_wgrad_store_bf16', store)
+
+    def assert_benchmarked_dispatch(self, cfg, m):
+        """Every branch `bench.py`'s cfg2 / cfg3 step takes was taken here too."""
+        from m3p_amd import lib as L
+        lib = L.load()
+        d, M = cfg['emb_dim'], cfg['B'] * (cfg['T'] + cfg['R'])
+        n, Vp = cfg['B'] * cfg['n_pred'], m.arena().V_pad
+        assert M % 256 == 0 and n % 256 == 0 and n >= 4096
+        for e in (L.EPI_BIAS_GELUQ, L.EPI_MULQ, L.EPI_BIAS_LSE):
+            assert e in self.epilogues, (e, sorted(set(self.epilogues)))
+        assert L.EPI_DGELU not in self.epilogues and L.EPI_BIAS_GELU not in self.epilogues
+        assert (L.EPI_BIAS_GELUQ, M, 4 * d, d) in self.nt_shapes and (L.EPI_MULQ, M, 4 * d, d) in self.nt_shapes
+        assert (L.EPI_BIAS_LSE, n, Vp, d) in self.nt_shapes
+        # the kernels behind them (the library's own dispatch table, csrc/gemm.hip: nt_plan / wgrad_plan)
+        assert lib.m3p_gemm_nt_plan(M, 4 * d, d, L.EPI_BIAS_GELUQ) == L.KERN_NT_W8
+        assert lib.m3p_gemm_nt_plan(M, 3 * d, d, L.EPI_BIAS) == L.KERN_NT_W8
+        assert lib.m3p_gemm_nt_plan(n, Vp, d, L.EPI_BIAS_LSE) == L.KERN_NT_W8
+        if (4 * d // 256) * (d // 256) >= 9:       # (d = 256: four output tiles - the ring kernel's; tiles768 has cfg2's 36)
+            assert lib.m3p_gemm_wgrad_plan(M, 4 * d, d) == L.KERN_WGRAD_W4_CHUNKS
+            assert lib.m3p_gemm_wgrad_plan(M, d, 4 * d) == L.KERN_WGRAD_W4_CHUNKS
+        assert self.streamk == 0, 'the vocabulary data gradient fell back to stream-K'
+        assert self.pairs == cfg['n_layers'], 'out_lin + q/k/v weight gradients were not paired'
+        assert True in self.wgrad_zero, 'the tied matrix was not known to be zero when its weight gradient ran'
+        if 4 * d >= 2048:
+            assert lib.m3p_gemm_nt_plan(M, d, 4 * d, L.EPI_BIAS_DROP_RES) == L.KERN_NT_W4
+            assert lib.m3p_gemm_nt_plan(M, d, 4 * d, L.EPI_RES) == L.KERN_NT_W4
+        if lib.m3p_gemm_wgrad_plan(n, Vp, d) == L.KERN_WGRAD_W4_TILES:
+            assert self.store_rc == [0], self.store_rc           # stored, not accumulated
+        else:
+            assert self.store_rc == [-2], self.store_rc          # (tile, M-chunk) form: accumulates through the workspace
+
 
 def _build(cfg, dropout=0.0):
     from m3p_amd.model.transformer import TransformerModel
@@ -69,24 +158,21 @@ def test_cfg1_forward_losses_vs_golden(golden_dir):
         assert float(out[int(tot[b]):, b].abs().max()) == 0.0 if int(tot[b]) < out.shape[0] else True
 
 
-@pytest.mark.parametrize('cfg_name', ['cfg1', 'mid', 'large', 'tiny'])
-def test_gradients_vs_oracle(cfg_name):
+@pytest.mark.parametrize('cfg_name', ['cfg1', 'mid', 'large', 'tiny', 'tiles', 'tiles768'])
+def test_gradients_vs_oracle(cfg_name, monkeypatch):
     from oracle import ref_cpu as O
-    # 'mid': the cfg2 width at a short ragged sequence; 'large': the geometry of BASELINE configs[3] (M3P-large: d=1024,
-    # 16 heads, 100 regions + 256 tokens = 356 keys -> the 12-step attention instantiation) at 2 layers / small V
-    cfg = {'cfg1': synth.CONFIGS['cfg1'],
-           'mid': dict(emb_dim=768, n_heads=12, n_layers=2, n_words=5000, T=40, R=36, B=6, n_pred=6),
-           'large': dict(emb_dim=1024, n_heads=16, n_layers=2, n_words=5000, T=256, R=100, B=4, n_pred=38),
-           # smallest shapes: one region, six tokens, two sequences, head dim 32, one layer, one MLM target each
-           'tiny': dict(emb_dim=128, n_heads=4, n_layers=1, n_words=300, T=6, R=1, B=2, n_pred=1)}[cfg_name]
+    cfg = _cfg(cfg_name)
     m, P, sd = _build(cfg)
     m.train()
+    spy = _DispatchSpy(monkeypatch) if cfg_name.startswith('tiles') else None
     batch = synth.make_batch(cfg['T'], cfg['R'], cfg['B'], cfg['n_words'], cfg['n_pred'], seed=7)
     opt_zero = m.arena().zero_grad
     opt_zero()
     out, mlm, rel, bce = _losses(m, batch, cfg['R'])
     (mlm + bce).backward()
     torch.cuda.synchronize()
+    if spy is not None:
+        spy.assert_benchmarked_dispatch(cfg, m)
     names = list(sd.keys())
     leaves = {n: sd[n].clone().requires_grad_(True) for n in names}
     res = O.pretrain_losses(leaves, cfg['n_layers'], cfg['n_heads'], batch, cfg['R'])
@@ -144,24 +230,26 @@ def test_three_training_steps_track_golden(golden_dir):
     assert torch.equal(m.arena().w('ffns.0.lin1.weight'), after['ffns.0.lin1.weight'].to(torch.bfloat16))
 
 
-@pytest.mark.parametrize('cfg_name', ['cfg1', 'mid'])
-def test_dropout_on_training_step_vs_oracle_fed_the_same_masks(cfg_name):
+@pytest.mark.parametrize('cfg_name', ['cfg1', 'mid', 'tiles', 'tiles768'])
+def test_dropout_on_training_step_vs_oracle_fed_the_same_masks(cfg_name, monkeypatch):
     """The benchmarked configuration (dropout = attention_dropout = 0.1) end to end: every dropout site of the
     encoder (image rows, embedding, attention probabilities, attention output, FFN output, per layer) draws its keep
     mask from the counter-based hash keyed by functional._site(); the oracle is handed those very masks (NumPy twin of
     the device RNG), so output, losses and every gradient are compared element-wise with dropout switched on -
     same bars as the dropout-free parity tests."""
     from oracle import ref_cpu as O
-    cfg = {'cfg1': synth.CONFIGS['cfg1'],
-           'mid': dict(emb_dim=768, n_heads=12, n_layers=2, n_words=5000, T=40, R=36, B=6, n_pred=6)}[cfg_name]
+    cfg = _cfg(cfg_name)
     p = 0.1
     m, P, sd = _build(cfg, dropout=p)
     m.train()
+    spy = _DispatchSpy(monkeypatch) if cfg_name.startswith('tiles') else None
     batch = synth.make_batch(cfg['T'], cfg['R'], cfg['B'], cfg['n_words'], cfg['n_pred'], seed=7)
     m.arena().zero_grad()
     out, mlm, rel, bce = _losses(m, batch, cfg['R'])
     (mlm + bce).backward()
     torch.cuda.synchronize()
+    if spy is not None:
+        spy.assert_benchmarked_dispatch(cfg, m)
     keeps = encoder_keep_masks(m, m._fwd_counter, cfg['B'], cfg['T'], cfg['R'], p, p)
     frac = float(keeps['emb'].float().mean())
     assert abs(frac - (1 - p)) < 2e-2
@@ -284,3 +372,48 @@ def test_jointfwd_text_embed_override_and_its_gradient():
                    batch['image_loc'], text_embed=rows_ref)
     (o * w).sum().backward()
     assert rel_l2(rows.grad.float(), rows_ref.grad) < 5e-2
+
+
+def test_lazy_vocab_zero_changes_nothing(monkeypatch):
+    """Round 5: when a step's MLM head STORED the tied matrix's weight gradient, the fused Adam pass leaves that range of the
+    gradient arena un-zeroed (the next step's store overwrites it) - `Arena.defer_vocab_zero`.  Four steps at a size where the
+    store path runs - MLM + ITM, MLM + ITM, an ITM-ONLY step (no MLM head: the embedding scatter is the first writer and must
+    find zeros), MLM + ITM again - end in BIT-identical weights and moments with the switch on and off, and the switch was
+    actually exercised (a deferred range existed, was cleared by a store once and by a memset once)."""
+    from m3p_amd import functional as Fn, optim as Om
+    cfg = dict(emb_dim=768, n_heads=12, n_layers=1, n_words=88000, T=64, R=16, B=128, n_pred=32)     # n = 4096, 1032 output tiles
+    batch = synth.make_batch(cfg['T'], cfg['R'], cfg['B'], cfg['n_words'], cfg['n_pred'], seed=3)
+    results, events = [], []
+    for lazy in (True, False):
+        monkeypatch.setattr(Om, '_LAZY_VOCAB_ZERO', lazy)
+        m, P, sd = _build(cfg, dropout=0.1)
+        m.train()
+        opt = Om.get_optimizer(m.parameters(), 'adam_inverse_sqrt,beta1=0.9,beta2=0.98,lr=0.0001')
+        ar = m.arena()
+        ev = []
+        real_zero, real_defer = ar.ensure_zero, ar.defer_vocab_zero
+
+        def ensure_zero():
+            if ar.stale is not None:
+                ev.append('memset')
+            real_zero()
+
+        def defer():
+            ev.append('defer')
+            real_defer()
+        monkeypatch.setattr(ar, 'ensure_zero', ensure_zero)
+        monkeypatch.setattr(ar, 'defer_vocab_zero', defer)
+        for step in range(4):
+            out, mlm, rel, bce = _losses(m, batch, cfg['R'])
+            (bce if step == 2 else mlm + bce).backward()
+            opt.clip_grad_norm(5.0)
+            opt.step()
+        torch.cuda.synchronize()
+        ar.ensure_zero()
+        assert float(ar.grad.abs().max()) == 0.0
+        results.append((ar.master.clone(), [e['m'].clone() for e in opt._arenas.values()], [e['v'].clone() for e in opt._arenas.values()]))
+        events.append(ev)
+    assert events[0].count('defer') == 3 and events[0].count('memset') == 2 and events[1] == [], events
+    assert torch.equal(results[0][0], results[1][0])
+    assert all(torch.equal(a, b) for a, b in zip(results[0][1], results[1][1]))
+    assert all(torch.equal(a, b) for a, b in zip(results[0][2], results[1][2]))

@@ -30,7 +30,8 @@ for k, name in enumerate(names):
 st = torch.cuda.current_stream().cuda_stream
 M = int(os.environ.get('AB_M', '41984'))
 SHAPES = [('dW lin2', 768, 3072), ('dW lin1', 3072, 768), ('dW qkv', 2304, 768), ('dW out_lin', 768, 768)]
-ws = torch.empty(arms[0][1].m3p_gemm_wgrad_workspace_bytes(), dtype=torch.uint8, device='cuda')
+# (one zero-filled workspace per arm: since round 5 the kernels keep per-tile counters behind the slots, where earlier builds wrote tile ids)
+wss = [torch.zeros(a[1].m3p_gemm_wgrad_workspace_bytes(), dtype=torch.uint8, device='cuda') for a in arms]
 print('%-12s' % 'shape' + ''.join('%26s' % a[0] for a in arms))
 tot = [0.0] * len(arms)
 for name, N, K in SHAPES:
@@ -40,7 +41,7 @@ for name, N, K in SHAPES:
 
     def run(i, n):
         for _ in range(n):
-            rc = arms[i][1].m3p_gemm_wgrad_bf16(dy.data_ptr(), N, x.data_ptr(), K, outs[i].data_ptr(), K, M, N, K, 1.0, ws.data_ptr(), ws.numel(), st)
+            rc = arms[i][1].m3p_gemm_wgrad_bf16(dy.data_ptr(), N, x.data_ptr(), K, outs[i].data_ptr(), K, M, N, K, 1.0, wss[i].data_ptr(), wss[i].numel(), st)
             assert rc == 0, rc
     for i in range(len(arms)):
         run(i, 1)
