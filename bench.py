@@ -323,8 +323,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         evs = dp.exposed_events or []
-        exposed = [a.elapsed_time(b) for a, b, _ in evs]
-        payload = [n for _, _, n in evs]
+        exposed = [a.elapsed_time(b) for a, b, _, _ in evs]
+        payload = [n for _, _, n, _ in evs]
+        # the exposed tail, split: until the exchange stream has finished the GRADIENT buckets (an event recorded there right in
+        # front of the token-row gather) against everything behind it (the token-row gather + the scatter of the gathered rows)
+        grad_tail = [max(a.elapsed_time(t), 0.0) if t is not None else None for a, b, _, t in evs]
+        grad_tail = [min(g, x) for g, x in zip(grad_tail, exposed) if g is not None]
         e = torch.tensor([sum(exposed) / max(len(exposed), 1)], device='cuda', dtype=torch.float64)
         dist.all_reduce(e, op=dist.ReduceOp.MAX)
         # per-collective bus bandwidth: three more steps with every collective bracketed by events on the side stream
@@ -343,15 +347,40 @@ def main():
             ent = fam.setdefault('%s (%s)' % (name, kind), [0, 0.0, 0.0])
             ent[0] += 1; ent[1] += nbytes; ent[2] += ms
         dp.reducer.timings = None
-        buckets = {k: dict(MB=round(v[1] / v[0] / 1e6, 2), ms=round(v[2] / v[0], 3),
-                           busbw_GBps=round(v[1] * ((2.0 if 'allreduce' in k else 1.0) * (world - 1) / world) / (v[2] * 1e-3) / 1e9, 1))
-                   for k, v in fam.items() if v[2] > 0}
+        # Which side of SURVEY section 5's two bounds a collective lands on tells which algorithm RCCL picked: a RING moves
+        # (N-1)/N of the bytes over ONE xGMI link per hop (~153 GB/s per direction), a DIRECT exchange spreads them over all N-1
+        # links at once (an all-reduce = reduce-scatter + all-gather: twice that).
+        XGMI_LINK_GBPS = 153.0
+
+        def _bounds(name, nbytes):
+            f = (2.0 if 'allreduce' in name else 1.0) * (world - 1) / max(world, 1)
+            ring = f * nbytes / (XGMI_LINK_GBPS * 1e9) * 1e3
+            direct = ring / max(world - 1, 1)
+            return ring, direct
+        buckets = {}
+        for k, v in fam.items():
+            if v[2] <= 0:
+                continue
+            mb, ms = v[1] / v[0], v[2] / v[0]
+            ring, direct = _bounds(k, mb)
+            side = 'n/a (one rank)' if world == 1 else ('direct-like' if ms < (ring * direct) ** 0.5 else ('ring-like' if ms < 1.5 * ring else 'slower than a ring'))
+            buckets[k] = dict(MB=round(mb / 1e6, 2), ms=round(ms, 3),
+                              busbw_GBps=round(v[1] * ((2.0 if 'allreduce' in k else 1.0) * (world - 1) / world) / (v[2] * 1e-3) / 1e9, 1),
+                              ring_bound_ms=round(ring, 3), direct_bound_ms=round(direct, 3), lands=side)
+        g_tail = torch.tensor([sum(grad_tail) / max(len(grad_tail), 1)], device='cuda', dtype=torch.float64)
+        dist.all_reduce(g_tail, op=dist.ReduceOp.MAX)
         comm = dict(mode=dp.mode, exposed_ms_per_step=round(float(e.item()), 3),
+                    exposed_split_ms=dict(gradient_buckets=round(float(g_tail.item()), 3),
+                                          token_rows=round(max(float(e.item()) - float(g_tail.item()), 0.0), 3)),
+                    backend=dp.identity['backend'], ranks=dp.identity['ranks'], rccl_ranks_seen=dp.identity['devices_seen'],
+                    nccl_env={k: v for k, v in os.environ.items() if k.startswith(('NCCL_', 'RCCL_')) and 'DEBUG' not in k},
                     payload_MB_per_step=round(sum(payload) / max(len(payload), 1) / 1e6, 1), buckets=buckets,
                     reserved_cus=__import__('m3p_amd.distributed', fromlist=['x']).reserve_cus(),
                     note='exposed = compute-stream wait for the gradient collectives + token-row scatter before clip/Adam '
                          '(max over ranks); payload = bytes handed to RCCL per rank and step in backward (gradient buckets '
-                         'fp32, token rows bf16); buckets = average size / time / bus bandwidth per collective, measured on '
+                         'fp32, token rows bf16 with their ids in eight extra columns: one gather); exposed_split_ms = that wait up to the end of the gradient buckets on the '
+                         'exchange stream / the token-row gather + scatter behind it; rccl_ranks_seen = distinct devices among the ranks (all-gather of device tags); '
+                         'buckets = average size / time / bus bandwidth per collective with the ring and direct bounds of SURVEY section 5 (153 GB/s per xGMI link) and which one it lands by, measured on '
                          'rank 0 in three extra steps with each collective bracketed by events; zero1 gathers the updated '
                          'bf16 working copy during the next forward (the "params" rows; the fp32-read vectors travel in one packed all-reduce)')
 
@@ -401,7 +430,7 @@ def main():
             kname = '%s M=%d N=%d K=%d' % (kind, M, N, K)
             traffic, tsrc = None, None
             counter_clock = None
-            for rel in ('profiles/r04_traffic.json', 'profiles/r03_traffic.json', 'profiles/r02_traffic.json', 'profiles/r01_traffic.json'):
+            for rel in ('profiles/r05_traffic.json', 'profiles/r04_traffic.json', 'profiles/r03_traffic.json', 'profiles/r02_traffic.json', 'profiles/r01_traffic.json'):
                 tpath = os.path.join(ROOT, rel)
                 if os.path.exists(tpath):   # HBM bytes/launch from the committed rocprofv3 --pmc passes of this command
                     tj = json.load(open(tpath))

@@ -309,11 +309,12 @@ M3P_API int m3p_embed_assemble_bwd(const void* dh, const void* z, const float* m
 M3P_API int m3p_gather_rows(const void* src, const int32_t* idx, void* dst, int n, int d, void* stream);
 /* dst[idx[i],:] += src[i,:] (idx unique) — its backward */
 M3P_API int m3p_scatter_add_rows(const void* src, const int32_t* idx, void* dst, int n, int d, void* stream);
-/* dst[ids[i],:] (fp32 [V,d]) += rows[i,:] (bf16 [n,d]); ids may repeat (atomics), rows with ids[i] == pad_index are
- * skipped (nn.Embedding(padding_idx), transformer.py:21-26).  The embedding-lookup gradient of token rows gathered
- * from the data-parallel ranks (m3p_embed_assemble_bwd with d_tok_rows). */
-M3P_API int m3p_scatter_add_token_rows(const void* rows, const int64_t* ids, float* dst, int n, int d, int pad_index,
-                                       void* stream);
+/* dst[ids[i],:] (fp32 [V,d]) += rows[i,:] (bf16 [n,d], row pitch ld_rows elements); ids may repeat (atomics), rows with
+ * ids[i] == pad_index are skipped (nn.Embedding(padding_idx), transformer.py:21-26).  The embedding-lookup gradient of token
+ * rows gathered from the data-parallel ranks (m3p_embed_assemble_bwd with d_tok_rows); the pitch lets the exchange carry each
+ * row's id in extra columns behind it - one collective instead of two. */
+M3P_API int m3p_scatter_add_token_rows(const void* rows, int ld_rows, const int64_t* ids, float* dst, int n, int d,
+                                       int pad_index, void* stream);
 
 /* ----------------------------------------------------------------------------------
  * ITM head: transformer.py:546-558 (BertPooler: tanh(dense(hidden[:, 0]))) followed by
@@ -474,6 +475,9 @@ M3P_API int m3p_gemm_wgrad_plan(int M, int N, int K);
  * wherever it applies, 3 = ring kernels, 6 = eight-wave NT, 7 = round 1's choice, 9 = default without the skinny kernel; the
  * higher bits are ablation flags of the timeline builds.  Every launch reads it: set it only with no GEMM call in flight. */
 M3P_API void m3p_debug_set_variant(int v);
+/* The same kind of switch for the attention kernels: bit 0 = the two-phase backward (scores recomputed in both phases,
+ * rounds 1-4) instead of the one-pass form for the M3P sequence (tools/ab_attn.py). */
+M3P_API void m3p_debug_attn_variant(int v);
 
 /* ------------------------------------------------------------------------------------
  * Host-glue kernels (csrc/glue.hip): index / mask / loss arithmetic the reference does with chains of elementwise

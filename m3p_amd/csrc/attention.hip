@@ -58,6 +58,8 @@ __device__ unsigned long long g_attn_tl[4096 * 4 * 16];
 #define M3P_ATTN_BWD_NW 4
 #endif
 
+static int g_attn_variant = 0;      // developer switch (m3p_debug_attn_variant): bit 0 = the two-phase backward for the M3P sequence (A/B runs)
+
 template <int DH> struct AttnCfg {
   static constexpr int ROWB = DH * 2;        // bytes per K/V row in LDS
   static constexpr int CH = DH / 8;          // 16-B chunks per row
@@ -122,6 +124,28 @@ __device__ __forceinline__ void stage_rows(const bf16* __restrict__ g, size_t ld
     const int gr = min(row, S - 1);
     const int gc = Cf::swz(c, row);
     __builtin_amdgcn_global_load_lds(GLB_PTR(g + (size_t)gr * ld + gc * 8), LDS_PTR(lds + i * 1024), 16, 0, 0);
+  }
+}
+
+// The same transfers issued where the compiler cannot see them (persistent kernels: a tile is requested while the previous
+// one is still being computed on).  With the builtin form in flight the compiler assumes the transfer may alias ANY LDS read
+// it emits and puts s_waitcnt vmcnt(0) in front of each - the request then completes before the computation it was meant to
+// run under starts.  The caller owns the ordering: an (asm volatile) s_waitcnt vmcnt before the tile's first read.  Counted
+// vmcnt waits the compiler emits for its own loads stay correct: untracked younger operations only make them stricter.
+template <int DH>
+__device__ __forceinline__ void stage_rows_hidden(const bf16* __restrict__ g, size_t ld, int S, int nrows, char* lds,
+                                                  int wid, int lane, int nwaves) {
+  using Cf = AttnCfg<DH>;
+  const int rin = lane / Cf::CH, c = lane % Cf::CH;
+  const int ninstr = (nrows + Cf::RPI - 1) / Cf::RPI;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+  for (int i = wid; i < ninstr; i += nwaves) {
+    const int row = i * Cf::RPI + rin;
+    const int gr = min(row, S - 1);
+    const int gc = Cf::swz(c, row);
+    const bf16* src = g + (size_t)gr * ld + gc * 8;
+    const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)i * 1024u);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src), "s"(dst) : "memory", "m0");
   }
 }
 
@@ -381,8 +405,12 @@ void attn_fwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
 // transposes in phase A, K / V in phase B) are fetched once for two owned blocks: half the LDS reads per MFMA, and two
 // independent MFMA -> softmax -> MFMA chains per wave to hide each other's waits (counters, r03: the waves of this kernel
 // sit in s_waitcnt 56 % of their cycles; LDS array ~45 % busy).  Costs registers: KB = 2 runs two workgroups per CU.
-template <int DH, int KT, bool DROP, bool MASK, int NKC, int NTC, int NW = 4, int KB = 1, int KBQ = KB>
-__global__ __launch_bounds__(NW * 64, NTC == 11 ? M3P_ATTN_BWD_WPS : ((NW == 8 || KB == 2) ? 2 : 3))   // NW = 4: three 49-KB workgroups per CU; 8: one ~100-KB workgroup (long S)
+// ONEPASS (round 5; the M3P sequence only: NKC = 6, NTC = 11, twelve waves = ONE workgroup per CU): the scores are computed
+// ONCE.  Phase A leaves dS^T - bf16, [key][query], 60.5 KB - in LDS beside Q / dO / K (all four operand tiles of the head
+// are fetched once: 516 MB per launch instead of 813), and phase B is four MFMAs per 32-key step, dQ^T = K^T dS^T, both
+// operands through transposing LDS reads - no second QK^T / dO V^T, no second softmax, no V tile, no Q / dO fragments.
+template <int DH, int KT, bool DROP, bool MASK, int NKC, int NTC, int NW = 4, int KB = 1, int KBQ = KB, bool ONEPASS = false>
+__global__ __launch_bounds__(NW * 64, NTC == 11 ? M3P_ATTN_BWD_WPS : ((NW == 8 || KB == 2) ? 2 : 3))   // NW = 4: three 49-KB workgroups per CU; 8: one ~100-KB workgroup (long S); 12 (ONEPASS): one 143-KB workgroup, three waves per SIMD
 void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keylen, const bf16* __restrict__ ctx,
                      const bf16* __restrict__ dctx, const float* __restrict__ lse,
                      const unsigned long long* __restrict__ keepmask, bf16* __restrict__ dqkv,
@@ -428,6 +456,13 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
   const int fq = lane & 15, fg = lane >> 4;
   float* sB = sD + nk * 32;           // [NW waves][3][DH] bias-gradient accumulators (q | k | v), one slot per wave
   float* sBw = sB + wid * 3 * DH;
+  // ONEPASS: the K tile (staged with Q / dO, read in phase B) and dS^T [NTC * 16 keys][NTC * 16 queries] bf16 behind them.  Row
+  // pitch 352 B = 11 x 32: the 16 rows x 32 B a transposing read (or phase A's store) touches then fall on distinct 32-B bank
+  // groups for any eight consecutive rows.
+  constexpr int DSP = NTC * 32;
+  char* sK = reinterpret_cast<char*>(sB + NW * 3 * DH);
+  char* sDS = sK + tile_bytes;
+  static_assert(!ONEPASS || (NKC == 6 && NTC == 11 && KB == 1 && DH == 64), "ONEPASS is the M3P-sequence instantiation");
   // bias gradients = column sums of the bf16 dQ/dK/dV rows this block writes.  Each lane keeps running sums of ITS rows in
   // registers (part x d-tile x 4 columns); the reduction over the 16 lanes (fq) that hold different rows of the same columns
   // happens once per phase - four DPP adds per value - into the wave's LDS slot, and the slots are summed at the end of the
@@ -491,6 +526,7 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
   }
   stage_rows<DH>(Qg, ld, S, nk * 32, s0, wid, lane, NW);
   stage_rows<DH>(dOg, (size_t)dmodel, S, nk * 32, s1, wid, lane, NW);
+  if (ONEPASS) stage_rows<DH>(Kg, ld, S, nk * 32, sK, wid, lane, NW);      // (behind dO: the D prologue waits for this wave's dO rows with vmcnt(0) anyway)
   bf16x8 kf[KB][Cf::KK], vf[KB][Cf::KK];
   auto load_kv = [&](int u, int kb) {
     const int keyc = min(kb * 16 + fq, S - 1);
@@ -706,6 +742,19 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
         sfrag[u] = bf16x8{(bf16)ds2[0][0], (bf16)ds2[0][1], (bf16)ds2[0][2], (bf16)ds2[0][3],
                           (bf16)ds2[1][0], (bf16)ds2[1][1], (bf16)ds2[1][2], (bf16)ds2[1][3]};
       }
+      if constexpr (ONEPASS) {
+        // dS^T[key = 16 kb0 + fq][query = 16 t + 4 fg + r] - this lane's four values of a tile are four consecutive queries of
+        // its key row: one 8-byte LDS store per tile
+        if (kb0 < NTC) {
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf) {
+            if (PAD_TILE(2 * kq + hf)) continue;
+            const bf16x4 d4 = hf ? bf16x4{sfrag[0][4], sfrag[0][5], sfrag[0][6], sfrag[0][7]}
+                                 : bf16x4{sfrag[0][0], sfrag[0][1], sfrag[0][2], sfrag[0][3]};
+            *reinterpret_cast<bf16x4*>(sDS + (kb0 * 16 + fq) * DSP + (32 * kq + 16 * hf + 4 * fg) * 2) = d4;
+          }
+        }
+      }
       STEP_SEG(13);      // 13: P / dS built (waits for the MFMA results, the keep words, lse / D)
       if (kPreA) {      // (behind the last step of a block: the first steps of the next owned block, clamped on the last one)
         if (kq + 2 < nk) mask_words_A(kb0, kq + 2, kq & 1);
@@ -757,6 +806,46 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
   __syncthreads();   // everyone done with Q / dO tiles
   BTL(4);
 
+  if constexpr (ONEPASS) {
+    // ================= phase B, one-pass form: dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q] =================
+    // A operand: K^T through transposing reads of the K tile (rows = keys), B operand: dS^T through transposing reads of the
+    // tile phase A left (rows = keys, this wave's 16 query columns) - lane fq holds query column fq, keys 4 fg + r of both
+    // 16-key tiles of the step, exactly the contraction order of the K^T fragment.
+    BTL(5);
+    for (int qb = wid; qb < nt; qb += NW) {
+      f32x4 dq[Cf::NT];
+#pragma unroll
+      for (int n = 0; n < Cf::NT; ++n) dq[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const char* pds = sDS + trow * DSP + qb * 32 + (fq & 3) * 8;
+#pragma unroll
+      for (int kq = 0; kq < NKC; ++kq) {
+        const bf16x4 lo = lds_tr16(pds + (32 * kq) * DSP);
+        const bf16x4 hi = PAD_TILE(2 * kq + 1) ? bf16x4{0, 0, 0, 0} : lds_tr16(pds + (32 * kq + 16) * DSP);
+        const bf16x8 sfr = cat8(lo, hi);
+#pragma unroll
+        for (int n = 0; n < Cf::NT; ++n) {
+          const char* pk = sK + kq * 32 * Cf::ROWB + t_off[n];
+          const bf16x8 kT = cat8(lds_tr16(pk), lds_tr16(pk + 16 * Cf::ROWB));
+          dq[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kT, sfr, dq[n], 0, 0, 0);
+        }
+      }
+      const int q = qb * 16 + fq;
+      if (q < S) {
+        bf16* pq = dQg + (size_t)q * ld + 4 * fg;
+#pragma unroll
+        for (int n = 0; n < Cf::NT; ++n)
+          *reinterpret_cast<bf16x4*>(pq + 16 * n) = bf16x4{(bf16)(dq[n][0] * qscale), (bf16)(dq[n][1] * qscale), (bf16)(dq[n][2] * qscale),
+                                                           (bf16)(dq[n][3] * qscale)};
+      }
+      if (dbias_qkv) {
+#pragma unroll
+        for (int n = 0; n < Cf::NT; ++n)
+          bias_acc(0, n, q < S ? bf16x4{(bf16)(dq[n][0] * qscale), (bf16)(dq[n][1] * qscale), (bf16)(dq[n][2] * qscale),
+                                        (bf16)(dq[n][3] * qscale)} : bf16x4{0, 0, 0, 0});
+      }
+    }
+    BTL(6);
+  } else {
   // ================= phase B: dQ (wave owns query blocks) =================
   stage_rows<DH>(Kg, ld, S, nk * 32, s0, wid, lane, NW);
   stage_rows<DH>(Vg, ld, S, nk * 32, s1, wid, lane, NW);
@@ -939,6 +1028,7 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
     BTL_SUM(11, tw);
   }
   BTL(6);
+  }      // (two-phase form)
 
   // ---- bias gradients: column sums of the bf16 dQ / dV rows this block wrote (k: zero, see above)
   if (dbias_qkv) {
@@ -962,6 +1052,331 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
 }
 
 #undef PAD_TILE
+
+// ---------------------------------------------------------------------------------------
+// backward, PERSISTENT one-pass form for the M3P sequence (round 5): 64-wide heads, 36 regions + 128 tokens = 11 tiles /
+// 6 steps, keep bits from the forward pass (or no dropout).  One twelve-wave workgroup per CU walks its share of the
+// (batch, head) pairs; per head
+//   [D = rowsum(dO O), lse -> LDS] B1 [K tile requested; phase A: each wave one 16-key block - S, dPd once, P / dS, dV, dK,
+//   dS^T -> LDS] B2 [dK / dV stored; the NEXT head's Q / dO tiles, O chunks, K / V fragments, lse, keep words requested;
+//   phase B: each wave one 16-query block, dQ^T = K^T dS^T, four MFMAs per 32-key step].
+// What the timeline of the plain one-pass kernel (profiles/r05_attn_bwd_onepass_timeline.txt) showed: of 31.5 k ticks a head
+// spends in its workgroup, 12.4 k are the two phases - the rest is the prologue's memory latency (11.1 k), barriers that wait
+// for global STORES (__syncthreads' vmcnt(0): 5.4 k) and the exit (2.6 k), none of which three independent four-wave
+// workgroups per CU hid any worse.  Here the next head's loads fly under phase B and the K tile's under phase A, the barriers
+// wait for LDS only, and the stores are never waited for inside the loop.
+// ---------------------------------------------------------------------------------------
+template <bool DROP, bool MASK>
+__global__ __launch_bounds__(768, 3)
+void attn_bwd_p_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keylen, const bf16* __restrict__ ctx,
+                       const bf16* __restrict__ dctx, const float* __restrict__ lse,
+                       const unsigned long long* __restrict__ keepmask, bf16* __restrict__ dqkv,
+                       float* __restrict__ dbias_qkv, int S, int H, int dmodel, int nheads, float qscale, float inv_keep,
+                       int stagger) {
+  constexpr int DH = 64, NW = 12, NKC = 6, NTC = 11, NR = NKC * 32;
+  using Cf = AttnCfg<DH>;
+  constexpr int DSP = NTC * 32;                      // row pitch of dS^T: 352 B (see attn_bwd_kernel, ONEPASS)
+  constexpr int TILE = NR * Cf::ROWB;                // 24 576 B
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  char* s0 = smem;                                   // Q
+  char* s1 = s0 + TILE;                              // dO
+  char* sK = s1 + TILE;                              // K (phase B)
+  char* sDS = sK + TILE;                             // dS^T [176 keys][176 queries] bf16
+  float* sL = reinterpret_cast<float*>(sDS + NTC * 16 * DSP);
+  float* sD = sL + NR;
+  float* sB = sD + NR;                               // [2 heads in flight][NW][3][DH] bias-gradient partial sums
+  const size_t ld = 3 * (size_t)dmodel;
+  const int fq = lane & 15, fg = lane >> 4;
+  const int rin = lane / Cf::CH, c8 = lane % Cf::CH;
+  int r_off[Cf::KK];
+#pragma unroll
+  for (int kk = 0; kk < Cf::KK; ++kk) r_off[kk] = fq * Cf::ROWB + Cf::swz(4 * kk + fg, fq) * 16;
+  const int trow = 4 * fg + (fq >> 2);
+  int t_off[Cf::NT];
+#pragma unroll
+  for (int n = 0; n < Cf::NT; ++n)
+    t_off[n] = trow * Cf::ROWB + Cf::swz(2 * n + ((fq & 3) >> 1), trow) * 16 + 8 * (fq & 1);
+  constexpr float kLog2e = 1.4426950408889634f;
+  constexpr float kMasked = -1.0e30f;
+  const float log2_inv_keep = DROP ? __builtin_amdgcn_logf(inv_keep) : 0.f;
+  const float keep_prob = DROP ? __builtin_amdgcn_rcpf(inv_keep) : 1.f;
+  constexpr int kStageInstr = NR / Cf::RPI;                       // 24 LDS-DMA instructions per tile
+  constexpr int kNIW = (kStageInstr + NW - 1) / NW;               // 2 of them per wave
+#define PAD_TILE(t) ((t) >= NTC)
+
+  // ---- what a head needs from global memory before its phase A; requested a head ahead
+  bf16x8 orow[kNIW], kf[Cf::KK], vf[Cf::KK];
+  float lse_r = 0.f;
+  unsigned long long mwA[2][2];
+  auto mask_words = [&](const unsigned long long* mbh, int kq_, int par_) {
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+      mwA[par_][hf] = mbh[((size_t)min(2 * kq_ + hf, NTC - 1) * NTC + min(wid, NTC - 1)) * 4 + (fq & 3)];
+  };
+  auto request_head = [&](int hd) {
+    const int b = hd / H, h = hd - b * H;
+    const bf16* Qg = qkv + (size_t)b * S * ld + h * DH;
+    const bf16* Og = ctx + (size_t)b * S * dmodel + h * DH;
+    const bf16* dOg = dctx + (size_t)b * S * dmodel + h * DH;
+#pragma unroll
+    for (int j = 0; j < kNIW; ++j) {
+      const int row = (wid + j * NW) * Cf::RPI + rin;
+      orow[j] = *reinterpret_cast<const bf16x8*>(Og + (size_t)min(row, S - 1) * dmodel + Cf::swz(c8, row) * 8);
+    }
+    stage_rows_hidden<DH>(Qg, ld, S, NR, s0, wid, lane, NW);
+    stage_rows_hidden<DH>(dOg, (size_t)dmodel, S, NR, s1, wid, lane, NW);
+    const int keyc = min(min(wid, NTC - 1) * 16 + fq, S - 1);
+#pragma unroll
+    for (int kk = 0; kk < Cf::KK; ++kk) {
+      kf[kk] = *reinterpret_cast<const bf16x8*>(Qg + dmodel + (size_t)keyc * ld + 32 * kk + 8 * fg);
+      vf[kk] = *reinterpret_cast<const bf16x8*>(Qg + 2 * dmodel + (size_t)keyc * ld + 32 * kk + 8 * fg);
+    }
+    if (tid < NR && tid < S) lse_r = lse[(size_t)hd * S + tid];      // (raw: arithmetic on it here would wait for the load here)
+    if (MASK) {
+      const unsigned long long* mbh = keepmask + (size_t)hd * NTC * NTC * 4;
+      mask_words(mbh, 0, 0);
+      mask_words(mbh, 1, 1);
+    }
+  };
+
+  f32x4 bsum[Cf::NT];
+#pragma unroll
+  for (int n = 0; n < Cf::NT; ++n) bsum[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto bias_acc = [&](int n, const bf16x4& v4) { bsum[n] += f32x4{(float)v4[0], (float)v4[1], (float)v4[2], (float)v4[3]}; };
+  auto bias_flush = [&](float* slot, int part) {
+#pragma unroll
+    for (int n = 0; n < Cf::NT; ++n) {
+      f32x4 x = bsum[n];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) x[r] = row16_sum(x[r]);
+      if (fq == 0) *reinterpret_cast<f32x4*>(slot + part * DH + 16 * n + 4 * fg) = x;
+      bsum[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto bias_reduce = [&](const float* slots, int h) {
+    for (int i = tid; i < 3 * DH; i += NW * 64) {
+      const int part = i / DH, c = i - part * DH;
+      if (part != 1) {      // (k-bias: identically zero, see attn_bwd_kernel)
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) tot += slots[w * 3 * DH + i];
+        atomicAdd(dbias_qkv + part * dmodel + h * DH + c, tot);
+      }
+    }
+  };
+
+  // a head's results: row `key` (= this lane's key of block `wid` in phase A, its query of block `wid` in phase B) of dK, dV, dQ
+  bf16x4 kb4[Cf::NT], vb4[Cf::NT], qb4[Cf::NT];
+  const int key = wid * 16 + fq;
+  bf16* dQg_prev = nullptr;
+  auto store_head = [&](bf16* dQh) {
+    if (wid < NTC && key < S) {
+      bf16* pq = dQh + (size_t)key * ld + 4 * fg;
+#pragma unroll
+      for (int n = 0; n < Cf::NT; ++n) {
+        *reinterpret_cast<bf16x4*>(pq + 16 * n) = qb4[n];
+        *reinterpret_cast<bf16x4*>(pq + dmodel + 16 * n) = kb4[n];
+        *reinterpret_cast<bf16x4*>(pq + 2 * dmodel + 16 * n) = vb4[n];
+      }
+    }
+  };
+  int hd = blockIdx.x;
+  if (hd >= nheads) return;
+  // staggered start: the workgroups of a launch all fetch, then all compute.  Four phases a fraction of a head apart spread the
+  // fetch bursts (183.1 -> 180.5 us at 2 x 1024 clocks per phase, nothing beyond: tools/ab_attn.py, profiles/r05_attn_bwd_ab.txt);
+  // the late starters' tail is 1 / 12 of what it was in the GEMMs (twelve heads per workgroup).
+  for (int i = 0; i < (int)((blockIdx.x >> 3) & 3) * stagger; ++i) __builtin_amdgcn_s_sleep(16);
+  request_head(hd);
+  int par = 0, prev_h = -1;
+  // -DM3P_ATTN_TL: s_memtime sums per segment over this workgroup's heads (tools/attn_bwd_p_timeline.py): 0 wait for the head's
+  // requests, 1 D / lse + barrier 1, 2 previous head's bias sums + stores, K request, 3 phase A, 4 bias flush + barrier 2,
+  // 5 next head's requests, 6 phase B, 7 heads
+#ifdef M3P_ATTN_TL
+  unsigned long long ptl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long pt0 = __builtin_amdgcn_s_memtime(), pt1;
+#define PSEG(k) do { __builtin_amdgcn_sched_barrier(0); pt1 = __builtin_amdgcn_s_memtime(); ptl[k] += pt1 - pt0; pt0 = pt1; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define PSEG(k) do { } while (0)
+#endif
+  for (;;) {
+    const int b = hd / H, h = hd - b * H;
+    bf16* dQg = dqkv + (size_t)b * S * ld + h * DH;
+    const bf16* Kg = qkv + (size_t)b * S * ld + h * DH + dmodel;
+    const int klen = keylen[b];
+    const unsigned long long* mbh = MASK ? keepmask + (size_t)hd * NTC * NTC * 4 : nullptr;
+    float* sBh = sB + par * (NW * 3 * DH);
+    // ---- D[q] = rowsum(dO O) keep, lse -> LDS.  This wave's dO rows (its own LDS-DMA) and O chunks have landed after its vmcnt.
+    // (__builtin_amdgcn_s_waitcnt, not inline asm: the compiler's own wait insertion must KNOW this wait happened - behind an
+    //  opaque asm it assumed the requests of the previous trip still pending and protected every register they target with a
+    //  vmcnt(0) in the middle of the next request.  Only LOADS are outstanding here: a head's dK / dV / dQ rows are stored
+    //  behind the NEXT head's first barrier, with a whole phase A to complete in before anything waits for vmcnt again.)
+    __builtin_amdgcn_s_waitcnt(0x0F70);                               // vmcnt(0)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // (the tiles' transfers are invisible to the compiler: this one cannot be dropped)
+    PSEG(0);
+#pragma unroll
+    for (int j = 0; j < kNIW; ++j) {
+      const int i = wid + j * NW;
+      if (i < kStageInstr) {
+        const bf16x8 dvv = *reinterpret_cast<const bf16x8*>(s1 + i * 1024 + lane * 16);
+        float part = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) part += (float)orow[j][e] * (float)dvv[e];
+        part = chunks_sum<Cf::CH>(part);
+        const int row = i * Cf::RPI + rin;
+        if (c8 == 0) sD[row] = row < S ? part * keep_prob : 0.f;
+      }
+    }
+    if (tid < NR) sL[tid] = tid < S ? lse_r * kLog2e - log2_inv_keep : INFINITY;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                  // B1: Q, dO, D, lse in place; phase B of the previous head over
+    asm volatile("" ::: "memory");
+    PSEG(1);
+    if (prev_h >= 0 && dbias_qkv) bias_reduce(sB + (par ^ 1) * (NW * 3 * DH), prev_h);
+    if (prev_h >= 0) store_head(dQg_prev);
+    dQg_prev = dQg;
+    stage_rows_hidden<DH>(Kg, ld, S, NR, sK, wid, lane, NW);       // lands under phase A
+    PSEG(2);
+    // ================= phase A: dV, dK, dS^T (this wave: key block `wid`) =================
+    if (wid < NTC) {
+      const float kbias = (key < klen) ? 0.f : kMasked;
+      f32x4 dv[Cf::NT], dk[Cf::NT];
+#pragma unroll
+      for (int n = 0; n < Cf::NT; ++n) dv[n] = dk[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kq = 0; kq < NKC; ++kq) {
+        f32x4 scA[2], dpA[2], dnegA[2];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          const int t = 2 * kq + hf;
+          dnegA[hf] = f32x4{-sD[16 * t + 4 * fg + 0], -sD[16 * t + 4 * fg + 1], -sD[16 * t + 4 * fg + 2], -sD[16 * t + 4 * fg + 3]};
+          scA[hf] = f32x4{kbias, kbias, kbias, kbias};
+          dpA[hf] = DROP ? f32x4{0.f, 0.f, 0.f, 0.f} : dnegA[hf];
+        }
+#pragma unroll
+        for (int kk = 0; kk < Cf::KK; ++kk) {
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf) {
+            const int t = 2 * kq + hf;
+            if (PAD_TILE(t)) continue;
+            const bf16x8 qf = *reinterpret_cast<const bf16x8*>(s0 + t * 16 * Cf::ROWB + r_off[kk]);
+            const bf16x8 df = *reinterpret_cast<const bf16x8*>(s1 + t * 16 * Cf::ROWB + r_off[kk]);
+            scA[hf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf[kk], scA[hf], 0, 0, 0);   // S[q][key]
+            dpA[hf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, vf[kk], dpA[hf], 0, 0, 0);   // dPd[q][key]
+          }
+        }
+        f32x4 pd2[2], ds2[2];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          const int t = 2 * kq + hf;
+          if (PAD_TILE(t)) {
+            pd2[hf] = ds2[hf] = f32x4{0.f, 0.f, 0.f, 0.f};
+            continue;
+          }
+          uint32_t kbits = 0;
+          if (MASK) kbits = (uint32_t)(mwA[kq & 1][hf] >> (4 * fg + 16 * (fq >> 2)));
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int q = 16 * t + 4 * fg + r;
+            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(scA[hf][r], kLog2e, -sL[q]));   // padded q: lse = +inf -> 0
+            if (DROP) {      // p = P / keep here, dneg = -D keep
+              const float pd = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, p) & bit_to_mask(kbits, r));
+              pd2[hf][r] = pd;
+              ds2[hf][r] = __builtin_fmaf(pd, dpA[hf][r], p * dnegA[hf][r]);
+            } else {
+              pd2[hf][r] = p;
+              ds2[hf][r] = p * dpA[hf][r];
+            }
+          }
+        }
+        const bf16x8 pfrag = bf16x8{(bf16)pd2[0][0], (bf16)pd2[0][1], (bf16)pd2[0][2], (bf16)pd2[0][3],
+                                    (bf16)pd2[1][0], (bf16)pd2[1][1], (bf16)pd2[1][2], (bf16)pd2[1][3]};
+        const bf16x8 sfrag = bf16x8{(bf16)ds2[0][0], (bf16)ds2[0][1], (bf16)ds2[0][2], (bf16)ds2[0][3],
+                                    (bf16)ds2[1][0], (bf16)ds2[1][1], (bf16)ds2[1][2], (bf16)ds2[1][3]};
+        // dS^T[key][query]: this lane's four values of a tile are four consecutive queries of its key row
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          if (PAD_TILE(2 * kq + hf)) continue;
+          *reinterpret_cast<bf16x4*>(sDS + key * DSP + (32 * kq + 16 * hf + 4 * fg) * 2) =
+              hf ? bf16x4{sfrag[4], sfrag[5], sfrag[6], sfrag[7]} : bf16x4{sfrag[0], sfrag[1], sfrag[2], sfrag[3]};
+        }
+        if (MASK && kq + 2 < NKC) mask_words(mbh, kq + 2, kq & 1);      // keep words two steps ahead (each is an L2 miss)
+#pragma unroll
+        for (int n = 0; n < Cf::NT; ++n) {
+          const char* pq = s0 + kq * 32 * Cf::ROWB + t_off[n];
+          const char* pdo = s1 + kq * 32 * Cf::ROWB + t_off[n];
+          const bf16x8 qT = cat8(lds_tr16(pq), lds_tr16(pq + 16 * Cf::ROWB));
+          const bf16x8 dT = cat8(lds_tr16(pdo), lds_tr16(pdo + 16 * Cf::ROWB));
+          dv[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dT, pfrag, dv[n], 0, 0, 0);
+          dk[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qT, sfrag, dk[n], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int n = 0; n < Cf::NT; ++n) {
+        kb4[n] = bf16x4{(bf16)dk[n][0], (bf16)dk[n][1], (bf16)dk[n][2], (bf16)dk[n][3]};
+        vb4[n] = bf16x4{(bf16)dv[n][0], (bf16)dv[n][1], (bf16)dv[n][2], (bf16)dv[n][3]};
+        if (dbias_qkv) bias_acc(n, key < S ? vb4[n] : bf16x4{0, 0, 0, 0});
+      }
+    }
+    PSEG(3);
+    if (dbias_qkv) bias_flush(sBh + wid * 3 * DH, 2);
+    // B2: dS^T complete, the K tile landed (each wave waits for its own pieces; no store is outstanding - dK / dV go out below)
+    __builtin_amdgcn_s_waitcnt(0);                       // vmcnt(0) expcnt(0) lgkmcnt(0)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    PSEG(4);
+    const int next = hd + gridDim.x;
+    if (next < nheads) request_head(next);             // Q / dO tiles are free: everyone is past phase A
+    PSEG(5);
+    // ================= phase B: dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q] (this wave: query block `wid`) =================
+    if (wid < NTC) {
+      f32x4 dq[Cf::NT];
+#pragma unroll
+      for (int n = 0; n < Cf::NT; ++n) dq[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const char* pds = sDS + trow * DSP + wid * 32 + (fq & 3) * 8;
+#pragma unroll
+      for (int kq = 0; kq < NKC; ++kq) {
+        const bf16x4 lo = lds_tr16(pds + (32 * kq) * DSP);
+        const bf16x4 hi = PAD_TILE(2 * kq + 1) ? bf16x4{0, 0, 0, 0} : lds_tr16(pds + (32 * kq + 16) * DSP);
+        const bf16x8 sfr = cat8(lo, hi);
+#pragma unroll
+        for (int n = 0; n < Cf::NT; ++n) {
+          const char* pk = sK + kq * 32 * Cf::ROWB + t_off[n];
+          const bf16x8 kT = cat8(lds_tr16(pk), lds_tr16(pk + 16 * Cf::ROWB));
+          dq[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kT, sfr, dq[n], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int n = 0; n < Cf::NT; ++n) {
+        qb4[n] = bf16x4{(bf16)(dq[n][0] * qscale), (bf16)(dq[n][1] * qscale), (bf16)(dq[n][2] * qscale), (bf16)(dq[n][3] * qscale)};
+        if (dbias_qkv) bias_acc(n, key < S ? qb4[n] : bf16x4{0, 0, 0, 0});
+      }
+    }
+    if (dbias_qkv) bias_flush(sBh + wid * 3 * DH, 0);
+    PSEG(6);
+#ifdef M3P_ATTN_TL
+    ptl[7] += 1;
+#endif
+    prev_h = h;
+    par ^= 1;
+    if (next >= nheads) break;
+    hd = next;
+  }
+  store_head(dQg_prev);
+  if (dbias_qkv) {
+    __syncthreads();
+    bias_reduce(sB + (par ^ 1) * (NW * 3 * DH), prev_h);
+  }
+#ifdef M3P_ATTN_TL
+  if (lane == 0 && wid < 4 && blockIdx.x < 4096)
+    for (int k = 0; k < 8; ++k) g_attn_tl[(blockIdx.x * 4 + wid) * 16 + k] = ptl[k];
+#endif
+#undef PSEG
+#undef PAD_TILE
+}
 
 template <int DH>
 int launch_fwd(const bf16* qkv, const int* keylen, bf16* ctx, float* lse, unsigned long long* keepmask, int B, int S, int H,
@@ -998,20 +1413,47 @@ int launch_bwd(const bf16* qkv, const int* keylen, const bf16* ctx, const bf16* 
   const bool wide = (size_t)2 * ((size_t)2 * nk * 32 * DH * 2) > 160 * 1024;   // one workgroup per CU anyway: eight waves
   // the M3P sequence (36 regions + 128 tokens: 11 tiles, 6 steps): M3P_ATTN_BWD_KB blocks per wave pass, M3P_ATTN_BWD_NW waves
   const bool m3p_seq = nk == 6 && (S + 15) / 16 == 11;
-  const int nwaves = wide ? 8 : (m3p_seq ? M3P_ATTN_BWD_NW : 4);
-  const size_t lds = (size_t)2 * nk * 32 * DH * 2 + (size_t)2 * nk * 32 * sizeof(float) + 3 * nwaves * DH * sizeof(float);
+#ifndef M3P_ATTN_BWD_ONEPASS
+#define M3P_ATTN_BWD_ONEPASS 1
+#endif
+  // the one-pass form: 64-wide heads of the M3P sequence, keep bits from the forward pass or no dropout
+  const bool onepass = M3P_ATTN_BWD_ONEPASS && m3p_seq && DH == 64 && (!thresh24 || keepmask) && !(g_attn_variant & 1);
+  const int nwaves = wide ? 8 : (onepass ? 12 : (m3p_seq ? M3P_ATTN_BWD_NW : 4));
+  const size_t lds = (size_t)2 * nk * 32 * DH * 2 + (size_t)2 * nk * 32 * sizeof(float) + 3 * nwaves * DH * sizeof(float) +
+                     (onepass ? (size_t)nk * 32 * DH * 2 + (size_t)11 * 16 * 11 * 32 : 0);
 #define M3P_ATTN_BWD(KT, DROP, MASK)                                                                            \
   do {                                                                                                          \
     auto kern = attn_bwd_kernel<DH, KT, DROP, MASK, 0, 0>;                                                      \
     if (wide) kern = attn_bwd_kernel<DH, KT, DROP, MASK, 0, 0, 8>;                                              \
     if (nk == 6) kern = attn_bwd_kernel<DH, KT, DROP, MASK, 6, 0>;                                              \
     if (m3p_seq) kern = attn_bwd_kernel<DH, KT, DROP, MASK, 6, 11, M3P_ATTN_BWD_NW, M3P_ATTN_BWD_KB, M3P_ATTN_BWD_KBQ>;           \
+    if constexpr (DH == 64 && (MASK || !DROP)) { if (onepass) kern = attn_bwd_kernel<DH, KT, DROP, MASK, 6, 11, 12, 1, 1, true>; } \
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     if (e != hipSuccess) return (int)e;                                                                         \
     hipLaunchKernelGGL(kern, dim3(B* H), dim3(nwaves * 64), lds, st, qkv, keylen, ctx, dctx, lse, keepmask, dqkv, dbias, S, H, \
                        dmodel, qscale, seed, thresh24, inv_keep);                                               \
   } while (0)
   if (nk > 16) return M3P_EINVAL;
+  if constexpr (DH == 64) {
+    if (onepass && !(g_attn_variant & 2)) {
+      static int n_cu = 0;
+      if (!n_cu) {
+        hipDeviceProp_t prop;
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return M3P_EINVAL;
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+      }
+      const size_t ldsp = (size_t)3 * 192 * 128 + (size_t)11 * 16 * 11 * 32 + 2 * 192 * sizeof(float) + 2 * 12 * 3 * 64 * sizeof(float);
+      auto kp = thresh24 ? attn_bwd_p_kernel<true, true> : attn_bwd_p_kernel<false, false>;
+      hipError_t e = hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp);
+      if (e != hipSuccess) return (int)e;
+      const int nheads = B * H;
+      hipLaunchKernelGGL(kp, dim3(nheads < n_cu ? nheads : n_cu), dim3(768), ldsp, st, qkv, keylen, ctx, dctx, lse, keepmask, dqkv, dbias,
+                         S, H, dmodel, nheads, qscale, inv_keep, (g_attn_variant >> 8) ? ((g_attn_variant >> 8) & 0xff) - 1 : 2);   // (bits 8..: stagger + 1; default 2 x 1024 clocks per phase)
+      M3P_CHECK_LAUNCH();
+      return M3P_OK;
+    }
+  }
   if (!thresh24) M3P_ATTN_BWD(16, false, false);
   else if (keepmask) M3P_ATTN_BWD(16, true, true);
   else M3P_ATTN_BWD(16, true, false);
@@ -1023,6 +1465,8 @@ int launch_bwd(const bf16* qkv, const int* keylen, const bf16* ctx, const bf16* 
 }  // namespace
 
 extern "C" {
+
+void m3p_debug_attn_variant(int v) { g_attn_variant = v; }
 
 // debug (only with -DM3P_ATTN_TL): copies the forward kernel's phase stamps ([4096 WGs][4 waves][16] u64)
 __attribute__((visibility("default"))) int m3p_debug_attn_timeline(void* out, size_t bytes) {

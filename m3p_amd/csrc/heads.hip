@@ -34,14 +34,14 @@ __global__ __launch_bounds__(256) void scatter_add_rows_kernel(const bf16* __res
 // dst[ids[i],:] += rows[i,:] in fp32 (ids repeat: atomics; rows of pad_index skipped, nn.Embedding(padding_idx)).
 // One wave per row, one atomic instruction = 64 consecutive floats (full 128-B lines), like the fused
 // scatter of embed_bwd_rows_kernel.  Applies the token rows all-gathered from the other data-parallel ranks.
-__global__ __launch_bounds__(256) void scatter_add_token_rows_kernel(const bf16* __restrict__ rows, const int64_t* __restrict__ ids,
+__global__ __launch_bounds__(256) void scatter_add_token_rows_kernel(const bf16* __restrict__ rows, int ld_rows, const int64_t* __restrict__ ids,
                                                                      float* __restrict__ dst, int n, int d, int pad_index) {
   const int lane = threadIdx.x & 63;
   const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), nwave = (int)((gridDim.x * blockDim.x) >> 6);
   for (int r = wave; r < n; r += nwave) {
     const int64_t id = ids[r];
     if (id == pad_index) continue;
-    const bf16* src = rows + (size_t)r * d;
+    const bf16* src = rows + (size_t)r * ld_rows;
     float* out = dst + (size_t)id * d;
     for (int e = lane; e < d; e += 64) {
       const float v = (float)src[e];
@@ -380,11 +380,11 @@ int m3p_scatter_add_rows(const void* src, const int32_t* idx, void* dst, int n, 
   return M3P_OK;
 }
 
-int m3p_scatter_add_token_rows(const void* rows, const int64_t* ids, float* dst, int n, int d, int pad_index, void* stream) {
+int m3p_scatter_add_token_rows(const void* rows, int ld_rows, const int64_t* ids, float* dst, int n, int d, int pad_index, void* stream) {
   if (n <= 0) return M3P_OK;
-  if (d <= 0) return M3P_EINVAL;
+  if (d <= 0 || ld_rows < d) return M3P_EINVAL;
   const int blocks = (n + 3) / 4 < 4096 ? (n + 3) / 4 : 4096;
-  hipLaunchKernelGGL(scatter_add_token_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)rows, ids,
+  hipLaunchKernelGGL(scatter_add_token_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)rows, ld_rows, ids,
                      dst, n, d, pad_index);
   M3P_CHECK_LAUNCH();
   return M3P_OK;

@@ -295,12 +295,37 @@ class DataParallel(torch.nn.Module):
         if not self.single and arena.device.type == 'cuda' and reserve_cus():
             from . import lib as L
             L.load().m3p_set_persistent_grid(L.num_cus() - reserve_cus())
+        self.identity = self._identify()
         if broadcast and not self.single:
             dist.broadcast(arena.master, src=0, group=process_group)
             for p in module.parameters():
                 if getattr(p, '_m3p_arena', None) is None:
                     dist.broadcast(p.data, src=0, group=process_group)
             arena.mark_master_changed()
+
+    def _identify(self):
+        """First-contact facts about the process group (bench.py prints them under "comm"): the backend, how many ranks it
+        has, and how many DISTINCT devices those ranks sit on - an all-gather of a 16-byte device tag (the uuid of the device,
+        else host name + PCI bus id).  Eight ranks on one GPU (a launcher that did not set LOCAL_RANK, or HIP_VISIBLE_DEVICES
+        pinned) reads `devices_seen: 1` here instead of as an unexplained 8x slowdown."""
+        info = dict(backend=dist.get_backend(self.pg) if dist.is_initialized() else None, ranks=self.world, devices_seen=1)
+        if self.single or not dist.is_initialized():
+            return info
+        import hashlib
+        import socket
+        dev = self._arena.device
+        if dev.type == 'cuda':
+            props = torch.cuda.get_device_properties(dev)
+            tag = str(getattr(props, 'uuid', '')) or '%s/%s/%s' % (socket.gethostname(), getattr(props, 'pci_bus_id', dev.index),
+                                                                 getattr(props, 'pci_device_id', ''))
+            tag = socket.gethostname() + '/' + tag
+        else:
+            tag = '%s/cpu/%d' % (socket.gethostname(), os.getpid())
+        mine = torch.frombuffer(bytearray(hashlib.md5(tag.encode()).digest()), dtype=torch.uint8).to(dev)
+        every = torch.empty(self.world * 16, dtype=torch.uint8, device=dev)
+        _all_gather_into(every, mine, self.pg).wait()
+        info['devices_seen'] = len({bytes(r.tolist()) for r in every.view(self.world, 16).cpu()})
+        return info
 
     def forward(self, mode, **kwargs):
         return self.module(mode, **kwargs)
@@ -544,21 +569,30 @@ class DataParallel(torch.nn.Module):
         d = self._tokens[0][1].shape[1]
         sizes = [nm.value() if isinstance(nm, _Pending) else int(nm) for _, _, nm in self._tokens]
         n_tot = sum(sizes)
-        ids_s = torch.full((n_tot,), pad, dtype=torch.int64, device=dev)
-        rows_s = torch.empty((n_tot, d), dtype=torch.bfloat16, device=dev)
+        # one message per rank: a row's id rides in eight extra bf16 columns behind its d values (the int64 in the first four;
+        # a 16-byte tail keeps the rows 16-byte aligned) - ONE all-gather per step instead of two (round 5: each collective
+        # launch costs the step boundary a 30-45 us hand-over between the compute and the exchange stream)
+        pitch = d + 8
+        msg = torch.empty((n_tot, pitch), dtype=torch.bfloat16, device=dev)
+        ids_cols = msg[:, d:d + 4]
         o = 0
         for (ids, rows, _), nm in zip(self._tokens, sizes):
             n = ids.numel()
-            ids_s[o:o + n] = ids.reshape(-1)
-            rows_s[o:o + n] = rows
+            msg[o:o + n, :d] = rows
+            ids_cols[o:o + n] = ids.reshape(-1, 1).view(torch.bfloat16)
             if nm > n:
-                rows_s[o + n:o + nm].zero_()
+                msg[o + n:o + nm, :d].zero_()
+                ids_cols[o + n:o + nm] = torch.full((1, 1), pad, dtype=torch.int64, device=dev).view(torch.bfloat16)
             o += nm
-        ids_all = torch.empty((self.world * n_tot,), dtype=torch.int64, device=dev)
-        rows_all = torch.empty((self.world * n_tot, d), dtype=torch.bfloat16, device=dev)
-        self.reducer.all_gather(ids_all, ids_s, label='token ids')
-        self.reducer.all_gather(rows_all, rows_s, label='token rows')
-        self._tokens_out = (ids_all, rows_all, ids_s, rows_s)
+        msg_all = torch.empty((self.world * n_tot, pitch), dtype=torch.bfloat16, device=dev)
+        ev = None
+        if self.reducer.stream is not None and self.exposed_events is not None:
+            # (bench: where the gradient buckets end and the token rows begin on the exchange stream - splits the exposed tail)
+            ev = torch.cuda.Event(enable_timing=True)
+            with torch.cuda.stream(self.reducer.stream):
+                ev.record()
+        self.reducer.all_gather(msg_all, msg, label='token rows')
+        self._tokens_out = (msg_all, msg, d, ev)
         self._tokens = []
 
     def no_sync(self):
@@ -588,14 +622,16 @@ class DataParallel(torch.nn.Module):
             self._launch(('layer', i))
         self._launch('embed')
         self._exchange_tokens()
-        ev0 = ev1 = None
+        ev0 = ev1 = ev_tok = None
         if self.exposed_events is not None and self._arena.device.type == 'cuda':
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
         self.reducer.finish()
         if self._tokens_out is not None:
             from . import ops
-            ids_all, rows_all = self._tokens_out[:2]
+            msg_all, _, d_rows, ev_tok = self._tokens_out
+            rows_all = msg_all[:, :d_rows]                                            # (strided view: pitch d + 8)
+            ids_all = msg_all[:, d_rows:d_rows + 4].contiguous().view(torch.int64).view(-1)
             if self.mode == 'zero1' and self.world > 1:
                 # sharded exchange: this rank steps (and norms) its own shard of the vocabulary gradient only, so of the N x
                 # B x T gathered rows it needs those whose matrix row intersects that shard - the others become pad rows,
@@ -611,7 +647,7 @@ class DataParallel(torch.nn.Module):
             self._tokens_out = None
         if ev0 is not None:
             ev1.record()
-            self.exposed_events.append((ev0, ev1, self.reducer.bytes_reduced))
+            self.exposed_events.append((ev0, ev1, self.reducer.bytes_reduced, ev_tok))
         self.reducer.bytes_reduced = 0
         self._finished = True
 

@@ -65,7 +65,7 @@ SIGNATURES = {
     'm3p_glu_bwd': (_i, [_p, _i, _p, _p, _i, _i, _p]),
     'm3p_gather_rows': (_i, [_p, _p, _p, _i, _i, _p]),
     'm3p_scatter_add_rows': (_i, [_p, _p, _p, _i, _i, _p]),
-    'm3p_scatter_add_token_rows': (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    'm3p_scatter_add_token_rows': (_i, [_p, _i, _p, _p, _i, _i, _i, _p]),
     'm3p_ce_fwd_bwd': (_i, [_p, _i, _i, _i, _p, _p, _p, _f, _f, _p]),
     'm3p_ce_colsum_workspace_bytes': (C.c_size_t, [_i, _i]),
     'm3p_ce_fwd_bwd_colsum': (_i, [_p, _i, _i, _i, _p, _p, _p, _f, _p, _p, C.c_size_t, _p]),
@@ -89,6 +89,7 @@ SIGNATURES = {
     'm3p_gemm_nt_plan': (_i, [_i, _i, _i, _i]),
     'm3p_gemm_wgrad_plan': (_i, [_i, _i, _i]),
     'm3p_debug_set_variant': (None, [_i]),
+    'm3p_debug_attn_variant': (None, [_i]),
     'm3p_seq_masks': (_i, [_p, _p, _i, _i, _p, _p, _p]),
     'm3p_mask_to_rows': (_i, [_p, _i, _i, C.c_longlong, C.c_longlong, C.c_longlong, _i, _p, _i, _p]),
     'm3p_cast_rows_f32_bf16': (_i, [_p, C.c_longlong, C.c_longlong, _i, _i, _i, _p, _p]),
@@ -120,6 +121,8 @@ def load():
     _lib_tq = os.environ.get('M3P_TILE_QUEUE', '0') != '0'     # developer switch: dynamic tile queues without data parallelism
     if os.environ.get('M3P_VARIANT'):      # developer switch between GEMM kernel generations (A/B runs)
         lib.m3p_debug_set_variant(int(os.environ['M3P_VARIANT']))
+    if os.environ.get('M3P_ATTN_VARIANT'):
+        lib.m3p_debug_attn_variant(int(os.environ['M3P_ATTN_VARIANT']))
     _lib = lib
     if _lib_tq and torch.cuda.is_available():
         from . import ops

@@ -544,12 +544,12 @@ def embed_assemble_bwd(dh, saved, g_emb, g_img, tok, totlen, loc, grads, B, T, R
 
 
 def scatter_add_token_rows(rows, ids, dst, pad_index):
-    """dst[ids[i], :] (fp32 [V, d]) += rows[i, :] (bf16 [n, d]); pad rows skipped."""
+    """dst[ids[i], :] (fp32 [V, d]) += rows[i, :] (bf16 [n, d], any row pitch); pad rows skipped."""
     _chk_bf16(rows)
-    assert ids.dtype == torch.int64 and dst.dtype == torch.float32 and rows.is_contiguous() and ids.is_contiguous()
+    assert ids.dtype == torch.int64 and dst.dtype == torch.float32 and rows.stride(1) == 1 and ids.is_contiguous()
     n, d = rows.shape
     assert ids.numel() == n and dst.shape[1] == d and dst.stride(0) == d
-    L.check(L.load().m3p_scatter_add_token_rows(rows.data_ptr(), ids.data_ptr(), dst.data_ptr(), n, d, int(pad_index),
+    L.check(L.load().m3p_scatter_add_token_rows(rows.data_ptr(), rows.stride(0), ids.data_ptr(), dst.data_ptr(), n, d, int(pad_index),
                                                 L.stream()), 'm3p_scatter_add_token_rows')
 
 

@@ -150,6 +150,16 @@ class Adam(optim.Optimizer):
             if arena.model.ddp_hook is not None:
                 arena.model.ddp_hook.finish()
             active = self._active_ranges(arena)
+            # single GPU, and this step's MLM head stored its weight gradient over the tied vocabulary matrix (it will again next
+            # step): that range is not zeroed here - Arena.defer_vocab_zero, functional.py.  The range may span several active
+            # ranges (per-parameter step counts differ after a step without an MLM head): every piece is cut at its borders.
+            lazy = None
+            if arena.model.ddp_hook is None and getattr(arena, 'vocab_stored', False) and _LAZY_VOCAB_ZERO:
+                v0, vc = arena.vocab_range()
+                covered = sum(max(0, min(r['end'], v0 + vc) - max(r['start'], v0)) for r in active)
+                if covered == vc:
+                    lazy = (v0, v0 + vc)
+                    arena.defer_vocab_zero()
             for r in active:
                 group = r['group']
                 beta1, beta2 = group['betas']
@@ -157,15 +167,13 @@ class Adam(optim.Optimizer):
                 bc1 = 1 - beta1 ** step
                 bc2 = 1 - beta2 ** step
                 step_size = group['lr'] * math.sqrt(bc2) / bc1
-                pieces = [(s, e, True) for s, e in self._owned(arena, r['start'], r['end'])]
-                # single GPU, and this step's MLM head stored its weight gradient over the tied vocabulary matrix (it will
-                # again next step): that range is not zeroed here - Arena.defer_vocab_zero, functional.py
-                if arena.model.ddp_hook is None and getattr(arena, 'vocab_stored', False) and _LAZY_VOCAB_ZERO:
-                    v0, vc = arena.vocab_range()
-                    if len(pieces) == 1 and pieces[0][0] <= v0 and v0 + vc <= pieces[0][1]:
-                        s, e, _ = pieces[0]
-                        pieces = [(a, b, z) for a, b, z in ((s, v0, True), (v0, v0 + vc, False), (v0 + vc, e, True)) if b > a]
-                        arena.defer_vocab_zero()
+                pieces = []
+                for s, e in self._owned(arena, r['start'], r['end']):
+                    if lazy is None or e <= lazy[0] or s >= lazy[1]:
+                        pieces.append((s, e, True))
+                    else:
+                        cuts = sorted({s, e, min(max(lazy[0], s), e), min(max(lazy[1], s), e)})
+                        pieces.extend((a, b, not (lazy[0] <= a and b <= lazy[1])) for a, b in zip(cuts, cuts[1:]) if b > a)
                 for s, e, zero in pieces:
                     ops.adam_step(arena.master[s:e], arena.grad[s:e], ent['m'][s:e], ent['v'][s:e], arena.w16[s:e],
                                   group['lr'], beta1, beta2, group['eps'], group['weight_decay'], step_size,

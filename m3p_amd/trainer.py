@@ -535,10 +535,12 @@ class Trainer(object):
                 hook.materialize_master()
 
     def _state_dicts(self):
-        # sharded data parallelism (distributed.py, zero1): the other ranks' shards of the updated fp32 master arrive through
-        # all-gathers on the side stream that only the next forward waits for - a save straight after an optimizer step has to
-        # wait for them too (a stream-level wait, no collective: every rank holds the full master once they have landed, so
-        # master-only callers like save_best_model are fine).  The Adam MOMENTS stay sharded: a checkpoint holds this rank's
+        # sharded data parallelism (distributed.py, zero1): since round 4 the forward-side gathers move the bf16 working copy
+        # only, and the fp32 master of the big matrices stays on its owner rank until DataParallel.materialize_master() - a
+        # COLLECTIVE every rank must run (save_model / save_checkpoint / save_periodic / save_best_model / end_epoch do, through
+        # _materialize(), before their master-rank test).  A direct call of this method or of model.state_dict() without it
+        # raises under zero1 instead of handing out stale weights.  params_ready(None) below is the
+        # stream-level wait for the gathers that ARE in flight.  The Adam MOMENTS stay sharded: a checkpoint holds this rank's
         # shards of them (zeros elsewhere); neither the reference's reload (xtrainer.py:586-592) nor ours reads them back.
         for n in self.MODEL_NAMES:
             hook = getattr(_unwrap(getattr(self, n)), 'ddp_hook', None)

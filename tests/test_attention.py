@@ -100,3 +100,49 @@ def test_attention_perf_smoke():
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 10
         print('attn_bwd p=%.1f: %.3f ms  %.1f TF (algorithmic 2x fwd)' % (p, ms, 2 * fl / ms / 1e9))
+
+
+@pytest.mark.parametrize('p', [0.0, 0.1])
+def test_attention_bwd_forms_for_the_m3p_sequence(p):
+    """The three backward forms for 36 regions + 128 tokens (m3p_debug_attn_variant: 1 = two phases with the scores recomputed,
+    2 = one pass - dS^T handed from phase A to phase B through LDS - as one twelve-wave workgroup per head, 0 = the same as a
+    persistent kernel, the default) on MORE heads than CUs, so that persistent workgroups walk several heads: each against
+    the fp32 reference at the kernel's usual bar, and against each other to bf16 rounding."""
+    from m3p_amd import ops, rng, lib as L
+    B, S, H, dh = 32, 164, 12, 64
+    d = H * dh
+    seed = 99
+    qkv, qkvc = randn_bf16((B * S, 3 * d), 11, 0.7)
+    rs = np.random.RandomState(5)
+    keylen = torch.from_numpy(rs.randint(S // 2, S + 1, size=B).astype(np.int32))
+    keylen[0] = S
+    kw = dict(seed=seed, p_drop=p)
+    if p > 0:
+        ctx, lse, kmask = ops.attn_fwd(qkv, keylen.cuda(), B, S, H, dh, want_mask=True, **kw)
+        keep = torch.from_numpy(rng.keep_mask(B * H * S * S, seed, p, (B, H, S, S))).float()
+    else:
+        (ctx, lse), kmask, keep = ops.attn_fwd(qkv, keylen.cuda(), B, S, H, dh, **kw), None, None
+    x = qkvc.clone().requires_grad_(True)
+    ctx_ref, _ = _ref_attention(x, keylen.long(), B, S, H, dh, keep, p)
+    dctx, dctxc = randn_bf16((B * S, d), 13)
+    ctx_ref.backward(dctxc)
+    g = x.grad.clone()
+    g[:, :d] *= 1.0 / math.sqrt(dh)
+    outs = {}
+    lib = L.load()
+    try:
+        for variant in (1, 2, 0):
+            lib.m3p_debug_attn_variant(variant)
+            dbias = torch.zeros(3 * d, device='cuda')
+            dqkv = ops.attn_bwd(qkv, keylen.cuda(), ctx, dctx, lse, B, S, H, dh, dbias_qkv=dbias, keepmask=kmask, **kw)
+            torch.cuda.synchronize()
+            for name, sl in (('dq', slice(0, d)), ('dk', slice(d, 2 * d)), ('dv', slice(2 * d, 3 * d))):
+                assert rel_l2(dqkv[:, sl].float(), g[:, sl]) < 1.5e-2, (variant, name)
+            cs = dqkv.float().sum(0)
+            assert rel_l2(dbias[:d], cs[:d]) < 1e-4 and rel_l2(dbias[2 * d:], cs[2 * d:]) < 1e-4 and bool((dbias[d:2 * d] == 0).all()), variant
+            outs[variant] = dqkv.float()
+    finally:
+        lib.m3p_debug_attn_variant(0)
+    assert torch.equal(outs[2], outs[0])                                 # same arithmetic, different schedule
+    assert torch.equal(outs[1][:, d:], outs[0][:, d:])                   # dK, dV: phase A is the same code in all three
+    assert rel_l2(outs[1][:, :d], outs[0][:, :d]) < 2e-3                 # dQ: from recomputed scores against from the handed-over dS

@@ -267,3 +267,10 @@ def test_bench_multi_gpu_half_runs_unattended():
     assert comm['mode'] in ('zero1', 'allreduce') and comm['exposed_ms_per_step'] >= 0
     assert comm['buckets'] and all(b['ms'] > 0 and b['MB'] > 0 for b in comm['buckets'].values())
     assert any(k.startswith('params') for k in comm['buckets']) == (comm['mode'] == 'zero1')
+    # round 5, first-contact kit: who is in the group, where the exposed tail sits, which bound each collective lands by
+    assert comm['backend'] == 'nccl' and comm['ranks'] == 1 and comm['rccl_ranks_seen'] == 1
+    split = comm['exposed_split_ms']
+    assert split['gradient_buckets'] >= 0 and split['token_rows'] >= 0
+    assert abs(split['gradient_buckets'] + split['token_rows'] - comm['exposed_ms_per_step']) < 1e-2
+    assert all({'ring_bound_ms', 'direct_bound_ms', 'lands'} <= set(b) for b in comm['buckets'].values())
+    assert 'token rows (all_gather)' in comm['buckets'] and not any('token ids' in k for k in comm['buckets'])   # ONE gather

@@ -378,13 +378,14 @@ def test_lazy_vocab_zero_changes_nothing(monkeypatch):
     """Round 5: when a step's MLM head STORED the tied matrix's weight gradient, the fused Adam pass leaves that range of the
     gradient arena un-zeroed (the next step's store overwrites it) - `Arena.defer_vocab_zero`.  Four steps at a size where the
     store path runs - MLM + ITM, MLM + ITM, an ITM-ONLY step (no MLM head: the embedding scatter is the first writer and must
-    find zeros), MLM + ITM again - end in BIT-identical weights and moments with the switch on and off, and the switch was
-    actually exercised (a deferred range existed, was cleared by a store once and by a memset once)."""
+    find zeros), MLM + ITM again - end in the same weights and moments (to the run-to-run noise of the step's fp32 atomics) with
+    the switch on and off, and the switch was actually exercised (a deferred range existed, was cleared by a store once and by a memset once)."""
     from m3p_amd import functional as Fn, optim as Om
-    cfg = dict(emb_dim=768, n_heads=12, n_layers=1, n_words=88000, T=64, R=16, B=128, n_pred=32)     # n = 4096, 1032 output tiles
+    cfg = dict(emb_dim=768, n_heads=12, n_layers=1, n_words=88000, T=96, R=32, B=128, n_pred=32)     # n = 4096 (every ragged length >= 48 holds 32 targets), 1032 output tiles
     batch = synth.make_batch(cfg['T'], cfg['R'], cfg['B'], cfg['n_words'], cfg['n_pred'], seed=3)
+    assert batch['y'].numel() == 4096
     results, events = [], []
-    for lazy in (True, False):
+    for lazy in (True, False, False):      # (the third run measures the step's own run-to-run noise)
         monkeypatch.setattr(Om, '_LAZY_VOCAB_ZERO', lazy)
         m, P, sd = _build(cfg, dropout=0.1)
         m.train()
@@ -414,6 +415,11 @@ def test_lazy_vocab_zero_changes_nothing(monkeypatch):
         results.append((ar.master.clone(), [e['m'].clone() for e in opt._arenas.values()], [e['v'].clone() for e in opt._arenas.values()]))
         events.append(ev)
     assert events[0].count('defer') == 3 and events[0].count('memset') == 2 and events[1] == [], events
-    assert torch.equal(results[0][0], results[1][0])
-    assert all(torch.equal(a, b) for a, b in zip(results[0][1], results[1][1]))
-    assert all(torch.equal(a, b) for a, b in zip(results[0][2], results[1][2]))
+    # (not bit-for-bit: the step's fp32 atomics - embedding scatter, LayerNorm / bias column sums - add in a different order from
+    #  run to run; a stale vocabulary range would show up at the size of a whole gradient, orders of magnitude above these bars)
+    assert events[2] == []
+    for k, name in ((0, 'master'), (1, 'exp_avg'), (2, 'exp_avg_sq')):
+        pick = (lambda r: [r[0]]) if k == 0 else (lambda r, k=k: r[k])      # noqa: E731
+        for a, b, c in zip(pick(results[0]), pick(results[1]), pick(results[2])):
+            noise, diff = rel_l2(c, b), rel_l2(a, b)
+            assert diff <= max(10 * noise, 1e-7), (name, diff, noise)

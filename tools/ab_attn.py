@@ -23,8 +23,10 @@ tmp = tempfile.mkdtemp()
 arms = []
 for k, name in enumerate(sys.argv[1:]):
     path = os.path.join(tmp, 'arm%d.so' % k)
-    shutil.copy(os.path.join(ROOT, 'm3p_amd', name), path)
+    shutil.copy(os.path.join(ROOT, 'm3p_amd', name.split(':')[0]), path)      # <file>[:<m3p_debug_attn_variant value>]
     h = C.CDLL(path)
+    if ':' in name:
+        h.m3p_debug_attn_variant(int(name.split(':')[1]))
     for fn in ('m3p_attn_fwd', 'm3p_attn_bwd'):
         getattr(h, fn).restype, getattr(h, fn).argtypes = L.SIGNATURES[fn]
     arms.append((name, h))
