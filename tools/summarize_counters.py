@@ -43,7 +43,9 @@ def clock_ghz(name):
         return None
     return c / 8.0 / (ns + n * OVH_US * 1e3)
 TAG = os.environ.get('ROUND', 'r04')
-steps = float(max([c for n, (c, _) in stats.items() if 'adam_kernel' in n] + [1]))     # optimizer steps in the profiled run
+# optimizer steps in the profiled run: the global-norm kernel runs once per step (the fused Adam pass is two launches a step since
+# round 5 - the lazily zeroed vocabulary range is its own piece)
+steps = float(max([c for n, (c, _) in stats.items() if 'sumsq' in n] + [1]))
 rows, kernels = [], {}
 for name, (calls, avg_ns) in sorted(stats.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
     fk = fetch.get(name, {}).get('FETCH_SIZE')
