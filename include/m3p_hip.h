@@ -383,6 +383,14 @@ M3P_API int m3p_sumsq_ranges_f32(const float* base, const long long* starts, con
 M3P_API int m3p_adam_step(float* p, float* g, float* m, float* v, void* w16, long long n, float lr, float beta1,
                           float beta2, float eps, float weight_decay, float step_size, const double* gnorm_sq,
                           float max_norm, float grad_scale, int zero_grad, void* stream);
+/* The same update over n_ranges pieces [starts[r], starts[r] + counts[r]) (elements, multiples of 4) of the SAME flat arenas in
+ * one launch; step_sizes / zero_grad per piece (pieces of parameters with different update counts have different bias
+ * corrections; a piece whose gradient the next step overwrites need not be zeroed).  starts / counts / step_sizes / zero_grad
+ * are HOST arrays, read before the call returns.  p, g, m, v, w16 are the arenas' bases. */
+M3P_API int m3p_adam_step_ranges(float* p, float* g, float* m, float* v, void* w16, const long long* starts,
+                                 const long long* counts, const float* step_sizes, const int* zero_grad, int n_ranges,
+                                 float lr, float beta1, float beta2, float eps, float weight_decay, const double* gnorm_sq,
+                                 float max_norm, float grad_scale, void* stream);
 
 /* h = gelu_erf(u) elementwise (transformer.py:56 applied to the lin1 output :223-224), bf16,
  * n % 8 == 0.  Used instead of M3P_EPI_BIAS_GELU when the GEMM is persistent.

@@ -574,6 +574,115 @@ int m3p_sumsq_ranges_f32(const float* base, const long long* starts, const long 
   return M3P_OK;
 }
 
+// The same update over several pieces of the flat arenas in ONE launch (round 5): blocks are dealt to the pieces in proportion
+// to their sizes like m3p_sumsq_ranges_f32.  A sharded data-parallel rank steps fifteen bucket shards per optimizer step, the
+// single-GPU step two pieces (the lazily zeroed vocabulary range and the rest): per piece a launch ramps up and drains on its
+// own - fifteen launches streamed the one-rank wrapped step's 9.5 GB in 2.00 ms where two take 1.61 (profiles/r05_dp_prof.txt).
+constexpr int ADAM_MAX_RANGES = 32;
+struct AdamRanges {
+  AdamArgs c;                                  // common fields; p / g / m / v / w16 = the arenas' bases, n4 / step_size / zero_grad unused
+  unsigned long long start4[ADAM_MAX_RANGES];  // first quad of the piece
+  unsigned long long n4[ADAM_MAX_RANGES];
+  float step_size[ADAM_MAX_RANGES];
+  int zero_grad[ADAM_MAX_RANGES];
+  int blk0[ADAM_MAX_RANGES + 1];
+  int n;
+};
+__global__ __launch_bounds__(256) void adam_ranges_kernel(AdamRanges a) {
+  int r = 0;
+  while (r + 1 < a.n && (int)blockIdx.x >= a.blk0[r + 1]) ++r;
+  float coef = a.c.grad_scale;
+  if (a.c.gnorm_sq && a.c.max_norm > 0.f) {
+    const float norm = (float)sqrt(*a.c.gnorm_sq) * a.c.grad_scale;
+    const float cc = a.c.max_norm / (norm + 1e-6f);
+    coef *= (cc < 1.f) ? cc : 1.f;
+  }
+  const float ob1 = 1.f - a.c.beta1, ob2 = 1.f - a.c.beta2, wdl = a.c.weight_decay * a.c.lr;
+  const float step_size = a.step_size[r];
+  const bool zero = a.zero_grad[r] != 0;
+  const size_t base = (size_t)a.start4[r], n4 = (size_t)a.n4[r];
+  float* const P = a.c.p + 4 * base; float* const G = a.c.g + 4 * base; float* const M = a.c.m + 4 * base; float* const V = a.c.v + 4 * base;
+  bf16* const W = a.c.w16 ? a.c.w16 + 4 * base : nullptr;
+  const size_t stride = (size_t)(a.blk0[r + 1] - a.blk0[r]) * blockDim.x;
+  for (size_t i0 = (size_t)((int)blockIdx.x - a.blk0[r]) * blockDim.x + threadIdx.x; i0 < n4; i0 += 2 * stride) {
+    const size_t i1 = i0 + stride;
+    const bool two = i1 < n4;
+    f32x4 p[2], g[2], m[2], v[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const size_t i = u ? i1 : i0;
+      if (u == 0 || two) {
+        p[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(P + 4 * i));
+        g[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(G + 4 * i));
+        m[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(M + 4 * i));
+        v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(V + 4 * i));
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const size_t i = u ? i1 : i0;
+      if (u == 0 || two) {
+        const f32x4 gc = g[u] * coef;
+        const f32x4 mn = m[u] * a.c.beta1 + gc * ob1;
+        const f32x4 vn = v[u] * a.c.beta2 + gc * gc * ob2;
+        f32x4 pn = p[u];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float denom = sqrtf(vn[j]) + a.c.eps;
+          if (wdl != 0.f) pn[j] -= wdl * pn[j];
+          pn[j] -= step_size * (mn[j] / denom);
+        }
+        __builtin_nontemporal_store(pn, reinterpret_cast<f32x4*>(P + 4 * i));
+        __builtin_nontemporal_store(mn, reinterpret_cast<f32x4*>(M + 4 * i));
+        __builtin_nontemporal_store(vn, reinterpret_cast<f32x4*>(V + 4 * i));
+        if (W) Vec4<bf16>::store(W + 4 * i, pn);
+        if (zero) __builtin_nontemporal_store(f32x4{0.f, 0.f, 0.f, 0.f}, reinterpret_cast<f32x4*>(G + 4 * i));
+      }
+    }
+  }
+}
+
+int m3p_adam_step_ranges(float* p, float* g, float* m, float* v, void* w16, const long long* starts, const long long* counts,
+                         const float* step_sizes, const int* zero_grad, int n_ranges, float lr, float beta1, float beta2, float eps,
+                         float weight_decay, const double* gnorm_sq, float max_norm, float grad_scale, void* stream) {
+  if (!p || !g || !m || !v || !starts || !counts || !step_sizes || !zero_grad || n_ranges <= 0) return M3P_EINVAL;
+  if (((uintptr_t)p & 15) || ((uintptr_t)g & 15) || ((uintptr_t)m & 15) || ((uintptr_t)v & 15) || ((uintptr_t)w16 & 7)) return M3P_EINVAL;
+  for (int r = 0; r < n_ranges; ++r)
+    if (counts[r] < 0 || (counts[r] % 4) != 0 || starts[r] < 0 || (starts[r] % 4) != 0) return M3P_EINVAL;
+  int done = 0;
+  while (done < n_ranges) {
+    AdamRanges a;
+    a.c = AdamArgs{p, g, m, v, (bf16*)w16, 0, lr, beta1, beta2, eps, weight_decay, 0.f, gnorm_sq, max_norm,
+                   grad_scale == 0.f ? 1.f : grad_scale, 0};
+    a.n = 0;
+    long long total4 = 0;
+    for (; done < n_ranges && a.n < ADAM_MAX_RANGES; ++done) {
+      if (counts[done] == 0) continue;
+      a.start4[a.n] = (unsigned long long)starts[done] / 4;
+      a.n4[a.n] = (unsigned long long)counts[done] / 4;
+      a.step_size[a.n] = step_sizes[done];
+      a.zero_grad[a.n] = zero_grad[done];
+      total4 += counts[done] / 4;
+      ++a.n;
+    }
+    if (a.n == 0) continue;
+    long long want = (total4 + 255) / 256;      // one quad per thread and trip like m3p_adam_step, at most 4096 blocks, at least one per piece
+    if (want > 4096) want = 4096;
+    if (want < a.n) want = a.n;
+    int b = 0;
+    for (int r = 0; r < a.n; ++r) {
+      a.blk0[r] = b;
+      long long share = (long long)((double)a.n4[r] / (double)total4 * (double)want);
+      if (share < 1) share = 1;
+      b += (int)share;
+    }
+    a.blk0[a.n] = b;
+    hipLaunchKernelGGL(adam_ranges_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, a);
+    M3P_CHECK_LAUNCH();
+  }
+  return M3P_OK;
+}
+
 int m3p_adam_step(float* p, float* g, float* m, float* v, void* w16, long long n, float lr, float beta1, float beta2,
                   float eps, float weight_decay, float step_size, const double* gnorm_sq, float max_norm,
                   float grad_scale, int zero_grad, void* stream) {

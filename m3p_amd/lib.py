@@ -75,6 +75,7 @@ SIGNATURES = {
     'm3p_sumsq_f32': (_i, [_p, C.c_longlong, _p, _p]),
     'm3p_sumsq_ranges_f32': (_i, [_p, _p, _p, _i, _p, _p]),
     'm3p_adam_step': (_i, [_p, _p, _p, _p, _p, C.c_longlong, _f, _f, _f, _f, _f, _f, _p, _f, _f, _i, _p]),
+    'm3p_adam_step_ranges': (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _f, _f, _f, _f, _f, _p, _f, _f, _p]),
     'm3p_itm_score_fwd': (_i, [_p, _p, _p, _p, _p, _i, _i, _p]),
     'm3p_itm_score_bwd': (_i, [_p, _p, _p, _p, _p, _i, _p, _p, _p, _i, _i, _p]),
     'm3p_gelu_bwd': (_i, [_p, _p, _p, C.c_longlong, _p]),

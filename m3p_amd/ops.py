@@ -651,6 +651,21 @@ def adam_step(p, g, m, v, w16, lr, beta1, beta2, eps, weight_decay, step_size, g
     L.check(rc, 'm3p_adam_step')
 
 
+def adam_step_ranges(p, g, m, v, w16, pieces, lr, beta1, beta2, eps, weight_decay, gnorm_sq=None, max_norm=0.0, grad_scale=1.0):
+    """One launch of the fused Adam update over several pieces of the flat arenas: pieces = [(start, end, step_size, zero_grad)]."""
+    pieces = [q for q in pieces if q[1] > q[0]]
+    if not pieces:
+        return
+    n = len(pieces)
+    starts = (C.c_longlong * n)(*[int(a) for a, _, _, _ in pieces])
+    counts = (C.c_longlong * n)(*[int(b - a) for a, b, _, _ in pieces])
+    steps = (C.c_float * n)(*[float(st) for _, _, st, _ in pieces])
+    zeros = (C.c_int * n)(*[int(bool(z)) for _, _, _, z in pieces])
+    rc = L.load().m3p_adam_step_ranges(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), L.ptr(w16), starts, counts, steps, zeros, n,
+                                       lr, beta1, beta2, eps, weight_decay, L.ptr(gnorm_sq), max_norm, grad_scale, L.stream())
+    L.check(rc, 'm3p_adam_step_ranges')
+
+
 def transpose_bf16(src, dst):
     """dst[c, r] = src[r, c]; dst may have a row pitch larger than rows (pad columns untouched)."""
     rows, cols = src.shape

@@ -160,6 +160,9 @@ class Adam(optim.Optimizer):
                 if covered == vc:
                     lazy = (v0, v0 + vc)
                     arena.defer_vocab_zero()
+            # every piece of every active range of a parameter group goes into ONE launch (ops.adam_step_ranges): a sharded rank
+            # steps fifteen bucket shards, and fifteen launches streamed the same bytes 24 % slower than one
+            batches = {}
             for r in active:
                 group = r['group']
                 beta1, beta2 = group['betas']
@@ -167,20 +170,20 @@ class Adam(optim.Optimizer):
                 bc1 = 1 - beta1 ** step
                 bc2 = 1 - beta2 ** step
                 step_size = group['lr'] * math.sqrt(bc2) / bc1
-                pieces = []
+                pieces = batches.setdefault(id(group), (group, []))[1]
                 for s, e in self._owned(arena, r['start'], r['end']):
                     if lazy is None or e <= lazy[0] or s >= lazy[1]:
-                        pieces.append((s, e, True))
+                        pieces.append((s, e, step_size, True))
                     else:
                         cuts = sorted({s, e, min(max(lazy[0], s), e), min(max(lazy[1], s), e)})
-                        pieces.extend((a, b, not (lazy[0] <= a and b <= lazy[1])) for a, b in zip(cuts, cuts[1:]) if b > a)
-                for s, e, zero in pieces:
-                    ops.adam_step(arena.master[s:e], arena.grad[s:e], ent['m'][s:e], ent['v'][s:e], arena.w16[s:e],
-                                  group['lr'], beta1, beta2, group['eps'], group['weight_decay'], step_size,
-                                  gnorm_sq=ent['gnorm'] if max_norm > 0 else None, max_norm=max_norm,
-                                  grad_scale=self.grad_scale, zero_grad=zero)
+                        pieces.extend((a, b, step_size, not (lazy[0] <= a and b <= lazy[1])) for a, b in zip(cuts, cuts[1:]) if b > a)
                 for p in r['params']:
                     self.state[p]['step'] = step
+            for group, pieces in batches.values():
+                beta1, beta2 = group['betas']
+                ops.adam_step_ranges(arena.master, arena.grad, ent['m'], ent['v'], arena.w16, pieces, group['lr'], beta1, beta2,
+                                     group['eps'], group['weight_decay'], gnorm_sq=ent['gnorm'] if max_norm > 0 else None,
+                                     max_norm=max_norm, grad_scale=self.grad_scale)
             # sharded exchange: the other ranks' shards of the updated master come back through an all-gather that the
             # next forward waits for bucket by bucket (distributed.DataParallel.after_sharded_step)
             hook = arena.model.ddp_hook

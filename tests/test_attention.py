@@ -102,14 +102,15 @@ def test_attention_perf_smoke():
         print('attn_bwd p=%.1f: %.3f ms  %.1f TF (algorithmic 2x fwd)' % (p, ms, 2 * fl / ms / 1e9))
 
 
+@pytest.mark.parametrize('B,S', [(32, 164), (5, 161), (4, 176), (3, 170)])      # 11 tiles / 6 steps: every length from 161 to 176
 @pytest.mark.parametrize('p', [0.0, 0.1])
-def test_attention_bwd_forms_for_the_m3p_sequence(p):
+def test_attention_bwd_forms_for_the_m3p_sequence(p, B, S):
     """The three backward forms for 36 regions + 128 tokens (m3p_debug_attn_variant: 1 = two phases with the scores recomputed,
     2 = one pass - dS^T handed from phase A to phase B through LDS - as one twelve-wave workgroup per head, 0 = the same as a
     persistent kernel, the default) on MORE heads than CUs, so that persistent workgroups walk several heads: each against
     the fp32 reference at the kernel's usual bar, and against each other to bf16 rounding."""
     from m3p_amd import ops, rng, lib as L
-    B, S, H, dh = 32, 164, 12, 64
+    H, dh = 12, 64
     d = H * dh
     seed = 99
     qkv, qkvc = randn_bf16((B * S, 3 * d), 11, 0.7)

@@ -76,6 +76,40 @@ def test_cross_entropy_with_fused_bias_gradient(n, V):
     assert cs.shape == (ld,) and rel_l2(cs, logits.float().sum(0)) < 1e-5 and float(cs[V:].abs().max()) == 0.0
 
 
+def test_adam_step_over_ranges_in_one_launch():
+    """m3p_adam_step_ranges (every piece of an optimizer step in one launch: the shards of a data-parallel rank, the lazily
+    zeroed vocabulary range beside the rest) against m3p_adam_step piece by piece: bit-identical parameters, moments, bf16
+    copies; per-piece step sizes and zero flags honoured; what lies between the pieces untouched; more pieces than one
+    launch's descriptor holds."""
+    from m3p_amd import ops
+    n = 1 << 20
+    gen = torch.Generator(device='cuda').manual_seed(3)
+    bounds = [0, 64, 4096, 4096 + 300 * 64, 400_000, 400_000, 700_000, 790_000]        # (disjoint pieces, one of them empty)
+    pieces = [(a, b, 1e-3 * (k + 1), k % 3 != 1) for k, (a, b) in enumerate(zip(bounds[::2], bounds[1::2]))]
+    pieces += [(800_000 + 512 * k, 800_000 + 512 * k + 256, 2e-3, True) for k in range(40)]        # > 32 pieces: two launches
+    state = [torch.randn(n, device='cuda', generator=gen) for _ in range(3)] + [torch.rand(n, device='cuda', generator=gen)]
+    gn = torch.full((1,), 1e4, dtype=torch.float64, device='cuda')
+    outs = []
+    for form in ('pieces', 'ranges'):
+        p, g, m, v = (t.clone() for t in state)
+        w16 = torch.zeros(n, dtype=BF16, device='cuda')
+        if form == 'ranges':
+            ops.adam_step_ranges(p, g, m, v, w16, pieces, 1e-2, 0.9, 0.98, 1e-8, 0.01, gnorm_sq=gn, max_norm=5.0, grad_scale=0.5)
+        else:
+            for a, b, st, z in pieces:
+                if b > a:
+                    ops.adam_step(p[a:b], g[a:b], m[a:b], v[a:b], w16[a:b], 1e-2, 0.9, 0.98, 1e-8, 0.01, st, gnorm_sq=gn, max_norm=5.0,
+                                  grad_scale=0.5, zero_grad=z)
+        torch.cuda.synchronize()
+        outs.append((p, g, m, v, w16))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    p, g, m, v, w16 = outs[1]
+    assert torch.equal(p[64:4096], state[0][64:4096]) and torch.equal(g[790_000:800_000], state[1][790_000:800_000])     # gaps untouched
+    assert float(g[0:64].abs().max()) == 0.0 and torch.equal(g[4096:4096 + 300 * 64], state[1][4096:4096 + 300 * 64])   # zero flag per piece
+    assert not torch.equal(p[0:64], state[0][0:64])
+
+
 def test_adam_step_matches_oracle():
     from m3p_amd import ops
     from oracle import ref_cpu as O

@@ -3,7 +3,7 @@
 R=$(cd "$(dirname "$0")/.." && pwd)
 out=$R/gpurun_out/dpprof; rm -rf $out; mkdir -p $out
 cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/plain -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $out/plain.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/plain -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-also > $out/plain.log 2>&1
 M3P_DP_FORCE=1 HSA_ENABLE_IPC_MODE_LEGACY=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29631 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 rocprofv3 --kernel-trace --stats --output-format csv -d $out/wrapped -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $out/wrapped.log 2>&1
 tail -1 $out/plain.log | cut -c1-200; tail -1 $out/wrapped.log | cut -c1-200
 cd $R
