@@ -182,6 +182,15 @@ class Arena:
                     self.params[n].register_hook(_hook)
 
     def p(self, name):
+        """The fp32 master of a parameter, for a kernel that reads it in fp32 (biases, LayerNorm weights, the position /
+        language / location tables, the ITM score vector).  Under the sharded data-parallel exchange only the parameters that
+        travel in the packed fp32 all-reduce are current on every rank - a big matrix's master is current on its owner rank
+        only: handing THAT to a kernel would feed it stale weights on the other ranks, so it is refused here (the
+        fp32-read set follows from the calls of this method, not from a list kept in step by hand)."""
+        hook = getattr(self.model, 'ddp_hook', None)
+        if hook is not None and getattr(hook, 'mode', None) == 'zero1' and hook._is_sharded_matrix(name):
+            raise AssertionError('%s is a sharded matrix under zero1: its fp32 master is current on its owner rank only - read the '
+                                 'bf16 working copy (Arena.w) or add it to distributed.DataParallel._FP32_TABLES' % name)
         return self.params[name]
 
     def qkv_w16(self, i):
