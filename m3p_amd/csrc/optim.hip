@@ -588,6 +588,12 @@ struct AdamRanges {
   int blk0[ADAM_MAX_RANGES + 1];
   int n;
 };
+#ifndef M3P_ADAM_Q
+#define M3P_ADAM_Q 2          // 16-byte quads per thread and trip (x 4 read streams = loads in flight before the first use)
+#endif
+#ifndef M3P_ADAM_MAXBLK
+#define M3P_ADAM_MAXBLK 4096
+#endif
 __global__ __launch_bounds__(256) void adam_ranges_kernel(AdamRanges a) {
   int r = 0;
   while (r + 1 < a.n && (int)blockIdx.x >= a.blk0[r + 1]) ++r;
@@ -604,14 +610,13 @@ __global__ __launch_bounds__(256) void adam_ranges_kernel(AdamRanges a) {
   float* const P = a.c.p + 4 * base; float* const G = a.c.g + 4 * base; float* const M = a.c.m + 4 * base; float* const V = a.c.v + 4 * base;
   bf16* const W = a.c.w16 ? a.c.w16 + 4 * base : nullptr;
   const size_t stride = (size_t)(a.blk0[r + 1] - a.blk0[r]) * blockDim.x;
-  for (size_t i0 = (size_t)((int)blockIdx.x - a.blk0[r]) * blockDim.x + threadIdx.x; i0 < n4; i0 += 2 * stride) {
-    const size_t i1 = i0 + stride;
-    const bool two = i1 < n4;
-    f32x4 p[2], g[2], m[2], v[2];
+  constexpr int Q = M3P_ADAM_Q;
+  for (size_t i0 = (size_t)((int)blockIdx.x - a.blk0[r]) * blockDim.x + threadIdx.x; i0 < n4; i0 += Q * stride) {
+    f32x4 p[Q], g[Q], m[Q], v[Q];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const size_t i = u ? i1 : i0;
-      if (u == 0 || two) {
+    for (int u = 0; u < Q; ++u) {
+      const size_t i = i0 + u * stride;
+      if (u == 0 || i < n4) {
         p[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(P + 4 * i));
         g[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(G + 4 * i));
         m[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(M + 4 * i));
@@ -619,9 +624,9 @@ __global__ __launch_bounds__(256) void adam_ranges_kernel(AdamRanges a) {
       }
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const size_t i = u ? i1 : i0;
-      if (u == 0 || two) {
+    for (int u = 0; u < Q; ++u) {
+      const size_t i = i0 + u * stride;
+      if (u == 0 || i < n4) {
         const f32x4 gc = g[u] * coef;
         const f32x4 mn = m[u] * a.c.beta1 + gc * ob1;
         const f32x4 vn = v[u] * a.c.beta2 + gc * gc * ob2;
@@ -667,7 +672,7 @@ int m3p_adam_step_ranges(float* p, float* g, float* m, float* v, void* w16, cons
     }
     if (a.n == 0) continue;
     long long want = (total4 + 255) / 256;      // one quad per thread and trip like m3p_adam_step, at most 4096 blocks, at least one per piece
-    if (want > 4096) want = 4096;
+    if (want > M3P_ADAM_MAXBLK) want = M3P_ADAM_MAXBLK;
     if (want < a.n) want = a.n;
     int b = 0;
     for (int r = 0; r < a.n; ++r) {

@@ -1,3 +1,3 @@
 #!/bin/bash
 mkdir -p gpurun_out/r05
-timeout 900 python -m pytest tests/test_small_kernels.py tests/test_attention.py tests/test_model_parity.py tests/test_distributed_gpu.py -q -m gpu 2>&1 | tail -12 > gpurun_out/r05/adam_attn_tests.log
+timeout 600 python tools/ab_adam.py libm3p_hip.so libm3p_hip_adamq4.so libm3p_hip_adamq1.so libm3p_hip_adamb2k.so libm3p_hip_adamb8k.so libm3p_hip_adamb16k.so libm3p_hip_adamq4b8k.so > gpurun_out/r05/adam_ab.txt 2>&1
