@@ -526,6 +526,9 @@ M3P_API int m3p_probe_mfma_16x16x32(const void* a_rowmajor_16x32, const void* b_
 M3P_API int m3p_probe_mfma_fp8_16x16x128(const void* a_16x128, const void* w_16x128, float* d_16x16, int a_is_bf8,
                                          void* stream);
 M3P_API int m3p_probe_tr16(const void* tile_bf16_64x16, void* out_64x4, void* stream);
+/* v_permlane16_swap_b32 x, y with (x, y) = (lane, 100 + lane): out[lane] = x, out[64 + lane] = y afterwards - the odd 16-lane rows
+ * of x trade places with the even rows of y (what the persistent attention backward's widened row stores rest on) */
+M3P_API int m3p_probe_permlane16_swap(void* out_2x64_u32, void* stream);
 
 #ifdef __cplusplus
 }

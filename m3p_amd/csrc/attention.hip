@@ -1087,6 +1087,9 @@ void attn_bwd_p_kernel(const bf16* __restrict__ qkv, const int* __restrict__ key
   float* sL = reinterpret_cast<float*>(sDS + NTC * 16 * DSP);
   float* sD = sL + NR;
   float* sB = sD + NR;                               // [2 heads in flight][NW][3][DH] bias-gradient partial sums
+  // the head's dropout keep words of this wave's key tile: [NW][11 query tiles x 4] - ONE 8-byte load per lane and head (lane
+  // 4 t + r fetches word (t, r)) parked here, instead of two loads per step (vector-memory ISSUE is what the CU runs short of)
+  unsigned long long* sMW = reinterpret_cast<unsigned long long*>(sB + 2 * NW * 3 * DH) + wid * 48;
   const size_t ld = 3 * (size_t)dmodel;
   const int fq = lane & 15, fg = lane >> 4;
   const int rin = lane / Cf::CH, c8 = lane % Cf::CH;
@@ -1109,12 +1112,7 @@ void attn_bwd_p_kernel(const bf16* __restrict__ qkv, const int* __restrict__ key
   // ---- what a head needs from global memory before its phase A; requested a head ahead
   bf16x8 orow[kNIW], kf[Cf::KK], vf[Cf::KK];
   float lse_r = 0.f;
-  unsigned long long mwA[2][2];
-  auto mask_words = [&](const unsigned long long* mbh, int kq_, int par_) {
-#pragma unroll
-    for (int hf = 0; hf < 2; ++hf)
-      mwA[par_][hf] = mbh[((size_t)min(2 * kq_ + hf, NTC - 1) * NTC + min(wid, NTC - 1)) * 4 + (fq & 3)];
-  };
+  unsigned long long mw_req = 0;
   auto request_head = [&](int hd) {
     const int b = hd / H, h = hd - b * H;
     const bf16* Qg = qkv + (size_t)b * S * ld + h * DH;
@@ -1134,11 +1132,8 @@ void attn_bwd_p_kernel(const bf16* __restrict__ qkv, const int* __restrict__ key
       vf[kk] = *reinterpret_cast<const bf16x8*>(Qg + 2 * dmodel + (size_t)keyc * ld + 32 * kk + 8 * fg);
     }
     if (tid < NR && tid < S) lse_r = lse[(size_t)hd * S + tid];      // (raw: arithmetic on it here would wait for the load here)
-    if (MASK) {
-      const unsigned long long* mbh = keepmask + (size_t)hd * NTC * NTC * 4;
-      mask_words(mbh, 0, 0);
-      mask_words(mbh, 1, 1);
-    }
+    if (MASK && lane < 4 * NTC)
+      mw_req = keepmask[(size_t)hd * NTC * NTC * 4 + ((size_t)(lane >> 2) * NTC + min(wid, NTC - 1)) * 4 + (lane & 3)];
   };
 
   f32x4 bsum[Cf::NT];
@@ -1171,14 +1166,26 @@ void attn_bwd_p_kernel(const bf16* __restrict__ qkv, const int* __restrict__ key
   bf16x4 kb4[Cf::NT], vb4[Cf::NT], qb4[Cf::NT];
   const int key = wid * 16 + fq;
   bf16* dQg_prev = nullptr;
+  // A row's 16 columns of a d-tile sit in FOUR lanes (fg = 0..3, 8 bytes each): twelve 8-byte stores per lane and head.  One
+  // v_permlane16_swap per register of a d-tile PAIR (odd 16-lane rows of the first trade places with the even rows of the
+  // second: tests/test_hw_probes.py) leaves every lane with 16 contiguous bytes - columns 8 (fg >> 1) .. + 7 of tile
+  // n0 + (fg & 1) - and halves the store instructions at equal bytes and addresses: the segment that issues them is bound by
+  // the CU's vector-memory issue (eleven waves x 12 instructions: 3.2 k ticks per head), not by bandwidth (cdna guide, T21).
+  typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+  typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
   auto store_head = [&](bf16* dQh) {
-    if (wid < NTC && key < S) {
-      bf16* pq = dQh + (size_t)key * ld + 4 * fg;
+    if (wid < NTC) {
+      bf16* prow = dQh + (size_t)min(key, S - 1) * ld + 8 * (fg >> 1) + 16 * (fg & 1);
 #pragma unroll
-      for (int n = 0; n < Cf::NT; ++n) {
-        *reinterpret_cast<bf16x4*>(pq + 16 * n) = qb4[n];
-        *reinterpret_cast<bf16x4*>(pq + dmodel + 16 * n) = kb4[n];
-        *reinterpret_cast<bf16x4*>(pq + 2 * dmodel + 16 * n) = vb4[n];
+      for (int mat = 0; mat < 3; ++mat) {
+        bf16x4* r = mat == 0 ? qb4 : (mat == 1 ? kb4 : vb4);
+#pragma unroll
+        for (int n0 = 0; n0 < Cf::NT; n0 += 2) {
+          u32x2_t x = __builtin_bit_cast(u32x2_t, r[n0]), y = __builtin_bit_cast(u32x2_t, r[n0 + 1]);
+          asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %2\n\tv_permlane16_swap_b32 %1, %3"
+                       : "+v"(x[0]), "+v"(x[1]), "+v"(y[0]), "+v"(y[1]));
+          if (key < S) *reinterpret_cast<u32x4_t*>(prow + mat * dmodel + 16 * n0) = u32x4_t{x[0], x[1], y[0], y[1]};
+        }
       }
     }
   };
@@ -1205,7 +1212,6 @@ void attn_bwd_p_kernel(const bf16* __restrict__ qkv, const int* __restrict__ key
     bf16* dQg = dqkv + (size_t)b * S * ld + h * DH;
     const bf16* Kg = qkv + (size_t)b * S * ld + h * DH + dmodel;
     const int klen = keylen[b];
-    const unsigned long long* mbh = MASK ? keepmask + (size_t)hd * NTC * NTC * 4 : nullptr;
     float* sBh = sB + par * (NW * 3 * DH);
     // ---- D[q] = rowsum(dO O) keep, lse -> LDS.  This wave's dO rows (its own LDS-DMA) and O chunks have landed after its vmcnt.
     // (__builtin_amdgcn_s_waitcnt, not inline asm: the compiler's own wait insertion must KNOW this wait happened - behind an
@@ -1229,6 +1235,7 @@ void attn_bwd_p_kernel(const bf16* __restrict__ qkv, const int* __restrict__ key
       }
     }
     if (tid < NR) sL[tid] = tid < S ? lse_r * kLog2e - log2_inv_keep : INFINITY;
+    if (MASK && lane < 4 * NTC) sMW[lane] = mw_req;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                  // B1: Q, dO, D, lse in place; phase B of the previous head over
     asm volatile("" ::: "memory");
@@ -1275,7 +1282,7 @@ void attn_bwd_p_kernel(const bf16* __restrict__ qkv, const int* __restrict__ key
             continue;
           }
           uint32_t kbits = 0;
-          if (MASK) kbits = (uint32_t)(mwA[kq & 1][hf] >> (4 * fg + 16 * (fq >> 2)));
+          if (MASK) kbits = (uint32_t)(sMW[4 * t + (fq & 3)] >> (4 * fg + 16 * (fq >> 2)));
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int q = 16 * t + 4 * fg + r;
@@ -1301,7 +1308,6 @@ void attn_bwd_p_kernel(const bf16* __restrict__ qkv, const int* __restrict__ key
           *reinterpret_cast<bf16x4*>(sDS + key * DSP + (32 * kq + 16 * hf + 4 * fg) * 2) =
               hf ? bf16x4{sfrag[4], sfrag[5], sfrag[6], sfrag[7]} : bf16x4{sfrag[0], sfrag[1], sfrag[2], sfrag[3]};
         }
-        if (MASK && kq + 2 < NKC) mask_words(mbh, kq + 2, kq & 1);      // keep words two steps ahead (each is an L2 miss)
 #pragma unroll
         for (int n = 0; n < Cf::NT; ++n) {
           const char* pq = s0 + kq * 32 * Cf::ROWB + t_off[n];
@@ -1443,7 +1449,7 @@ int launch_bwd(const bf16* qkv, const int* keylen, const bf16* ctx, const bf16* 
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return M3P_EINVAL;
         n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
       }
-      const size_t ldsp = (size_t)3 * 192 * 128 + (size_t)11 * 16 * 11 * 32 + 2 * 192 * sizeof(float) + 2 * 12 * 3 * 64 * sizeof(float);
+      const size_t ldsp = (size_t)3 * 192 * 128 + (size_t)11 * 16 * 11 * 32 + 2 * 192 * sizeof(float) + 2 * 12 * 3 * 64 * sizeof(float) + 12 * 48 * 8;
       auto kp = thresh24 ? attn_bwd_p_kernel<true, true> : attn_bwd_p_kernel<false, false>;
       hipError_t e = hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp);
       if (e != hipSuccess) return (int)e;

@@ -52,6 +52,16 @@ __global__ void probe_tr16_kernel(const short* __restrict__ tile, short* __restr
 
 }  // namespace
 
+namespace {
+// v_permlane16_swap_b32 x, y: lane l holds (x, y) = (l, 100 + l) before; out[l] = x, out[64 + l] = y after
+__global__ void probe_permlane16_swap_kernel(unsigned* out) {
+  unsigned x = threadIdx.x, y = 100 + threadIdx.x;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+  out[threadIdx.x] = x;
+  out[64 + threadIdx.x] = y;
+}
+}  // namespace
+
 extern "C" {
 
 const char* m3p_version(void) { return "m3p_hip 0.1 gfx950"; }
@@ -67,6 +77,12 @@ int m3p_probe_mfma_fp8_16x16x128(const void* a, const void* w, float* d, int a_i
     hipLaunchKernelGGL((probe_mfma_fp8_kernel<1, 0>), dim3(1), dim3(64), 0, (hipStream_t)stream, (const unsigned char*)a, (const unsigned char*)w, d);
   else
     hipLaunchKernelGGL((probe_mfma_fp8_kernel<0, 0>), dim3(1), dim3(64), 0, (hipStream_t)stream, (const unsigned char*)a, (const unsigned char*)w, d);
+  M3P_CHECK_LAUNCH();
+  return M3P_OK;
+}
+
+int m3p_probe_permlane16_swap(void* out_2x64_u32, void* stream) {
+  hipLaunchKernelGGL(probe_permlane16_swap_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned*)out_2x64_u32);
   M3P_CHECK_LAUNCH();
   return M3P_OK;
 }

@@ -100,6 +100,7 @@ SIGNATURES = {
     'm3p_probe_mfma_16x16x32': (_i, [_p, _p, _p, _p, _p]),
     'm3p_probe_mfma_fp8_16x16x128': (_i, [_p, _p, _p, _i, _p]),
     'm3p_probe_tr16': (_i, [_p, _p, _p]),
+    'm3p_probe_permlane16_swap': (_i, [_p, _p]),
 }
 
 _lib = None

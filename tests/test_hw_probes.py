@@ -52,3 +52,19 @@ def test_ds_read_tr16_gather():
         for j in range(4):
             exp[l, j] = tile[4 * g + j, t]
     assert torch.equal(out.cpu(), exp), 'tr16 gather differs:\n%s' % out.cpu()
+
+
+def test_permlane16_swap_trades_odd_rows_of_x_for_even_rows_of_y():
+    """v_permlane16_swap_b32 x, y: afterwards x = [x.row0, y.row0, x.row2, y.row2] and y = [x.row1, y.row1, x.row3, y.row3]
+    (rows of 16 lanes) - four lanes that hold the 8-byte quarters of one 32-byte run then hold its 16-byte halves."""
+    from m3p_amd import lib as L
+    lib = L.load()
+    out = torch.zeros(128, dtype=torch.int32, device='cuda')
+    L.check(lib.m3p_probe_permlane16_swap(out.data_ptr(), L.stream()), 'probe')
+    torch.cuda.synchronize()
+    x, y = out[:64].cpu().tolist(), out[64:].cpu().tolist()
+    lanes = list(range(64))
+    xin, yin = lanes, [100 + l for l in lanes]
+    row = lambda v, r: v[16 * r:16 * r + 16]      # noqa: E731
+    assert x == row(xin, 0) + row(yin, 0) + row(xin, 2) + row(yin, 2), x
+    assert y == row(xin, 1) + row(yin, 1) + row(xin, 3) + row(yin, 3), y
