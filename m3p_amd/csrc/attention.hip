@@ -111,6 +111,29 @@ __device__ __forceinline__ bf16x8 cat8(bf16x4 a, bf16x4 b) {
   return bf16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
 }
 
+// A row's 16 columns of a d-tile sit in FOUR lanes (fg = lane >> 4 = 0..3 hold columns 4 fg .. 4 fg + 3: 8 bytes each) after
+// the MFMA chains of the backward kernels: NT 8-byte stores per lane and matrix row.  One v_permlane16_swap per register of
+// a d-tile PAIR (odd 16-lane rows of the first trade places with the even rows of the second: tests/test_hw_probes.py)
+// leaves every lane with 16 contiguous bytes - columns 8 (fg >> 1) .. + 7 of tile n0 + (fg & 1) - and halves the store
+// instructions at equal bytes and addresses.  The store tails of these kernels are bound by the CU's vector-memory ISSUE
+// (eleven waves x 12 instructions per head: 3.2 k ticks in the persistent kernel's timeline), not by bandwidth (cdna guide,
+// T21): 185.7 -> 168.2 us on the persistent backward.  `row` = the lane's matrix row (d-tile 0, column 0); every lane of the
+// wave must come through here (the swap exchanges registers between lanes), `ok` masks the store.
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+template <int NT>
+__device__ __forceinline__ void store_row_widened(bf16* row, int fg, bool ok, const bf16x4 (&r)[NT]) {
+  static_assert(NT % 2 == 0, "d-tiles are swapped in pairs");
+  bf16* p = row + 8 * (fg >> 1) + 16 * (fg & 1);
+#pragma unroll
+  for (int n0 = 0; n0 < NT; n0 += 2) {
+    u32x2_t x = __builtin_bit_cast(u32x2_t, r[n0]), y = __builtin_bit_cast(u32x2_t, r[n0 + 1]);
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %2\n\tv_permlane16_swap_b32 %1, %3"
+                 : "+v"(x[0]), "+v"(x[1]), "+v"(y[0]), "+v"(y[1]));
+    if (ok) *reinterpret_cast<u32x4_t*>(p + 16 * n0) = u32x4_t{x[0], x[1], y[0], y[1]};
+  }
+}
+
 // Stage `nrows` rows (clamped to the last valid row `S-1`) of a [S, DH] head slice whose rows
 // are `ld` elements apart into LDS as [nrows][DH] with the chunk swizzle.
 template <int DH>
@@ -366,12 +389,12 @@ void attn_fwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
       }
     }
     if (qb == wrot) ATL(6);
-    if (q < S) {
-      bf16* op = ctx + (size_t)(b * S + q) * dmodel + h * DH + 4 * fg;
+    {
+      bf16x4 ob[Cf::NT];
 #pragma unroll
-      for (int n = 0; n < Cf::NT; ++n)
-        *reinterpret_cast<bf16x4*>(op + 16 * n) = bf16x4{(bf16)o[n][0], (bf16)o[n][1], (bf16)o[n][2], (bf16)o[n][3]};
-      if (fg == 0) lse[(size_t)(b * H + h) * S + q] = mx + __logf(sum);
+      for (int n = 0; n < Cf::NT; ++n) ob[n] = bf16x4{(bf16)o[n][0], (bf16)o[n][1], (bf16)o[n][2], (bf16)o[n][3]};
+      store_row_widened<Cf::NT>(ctx + (size_t)(b * S + min(q, S - 1)) * dmodel + h * DH, fg, q < S, ob);      // (16-byte stores)
+      if (q < S && fg == 0) lse[(size_t)(b * H + h) * S + q] = mx + __logf(sum);
     }
     if (qb == wrot) ATL(7);
   }
@@ -780,24 +803,19 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
 #endif
 #pragma unroll
     for (int u = 0; u < KB; ++u) {
-      if (key[u] < S) {
-        bf16* pk = dKg + (size_t)key[u] * ld + 4 * fg;
-        bf16* pv = dVg + (size_t)key[u] * ld + 4 * fg;
+      bf16x4 kb4[Cf::NT], vb4[Cf::NT];
 #pragma unroll
-        for (int n = 0; n < Cf::NT; ++n) {
-          const bf16x4 kb4 = bf16x4{(bf16)dk[u][n][0], (bf16)dk[u][n][1], (bf16)dk[u][n][2], (bf16)dk[u][n][3]};
-          const bf16x4 vb4 = bf16x4{(bf16)dv[u][n][0], (bf16)dv[u][n][1], (bf16)dv[u][n][2], (bf16)dv[u][n][3]};
-          *reinterpret_cast<bf16x4*>(pk + 16 * n) = kb4;
-          *reinterpret_cast<bf16x4*>(pv + 16 * n) = vb4;
-        }
+      for (int n = 0; n < Cf::NT; ++n) {
+        kb4[n] = bf16x4{(bf16)dk[u][n][0], (bf16)dk[u][n][1], (bf16)dk[u][n][2], (bf16)dk[u][n][3]};
+        vb4[n] = bf16x4{(bf16)dv[u][n][0], (bf16)dv[u][n][1], (bf16)dv[u][n][2], (bf16)dv[u][n][3]};
       }
+      const bool ok = key[u] < S;
       if (dbias_qkv) {   // (rows >= S contribute zeros; the shuffles need all 64 lanes)
 #pragma unroll
-        for (int n = 0; n < Cf::NT; ++n) {
-          const bool ok = key[u] < S;
-          bias_acc(2, n, ok ? bf16x4{(bf16)dv[u][n][0], (bf16)dv[u][n][1], (bf16)dv[u][n][2], (bf16)dv[u][n][3]} : bf16x4{0, 0, 0, 0});
-        }
+        for (int n = 0; n < Cf::NT; ++n) bias_acc(2, n, ok ? vb4[n] : bf16x4{0, 0, 0, 0});
       }
+      store_row_widened<Cf::NT>(dKg + (size_t)keyc[u] * ld, fg, ok, kb4);      // (16-byte stores: see store_row_widened)
+      store_row_widened<Cf::NT>(dVg + (size_t)keyc[u] * ld, fg, ok, vb4);
     }
     BTL_SUM(10, tw);
   }
@@ -830,19 +848,15 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
         }
       }
       const int q = qb * 16 + fq;
-      if (q < S) {
-        bf16* pq = dQg + (size_t)q * ld + 4 * fg;
+      bf16x4 qb4[Cf::NT];
 #pragma unroll
-        for (int n = 0; n < Cf::NT; ++n)
-          *reinterpret_cast<bf16x4*>(pq + 16 * n) = bf16x4{(bf16)(dq[n][0] * qscale), (bf16)(dq[n][1] * qscale), (bf16)(dq[n][2] * qscale),
-                                                           (bf16)(dq[n][3] * qscale)};
-      }
+      for (int n = 0; n < Cf::NT; ++n)
+        qb4[n] = bf16x4{(bf16)(dq[n][0] * qscale), (bf16)(dq[n][1] * qscale), (bf16)(dq[n][2] * qscale), (bf16)(dq[n][3] * qscale)};
       if (dbias_qkv) {
 #pragma unroll
-        for (int n = 0; n < Cf::NT; ++n)
-          bias_acc(0, n, q < S ? bf16x4{(bf16)(dq[n][0] * qscale), (bf16)(dq[n][1] * qscale), (bf16)(dq[n][2] * qscale),
-                                        (bf16)(dq[n][3] * qscale)} : bf16x4{0, 0, 0, 0});
+        for (int n = 0; n < Cf::NT; ++n) bias_acc(0, n, q < S ? qb4[n] : bf16x4{0, 0, 0, 0});
       }
+      store_row_widened<Cf::NT>(dQg + (size_t)min(q, S - 1) * ld, fg, q < S, qb4);
     }
     BTL(6);
   } else {
@@ -1007,23 +1021,16 @@ void attn_bwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
 #endif
 #pragma unroll
     for (int u = 0; u < KBQ; ++u) {
-      if (q[u] < S) {
-        bf16* pq = dQg + (size_t)q[u] * ld + 4 * fg;
+      bf16x4 qb4[Cf::NT];
 #pragma unroll
-        for (int n = 0; n < Cf::NT; ++n) {
-          const bf16x4 qb4 = bf16x4{(bf16)(dq[u][n][0] * qscale), (bf16)(dq[u][n][1] * qscale), (bf16)(dq[u][n][2] * qscale),
-                                    (bf16)(dq[u][n][3] * qscale)};
-          *reinterpret_cast<bf16x4*>(pq + 16 * n) = qb4;
-        }
-      }
+      for (int n = 0; n < Cf::NT; ++n)
+        qb4[n] = bf16x4{(bf16)(dq[u][n][0] * qscale), (bf16)(dq[u][n][1] * qscale), (bf16)(dq[u][n][2] * qscale), (bf16)(dq[u][n][3] * qscale)};
+      const bool ok = q[u] < S;
       if (dbias_qkv) {
 #pragma unroll
-        for (int n = 0; n < Cf::NT; ++n) {
-          const bool ok = q[u] < S;
-          bias_acc(0, n, ok ? bf16x4{(bf16)(dq[u][n][0] * qscale), (bf16)(dq[u][n][1] * qscale), (bf16)(dq[u][n][2] * qscale),
-                                     (bf16)(dq[u][n][3] * qscale)} : bf16x4{0, 0, 0, 0});
-        }
+        for (int n = 0; n < Cf::NT; ++n) bias_acc(0, n, ok ? qb4[n] : bf16x4{0, 0, 0, 0});
       }
+      store_row_widened<Cf::NT>(dQg + (size_t)qc[u] * ld, fg, ok, qb4);
     }
     BTL_SUM(11, tw);
   }
@@ -1166,27 +1173,12 @@ void attn_bwd_p_kernel(const bf16* __restrict__ qkv, const int* __restrict__ key
   bf16x4 kb4[Cf::NT], vb4[Cf::NT], qb4[Cf::NT];
   const int key = wid * 16 + fq;
   bf16* dQg_prev = nullptr;
-  // A row's 16 columns of a d-tile sit in FOUR lanes (fg = 0..3, 8 bytes each): twelve 8-byte stores per lane and head.  One
-  // v_permlane16_swap per register of a d-tile PAIR (odd 16-lane rows of the first trade places with the even rows of the
-  // second: tests/test_hw_probes.py) leaves every lane with 16 contiguous bytes - columns 8 (fg >> 1) .. + 7 of tile
-  // n0 + (fg & 1) - and halves the store instructions at equal bytes and addresses: the segment that issues them is bound by
-  // the CU's vector-memory issue (eleven waves x 12 instructions: 3.2 k ticks per head), not by bandwidth (cdna guide, T21).
-  typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
-  typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-  auto store_head = [&](bf16* dQh) {
+  auto store_head = [&](bf16* dQh) {      // (16-byte stores: store_row_widened)
     if (wid < NTC) {
-      bf16* prow = dQh + (size_t)min(key, S - 1) * ld + 8 * (fg >> 1) + 16 * (fg & 1);
-#pragma unroll
-      for (int mat = 0; mat < 3; ++mat) {
-        bf16x4* r = mat == 0 ? qb4 : (mat == 1 ? kb4 : vb4);
-#pragma unroll
-        for (int n0 = 0; n0 < Cf::NT; n0 += 2) {
-          u32x2_t x = __builtin_bit_cast(u32x2_t, r[n0]), y = __builtin_bit_cast(u32x2_t, r[n0 + 1]);
-          asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %2\n\tv_permlane16_swap_b32 %1, %3"
-                       : "+v"(x[0]), "+v"(x[1]), "+v"(y[0]), "+v"(y[1]));
-          if (key < S) *reinterpret_cast<u32x4_t*>(prow + mat * dmodel + 16 * n0) = u32x4_t{x[0], x[1], y[0], y[1]};
-        }
-      }
+      bf16* row = dQh + (size_t)min(key, S - 1) * ld;
+      store_row_widened<Cf::NT>(row, fg, key < S, qb4);
+      store_row_widened<Cf::NT>(row + dmodel, fg, key < S, kb4);
+      store_row_widened<Cf::NT>(row + 2 * dmodel, fg, key < S, vb4);
     }
   };
   int hd = blockIdx.x;
