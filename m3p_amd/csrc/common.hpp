@@ -99,12 +99,14 @@ __device__ __forceinline__ float gelu_erf_grad_f(float x) {
 }
 
 // gelu_erf'(u) in ONE byte for the FFN data gradient (M3P_EPI_MULQ): gelu' lies in [-0.1290, 1.1290], the code is the
-// nearest level of the grid g = (code - 27) / 200 over [-0.135, 1.14] (step 5e-3: |error| <= 2.5e-3, rms 1.4e-3 - the size of the
-// bf16 rounding of the gradient it multiplies), decoded with one fma.  The grid CONTAINS 0 and 1 (codes 27 and 227; round 5, ADVICE
-// r4): dead and saturated units - most of an FFN's activations - decode to 0 and 1 within one fp32 rounding of the fma (-8e-9, 1 - 6e-8) instead of carrying a
-// systematic -0.0015 / +0.0015 bias.  It is
-// symmetric about 1/2 like gelu' itself (gelu'(-u) = 1 - gelu'(u)  <->  code(-u) = 254 - code(u)).
-constexpr float GQ_OFF = 0.135f, GQ_STEP = 0.005f, GQ_INV = 200.0f;
+// nearest level of the grid g = (code - 27) / 201 over [-0.1343, 1.1343] (step 4.98e-3: |error| <= 2.5e-3, rms 1.4e-3 - the size
+// of the bf16 rounding of the gradient it multiplies), decoded with one fma.  The grid CONTAINS 0 and 1 (codes 27 and 228; round 5,
+// ADVICE r4): dead and saturated units - most of an FFN's activations - decode to 0 and 1 within one fp32 rounding of the fma
+// instead of carrying a systematic -0.0015 / +0.0015 bias.  It is symmetric about 1/2 like gelu' itself, and since round 6 the
+// centre 1/2 sits BETWEEN two levels (127 | 128):  gelu'(-u) = 1 - gelu'(u)  <->  code(-u) = 255 - code(u) = code(u) ^ 0xFF,
+// so an epilogue that looks the code of |u| up in a table fixes the sign with one XOR on four packed codes (gemm.hip:
+// epilogue_piece_geluq_lut).
+constexpr float GQ_STEP = 1.0f / 201.0f, GQ_OFF = 27.0f / 201.0f, GQ_INV = 201.0f;
 __device__ __forceinline__ uint32_t gelu_grad_code(float g) {
   return (uint32_t)__builtin_rintf(fminf(fmaxf((g + GQ_OFF) * GQ_INV, 0.f), 255.f));
 }

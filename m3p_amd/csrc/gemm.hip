@@ -28,7 +28,8 @@
 static int g_variant = 1;  // debug: 0 = force the 128x128 2-stage kernel, 1 = auto (skinny for M <= 128, eight-wave 256x256 for full tiles, ring otherwise),
                            // 2 = force the four-wave 256x256 kernel, 3 = force ring, 6 = force eight-wave 256x256, 7 = the round-1 auto choice (w4 / ring), 9 = auto without the skinny kernel
 static int g_ablate = 0;  // debug: timeline kernels only (bit0 = no fragment reads, bit1 = no LDS-DMA)
-extern "C" void m3p_debug_set_variant(int v) { g_variant = v & 0xff; g_ablate = v >> 8; }     // (declared in the header's developer section)
+static int g_w8_strip = 0; // debug: eight-wave kernel's strip rule (bits 0-3: strip width in tiles, 0 = the default rule; bit 4: odd strips walk M backwards)
+extern "C" void m3p_debug_set_variant(int v) { g_variant = v & 0xff; g_ablate = (v >> 8) & 0xff; g_w8_strip = (v >> 16) & 0xff; }     // (declared in the header's developer section)
 
 namespace {
 
@@ -293,6 +294,9 @@ __device__ __forceinline__ void lds_r128(uint32_t a, u32x4_lds& v) { asm volatil
 #ifndef M3P_W8_SPARE_EPILOGUE
 #define M3P_W8_SPARE_EPILOGUE 1
 #endif
+#ifndef M3P_MQ_PREFETCH
+#define M3P_MQ_PREFETCH 0
+#endif
 #ifndef M3P_DGELU_LUT
 #define M3P_DGELU_LUT 1
 #endif
@@ -341,6 +345,31 @@ __device__ __forceinline__ void load_aux(const M3PEpilogue& ep, int mrow0, int n
 // direct form touches sixteen 32-byte row pieces per instruction.  Measured: dGELU 0.349 -> 0.340 ms, the
 // residual epilogues unchanged (the aux tile costs ~60 us per 41984 x 3072 GEMM either way - see DESIGN.md).
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // (HIP's uint4 is a struct: arrays of it passed by reference end up in scratch)
+
+// 16-byte output-row store.  M3P_ST_POLICY (A/B builds): 0 plain, 1 nt, 2 sc1 (write-through, line dropped from this XCD's L2),
+// 3 sc0 sc1, 4 sc1 nt
+#ifndef M3P_ST_POLICY
+#define M3P_ST_POLICY 0
+#endif
+template <class P>
+__device__ __forceinline__ void st16(P* p, const u32x4& v) {
+#if M3P_ST_POLICY == 0
+  *reinterpret_cast<u32x4*>(p) = v;
+#elif M3P_ST_POLICY == 1
+  __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p));
+#elif M3P_ST_POLICY == 2
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
+#elif M3P_ST_POLICY == 3
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
+#else
+  asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
+#endif
+}
+template <bool NT>
+__device__ __forceinline__ void st16p(void* p, const u32x4& v) {
+  if (NT) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p));
+  else *reinterpret_cast<u32x4*>(p) = v;
+}
 template <int EPI>
 __device__ __forceinline__ void load_aux_rows_issue(const M3PEpilogue& ep, int mrow0, int nw, int lane, u32x4 (&t)[4]) {
   constexpr bool kAux = (EPI == M3P_EPI_BIAS_DROP_RES || EPI == M3P_EPI_RES || EPI == M3P_EPI_DGELU || EPI == M3P_EPI_MUL);
@@ -476,8 +505,8 @@ __device__ __forceinline__ void epilogue_rows16_flush_alds(bf16* __restrict__ C,
   lds_r128(la + ep_off<true>(8 + srow, sch * 16), R[1]);
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(R[0]), "+v"(R[1]));
   bf16* Cp = C + (size_t)mrow0 * ldc + nw + sch * 8;
-  *reinterpret_cast<u32x4*>(Cp + (size_t)srow * ldc) = R[0];
-  *reinterpret_cast<u32x4*>(Cp + (size_t)(8 + srow) * ldc) = flip_halves(R[1], true);
+  st16(Cp + (size_t)srow * ldc, R[0]);
+  st16(Cp + (size_t)(8 + srow) * ldc, flip_halves(R[1], true));
 }
 // the wait that belongs to epilogue_rows_read<SW, true>: `younger` (8 or 0) LDS instructions of this wave may stay in flight
 template <bool SW>
@@ -493,7 +522,7 @@ __device__ __forceinline__ void epilogue_rows_store(bf16* __restrict__ C, int ld
   const int srow = lane >> 3, sch = lane & 7;
   bf16* Cp = C + (size_t)mrow0 * ldc + nw + sch * 8;
 #pragma unroll
-  for (int it = 0; it < 4; ++it) *reinterpret_cast<u32x4*>(Cp + (size_t)(it * 8 + srow) * ldc) = R[it];
+  for (int it = 0; it < 4; ++it) st16(Cp + (size_t)(it * 8 + srow) * ldc, R[it]);
 }
 template <int EPI, bool SW = false, bool ALDS = false>
 __device__ __forceinline__ void epilogue_half(const M3PEpilogue& ep, bf16* __restrict__ C, int ldc, int N,
@@ -516,7 +545,7 @@ __device__ __forceinline__ void epilogue_half(const M3PEpilogue& ep, bf16* __res
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
     const int row = it * 8 + srow;
-    *reinterpret_cast<u32x4*>(Cp + (size_t)row * ldc) = flip_halves(*reinterpret_cast<const u32x4*>(r1 + ep_off<SW>(row, sch * 16)), SW && (it & 1));
+    st16(Cp + (size_t)row * ldc, flip_halves(*reinterpret_cast<const u32x4*>(r1 + ep_off<SW>(row, sch * 16)), SW && (it & 1)));
   }
   if (EPI == M3P_EPI_BIAS_GELU) {
 #pragma unroll
@@ -528,7 +557,7 @@ __device__ __forceinline__ void epilogue_half(const M3PEpilogue& ep, bf16* __res
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int row = it * 8 + srow;
-      *reinterpret_cast<u32x4*>(Up + (size_t)row * ep.ld_out2) = flip_halves(*reinterpret_cast<const u32x4*>(r1 + ep_off<SW>(row, sch * 16)), SW && (it & 1));
+      st16(Up + (size_t)row * ep.ld_out2, flip_halves(*reinterpret_cast<const u32x4*>(r1 + ep_off<SW>(row, sch * 16)), SW && (it & 1)));
     }
   }
 }
@@ -606,13 +635,27 @@ __device__ __forceinline__ void epilogue_piece16(const M3PEpilogue& ep, bf16* __
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
     const int row = it * 8 + srow;
-    *reinterpret_cast<u32x4*>(Cp + (size_t)row * ldc) = flip_halves(*reinterpret_cast<const u32x4*>(r1 + ep_off<true>(row, sch * 16)), it & 1);
+    st16(Cp + (size_t)row * ldc, flip_halves(*reinterpret_cast<const u32x4*>(r1 + ep_off<true>(row, sch * 16)), it & 1));
   }
 }
 
 // 16-row piece of the byte-derivative epilogue (M3P_EPI_MULQ): out = acc * decode(code), column sums.  `q` holds this
 // lane's sixteen codes of the piece in accumulator order (dword j = columns 16 j + 4 fg .. + 3 of row fr: the fragment-order
 // layout of common.hpp, fetched by the caller with one 16-byte load) - no aux trip through LDS, three VALU per element.
+// M3P_MQ_ABL (timing ablations, results are garbage): 1 = the codes are not read (the caller passes lane numbers), 2 = dU is
+// neither staged nor stored, 4 = no column sums
+#ifndef M3P_MQ_ABL
+#define M3P_MQ_ABL 0
+#endif
+#ifndef M3P_MQ_NT
+#define M3P_MQ_NT 1          // dU rows leave with non-temporal stores: 209 -> 194 us on the 41984 x 3072 x 768 product (profiles/r06_store_policy.txt)
+#endif
+#ifndef M3P_MQ_CSUMV
+#define M3P_MQ_CSUMV 1
+#endif
+#ifndef M3P_MQ_NTLOAD
+#define M3P_MQ_NTLOAD 0
+#endif
 __device__ __forceinline__ void epilogue_pieceq(bf16* __restrict__ C, int ldc, int mrow0, int nw, char* r1, const f32x4 (&rows)[4],
                                                 const u32x4& q, int lane, f32x4 (&csum)[4]) {
   const int fr = lane & 15, fg = lane >> 4;
@@ -624,16 +667,20 @@ __device__ __forceinline__ void epilogue_pieceq(bf16* __restrict__ C, int ldc, i
     g = g * GQ_STEP - GQ_OFF;
     const f32x4 v = rows[j] * g;
     const bf16x4 ob = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-    if (M3P_EPI_ALDS) lds_w64(lds_addr(r1) + ep_off8<true>(fr, (j * 16 + fg * 4) * 2), ob);
+    if (M3P_MQ_ABL & 2) asm volatile("" :: "v"(ob));
+    else if (M3P_EPI_ALDS) lds_w64(lds_addr(r1) + ep_off8<true>(fr, (j * 16 + fg * 4) * 2), ob);
     else *reinterpret_cast<bf16x4*>(r1 + ep_off8<true>(fr, (j * 16 + fg * 4) * 2)) = ob;
-    csum[j] += f32x4{(float)ob[0], (float)ob[1], (float)ob[2], (float)ob[3]};
+    // column sums (lin1's bias gradient) of the fp32 products: one add per element (round 6; summing the bf16-rounded values
+    // cost an unpack per element on top and is no closer to the fp32 reference's sum)
+    if (!(M3P_MQ_ABL & 4)) { if (M3P_MQ_CSUMV) csum[j] += v; else csum[j] += f32x4{(float)ob[0], (float)ob[1], (float)ob[2], (float)ob[3]}; }
   }
+  if (M3P_MQ_ABL & 2) return;
   if (M3P_EPI_ALDS) { epilogue_rows16_flush_alds(C, ldc, mrow0, nw, r1, lane); return; }
   bf16* Cp = C + (size_t)mrow0 * ldc + nw + sch * 8;
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
     const int row = it * 8 + srow;
-    *reinterpret_cast<u32x4*>(Cp + (size_t)row * ldc) = flip_halves(*reinterpret_cast<const u32x4*>(r1 + ep_off<true>(row, sch * 16)), it & 1);
+    st16p<M3P_MQ_NT != 0>(Cp + (size_t)row * ldc, flip_halves(*reinterpret_cast<const u32x4*>(r1 + ep_off<true>(row, sch * 16)), it & 1));
   }
 }
 
@@ -702,7 +749,7 @@ __device__ __forceinline__ void epilogue_half_lse(bf16* __restrict__ C, int ldc,
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
     const int row = it * 8 + srow;
-    *reinterpret_cast<u32x4*>(Cp + (size_t)row * ldc) = flip_halves(*reinterpret_cast<const u32x4*>(r1 + ep_off<true>(row, sch * 16)), it & 1);
+    st16(Cp + (size_t)row * ldc, flip_halves(*reinterpret_cast<const u32x4*>(r1 + ep_off<true>(row, sch * 16)), it & 1));
   }
 }
 
@@ -711,6 +758,11 @@ __device__ __forceinline__ void epilogue_half_lse(bf16* __restrict__ C, int ldc,
 // straight from the accumulator layout in fragment order (16 bytes per lane and 16-row block: 1 KB per wave instruction,
 // no staging) - what M3P_EPI_MULQ reads back the same way.  u itself is never stored.  The arithmetic is written on
 // four-element vectors so that the polynomial runs on packed f32 instructions (the epilogue has the VALU to itself).
+// M3P_GQ_ABL (timing ablations of this epilogue, results are garbage): 1 = no arithmetic (h = x, code = bits of x),
+// 2 = the codes are not stored, 4 = h is neither staged nor stored
+#ifndef M3P_GQ_ABL
+#define M3P_GQ_ABL 0
+#endif
 __device__ __forceinline__ void epilogue_half_geluq(bf16* __restrict__ C, int ldc, uint8_t* __restrict__ qout, int mrow0, int nw,
                                                     char* r1, const f32x4 (&rows0)[4], const f32x4 (&rows1)[4],
                                                     const f32x4 (&biasv)[4], int lane) {
@@ -723,6 +775,15 @@ __device__ __forceinline__ void epilogue_half_geluq(bf16* __restrict__ C, int ld
     for (int j = 0; j < 4; ++j) {
       // (x stays fp32: with u never stored there is no bf16 copy anything else would have to agree with)
       const f32x4 x = (ii ? rows1[j] : rows0[j]) + biasv[j];
+#if M3P_GQ_ABL & 1
+      {
+        code[j] = __builtin_bit_cast(uint32_t, x[0]);
+        const bf16x4 hb = bf16x4{(bf16)x[0], (bf16)x[1], (bf16)x[2], (bf16)x[3]};
+        if (M3P_GQ_ABL & 4) asm volatile("" :: "v"(hb));
+        else *reinterpret_cast<bf16x4*>(r1 + ep_off8<true>(ii * 16 + fr, (j * 16 + fg * 4) * 2)) = hb;
+        continue;
+      }
+#endif
       // gelu_parts (common.hpp) on a vector: Phi(|x|) = 1 - (poly(t) t e) / 2, t = 1 / (1 + p z), z = |x| / sqrt 2, e = exp(-z^2)
       f32x4 z, t, e;
 #if M3P_GQ_TRIM
@@ -769,11 +830,14 @@ __device__ __forceinline__ void epilogue_half_geluq(bf16* __restrict__ C, int ld
       const f32x4 qf = gd * GQ_INV + (GQ_OFF * GQ_INV + 0.5f);                 // in [1.7, 253.3): truncation = round to nearest
       code[j] = (uint32_t)qf[0] | ((uint32_t)qf[1] << 8) | ((uint32_t)qf[2] << 16) | ((uint32_t)qf[3] << 24);
 #endif
-      if (M3P_EPI_ALDS) lds_w64(lds_addr(r1) + ep_off8<true>(ii * 16 + fr, (j * 16 + fg * 4) * 2), bf16x4{(bf16)hv[0], (bf16)hv[1], (bf16)hv[2], (bf16)hv[3]});
+      if (M3P_GQ_ABL & 4) { const bf16x4 hb = bf16x4{(bf16)hv[0], (bf16)hv[1], (bf16)hv[2], (bf16)hv[3]}; asm volatile("" :: "v"(hb)); }
+      else if (M3P_EPI_ALDS) lds_w64(lds_addr(r1) + ep_off8<true>(ii * 16 + fr, (j * 16 + fg * 4) * 2), bf16x4{(bf16)hv[0], (bf16)hv[1], (bf16)hv[2], (bf16)hv[3]});
       else *reinterpret_cast<bf16x4*>(r1 + ep_off8<true>(ii * 16 + fr, (j * 16 + fg * 4) * 2)) = bf16x4{(bf16)hv[0], (bf16)hv[1], (bf16)hv[2], (bf16)hv[3]};
     }
-    *reinterpret_cast<u32x4*>(qout + ii * 1024 + lane * 16) = code;
+    if (M3P_GQ_ABL & 2) asm volatile("" :: "v"(code));
+    else st16(qout + ii * 1024 + lane * 16, code);
   }
+  if (M3P_GQ_ABL & 4) return;
   if (M3P_EPI_ALDS) {
     u32x4 R[4];
     epilogue_rows_read<true, true>(r1, lane, R);
@@ -785,8 +849,97 @@ __device__ __forceinline__ void epilogue_half_geluq(bf16* __restrict__ C, int ld
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
     const int row = it * 8 + srow;
-    *reinterpret_cast<u32x4*>(Cp + (size_t)row * ldc) = flip_halves(*reinterpret_cast<const u32x4*>(r1 + ep_off<true>(row, sch * 16)), it & 1);
+    st16(Cp + (size_t)row * ldc, flip_halves(*reinterpret_cast<const u32x4*>(r1 + ep_off<true>(row, sch * 16)), it & 1));
   }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 6: the lin1 + GELU + byte epilogue from ONE table read per element (M3P_GQ_LUT, default).
+// The round-4 form above evaluates erf and the Gaussian on the VALU - ~17 issue slots and two quarter-rate
+// transcendentals per element, with the matrix pipe idle: measured (profiles/r06_gq_ablation.txt) the arithmetic alone is
+// 46-64 us of the 232-us launch.  Both results are functions of x, and to the accuracy a bf16 output and a one-byte code can
+// carry they are functions of the upper 16 bits of x:
+//     h(x)     = max(x, 0) - |x| T(|x|)          T = 1 - Phi, the upper Gaussian tail
+//     code(x)  = c(|x|) ^ (x < 0 ? 0xFF : 0)     c = the byte code of gelu'(|x|) (common.hpp: the grid is symmetric about 1/2)
+// so one 32-bit table word per bf16 magnitude holds T as an fp32 whose low mantissa byte is replaced by c (T keeps 15
+// mantissa bits: relative error 2^-16, far below the bf16 rounding of h).  The index is the TRUNCATED bf16 magnitude of the
+// fp32 x (one v_bfe - no rounding instruction), clamped to |x| in [2^-15, 8) (one v_med3); the entry is evaluated at the
+// MIDDLE of its truncation bucket, which makes the index error that of round-to-nearest (|dx| <= 2^-9 |x|, what a bf16
+// pre-activation would carry anyway).  x itself enters h in full fp32 (fma(-|x|, T, max(x, 0))).
+// Per element: v_bfe, v_med3, v_lshl_add (address), ds_read_b32, v_max, v_fma, half a v_cvt_pk_bf16 and 7/4 of an
+// instruction for the code (v_perm gathers the four code bytes and - selectors 9 / 11 - the four sign masks) = ~7 VALU + 1 LDS
+// read; the bias rides in the accumulators (they start an output tile at the bias instead of zero), so there is no add.
+// 16-row pieces: staging 2 KB per wave, the 9-KB table beside it (25 of the 32 KB the two stages leave).
+// ---------------------------------------------------------------------------------------------------------------------
+#ifndef M3P_GQ_LUT
+#define M3P_GQ_LUT 1
+#endif
+#ifndef M3P_GQ_NT
+#define M3P_GQ_NT 1          // h rows and codes leave with non-temporal stores (r06_store_policy.txt)
+#endif
+constexpr int GQ_TAB_BYTES = GELU_TAB_N * 4;
+__device__ __forceinline__ void geluq_table_fill(uint32_t* tab, int tid, int nthreads) {
+  for (int i = tid; i < GELU_TAB_N; i += nthreads) {
+    // middle of the truncation bucket of bf16 magnitude GELU_TAB_LO + i (the last bucket stands for every |x| >= 8, the first
+    // for every |x| < 2^-15: T = 1/2 there, code 128 - half a step from gelu'(0) = 1/2 like its mirror image 127)
+    const float xm = __builtin_bit_cast(float, ((uint32_t)(GELU_TAB_LO + i) << 16) | 0x8000u);
+    const float tail = 0.5f * erfcf(xm * 0.70710678118654752440f);
+    const float gd = (1.0f - tail) + xm * 0.39894228040143267794f * __expf(-0.5f * xm * xm);
+    tab[i] = (__builtin_bit_cast(uint32_t, tail) & 0xFFFFFF00u) | gelu_grad_code(gd);
+  }
+}
+__device__ __forceinline__ void lds_r32(uint32_t a, uint32_t& v) { asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(a)); }
+// one 16-row piece (this wave's 16 x 64 block at (mrow0, nw)): `rows` = accumulators INCLUDING the bias, tab_off = LDS byte
+// address of the table minus 4 * GELU_TAB_LO, r1 = the wave's 2 KB of staging rows, qout = where the piece's 1024 code bytes go
+__device__ __forceinline__ void epilogue_piece_geluq_lut(bf16* __restrict__ C, int ldc, uint8_t* __restrict__ qout, int mrow0, int nw,
+                                                         char* r1, const f32x4 (&rows)[4], int lane, uint32_t tab_off) {
+  const int fr = lane & 15, fg = lane >> 4;
+  const int srow = lane >> 3, sch = lane & 7;
+  uint32_t w[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float xf = rows[j][r];       // (through a scalar: __builtin_bit_cast applied to a vector ELEMENT reads element 0 - seen in the ISA)
+      const uint32_t xb = __builtin_bit_cast(uint32_t, xf);
+      const uint32_t mag = __builtin_amdgcn_ubfe(xb, 16, 15);
+      const uint32_t idx = min(max(mag, (uint32_t)GELU_TAB_LO), (uint32_t)(GELU_TAB_HI - 1));     // (v_med3_u32)
+      lds_r32((idx << 2) + tab_off, w[j][r]);
+    }
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[0][2]), "+v"(w[0][3]), "+v"(w[1][0]), "+v"(w[1][1]), "+v"(w[1][2]), "+v"(w[1][3]),
+                                        "+v"(w[2][0]), "+v"(w[2][1]), "+v"(w[2][2]), "+v"(w[2][3]), "+v"(w[3][0]), "+v"(w[3][1]), "+v"(w[3][2]), "+v"(w[3][3]));
+  const uint32_t la = lds_addr(r1);
+  u32x4 code;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    f32x4 hv;
+    float xs[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      xs[r] = rows[j][r];
+      // two instructions, written out: from C the compiler canonicalises the MFMA result first (v_max x, x) and forms -|x| with
+      // an extra v_or to feed a packed fma (5 issue slots per element instead of 2)
+      float mx;
+      asm("v_max_f32 %0, 0, %1" : "=v"(mx) : "v"(xs[r]));
+      asm("v_fma_f32 %0, -|%1|, %2, %3" : "=v"(hv[r]) : "v"(xs[r]), "v"(w[j][r]), "v"(mx));
+    }
+    // code bytes 0 / 1 / 2 / 3 = low byte of w[j][0..3]; sign masks (0xFF where x < 0) by the sign-replicating selectors
+    const uint32_t x0 = __builtin_bit_cast(uint32_t, xs[0]), x1 = __builtin_bit_cast(uint32_t, xs[1]);
+    const uint32_t x2 = __builtin_bit_cast(uint32_t, xs[2]), x3 = __builtin_bit_cast(uint32_t, xs[3]);
+    const uint32_t blo = __builtin_amdgcn_perm(w[j][1], w[j][0], 0x0c0c0400u), bhi = __builtin_amdgcn_perm(w[j][3], w[j][2], 0x04000c0cu);
+    const uint32_t slo = __builtin_amdgcn_perm(x1, x0, 0x0c0c0b09u), shi = __builtin_amdgcn_perm(x3, x2, 0x0b090c0cu);
+    code[j] = (blo | bhi) ^ (slo | shi);
+    lds_w64(la + ep_off8<true>(fr, (j * 16 + fg * 4) * 2), bf16x4{(bf16)hv[0], (bf16)hv[1], (bf16)hv[2], (bf16)hv[3]});
+  }
+  st16p<M3P_GQ_NT != 0>(qout + lane * 16, code);
+  u32x4 R[2];
+  lds_r128(la + ep_off<true>(srow, sch * 16), R[0]);
+  lds_r128(la + ep_off<true>(8 + srow, sch * 16), R[1]);
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(R[0]), "+v"(R[1]));
+  bf16* Cp = C + (size_t)mrow0 * ldc + nw + sch * 8;
+  st16p<M3P_GQ_NT != 0>(Cp + (size_t)srow * ldc, R[0]);
+  st16p<M3P_GQ_NT != 0>(Cp + (size_t)(8 + srow) * ldc, flip_halves(R[1], true));
 }
 
 #if defined(M3P_RING_TL) || defined(M3P_W8_TL) || defined(M3P_WG_TL)
@@ -1094,7 +1247,7 @@ template <int EPI, bool DYN = false>
 __global__ __launch_bounds__(512)
 void gemm_nt_w8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ W, int ldw,
                        bf16* __restrict__ C, int ldc, int M, int N, int K, M3PEpilogue ep,
-                       int tiles_m, int tiles_n, int* __restrict__ tile_ctr) {
+                       int tiles_m, int tiles_n, int* __restrict__ tile_ctr, int strip_arg) {
   constexpr int BM = 256, BN = 256, NWAVES = 8;
   constexpr int A_BYTES = BM * ROWB, STAGE = (BM + BN) * ROWB;      // 32 KB, 64 KB
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1102,14 +1255,17 @@ void gemm_nt_w8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ntiles = tiles_m * tiles_n;
-  const int n_strips = (tiles_n >= 12) ? (tiles_n + 3) / 4 : 1;
+  const int strip_req = strip_arg & 15;
+  const int n_strips = strip_req ? (tiles_n + strip_req - 1) / strip_req : ((tiles_n >= 12) ? (tiles_n + 3) / 4 : 1);
   const int strip_w = (tiles_n + n_strips - 1) / n_strips;
+  const bool serpentine = (strip_arg & 16) != 0;
   auto split_tile = [&](int t, int& tm, int& tn) {
     const int strip = t / (tiles_m * strip_w);
     const int rem = t - strip * tiles_m * strip_w;
     const int bn = min(strip_w, tiles_n - strip * strip_w);
     tm = rem / bn;
     tn = strip * strip_w + (rem - tm * bn);
+    if (serpentine && (strip & 1)) tm = tiles_m - 1 - tm;
   };
   const int nwg = gridDim.x;
   const int per_xcd = nwg >> 3;
@@ -1138,9 +1294,11 @@ void gemm_nt_w8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
   constexpr bool kSpare = M3P_W8_SPARE_EPILOGUE;
   constexpr bool kMulE = (EPI == M3P_EPI_DGELU || EPI == M3P_EPI_MUL || EPI == M3P_EPI_MULQ);
   constexpr bool kAuxE = (EPI == M3P_EPI_BIAS_DROP_RES || EPI == M3P_EPI_RES || kMulE);
-  constexpr int kTabBytes = (EPI == M3P_EPI_DGELU && M3P_DGELU_LUT) ? GELU_TAB_N * (int)sizeof(float) : 0;
+  constexpr bool kGqLut = (EPI == M3P_EPI_BIAS_GELUQ) && M3P_GQ_LUT;
+  constexpr int kTabBytes = ((EPI == M3P_EPI_DGELU && M3P_DGELU_LUT) || kGqLut) ? GELU_TAB_N * (int)sizeof(float) : 0;
   float* gtab = (EPI == M3P_EPI_DGELU && M3P_DGELU_LUT) ? reinterpret_cast<float*>(smem + 2 * STAGE) : nullptr;
   if (EPI == M3P_EPI_DGELU && M3P_DGELU_LUT) gelu_grad_table_fill(gtab, tid, 512);
+  if (kGqLut) geluq_table_fill(reinterpret_cast<uint32_t*>(smem + 2 * STAGE), tid, 512);      // (the prologue's barrier publishes it)
   int* const mbox = reinterpret_cast<int*>(smem + 2 * STAGE + kTabBytes);
 
   // ---- load cursor: one LDS-DMA = 8 rows x 128 B; piece i of wave w covers row group w + 8 i of an operand
@@ -1277,6 +1435,17 @@ void gemm_nt_w8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if constexpr (kGqLut) {      // the accumulators of an output tile start at its bias (this lane's columns nw + 16 j + 4 fg .. + 3)
+    int tm0, tn0;
+    split_tile(slot, tm0, tn0);
+    const float* bp = ep.bias + tn0 * BN + wn * 64 + fg * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f32x4 b = *reinterpret_cast<const f32x4*>(bp + j * 16);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i][j] = b;
+    }
+  }
 #ifndef M3P_W8_SETPRIO
 #define M3P_W8_SETPRIO 1
 #endif
@@ -1329,6 +1498,14 @@ void gemm_nt_w8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
 #endif
   // ---- prologue: K-tiles 0 and 1 into stages 0 and 1
   set_load_tile(slot);
+#if M3P_MQ_PREFETCH
+  if (EPI == M3P_EPI_MULQ) {       // (the first output tile's codes: see the epilogue)
+    int tm2, tn2;
+    split_tile(slot, tm2, tn2);
+    const uint8_t* pf = reinterpret_cast<const uint8_t*>(ep.aux) + gq_block_offset(tm2, tn2, tiles_n, wid, 0) + lane * 128;
+    __builtin_amdgcn_global_load_lds(GLB_PTR(pf), LDS_PTR(smem + 2 * STAGE + 8 * 2048 + wid * 256), 4, 0, 0);
+  }
+#endif
   stage_next(0);
 #define W8_H1 (dyn ? h1d : (step + 1 < total))
 #define W8_MORE2 (dyn ? l_alive : more2)
@@ -1480,6 +1657,32 @@ void gemm_nt_w8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
           }
         }
         W8_TSEG(2);
+      } else if constexpr (kGqLut) {
+        // (the launcher admits whole, aligned tiles only: `fast` always holds)
+        f32x4 bnext[4];
+        {
+          const bool more_tiles = dyn ? (t_cmp >= 0) : (c_q < my_tiles);       // (c_q / t_cmp already name the NEXT output tile)
+          int tm2 = tm, tn2 = tn;
+          if (more_tiles) split_tile(dyn ? t_cmp : tile_of(c_q), tm2, tn2);
+          const float* bp = ep.bias + tn2 * BN + wn * 64 + fg * 4;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) bnext[j] = *reinterpret_cast<const f32x4*>(bp + j * 16);
+        }
+        {
+          char* r1 = smem + 2 * STAGE + kTabBytes + wid * 2048;
+          const uint32_t tab_off = lds0 + 2 * STAGE - 4 * GELU_TAB_LO;
+          uint8_t* qo = reinterpret_cast<uint8_t*>(ep.out2) + gq_block_offset(tm, tn, tiles_n, wid, 0);
+#pragma unroll
+          for (int hp = 0; hp < 8; ++hp) {
+            epilogue_piece_geluq_lut(C, ldc, qo + 1024 * hp, mw + 16 * hp, nw, r1, acc[hp], lane, tab_off);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = bnext[j];
+        W8_TSEG(2);
       } else if constexpr (EPI == M3P_EPI_BIAS_GELUQ) {
         if (fast) {
           char* r1 = smem + 2 * STAGE + wid * 4096;
@@ -1503,21 +1706,37 @@ void gemm_nt_w8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
         if (fast) {
           const uint8_t* qp = reinterpret_cast<const uint8_t*>(ep.aux) + gq_block_offset(tm, tn, tiles_n, wid, 0) + lane * 16;
           char* r1 = smem + 2 * STAGE + wid * 2048;
-          u32x4 qa = *reinterpret_cast<const u32x4*>(qp), qb = *reinterpret_cast<const u32x4*>(qp + 1024);
+#if M3P_MQ_ABL & 1
+#define MQ_LD(off) u32x4{(uint32_t)lane * 0x01010101u, 0x40404040u + (off), 0x80808080u, 0xc0c0c0c0u}
+#else
+#define MQ_LD(off) (M3P_MQ_NTLOAD ? __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(qp + (off))) : *reinterpret_cast<const u32x4*>(qp + (off)))
+#endif
+          u32x4 qa = MQ_LD(0), qb = MQ_LD(1024);
           __builtin_amdgcn_sched_barrier(0);
           if (W8_MORE2) { issue_load(cur, 0); issue_load(cur, 1); issue_load(cur, 2); spread_pending = true; }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int hp = 0; hp < 8; hp += 2) {
             u32x4 qc = qa, qd = qb;
-            if (hp + 2 < 8) qc = *reinterpret_cast<const u32x4*>(qp + (hp + 2) * 1024);
+            if (hp + 2 < 8) qc = MQ_LD((hp + 2) * 1024);
             epilogue_pieceq(C, ldc, mw + 16 * hp, nw, r1, acc[hp], qa, lane, csum);
             __builtin_amdgcn_sched_barrier(0);
-            if (hp + 3 < 8) qd = *reinterpret_cast<const u32x4*>(qp + (hp + 3) * 1024);
+            if (hp + 3 < 8) qd = MQ_LD((hp + 3) * 1024);
             epilogue_pieceq(C, ldc, mw + 16 * (hp + 1), nw, r1, acc[hp + 1], qb, lane, csum);
             __builtin_amdgcn_sched_barrier(0);
             qa = qc; qb = qd;
           }
+#undef MQ_LD
+#if M3P_MQ_PREFETCH
+          // the NEXT output tile's codes (this wave's 8 KB = 64 lines) pulled towards this XCD's L2 a whole K loop ahead: one
+          // 4-byte LDS-DMA per lane, each touching another 128-byte line, into 256 idle bytes behind the staging rows
+          if (dyn ? (t_cmp >= 0) : (c_q < my_tiles)) {
+            int tm2, tn2;
+            split_tile(dyn ? t_cmp : tile_of(c_q), tm2, tn2);
+            const uint8_t* pf = reinterpret_cast<const uint8_t*>(ep.aux) + gq_block_offset(tm2, tn2, tiles_n, wid, 0) + lane * 128;
+            __builtin_amdgcn_global_load_lds(GLB_PTR(pf), LDS_PTR(smem + 2 * STAGE + 8 * 2048 + wid * 256), 4, 0, 0);
+          }
+#endif
         }
         W8_TSEG(2);
       } else if (fast && kSpare && kMulE) {
@@ -1576,10 +1795,12 @@ void gemm_nt_w8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
           for (int j = 0; j < 4; ++j)
             epilogue_store<EPI>(ep, C, ldc, M, N, mw + i * 16 + fr, nw + j * 16 + fg * 4, acc[i][j], csum[j]);
       }
+      if constexpr (!kGqLut) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+          for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
       if (W8_H1) {
         if (!kSpare) {
           // the staging rows are where K-tile +2 goes: nobody requests it before every wave is done with its round trip
@@ -1643,14 +1864,18 @@ void gemm_nt_w8f8_kernel(const uint8_t* __restrict__ A, int lda, const uint8_t* 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ntiles = tiles_m * tiles_n;
-  const int n_strips = (tiles_n >= 12) ? (tiles_n + 3) / 4 : 1;
+  constexpr int strip_arg = 0;
+  const int strip_req = strip_arg & 15;
+  const int n_strips = strip_req ? (tiles_n + strip_req - 1) / strip_req : ((tiles_n >= 12) ? (tiles_n + 3) / 4 : 1);
   const int strip_w = (tiles_n + n_strips - 1) / n_strips;
+  const bool serpentine = (strip_arg & 16) != 0;
   auto split_tile = [&](int t, int& tm, int& tn) {
     const int strip = t / (tiles_m * strip_w);
     const int rem = t - strip * tiles_m * strip_w;
     const int bn = min(strip_w, tiles_n - strip * strip_w);
     tm = rem / bn;
     tn = strip * strip_w + (rem - tm * bn);
+    if (serpentine && (strip & 1)) tm = tiles_m - 1 - tm;
   };
   const int nwg = gridDim.x;
   const int per_xcd = nwg >> 3;
@@ -1662,9 +1887,11 @@ void gemm_nt_w8f8_kernel(const uint8_t* __restrict__ A, int lda, const uint8_t* 
   constexpr bool kSpare = M3P_W8_SPARE_EPILOGUE;
   constexpr bool kMulE = (EPI == M3P_EPI_DGELU || EPI == M3P_EPI_MUL);
   constexpr bool kAuxE = (EPI == M3P_EPI_BIAS_DROP_RES || EPI == M3P_EPI_RES || kMulE);
-  constexpr int kTabBytes = (EPI == M3P_EPI_DGELU && M3P_DGELU_LUT) ? GELU_TAB_N * (int)sizeof(float) : 0;
+  constexpr bool kGqLut = (EPI == M3P_EPI_BIAS_GELUQ) && M3P_GQ_LUT;
+  constexpr int kTabBytes = ((EPI == M3P_EPI_DGELU && M3P_DGELU_LUT) || kGqLut) ? GELU_TAB_N * (int)sizeof(float) : 0;
   float* gtab = (EPI == M3P_EPI_DGELU && M3P_DGELU_LUT) ? reinterpret_cast<float*>(smem + 2 * STAGE) : nullptr;
   if (EPI == M3P_EPI_DGELU && M3P_DGELU_LUT) gelu_grad_table_fill(gtab, tid, 512);
+  if (kGqLut) geluq_table_fill(reinterpret_cast<uint32_t*>(smem + 2 * STAGE), tid, 512);      // (the prologue's barrier publishes it)
   const int nk = K / BK8;
   const int total = my_tiles * nk;
   // per-tensor scales of the two operands (device scalars: delayed scaling keeps them on the device)
@@ -3034,11 +3261,11 @@ int launch_nt(const bf16* A, int lda, const bf16* W, int ldw, bf16* C, int ldc, 
         if (e != hipSuccess) return (int)e;
         attr_set8d = true;
       }
-      hipLaunchKernelGGL(kern_d, dim3(grid), dim3(512), lds, st, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_m, tiles_n, ctr);
+      hipLaunchKernelGGL(kern_d, dim3(grid), dim3(512), lds, st, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_m, tiles_n, ctr, g_w8_strip);
       M3P_CHECK_LAUNCH();
       return M3P_OK;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_m, tiles_n, ctr);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_m, tiles_n, ctr, g_w8_strip);
     M3P_CHECK_LAUNCH();
     return M3P_OK;
   }
@@ -3112,7 +3339,8 @@ static int launch_nt_gq(const bf16* A, int lda, const bf16* W, int ldw, bf16* C,
     return M3P_EINVAL;
   if (EPI == M3P_EPI_BIAS_LSE && (ep.ld_out2 <= 0 || ep.ld_out2 > N)) return M3P_EINVAL;
   const int tiles_m = M / 256, tiles_n = N / 256;
-  const size_t lds = 2 * 512 * ROWB + 8 * (EPI != M3P_EPI_MULQ ? 4096 : 2048);
+  const size_t lds = 2 * 512 * ROWB + ((EPI == M3P_EPI_BIAS_GELUQ && M3P_GQ_LUT) ? GQ_TAB_BYTES + 8 * 2048 : 8 * (EPI != M3P_EPI_MULQ ? 4096 : 2048)) +
+                     ((EPI == M3P_EPI_MULQ && M3P_MQ_PREFETCH) ? 2048 : 0);
   auto kern = gemm_nt_w8_kernel<EPI>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -3123,7 +3351,7 @@ static int launch_nt_gq(const bf16* A, int lda, const bf16* W, int ldw, bf16* C,
   int grid = num_cus();
   const int ntiles = tiles_m * tiles_n;
   if (ntiles < grid) grid = (ntiles + 7) / 8 * 8;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_m, tiles_n, (int*)nullptr);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_m, tiles_n, (int*)nullptr, g_w8_strip);
   M3P_CHECK_LAUNCH();
   return M3P_OK;
 }

@@ -681,7 +681,7 @@ def gelu_fwd(u, grad_inplace=False):
     return h
 
 
-GQ_OFF, GQ_STEP = 0.135, 0.005       # the byte code of gelu' (csrc/common.hpp): gelu' ~ code * GQ_STEP - GQ_OFF
+GQ_OFF, GQ_STEP = 27.0 / 201.0, 1.0 / 201.0       # the byte code of gelu' (csrc/common.hpp): gelu' ~ code * GQ_STEP - GQ_OFF
 
 
 def gq_eligible(M, N):

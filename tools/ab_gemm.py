@@ -28,6 +28,8 @@ for k, spec in enumerate(sys.argv[1:]):
     fn = h.m3p_gemm_nt_bf16
     fn.restype, fn.argtypes = L.SIGNATURES['m3p_gemm_nt_bf16']
     h.m3p_debug_set_variant(int(var))
+    if os.environ.get('AB_GRID'):
+        assert h.m3p_set_persistent_grid(int(os.environ['AB_GRID'])) == 0
     arms.append((spec, fn))
 
 SHAPES = [('QKV fwd', 2304, 768, 1), ('FFN1 fwd', 3072, 768, 1), ('out_lin fwd', 768, 768, 3), ('FFN2 fwd', 768, 3072, 3),

@@ -10,16 +10,23 @@ f = lib.m3p_debug_ring_timeline
 f.restype = C.c_int; f.argtypes = [C.c_void_p, C.c_size_t]
 M = int(os.environ.get('AB_M', '41984'))
 names = ['K loop', 'bias + aux fetch / wait', 'epilogue pieces (compute, staging, stores)', 'restart (zero, barrier, request, fragments)', 'prologue']
-for nm, N, K, epi in (('FFN1 fwd (bias)', 3072, 768, L.EPI_BIAS), ('dU (dGELU)', 3072, 768, L.EPI_DGELU), ('FFN2 fwd (bias+drop+res)', 768, 3072, L.EPI_BIAS_DROP_RES),
-                      ('dctx (none)', 768, 768, L.EPI_NONE)):
+SHAPES = (('FFN1 fwd (bias)', 3072, 768, L.EPI_BIAS), ('FFN1 fwd (bias + GELU + byte)', 3072, 768, L.EPI_BIAS_GELUQ),
+          ('dU (byte decode)', 3072, 768, L.EPI_MULQ), ('q/k/v (bias)', 2304, 768, L.EPI_BIAS), ('out_lin (bias+drop+res)', 768, 768, L.EPI_BIAS_DROP_RES))
+if os.environ.get('TL_ONLY'):
+    SHAPES = tuple(sh for sh in SHAPES if any(k in sh[0] for k in os.environ['TL_ONLY'].split(',')))
+lib.m3p_debug_set_variant(int(os.environ.get('M3P_VARIANT', '6')))
+for nm, N, K, epi in SHAPES:
     a = torch.randn(M, K, device='cuda').to(torch.bfloat16); w = (torch.randn(N, K, device='cuda') * 0.05).to(torch.bfloat16)
     aux = torch.randn(M, N, device='cuda').to(torch.bfloat16)
     bias = torch.randn(N, device='cuda')
     out = torch.empty(M, N, dtype=torch.bfloat16, device='cuda')
+    codes = torch.randint(0, 256, (M * N,), dtype=torch.uint8, device='cuda')
     kw = {}
-    if epi in (L.EPI_BIAS, L.EPI_BIAS_DROP_RES): kw['bias'] = bias
+    if epi in (L.EPI_BIAS, L.EPI_BIAS_DROP_RES, L.EPI_BIAS_GELUQ): kw['bias'] = bias
     if epi in (L.EPI_DGELU, L.EPI_BIAS_DROP_RES): kw['aux'] = aux
     if epi == L.EPI_BIAS_DROP_RES: kw.update(seed=5, p_drop=0.1)
+    if epi == L.EPI_BIAS_GELUQ: kw['out2'] = codes
+    if epi == L.EPI_MULQ: kw.update(aux=codes, colsum=torch.zeros(N, device='cuda'))
     for _ in range(3):
         ops.gemm_nt(a, w, epi, out=out, **kw)
     torch.cuda.synchronize()
