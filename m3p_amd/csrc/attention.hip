@@ -20,6 +20,9 @@
 #ifndef M3P_ATTN_SKIP_PAD
 #define M3P_ATTN_SKIP_PAD 1
 #endif
+#ifndef M3P_ATTN_WL_BATCH
+#define M3P_ATTN_WL_BATCH 1     // forward: a key tile's four keep words written by one statement (one s_nop 3 instead of four)
+#endif
 
 namespace {
 
@@ -339,31 +342,45 @@ void attn_fwd_kernel(const bf16* __restrict__ qkv, const int* __restrict__ keyle
         }
       }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int t = 2 * kk + (j >> 2), r = j & 3;
-        float v = 0.f;
-        if (t < nt) {
-          v = s[t][r] * invk;
-          if (DROP) {
+      for (int hf = 0; hf < 2; ++hf) {
+        const int t = 2 * kk + hf;
+        unsigned long long kw[4] = {0ull, 0ull, 0ull, 0ull};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int j = 4 * hf + r;
+          float v = 0.f;
+          if (t < nt) {
+            v = s[t][r] * invk;
+            if (DROP) {
 #if defined(M3P_ATTN_ABL) && (M3P_ATTN_ABL & 2)       // (timing ablation: no hash - a keep decision that costs nothing)
-            const bool keep = ((lane + j) & 15) != 0;
+              const bool keep = ((lane + j) & 15) != 0;
 #else
-            const bool keep = kq[j];
+              const bool keep = kq[j];
 #endif
-            const unsigned long long kw = __builtin_amdgcn_ballot_w64(keep);
-            // (s_nop: a v_writelane that reads an SGPR the v_cmp just wrote gets the stale value without wait
-            //  states - measured; the assembler does not insert them for inline asm)
-            #if !(defined(M3P_ATTN_ABL) && (M3P_ATTN_ABL & 1))     // (timing ablation bit 0: no ballot words - backward would read garbage)
-            asm("s_nop 3\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4"
-                : "+v"(mlo[(4 * t + r) >> 6]), "+v"(mhi[(4 * t + r) >> 6])
-                : "s"((uint32_t)kw), "s"((uint32_t)(kw >> 32)), "i"((4 * t + r) & 63));
-#else
-            (void)kw;
+              kw[r] = __builtin_amdgcn_ballot_w64(keep);
+#if !M3P_ATTN_WL_BATCH
+              asm("s_nop 3\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4"
+                  : "+v"(mlo[(4 * t + r) >> 6]), "+v"(mhi[(4 * t + r) >> 6])
+                  : "s"((uint32_t)kw[r]), "s"((uint32_t)(kw[r] >> 32)), "i"((4 * t + r) & 63));
 #endif
-            v = keep ? v : 0.f;
+              v = keep ? v : 0.f;
+            }
           }
+          p[j] = v;
         }
-        p[j] = v;
+#if M3P_ATTN_WL_BATCH && !(defined(M3P_ATTN_ABL) && (M3P_ATTN_ABL & 1))     // (timing ablation bit 0: no ballot words - backward would read garbage)
+        if (DROP && t < nt) {
+          // the four ballots of a key tile dropped into lanes 4 t .. 4 t + 3 of the word registers by ONE statement: a
+          // v_writelane that reads an SGPR a v_cmp has just written gets the stale value without wait states (measured; the
+          // assembler pads nothing inside inline asm) - one s_nop 3 now serves eight writes (round 6; it was one per element)
+          asm("s_nop 3\n\tv_writelane_b32 %0, %2, %10\n\tv_writelane_b32 %1, %3, %10\n\tv_writelane_b32 %0, %4, %11\n\tv_writelane_b32 %1, %5, %11\n\t"
+              "v_writelane_b32 %0, %6, %12\n\tv_writelane_b32 %1, %7, %12\n\tv_writelane_b32 %0, %8, %13\n\tv_writelane_b32 %1, %9, %13"
+              : "+v"(mlo[(4 * t) >> 6]), "+v"(mhi[(4 * t) >> 6])
+              : "s"((uint32_t)kw[0]), "s"((uint32_t)(kw[0] >> 32)), "s"((uint32_t)kw[1]), "s"((uint32_t)(kw[1] >> 32)),
+                "s"((uint32_t)kw[2]), "s"((uint32_t)(kw[2] >> 32)), "s"((uint32_t)kw[3]), "s"((uint32_t)(kw[3] >> 32)),
+                "i"((4 * t) & 63), "i"((4 * t + 1) & 63), "i"((4 * t + 2) & 63), "i"((4 * t + 3) & 63));
+        }
+#endif
       }
       pf[kk] = bf16x8{(bf16)p[0], (bf16)p[1], (bf16)p[2], (bf16)p[3], (bf16)p[4], (bf16)p[5], (bf16)p[6], (bf16)p[7]};
     }
@@ -1434,22 +1451,21 @@ int launch_bwd(const bf16* qkv, const int* keylen, const bf16* ctx, const bf16* 
   if (nk > 16) return M3P_EINVAL;
   if constexpr (DH == 64) {
     if (onepass && !(g_attn_variant & 2)) {
-      static int n_cu = 0;
-      if (!n_cu) {
-        hipDeviceProp_t prop;
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return M3P_EINVAL;
-        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-      }
+      // CU count of the CURRENT device (one attribute query per call: a process may drive several devices), and the 157 KB of
+      // dynamic LDS this kernel needs: a device that refuses them takes the two-phase kernel below instead
+      int dev = 0, n_cu = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
+        n_cu = 256;
       const size_t ldsp = (size_t)3 * 192 * 128 + (size_t)11 * 16 * 11 * 32 + 2 * 192 * sizeof(float) + 2 * 12 * 3 * 64 * sizeof(float) + 12 * 48 * 8;
       auto kp = thresh24 ? attn_bwd_p_kernel<true, true> : attn_bwd_p_kernel<false, false>;
-      hipError_t e = hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp);
-      if (e != hipSuccess) return (int)e;
-      const int nheads = B * H;
-      hipLaunchKernelGGL(kp, dim3(nheads < n_cu ? nheads : n_cu), dim3(768), ldsp, st, qkv, keylen, ctx, dctx, lse, keepmask, dqkv, dbias,
-                         S, H, dmodel, nheads, qscale, inv_keep, (g_attn_variant >> 8) ? ((g_attn_variant >> 8) & 0xff) - 1 : 2);   // (bits 8..: stagger + 1; default 2 x 1024 clocks per phase)
-      M3P_CHECK_LAUNCH();
-      return M3P_OK;
+      if (hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp) == hipSuccess) {
+        const int nheads = B * H;
+        hipLaunchKernelGGL(kp, dim3(nheads < n_cu ? nheads : n_cu), dim3(768), ldsp, st, qkv, keylen, ctx, dctx, lse, keepmask, dqkv, dbias,
+                           S, H, dmodel, nheads, qscale, inv_keep, (g_attn_variant >> 8) ? ((g_attn_variant >> 8) & 0xff) - 1 : 2);   // (bits 8..: stagger + 1; default 2 x 1024 clocks per phase)
+        M3P_CHECK_LAUNCH();
+        return M3P_OK;
+      }
+      (void)hipGetLastError();
     }
   }
   if (!thresh24) M3P_ATTN_BWD(16, false, false);

@@ -6,15 +6,14 @@ import numpy as np
 
 
 def hash32(idx, seed):
-    with np.errstate(over='ignore'):
-        h = (np.asarray(idx, dtype=np.uint64) * np.uint64(0x9E3779B1) + np.uint64(seed)) & np.uint64(0xFFFFFFFF)
-        h = h.astype(np.uint32)
-        h ^= h >> np.uint32(16)
-        h = (h.astype(np.uint64) * np.uint64(0x21f0aaad) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
-        h ^= h >> np.uint32(15)
-        h = (h.astype(np.uint64) * np.uint64(0x735a2d97) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
-        h ^= h >> np.uint32(15)
-    return h
+    """m3p_hash32 of csrc/common.hpp (round 6: add the seed, three rounds of xor-shift-16 + 24-bit multiply-add, xor-shift-16)."""
+    m32, m24, s16 = np.uint64(0xFFFFFFFF), np.uint64(0xFFFFFF), np.uint64(16)
+    h = (np.asarray(idx, dtype=np.uint64) + np.uint64(int(seed) & 0xFFFFFFFF)) & m32
+    for k in (0x9E3779, 0x85EBCB, 0xC2B2AF):
+        h ^= h >> s16
+        h = (h + (h & m24) * np.uint64(k)) & m32
+    h ^= h >> s16
+    return h.astype(np.uint32)
 
 
 def keep_mask(n_elems, seed, p, shape=None):

@@ -62,12 +62,18 @@ def test_rng_twin_statistics_and_determinism():
     assert abs((k1 == k3).mean() - (0.81 + 0.01)) < 5e-3          # independent streams
     assert rng.keep_mask(1000, 5, 0.0).all()
     assert rng.stream_seed(1, 2, 3) != rng.stream_seed(1, 2, 4) != rng.stream_seed(1, 3, 3)
-    # known-answer for the hash itself (pins the C and NumPy versions to each other)
-    assert int(rng.hash32(np.array([0, 1, 12345], dtype=np.uint64), 0)[0]) == 0
-    h = rng.hash32(np.array([1], dtype=np.uint64), 7)[0]
-    x = (1 * 0x9E3779B1 + 7) & 0xFFFFFFFF
-    x ^= x >> 16; x = (x * 0x21f0aaad) & 0xFFFFFFFF; x ^= x >> 15; x = (x * 0x735a2d97) & 0xFFFFFFFF; x ^= x >> 15
-    assert int(h) == x
+    # known-answer for the hash itself, restated in plain Python integers (csrc/common.hpp: m3p_hash32; the GPU tests pin the C
+    # version to this twin through every dropout site's mask)
+    def ref(idx, seed):
+        h = (idx + seed) & 0xFFFFFFFF
+        for k in (0x9E3779, 0x85EBCB, 0xC2B2AF):
+            h ^= h >> 16
+            h = (h + (h & 0xFFFFFF) * k) & 0xFFFFFFFF
+        return h ^ (h >> 16)
+    assert int(rng.hash32(np.array([0], dtype=np.uint64), 0)[0]) == 0
+    for idx, seed in ((1, 7), (12345, 0), (0x3FFFFFF, 0xDEADBEEF), (41_000_000, 0xFFFFFFFF)):
+        assert int(rng.hash32(np.array([idx], dtype=np.uint64), seed)[0]) == ref(idx, seed)
+    assert ref(1, 7) == 0xB9D534D5      # (one literal, so that twin and restatement cannot drift together)
 
 
 def test_synthetic_batch_contract():
