@@ -297,6 +297,9 @@ __device__ __forceinline__ void lds_r128(uint32_t a, u32x4_lds& v) { asm volatil
 #ifndef M3P_MQ_PREFETCH
 #define M3P_MQ_PREFETCH 0
 #endif
+#ifndef M3P_LSE_NT
+#define M3P_LSE_NT 1      // the 2.4 GB of logits leave with non-temporal stores: 1883 -> 1847 us (profiles/r06_lse_nt.txt)
+#endif
 #ifndef M3P_DGELU_LUT
 #define M3P_DGELU_LUT 1
 #endif
@@ -749,7 +752,7 @@ __device__ __forceinline__ void epilogue_half_lse(bf16* __restrict__ C, int ldc,
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
     const int row = it * 8 + srow;
-    st16(Cp + (size_t)row * ldc, flip_halves(*reinterpret_cast<const u32x4*>(r1 + ep_off<true>(row, sch * 16)), it & 1));
+    st16p<M3P_LSE_NT != 0>(Cp + (size_t)row * ldc, flip_halves(*reinterpret_cast<const u32x4*>(r1 + ep_off<true>(row, sch * 16)), it & 1));
   }
 }
 

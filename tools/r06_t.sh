@@ -1,2 +1,5 @@
 #!/bin/bash
-python tools/ab_attn_fwd.py libm3p_hip.so libm3p_hip_r05.so libm3p_hip_wl0.so libm3p_hip_fa1.so libm3p_hip_fa2.so libm3p_hip_fa3.so libm3p_hip.so 2>&1 | tee gpurun_out/r06/s6_attn_fwd_ab.txt
+for r in 1 2 3; do
+python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-also 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('draw in kernel', d['ms_per_step'])"
+M3P_ATTN_KEEP_AHEAD=1 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-also 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('words ahead on a side stream', d['ms_per_step'])"
+done
