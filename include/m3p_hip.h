@@ -84,6 +84,16 @@ typedef struct M3PEpilogue {
   float inv_keep;     /* 1 / (1 - p)                                                   */
   const float* descale_a;  /* m3p_gemm_nt_fp8 only: device scalars, the accumulators are multiplied by    */
   const float* descale_b;  /* (*descale_a) * (*descale_b) (NULL = 1) before the epilogue                  */
+  /* round 6 - BIAS_GELUQ and MULQ only: the epilogue also leaves an 8-BIT COPY of C for the fp8 product that consumes it
+   * (lin2 forward reads gelu(u), the dx1 data gradient reads dU): out8 [M, ld_out8] bytes, row-major,
+   * = sat(C_fp32 * (*scale8)) in e4m3 (out8_bf8 = 0) or e5m2 (1), and *amax8 is raised to max |C| (atomic max; the
+   * caller zeroes it) - what m3p_quant_fp8 would make of C in a pass of its own.  NULL = no copy.  ld_out8 % 16 == 0,
+   * 16-byte aligned base. */
+  void* out8;
+  const float* scale8;
+  float* amax8;
+  int32_t ld_out8;
+  int32_t out8_bf8;
 } M3PEpilogue;
 
 /* C[M,N] (bf16, row pitch ldc) = epilogue( A[M,K] (bf16, pitch lda) x W[N,K]^T (bf16, pitch ldw) ).

@@ -297,6 +297,9 @@ __device__ __forceinline__ void lds_r128(uint32_t a, u32x4_lds& v) { asm volatil
 #ifndef M3P_MQ_PREFETCH
 #define M3P_MQ_PREFETCH 0
 #endif
+#ifndef M3P_MQ_EARLYREQ
+#define M3P_MQ_EARLYREQ 0
+#endif
 #ifndef M3P_LSE_NT
 #define M3P_LSE_NT 1      // the 2.4 GB of logits leave with non-temporal stores: 1883 -> 1847 us (profiles/r06_lse_nt.txt)
 #endif
@@ -645,6 +648,47 @@ __device__ __forceinline__ void epilogue_piece16(const M3PEpilogue& ep, bf16* __
 // 16-row piece of the byte-derivative epilogue (M3P_EPI_MULQ): out = acc * decode(code), column sums.  `q` holds this
 // lane's sixteen codes of the piece in accumulator order (dword j = columns 16 j + 4 fg .. + 3 of row fr: the fragment-order
 // layout of common.hpp, fetched by the caller with one 16-byte load) - no aux trip through LDS, three VALU per element.
+
+// Round 6: the 8-bit copy of a 16 x 64 output piece for the fp8 product that consumes this output (M3PEpilogue::out8): four
+// values of a lane -> one dword (v_cvt_pk_fp8 / _bf8 on the scaled, saturated fp32 values), 16 x 64 bytes through the wave's
+// staging rows (64-byte pitch, the 16-byte chunk index XORed with (row >> 1) & 3: two lanes per bank on the way in, the
+// minimum for 64 four-byte writes) and out as ONE 16-byte store per lane (4 lanes per 64-byte row segment).  The staging rows
+// are the ones the bf16 piece just left: LDS instructions of a wave execute in order, so the writes below cannot pass the
+// row reads in front of them.  `amax` = this lane's running max |value| (folded into *amax8 once, at the end of the kernel).
+template <bool BF8>
+__device__ __forceinline__ uint32_t pack8(const f32x4& v, float scale, float& amax) {
+  constexpr float kMax = BF8 ? 57344.f : 448.f;
+  float f[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    amax = fmaxf(amax, fabsf(v[r]));
+    f[r] = __builtin_amdgcn_fmed3f(v[r] * scale, -kMax, kMax);
+  }
+  int w = 0;
+  if (BF8) { w = __builtin_amdgcn_cvt_pk_bf8_f32(f[0], f[1], w, false); w = __builtin_amdgcn_cvt_pk_bf8_f32(f[2], f[3], w, true); }
+  else { w = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], w, false); w = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], w, true); }
+  return (uint32_t)w;
+}
+__device__ __forceinline__ void lds_w32(uint32_t a, uint32_t v) { asm volatile("ds_write_b32 %0, %1" :: "v"(a), "v"(v)); }
+__device__ __forceinline__ void piece8_write(char* r8, const uint32_t (&w8)[4], int lane) {
+  const int fr = lane & 15, fg = lane >> 4;
+  const uint32_t la = lds_addr(r8);
+  asm volatile("" ::: "memory");      // (callers that stage the bf16 piece with plain C++ accesses: none of those may sink below here)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) lds_w32(la + fr * 64 + ((j ^ ((fr >> 1) & 3)) << 4) + fg * 4, w8[j]);
+}
+__device__ __forceinline__ void piece8_store(uint8_t* __restrict__ o8, int ld8, int mrow0, int nw, char* r8, int lane) {
+  const uint32_t la = lds_addr(r8);
+  const int row = lane >> 2, c = lane & 3;
+  u32x4_lds R;
+  lds_r128(la + row * 64 + (c << 4), R);
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(R) :: "memory");      // (... and none of the next piece's may rise above here)
+  st16p<true>(o8 + (size_t)(mrow0 + row) * ld8 + nw + ((c ^ ((row >> 1) & 3)) << 4), u32x4{R[0], R[1], R[2], R[3]});
+}
+__device__ __forceinline__ void piece8_flush(uint8_t* __restrict__ o8, int ld8, int mrow0, int nw, char* r1, const uint32_t (&w8)[4], int lane) {
+  piece8_write(r1, w8, lane);
+  piece8_store(o8, ld8, mrow0, nw, r1, lane);
+}
 // M3P_MQ_ABL (timing ablations, results are garbage): 1 = the codes are not read (the caller passes lane numbers), 2 = dU is
 // neither staged nor stored, 4 = no column sums
 #ifndef M3P_MQ_ABL
@@ -659,10 +703,13 @@ __device__ __forceinline__ void epilogue_piece16(const M3PEpilogue& ep, bf16* __
 #ifndef M3P_MQ_NTLOAD
 #define M3P_MQ_NTLOAD 0
 #endif
+template <int O8 = 0>      // 0: no 8-bit copy, 1: e4m3, 2: e5m2
 __device__ __forceinline__ void epilogue_pieceq(bf16* __restrict__ C, int ldc, int mrow0, int nw, char* r1, const f32x4 (&rows)[4],
-                                                const u32x4& q, int lane, f32x4 (&csum)[4]) {
+                                                const u32x4& q, int lane, f32x4 (&csum)[4], uint8_t* __restrict__ o8 = nullptr, int ld8 = 0,
+                                                float scale8 = 1.f, float* amax = nullptr, char* r8 = nullptr) {
   const int fr = lane & 15, fg = lane >> 4;
   const int srow = lane >> 3, sch = lane & 7;
+  uint32_t w8[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const uint32_t w = q[j];
@@ -671,20 +718,43 @@ __device__ __forceinline__ void epilogue_pieceq(bf16* __restrict__ C, int ldc, i
     const f32x4 v = rows[j] * g;
     const bf16x4 ob = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
     if (M3P_MQ_ABL & 2) asm volatile("" :: "v"(ob));
-    else if (M3P_EPI_ALDS) lds_w64(lds_addr(r1) + ep_off8<true>(fr, (j * 16 + fg * 4) * 2), ob);
+    else if (M3P_EPI_ALDS || O8) lds_w64(lds_addr(r1) + ep_off8<true>(fr, (j * 16 + fg * 4) * 2), ob);
     else *reinterpret_cast<bf16x4*>(r1 + ep_off8<true>(fr, (j * 16 + fg * 4) * 2)) = ob;
     // column sums (lin1's bias gradient) of the fp32 products: one add per element (round 6; summing the bf16-rounded values
     // cost an unpack per element on top and is no closer to the fp32 reference's sum)
     if (!(M3P_MQ_ABL & 4)) { if (M3P_MQ_CSUMV) csum[j] += v; else csum[j] += f32x4{(float)ob[0], (float)ob[1], (float)ob[2], (float)ob[3]}; }
+    if (O8) w8[j] = (O8 == 2) ? pack8<true>(v, scale8, *amax) : pack8<false>(v, scale8, *amax);
   }
+  if (O8) piece8_write(r8, w8, lane);
   if (M3P_MQ_ABL & 2) return;
   if (M3P_EPI_ALDS) { epilogue_rows16_flush_alds(C, ldc, mrow0, nw, r1, lane); return; }
   bf16* Cp = C + (size_t)mrow0 * ldc + nw + sch * 8;
+  if (O8) {
+    // every staging access of this form is one the compiler does not see (no vmcnt(0) in front of each: with the 8-bit rows'
+    // stores in flight as well, those waits cost ~50 us per launch); both pieces' row reads share one wait
+    const uint32_t la = lds_addr(r1), l8 = lds_addr(r8);
+    const int row8 = lane >> 2, c8 = lane & 3;
+    u32x4_lds Ra, Rb, R8;
+    lds_r128(la + ep_off<true>(srow, sch * 16), Ra);
+    lds_r128(la + ep_off<true>(8 + srow, sch * 16), Rb);
+    lds_r128(l8 + row8 * 64 + (c8 << 4), R8);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Ra), "+v"(Rb), "+v"(R8));
+    st16p<M3P_MQ_NT != 0>(Cp + (size_t)srow * ldc, u32x4{Ra[0], Ra[1], Ra[2], Ra[3]});
+    st16p<M3P_MQ_NT != 0>(Cp + (size_t)(8 + srow) * ldc, u32x4{Rb[2], Rb[3], Rb[0], Rb[1]});
+    st16p<true>(o8 + (size_t)(mrow0 + row8) * ld8 + nw + ((c8 ^ ((row8 >> 1) & 3)) << 4), u32x4{R8[0], R8[1], R8[2], R8[3]});
+    return;
+  }
+  u32x4 R2[2];
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
     const int row = it * 8 + srow;
-    st16p<M3P_MQ_NT != 0>(Cp + (size_t)row * ldc, flip_halves(*reinterpret_cast<const u32x4*>(r1 + ep_off<true>(row, sch * 16)), it & 1));
+    R2[it] = flip_halves(*reinterpret_cast<const u32x4*>(r1 + ep_off<true>(row, sch * 16)), it & 1);
   }
+  // (the 8-bit piece has staging rows of its own, r8: its writes were issued with the bf16 piece's - below - and its row read
+  //  shares the wait of theirs; the first version took a second, serialised trip through r1: 277 against 207 us per launch)
+#pragma unroll
+  for (int it = 0; it < 2; ++it) st16p<M3P_MQ_NT != 0>(Cp + (size_t)(it * 8 + srow) * ldc, R2[it]);
+  if (O8) piece8_store(o8, ld8, mrow0, nw, r8, lane);
 }
 
 // 32-row piece of the vocabulary projection's epilogue (M3P_EPI_BIAS_LSE): logits = acc + bias as for M3P_EPI_BIAS, plus what
@@ -895,10 +965,13 @@ __device__ __forceinline__ void geluq_table_fill(uint32_t* tab, int tid, int nth
 __device__ __forceinline__ void lds_r32(uint32_t a, uint32_t& v) { asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(a)); }
 // one 16-row piece (this wave's 16 x 64 block at (mrow0, nw)): `rows` = accumulators INCLUDING the bias, tab_off = LDS byte
 // address of the table minus 4 * GELU_TAB_LO, r1 = the wave's 2 KB of staging rows, qout = where the piece's 1024 code bytes go
+template <int O8 = 0>      // 0: no 8-bit copy of h, 1: e4m3
 __device__ __forceinline__ void epilogue_piece_geluq_lut(bf16* __restrict__ C, int ldc, uint8_t* __restrict__ qout, int mrow0, int nw,
-                                                         char* r1, const f32x4 (&rows)[4], int lane, uint32_t tab_off) {
+                                                         char* r1, const f32x4 (&rows)[4], int lane, uint32_t tab_off,
+                                                         uint8_t* __restrict__ o8 = nullptr, int ld8 = 0, float scale8 = 1.f, float* amax = nullptr) {
   const int fr = lane & 15, fg = lane >> 4;
   const int srow = lane >> 3, sch = lane & 7;
+  uint32_t w8[4];
   uint32_t w[4][4];
 #pragma unroll
   for (int j = 0; j < 4; ++j)
@@ -934,6 +1007,7 @@ __device__ __forceinline__ void epilogue_piece_geluq_lut(bf16* __restrict__ C, i
     const uint32_t slo = __builtin_amdgcn_perm(x1, x0, 0x0c0c0b09u), shi = __builtin_amdgcn_perm(x3, x2, 0x0b090c0cu);
     code[j] = (blo | bhi) ^ (slo | shi);
     lds_w64(la + ep_off8<true>(fr, (j * 16 + fg * 4) * 2), bf16x4{(bf16)hv[0], (bf16)hv[1], (bf16)hv[2], (bf16)hv[3]});
+    if (O8) w8[j] = pack8<false>(hv, scale8, *amax);
   }
   st16p<M3P_GQ_NT != 0>(qout + lane * 16, code);
   u32x4 R[2];
@@ -943,6 +1017,7 @@ __device__ __forceinline__ void epilogue_piece_geluq_lut(bf16* __restrict__ C, i
   bf16* Cp = C + (size_t)mrow0 * ldc + nw + sch * 8;
   st16p<M3P_GQ_NT != 0>(Cp + (size_t)srow * ldc, R[0]);
   st16p<M3P_GQ_NT != 0>(Cp + (size_t)(8 + srow) * ldc, flip_halves(R[1], true));
+  if (O8) piece8_flush(o8, ld8, mrow0, nw, r1, w8, lane);
 }
 
 #if defined(M3P_RING_TL) || defined(M3P_W8_TL) || defined(M3P_WG_TL)
@@ -1246,7 +1321,7 @@ __device__ __forceinline__ const T* uniform_ptr(const T* p) {      // a wave-uni
   return reinterpret_cast<const T*>(((uint64_t)hi << 32) | lo);
 }
 
-template <int EPI, bool DYN = false>
+template <int EPI, bool DYN = false, bool O8 = false>      // O8: BIAS_GELUQ / MULQ also leave the 8-bit copy (M3PEpilogue::out8)
 __global__ __launch_bounds__(512)
 void gemm_nt_w8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restrict__ W, int ldw,
                        bf16* __restrict__ C, int ldc, int M, int N, int K, M3PEpilogue ep,
@@ -1548,6 +1623,8 @@ void gemm_nt_w8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
         csum[j][r] = 0.f;
       }
   };
+  float amax_run = 0.f;       // (BIAS_GELUQ with an 8-bit copy: this lane's max |output| over the launch; MULQ keeps it in LDS)
+  if constexpr (O8 && EPI == M3P_EPI_MULQ) reinterpret_cast<float*>(smem + 2 * STAGE + 8 * 2048)[tid] = 0.f;
   bool spread_pending = false;
 #ifdef M3P_W8_TL
   W8_TSEG(4);
@@ -1607,7 +1684,9 @@ void gemm_nt_w8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
     // (on an output tile's last K-tile both wait for the epilogue, which stages through that stage and wants the registers)
     // (epilogues with an aux tile ask for it FIRST: vmcnt retires in order, so a load issued behind the three LDS-DMAs
     //  would wait for them too - on an output tile's last K-tile the request moves into the epilogue, behind the aux loads)
-    const bool req = W8_MORE2 && (!last_kt || (kSpare && !kAuxE));
+    // (M3P_MQ_EARLYREQ, A/B: the byte-decode epilogue asks for K-tile + 2 on schedule and fetches its codes BEHIND the transfers)
+    constexpr bool kReqLate = kAuxE && !(M3P_MQ_EARLYREQ && EPI == M3P_EPI_MULQ);
+    const bool req = W8_MORE2 && (!last_kt || (kSpare && !kReqLate));
     if (req) {
       if (!M3P_W8_SPREAD) stage_next(cur);
       else if (!M3P_W8_INTERLEAVE) { issue_load(cur, 0); issue_load(cur, 1); issue_load(cur, 2); }
@@ -1675,10 +1754,20 @@ void gemm_nt_w8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
           char* r1 = smem + 2 * STAGE + kTabBytes + wid * 2048;
           const uint32_t tab_off = lds0 + 2 * STAGE - 4 * GELU_TAB_LO;
           uint8_t* qo = reinterpret_cast<uint8_t*>(ep.out2) + gq_block_offset(tm, tn, tiles_n, wid, 0);
+          if constexpr (O8) {      // + the e4m3 copy of h for an fp8 lin2
+            const float sc8 = ep.scale8 ? *ep.scale8 : 1.f;
 #pragma unroll
-          for (int hp = 0; hp < 8; ++hp) {
-            epilogue_piece_geluq_lut(C, ldc, qo + 1024 * hp, mw + 16 * hp, nw, r1, acc[hp], lane, tab_off);
-            __builtin_amdgcn_sched_barrier(0);
+            for (int hp = 0; hp < 8; ++hp) {
+              epilogue_piece_geluq_lut<1>(C, ldc, qo + 1024 * hp, mw + 16 * hp, nw, r1, acc[hp], lane, tab_off,
+                                          reinterpret_cast<uint8_t*>(ep.out8), ep.ld_out8, sc8, &amax_run);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          } else {
+#pragma unroll
+            for (int hp = 0; hp < 8; ++hp) {
+              epilogue_piece_geluq_lut(C, ldc, qo + 1024 * hp, mw + 16 * hp, nw, r1, acc[hp], lane, tab_off);
+              __builtin_amdgcn_sched_barrier(0);
+            }
           }
         }
 #pragma unroll
@@ -1716,8 +1805,26 @@ void gemm_nt_w8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
 #endif
           u32x4 qa = MQ_LD(0), qb = MQ_LD(1024);
           __builtin_amdgcn_sched_barrier(0);
-          if (W8_MORE2) { issue_load(cur, 0); issue_load(cur, 1); issue_load(cur, 2); spread_pending = true; }
+          if (W8_MORE2 && !M3P_MQ_EARLYREQ) { issue_load(cur, 0); issue_load(cur, 1); issue_load(cur, 2); spread_pending = true; }
           __builtin_amdgcn_sched_barrier(0);
+          if constexpr (O8) {      // + the 8-bit copy of dU for an fp8 dx1 product
+            const float sc8 = ep.scale8 ? *ep.scale8 : 1.f;
+            uint8_t* o8 = reinterpret_cast<uint8_t*>(ep.out8);
+            // (this lane's running max |dU| lives in LDS between output tiles: one more register across the K loop spills here)
+            float* amax_slot = reinterpret_cast<float*>(smem + 2 * STAGE + 8 * 2048) + tid;
+            float amax_t = *amax_slot;
+#pragma unroll
+            for (int hp = 0; hp < 8; ++hp) {
+              u32x4 qc = qb;
+              if (hp + 2 < 8) qc = MQ_LD((hp + 2) * 1024);
+              char* r8 = smem + 2 * STAGE + 8 * 2048 + 2048 + wid * 1024;
+              if (ep.out8_bf8) epilogue_pieceq<2>(C, ldc, mw + 16 * hp, nw, r1, acc[hp], qa, lane, csum, o8, ep.ld_out8, sc8, &amax_t, r8);
+              else epilogue_pieceq<1>(C, ldc, mw + 16 * hp, nw, r1, acc[hp], qa, lane, csum, o8, ep.ld_out8, sc8, &amax_t, r8);
+              __builtin_amdgcn_sched_barrier(0);
+              qa = qb; qb = qc;
+            }
+            *amax_slot = amax_t;
+          } else {
 #pragma unroll
           for (int hp = 0; hp < 8; hp += 2) {
             u32x4 qc = qa, qd = qb;
@@ -1728,6 +1835,7 @@ void gemm_nt_w8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
             epilogue_pieceq(C, ldc, mw + 16 * (hp + 1), nw, r1, acc[hp + 1], qb, lane, csum);
             __builtin_amdgcn_sched_barrier(0);
             qa = qc; qb = qd;
+          }
           }
 #undef MQ_LD
 #if M3P_MQ_PREFETCH
@@ -1825,6 +1933,25 @@ void gemm_nt_w8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
     }
   }
   if (kMulE && ep.colsum && csum_nw >= 0) flush_csum();
+  if constexpr (O8 && (EPI == M3P_EPI_BIAS_GELUQ || EPI == M3P_EPI_MULQ)) {
+    if (ep.amax8) {
+      // one candidate per workgroup, and only if it beats what is there (same-address atomics serialise at the memory side:
+      // optim.hip, quant_fp8_kernel); the staging rows are free now
+      float* wmax = reinterpret_cast<float*>(smem + 2 * STAGE + kTabBytes);
+      if constexpr (EPI == M3P_EPI_MULQ) amax_run = reinterpret_cast<float*>(smem + 2 * STAGE + 8 * 2048)[tid];
+      const float mxw = wave_max(amax_run);
+      __syncthreads();
+      if (lane == 0) wmax[wid] = mxw;
+      __syncthreads();
+      if (tid == 0) {
+        float mx = wmax[0];
+#pragma unroll
+        for (int w = 1; w < NWAVES; ++w) mx = fmaxf(mx, wmax[w]);
+        unsigned int* slot = reinterpret_cast<unsigned int*>(ep.amax8);
+        if (__float_as_uint(mx) > __builtin_nontemporal_load(slot)) atomicMax(slot, __float_as_uint(mx));
+      }
+    }
+  }
 #ifdef M3P_W8_TL
   tacc[6] = __builtin_amdgcn_s_memtime();
   if (lane == 0)
@@ -3343,7 +3470,26 @@ static int launch_nt_gq(const bf16* A, int lda, const bf16* W, int ldw, bf16* C,
   if (EPI == M3P_EPI_BIAS_LSE && (ep.ld_out2 <= 0 || ep.ld_out2 > N)) return M3P_EINVAL;
   const int tiles_m = M / 256, tiles_n = N / 256;
   const size_t lds = 2 * 512 * ROWB + ((EPI == M3P_EPI_BIAS_GELUQ && M3P_GQ_LUT) ? GQ_TAB_BYTES + 8 * 2048 : 8 * (EPI != M3P_EPI_MULQ ? 4096 : 2048)) +
-                     ((EPI == M3P_EPI_MULQ && M3P_MQ_PREFETCH) ? 2048 : 0);
+                     (EPI == M3P_EPI_MULQ ? 2048 + 8 * 1024 : 0);      // (MULQ: behind the staging rows 2 KB - the 8-bit copy's running maxima / the
+                                                                       //  prefetch experiment - and the 8-bit copy's own staging rows, 1 KB per wave)
+  int grid = num_cus();
+  const int ntiles = tiles_m * tiles_n;
+  if (ntiles < grid) grid = (ntiles + 7) / 8 * 8;
+  if constexpr (EPI == M3P_EPI_BIAS_GELUQ || EPI == M3P_EPI_MULQ) {
+    if (ep.out8) {      // the instantiation that also leaves the 8-bit copy (its own registers: the plain one must not pay for it)
+      if (((uintptr_t)ep.out8 & 15) || (ep.ld_out8 & 15) || ep.ld_out8 < N) return M3P_EINVAL;
+      auto kern8 = gemm_nt_w8_kernel<EPI, false, true>;
+      static bool attr_set8 = false;
+      if (!attr_set8) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set8 = true;
+      }
+      hipLaunchKernelGGL(kern8, dim3(grid), dim3(512), lds, st, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_m, tiles_n, (int*)nullptr, g_w8_strip);
+      M3P_CHECK_LAUNCH();
+      return M3P_OK;
+    }
+  }
   auto kern = gemm_nt_w8_kernel<EPI>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -3351,9 +3497,6 @@ static int launch_nt_gq(const bf16* A, int lda, const bf16* W, int ldw, bf16* C,
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  int grid = num_cus();
-  const int ntiles = tiles_m * tiles_n;
-  if (ntiles < grid) grid = (ntiles + 7) / 8 * 8;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, A, lda, W, ldw, C, ldc, M, N, K, ep, tiles_m, tiles_n, (int*)nullptr, g_w8_strip);
   M3P_CHECK_LAUNCH();
   return M3P_OK;

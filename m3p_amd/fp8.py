@@ -24,10 +24,22 @@ SITES = ('x', 'ctx', 'x1', 'hact', 'wqkv', 'wout', 'w1', 'w2', 'dy2', 'du', 'dao
 # 3072-deep contraction do (+11 .. +43 us each); the two 1024 x 1024 products break even, and the dU product would need
 # the derivative pre-computed by the forward GELU pass (+40 us there) to save 18 us.  M3P_FP8_ALL=1: all eight (A/B runs).
 import os as _os
+# Round 6: the two 4096-deep products take their 8-bit operand from the PRODUCER's epilogue - lin1 + GELU + byte leaves the e4m3
+# copy of h for lin2 forward, the byte-decode dU product the e5m2 copy of dU for dx1 (M3PEpilogue::out8) - so they pay no
+# quantisation pass at all, and lin1 itself stays on the bf16 GELU + byte kernel (its 8-bit form needed a GELU pass of its own
+# and the pre-activation stored for backward: 1.81 + 0.75 ms per cfg4 step).  The default runs exactly these two products in 8
+# bits: zero activation / gradient quantisation launches.  M3P_FP8_SITES picks another recipe for A/B runs: "r5" = the round-5
+# one (lin1 in 8 bits, GELU pass with the 8-bit copy), "qkv" = the default plus q/k/v forward and its data gradient
+# (profiles/r06_fp8_cfg4_ab.txt: all three within the box's noise of each other and of bf16).
+_recipe = _os.environ.get('M3P_FP8_SITES', '')
 if _os.environ.get('M3P_FP8_ALL', '0') != '0':
     FWD_SITES, BWD_SITES = {'wqkv', 'wout', 'w1', 'w2'}, {'wqkv', 'wout', 'w1', 'w2'}
-else:
+elif _recipe == 'r5':
     FWD_SITES, BWD_SITES = {'wqkv', 'w1', 'w2'}, {'wqkv', 'w1'}
+elif _recipe == 'qkv':      # + the fused q/k/v projection and its data gradient, their operands quantised by passes of their own
+    FWD_SITES, BWD_SITES = {'wqkv', 'w2'}, {'wqkv', 'w1'}
+else:
+    FWD_SITES, BWD_SITES = {'w2'}, {'w1'}
 _BF8 = {'dy2', 'du', 'dao', 'dqkv'}
 E4M3_MAX, E5M2_MAX = 448.0, 57344.0
 
@@ -103,14 +115,17 @@ class Fp8State:
             if not self.seen[k]:
                 self._first_use(w, k)
             if first:
-                w8 = torch.empty(w.shape, dtype=torch.uint8, device=w.device)
+                w8 = torch.empty(w.shape, dtype=torch.uint8, device=w.device) if site in FWD_SITES else None
                 wt8 = torch.empty(wt.shape, dtype=torch.uint8, device=w.device) if site in BWD_SITES else None
                 self.weights[(i, site)] = (w8, wt8, self._wdsc[j:j + 1])
             w8, wt8, _ = self.weights[(i, site)]
             assert w.is_contiguous() and wt.is_contiguous() and w.numel() % 8 == 0
-            rows.append([w.data_ptr(), w8.data_ptr(), self.scale[k:k + 1].data_ptr(), self.amax[k:k + 1].data_ptr(), w.numel() // 8])
+            # (only the copies a product reads are made; the matrix's running maximum rides on the first of them)
+            if w8 is not None:
+                rows.append([w.data_ptr(), w8.data_ptr(), self.scale[k:k + 1].data_ptr(), self.amax[k:k + 1].data_ptr(), w.numel() // 8])
             if wt8 is not None:
-                rows.append([wt.data_ptr(), wt8.data_ptr(), self.scale[k:k + 1].data_ptr(), 0, wt.numel() // 8])
+                rows.append([wt.data_ptr(), wt8.data_ptr(), self.scale[k:k + 1].data_ptr(),
+                             0 if w8 is not None else self.amax[k:k + 1].data_ptr(), wt.numel() // 8])
         # (roll() rewrites descale in place; the copies made now stay valid for the 8-bit weights quantised now)
         torch.index_select(self.descale, 0, self._wk, out=self._wdsc)
         if self._wdesc is None or self._wdesc[1] != rows:

@@ -621,11 +621,24 @@ class EncoderFn(torch.autograd.Function):
             x1, mean1, rstd1 = ops.layernorm_fwd(pre1, ar.p('layer_norm1.%d.weight' % i), ar.p('layer_norm1.%d.bias' % i))
             hact8 = None
             u_holds_grad = False     # does the pass below leave gelu'(u) in u's buffer? (backward then only multiplies)
-            if st8 is None and not _GELU_GRAD_IN_FWD and _GELU_BYTE_GRAD == 2 and track and ops.gq_eligible(M, 4 * d):
+            if (st8 is None or 'w1' not in fp8mod.FWD_SITES) and not _GELU_GRAD_IN_FWD and _GELU_BYTE_GRAD == 2 and track \
+                    and ops.gq_eligible(M, 4 * d):
                 # lin1 + GELU in ONE launch: the epilogue writes h and, for backward, gelu'(u) as one byte per element in the
                 # dU GEMM's own fragment order (EPI_MULQ decodes it with one fma); u is never stored
                 u = torch.empty((M * 4 * d,), dtype=torch.uint8, device=dev)
-                hact = ops.gemm_nt(x1, ar.w(f + 'lin1.weight'), L.EPI_BIAS_GELUQ, bias=ar.p(f + 'lin1.bias'), out2=u)
+                o8 = {}
+                if st8 is not None and 'w2' in fp8mod.FWD_SITES:
+                    # fp8 (round 6): the same epilogue leaves the e4m3 copy of h that the 8-bit lin2 product reads - no
+                    # quantisation pass, no GELU pass (a site's first use has no scale yet: bf16 once, its maximum measured)
+                    kh = st8.index(i, 'hact')
+                    if st8.seen[kh]:
+                        o8 = dict(out8=torch.empty((M, 4 * d), dtype=torch.uint8, device=dev), scale8=st8.scale[kh:kh + 1],
+                                  amax8=st8.amax[kh:kh + 1])
+                hact = ops.gemm_nt(x1, ar.w(f + 'lin1.weight'), L.EPI_BIAS_GELUQ, bias=ar.p(f + 'lin1.bias'), out2=u, **o8)
+                if o8:
+                    hact8 = (o8['out8'], st8.descale[kh:kh + 1])
+                elif st8 is not None and 'w2' in fp8mod.FWD_SITES:
+                    st8._first_use(hact, kh)
                 u_holds_grad = 'q'
             elif M >= 1024 or st8 is not None:
                 # persistent GEMM: bias in the epilogue, GELU as its own HBM-speed pass
@@ -708,11 +721,12 @@ class EncoderFn(torch.autograd.Function):
         last = hook.encoder_backward_begin() if hook is not None else True
         st8 = model.fp8_state() if model.fp8 else None
 
-        def dgrad(g, i, gsite, wsite, wt16, epi, **kw):
-            """data gradient g [M, n] x W -> [M, k] on the transposed weight copy (bf8 gradient x fp8 weight when fp8 is on)"""
+        def dgrad(g, i, gsite, wsite, wt16, epi, pre8=None, **kw):
+            """data gradient g [M, n] x W -> [M, k] on the transposed weight copy (bf8 gradient x fp8 weight when fp8 is on;
+            pre8 = the gradient's 8-bit copy and its descale where the producing epilogue already left them)"""
             if st8 is None or wsite not in fp8mod.BWD_SITES:
                 return ops.gemm_nt(g, wt16, epi, **kw)
-            g8, dgs = st8.quant(g, i, gsite)
+            g8, dgs = pre8 if pre8 is not None else st8.quant(g, i, gsite)
             _, wt8, dws = st8.weights[(i, wsite)]
             return ops.gemm_nt_fp8(g8, wt8, epi, a_is_bf8=True, descale_a=dgs, descale_b=dws, **kw)
 
@@ -728,14 +742,25 @@ class EncoderFn(torch.autograd.Function):
             if dY2 is None:
                 dY2 = dpre2
             ops.gemm_wgrad(dY2, hact, ar.g(f + 'lin2.weight'))
+            du8 = None
             if ctx.u_holds_grad == 'q':
-                dU = ops.gemm_nt(dY2, ar.wt[('lin2', i)], L.EPI_MULQ, aux=u, colsum=ar.g(f + 'lin1.bias'))
+                o8 = {}
+                if st8 is not None and 'w1' in fp8mod.BWD_SITES:      # + the e5m2 copy of dU for the 8-bit dx1 product
+                    kd = st8.index(i, 'du')
+                    if st8.seen[kd]:
+                        o8 = dict(out8=torch.empty((M, 4 * d), dtype=torch.uint8, device=dY2.device), scale8=st8.scale[kd:kd + 1],
+                                  amax8=st8.amax[kd:kd + 1], out8_bf8=True)
+                dU = ops.gemm_nt(dY2, ar.wt[('lin2', i)], L.EPI_MULQ, aux=u, colsum=ar.g(f + 'lin1.bias'), **o8)
+                if o8:
+                    du8 = (o8['out8'], st8.descale[kd:kd + 1])
+                elif st8 is not None and 'w1' in fp8mod.BWD_SITES:
+                    st8._first_use(dU, kd)
             else:
                 dU = dgrad(dY2, i, 'dy2', 'w2', ar.wt[('lin2', i)], L.EPI_MUL if ctx.u_holds_grad else L.EPI_DGELU, aux=u,
                            colsum=ar.g(f + 'lin1.bias'))
             del hact, u, pre2
             ops.gemm_wgrad(dU, x1, ar.g(f + 'lin1.weight'))
-            dx1 = dgrad(dU, i, 'du', 'w1', ar.wt[('lin1', i)], L.EPI_RES, aux=dpre2)
+            dx1 = dgrad(dU, i, 'du', 'w1', ar.wt[('lin1', i)], L.EPI_RES, aux=dpre2, pre8=du8)
             del dU, dpre2, dY2
             # LayerNorm1 and the attention-output dropout
             dpre1, dAO = ops.layernorm_bwd(dx1, None, pre1, ar.p('layer_norm1.%d.weight' % i), mean1, rstd1, None,

@@ -30,6 +30,7 @@ class Epilogue(C.Structure):
         ('ld_aux', C.c_int32), ('ld_out2', C.c_int32), ('scale_cols', C.c_int32), ('scale', C.c_float),
         ('alpha', C.c_float), ('seed', C.c_uint32), ('thresh24', C.c_uint32), ('inv_keep', C.c_float),
         ('descale_a', C.c_void_p), ('descale_b', C.c_void_p),
+        ('out8', C.c_void_p), ('scale8', C.c_void_p), ('amax8', C.c_void_p), ('ld_out8', C.c_int32), ('out8_bf8', C.c_int32),
     ]
 
 

@@ -45,9 +45,11 @@ def _chk_bf16(*ts):
 
 
 def gemm_nt(a, w, epilogue=L.EPI_NONE, bias=None, aux=None, out=None, out2=None, colsum=None,
-            scale_cols=0, scale=1.0, alpha=1.0, seed=0, p_drop=0.0, n=None):
+            scale_cols=0, scale=1.0, alpha=1.0, seed=0, p_drop=0.0, n=None, out8=None, scale8=None, amax8=None, out8_bf8=False):
     """C[M,N] = epi(a[M,K] @ w[N,K]^T).  a, w bf16 (row pitch = stride(0)); returns C (bf16).
-    ``n`` restricts the number of output columns (rows of w) used."""
+    ``n`` restricts the number of output columns (rows of w) used.
+    out8 (EPI_BIAS_GELUQ / EPI_MULQ): uint8 [M, N] that receives the 8-bit copy of C - sat(C * scale8) in e4m3, or e5m2 with
+    out8_bf8 - for the fp8 product that consumes C; amax8 (fp32 [1], zeroed by the caller) is raised to max |C|."""
     M, K = a.shape
     N = w.shape[0] if n is None else n
     if epilogue == L.EPI_MULQ:     # aux = the byte codes of gelu_fwd_gq for this [M, N], in the GEMM's fragment order
@@ -82,6 +84,10 @@ def gemm_nt(a, w, epilogue=L.EPI_NONE, bias=None, aux=None, out=None, out2=None,
     ep.inv_keep = 1.0 / (1.0 - p_drop) if p_drop > 0 else 1.0
     if bias is not None:
         assert bias.dtype == torch.float32
+    if out8 is not None:
+        assert epilogue in (L.EPI_BIAS_GELUQ, L.EPI_MULQ) and out8.dtype == torch.uint8 and out8.shape == (M, N) and out8.stride(1) == 1
+        ep.out8, ep.ld_out8, ep.out8_bf8 = out8.data_ptr(), out8.stride(0), 1 if out8_bf8 else 0
+        ep.scale8, ep.amax8 = L.ptr(scale8), L.ptr(amax8)
     e0 = _prof_begin((_EPI_NAMES[epilogue], M, N, K))
     rc = L.load().m3p_gemm_nt_bf16(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(),
                                    out.stride(0), M, N, K, epilogue, C.byref(ep), L.stream())

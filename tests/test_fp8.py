@@ -223,3 +223,47 @@ def test_byte_derivative_training_curve_follows_the_stored_pre_activation(monkey
     rel = np.abs(run(byte) - run(ref)) / run(ref)
     assert rel.max() < 0.01, (rel.max(), ref, byte)
     assert abs(byte.mean() - ref.mean()) / ref.mean() < 0.005
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('M,N,K', [(1024, 512, 64), (2048, 1024, 256)])
+def test_byte_epilogues_leave_the_8bit_copy_of_their_output(M, N, K):
+    """Round 6: lin1 + GELU + byte (EPI_BIAS_GELUQ) and the byte-decode data gradient (EPI_MULQ) also leave the e4m3 / e5m2 copy
+    of their output for the fp8 product that consumes it (M3PEpilogue::out8): the bf16 output and the codes are bit for bit what
+    the launch without the copy leaves; the copy is the OCP cast of (output * scale) within one 8-bit rounding of the cast
+    of the stored bf16 output (it is taken from the fp32 value), saturating; the running maximum is raised to max |output|."""
+    from m3p_amd import ops, lib as L
+    g = torch.Generator(device='cuda').manual_seed(M + N + K)
+    a = torch.randn((M, K), device='cuda', generator=g).to(torch.bfloat16)
+    w = (torch.randn((N, K), device='cuda', generator=g) * (1.5 / math.sqrt(K))).to(torch.bfloat16)
+    bias = torch.randn((N,), device='cuda', generator=g)
+    # forward: h, codes, h8
+    q0 = torch.empty(M * N, dtype=torch.uint8, device='cuda')
+    h0 = ops.gemm_nt(a, w, L.EPI_BIAS_GELUQ, bias=bias, out2=q0)
+    scale = torch.tensor([37.0], device='cuda')           # (large enough that the biggest activations saturate at 448)
+    amax = torch.zeros(1, device='cuda')
+    q1 = torch.empty(M * N, dtype=torch.uint8, device='cuda')
+    h8 = torch.empty((M, N), dtype=torch.uint8, device='cuda')
+    h1 = ops.gemm_nt(a, w, L.EPI_BIAS_GELUQ, bias=bias, out2=q1, out8=h8, scale8=scale, amax8=amax)
+    assert torch.equal(h1, h0) and torch.equal(q1, q0)
+    ref8 = (h0.float() * 37.0).clamp(-448, 448).to(torch.float8_e4m3fn).float()
+    got8 = h8.view(torch.float8_e4m3fn).float()
+    assert torch.isfinite(got8).all() and float(got8.abs().max()) <= 448.0
+    # e4m3 has 3 mantissa bits: one code apart is <= 12.5 % relative; the fp32 source may round to the neighbour of the bf16's
+    close = (got8 - ref8).abs() <= 0.126 * ref8.abs().clamp_min(2.0 ** -9 * 37.0)
+    assert float(close.float().mean()) > 0.9999 and float((got8 == ref8).float().mean()) > 0.97
+    assert abs(float(amax) - float(h0.float().abs().max())) <= 2.0 ** -7 * float(amax)
+    # backward: dU, column sums, dU8 in e5m2
+    dy = (torch.randn((M, K), device='cuda', generator=g) * 0.01).to(torch.bfloat16)
+    cs0, cs1 = torch.zeros(N, device='cuda'), torch.zeros(N, device='cuda')
+    du0 = ops.gemm_nt(dy, w, L.EPI_MULQ, aux=q0, colsum=cs0)
+    s2 = torch.tensor([4096.0], device='cuda')
+    amax2 = torch.zeros(1, device='cuda')
+    du8 = torch.empty((M, N), dtype=torch.uint8, device='cuda')
+    du1 = ops.gemm_nt(dy, w, L.EPI_MULQ, aux=q0, colsum=cs1, out8=du8, scale8=s2, amax8=amax2, out8_bf8=True)
+    assert torch.equal(du1, du0) and rel_l2(cs1, cs0) < 1e-6
+    ref = (du0.float() * 4096.0).clamp(-57344, 57344).to(torch.float8_e5m2).float()
+    got = du8.view(torch.float8_e5m2).float()
+    close = (got - ref).abs() <= 0.26 * ref.abs().clamp_min(2.0 ** -9 * 4096.0 * 1e-3)
+    assert float(close.float().mean()) > 0.9999 and float((got == ref).float().mean()) > 0.95
+    assert abs(float(amax2) - float(du0.float().abs().max())) <= 2.0 ** -7 * float(amax2)
