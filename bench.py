@@ -369,10 +369,11 @@ def main():
                               ring_bound_ms=round(ring, 3), direct_bound_ms=round(direct, 3), lands=side)
         g_tail = torch.tensor([sum(grad_tail) / max(len(grad_tail), 1)], device='cuda', dtype=torch.float64)
         dist.all_reduce(g_tail, op=dist.ReduceOp.MAX)
+        ident = dp.identify()       # (collective: every rank is here)
         comm = dict(mode=dp.mode, exposed_ms_per_step=round(float(e.item()), 3),
                     exposed_split_ms=dict(gradient_buckets=round(float(g_tail.item()), 3),
                                           token_rows=round(max(float(e.item()) - float(g_tail.item()), 0.0), 3)),
-                    backend=dp.identity['backend'], ranks=dp.identity['ranks'], rccl_ranks_seen=dp.identity['devices_seen'],
+                    backend=ident['backend'], ranks=ident['ranks'], rccl_ranks_seen=ident['devices_seen'],
                     nccl_env={k: v for k, v in os.environ.items() if k.startswith(('NCCL_', 'RCCL_')) and 'DEBUG' not in k},
                     payload_MB_per_step=round(sum(payload) / max(len(payload), 1) / 1e6, 1), buckets=buckets,
                     reserved_cus=__import__('m3p_amd.distributed', fromlist=['x']).reserve_cus(),

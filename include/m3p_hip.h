@@ -213,8 +213,8 @@ M3P_API int m3p_attn_fwd(const void* qkv, const int32_t* keylen, void* ctx, floa
                          void* stream);
 /* keepmask (nullable): if given and thresh24 != 0, the forward also leaves the dropout keep
  * bits, [B*H][nt][nt][4] 64-bit words with nt = ceil(S/16); word [qb][t][r] bit l is the
- * keep decision of (query 16qb + (l & 15), key 16t + 4(l >> 4) + r).  m3p_attn_bwd given the
- * same buffer tests bits instead of regenerating the hash twice per (query, key) pair. */
+ * keep decision of (query 16qb + (l & 15), key 16t + 4(l >> 4) + r).  m3p_attn_bwd tests these bits
+ * (it needs them whenever dropout is on). */
 
 /* Backward: given dctx (bf16 [B*S, H*dh]) writes dqkv (bf16 [B*S, 3*H*dh]; the q block is
  * multiplied by qscale = 1/sqrt(dh) so it is the gradient of the *unscaled* projection)
@@ -222,7 +222,9 @@ M3P_API int m3p_attn_fwd(const void* qkv, const int32_t* keylen, void* ctx, floa
  * dqkv into the fp32 [3*H*dh] bias gradient of the fused q/k/v projection.  The k block of
  * the bias gradient is left untouched: it is identically 0 (softmax is invariant to a
  * per-query shift of the scores; the reference's value there is fp32 noise).  Scores are recomputed from
- * qkv + lse (nothing S x S is ever stored).  S <= 384. */
+ * qkv + lse (nothing S x S is ever stored).  S <= 384.  With dropout on (thresh24 != 0) keepmask - the words m3p_attn_fwd
+ * left - is REQUIRED (M3P_EINVAL without; round 6: the instantiations that re-drew the decisions from (seed, thresh24) served
+ * tests only); seed is unused. */
 M3P_API int m3p_attn_bwd(const void* qkv, const int32_t* keylen, const void* ctx, const void* dctx,
                          const float* lse, const uint64_t* keepmask, void* dqkv, float* dbias_qkv, int B, int S,
                          int H, int dh, float qscale, uint32_t seed, uint32_t thresh24, float inv_keep,

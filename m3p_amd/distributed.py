@@ -295,13 +295,20 @@ class DataParallel(torch.nn.Module):
         if not self.single and arena.device.type == 'cuda' and reserve_cus():
             from . import lib as L
             L.load().m3p_set_persistent_grid(L.num_cus() - reserve_cus())
-        self.identity = self._identify()
+        self._identity = None        # first-contact facts: gathered by identify() (a collective) only when somebody asks
         if broadcast and not self.single:
             dist.broadcast(arena.master, src=0, group=process_group)
             for p in module.parameters():
                 if getattr(p, '_m3p_arena', None) is None:
                     dist.broadcast(p.data, src=0, group=process_group)
             arena.mark_master_changed()
+
+    def identify(self):
+        """COLLECTIVE on first use (every rank must call it: bench.py's multi-GPU half does; constructing DataParallel no longer
+        does - ADVICE r5) - cached afterwards."""
+        if self._identity is None:
+            self._identity = self._identify()
+        return self._identity
 
     def _identify(self):
         """First-contact facts about the process group (bench.py prints them under "comm"): the backend, how many ranks it

@@ -294,10 +294,15 @@ class Arena:
             self._transposes_stale = False
 
     def zero_grad(self):
+        """After this every gradient is PHYSICALLY zero (an explicit zero_grad is what callers outside the step protocol rely
+        on - clip_grad_norm_ / p.grad.add_ on model.parameters(), a wrapper attached after single-GPU steps: ADVICE r5); the
+        lazily zeroed vocabulary range is only ever left behind by the fused optimizer step (after_fused_step)."""
         if not self.grads_known_zero:
             self.grad.zero_()
             self.grads_known_zero = True
             self.stale = None
+        self.ensure_zero()
+        self.vocab_stored = False
         self.touched.clear()
         if self.model.ddp_hook is not None:
             self.model.ddp_hook.step_done()
@@ -1200,13 +1205,17 @@ class MLMHeadFn(torch.autograd.Function):
             # gradient that follows it in the arena - receive += 0
             o = ar.offsets['embeddings.weight'][0]
             will_store = fresh and L.load().m3p_gemm_wgrad_plan(n, ar.V_pad, d) == L.KERN_WGRAD_W4_TILES
-            if will_store and ar.stale == ar.vocab_range():
-                ar.stale = None          # (lazily zeroed by the optimizer: the store below covers exactly that range)
-            else:
+            lazy = will_store and ar.stale == ar.vocab_range()      # (lazily zeroed by the optimizer: a STORE covers exactly that range)
+            if not lazy:
                 ar.ensure_zero()
             ar.vocab_stored = ops.gemm_wgrad(dlogits, hs, ar.grad[o:o + ar.V_pad * d].view(ar.V_pad, d), n=ar.V_pad, k=d,
-                                             dw_is_zero=fresh, report_store=True)
-            assert ar.vocab_stored or not will_store, 'the dispatch table promised a stored vocabulary weight gradient'
+                                             dw_is_zero=fresh, report_store=True, must_store=lazy)
+            if lazy:
+                # (only now: had the launcher declined the store, ops.gemm_wgrad has raised instead of accumulating onto the
+                #  previous step's gradient - ADVICE r5; `stale` stays set until a store has really covered the range)
+                ar.stale = None
+            if will_store and not ar.vocab_stored:
+                raise RuntimeError('the dispatch table promised a stored vocabulary weight gradient, the launcher accumulated')
         else:
             ops.gemm_wgrad(dlogits, hs, ar.g('embeddings.weight'), n=V, k=d)
         if dbias is not None:

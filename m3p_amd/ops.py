@@ -210,9 +210,11 @@ def _wgrad_workspace(device):
     return ws
 
 
-def gemm_wgrad(dy, x, dw, alpha=1.0, n=None, k=None, dw_is_zero=False, report_store=False):
+def gemm_wgrad(dy, x, dw, alpha=1.0, n=None, k=None, dw_is_zero=False, report_store=False, must_store=False):
     """dw[N,K] (fp32) += alpha * dy[M,N]^T @ x[M,K].  dw_is_zero: the caller knows dw[:N, :K] to hold zeros - shapes dealt out
-    as whole tiles (the vocabulary matrix) are then stored instead of accumulated with atomics; same result."""
+    as whole tiles (the vocabulary matrix) are then stored instead of accumulated with atomics; same result.  must_store: dw is
+    only LOGICALLY zero (the arena's lazily zeroed range): a launcher that declines the store raises here instead of
+    accumulating onto what the buffer physically holds."""
     _chk_bf16(dy, x)
     assert dw.dtype == torch.float32 and dw.stride(-1) == 1
     M = dy.shape[0]
@@ -229,6 +231,8 @@ def gemm_wgrad(dy, x, dw, alpha=1.0, n=None, k=None, dw_is_zero=False, report_st
             return True if report_store else dw
         if rc != -2:        # (M3P_ENOTIMPL: not a whole-tile shape - accumulate below)
             L.check(rc, 'm3p_gemm_wgrad_store_bf16')
+        if must_store:
+            raise L.M3PError('m3p_gemm_wgrad_store_bf16 declined (M3P_ENOTIMPL) a store the caller depends on: dw is not physically zero')
     rc = L.load().m3p_gemm_wgrad_bf16(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), dw.data_ptr(),
                                       dw.stride(0), M, N, K, alpha, ws.data_ptr(), ws.numel(), L.stream())
     L.check(rc, 'm3p_gemm_wgrad_bf16')
@@ -300,8 +304,10 @@ def attn_fwd(qkv, keylen, B, S, H, dh, seed=0, p_drop=0.0, want_mask=False):
 
 
 def attn_bwd(qkv, keylen, ctx, dctx, lse, B, S, H, dh, dbias_qkv=None, seed=0, p_drop=0.0, keepmask=None):
+    """dqkv of attn_fwd.  With dropout on, keepmask = the words attn_fwd(..., want_mask=True) returned (required)."""
     _chk_bf16(qkv, ctx, dctx)
     assert dctx.is_contiguous() and ctx.is_contiguous()
+    assert p_drop == 0 or keepmask is not None, 'attention backward with dropout needs the keep words of the forward pass'
     dqkv = torch.empty_like(qkv)
     rc = L.load().m3p_attn_bwd(qkv.data_ptr(), keylen.data_ptr(), ctx.data_ptr(), dctx.data_ptr(), lse.data_ptr(),
                                L.ptr(keepmask), dqkv.data_ptr(), L.ptr(dbias_qkv), B, S, H, dh, 1.0 / (dh ** 0.5), seed,

@@ -163,6 +163,7 @@ class Adam(optim.Optimizer):
             # every piece of every active range of a parameter group goes into ONE launch (ops.adam_step_ranges): a sharded rank
             # steps fifteen bucket shards, and fifteen launches streamed the same bytes 24 % slower than one
             batches = {}
+            bump = []          # (parameter, new step count): applied only once every launch below has been accepted
             for r in active:
                 group = r['group']
                 beta1, beta2 = group['betas']
@@ -177,13 +178,20 @@ class Adam(optim.Optimizer):
                     else:
                         cuts = sorted({s, e, min(max(lazy[0], s), e), min(max(lazy[1], s), e)})
                         pieces.extend((a, b, step_size, not (lazy[0] <= a and b <= lazy[1])) for a, b in zip(cuts, cuts[1:]) if b > a)
-                for p in r['params']:
-                    self.state[p]['step'] = step
+                bump.extend((p, step) for p in r['params'])
+            for group, pieces in batches.values():
+                # (the kernel takes pieces whose borders are multiples of four elements: a bad one is refused HERE, before any
+                #  launch of this step has changed a parameter or a step counter)
+                bad = [(a, b) for a, b, _, _ in pieces if (a | b) & 3]
+                if bad:
+                    raise ValueError('fused Adam: piece borders must be multiples of 4 elements, got %s' % bad[:3])
             for group, pieces in batches.values():
                 beta1, beta2 = group['betas']
                 ops.adam_step_ranges(arena.master, arena.grad, ent['m'], ent['v'], arena.w16, pieces, group['lr'], beta1, beta2,
                                      group['eps'], group['weight_decay'], gnorm_sq=ent['gnorm'] if max_norm > 0 else None,
                                      max_norm=max_norm, grad_scale=self.grad_scale)
+            for p, step in bump:
+                self.state[p]['step'] = step
             # sharded exchange: the other ranks' shards of the updated master come back through an all-gather that the
             # next forward waits for bucket by bucket (distributed.DataParallel.after_sharded_step)
             hook = arena.model.ddp_hook

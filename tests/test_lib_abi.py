@@ -60,3 +60,34 @@ def test_header_is_plain_c(tmp_path):
     res = subprocess.run([gcc, '-std=c99', '-Wall', '-Werror', '-fsyntax-only', '-I', os.path.join(ROOT, 'include'), str(src)],
                          capture_output=True, text=True)
     assert res.returncode == 0, res.stderr
+
+
+def test_epilogue_struct_has_the_headers_size_and_field_offsets(tmp_path):
+    """The M3PEpilogue the Python side (and INTEGRATION.md's stub) hands over is copied BY VALUE: its size and every field's
+    offset must be the C compiler's for include/m3p_hip.h (round 5 review: the stub in INTEGRATION.md had stopped two fields short)."""
+    import ctypes
+    import re
+    import shutil
+    import subprocess
+    from m3p_amd import lib as L
+    gcc = shutil.which('gcc')
+    if gcc is None:
+        pytest.skip('no gcc')
+    fields = [f[0] for f in L.Epilogue._fields_]
+    body = ''.join('  printf("%s %%zu\\n", offsetof(M3PEpilogue, %s));\n' % (f, f) for f in fields)
+    src = tmp_path / 'probe.c'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "m3p_hip.h"\nint main(void) {\n  printf("sizeof %zu\\n", sizeof(M3PEpilogue));\n'
+                   + body + '  return 0;\n}\n')
+    exe = tmp_path / 'probe'
+    res = subprocess.run([gcc, '-std=c99', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    out = dict(line.split() for line in subprocess.run([str(exe)], capture_output=True, text=True).stdout.splitlines())
+    assert int(out['sizeof']) == ctypes.sizeof(L.Epilogue)
+    for f in fields:
+        assert int(out[f]) == getattr(L.Epilogue, f).offset, f
+    # the condensed stub of INTEGRATION.md names the same fields in the same order
+    doc = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    stub = doc[doc.index('class M3PEpilogue(C.Structure)'):]
+    stub = stub[:stub.index('lib.m3p_gemm_nt_bf16.restype')]
+    assert re.findall(r'\("(\w+)", C\.', stub) == fields
+    assert 'C.sizeof(M3PEpilogue) == %d' % ctypes.sizeof(L.Epilogue) in stub
