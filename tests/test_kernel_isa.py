@@ -61,11 +61,23 @@ def test_eight_wave_gemm_fits_two_waves_per_simd(tmp_path):
     body = out.read_text()
     seen = 0
     queued = 0
-    for m in re.finditer(r'^(_ZN\S*gemm_nt_w8_kernelILi(\d)ELb([01])E\S*):', body, re.M):
+    copies = 0
+    for m in re.finditer(r'^(_ZN\S*gemm_nt_w8_kernelILi(\d)ELb([01])ELb([01])E\S*):', body, re.M):
         k = body.index('; Kernel info:', body.index('.Lfunc_end', m.end()))
         info = dict(re.findall(r'; (\w+): (\d+)', body[k:k + 700]))
-        epi, dyn = int(m.group(2)), m.group(3) == '1'
+        epi, dyn, o8 = int(m.group(2)), m.group(3) == '1', m.group(4) == '1'
         assert int(info['Occupancy']) >= 2 and int(info['NumVgprs']) <= 256, (m.group(1), info)
+        if o8:
+            # (round 6, fp8 path only: the byte epilogues that also leave the 8-bit copy of their output.  GELU + byte: no
+            #  scratch; byte-decode: loop-invariant addresses parked in front of the K loop and fetched back in the epilogue -
+            #  a dozen dwords, none of them touched inside the K loop)
+            assert epi in (7, 8) and not dyn, m.group(1)
+            assert int(info['ScratchSize']) <= (64 if epi == 7 else 0), (m.group(1), info['ScratchSize'])
+            fn = body[m.end():body.index('.Lfunc_end', m.end())]
+            mf = [x.start() for x in re.finditer(r'v_mfma', fn)]
+            assert not re.search(r'scratch_', fn[mf[0]:mf[-1]]), 'scratch access inside the K loop of %s' % m.group(1)
+            copies += 1
+            continue
         if dyn:
             # the tile-queue instantiations (data parallelism only) carry a dozen registers of bookkeeping: a few dwords of
             # scratch at most, and none exists for the multiply epilogues (they spilled ~100 bytes: the launcher keeps those
@@ -77,7 +89,7 @@ def test_eight_wave_gemm_fits_two_waves_per_simd(tmp_path):
             # (7 - 9: the round-4 epilogues - byte-derivative multiply, bias-GELU + byte, bias + block statistics - no scratch)
             assert int(info['ScratchSize']) <= (32 if epi in (5, 6) else 0), (m.group(1), info['ScratchSize'])
             seen += 1
-    assert seen == 10 and queued == 5, (seen, queued)
+    assert seen == 10 and queued == 5 and copies == 2, (seen, queued, copies)
     for m in re.finditer(r'^(_ZN\S*gemm_nt_w8f8_kernel\S*):', body, re.M):
         k = body.index('; Kernel info:', body.index('.Lfunc_end', m.end()))
         info = dict(re.findall(r'; (\w+): (\d+)', body[k:k + 700]))

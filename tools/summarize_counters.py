@@ -5,7 +5,7 @@ profiles/<ROUND>_counters.md (ROUND defaults to r02): per kernel, launches per s
 pass), achieved HBM GB/s, and MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES)."""
 import collections, csv, glob, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(ROOT, 'gpurun_out', 'counters')
+src = os.path.join(ROOT, 'gpurun_out', os.environ.get('COUNTERS_DIR', 'counters'))
 
 def newest(pattern):
     """gpurun merges a call's files into what earlier calls left behind: only the newest run of a pass counts"""
