@@ -88,7 +88,7 @@ typedef struct M3PEpilogue {
    * (lin2 forward reads gelu(u), the dx1 data gradient reads dU): out8 [M, ld_out8] bytes, row-major,
    * = sat(C_fp32 * (*scale8)) in e4m3 (out8_bf8 = 0) or e5m2 (1), and *amax8 is raised to max |C| (atomic max; the
    * caller zeroes it) - what m3p_quant_fp8 would make of C in a pass of its own.  NULL = no copy.  ld_out8 % 16 == 0,
-   * 16-byte aligned base. */
+   * 16-byte aligned base.  BIAS_GELUQ (an activation) takes out8_bf8 = 0 only, MULQ (a gradient) out8_bf8 = 1 only. */
   void* out8;
   const float* scale8;
   float* amax8;

@@ -937,13 +937,13 @@ __device__ __forceinline__ void epilogue_half_geluq(bf16* __restrict__ C, int ld
 //     code(x)  = c(|x|) ^ (x < 0 ? 0xFF : 0)     c = the byte code of gelu'(|x|) (common.hpp: the grid is symmetric about 1/2)
 // so one 32-bit table word per bf16 magnitude holds T as an fp32 whose low mantissa byte is replaced by c (T keeps 15
 // mantissa bits: relative error 2^-16, far below the bf16 rounding of h).  The index is the TRUNCATED bf16 magnitude of the
-// fp32 x (one v_bfe - no rounding instruction), clamped to |x| in [2^-15, 8) (one v_med3); the entry is evaluated at the
+// fp32 x (one v_bfe - no rounding instruction), clamped to |x| in [2^-11, 8) (one v_med3); the entry is evaluated at the
 // MIDDLE of its truncation bucket, which makes the index error that of round-to-nearest (|dx| <= 2^-9 |x|, what a bf16
 // pre-activation would carry anyway).  x itself enters h in full fp32 (fma(-|x|, T, max(x, 0))).
 // Per element: v_bfe, v_med3, v_lshl_add (address), ds_read_b32, v_max, v_fma, half a v_cvt_pk_bf16 and 7/4 of an
 // instruction for the code (v_perm gathers the four code bytes and - selectors 9 / 11 - the four sign masks) = ~7 VALU + 1 LDS
 // read; the bias rides in the accumulators (they start an output tile at the bias instead of zero), so there is no add.
-// 16-row pieces: staging 2 KB per wave, the 9-KB table beside it (25 of the 32 KB the two stages leave).
+// 16-row pieces: staging 2 KB per wave + 1 KB for the 8-bit copy, the 7-KB table beside them (31 of the 32 KB the two stages leave).
 // ---------------------------------------------------------------------------------------------------------------------
 #ifndef M3P_GQ_LUT
 #define M3P_GQ_LUT 1
@@ -951,12 +951,16 @@ __device__ __forceinline__ void epilogue_half_geluq(bf16* __restrict__ C, int ld
 #ifndef M3P_GQ_NT
 #define M3P_GQ_NT 1          // h rows and codes leave with non-temporal stores (r06_store_policy.txt)
 #endif
-constexpr int GQ_TAB_BYTES = GELU_TAB_N * 4;
+// |x| in [2^-11, 8): 14 exponents x 128 mantissas = 1792 words, 7 KB (below 2^-11 the first entry serves: T = 0.4998 against
+// 1/2 - 0.4 |x|, an error of 4e-4 relative in h, a fifth of its bf16 rounding; gelu' = 1/2 +- 4e-4 -> codes 128 / 127 either way).
+// The 2 KB this saves against the dGELU table's range [2^-15, 8) are what lets the 8-bit copy of h have staging rows of its own.
+constexpr int GQ_TAB_LO = 0x3A00, GQ_TAB_HI = 0x4100, GQ_TAB_N = GQ_TAB_HI - GQ_TAB_LO;
+constexpr int GQ_TAB_BYTES = GQ_TAB_N * 4;
 __device__ __forceinline__ void geluq_table_fill(uint32_t* tab, int tid, int nthreads) {
-  for (int i = tid; i < GELU_TAB_N; i += nthreads) {
-    // middle of the truncation bucket of bf16 magnitude GELU_TAB_LO + i (the last bucket stands for every |x| >= 8, the first
-    // for every |x| < 2^-15: T = 1/2 there, code 128 - half a step from gelu'(0) = 1/2 like its mirror image 127)
-    const float xm = __builtin_bit_cast(float, ((uint32_t)(GELU_TAB_LO + i) << 16) | 0x8000u);
+  for (int i = tid; i < GQ_TAB_N; i += nthreads) {
+    // middle of the truncation bucket of bf16 magnitude GQ_TAB_LO + i (the last bucket stands for every |x| >= 8, the first
+    // for every |x| < 2^-11: T = 1/2 there, code 128 - half a step from gelu'(0) = 1/2 like its mirror image 127)
+    const float xm = __builtin_bit_cast(float, ((uint32_t)(GQ_TAB_LO + i) << 16) | 0x8000u);
     const float tail = 0.5f * erfcf(xm * 0.70710678118654752440f);
     const float gd = (1.0f - tail) + xm * 0.39894228040143267794f * __expf(-0.5f * xm * xm);
     tab[i] = (__builtin_bit_cast(uint32_t, tail) & 0xFFFFFF00u) | gelu_grad_code(gd);
@@ -964,11 +968,12 @@ __device__ __forceinline__ void geluq_table_fill(uint32_t* tab, int tid, int nth
 }
 __device__ __forceinline__ void lds_r32(uint32_t a, uint32_t& v) { asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(a)); }
 // one 16-row piece (this wave's 16 x 64 block at (mrow0, nw)): `rows` = accumulators INCLUDING the bias, tab_off = LDS byte
-// address of the table minus 4 * GELU_TAB_LO, r1 = the wave's 2 KB of staging rows, qout = where the piece's 1024 code bytes go
+// address of the table minus 4 * GQ_TAB_LO, r1 = the wave's 2 KB of staging rows, qout = where the piece's 1024 code bytes go
 template <int O8 = 0>      // 0: no 8-bit copy of h, 1: e4m3
 __device__ __forceinline__ void epilogue_piece_geluq_lut(bf16* __restrict__ C, int ldc, uint8_t* __restrict__ qout, int mrow0, int nw,
                                                          char* r1, const f32x4 (&rows)[4], int lane, uint32_t tab_off,
-                                                         uint8_t* __restrict__ o8 = nullptr, int ld8 = 0, float scale8 = 1.f, float* amax = nullptr) {
+                                                         uint8_t* __restrict__ o8 = nullptr, int ld8 = 0, float scale8 = 1.f, float* amax = nullptr,
+                                                         char* r8 = nullptr) {
   const int fr = lane & 15, fg = lane >> 4;
   const int srow = lane >> 3, sch = lane & 7;
   uint32_t w8[4];
@@ -980,7 +985,7 @@ __device__ __forceinline__ void epilogue_piece_geluq_lut(bf16* __restrict__ C, i
       const float xf = rows[j][r];       // (through a scalar: __builtin_bit_cast applied to a vector ELEMENT reads element 0 - seen in the ISA)
       const uint32_t xb = __builtin_bit_cast(uint32_t, xf);
       const uint32_t mag = __builtin_amdgcn_ubfe(xb, 16, 15);
-      const uint32_t idx = min(max(mag, (uint32_t)GELU_TAB_LO), (uint32_t)(GELU_TAB_HI - 1));     // (v_med3_u32)
+      const uint32_t idx = min(max(mag, (uint32_t)GQ_TAB_LO), (uint32_t)(GQ_TAB_HI - 1));     // (v_med3_u32)
       lds_r32((idx << 2) + tab_off, w[j][r]);
     }
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[0][2]), "+v"(w[0][3]), "+v"(w[1][0]), "+v"(w[1][1]), "+v"(w[1][2]), "+v"(w[1][3]),
@@ -1010,14 +1015,22 @@ __device__ __forceinline__ void epilogue_piece_geluq_lut(bf16* __restrict__ C, i
     if (O8) w8[j] = pack8<false>(hv, scale8, *amax);
   }
   st16p<M3P_GQ_NT != 0>(qout + lane * 16, code);
+  if (O8) piece8_write(r8, w8, lane);      // (staging rows of its own: its round trip shares the bf16 piece's wait)
   u32x4 R[2];
+  u32x4_lds R8;
   lds_r128(la + ep_off<true>(srow, sch * 16), R[0]);
   lds_r128(la + ep_off<true>(8 + srow, sch * 16), R[1]);
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(R[0]), "+v"(R[1]));
+  const int row8 = lane >> 2, c8 = lane & 3;
+  if (O8) {
+    lds_r128(lds_addr(r8) + row8 * 64 + (c8 << 4), R8);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(R[0]), "+v"(R[1]), "+v"(R8));
+  } else {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(R[0]), "+v"(R[1]));
+  }
   bf16* Cp = C + (size_t)mrow0 * ldc + nw + sch * 8;
   st16p<M3P_GQ_NT != 0>(Cp + (size_t)srow * ldc, R[0]);
   st16p<M3P_GQ_NT != 0>(Cp + (size_t)(8 + srow) * ldc, flip_halves(R[1], true));
-  if (O8) piece8_flush(o8, ld8, mrow0, nw, r1, w8, lane);
+  if (O8) st16p<true>(o8 + (size_t)(mrow0 + row8) * ld8 + nw + ((c8 ^ ((row8 >> 1) & 3)) << 4), u32x4{R8[0], R8[1], R8[2], R8[3]});
 }
 
 #if defined(M3P_RING_TL) || defined(M3P_W8_TL) || defined(M3P_WG_TL)
@@ -1373,7 +1386,7 @@ void gemm_nt_w8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
   constexpr bool kMulE = (EPI == M3P_EPI_DGELU || EPI == M3P_EPI_MUL || EPI == M3P_EPI_MULQ);
   constexpr bool kAuxE = (EPI == M3P_EPI_BIAS_DROP_RES || EPI == M3P_EPI_RES || kMulE);
   constexpr bool kGqLut = (EPI == M3P_EPI_BIAS_GELUQ) && M3P_GQ_LUT;
-  constexpr int kTabBytes = ((EPI == M3P_EPI_DGELU && M3P_DGELU_LUT) || kGqLut) ? GELU_TAB_N * (int)sizeof(float) : 0;
+  constexpr int kTabBytes = (EPI == M3P_EPI_DGELU && M3P_DGELU_LUT) ? GELU_TAB_N * (int)sizeof(float) : (kGqLut ? GQ_TAB_BYTES : 0);
   float* gtab = (EPI == M3P_EPI_DGELU && M3P_DGELU_LUT) ? reinterpret_cast<float*>(smem + 2 * STAGE) : nullptr;
   if (EPI == M3P_EPI_DGELU && M3P_DGELU_LUT) gelu_grad_table_fill(gtab, tid, 512);
   if (kGqLut) geluq_table_fill(reinterpret_cast<uint32_t*>(smem + 2 * STAGE), tid, 512);      // (the prologue's barrier publishes it)
@@ -1752,14 +1765,15 @@ void gemm_nt_w8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
         }
         {
           char* r1 = smem + 2 * STAGE + kTabBytes + wid * 2048;
-          const uint32_t tab_off = lds0 + 2 * STAGE - 4 * GELU_TAB_LO;
+          const uint32_t tab_off = lds0 + 2 * STAGE - 4 * GQ_TAB_LO;
           uint8_t* qo = reinterpret_cast<uint8_t*>(ep.out2) + gq_block_offset(tm, tn, tiles_n, wid, 0);
           if constexpr (O8) {      // + the e4m3 copy of h for an fp8 lin2
             const float sc8 = ep.scale8 ? *ep.scale8 : 1.f;
 #pragma unroll
             for (int hp = 0; hp < 8; ++hp) {
               epilogue_piece_geluq_lut<1>(C, ldc, qo + 1024 * hp, mw + 16 * hp, nw, r1, acc[hp], lane, tab_off,
-                                          reinterpret_cast<uint8_t*>(ep.out8), ep.ld_out8, sc8, &amax_run);
+                                          reinterpret_cast<uint8_t*>(ep.out8), ep.ld_out8, sc8, &amax_run,
+                                          smem + 2 * STAGE + kTabBytes + 8 * 2048 + wid * 1024);
               __builtin_amdgcn_sched_barrier(0);
             }
           } else {
@@ -1818,8 +1832,8 @@ void gemm_nt_w8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
               u32x4 qc = qb;
               if (hp + 2 < 8) qc = MQ_LD((hp + 2) * 1024);
               char* r8 = smem + 2 * STAGE + 8 * 2048 + 2048 + wid * 1024;
-              if (ep.out8_bf8) epilogue_pieceq<2>(C, ldc, mw + 16 * hp, nw, r1, acc[hp], qa, lane, csum, o8, ep.ld_out8, sc8, &amax_t, r8);
-              else epilogue_pieceq<1>(C, ldc, mw + 16 * hp, nw, r1, acc[hp], qa, lane, csum, o8, ep.ld_out8, sc8, &amax_t, r8);
+              // (e5m2 only: the copy of a GRADIENT - the launcher refuses anything else, one code path in the instantiation)
+              epilogue_pieceq<2>(C, ldc, mw + 16 * hp, nw, r1, acc[hp], qa, lane, csum, o8, ep.ld_out8, sc8, &amax_t, r8);
               __builtin_amdgcn_sched_barrier(0);
               qa = qb; qb = qc;
             }
@@ -2018,7 +2032,7 @@ void gemm_nt_w8f8_kernel(const uint8_t* __restrict__ A, int lda, const uint8_t* 
   constexpr bool kMulE = (EPI == M3P_EPI_DGELU || EPI == M3P_EPI_MUL);
   constexpr bool kAuxE = (EPI == M3P_EPI_BIAS_DROP_RES || EPI == M3P_EPI_RES || kMulE);
   constexpr bool kGqLut = (EPI == M3P_EPI_BIAS_GELUQ) && M3P_GQ_LUT;
-  constexpr int kTabBytes = ((EPI == M3P_EPI_DGELU && M3P_DGELU_LUT) || kGqLut) ? GELU_TAB_N * (int)sizeof(float) : 0;
+  constexpr int kTabBytes = (EPI == M3P_EPI_DGELU && M3P_DGELU_LUT) ? GELU_TAB_N * (int)sizeof(float) : (kGqLut ? GQ_TAB_BYTES : 0);
   float* gtab = (EPI == M3P_EPI_DGELU && M3P_DGELU_LUT) ? reinterpret_cast<float*>(smem + 2 * STAGE) : nullptr;
   if (EPI == M3P_EPI_DGELU && M3P_DGELU_LUT) gelu_grad_table_fill(gtab, tid, 512);
   if (kGqLut) geluq_table_fill(reinterpret_cast<uint32_t*>(smem + 2 * STAGE), tid, 512);      // (the prologue's barrier publishes it)
@@ -3469,7 +3483,7 @@ static int launch_nt_gq(const bf16* A, int lda, const bf16* W, int ldw, bf16* C,
     return M3P_EINVAL;
   if (EPI == M3P_EPI_BIAS_LSE && (ep.ld_out2 <= 0 || ep.ld_out2 > N)) return M3P_EINVAL;
   const int tiles_m = M / 256, tiles_n = N / 256;
-  const size_t lds = 2 * 512 * ROWB + ((EPI == M3P_EPI_BIAS_GELUQ && M3P_GQ_LUT) ? GQ_TAB_BYTES + 8 * 2048 : 8 * (EPI != M3P_EPI_MULQ ? 4096 : 2048)) +
+  const size_t lds = 2 * 512 * ROWB + ((EPI == M3P_EPI_BIAS_GELUQ && M3P_GQ_LUT) ? GQ_TAB_BYTES + 8 * 2048 + 8 * 1024 : 8 * (EPI != M3P_EPI_MULQ ? 4096 : 2048)) +
                      (EPI == M3P_EPI_MULQ ? 2048 + 8 * 1024 : 0);      // (MULQ: behind the staging rows 2 KB - the 8-bit copy's running maxima / the
                                                                        //  prefetch experiment - and the 8-bit copy's own staging rows, 1 KB per wave)
   int grid = num_cus();
@@ -3478,6 +3492,8 @@ static int launch_nt_gq(const bf16* A, int lda, const bf16* W, int ldw, bf16* C,
   if constexpr (EPI == M3P_EPI_BIAS_GELUQ || EPI == M3P_EPI_MULQ) {
     if (ep.out8) {      // the instantiation that also leaves the 8-bit copy (its own registers: the plain one must not pay for it)
       if (((uintptr_t)ep.out8 & 15) || (ep.ld_out8 & 15) || ep.ld_out8 < N) return M3P_EINVAL;
+      // the copy of an activation is e4m3, of a gradient e5m2 - what the fp8 product's operand slots take (include/m3p_hip.h)
+      if ((EPI == M3P_EPI_MULQ) != (ep.out8_bf8 != 0)) return M3P_EINVAL;
       auto kern8 = gemm_nt_w8_kernel<EPI, false, true>;
       static bool attr_set8 = false;
       if (!attr_set8) {
