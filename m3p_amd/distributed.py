@@ -347,6 +347,11 @@ class DataParallel(torch.nn.Module):
         if self.single or not self.reducer.enabled or key in self._launched:
             return
         self._launched.add(key)
+        st = self._arena.stale
+        if st is not None and st[0] < self._ranges[key][1] and st[0] + st[1] > self._ranges[key][0]:
+            # a lazily zeroed range (Arena.defer_vocab_zero) that no store has covered this step - a rank whose batch held no
+            # masked word runs no MLM head - must be physically zero before it is summed with the other ranks' gradients
+            self._arena.ensure_zero()
         if self.mode == 'zero1':
             self.reducer.reduce_scatter_range(*self._ranges[key], label=key)
         else:
@@ -379,19 +384,24 @@ class DataParallel(torch.nn.Module):
         if self.mode == 'zero1':
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg)
 
-    def after_sharded_step(self, touched_ranges):
+    def after_sharded_step(self, touched_ranges, keep=None):
         """zero1, called by the optimizer once Adam has run on this rank's shards: zero the rest of the touched gradient
         ranges (they hold this rank's un-reduced partials), exchange the fp32-read parameters (one packed all-reduce), then
         gather the updated bf16 working copy bucket by bucket in forward order on the side stream; the transposed copies
-        come last.  The next forward waits per bucket (``params_ready``).  -> True if it took care of the bf16 copies."""
+        come last.  The next forward waits per bucket (``params_ready``).  -> True if it took care of the bf16 copies.
+        keep: [start, end) the optimizer left lazily un-zeroed (Arena.defer_vocab_zero: the next step's MLM head STORES over the
+        whole vocabulary range, foreign shards included) - not zeroed here either."""
         if self.mode != 'zero1':
             return False
         ar = self._arena
+        k0, k1 = keep if keep is not None else (0, 0)
         for s, e in touched_ranges:
             pos = s
             for a, b in self.owned(s, e) + [(e, e)]:
                 if a > pos:
-                    ar.grad[pos:a].zero_()
+                    for z0, z1 in ((pos, min(a, k0)), (max(pos, k1), a)) if k1 > k0 else ((pos, a),):
+                        if z1 > z0:
+                            ar.grad[z0:z1].zero_()
                 pos = max(pos, b)
         touched_keys = [k for k, (s, e) in self._ranges.items() if any(a < e and s < b for a, b in touched_ranges)]
         red = self.reducer

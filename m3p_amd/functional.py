@@ -111,6 +111,7 @@ class Arena:
         self.epoch = 0          # bumped whenever the weights change (load / cast / optimizer step): 8-bit copies key on it
         self.grads_known_zero = True
         self.touched = set()   # names of parameters that received gradient since the last zero_grad
+        self.planned = set()   # the subset of `touched` that was only announced (plan()), not written yet
         # Lazy zero of the tied vocabulary matrix's gradient (round 5).  When a step's MLM head STORED its weight gradient over
         # grad[o : o + V_pad * d] (whole-tile sizes, first product into the zeroed matrix), the next step will almost always do
         # the same - so the fused Adam pass does not write 768 MB of zeros there only for them to be overwritten (0.77 GB of the
@@ -128,18 +129,30 @@ class Arena:
 
     def touch(self, *names):
         self.touched.update(names)
+        self.planned.difference_update(names)
+        self.grads_known_zero = False
+
+    def plan(self, *names):
+        """Mark parameters as part of this step's optimizer ranges BEFORE anything has written their gradient (data
+        parallelism: a head that MAY run on some rank is stepped - and its range zeroed - on every rank).  Unlike touch() this
+        does not count as a write: a kernel that wants to STORE over such a range (range_untouched) still may."""
+        new = [n for n in names if n not in self.touched]
+        self.planned.update(new)
+        self.touched.update(new)
         self.grads_known_zero = False
 
     def range_untouched(self, start, count):
         """No parameter whose gradient overlaps grad[start : start + count] has received gradient since the last zero_grad
         (what a kernel that STORES into that range instead of accumulating needs to know)."""
         end = start + count
-        return not any(o < end and o + cnt > start for n in self.touched for (o, cnt, _) in (self.offsets[n],))
+        return not any(o < end and o + cnt > start for n in self.touched if n not in self.planned for (o, cnt, _) in (self.offsets[n],))
 
     def touch_layer(self, i, cross=False):
         self.touched.update(self._layer_names[i])
+        self.planned.difference_update(self._layer_names[i])
         if cross:
             self.touched.update(self._cross_names[i])
+            self.planned.difference_update(self._cross_names[i])
         self.grads_known_zero = False
 
     # ---- views
@@ -304,6 +317,7 @@ class Arena:
         self.ensure_zero()
         self.vocab_stored = False
         self.touched.clear()
+        self.planned.clear()
         if self.model.ddp_hook is not None:
             self.model.ddp_hook.step_done()
 
@@ -314,6 +328,7 @@ class Arena:
         if copies_scheduled:
             self._transposes_stale = False
         self.touched.clear()
+        self.planned.clear()
         self.grads_known_zero = True
         self.vocab_stored = False
         if self.model.ddp_hook is not None:

@@ -150,11 +150,15 @@ class Adam(optim.Optimizer):
             if arena.model.ddp_hook is not None:
                 arena.model.ddp_hook.finish()
             active = self._active_ranges(arena)
-            # single GPU, and this step's MLM head stored its weight gradient over the tied vocabulary matrix (it will again next
-            # step): that range is not zeroed here - Arena.defer_vocab_zero, functional.py.  The range may span several active
-            # ranges (per-parameter step counts differ after a step without an MLM head): every piece is cut at its borders.
+            # this step's MLM head stored its weight gradient over the tied vocabulary matrix (it will again next step): that
+            # range is not zeroed here - Arena.defer_vocab_zero, functional.py.  The range may span several active ranges
+            # (per-parameter step counts differ after a step without an MLM head): every piece is cut at its borders.
+            # Under data parallelism too (round 6: the wrapped step paid 0.3 ms for these zeros, profiles/r06_dp_overhead.txt):
+            # the bucket collectives work on the arena in place after the store, the exchanged token rows enter through
+            # Arena.g() (which zeroes a still-stale range first), and a sharded rank leaves its foreign shards of the range
+            # un-zeroed as well (after_sharded_step(keep=...)) - the store covers them.
             lazy = None
-            if arena.model.ddp_hook is None and getattr(arena, 'vocab_stored', False) and _LAZY_VOCAB_ZERO:
+            if getattr(arena, 'vocab_stored', False) and _LAZY_VOCAB_ZERO:
                 v0, vc = arena.vocab_range()
                 covered = sum(max(0, min(r['end'], v0 + vc) - max(r['start'], v0)) for r in active)
                 if covered == vc:
@@ -195,7 +199,7 @@ class Adam(optim.Optimizer):
             # sharded exchange: the other ranks' shards of the updated master come back through an all-gather that the
             # next forward waits for bucket by bucket (distributed.DataParallel.after_sharded_step)
             hook = arena.model.ddp_hook
-            gathered = hook is not None and hook.after_sharded_step([(r['start'], r['end']) for r in active])
+            gathered = hook is not None and hook.after_sharded_step([(r['start'], r['end']) for r in active], keep=lazy)
             # untouched ranges may still hold stale values only if someone wrote them by hand
             arena.after_fused_step(copies_scheduled=gathered)
         # parameters outside any arena (never the case on the hot path) — reference loop

@@ -147,7 +147,7 @@ class Trainer(object):
             model.plan_step(vocab_dense)
             arena = model.module.arena()
             for head in expect:
-                arena.touch(*_REGION_HEADS[head])
+                arena.plan(*_REGION_HEADS[head])       # (announced, not written: the MLM head's first product may still STORE)
 
     def optimize(self, loss):
         """xtrainer.py:205-243 without the host round trips: backward -> (bucketed

@@ -123,9 +123,17 @@ class _FakeArena:
         self.w16 = torch.zeros(self.total, dtype=torch.bfloat16)
         self.V, self.d = V, d
         self._transposes_stale = False
+        self.stale = None                    # (start, count) of a lazily zeroed range, functional.Arena.defer_vocab_zero
+
+    def ensure_zero(self):
+        if self.stale is not None:
+            self.grad[self.stale[0]:self.stale[0] + self.stale[1]].zero_()
+            self.stale = None
 
     def g(self, name):
         o, n, _ = self.offsets[name]
+        if self.stale is not None and o < self.stale[0] + self.stale[1] and o + n > self.stale[0]:
+            self.ensure_zero()
         return self.grad[o:o + n].view(self.V, self.d) if name == 'embeddings.weight' else self.grad[o:o + n]
 
     def touch(self, *names):
@@ -342,6 +350,40 @@ def _protocol_worker(rank, world, port, q, mode):
             assert not dp.master_partial
             results['F'] = float((ar.master - want)[named | own].abs().max())
             results['Fz'] = float(ar.grad[~reduced()[1]].abs().max())     # un-reduced partials outside the shards: zeroed
+        dp.step_done()
+
+        # --- step G (round 6): the optimizer left the vocabulary range lazily un-zeroed (it still holds last step's gradient, 7.0
+        # here).  Rank 0's MLM head STORES over it; the other ranks' batches held no masked word - no MLM head, no store - and
+        # their stale range must be zeroed before the 'vocab' bucket sums it with rank 0's.  Token rows enter through g().
+        dp.plan_step(True)
+        fill(0.0)
+        v0, vc = 0, 512
+        ar.grad[v0:v0 + vc] = 7.0
+        ar.stale = (v0, vc)
+        nm = dp.encoder_forward(2)
+        if rank == 0:
+            ar.grad[v0:v0 + vc] = 5.0                           # the store
+            ar.stale = None
+            dp.mlm_head_done()
+        assert dp.encoder_backward_begin()
+        dp.layer_done(1, True); dp.layer_done(0, True)
+        ig, rg = tokens(2, 600 + rank)
+        dp.embed_done(True, ids=ig, rows=rg, n_max=nm)
+        dp.finish()
+        assert ar.stale is None
+        want = torch.zeros_like(ar.grad)
+        want[v0:v0 + vc] = 5.0
+        want[:ar.V * ar.d] += expected_tokens([(2, 600 + r) for r in range(world)]).view(-1)
+        results['G'] = float((reduced()[0] - want).abs().max())
+        if mode == 'zero1':
+            # ... and the sharded step leaves a lazily kept range alone outside this rank's shards, zeroes the rest
+            before = ar.grad.clone()
+            dp.after_sharded_step([(0, ar.total)], keep=(v0, v0 + vc))
+            own = reduced()[1]
+            keep = torch.zeros(ar.total, dtype=torch.bool)
+            keep[v0:v0 + vc] = True
+            results['Gkeep'] = float((ar.grad - before)[keep & ~own].abs().max()) if bool((keep & ~own).any()) else 0.0
+            results['Gzero'] = float(ar.grad[~keep & ~own].abs().max())
         dp.step_done()
 
         if rank == 0:

@@ -238,6 +238,78 @@ def test_dp_one_rank_over_rccl(mode):
     _check('pretrain', 'nccl', world=1, mode=mode)
 
 
+BIG = dict(emb_dim=768, n_heads=12, n_layers=1, n_words=88000, T=96, R=32, B=128, n_pred=32)   # 4096 predicted rows: the store path
+
+
+def _lazy_worker(port, q, mode):
+    """One forced rank over RCCL at a size where the MLM head STORES the vocabulary weight gradient: MLM + ITM, MLM + ITM, an
+    ITM-only step, MLM + ITM - with the lazy zero of the vocabulary range on, off, off (the third run is the noise floor)."""
+    try:
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1',
+                          HSA_ENABLE_IPC_MODE_LEGACY='0', M3P_DP_MODE=mode, M3P_DP_FORCE='1')
+        torch.cuda.set_device(0)
+        dist.init_process_group('nccl', rank=0, world_size=1)
+        from m3p_amd import optim as Om
+        global CFG
+        CFG = BIG
+        outs, events = [], []
+        for lazy in (True, False, False):
+            Om._LAZY_VOCAB_ZERO = lazy
+            tr, m = _build('pretrain', True)
+            assert tr.model.mode == mode
+            ar = m.arena()
+            ev = []
+            real_zero, real_defer = ar.ensure_zero, ar.defer_vocab_zero
+
+            def ensure_zero(ar=ar, ev=ev, real_zero=real_zero):
+                if ar.stale is not None:
+                    ev.append('memset')
+                real_zero()
+
+            def defer(ev=ev, real_defer=real_defer):
+                ev.append('defer')
+                real_defer()
+            ar.ensure_zero, ar.defer_vocab_zero = ensure_zero, defer
+            full = synth.make_batch(CFG['T'], CFG['R'], CFG['B'], CFG['n_words'], CFG['n_pred'], seed=3)
+            assert full['y'].numel() == 4096
+            extra = synth.make_region_targets(CFG['R'], CFG['B'], seed=77)
+            extra.update(x2=full['x'], len2=full['lengths'], clcm=torch.zeros(CFG['B'], dtype=torch.long))
+            tup = _slice(full, extra, slice(0, CFG['B']), slice(0, CFG['B'] // 2))
+            for step in range(4):
+                _run_step(tr, 'finetune' if step == 2 else 'pretrain', tup)
+            tr.model.materialize_master()
+            torch.cuda.synchronize()
+            ar.ensure_zero()
+            assert float(ar.grad.abs().max()) == 0.0
+            outs.append(ar.master.float().cpu().numpy())
+            events.append(ev)
+        q.put(('ok', outs, events))
+        dist.destroy_process_group()
+    except Exception:
+        q.put(('err', traceback.format_exc(), None))
+        raise
+
+
+@pytest.mark.parametrize('mode', ['zero1', 'allreduce'])
+def test_dp_lazy_vocab_zero_changes_nothing(mode):
+    """Round 6: the lazily zeroed vocabulary gradient range (Arena.defer_vocab_zero) under the data-parallel wrapper - the bucket
+    collectives, the exchanged token rows (which enter through Arena.g()) and, sharded, the foreign shards the rank leaves
+    un-zeroed: same weights with the switch on and off, to the step's own run-to-run noise, and the switch was exercised."""
+    import numpy as np
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_lazy_worker, args=(_free_port(), q, mode))
+    p.start()
+    status, outs, events = q.get(timeout=900)
+    p.join(timeout=120)
+    assert status == 'ok', outs
+    assert events[0].count('defer') == 3 and events[0].count('memset') >= 1 and events[1] == [] and events[2] == [], events
+    a, b, c = outs
+    noise = float(np.linalg.norm(c - b) / np.linalg.norm(b))
+    diff = float(np.linalg.norm(a - b) / np.linalg.norm(b))
+    assert diff <= max(10 * noise, 1e-7), (diff, noise)
+
+
 @pytest.mark.parametrize('scenario', ['pretrain', 'clcm'])
 def test_dp_two_ranks_over_rccl(scenario):
     if torch.cuda.device_count() < 2:

@@ -25,12 +25,25 @@ def main():
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--top', type=int, default=25)
     ap.add_argument('--marker', default='adam_kernel', help='a kernel launched once per step (the sharded data-parallel step launches Adam per shard: use ce_grad_tile_kernel)')
+    ap.add_argument('--boundary', default=None, metavar='FROM,TO',
+                    help='also list every launch (relative start us, duration us, queue, name) from the last launch of kernel FROM '
+                         'to the first launch of kernel TO after it - the step boundary on its streams')
     a = ap.parse_args()
-    rows = []
+    rows, queue = [], {}
     with open(a.csv) as f:
         for r in csv.DictReader(f):
             rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']))
+            queue[(rows[-1][0], rows[-1][2])] = r.get('Queue_Id', '?')
     rows.sort()
+    if a.boundary:
+        frm, to = a.boundary.split(',')
+        marks = [i for i, r in enumerate(rows) if a.marker in r[2]]
+        i0 = max(i for i in range(marks[-2]) if frm in rows[i][2])           # the step before the last full one
+        i1 = next(i for i in range(i0 + 1, len(rows)) if to in rows[i][2])
+        t0 = rows[i0][0]
+        print('step boundary: %s .. %s' % (frm, to))
+        for s, e, n in rows[i0:i1 + 1]:
+            print('  %9.1f us  %8.1f us  q%-3s %s' % ((s - t0) / 1e3, (e - s) / 1e3, queue[(s, n)], short(n)))
     adam = [i for i, r in enumerate(rows) if a.marker in r[2]]
     assert len(adam) > a.steps, 'not enough steps in the trace'
     lo, hi = adam[-a.steps - 1] + 1, adam[-1] + 1
