@@ -42,6 +42,12 @@ __device__ unsigned long long g_attn_tl[4096 * 4 * 16];
 #define BTL_SUM(i, t0) do { } while (0)
 #endif
 
+// -DM3P_ATTN_BWDP_ABL=<bits>: timing ablations of the persistent backward's phase A (results are garbage): 1 no softmax / dropout
+// arithmetic, 2 the Q / dO row fragments are not read from LDS (registers stand in), 4 likewise
+// the transposed Q / dO fragments, 8 no dS^T store, 16 no MFMA in phase A
+#ifndef M3P_ATTN_BWDP_ABL
+#define M3P_ATTN_BWDP_ABL 0
+#endif
 #ifndef M3P_ATTN_BWD_NEXTFRAG
 #define M3P_ATTN_BWD_NEXTFRAG 1
 #endif
@@ -1277,8 +1283,13 @@ void attn_bwd_p_kernel(const bf16* __restrict__ qkv, const int* __restrict__ key
           for (int hf = 0; hf < 2; ++hf) {
             const int t = 2 * kq + hf;
             if (PAD_TILE(t)) continue;
-            const bf16x8 qf = *reinterpret_cast<const bf16x8*>(s0 + t * 16 * Cf::ROWB + r_off[kk]);
-            const bf16x8 df = *reinterpret_cast<const bf16x8*>(s1 + t * 16 * Cf::ROWB + r_off[kk]);
+            const bf16x8 qf = (M3P_ATTN_BWDP_ABL & 2) ? kf[kk ^ 1] : *reinterpret_cast<const bf16x8*>(s0 + t * 16 * Cf::ROWB + r_off[kk]);
+            const bf16x8 df = (M3P_ATTN_BWDP_ABL & 2) ? vf[kk ^ 1] : *reinterpret_cast<const bf16x8*>(s1 + t * 16 * Cf::ROWB + r_off[kk]);
+            if (M3P_ATTN_BWDP_ABL & 16) {
+              scA[hf] += f32x4{(float)qf[0], (float)qf[1], (float)kf[kk][0], (float)kf[kk][1]};
+              dpA[hf] += f32x4{(float)df[0], (float)df[1], (float)vf[kk][0], (float)vf[kk][1]};
+              continue;
+            }
             scA[hf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf[kk], scA[hf], 0, 0, 0);   // S[q][key]
             dpA[hf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, vf[kk], dpA[hf], 0, 0, 0);   // dPd[q][key]
           }
@@ -1296,6 +1307,11 @@ void attn_bwd_p_kernel(const bf16* __restrict__ qkv, const int* __restrict__ key
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int q = 16 * t + 4 * fg + r;
+            if (M3P_ATTN_BWDP_ABL & 1) {
+              pd2[hf][r] = scA[hf][r];
+              ds2[hf][r] = dpA[hf][r];
+              continue;
+            }
             const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(scA[hf][r], kLog2e, -sL[q]));   // padded q: lse = +inf -> 0
             if (DROP) {      // p = P / keep here, dneg = -D keep
               const float pd = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, p) & bit_to_mask(kbits, r));
@@ -1314,7 +1330,7 @@ void attn_bwd_p_kernel(const bf16* __restrict__ qkv, const int* __restrict__ key
         // dS^T[key][query]: this lane's four values of a tile are four consecutive queries of its key row
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
-          if (PAD_TILE(2 * kq + hf)) continue;
+          if (PAD_TILE(2 * kq + hf) || (M3P_ATTN_BWDP_ABL & 8)) continue;
           *reinterpret_cast<bf16x4*>(sDS + key * DSP + (32 * kq + 16 * hf + 4 * fg) * 2) =
               hf ? bf16x4{sfrag[4], sfrag[5], sfrag[6], sfrag[7]} : bf16x4{sfrag[0], sfrag[1], sfrag[2], sfrag[3]};
         }
@@ -1322,8 +1338,13 @@ void attn_bwd_p_kernel(const bf16* __restrict__ qkv, const int* __restrict__ key
         for (int n = 0; n < Cf::NT; ++n) {
           const char* pq = s0 + kq * 32 * Cf::ROWB + t_off[n];
           const char* pdo = s1 + kq * 32 * Cf::ROWB + t_off[n];
-          const bf16x8 qT = cat8(lds_tr16(pq), lds_tr16(pq + 16 * Cf::ROWB));
-          const bf16x8 dT = cat8(lds_tr16(pdo), lds_tr16(pdo + 16 * Cf::ROWB));
+          const bf16x8 qT = (M3P_ATTN_BWDP_ABL & 4) ? kf[n & 1] : cat8(lds_tr16(pq), lds_tr16(pq + 16 * Cf::ROWB));
+          const bf16x8 dT = (M3P_ATTN_BWDP_ABL & 4) ? vf[n & 1] : cat8(lds_tr16(pdo), lds_tr16(pdo + 16 * Cf::ROWB));
+          if (M3P_ATTN_BWDP_ABL & 16) {
+            dv[n] += f32x4{(float)dT[0], (float)pfrag[0], (float)dT[4], (float)pfrag[4]};
+            dk[n] += f32x4{(float)qT[0], (float)sfrag[0], (float)qT[4], (float)sfrag[4]};
+            continue;
+          }
           dv[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dT, pfrag, dv[n], 0, 0, 0);
           dk[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qT, sfrag, dk[n], 0, 0, 0);
         }

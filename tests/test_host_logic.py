@@ -160,7 +160,7 @@ def test_store_range_check_sees_every_parameter_the_pad_rows_reach():
     V, d, V_pad = 1000, 64, 1024                       # pad rows: 24 * 64 = 1536 elements > V = 1000 bias elements
     offsets = {'embeddings.weight': (0, V * d, (V, d)), 'pred_layer.proj.bias': (V * d, V, (V,)),
                'position_embeddings.weight': (V * d + 1024, 512 * d, (512, d)), 'layer_norm_emb.weight': (V * d + 1024 + 512 * d, d, (d,))}
-    ar = SimpleNamespace(offsets=offsets, touched=set())
+    ar = SimpleNamespace(offsets=offsets, touched=set(), planned=set(), grads_known_zero=True)
     fresh = lambda: Arena.range_untouched(ar, 0, V_pad * d)    # noqa: E731
     assert fresh()
     ar.touched = {'layer_norm_emb.weight'}              # behind the range: harmless
@@ -170,4 +170,13 @@ def test_store_range_check_sees_every_parameter_the_pad_rows_reach():
     ar.touched = {'pred_layer.proj.bias'}
     assert not fresh()
     ar.touched = {'embeddings.weight'}
+    assert not fresh()
+    # round 6: a parameter that data parallelism only ANNOUNCED for this step (Arena.plan: every rank steps the heads some rank may
+    # train) has not been written - the store is still allowed - until a real writer touches it
+    ar.touched = set()
+    Arena.plan(ar, 'embeddings.weight', 'pred_layer.proj.bias')
+    assert ar.touched == {'embeddings.weight', 'pred_layer.proj.bias'} and fresh()
+    Arena.touch(ar, 'pred_layer.proj.bias')
+    assert not fresh() and ar.planned == {'embeddings.weight'}
+    Arena.plan(ar, 'pred_layer.proj.bias')              # announcing what has been written does not make it unwritten
     assert not fresh()
