@@ -45,6 +45,9 @@ __device__ unsigned long long g_attn_tl[4096 * 4 * 16];
 // -DM3P_ATTN_BWDP_ABL=<bits>: timing ablations of the persistent backward's phase A (results are garbage): 1 no softmax / dropout
 // arithmetic, 2 the Q / dO row fragments are not read from LDS (registers stand in), 4 likewise
 // the transposed Q / dO fragments, 8 no dS^T store, 16 no MFMA in phase A
+#ifndef M3P_ATTN_BWDP_FLUSH16
+#define M3P_ATTN_BWDP_FLUSH16 0   // 1: the persistent backward's bias sums by four full butterflies per value (round 5)
+#endif
 #ifndef M3P_ATTN_BWDP_ABL
 #define M3P_ATTN_BWDP_ABL 0
 #endif
@@ -1171,7 +1174,14 @@ void attn_bwd_p_kernel(const bf16* __restrict__ qkv, const int* __restrict__ key
 #pragma unroll
   for (int n = 0; n < Cf::NT; ++n) bsum[n] = f32x4{0.f, 0.f, 0.f, 0.f};
   auto bias_acc = [&](int n, const bf16x4& v4) { bsum[n] += f32x4{(float)v4[0], (float)v4[1], (float)v4[2], (float)v4[3]}; };
+  // Column sums of the 16 values a lane holds over its DPP row (the 16 lanes of one fg), as a HALVING butterfly (round 6: the two
+  // flushes per head were 23 % of this kernel's VALU instructions - 64 v_mov_dpp + 32 v_pk_add each - for 128 floats,
+  // profiles/r06_attn_bwd_ablation.txt): in each of the first two stages a lane keeps only the half of the values its row
+  // position selects - lanes 8..15 the tiles n = 2, 3 (partner: lane + 8), then lanes of odd 4-lane banks the odd tile (partner:
+  // half-mirror) - one bank-masked v_add_f32_dpp per kept value and side; the last two stages are plain quad butterflies on the
+  // four values left.  16 + 8 + 4 + 4 adds instead of 64 + 32; lanes 0 / 4 / 8 / 12 of a row end with tiles 0 / 1 / 2 / 3.
   auto bias_flush = [&](float* slot, int part) {
+#if M3P_ATTN_BWDP_FLUSH16
 #pragma unroll
     for (int n = 0; n < Cf::NT; ++n) {
       f32x4 x = bsum[n];
@@ -1180,6 +1190,34 @@ void attn_bwd_p_kernel(const bf16* __restrict__ qkv, const int* __restrict__ key
       if (fq == 0) *reinterpret_cast<f32x4*>(slot + part * DH + 16 * n + 4 * fg) = x;
       bsum[n] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+#else
+    float t[2][4], u[4];
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        asm volatile("v_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0x3" : "=v"(t[n][r]) : "v"(bsum[n][r]));
+        asm volatile("v_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xc" : "+v"(t[n][r]) : "v"(bsum[n + 2][r]));
+      }
+    asm volatile("s_nop 1");      // (a VALU result read through DPP: two wait states - the compiler does not see into the asm)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      asm volatile("v_add_f32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0x5" : "=v"(u[r]) : "v"(t[0][r]));
+      asm volatile("v_add_f32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xa" : "+v"(u[r]) : "v"(t[1][r]));
+    }
+    asm volatile("s_nop 1");
+    f32x4 x;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v = u[r];
+      v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+      v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+      x[r] = v;
+    }
+    if ((fq & 3) == 0) *reinterpret_cast<f32x4*>(slot + part * DH + 16 * (fq >> 2) + 4 * fg) = x;
+#pragma unroll
+    for (int n = 0; n < Cf::NT; ++n) bsum[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#endif
   };
   auto bias_reduce = [&](const float* slots, int h) {
     for (int i = tid; i < 3 * DH; i += NW * 64) {
