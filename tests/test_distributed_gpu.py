@@ -241,14 +241,15 @@ def test_dp_one_rank_over_rccl(mode):
 BIG = dict(emb_dim=768, n_heads=12, n_layers=1, n_words=88000, T=96, R=32, B=128, n_pred=32)   # 4096 predicted rows: the store path
 
 
-def _lazy_worker(port, q, mode):
-    """One forced rank over RCCL at a size where the MLM head STORES the vocabulary weight gradient: MLM + ITM, MLM + ITM, an
-    ITM-only step, MLM + ITM - with the lazy zero of the vocabulary range on, off, off (the third run is the noise floor)."""
+def _lazy_worker(rank, world, port, q, mode, backend):
+    """Ranks over RCCL (a forced world of one) or gloo (two ranks on the one device) at a size where the MLM head STORES the
+    vocabulary weight gradient: MLM + ITM, MLM + ITM, an ITM-only step, MLM + ITM - with the lazy zero of the vocabulary range
+    on, off, off (the third run is the noise floor)."""
     try:
-        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1',
-                          HSA_ENABLE_IPC_MODE_LEGACY='0', M3P_DP_MODE=mode, M3P_DP_FORCE='1')
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                          HSA_ENABLE_IPC_MODE_LEGACY='0', M3P_DP_MODE=mode, M3P_DP_FORCE='1' if world == 1 else '0')
         torch.cuda.set_device(0)
-        dist.init_process_group('nccl', rank=0, world_size=1)
+        dist.init_process_group(backend, rank=rank, world_size=world)
         from m3p_amd import optim as Om
         global CFG
         CFG = BIG
@@ -270,9 +271,9 @@ def _lazy_worker(port, q, mode):
                 ev.append('defer')
                 real_defer()
             ar.ensure_zero, ar.defer_vocab_zero = ensure_zero, defer
-            full = synth.make_batch(CFG['T'], CFG['R'], CFG['B'], CFG['n_words'], CFG['n_pred'], seed=3)
+            full = synth.make_batch(CFG['T'], CFG['R'], CFG['B'], CFG['n_words'], CFG['n_pred'], seed=3 + rank)
             assert full['y'].numel() == 4096
-            extra = synth.make_region_targets(CFG['R'], CFG['B'], seed=77)
+            extra = synth.make_region_targets(CFG['R'], CFG['B'], seed=77 + rank)
             extra.update(x2=full['x'], len2=full['lengths'], clcm=torch.zeros(CFG['B'], dtype=torch.long))
             tup = _slice(full, extra, slice(0, CFG['B']), slice(0, CFG['B'] // 2))
             for step in range(4):
@@ -283,26 +284,38 @@ def _lazy_worker(port, q, mode):
             assert float(ar.grad.abs().max()) == 0.0
             outs.append(ar.master.float().cpu().numpy())
             events.append(ev)
-        q.put(('ok', outs, events))
+        pm = m.arena().master.clone()
+        gathered = [torch.zeros_like(pm) for _ in range(world)]
+        dist.all_gather(gathered, pm)
+        same = all(torch.equal(gathered[0], t) for t in gathered)
+        if rank == 0:
+            q.put(('ok', outs, events, same))
+        dist.barrier()
         dist.destroy_process_group()
     except Exception:
-        q.put(('err', traceback.format_exc(), None))
+        if rank == 0:
+            q.put(('err', traceback.format_exc(), None, False))
         raise
 
 
-@pytest.mark.parametrize('mode', ['zero1', 'allreduce'])
-def test_dp_lazy_vocab_zero_changes_nothing(mode):
+@pytest.mark.parametrize('mode,world,backend', [('zero1', 1, 'nccl'), ('allreduce', 1, 'nccl'), ('zero1', 2, 'gloo')])
+def test_dp_lazy_vocab_zero_changes_nothing(mode, world, backend):
     """Round 6: the lazily zeroed vocabulary gradient range (Arena.defer_vocab_zero) under the data-parallel wrapper - the bucket
     collectives, the exchanged token rows (which enter through Arena.g()) and, sharded, the foreign shards the rank leaves
-    un-zeroed: same weights with the switch on and off, to the step's own run-to-run noise, and the switch was exercised."""
+    un-zeroed: same weights with the switch on and off, to the step's own run-to-run noise, the switch was exercised, and the
+    ranks end bit-identical."""
     import numpy as np
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    p = ctx.Process(target=_lazy_worker, args=(_free_port(), q, mode))
-    p.start()
-    status, outs, events = q.get(timeout=900)
-    p.join(timeout=120)
+    port = _free_port()
+    procs = [ctx.Process(target=_lazy_worker, args=(r, world, port, q, mode, backend)) for r in range(world)]
+    for p in procs:
+        p.start()
+    status, outs, events, same = q.get(timeout=900)
+    for p in procs:
+        p.join(timeout=120)
     assert status == 'ok', outs
+    assert same, 'parameters diverged across ranks'
     assert events[0].count('defer') == 3 and events[0].count('memset') >= 1 and events[1] == [] and events[2] == [], events
     a, b, c = outs
     noise = float(np.linalg.norm(c - b) / np.linalg.norm(b))
