@@ -1347,7 +1347,9 @@ void gemm_nt_w8_kernel(const bf16* __restrict__ A, int lda, const bf16* __restri
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ntiles = tiles_m * tiles_n;
   const int strip_req = strip_arg & 15;
-  const int n_strips = strip_req ? (tiles_n + strip_req - 1) / strip_req : ((tiles_n >= 12) ? (tiles_n + 3) / 4 : 1);
+  // (round 6: nine n-tiles - the QKV projection - in three strips of three instead of one row of nine: 131.4 -> 124.1 us on
+  //  one box, 132 -> 131 on two others - never slower; profiles/r06_qkv_strips.txt)
+  const int n_strips = strip_req ? (tiles_n + strip_req - 1) / strip_req : ((tiles_n >= 9) ? (tiles_n + 3) / 4 : 1);
   const int strip_w = (tiles_n + n_strips - 1) / n_strips;
   const bool serpentine = (strip_arg & 16) != 0;
   auto split_tile = [&](int t, int& tm, int& tn) {
