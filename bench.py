@@ -431,8 +431,10 @@ def main():
             kname = '%s M=%d N=%d K=%d' % (kind, M, N, K)
             traffic, tsrc = None, None
             counter_clock = None
-            for rel in ('profiles/r05_traffic.json', 'profiles/r04_traffic.json', 'profiles/r03_traffic.json', 'profiles/r02_traffic.json', 'profiles/r01_traffic.json'):
-                tpath = os.path.join(ROOT, rel)
+            import glob
+            # newest round first (profiles/rNN_traffic.json, then rNN_cfg3_traffic.json for the 1024-sequence batch's shapes)
+            for tpath in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]*_traffic.json')), reverse=True):
+                rel = os.path.relpath(tpath, ROOT)
                 if os.path.exists(tpath):   # HBM bytes/launch from the committed rocprofv3 --pmc passes of this command
                     tj = json.load(open(tpath))
                     traffic = tj.get('bench_keys', {}).get(kname)
