@@ -3493,7 +3493,7 @@ static int launch_nt_gq(const bf16* A, int lda, const bf16* W, int ldw, bf16* C,
   if (ntiles < grid) grid = (ntiles + 7) / 8 * 8;
   if constexpr (EPI == M3P_EPI_BIAS_GELUQ || EPI == M3P_EPI_MULQ) {
     if (ep.out8) {      // the instantiation that also leaves the 8-bit copy (its own registers: the plain one must not pay for it)
-      if (((uintptr_t)ep.out8 & 15) || (ep.ld_out8 & 15) || ep.ld_out8 < N) return M3P_EINVAL;
+      if (((uintptr_t)ep.out8 & 15) || (ep.ld_out8 & 15) || ep.ld_out8 < N || !ep.scale8 || !ep.amax8) return M3P_EINVAL;
       // the copy of an activation is e4m3, of a gradient e5m2 - what the fp8 product's operand slots take (include/m3p_hip.h)
       if ((EPI == M3P_EPI_MULQ) != (ep.out8_bf8 != 0)) return M3P_EINVAL;
       auto kern8 = gemm_nt_w8_kernel<EPI, false, true>;
