@@ -1,5 +1,5 @@
 #!/bin/bash
-R=$(cd "$(dirname "$0")/.." && pwd)
+R=$(cd "$(dirname "$0")/../.." && pwd)
 out=$R/gpurun_out/dpgaps; rm -rf $out; mkdir -p $out
 cd /tmp; export TMPDIR=/tmp
 M3P_DP_FORCE=1 HSA_ENABLE_IPC_MODE_LEGACY=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29633 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $out/wrapped -- python $R/bench.py --gpus 1 --steps 12 --warmup 5 --no-cpu-baseline > $out/wrapped.log 2>&1

@@ -1,6 +1,6 @@
 #!/bin/bash
 # kernel census of the one-rank wrapped (zero1) step against the plain step: where the wrap's own time goes
-R=$(cd "$(dirname "$0")/.." && pwd)
+R=$(cd "$(dirname "$0")/../.." && pwd)
 out=$R/gpurun_out/dpprof; rm -rf $out; mkdir -p $out
 cd /tmp; export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/plain -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-also > $out/plain.log 2>&1

@@ -1,5 +1,5 @@
 #!/bin/bash
-R=$(cd "$(dirname "$0")/.." && pwd)
+R=$(cd "$(dirname "$0")/../.." && pwd)
 out=$R/gpurun_out/plaingaps; rm -rf $out; mkdir -p $out
 cd /tmp; export TMPDIR=/tmp
 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $out/plain -- python $R/bench.py --steps 12 --warmup 5 --no-cpu-baseline > $out/plain.log 2>&1

@@ -1,6 +1,6 @@
 #!/bin/bash
 # MFMA utilisation, wait share and sustained clock of the vendor's kernel and ours on the same shapes
-R=$(cd "$(dirname "$0")/.." && pwd)
+R=$(cd "$(dirname "$0")/../.." && pwd)
 out=$R/gpurun_out/pmc; rm -rf $out; mkdir -p $out
 cd /tmp; export TMPDIR=/tmp
 for shape in "768 3072" "3072 768"; do

@@ -1,6 +1,6 @@
 #!/bin/bash
 # kernel census of the cfg4 step, bf16 against --fp8 (where the 8-bit path's time goes)
-R=$(cd "$(dirname "$0")/.." && pwd)
+R=$(cd "$(dirname "$0")/../.." && pwd)
 out=$R/gpurun_out/fp8prof; rm -rf $out; mkdir -p $out
 cd /tmp; export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/bf16 -- python $R/bench.py --config cfg4 --batch 64 --steps 10 --warmup 3 --no-cpu-baseline > $out/bf16.log 2>&1
