@@ -100,7 +100,7 @@ def test_attention_perf_smoke():
         print('attn_bwd p=%.1f: %.3f ms  %.1f TF (algorithmic 2x fwd)' % (p, ms, 2 * fl / ms / 1e9))
 
 
-@pytest.mark.parametrize('B,S', [(32, 164), (5, 161), (4, 176), (3, 170)])      # 11 tiles / 6 steps: every length from 161 to 176
+@pytest.mark.parametrize('B,S', [(32, 164), (5, 161), (4, 176), (3, 170), (256, 164)])      # 11 tiles / 6 steps: every length from 161 to 176; (256, 164) = the benchmarked launch, twelve heads per persistent workgroup
 @pytest.mark.parametrize('p', [0.0, 0.1])
 def test_attention_bwd_forms_for_the_m3p_sequence(p, B, S):
     """The three backward forms for 36 regions + 128 tokens (m3p_debug_attn_variant: 1 = two phases with the scores recomputed,
