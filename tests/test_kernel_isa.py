@@ -216,3 +216,26 @@ def test_generated_kernel_bodies_are_up_to_date():
     import sys
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'gen', 'gen_w4.py'), '--check'], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr or r.stdout
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason='hipcc not installed')
+def test_persistent_attention_backward_fits_three_waves_per_simd(tmp_path):
+    """attn_bwd_p_kernel runs one twelve-wave workgroup per CU: three waves per SIMD means at most 170 registers and no scratch;
+    and its per-head bias sums are the halving butterfly of round 6 (bank-masked v_add_f32_dpp from inline asm - 48 of them per
+    instantiation with dropout: two flushes of 16 + 8), not four full butterflies per value."""
+    out = tmp_path / 'attention.s'
+    cmd = [HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-munsafe-fp-atomics', '-ffp-contract=fast',
+           '-Wno-unused-result', '--cuda-device-only', '-S', os.path.join(ROOT, 'm3p_amd', 'csrc', 'attention.hip'), '-o', str(out)]
+    subprocess.run(cmd, check=True, capture_output=True, timeout=600)
+    body = out.read_text()
+    found = 0
+    for m in re.finditer(r'^(_ZN\S*attn_bwd_p_kernelILb[01]ELb[01]E\S*):', body, re.M):
+        end = body.index('.Lfunc_end', m.end())
+        k = body.index('; Kernel info:', end)
+        info = dict(re.findall(r'; (\w+): (\d+)', body[k:k + 600]))
+        assert info['ScratchSize'] == '0' and int(info['NumVgprs']) <= 170, (m.group(1), info['ScratchSize'], info['NumVgprs'])
+        text = body[m.end():end]
+        masked = len(re.findall(r'v_add_f32_dpp [^\n]*bank_mask:0x(?:3|c|5|a)\b', text))
+        assert masked == 48, (m.group(1), masked)
+        found += 1
+    assert found == 2
